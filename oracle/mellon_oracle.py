@@ -1,0 +1,646 @@
+"""TEST INFRASTRUCTURE ONLY -- float64 NumPy/SciPy restatement of Mellon's
+sparse-GP density path (reference: settylab/Mellon v1.7.1, pure Python on JAX).
+
+Why a restatement: the reference cannot be imported here (jax, jaxlib, jaxopt,
+pynndescent are absent and there is no network), and nothing under
+/root/reference may travel to the GPU box.  Every function below cites the
+reference file:line whose arithmetic it follows.  Third-party arithmetic on the
+path is mapped as follows (all unpinned in the reference's pyproject.toml:24-27):
+  * jax.numpy.linalg.cholesky / jax.scipy.linalg.solve_triangular -> scipy.linalg
+    (LAPACK potrf/trtrs both sides);
+  * jaxopt.ScipyMinimize(method="L-BFGS-B") -> scipy.optimize.minimize with the
+    jaxopt defaults (maxiter=500, tol=None => SciPy ftol=2.22e-9, gtol=1e-5,
+    maxcor=10) and the analytic gradient of the loss (the reference uses
+    autodiff of the same function);
+  * sklearn.linear_model.Ridge(alpha=1, fit_intercept=False) -> closed form
+    (L^T L + I)^-1 L^T t (checked against sklearn in tests/test_oracle.py);
+  * pynndescent.NNDescent (approximate) -> exact Euclidean 1-NN (KD-tree).
+
+PARITY PINNING.  The reference holds exactly one set of absolute golden numbers
+on this path: tests/test_reference_results.py:26-63,93-130 (FunctionEstimator,
+n=50).  tests/test_oracle_golden.py reproduces them with this file plus
+oracle/jax_prng.py (distance, Matern52, ls heuristic, full Cholesky solve and
+the sparse `_sparse_solve` are pinned that way).  The DensityEstimator
+log-density itself has no absolute golden vector anywhere in the reference
+("parity unpinned" for that output): it is anchored by the pinned building
+blocks above, by the reference's analytic/property tests re-expressed in
+tests/test_oracle.py, and by strict convexity of the MAP objective.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (mellon_amd) never does.
+"""
+import math
+from collections import namedtuple
+
+import numpy as np
+from scipy.linalg import cholesky as _sp_cholesky
+from scipy.linalg import solve_triangular as _sp_trsolve
+from scipy.optimize import minimize as _sp_minimize
+from scipy.special import gammaln
+
+DEFAULT_JITTER = 1e-6          # util.py:48
+DEFAULT_RANK = 0.99            # decomposition.py:17
+DEFAULT_N_LANDMARKS = 5000     # parameters.py:53
+DEFAULT_RANDOM_SEED = 42       # parameters.py:54
+
+
+# --------------------------------------------------------------------------
+# util.py
+# --------------------------------------------------------------------------
+def ensure_2d(x):
+    """util.py:135-147 -- 1-D input becomes n x 1."""
+    x = np.asarray(x, dtype=np.float64)
+    return np.atleast_2d(x.T).T
+
+
+def select_active_dims(x, active_dims):
+    """util.py:150-171."""
+    if active_dims is None:
+        return x
+    if np.isscalar(active_dims):
+        active_dims = [active_dims]
+    return x[..., active_dims]
+
+
+def distance(x, y):
+    """util.py:351-366 -- note the +1e-12 INSIDE the sqrt and the clamp."""
+    xx = np.sum(x * x, axis=1)[:, None]
+    yy = np.sum(y * y, axis=1)[None, :]
+    xy = x @ y.T
+    sq = xx - 2.0 * xy + yy + 1e-12
+    return np.sqrt(np.maximum(sq, 0.0))
+
+
+def stabilize(A, jitter=DEFAULT_JITTER):
+    """util.py:269-293."""
+    return A + np.eye(A.shape[0]) * jitter
+
+
+def add_variance(K, M=None, jitter=DEFAULT_JITTER):
+    """util.py:296-331."""
+    if M is None:
+        return stabilize(K, jitter)
+    if np.isscalar(M):
+        return K + np.eye(K.shape[0]) * max(jitter, M ** 2)
+    noise = M @ M.T
+    dn = np.diag(noise)
+    diff = np.where(dn < jitter, jitter - dn, 0.0)
+    return K + noise + np.diag(diff)
+
+
+def mle(nn_distances, d):
+    """util.py:334-348."""
+    return gammaln(d / 2 + 1) - (d / 2) * np.log(np.pi) - d * np.log(nn_distances)
+
+
+# --------------------------------------------------------------------------
+# cov.py / base_cov.py -- the kernel-plugin surface
+# --------------------------------------------------------------------------
+class Covariance:
+    """base_cov.py:17-224 (k, __call__, + * **, active_dims, dict round trip)."""
+
+    def __call__(self, x, y):
+        return self.k(x, y)
+
+    def __add__(self, other):
+        return Add(self, other)
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        return Mul(self, other)
+
+    __rmul__ = __mul__
+
+    def __pow__(self, other):
+        return Pow(self, other)
+
+    def diag(self, x):
+        """base_cov.py:71-93 -- k(x_i, x_i) for every row."""
+        x = np.asarray(x, dtype=np.float64)
+        return np.array([self.k(x[i:i + 1], x[i:i + 1])[0, 0] for i in range(x.shape[0])])
+
+    @staticmethod
+    def from_dict(state):
+        """base_cov.py:197-224, 272-298 -- accepts the reference's wire format."""
+        if not isinstance(state, dict) or state.get("type") != "mellon.Covariance":
+            raise ValueError("The passed dict does not seem to define a covariance kernel.")
+        cls = _CLASSES[state["metadata"]["classname"]]
+        obj = cls.__new__(cls)
+        if issubclass(cls, _Pair):
+            obj.left = Covariance.from_dict(state["left_data"])
+            rd = state["right_data"]
+            if isinstance(rd, dict) and rd.get("type") == "mellon.Covariance":
+                obj.right = Covariance.from_dict(rd)
+            else:
+                obj.right = _deserialize(rd)
+            obj.active_dims = _deserialize(state.get("active_dims"))
+        else:
+            for name, val in state["data"].items():
+                setattr(obj, name, _deserialize(val))
+        return obj
+
+
+def _deserialize(v):
+    """util.py:95-132 subset: slices and arrays as tagged dicts."""
+    if isinstance(v, dict) and v.get("type") == "slice":
+        return slice(v["start"], v["stop"], v["step"])
+    if isinstance(v, dict) and v.get("type") == "jax.numpy":
+        return np.array(v["data"], dtype=v.get("dtype", None))
+    return v
+
+
+class _Stationary(Covariance):
+    def __init__(self, ls=1.0, active_dims=None):
+        self.ls = ls
+        self.active_dims = active_dims
+
+    def _dist(self, x, y):
+        x = select_active_dims(x, self.active_dims)
+        y = select_active_dims(y, self.active_dims)
+        return distance(x, y)
+
+
+class Matern32(_Stationary):
+    def k(self, x, y):
+        """cov.py:62-66."""
+        r = np.sqrt(3.0) * self._dist(x, y) / self.ls
+        return (r + 1) * np.exp(-r)
+
+
+class Matern52(_Stationary):
+    def k(self, x, y):
+        """cov.py:157-161."""
+        r = np.sqrt(5.0) * self._dist(x, y) / self.ls
+        return (r + np.square(r) / 3 + 1) * np.exp(-r)
+
+
+class ExpQuad(_Stationary):
+    def k(self, x, y):
+        """cov.py:255-259."""
+        r = self._dist(x, y) / self.ls
+        return np.exp(-np.square(r) / 2)
+
+
+class Exponential(_Stationary):
+    def k(self, x, y):
+        """cov.py:352-356 (note the non-standard /2)."""
+        r = self._dist(x, y) / self.ls
+        return np.exp(-r / 2)
+
+
+class RatQuad(_Stationary):
+    def __init__(self, alpha=1.0, ls=1.0, active_dims=None):
+        """cov.py:428 -- argument order (alpha, ls, active_dims)."""
+        self.alpha = alpha
+        self.ls = ls
+        self.active_dims = active_dims
+
+    def k(self, x, y):
+        """cov.py:453-457."""
+        r = self._dist(x, y) / self.ls
+        return (np.square(r) / (2 * self.alpha) + 1) ** -self.alpha
+
+
+class Linear(_Stationary):
+    def k(self, x, y):
+        """cov.py:551-556."""
+        x = select_active_dims(x, self.active_dims)
+        y = select_active_dims(y, self.active_dims)
+        return (x @ y.T) / self.ls
+
+
+class _Pair(Covariance):
+    """base_cov.py:227-298."""
+
+    def __init__(self, left, right, active_dims=None):
+        self.left = left
+        self.right = right
+        self.active_dims = active_dims
+
+    def _sel(self, x, y):
+        return select_active_dims(x, self.active_dims), select_active_dims(y, self.active_dims)
+
+
+class Add(_Pair):
+    def k(self, x, y):
+        """base_cov.py:309-315."""
+        x, y = self._sel(x, y)
+        if callable(self.right):
+            return self.left(x, y) + self.right(x, y)
+        return self.left(x, y) + self.right
+
+
+class Mul(_Pair):
+    def k(self, x, y):
+        """base_cov.py:375-381."""
+        x, y = self._sel(x, y)
+        if callable(self.right):
+            return self.left(x, y) * self.right(x, y)
+        return self.left(x, y) * self.right
+
+
+class Pow(_Pair):
+    def k(self, x, y):
+        """base_cov.py:449-453."""
+        x, y = self._sel(x, y)
+        return self.left(x, y) ** self.right
+
+
+_CLASSES = {c.__name__: c for c in
+            (Matern32, Matern52, ExpQuad, Exponential, RatQuad, Linear, Add, Mul, Pow)}
+
+
+def compute_cov_func(cov_func_curry, ls, ls_time=None):
+    """parameters.py:616-645."""
+    if ls_time is not None:
+        return cov_func_curry(ls=ls, active_dims=slice(None, -1)) * cov_func_curry(
+            ls=ls_time, active_dims=-1)
+    return cov_func_curry(ls=ls)
+
+
+# --------------------------------------------------------------------------
+# decomposition.py
+# --------------------------------------------------------------------------
+_NOT_PD = ("Covariance not positively definite with jitter={jitter}. "
+           "Consider increasing the jitter for numerical stabilization.")
+
+
+def _chol_lower(W, jitter):
+    """jnp.linalg.cholesky returns NaNs on failure and the reference turns any
+    NaN into ValueError (decomposition.py:115-122); LAPACK raises instead."""
+    try:
+        L = _sp_cholesky(W, lower=True, check_finite=False)
+    except np.linalg.LinAlgError:
+        raise ValueError(_NOT_PD.format(jitter=jitter))
+    if np.any(np.isnan(L)):
+        raise ValueError(_NOT_PD.format(jitter=jitter))
+    return L
+
+
+def full_rank(x, cov_func, sigma=0.0, jitter=DEFAULT_JITTER):
+    """decomposition.py:79-123 -- chol(K(x,x) + max(sigma^2, jitter) I)."""
+    sigma2 = np.square(sigma)
+    sigma2 = np.where(sigma2 < jitter, jitter, sigma2)
+    W = stabilize(cov_func(x, x), sigma2)
+    return _chol_lower(W, jitter)
+
+
+def standard_low_rank(x, cov_func, xu, Lp=None, sigma=0.0, jitter=DEFAULT_JITTER):
+    """decomposition.py:174-210 -- L = K(x,xu) Lp^-T."""
+    C = cov_func(x, xu)
+    if Lp is None:
+        Lp = full_rank(xu, cov_func, sigma=sigma, jitter=jitter)
+    return _sp_trsolve(Lp, C.T, lower=True, check_finite=False).T
+
+
+# --------------------------------------------------------------------------
+# parameters.py -- heuristics and decision tables
+# --------------------------------------------------------------------------
+FULL, FULL_NYSTROEM, SPARSE_CHOLESKY, SPARSE_NYSTROEM = (
+    "full", "full_nystroem", "sparse_cholesky", "sparse_nystroem")
+
+
+def compute_rank(gp_type):
+    """parameters.py:88-115."""
+    if gp_type in (FULL_NYSTROEM, SPARSE_NYSTROEM):
+        return DEFAULT_RANK
+    return 1.0
+
+
+def compute_n_landmarks(gp_type, n_samples, landmarks):
+    """parameters.py:118-172."""
+    if landmarks is not None:
+        return landmarks.shape[0]
+    if gp_type in (FULL, FULL_NYSTROEM):
+        return n_samples
+    if gp_type in (SPARSE_CHOLESKY, SPARSE_NYSTROEM):
+        return DEFAULT_N_LANDMARKS
+    return min(n_samples, DEFAULT_N_LANDMARKS)
+
+
+def _rank_is_full(rank, bound):
+    return (rank is None
+            or (isinstance(rank, (int, np.integer)) and not isinstance(rank, bool) and rank >= bound)
+            or (isinstance(rank, float) and rank >= 1.0)
+            or rank == 0)
+
+
+def compute_gp_type(n_landmarks, rank, n_samples):
+    """parameters.py:175-240, pinned by tests/test_parameters.py:271-290."""
+    if n_landmarks == 0 or n_landmarks >= n_samples:
+        return FULL if _rank_is_full(rank, n_samples) else FULL_NYSTROEM
+    return SPARSE_CHOLESKY if _rank_is_full(rank, n_landmarks) else SPARSE_NYSTROEM
+
+
+def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS,
+                      random_state=DEFAULT_RANDOM_SEED):
+    """parameters.py:243-291 -- sklearn k_means centroids (third party)."""
+    if n_landmarks == 0:
+        return None
+    x = ensure_2d(x)
+    if n_landmarks >= x.shape[0]:
+        return None
+    from sklearn.cluster import k_means
+    return k_means(x, n_landmarks, n_init=1, random_state=random_state)[0]
+
+
+def exact_nn_distances(x):
+    """Stand-in for parameters.py:352-433 (pynndescent k=1, approximate):
+    the exact Euclidean nearest-neighbour distance of every row."""
+    from sklearn.neighbors import KDTree, BallTree
+    x = ensure_2d(x)
+    tree = (KDTree if x.shape[1] <= 20 else BallTree)(x)
+    dist, _ = tree.query(x, k=2)
+    return dist[:, 1]
+
+
+def validate_nn_distances(nn):
+    """validation.py:528-592."""
+    nn = np.asarray(nn, dtype=np.float64)
+    bad = np.isnan(nn) | np.isinf(nn) | (nn <= 0)
+    if np.all(bad):
+        raise ValueError("All computed nearest neighbor distances contain invalid values.")
+    return np.where(~bad, nn, np.min(nn[~bad]))
+
+
+def compute_mu(nn_distances, d):
+    """parameters.py:586-599 -- jnp.quantile default == np.quantile 'linear'."""
+    return float(np.quantile(mle(nn_distances, d), 0.01)) - 10
+
+
+def compute_ls(nn_distances):
+    """parameters.py:602-613."""
+    return float(np.exp(np.log(nn_distances).mean() + 3.0))
+
+
+def compute_initial_value(nn_distances, d, mu, L):
+    """parameters.py:877-896 -- Ridge(alpha=1, no intercept) closed form."""
+    target = mle(nn_distances, d) - mu
+    G = L.T @ L + np.eye(L.shape[1])
+    c = _sp_cholesky(G, lower=True, check_finite=False)
+    rhs = L.T @ target
+    return _sp_trsolve(c.T, _sp_trsolve(c, rhs, lower=True), lower=False)
+
+
+# --------------------------------------------------------------------------
+# inference.py
+# --------------------------------------------------------------------------
+def nn_likelihood_constants(r, d):
+    """inference.py:83-85 -- V and Vdr of the nearest-neighbour likelihood."""
+    const = (d * np.log(np.pi) / 2) - gammaln(d / 2 + 1)
+    V = np.log(r) * d + const
+    Vdr = np.log(d) + ((d - 1) * np.log(r)) + const
+    return V, Vdr
+
+
+def loss_and_grad(z, L, mu, V, Vdr):
+    """inference.py:35-92,167-192: loss(z) = -(prior(z) + lik(L z + mu));
+    gradient derived analytically: z + L^T (exp(f+V) - 1)."""
+    k = z.shape[0]
+    f = L @ z + mu
+    A = np.exp(f + V)
+    loss = 0.5 * np.dot(z, z) + (k / 2) * np.log(2 * np.pi) - np.sum((f + Vdr) - A)
+    grad = z + L.T @ (A - 1.0)
+    return loss, grad
+
+
+LBFGSB_OPTIONS = dict(maxiter=500)   # jaxopt.ScipyMinimize default; SciPy fills the rest
+
+MapResult = namedtuple("MapResult", "pre_transformation loss n_eval n_iter status")
+
+
+def minimize_lbfgsb(fun_and_grad, z0, options=None):
+    """inference.py:272-288 via jaxopt.ScipyMinimize(method='L-BFGS-B')."""
+    opts = dict(LBFGSB_OPTIONS)
+    if options:
+        opts.update(options)
+    res = _sp_minimize(fun_and_grad, np.asarray(z0, dtype=np.float64), jac=True,
+                       method="L-BFGS-B", options=opts)
+    return MapResult(res.x, float(res.fun), int(res.nfev), int(res.nit), int(res.status))
+
+
+def laplace_std(z, L, mu, V):
+    """inference.py:291-338 -- diag of the Hessian in closed form:
+    1 + sum_i L_ij^2 exp(f_i+V_i), clipped at 1e-8, std = 1/sqrt."""
+    a = np.exp(L @ z + mu + V)
+    h = 1.0 + (L * L).T @ a
+    return 1.0 / np.sqrt(np.maximum(h, 1e-8))
+
+
+# --------------------------------------------------------------------------
+# conditional.py -- predictors (mean only)
+# --------------------------------------------------------------------------
+def _get_L(x, cov_func, jitter=DEFAULT_JITTER, y_cov_factor=None, K=None):
+    """conditional.py:69-81."""
+    if K is None:
+        K = cov_func(x, x)
+    return _chol_lower(add_variance(K, y_cov_factor, jitter=jitter), jitter)
+
+
+def sigma_to_y_cov_factor(sigma, y_cov_factor, n):
+    """conditional.py:100-135 (scalar / vector sigma only)."""
+    if sigma is None and y_cov_factor is None:
+        raise ValueError("No input uncertainty specified.")
+    if y_cov_factor is not None and sigma is not None and np.any(np.asarray(sigma) > 0):
+        raise ValueError("One can specify either `sigma` or `y_cov_factor`, not both.")
+    if y_cov_factor is not None:
+        return y_cov_factor
+    sigma = np.asarray(sigma, dtype=np.float64)
+    if sigma.ndim == 0:
+        return np.eye(n) * sigma
+    if sigma.ndim == 1:
+        return np.diag(sigma)
+    raise ValueError("Unsupported sigma dimensions in the oracle.")
+
+
+def sparse_solve(Lp, A, r_l, A_l):
+    """conditional.py:57-66."""
+    LBB = stabilize(A_l @ A.T, 1.0)
+    L_B = _sp_cholesky(LBB, lower=True, check_finite=False)
+    c = _sp_trsolve(L_B, A @ r_l, lower=True)
+    w = _sp_trsolve(Lp.T, _sp_trsolve(L_B.T, c, lower=False), lower=False)
+    return w, L_B
+
+
+class Predictor:
+    """base_predictor.py:180-257 (mean / __call__ only)."""
+
+    def __init__(self, cov_func, centers, weights, mu, n_obs):
+        self.cov_func, self.centers, self.weights = cov_func, centers, weights
+        self.mu, self.n_obs = mu, n_obs
+        self.n_input_features = centers.shape[1]
+
+    def __call__(self, Xnew, normalize=False):
+        Xnew = ensure_2d(Xnew)
+        if Xnew.shape[1] != self.n_input_features:
+            raise ValueError(
+                f"The predictor was trained on data with {self.n_input_features} features "
+                f"but the input has {Xnew.shape[1]} features.")
+        out = self.mu + self.cov_func(Xnew, self.centers) @ self.weights
+        if normalize:
+            out = out - math.log(self.n_obs)
+        return out
+
+    mean = __call__
+
+
+def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTER,
+                     y_is_mean=False):
+    """conditional.py:183-264 (non per-feature sigma)."""
+    x = ensure_2d(x)
+    if L is None:
+        if y_is_mean:
+            L = _get_L(x, cov_func, jitter)
+        else:
+            L = _get_L(x, cov_func, jitter, sigma_to_y_cov_factor(sigma, None, x.shape[0]))
+    r = y - mu
+    w = _sp_trsolve(L.T, _sp_trsolve(L, r, lower=True), lower=False)
+    return Predictor(cov_func, x, w, mu, x.shape[0])
+
+
+def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
+                          jitter=DEFAULT_JITTER, y_is_mean=False):
+    """conditional.py:455-547 (scalar / element-wise sigma)."""
+    x, xu = ensure_2d(x), ensure_2d(xu)
+    Kuf = cov_func(xu, x)
+    if Lp is None:
+        Lp = _get_L(xu, cov_func, jitter)
+    A = _sp_trsolve(Lp, Kuf, lower=True)
+    r = y - mu
+    if y_is_mean:
+        r_l, A_l = r, A
+    else:
+        sigma2 = np.square(sigma)            # conditional.py:155-159
+        r_l, A_l = r / sigma2, A / sigma2
+    w, _ = sparse_solve(Lp, A, r_l, A_l)
+    return Predictor(cov_func, xu, w, mu, x.shape[0])
+
+
+def landmarks_conditional_cholesky(xu, z, mu, cov_func, n_obs, L=None,
+                                   jitter=DEFAULT_JITTER):
+    """conditional.py:750-818 -- weights = Lp^-T z."""
+    xu = ensure_2d(xu)
+    if L is None:
+        L = _get_L(xu, cov_func, jitter)
+    w = _sp_trsolve(L.T, z, lower=False)
+    return Predictor(cov_func, xu, w, mu, n_obs)
+
+
+def compute_conditional(x, landmarks, z, y, mu, cov_func, L, Lp=None, sigma=0.0,
+                        jitter=DEFAULT_JITTER, y_is_mean=False):
+    """inference.py:375-508 dispatch."""
+    if landmarks is None:
+        return full_conditional(x, y, mu, cov_func, Lp, sigma=sigma, jitter=jitter,
+                                y_is_mean=y_is_mean)
+    if z is not None and z.shape[0] == landmarks.shape[0]:
+        return landmarks_conditional_cholesky(landmarks, z, mu, cov_func, x.shape[0], Lp,
+                                              jitter=jitter)
+    return landmarks_conditional(x, landmarks, y, mu, cov_func, None, sigma=sigma,
+                                 jitter=jitter, y_is_mean=y_is_mean)
+
+
+# --------------------------------------------------------------------------
+# estimators (density_estimator.py:404-581, function_estimator.py:295-374,
+# time_sensitive_density_estimator.py:608-665) as plain functions
+# --------------------------------------------------------------------------
+DensityFit = namedtuple(
+    "DensityFit",
+    "log_density_x pre_transformation L Lp landmarks mu ls d nn_distances cov_func "
+    "initial_value loss n_eval gp_type predict")
+
+
+def density_fit(x, cov_func_curry=Matern52, n_landmarks=None, rank=None, landmarks=None,
+                nn_distances=None, d=None, mu=None, ls=None, ls_factor=1.0, cov_func=None,
+                jitter=DEFAULT_JITTER, initial_value=None, lbfgsb_options=None,
+                ls_time=None, random_state=DEFAULT_RANDOM_SEED):
+    """DensityEstimator.fit_predict with the attribute pipeline of
+    density_estimator.py:404-444 (sparse_cholesky and full gp types)."""
+    x = ensure_2d(x)
+    n = x.shape[0]
+    if n_landmarks is None:
+        n_landmarks = compute_n_landmarks(None, n, landmarks)
+    if rank is None:
+        rank = compute_rank(None)
+    gp_type = compute_gp_type(n_landmarks, rank, n)
+    if gp_type not in (FULL, SPARSE_CHOLESKY):
+        raise NotImplementedError("oracle covers gp_type full and sparse_cholesky only")
+    if nn_distances is None:
+        nn_distances = exact_nn_distances(x)
+    nn_distances = validate_nn_distances(nn_distances)
+    if d is None:
+        d = x.shape[1] if ls_time is None else x.shape[1] - 1
+        if d > 50:
+            raise ValueError("The detected dimensionality of the data is over 50")
+    if mu is None:
+        mu = compute_mu(nn_distances, d)
+    if ls is None:
+        ls = compute_ls(nn_distances) * ls_factor
+    if cov_func is None:
+        cov_func = compute_cov_func(cov_func_curry, ls, ls_time)
+    if landmarks is None and gp_type == SPARSE_CHOLESKY:
+        landmarks = compute_landmarks(x, gp_type, n_landmarks, random_state)
+    if gp_type == FULL:
+        landmarks = None
+        Lp = full_rank(x, cov_func, sigma=0.0, jitter=jitter)
+        L = Lp                                              # parameters.py:847-850
+    else:
+        Lp = full_rank(landmarks, cov_func, sigma=0.0, jitter=jitter)
+        L = standard_low_rank(x, cov_func, landmarks, Lp=Lp)
+    if initial_value is None:
+        initial_value = compute_initial_value(nn_distances, d, mu, L)
+    V, Vdr = nn_likelihood_constants(nn_distances, d)
+    res = minimize_lbfgsb(lambda z: loss_and_grad(z, L, mu, V, Vdr), initial_value,
+                          lbfgsb_options)
+    z = res.pre_transformation
+    log_density_x = L @ z + mu                              # inference.py:354
+    predict = compute_conditional(x, landmarks, z, log_density_x, mu, cov_func, L, Lp,
+                                  sigma=None, jitter=jitter, y_is_mean=True)
+    return DensityFit(log_density_x, z, L, Lp, landmarks, mu, ls, d, nn_distances, cov_func,
+                      initial_value, res.loss, res.n_eval, gp_type, predict)
+
+
+def function_fit(x, y, sigma, cov_func_curry=Matern52, n_landmarks=None, landmarks=None,
+                 nn_distances=None, mu=0.0, ls=None, ls_factor=1.0, cov_func=None,
+                 jitter=DEFAULT_JITTER, y_is_mean=False, random_state=DEFAULT_RANDOM_SEED):
+    """FunctionEstimator.fit (function_estimator.py:295-374) -> Predictor."""
+    x = ensure_2d(x)
+    n = x.shape[0]
+    if n_landmarks is None:
+        n_landmarks = compute_n_landmarks(None, n, landmarks)
+    gp_type = compute_gp_type(n_landmarks, 1.0, n)
+    if cov_func is None:
+        if ls is None:
+            if nn_distances is None:
+                nn_distances = exact_nn_distances(x)
+            ls = compute_ls(validate_nn_distances(nn_distances)) * ls_factor
+        cov_func = compute_cov_func(cov_func_curry, ls)
+    if landmarks is None:
+        landmarks = compute_landmarks(x, gp_type, n_landmarks, random_state)
+    return compute_conditional(x, landmarks, None, np.asarray(y, dtype=np.float64), mu,
+                               cov_func, None, None, sigma, jitter=jitter,
+                               y_is_mean=y_is_mean)
+
+
+def per_time_nn_distances(x, times):
+    """parameters.py:444-531 -- nearest neighbour within each time point."""
+    x = ensure_2d(x)
+    times = np.asarray(times)
+    out = np.empty(x.shape[0])
+    for t in np.unique(times):
+        idx = np.flatnonzero(times == t)
+        out[idx] = exact_nn_distances(x[idx])
+    return out
+
+
+# --------------------------------------------------------------------------
+# synthetic workloads shared verbatim by CPU baseline, tests and bench
+# --------------------------------------------------------------------------
+def gaussian_mixture(n, d, seed, k=10):
+    """10-component isotropic Gaussian mixture, float64, PCG64(seed)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    means = rng.normal(0.0, 3.0, size=(k, d))
+    sig = rng.uniform(0.5, 1.5, size=k)
+    comp = rng.integers(0, k, size=n)
+    x = means[comp] + rng.normal(size=(n, d)) * sig[comp][:, None]
+    return np.ascontiguousarray(x[rng.permutation(n)])

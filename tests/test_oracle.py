@@ -1,0 +1,207 @@
+"""Anchor the oracle with the reference's analytic / property tests
+(SURVEY.md S8c), re-expressed in NumPy.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import mellon_oracle as mo
+
+
+def _data(n=100, d=2, seed=0):
+    rng = np.random.default_rng(seed)
+    L = np.array([[2.0, 0.0], [1.0, 1.0]]) if d == 2 else np.eye(d)
+    return rng.normal(size=(n, d)) @ L.T
+
+
+def test_distance_quirk():
+    # util.py:362-366: +1e-12 inside sqrt => dist(x,x) = 1e-6 exactly in spirit
+    x = np.array([[1.0, 2.0], [3.0, 4.0]])
+    D = mo.distance(x, x)
+    assert np.allclose(np.diag(D), 1e-6, rtol=1e-3)
+    assert np.isclose(D[0, 1], np.sqrt(8.0 + 1e-12))
+
+
+def test_nn_distances_exact():
+    # tests/test_parameters.py:244-258
+    x = np.array([[1, 2], [2, 3], [3, 4]], dtype=float)
+    assert np.allclose(mo.exact_nn_distances(x), np.sqrt(2))
+    x = np.array([[1, 1], [2, 2], [4, 4], [5, 5]], dtype=float)
+    assert np.allclose(mo.exact_nn_distances(x), np.sqrt(2))
+
+
+def test_gp_type_table():
+    # tests/test_parameters.py:271-290
+    f = mo.compute_gp_type
+    assert f(0, 100, 100) == mo.FULL
+    assert f(100, 1.0, 100) == mo.FULL
+    assert f(100, None, 100) == mo.FULL
+    assert f(100, 0, 100) == mo.FULL
+    assert f(100, 50, 100) == mo.FULL_NYSTROEM
+    assert f(100, 0.5, 100) == mo.FULL_NYSTROEM
+    assert f(50, 50, 100) == mo.SPARSE_CHOLESKY
+    assert f(50, 1.0, 100) == mo.SPARSE_CHOLESKY
+    assert f(50, None, 100) == mo.SPARSE_CHOLESKY
+    assert f(50, 0, 100) == mo.SPARSE_CHOLESKY
+    assert f(50, 25, 100) == mo.SPARSE_NYSTROEM
+    assert f(50, 0.5, 100) == mo.SPARSE_NYSTROEM
+
+
+def test_rank_and_n_landmarks_tables():
+    # tests/test_parameters.py:318-365
+    assert mo.compute_rank(mo.FULL_NYSTROEM) == 0.99
+    assert mo.compute_rank(mo.SPARSE_CHOLESKY) == 1.0
+    assert mo.compute_rank(None) == 1.0
+    assert mo.compute_n_landmarks(None, 100, np.ones((50, 2))) == 50
+    assert mo.compute_n_landmarks(None, 100, None) == 100
+    assert mo.compute_n_landmarks(mo.FULL, 100, None) == 100
+    assert mo.compute_n_landmarks(mo.SPARSE_CHOLESKY, 80, None) == 5000
+
+
+@pytest.mark.parametrize("cls,form", [
+    (mo.Matern32, lambda r: (1 + np.sqrt(3) * r) * np.exp(-np.sqrt(3) * r)),
+    (mo.Matern52, lambda r: (1 + np.sqrt(5) * r + 5 * r * r / 3) * np.exp(-np.sqrt(5) * r)),
+    (mo.ExpQuad, lambda r: np.exp(-r * r / 2)),
+    (mo.Exponential, lambda r: np.exp(-r / 2)),
+])
+def test_kernel_closed_forms(cls, form):
+    # tests/test_cov.py:41-64 evaluates at x=1, y in {2, 1.5}, ls=1.2
+    x = np.array([[1.0]])
+    for yv in (2.0, 1.5):
+        y = np.array([[yv]])
+        r = np.sqrt((1.0 - yv) ** 2 + 1e-12) / 1.2
+        assert np.isclose(cls(1.2)(x, y)[0, 0], form(r), rtol=1e-13)
+
+
+def test_ratquad_and_linear():
+    x, y = _data(5), _data(4, seed=1)
+    r = mo.distance(x, y) / 0.7
+    assert np.allclose(mo.RatQuad(2.0, 0.7)(x, y), (r * r / 4.0 + 1) ** -2.0)
+    assert np.allclose(mo.Linear(0.7)(x, y), x @ y.T / 0.7)
+
+
+def test_active_dims_and_algebra():
+    # tests/test_base_cov.py: Add/Mul/Pow, scalar right operand, nested active_dims
+    x, y = _data(6, 2), _data(5, 2, seed=3)
+    a, b = mo.Matern52(1.3, active_dims=0), mo.ExpQuad(0.9, active_dims=[1])
+    assert np.allclose((a * b)(x, y), a(x, y) * b(x, y))
+    assert np.allclose((a + b)(x, y), a(x, y) + b(x, y))
+    assert np.allclose((a + 2.0)(x, y), a(x, y) + 2.0)
+    assert np.allclose((3.0 * a)(x, y), a(x, y) * 3.0)
+    assert np.allclose((a ** 2)(x, y), a(x, y) ** 2)
+    assert np.allclose(a(x, y), mo.Matern52(1.3)(x[:, :1], y[:, :1]))
+    t = mo.compute_cov_func(mo.Matern52, 1.1, ls_time=0.5)
+    assert np.allclose(t(x, y), mo.Matern52(1.1)(x[:, :-1], y[:, :-1]) * mo.Matern52(0.5)(x[:, -1:], y[:, -1:]))
+
+
+def test_ridge_closed_form_matches_sklearn():
+    # parameters.py:895-896
+    from sklearn.linear_model import Ridge
+    rng = np.random.default_rng(0)
+    L = rng.normal(size=(200, 17))
+    nn = rng.uniform(0.1, 1.0, size=200)
+    z0 = mo.compute_initial_value(nn, 3, -5.0, L)
+    ref = Ridge(fit_intercept=False).fit(L, mo.mle(nn, 3) + 5.0).coef_
+    assert np.allclose(z0, ref, rtol=1e-9, atol=1e-11)
+
+
+def test_loss_gradient_finite_difference():
+    rng = np.random.default_rng(1)
+    L = rng.normal(size=(60, 9)) * 0.3
+    nn = rng.uniform(0.1, 1.0, size=60)
+    V, Vdr = mo.nn_likelihood_constants(nn, 4)
+    z = rng.normal(size=9) * 0.1
+    f0, g = mo.loss_and_grad(z, L, -3.0, V, Vdr)
+    for j in range(9):
+        e = np.zeros(9)
+        e[j] = 1e-6
+        fp, _ = mo.loss_and_grad(z + e, L, -3.0, V, Vdr)
+        fm, _ = mo.loss_and_grad(z - e, L, -3.0, V, Vdr)
+        assert np.isclose((fp - fm) / 2e-6, g[j], rtol=1e-6, atol=1e-7)
+
+
+def test_lbfgsb_quadratic():
+    # tests/test_inference.py:59-72
+    res = mo.minimize_lbfgsb(lambda z: (float(z @ z), 2 * z), np.ones(4))
+    assert res.loss < 1e-10
+
+
+def test_laplace_std_is_hessian_diag():
+    # tests/test_laplace.py: std == 1/sqrt(diag H); finite-difference the gradient
+    rng = np.random.default_rng(2)
+    L = rng.normal(size=(40, 5)) * 0.3
+    nn = rng.uniform(0.1, 1.0, size=40)
+    V, Vdr = mo.nn_likelihood_constants(nn, 2)
+    z = rng.normal(size=5) * 0.1
+    std = mo.laplace_std(z, L, -2.0, V)
+    for j in range(5):
+        e = np.zeros(5)
+        e[j] = 1e-5
+        gp = mo.loss_and_grad(z + e, L, -2.0, V, Vdr)[1][j]
+        gm = mo.loss_and_grad(z - e, L, -2.0, V, Vdr)[1][j]
+        assert np.isclose(1 / np.sqrt((gp - gm) / 2e-5), std[j], rtol=1e-6)
+
+
+def test_not_positive_definite_raises():
+    # decomposition.py:116-122
+    x = np.zeros((4, 2))
+    with pytest.raises(ValueError, match="not positively definite"):
+        mo.full_rank(x, mo.Matern52(1.0) * -1.0, jitter=1e-6)
+
+
+def test_density_predict_equals_fit_predict_sparse():
+    # tests/test_density_estimator.py:40-44 (rel err < 1e-5)
+    x = _data(100)
+    fit = mo.density_fit(x, n_landmarks=10)
+    assert fit.gp_type == mo.SPARSE_CHOLESKY
+    pred = fit.predict(x)
+    rel = np.std(pred - fit.log_density_x) / np.std(fit.log_density_x)
+    assert rel < 1e-5
+
+
+def test_density_full_and_1d():
+    # tests/test_density_estimator.py:257-269 (1-D input)
+    x = _data(100)
+    fit = mo.density_fit(x)
+    assert fit.gp_type == mo.FULL and fit.log_density_x.shape == (100,)
+    pred = fit.predict(x)
+    assert np.std(pred - fit.log_density_x) / np.std(fit.log_density_x) < 1e-5
+    f1 = mo.density_fit(x[:, 0])
+    assert f1.log_density_x.shape == (100,)
+
+
+def test_density_approximations_close_to_default():
+    # tests/test_density_estimator.py:80-96
+    x = _data(100)
+    full = mo.density_fit(x).log_density_x
+    sparse = mo.density_fit(x, n_landmarks=10).log_density_x
+    assert np.std(full - sparse) / np.std(full) < 2e-1
+
+
+def test_predictor_feature_mismatch():
+    # base_predictor.py:215-220
+    x = _data(50)
+    fit = mo.density_fit(x, n_landmarks=10)
+    with pytest.raises(ValueError):
+        fit.predict(np.zeros((3, 5)))
+
+
+def test_dimensionality_guard():
+    # density_estimator.py:327-333
+    with pytest.raises(ValueError):
+        mo.density_fit(np.random.default_rng(0).normal(size=(60, 51)), n_landmarks=10)
+
+
+def test_covariance_dict_round_trip():
+    c = mo.Matern52(1.5, active_dims=slice(None, -1)) * mo.Matern52(0.4, active_dims=-1)
+    state = {
+        "type": "mellon.Covariance",
+        "left_data": {"type": "mellon.Covariance",
+                      "data": {"ls": 1.5, "active_dims": {"type": "slice", "start": None, "stop": -1, "step": None}},
+                      "metadata": {"classname": "Matern52", "module_name": "mellon.cov"}},
+        "right_data": {"type": "mellon.Covariance", "data": {"ls": 0.4, "active_dims": -1},
+                       "metadata": {"classname": "Matern52", "module_name": "mellon.cov"}},
+        "active_dims": None,
+        "metadata": {"classname": "Mul", "module_name": "mellon"},
+    }
+    c2 = mo.Covariance.from_dict(state)
+    x, y = _data(7, 2), _data(3, 2, seed=5)
+    assert np.allclose(c(x, y), c2(x, y))
