@@ -1,0 +1,183 @@
+/*
+ * mellon_hip.h -- C ABI of libmellon_hip.so, the MI355X (gfx950) sparse-GP density core.
+ *
+ * The reference (settylab/Mellon v1.7.1) has NO native code: its hot path is Python on
+ * JAX/XLA:CPU.  Each entry point below replaces the arithmetic of the reference function(s)
+ * cited next to it (paths relative to the reference checkout), so that the reference's
+ * estimator classes -- or this repo's mirror of them, mellon_amd/ -- can bind it with ctypes.
+ * INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *   - all matrices are row-major float64; sizes are int64_t, feature counts int32_t;
+ *   - every data pointer may be a HOST pointer or a DEVICE pointer obtained from mln_malloc():
+ *     the library detects which (hipPointerGetAttributes) and stages host buffers itself;
+ *   - the caller owns every buffer it passes; the library owns what sits behind mln_ctx /
+ *     mln_fit handles; no pointer is retained after a call returns except inside a handle;
+ *   - every function returns an mln_status (0 = ok); no C++ exception crosses the ABI;
+ *     mln_last_error() gives the text.  MLN_ERR_NOT_PD maps to the reference's
+ *     ValueError("Covariance not positively definite with jitter=...") (decomposition.py:116-122);
+ *   - a mln_ctx is bound to one GPU and is not thread-safe; calls are synchronous on return;
+ *   - there is no CPU fallback: without a usable gfx950 device mln_ctx_create fails.
+ */
+#ifndef MELLON_HIP_H
+#define MELLON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mln_ctx mln_ctx;
+typedef struct mln_fit mln_fit;
+
+typedef enum {
+  MLN_OK = 0,
+  MLN_ERR_NOT_PD = 1,      /* non-positive / NaN pivot in a Cholesky factorisation          */
+  MLN_ERR_SHAPE = 2,       /* inconsistent sizes                                            */
+  MLN_ERR_HIP = 3,         /* HIP runtime failure (text in mln_last_error)                  */
+  MLN_ERR_RCCL = 4,        /* RCCL failure                                                  */
+  MLN_ERR_ARG = 5,         /* null pointer / bad enum / unsupported descriptor              */
+  MLN_ERR_UNSUPPORTED = 6  /* valid request this build cannot serve (e.g. m too large)      */
+} mln_status;
+
+/* ---- kernel-plugin surface: mellon/base_cov.py:17-497 + mellon/cov.py ------------------- */
+typedef enum {
+  MLN_K_MATERN32 = 1,    /* cov.py:62-66   */
+  MLN_K_MATERN52 = 2,    /* cov.py:157-161 */
+  MLN_K_EXPQUAD = 3,     /* cov.py:255-259 */
+  MLN_K_EXPONENTIAL = 4, /* cov.py:352-356 */
+  MLN_K_RATQUAD = 5,     /* cov.py:453-457 */
+  MLN_K_LINEAR = 6       /* cov.py:551-556 */
+} mln_kind;
+
+/* A covariance tree (Covariance / Add / Mul / Pow, base_cov.py:301-453) is lowered to a postfix
+ * program over leaves.  Each leaf carries the FINAL column indices it sees after every enclosing
+ * `active_dims` selection has been composed (util.py:150-171).                                 */
+typedef struct {
+  int32_t kind;        /* mln_kind                                        */
+  int32_t ndims;       /* number of active columns                        */
+  double ls;           /* length scale                                    */
+  double alpha;        /* RatQuad only                                    */
+  const int32_t* dims; /* ndims column indices into the d input columns   */
+} mln_leaf;
+
+typedef enum { MLN_OP_LEAF = 0, MLN_OP_CONST = 1, MLN_OP_ADD = 2, MLN_OP_MUL = 3, MLN_OP_POW = 4 } mln_op;
+
+typedef struct {
+  int32_t op;   /* mln_op                                   */
+  int32_t leaf; /* MLN_OP_LEAF: index into leaves           */
+  double value; /* MLN_OP_CONST: the scalar                 */
+} mln_tok;
+
+#define MLN_MAX_LEAVES 4
+#define MLN_MAX_TOKS 16
+#define MLN_MAX_DIMS 256 /* total over all leaves */
+
+typedef struct {
+  int32_t n_leaves;
+  int32_t n_toks;
+  const mln_leaf* leaves;
+  const mln_tok* toks;
+} mln_kernel_desc;
+
+/* ---- context / memory ------------------------------------------------------------------- */
+int mln_ctx_create(int device, mln_ctx** out);
+void mln_ctx_destroy(mln_ctx* ctx);
+const char* mln_last_error(mln_ctx* ctx); /* ctx may be NULL: last error of the calling thread */
+int mln_device_info(mln_ctx* ctx, char* name, int name_cap, int* n_cu, int64_t* mem_bytes);
+int mln_synchronize(mln_ctx* ctx);
+
+int mln_malloc(mln_ctx* ctx, int64_t bytes, void** dev_ptr);
+int mln_free(mln_ctx* ctx, void* dev_ptr);
+int mln_memcpy(mln_ctx* ctx, void* dst, const void* src, int64_t bytes); /* any host/device mix */
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------
+ * Cells (rows of x) are sharded; landmarks, Lp and z are replicated.  Collectives: all-reduce
+ * of (loss, grad) per objective evaluation and of the m x m Ridge Gram once per fit.          */
+#define MLN_UNIQUE_ID_BYTES 128
+int mln_comm_unique_id(void* id_out /* MLN_UNIQUE_ID_BYTES */);
+int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank);
+int mln_comm_allreduce_sum(mln_ctx* ctx, double* buf, int64_t count); /* host or device buffer */
+
+/* ---- a-1..a-3: K = cov(x, y)   (util.py:351-366 distance, cov.py k(), base_cov.py Add/Mul/Pow)
+ * x: n x d, y: m x d, out: n x m.                                                              */
+int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n,
+                      const double* y, int64_t m, int32_t d, double* out);
+
+/* ---- a-4/a-5: in-place lower Cholesky of (A + add_diag * I), A m x m symmetric (lower read).
+ * decomposition.py:111-123 (`stabilize` util.py:269-293 + jnp.linalg.cholesky).  Strict upper
+ * triangle of the result is zero.  MLN_ERR_NOT_PD on a non-positive or NaN pivot.              */
+int mln_chol_lower(mln_ctx* ctx, double* A, int64_t m, double add_diag);
+
+/* triangular solves with a lower factor Lf (m x m):  B (m x p) <- op(Lf)^-1 B.
+ * trans = 0: Lf^-1 B (solve_triangular(L, B, lower=True)); trans = 1: Lf^-T B
+ * (solve_triangular(L.T, B)), conditional.py:63-65,264,818.                                    */
+int mln_trsm_lower(mln_ctx* ctx, const double* Lf, int64_t m, int32_t trans, double* B, int64_t p);
+
+/* ---- fit handle: device-resident shard state --------------------------------------------------
+ * mln_fit_prepare follows parameters.compute_Lp (parameters.py:648-714) and compute_L
+ * (parameters.py:783-874):
+ *   xu != NULL (sparse_cholesky): Lp = chol(cov(xu,xu) + max(sigma^2,jitter) I)  decomposition.py:111-123
+ *                                 L  = cov(x,xu) Lp^-T                           decomposition.py:205-210
+ *   xu == NULL (full):            Lp = chol(cov(x,x) + jitter I);  L = Lp        parameters.py:847-850
+ * Lp_in (optional, m x m) skips the factorisation (the estimator's `Lp=` ctor argument).
+ * x is THIS RANK's shard (n_local x d); with a communicator the full-GP branch is refused.    */
+int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                    int32_t d, const double* xu, int64_t m, double jitter, const double* Lp_in,
+                    mln_fit** out);
+void mln_fit_destroy(mln_fit* fit);
+int mln_fit_get_Lp(mln_fit* fit, double* out /* m x m */);
+int mln_fit_get_L(mln_fit* fit, int64_t row0, int64_t n_rows, double* out /* n_rows x m */);
+int mln_fit_rank(mln_fit* fit, int64_t* m_out); /* number of columns of L */
+
+/* a-9: Ridge initial value  z0 = (L^T L + I)^-1 L^T target   (parameters.py:877-896;
+ * sklearn Ridge(alpha=1, fit_intercept=False)).  target: n_local.  All-reduced over ranks.     */
+int mln_ridge_init(mln_fit* fit, const double* target, double* z0 /* m */);
+
+/* a-7: nearest-neighbour likelihood constants of this shard (inference.py:83-85), computed by
+ * the caller from nn_distances and d:  V = d log r + c,  Vdr = log d + (d-1) log r + c.        */
+int mln_fit_set_likelihood(mln_fit* fit, const double* V, const double* Vdr, double mu);
+
+/* a-7 (+ a-14): loss(z) = 1/2 |z|^2 + (m/2) log 2pi - sum_i [f_i + Vdr_i - exp(f_i + V_i)],
+ * f = L z + mu (inference.py:35-92,167-192), its gradient z + L^T (exp(f+V) - 1), and optionally
+ * the diagonal of the Hessian 1 + sum_i L_ij^2 exp(f_i+V_i) (inference.py:291-338 in closed form).
+ * One pass over L.  Sums are all-reduced over ranks; prior terms are added once.               */
+int mln_objective(mln_fit* fit, const double* z, double* loss, double* grad /* m */,
+                  double* hess_diag /* m or NULL */);
+
+/* a-11: f = L z + mu on this shard (inference.py:341-354).                                     */
+int mln_transform(mln_fit* fit, const double* z, double* f_out /* n_local */);
+
+/* a-12: predictor weights.
+ *   sparse-Cholesky:  w = Lp^-T z                       conditional.py:818
+ *   full:             w = Lp^-T Lp^-1 (y - mu)          conditional.py:263-264                 */
+int mln_weights_cholesky(mln_fit* fit, const double* z, double* w /* m */);
+int mln_weights_full(mln_fit* fit, const double* y, int64_t p, double mu, double* w /* m x p */);
+
+/* a-12 (FunctionEstimator, scalar sigma): conditional.py:513-547 + _sparse_solve :57-66
+ *   A = Lp^-1 cov(xu,x);  L_B = chol(A A^T / sigma^2 + I);
+ *   W = Lp^-T L_B^-T L_B^-1 A (y - mu) / sigma^2          (m x p)
+ * x, y are this rank's shard; A A^T and A y are all-reduced.                                   */
+int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                     int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
+                     double sigma, double jitter, double* W /* m x p */);
+
+/* a-13: mean(Xnew) = mu + cov(Xnew, centers) W   (conditional.py:366-373,651-658,899-906).
+ * centers: m x d (landmarks or, full GP, the training cells); W: m x p; out: n_new x p.
+ * cov(Xnew, centers) is never materialised for p == 1.                                         */
+int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                     int32_t d, const double* centers, int64_t m, const double* W, int64_t p,
+                     double mu, double* out);
+
+/* wall-clock seconds of the stages of the last mln_fit_prepare / mln_ridge_init and counters
+ * of mln_objective: [0] kernel matrix, [1] cholesky, [2] trsm, [3] ridge gram, [4] ridge solve,
+ * [5] objective kernel time (sum, HIP events), [6] objective launches, [7] bytes of L streamed
+ * per objective launch.                                                                        */
+#define MLN_N_STAGE_TIMES 8
+int mln_stage_times(mln_fit* fit, double* out /* MLN_N_STAGE_TIMES */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELLON_HIP_H */

@@ -1,0 +1,58 @@
+"""Build libmellon_hip.so in-tree with hipcc for gfx950 (no GPU needed to compile)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmellon_hip.so")
+SOURCES = ["api.hip", "cov_kernels.hip", "dgemm.hip", "linalg.hip", "objective.hip"]
+HEADERS = ["mln_internal.h", "linalg.h", os.path.join("..", "..", "include", "mellon_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return job, r
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for (src, obj), r in ex.map(cc, jobs):
+            if verbose and (r.stdout or r.stderr):
+                sys.stderr.write(r.stdout + r.stderr)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}")
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose and (r.stdout or r.stderr):
+            sys.stderr.write(r.stdout + r.stderr)
+        if r.returncode != 0:
+            raise RuntimeError("link of libmellon_hip.so failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,382 @@
+"""ctypes binding of libmellon_hip.so (include/mellon_hip.h).
+
+This is the whole Python <-> device boundary: NumPy float64 C-contiguous arrays (or
+``DeviceArray`` handles) in, NumPy arrays out.  There is no CPU fallback -- if the shared
+library is missing or no gfx950 device is visible, every compute entry raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmellon_hip.so")
+
+MLN_OK, MLN_ERR_NOT_PD, MLN_ERR_SHAPE, MLN_ERR_HIP, MLN_ERR_RCCL, MLN_ERR_ARG, MLN_ERR_UNSUPPORTED = range(7)
+MLN_UNIQUE_ID_BYTES = 128
+MLN_N_STAGE_TIMES = 8
+
+K_MATERN32, K_MATERN52, K_EXPQUAD, K_EXPONENTIAL, K_RATQUAD, K_LINEAR = 1, 2, 3, 4, 5, 6
+OP_LEAF, OP_CONST, OP_ADD, OP_MUL, OP_POW = 0, 1, 2, 3, 4
+
+
+class MellonHipError(RuntimeError):
+    """HIP / RCCL / argument failure inside libmellon_hip.so."""
+
+
+class Leaf(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ndims", C.c_int32), ("ls", C.c_double), ("alpha", C.c_double),
+                ("dims", C.POINTER(C.c_int32))]
+
+
+class Tok(C.Structure):
+    _fields_ = [("op", C.c_int32), ("leaf", C.c_int32), ("value", C.c_double)]
+
+
+class KernelDesc(C.Structure):
+    _fields_ = [("n_leaves", C.c_int32), ("n_toks", C.c_int32), ("leaves", C.POINTER(Leaf)),
+                ("toks", C.POINTER(Tok))]
+
+
+# every symbol include/mellon_hip.h declares: (name, restype, argtypes)
+_vp, _i64, _i32, _dbl, _dp = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_void_p
+_KD = C.POINTER(KernelDesc)
+SYMBOLS = [
+    ("mln_ctx_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("mln_ctx_destroy", None, [_vp]),
+    ("mln_last_error", C.c_char_p, [_vp]),
+    ("mln_device_info", C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
+    ("mln_synchronize", C.c_int, [_vp]),
+    ("mln_malloc", C.c_int, [_vp, _i64, C.POINTER(_vp)]),
+    ("mln_free", C.c_int, [_vp, _vp]),
+    ("mln_memcpy", C.c_int, [_vp, _vp, _vp, _i64]),
+    ("mln_comm_unique_id", C.c_int, [_vp]),
+    ("mln_comm_init", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    ("mln_comm_allreduce_sum", C.c_int, [_vp, _dp, _i64]),
+    ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
+    ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
+    ("mln_trsm_lower", C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64]),
+    ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, C.POINTER(_vp)]),
+    ("mln_fit_destroy", None, [_vp]),
+    ("mln_fit_get_Lp", C.c_int, [_vp, _dp]),
+    ("mln_fit_get_L", C.c_int, [_vp, _i64, _i64, _dp]),
+    ("mln_fit_rank", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("mln_ridge_init", C.c_int, [_vp, _dp, _dp]),
+    ("mln_fit_set_likelihood", C.c_int, [_vp, _dp, _dp, _dbl]),
+    ("mln_objective", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
+    ("mln_transform", C.c_int, [_vp, _dp, _dp]),
+    ("mln_weights_cholesky", C.c_int, [_vp, _dp, _dp]),
+    ("mln_weights_full", C.c_int, [_vp, _dp, _i64, _dbl, _dp]),
+    ("mln_sparse_solve", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp]),
+    ("mln_predict_mean", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp]),
+    ("mln_stage_times", C.c_int, [_vp, _dp]),
+]
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libmellon_hip.so and declare every prototype.  Raises if it was not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MellonHipError(
+                f"{LIB_PATH} is missing: build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "(hipcc --offload-arch=gfx950).  mellon_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)   # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class DeviceArray:
+    """A float64 array resident in HBM (owned by a Context)."""
+
+    def __init__(self, ctx, shape):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        ptr = C.c_void_p()
+        ctx._check(ctx.lib.mln_malloc(ctx.handle, self.size * 8, C.byref(ptr)))
+        self.ptr = ptr.value
+
+    @property
+    def nbytes(self):
+        return self.size * 8
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        self.ctx._check(self.ctx.lib.mln_memcpy(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle is not None:
+            self.ctx.lib.mln_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    """Pointer of a NumPy array or DeviceArray (None -> NULL)."""
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    return a.ctypes.data
+
+
+class Context:
+    """One GPU, one HIP stream (mln_ctx).  Not thread-safe."""
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) if "MELLON_AMD_DEVICE" not in os.environ \
+                else int(os.environ["MELLON_AMD_DEVICE"])
+        h = C.c_void_p()
+        rc = self.lib.mln_ctx_create(int(device), C.byref(h))
+        self.handle = None
+        if rc != MLN_OK:
+            msg = self.lib.mln_last_error(None).decode()
+            raise MellonHipError(f"mln_ctx_create(device={device}) failed: {msg}")
+        self.handle = h.value
+        self.device = int(device)
+        self.n_ranks, self.rank = 1, 0
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.mln_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, jitter=None):
+        if rc == MLN_OK:
+            return
+        msg = self.lib.mln_last_error(self.handle).decode()
+        if rc == MLN_ERR_NOT_PD:
+            # same text as the reference (decomposition.py:116-122, conditional.py:74-80)
+            raise ValueError(
+                f"Covariance not positively definite with jitter={jitter}. "
+                "Consider increasing the jitter for numerical stabilization.")
+        if rc == MLN_ERR_SHAPE:
+            raise ValueError(f"libmellon_hip: {msg}")
+        if rc == MLN_ERR_UNSUPPORTED:
+            raise NotImplementedError(f"libmellon_hip: {msg}")
+        raise MellonHipError(f"libmellon_hip error {rc}: {msg}")
+
+    # -- info / memory ---------------------------------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        cu, mem = C.c_int(), C.c_int64()
+        self._check(self.lib.mln_device_info(self.handle, name, 64, C.byref(cu), C.byref(mem)))
+        return {"arch": name.value.decode(), "n_cu": cu.value, "mem_bytes": mem.value}
+
+    def synchronize(self):
+        self._check(self.lib.mln_synchronize(self.handle))
+
+    def to_device(self, a):
+        a = _f64(a)
+        d = DeviceArray(self, a.shape)
+        self._check(self.lib.mln_memcpy(self.handle, d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
+    def empty(self, shape):
+        return DeviceArray(self, shape)
+
+    # -- communicator ------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(MLN_UNIQUE_ID_BYTES)
+        self._check(self.lib.mln_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        buf = C.create_string_buffer(bytes(unique_id), MLN_UNIQUE_ID_BYTES)
+        self._check(self.lib.mln_comm_init(self.handle, buf, int(n_ranks), int(rank)))
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def allreduce_sum(self, a):
+        if isinstance(a, DeviceArray):
+            self._check(self.lib.mln_comm_allreduce_sum(self.handle, a.ptr, a.size))
+            return a
+        a = _f64(a).copy()
+        self._check(self.lib.mln_comm_allreduce_sum(self.handle, a.ctypes.data, a.size))
+        return a
+
+    # -- operators -----------------------------------------------------------------------------------
+    def kernel_matrix(self, desc, x, y):
+        x, y = _as2d(x), _as2d(y)
+        if x.shape[1] != y.shape[1]:
+            raise ValueError("x and y must have the same number of features")
+        out = np.empty((x.shape[0], y.shape[0]), dtype=np.float64)
+        self._check(self.lib.mln_kernel_matrix(self.handle, desc.ref, _ptr(x), x.shape[0], _ptr(y), y.shape[0],
+                                               x.shape[1], out.ctypes.data))
+        return out
+
+    def chol_lower(self, A, add_diag=0.0, jitter=None):
+        A = _f64(A).copy()
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("A must be square")
+        self._check(self.lib.mln_chol_lower(self.handle, A.ctypes.data, A.shape[0], float(add_diag)),
+                    jitter=add_diag if jitter is None else jitter)
+        return A
+
+    def trsm_lower(self, Lf, B, trans=False):
+        Lf = _f64(Lf)
+        B2 = _f64(B).copy()
+        shape = B2.shape
+        B2 = B2.reshape(Lf.shape[0], -1)
+        self._check(self.lib.mln_trsm_lower(self.handle, Lf.ctypes.data, Lf.shape[0], 1 if trans else 0,
+                                            B2.ctypes.data, B2.shape[1]))
+        return B2.reshape(shape)
+
+    def predict_mean(self, desc, xnew, centers, W, mu):
+        xnew = xnew if isinstance(xnew, DeviceArray) else _as2d(xnew)
+        centers = centers if isinstance(centers, DeviceArray) else _as2d(centers)
+        Wd = W if isinstance(W, DeviceArray) else _f64(W)
+        n_new, d = xnew.shape
+        m = centers.shape[0]
+        p = 1 if len(Wd.shape) == 1 else Wd.shape[1]
+        out = np.empty((n_new,) if len(Wd.shape) == 1 else (n_new, p), dtype=np.float64)
+        self._check(self.lib.mln_predict_mean(self.handle, desc.ref, _ptr(xnew), n_new, d, _ptr(centers), m,
+                                              _ptr(Wd), p, float(mu), out.ctypes.data))
+        return out
+
+    def sparse_solve(self, desc, x, xu, y, mu, sigma, jitter):
+        x = x if isinstance(x, DeviceArray) else _as2d(x)
+        xu = _as2d(xu)
+        y2 = _f64(y)
+        p = 1 if y2.ndim == 1 else y2.shape[1]
+        W = np.empty((xu.shape[0],) if y2.ndim == 1 else (xu.shape[0], p), dtype=np.float64)
+        self._check(self.lib.mln_sparse_solve(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1], _ptr(xu),
+                                              xu.shape[0], y2.ctypes.data, p, float(mu), float(sigma),
+                                              float(jitter), W.ctypes.data), jitter=jitter)
+        return W
+
+    def fit_prepare(self, desc, x, landmarks, jitter, Lp=None):
+        return Fit(self, desc, x, landmarks, jitter, Lp)
+
+
+def _as2d(a):
+    a = _f64(a)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    return np.ascontiguousarray(a)
+
+
+class Fit:
+    """Device-resident shard state of one estimator fit (mln_fit)."""
+
+    def __init__(self, ctx, desc, x, landmarks, jitter, Lp=None):
+        self.ctx, self.lib, self.handle = ctx, ctx.lib, None
+        x = x if isinstance(x, DeviceArray) else _as2d(x)
+        n, d = x.shape
+        xu = None if landmarks is None else (landmarks if isinstance(landmarks, DeviceArray) else _as2d(landmarks))
+        m = n if xu is None else xu.shape[0]
+        Lp_ = None if Lp is None else _f64(Lp)
+        if Lp_ is not None and Lp_.shape != (m, m):
+            raise ValueError(f"Lp has shape {Lp_.shape}, expected {(m, m)}")
+        h = C.c_void_p()
+        ctx._check(self.lib.mln_fit_prepare(ctx.handle, desc.ref, _ptr(x), n, d, _ptr(xu), m, float(jitter),
+                                            _ptr(Lp_), C.byref(h)), jitter=jitter)
+        self.handle = h.value
+        self.n, self.d, self.m, self.jitter = n, d, m, jitter
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            self.lib.mln_fit_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def Lp(self):
+        out = np.empty((self.m, self.m), dtype=np.float64)
+        self.ctx._check(self.lib.mln_fit_get_Lp(self.handle, out.ctypes.data))
+        return out
+
+    def L(self, row0=0, n_rows=None):
+        n_rows = self.n - row0 if n_rows is None else n_rows
+        out = np.empty((n_rows, self.m), dtype=np.float64)
+        self.ctx._check(self.lib.mln_fit_get_L(self.handle, row0, n_rows, out.ctypes.data))
+        return out
+
+    def ridge_init(self, target):
+        target = target if isinstance(target, DeviceArray) else _f64(target)
+        z0 = np.empty(self.m, dtype=np.float64)
+        self.ctx._check(self.lib.mln_ridge_init(self.handle, _ptr(target), z0.ctypes.data), jitter="ridge")
+        return z0
+
+    def set_likelihood(self, V, Vdr, mu):
+        V = V if isinstance(V, DeviceArray) else _f64(V)
+        Vdr = Vdr if isinstance(Vdr, DeviceArray) else _f64(Vdr)
+        self.ctx._check(self.lib.mln_fit_set_likelihood(self.handle, _ptr(V), _ptr(Vdr), float(mu)))
+
+    def objective(self, z, with_hess=False):
+        z = _f64(z)
+        loss = C.c_double()
+        grad = np.empty(self.m, dtype=np.float64)
+        hess = np.empty(self.m, dtype=np.float64) if with_hess else None
+        self.ctx._check(self.lib.mln_objective(self.handle, z.ctypes.data, C.byref(loss), grad.ctypes.data,
+                                               _ptr(hess)))
+        return (loss.value, grad, hess) if with_hess else (loss.value, grad)
+
+    def transform(self, z, out=None):
+        z = _f64(z)
+        ret = np.empty(self.n, dtype=np.float64) if out is None else out
+        self.ctx._check(self.lib.mln_transform(self.handle, z.ctypes.data, _ptr(ret)))
+        return ret
+
+    def weights_cholesky(self, z):
+        z = _f64(z)
+        w = np.empty(self.m, dtype=np.float64)
+        self.ctx._check(self.lib.mln_weights_cholesky(self.handle, z.ctypes.data, w.ctypes.data))
+        return w
+
+    def weights_full(self, y, mu):
+        y2 = _f64(y)
+        p = 1 if y2.ndim == 1 else y2.shape[1]
+        w = np.empty_like(y2)
+        self.ctx._check(self.lib.mln_weights_full(self.handle, y2.ctypes.data, p, float(mu), w.ctypes.data))
+        return w
+
+    def stage_times(self):
+        out = np.zeros(MLN_N_STAGE_TIMES, dtype=np.float64)
+        self.ctx._check(self.lib.mln_stage_times(self.handle, out.ctypes.data))
+        keys = ["kernel_matrix_s", "cholesky_s", "trsm_s", "ridge_gram_s", "ridge_solve_s",
+                "objective_kernel_s", "objective_launches", "objective_bytes_per_launch"]
+        return dict(zip(keys, out.tolist()))
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on GPU ``LOCAL_RANK`` (or ``MELLON_AMD_DEVICE``)."""
+    global _default_ctx
+    if _default_ctx is None or _default_ctx.handle is None:
+        _default_ctx = Context()
+    return _default_ctx

@@ -1,0 +1,846 @@
+// C ABI of libmellon_hip.so (see include/mellon_hip.h for the reference citations per entry).
+#include <dlfcn.h>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "linalg.h"
+#include "mln_internal.h"
+
+// ---- errors -------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void mln_set_error(mln_ctx* ctx, const std::string& msg) {
+  g_last_error = msg;
+  if (ctx) ctx->err = msg;
+}
+
+int mln_hip_fail(mln_ctx* ctx, hipError_t e, const char* what, const char* file, int line) {
+  mln_set_error(ctx, std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " (" + file + ":" +
+                         std::to_string(line) + ")");
+  (void)hipGetLastError();
+  return MLN_ERR_HIP;
+}
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- RCCL, bound lazily so single-GPU use never touches it ------------------------------------
+namespace rccl {
+typedef struct { char internal[128]; } UniqueId;
+typedef int (*GetUniqueId_t)(UniqueId*);
+typedef int (*CommInitRank_t)(void**, int, UniqueId, int);
+typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*CommDestroy_t)(void*);
+typedef const char* (*GetErrorString_t)(int);
+static void* lib = nullptr;
+static GetUniqueId_t GetUniqueId = nullptr;
+static CommInitRank_t CommInitRank = nullptr;
+static AllReduce_t AllReduce = nullptr;
+static CommDestroy_t CommDestroy = nullptr;
+static GetErrorString_t GetErrorString = nullptr;
+constexpr int kDouble = 8;  // ncclFloat64
+constexpr int kSum = 0;     // ncclSum
+static bool load(std::string* why) {
+  if (lib) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  if (!lib) { *why = std::string("cannot load librccl: ") + dlerror(); return false; }
+  GetUniqueId = (GetUniqueId_t)dlsym(lib, "ncclGetUniqueId");
+  CommInitRank = (CommInitRank_t)dlsym(lib, "ncclCommInitRank");
+  AllReduce = (AllReduce_t)dlsym(lib, "ncclAllReduce");
+  CommDestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
+  GetErrorString = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
+  if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { *why = "librccl lacks nccl symbols"; return false; }
+  return true;
+}
+}  // namespace rccl
+
+static int rccl_fail(mln_ctx* ctx, int code, const char* what) {
+  std::string s = std::string("RCCL error in ") + what + ": ";
+  s += rccl::GetErrorString ? rccl::GetErrorString(code) : std::to_string(code);
+  mln_set_error(ctx, s);
+  return MLN_ERR_RCCL;
+}
+
+// ---- pointer helpers ------------------------------------------------------------------------------
+static bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// Read-only input that may live on host or device.
+struct DevIn {
+  mln_ctx* ctx;
+  const double* dev = nullptr;
+  double* owned = nullptr;
+  int init(mln_ctx* c, const double* p, size_t count) {
+    ctx = c;
+    if (count == 0 || !p) { dev = p; return MLN_OK; }
+    if (is_device_ptr(p)) { dev = p; return MLN_OK; }
+    MLN_HIP(ctx, hipMalloc((void**)&owned, count * sizeof(double)));
+    MLN_HIP(ctx, hipMemcpyAsync(owned, p, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    dev = owned;
+    return MLN_OK;
+  }
+  ~DevIn() {
+    if (owned) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(owned); }
+  }
+};
+
+// Output that may live on host or device.
+struct DevOut {
+  mln_ctx* ctx;
+  double* dev = nullptr;
+  double* owned = nullptr;
+  double* host = nullptr;
+  size_t count = 0;
+  int init(mln_ctx* c, double* p, size_t n, bool copy_in = false) {
+    ctx = c; count = n;
+    if (n == 0) { dev = p; return MLN_OK; }
+    if (is_device_ptr(p)) { dev = p; return MLN_OK; }
+    host = p;
+    MLN_HIP(ctx, hipMalloc((void**)&owned, n * sizeof(double)));
+    if (copy_in) MLN_HIP(ctx, hipMemcpyAsync(owned, p, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    dev = owned;
+    return MLN_OK;
+  }
+  int commit() {
+    if (owned && count) {
+      MLN_HIP(ctx, hipMemcpyAsync(host, owned, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MLN_OK;
+  }
+  ~DevOut() {
+    if (owned) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(owned); }
+  }
+};
+
+int mln_scratch(mln_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    if (ctx->scratch) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; }
+    size_t want = bytes + bytes / 4 + 4096;
+    MLN_HIP(ctx, hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return MLN_OK;
+}
+
+// ---- covariance lowering ---------------------------------------------------------------------------
+int mln_lower_cov(mln_ctx* ctx, const mln_kernel_desc* cov, int d, DevCov* out) {
+  if (!cov || !cov->leaves || !cov->toks) { mln_set_error(ctx, "null covariance descriptor"); return MLN_ERR_ARG; }
+  if (cov->n_leaves < 1 || cov->n_leaves > MLN_MAX_LEAVES || cov->n_toks < 1 || cov->n_toks > MLN_MAX_TOKS) {
+    mln_set_error(ctx, "covariance descriptor: too many leaves / tokens for the device program");
+    return MLN_ERR_UNSUPPORTED;
+  }
+  std::memset(out, 0, sizeof(DevCov));
+  out->n_leaves = cov->n_leaves;
+  out->n_toks = cov->n_toks;
+  int off = 0;
+  for (int l = 0; l < cov->n_leaves; ++l) {
+    const mln_leaf& lf = cov->leaves[l];
+    if (lf.kind < MLN_K_MATERN32 || lf.kind > MLN_K_LINEAR) { mln_set_error(ctx, "unknown kernel kind"); return MLN_ERR_ARG; }
+    if (lf.ndims < 0 || off + lf.ndims > MLN_MAX_DIMS || (lf.ndims > 0 && !lf.dims)) {
+      mln_set_error(ctx, "covariance descriptor: active dims overflow"); return MLN_ERR_UNSUPPORTED;
+    }
+    out->leaves[l].kind = lf.kind; out->leaves[l].ndims = lf.ndims; out->leaves[l].dims_off = off;
+    out->leaves[l].ls = lf.ls; out->leaves[l].alpha = lf.alpha;
+    for (int k = 0; k < lf.ndims; ++k) {
+      if (lf.dims[k] < 0 || lf.dims[k] >= d) { mln_set_error(ctx, "active dim out of range"); return MLN_ERR_SHAPE; }
+      out->dims[off + k] = (short)lf.dims[k];
+    }
+    off += lf.ndims;
+  }
+  int depth = 0;
+  for (int t = 0; t < cov->n_toks; ++t) {
+    const mln_tok& tk = cov->toks[t];
+    out->tok_op[t] = tk.op; out->tok_leaf[t] = tk.leaf; out->tok_val[t] = tk.value;
+    if (tk.op == MLN_OP_LEAF) {
+      if (tk.leaf < 0 || tk.leaf >= cov->n_leaves) { mln_set_error(ctx, "token references unknown leaf"); return MLN_ERR_ARG; }
+      ++depth;
+    } else if (tk.op == MLN_OP_CONST) {
+      ++depth;
+    } else if (tk.op == MLN_OP_ADD || tk.op == MLN_OP_MUL || tk.op == MLN_OP_POW) {
+      if (depth < 2) { mln_set_error(ctx, "malformed covariance program"); return MLN_ERR_ARG; }
+      --depth;
+    } else { mln_set_error(ctx, "unknown token op"); return MLN_ERR_ARG; }
+    if (depth > 3) { mln_set_error(ctx, "covariance expression nests deeper than the device stack (3)"); return MLN_ERR_UNSUPPORTED; }
+  }
+  if (depth != 1) { mln_set_error(ctx, "malformed covariance program"); return MLN_ERR_ARG; }
+  if (cov->n_toks == 1 && cov->toks[0].op != MLN_OP_LEAF) { mln_set_error(ctx, "constant covariance"); return MLN_ERR_ARG; }
+  return MLN_OK;
+}
+
+// ---- context ----------------------------------------------------------------------------------------
+extern "C" const char* mln_last_error(mln_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int mln_ctx_create(int device, mln_ctx** out) {
+  if (!out) return MLN_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    (void)hipGetLastError();
+    mln_set_error(nullptr, "no HIP device visible: libmellon_hip has no CPU fallback");
+    return MLN_ERR_HIP;
+  }
+  if (device < 0 || device >= count) { mln_set_error(nullptr, "device index out of range"); return MLN_ERR_ARG; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { mln_set_error(nullptr, "hipGetDeviceProperties failed"); return MLN_ERR_HIP; }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    mln_set_error(nullptr, std::string("device is ") + prop.gcnArchName + "; this library is built for gfx950 only");
+    return MLN_ERR_UNSUPPORTED;
+  }
+  mln_ctx* ctx = new mln_ctx();
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+      hipMalloc((void**)&ctx->d_info, 4 * sizeof(int)) != hipSuccess) {
+    mln_set_error(nullptr, "failed to initialise the HIP context");
+    delete ctx;
+    return MLN_ERR_HIP;
+  }
+  *out = ctx;
+  return MLN_OK;
+}
+
+extern "C" void mln_ctx_destroy(mln_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm && rccl::CommDestroy) rccl::CommDestroy(ctx->comm);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->d_info) (void)hipFree(ctx->d_info);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int mln_device_info(mln_ctx* ctx, char* name, int name_cap, int* n_cu, int64_t* mem_bytes) {
+  if (!ctx) return MLN_ERR_ARG;
+  hipDeviceProp_t prop;
+  MLN_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_cap > 0) { std::strncpy(name, prop.gcnArchName, name_cap - 1); name[name_cap - 1] = 0; }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
+  return MLN_OK;
+}
+
+extern "C" int mln_synchronize(mln_ctx* ctx) {
+  if (!ctx) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
+}
+
+extern "C" int mln_malloc(mln_ctx* ctx, int64_t bytes, void** dev_ptr) {
+  if (!ctx || !dev_ptr || bytes < 0) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_HIP(ctx, hipMalloc(dev_ptr, (size_t)(bytes > 0 ? bytes : 8)));
+  return MLN_OK;
+}
+
+extern "C" int mln_free(mln_ctx* ctx, void* dev_ptr) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (dev_ptr) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, hipFree(dev_ptr)); }
+  return MLN_OK;
+}
+
+extern "C" int mln_memcpy(mln_ctx* ctx, void* dst, const void* src, int64_t bytes) {
+  if (!ctx || bytes < 0 || (bytes > 0 && (!dst || !src))) return MLN_ERR_ARG;
+  if (bytes == 0) return MLN_OK;
+  MLN_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
+}
+
+// ---- communicator -----------------------------------------------------------------------------------
+extern "C" int mln_comm_unique_id(void* id_out) {
+  std::string why;
+  if (!id_out) return MLN_ERR_ARG;
+  if (!rccl::load(&why)) { mln_set_error(nullptr, why); return MLN_ERR_RCCL; }
+  rccl::UniqueId id;
+  int rc = rccl::GetUniqueId(&id);
+  if (rc != 0) return rccl_fail(nullptr, rc, "ncclGetUniqueId");
+  std::memcpy(id_out, &id, MLN_UNIQUE_ID_BYTES);
+  return MLN_OK;
+}
+
+extern "C" int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank) {
+  if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MLN_ERR_ARG;
+  std::string why;
+  if (!rccl::load(&why)) { mln_set_error(ctx, why); return MLN_ERR_RCCL; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  rccl::UniqueId uid;
+  std::memcpy(&uid, id, MLN_UNIQUE_ID_BYTES);
+  int rc = rccl::CommInitRank(&ctx->comm, n_ranks, uid, rank);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclCommInitRank");
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return MLN_OK;
+}
+
+static int dev_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
+  if (ctx->n_ranks <= 1 || count <= 0) return MLN_OK;
+  int rc = rccl::AllReduce(dev, dev, (size_t)count, rccl::kDouble, rccl::kSum, ctx->comm, ctx->stream);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclAllReduce");
+  return MLN_OK;
+}
+
+extern "C" int mln_comm_allreduce_sum(mln_ctx* ctx, double* buf, int64_t count) {
+  if (!ctx || (count > 0 && !buf)) return MLN_ERR_ARG;
+  if (ctx->n_ranks <= 1) return MLN_OK;
+  DevOut o;
+  MLN_TRY(o.init(ctx, buf, (size_t)count, true));
+  MLN_TRY(dev_allreduce(ctx, o.dev, count));
+  return o.commit();
+}
+
+// ---- stand-alone operators -------------------------------------------------------------------------
+extern "C" int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n,
+                                 const double* y, int64_t m, int32_t d, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n < 0 || m < 0 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n == 0 || m == 0) return MLN_OK;
+  if (!x || !y || !out) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, dy;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, x, (size_t)n * d));
+  MLN_TRY(dy.init(ctx, y, (size_t)m * d));
+  MLN_TRY(o.init(ctx, out, (size_t)n * m));
+  MLN_TRY(launch_kernel_matrix(ctx, dc, dx.dev, n, dy.dev, m, d, o.dev, m, 0.0));
+  return o.commit();
+}
+
+static int64_t pad16(int64_t m) { return ((m + 15) / 16) * 16; }
+
+extern "C" int mln_chol_lower(mln_ctx* ctx, double* A, int64_t m, double add_diag) {
+  if (!ctx || (m > 0 && !A)) return MLN_ERR_ARG;
+  if (m < 0 || m > 65535) { mln_set_error(ctx, "cholesky: m out of range"); return MLN_ERR_SHAPE; }
+  if (m == 0) return MLN_OK;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevOut o;
+  MLN_TRY(o.init(ctx, A, (size_t)m * m, true));
+  if (add_diag != 0.0) MLN_TRY(launch_add_diag(ctx, o.dev, m, m, add_diag));
+  MLN_TRY(dev_cholesky_lower(ctx, o.dev, m, m));
+  return o.commit();
+}
+
+extern "C" int mln_trsm_lower(mln_ctx* ctx, const double* Lf, int64_t m, int32_t trans, double* B, int64_t p) {
+  if (!ctx || (m > 0 && (!Lf || (p > 0 && !B)))) return MLN_ERR_ARG;
+  if (m < 0 || p < 0) return MLN_ERR_SHAPE;
+  if (m == 0 || p == 0) return MLN_OK;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevIn dl;
+  DevOut b;
+  MLN_TRY(dl.init(ctx, Lf, (size_t)m * m));
+  MLN_TRY(b.init(ctx, B, (size_t)m * p, true));
+  TriInv t;
+  MLN_TRY(triinv_build(ctx, dl.dev, m, m, trans == 0, trans != 0, &t));
+  int rc = trans == 0 ? triinv_solve_left(ctx, t, b.dev, p, p) : triinv_solve_left_T(ctx, t, b.dev, p, p);
+  if (rc == MLN_OK) rc = b.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  triinv_free(&t);
+  return rc;
+}
+
+// ---- fit handle --------------------------------------------------------------------------------------
+struct mln_fit {
+  mln_ctx* ctx = nullptr;
+  DevCov cov;
+  int d = 0;
+  int64_t n = 0, m = 0, ldl = 0, ldp = 0;
+  bool full = false;
+  double* L = nullptr;   // n x ldl (full GP: aliases Lp)
+  double* Lp = nullptr;  // m x ldp
+  TriInv tri;            // block-scaled Lp
+  double *V = nullptr, *Vdr = nullptr;
+  double mu = 0.0;
+  // objective workspace
+  int n_wg = 0;
+  double *part_grad = nullptr, *part_hess = nullptr, *part_loss = nullptr;
+  double *d_z = nullptr, *d_out = nullptr;  // m ; 1 + 2m
+  double *h_z = nullptr, *h_out = nullptr;  // pinned
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double times[MLN_N_STAGE_TIMES] = {0};
+};
+
+static void fit_free(mln_fit* f) {
+  if (!f) return;
+  mln_ctx* ctx = f->ctx;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (f->L && f->L != f->Lp) (void)hipFree(f->L);
+  if (f->Lp) (void)hipFree(f->Lp);
+  triinv_free(&f->tri);
+  void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (f->h_z) (void)hipHostFree(f->h_z);
+  if (f->h_out) (void)hipHostFree(f->h_out);
+  if (f->ev0) (void)hipEventDestroy(f->ev0);
+  if (f->ev1) (void)hipEventDestroy(f->ev1);
+  delete f;
+}
+
+extern "C" void mln_fit_destroy(mln_fit* fit) { fit_free(fit); }
+
+static int fit_alloc_workspace(mln_fit* f) {
+  mln_ctx* ctx = f->ctx;
+  int64_t steps = (f->n + 1) / 2;
+  int n_wg = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  if (steps < n_wg) n_wg = (int)(steps > 0 ? steps : 1);
+  f->n_wg = n_wg;
+  const size_t pm = (size_t)f->ldl;
+  MLN_HIP(ctx, hipMalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
+  MLN_HIP(ctx, hipMalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
+  MLN_HIP(ctx, hipMalloc((void**)&f->part_loss, sizeof(double) * n_wg));
+  MLN_HIP(ctx, hipMalloc((void**)&f->d_z, sizeof(double) * pm));
+  MLN_HIP(ctx, hipMalloc((void**)&f->d_out, sizeof(double) * (1 + 2 * pm)));
+  MLN_HIP(ctx, hipHostMalloc((void**)&f->h_z, sizeof(double) * pm, hipHostMallocDefault));
+  MLN_HIP(ctx, hipHostMalloc((void**)&f->h_out, sizeof(double) * (1 + 2 * pm), hipHostMallocDefault));
+  MLN_HIP(ctx, hipEventCreate(&f->ev0));
+  MLN_HIP(ctx, hipEventCreate(&f->ev1));
+  return MLN_OK;
+}
+
+static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, int32_t d,
+                            const double* xu, int64_t m, double jitter, const double* Lp_in, mln_fit* f) {
+  f->ctx = ctx;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &f->cov));
+  f->d = d; f->n = n; f->full = (xu == nullptr);
+  if (f->full) m = n;
+  f->m = m;
+  if (m < 1 || m > 65535) { mln_set_error(ctx, "number of landmarks out of range"); return MLN_ERR_SHAPE; }
+  if (m > objective_max_m()) { mln_set_error(ctx, "m > 8192 landmarks is not supported by this build"); return MLN_ERR_UNSUPPORTED; }
+  if (f->full && ctx->n_ranks > 1) { mln_set_error(ctx, "the full (non-sparse) GP cannot be cell-sharded"); return MLN_ERR_UNSUPPORTED; }
+  f->ldp = pad16(m);
+  f->ldl = pad16(m);
+  DevIn dx, du;
+  MLN_TRY(dx.init(ctx, x, (size_t)n * d));
+  if (!f->full) MLN_TRY(du.init(ctx, xu, (size_t)m * d));
+  const double* centers = f->full ? dx.dev : du.dev;
+
+  // Lp = chol(cov(xu, xu) + max(sigma^2, jitter) I), sigma = 0     decomposition.py:111-123
+  double t0 = now_s();
+  const size_t lp_bytes = sizeof(double) * (size_t)m * f->ldp;
+  MLN_HIP(ctx, hipMalloc((void**)&f->Lp, lp_bytes));
+  MLN_HIP(ctx, hipMemsetAsync(f->Lp, 0, lp_bytes, ctx->stream));
+  if (Lp_in) {
+    DevIn dl;
+    MLN_TRY(dl.init(ctx, Lp_in, (size_t)m * m));
+    MLN_TRY(launch_copy_block(ctx, dl.dev, m, f->Lp, f->ldp, m, m));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else {
+    MLN_TRY(launch_kernel_matrix(ctx, f->cov, centers, m, centers, m, d, f->Lp, f->ldp, jitter));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f->times[0] += now_s() - t0;
+    t0 = now_s();
+    MLN_TRY(dev_cholesky_lower(ctx, f->Lp, m, f->ldp));
+  }
+  MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  f->times[1] += now_s() - t0;
+
+  if (f->full) {
+    f->L = f->Lp;  // parameters.py:847-850
+  } else {
+    // L = cov(x, xu) Lp^-T                                          decomposition.py:205-210
+    t0 = now_s();
+    const size_t l_bytes = sizeof(double) * (size_t)(n > 0 ? n : 1) * f->ldl;
+    MLN_HIP(ctx, hipMalloc((void**)&f->L, l_bytes));
+    MLN_HIP(ctx, hipMemsetAsync(f->L, 0, l_bytes, ctx->stream));
+    MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f->times[0] += now_s() - t0;
+    t0 = now_s();
+    MLN_TRY(triinv_solve_right_T(ctx, f->tri, f->L, n, f->ldl));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f->times[2] += now_s() - t0;
+  }
+  MLN_TRY(fit_alloc_workspace(f));
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                               int32_t d, const double* xu, int64_t m, double jitter, const double* Lp_in,
+                               mln_fit** out) {
+  if (!ctx || !out) return MLN_ERR_ARG;
+  *out = nullptr;
+  if (n_local < 0 || d < 1 || (n_local > 0 && !x)) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  mln_fit* f = new mln_fit();
+  int rc = fit_prepare_impl(ctx, cov, x, n_local, d, xu, m, jitter, Lp_in, f);
+  if (rc != MLN_OK) { fit_free(f); return rc; }
+  *out = f;
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_rank(mln_fit* fit, int64_t* m_out) {
+  if (!fit || !m_out) return MLN_ERR_ARG;
+  *m_out = fit->m;
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_get_Lp(mln_fit* f, double* out) {
+  if (!f || !out) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevOut o;
+  MLN_TRY(o.init(ctx, out, (size_t)f->m * f->m));
+  MLN_TRY(launch_copy_block(ctx, f->Lp, f->ldp, o.dev, f->m, f->m, f->m));
+  return o.commit();
+}
+
+extern "C" int mln_fit_get_L(mln_fit* f, int64_t row0, int64_t n_rows, double* out) {
+  if (!f || (n_rows > 0 && !out)) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (row0 < 0 || n_rows < 0 || row0 + n_rows > f->n) { mln_set_error(ctx, "row range out of bounds"); return MLN_ERR_SHAPE; }
+  if (n_rows == 0) return MLN_OK;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevOut o;
+  MLN_TRY(o.init(ctx, out, (size_t)n_rows * f->m));
+  MLN_TRY(launch_copy_block(ctx, f->L + row0 * f->ldl, f->ldl, o.dev, f->m, n_rows, f->m));
+  return o.commit();
+}
+
+extern "C" int mln_fit_set_likelihood(mln_fit* f, const double* V, const double* Vdr, double mu) {
+  if (!f || (f->n > 0 && (!V || !Vdr))) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(double) * (size_t)(f->n > 0 ? f->n : 1);
+  if (!f->V) MLN_HIP(ctx, hipMalloc((void**)&f->V, bytes));
+  if (!f->Vdr) MLN_HIP(ctx, hipMalloc((void**)&f->Vdr, bytes));
+  if (f->n > 0) {
+    MLN_HIP(ctx, hipMemcpyAsync(f->V, V, sizeof(double) * f->n, hipMemcpyDefault, ctx->stream));
+    MLN_HIP(ctx, hipMemcpyAsync(f->Vdr, Vdr, sizeof(double) * f->n, hipMemcpyDefault, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  f->mu = mu;
+  return MLN_OK;
+}
+
+static ObjArgs obj_args(mln_fit* f) {
+  ObjArgs a{};
+  a.L = f->L; a.ldl = f->ldl; a.n = f->n; a.m = f->m;
+  a.z = f->d_z; a.V = f->V; a.Vdr = f->Vdr; a.mu = f->mu;
+  a.part_grad = f->part_grad; a.part_hess = nullptr; a.part_loss = f->part_loss;
+  a.weights = nullptr; a.f_out = nullptr;
+  a.n_wg = f->n_wg; a.m_pad = f->ldl;
+  return a;
+}
+
+extern "C" int mln_objective(mln_fit* f, const double* z, double* loss, double* grad, double* hess_diag) {
+  if (!f || !z || !loss || !grad) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t m = f->m;
+  const bool zdev = is_device_ptr(z);
+  if (zdev) {
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_z, z, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+    MLN_HIP(ctx, hipMemcpyAsync(f->h_z, z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    std::memcpy(f->h_z, z, sizeof(double) * m);
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_z, f->h_z, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+  }
+  ObjArgs a = obj_args(f);
+  if (hess_diag) a.part_hess = f->part_hess;
+  const int64_t nout = 1 + m + (hess_diag ? m : 0);
+  MLN_HIP(ctx, hipEventRecord(f->ev0, ctx->stream));
+  MLN_TRY(launch_objective(ctx, a));
+  MLN_HIP(ctx, hipEventRecord(f->ev1, ctx->stream));
+  MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+  MLN_TRY(dev_allreduce(ctx, f->d_out, nout));
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->times[5] += 1e-3 * ms;
+  f->times[6] += 1.0;
+  f->times[7] = (double)f->n * (double)f->ldl * 8.0;
+  // prior terms, added once (inference.py:45-46): 1/2 |z|^2 + (k/2) log 2 pi ; d/dz = z ; d2/dz2 = 1
+  double zz = 0.0;
+  for (int64_t j = 0; j < m; ++j) zz += f->h_z[j] * f->h_z[j];
+  *loss = f->h_out[0] + 0.5 * zz + 0.5 * (double)m * std::log(2.0 * M_PI);
+  std::vector<double> tmp;
+  double* gh = grad;
+  if (is_device_ptr(grad)) { tmp.resize(m); gh = tmp.data(); }
+  for (int64_t j = 0; j < m; ++j) gh[j] = f->h_out[1 + j] + f->h_z[j];
+  if (gh != grad) MLN_HIP(ctx, hipMemcpy(grad, gh, sizeof(double) * m, hipMemcpyHostToDevice));
+  if (hess_diag) {
+    std::vector<double> th;
+    double* hh = hess_diag;
+    if (is_device_ptr(hess_diag)) { th.resize(m); hh = th.data(); }
+    for (int64_t j = 0; j < m; ++j) hh[j] = f->h_out[1 + m + j] + 1.0;
+    if (hh != hess_diag) MLN_HIP(ctx, hipMemcpy(hess_diag, hh, sizeof(double) * m, hipMemcpyHostToDevice));
+  }
+  return MLN_OK;
+}
+
+extern "C" int mln_transform(mln_fit* f, const double* z, double* f_out) {
+  if (!f || !z || (f->n > 0 && !f_out)) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  if (f->n == 0) return MLN_OK;
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_z, z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  DevOut o;
+  MLN_TRY(o.init(ctx, f_out, (size_t)f->n));
+  ObjArgs a = obj_args(f);
+  a.f_out = o.dev;
+  MLN_TRY(launch_objective(ctx, a));
+  return o.commit();
+}
+
+// G (m x ldg, lower + upper filled) = L^T L over this rank's rows, all-reduced.
+static int fit_gram(mln_fit* f, double* G, int64_t ldg) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, n = f->n;
+  int split = (int)(n / 8192);
+  if (split < 1) split = 1;
+  if (split > 16) split = 16;
+  const size_t stride = (size_t)m * ldg;
+  double* parts = nullptr;
+  if (split > 1) MLN_HIP(ctx, hipMalloc((void**)&parts, sizeof(double) * stride * split));
+  GemmArgs g{};
+  g.A = f->L; g.lda = f->ldl; g.B = f->L; g.ldb = f->ldl;
+  g.C = (split > 1) ? parts : G; g.ldc = ldg;
+  g.M = m; g.N = m; g.K = n; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0; g.lower_only = 1;
+  g.split_k = split; g.c_split_stride = (int64_t)stride;
+  int rc = MLN_OK;
+  if (split > 1) rc = (hipMemsetAsync(parts, 0, sizeof(double) * stride * split, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  else rc = (hipMemsetAsync(G, 0, sizeof(double) * stride, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  if (rc == MLN_OK && n > 0) rc = launch_dgemm(ctx, g);
+  if (rc == MLN_OK && split > 1) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, G, (int64_t)stride, 0.0);
+  if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
+  if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)stride);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (parts) (void)hipFree(parts);
+  return rc;
+}
+
+// rhs (m) = L^T t over this rank's rows, all-reduced; t is a device vector of length n
+static int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev) {
+  mln_ctx* ctx = f->ctx;
+  ObjArgs a = obj_args(f);
+  a.weights = t_dev;
+  a.part_loss = nullptr;
+  MLN_TRY(launch_objective(ctx, a));
+  MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+  MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
+  MLN_HIP(ctx, hipMemcpyAsync(rhs_dev, f->d_out + 1, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
+  return MLN_OK;
+}
+
+extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
+  if (!f || !z0 || (f->n > 0 && !target)) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t m = f->m, ldg = pad16(m);
+  double t0 = now_s();
+  double* G = nullptr;
+  double* rhs = nullptr;
+  MLN_HIP(ctx, hipMalloc((void**)&G, sizeof(double) * (size_t)m * ldg));
+  MLN_HIP(ctx, hipMalloc((void**)&rhs, sizeof(double) * (size_t)ldg));
+  DevIn dt;
+  int rc = dt.init(ctx, target, (size_t)f->n);
+  if (rc == MLN_OK) rc = fit_gram(f, G, ldg);
+  f->times[3] += now_s() - t0;
+  t0 = now_s();
+  if (rc == MLN_OK) rc = fit_gemvT(f, dt.dev, rhs);
+  if (rc == MLN_OK) rc = launch_add_diag(ctx, G, m, ldg, 1.0);  // Ridge alpha = 1
+  if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, G, m, ldg);
+  TriInv t;
+  if (rc == MLN_OK) rc = triinv_build(ctx, G, m, ldg, true, true, &t);
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, rhs, 1, 1);
+  if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, t, rhs, 1, 1);
+  if (rc == MLN_OK) {
+    hipError_t e = hipMemcpyAsync(z0, rhs, sizeof(double) * m, hipMemcpyDefault, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "copy z0", __FILE__, __LINE__);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  triinv_free(&t);
+  (void)hipFree(G);
+  (void)hipFree(rhs);
+  f->times[4] += now_s() - t0;
+  return rc;
+}
+
+extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
+  if (!f || !z || !w) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevOut o;
+  MLN_TRY(o.init(ctx, w, (size_t)f->m));
+  MLN_HIP(ctx, hipMemcpyAsync(o.dev, z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  MLN_TRY(triinv_solve_left_T(ctx, f->tri, o.dev, 1, 1));  // conditional.py:818
+  return o.commit();
+}
+
+extern "C" int mln_weights_full(mln_fit* f, const double* y, int64_t p, double mu, double* w) {
+  if (!f || !y || !w || p < 1) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t cnt = f->m * p;
+  DevOut o;
+  MLN_TRY(o.init(ctx, w, (size_t)cnt));
+  MLN_HIP(ctx, hipMemcpyAsync(o.dev, y, sizeof(double) * cnt, hipMemcpyDefault, ctx->stream));
+  // r = y - mu ; w = Lp^-T Lp^-1 r                                conditional.py:263-264
+  if (mu != 0.0) {
+    double* ones = nullptr;
+    MLN_HIP(ctx, hipMalloc((void**)&ones, sizeof(double) * cnt));
+    std::vector<double> h((size_t)cnt, 1.0);
+    MLN_HIP(ctx, hipMemcpyAsync(ones, h.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_axpby(ctx, cnt, -mu, ones, 1.0, o.dev);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ones);
+    if (rc != MLN_OK) return rc;
+  }
+  MLN_TRY(triinv_solve_left(ctx, f->tri, o.dev, p, p));
+  MLN_TRY(triinv_solve_left_T(ctx, f->tri, o.dev, p, p));
+  return o.commit();
+}
+
+extern "C" int mln_stage_times(mln_fit* f, double* out) {
+  if (!f || !out) return MLN_ERR_ARG;
+  for (int i = 0; i < MLN_N_STAGE_TIMES; ++i) out[i] = f->times[i];
+  return MLN_OK;
+}
+
+// ---- prediction -----------------------------------------------------------------------------------
+extern "C" int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                                int32_t d, const double* centers, int64_t m, const double* W, int64_t p,
+                                double mu, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n_new < 0 || m < 1 || p < 1 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n_new == 0) return MLN_OK;
+  if (!xnew || !centers || !W || !out) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, dc_, dw;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, xnew, (size_t)n_new * d));
+  MLN_TRY(dc_.init(ctx, centers, (size_t)m * d));
+  MLN_TRY(dw.init(ctx, W, (size_t)m * p));
+  MLN_TRY(o.init(ctx, out, (size_t)n_new * p));
+  if (p == 1) {
+    MLN_TRY(launch_predict_mean1(ctx, dc, dx.dev, n_new, dc_.dev, m, d, dw.dev, mu, o.dev));
+    return o.commit();
+  }
+  // p > 1 (FunctionEstimator): materialise row chunks of cov(Xnew, centers) and contract on the
+  // matrix cores: out = mu + K W                                   conditional.py:651-658
+  int64_t chunk = (int64_t)((1ull << 30) / (sizeof(double) * (size_t)m));
+  chunk = (chunk / 128) * 128;
+  if (chunk < 128) chunk = 128;
+  if (chunk > n_new) chunk = n_new;
+  double* Kc = nullptr;
+  double* mus = nullptr;
+  MLN_HIP(ctx, hipMalloc((void**)&Kc, sizeof(double) * (size_t)chunk * m));
+  int rc = MLN_OK;
+  if (mu != 0.0) {
+    std::vector<double> h((size_t)(chunk * p), mu);
+    rc = (hipMalloc((void**)&mus, sizeof(double) * h.size()) == hipSuccess &&
+          hipMemcpy(mus, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  }
+  for (int64_t r0 = 0; r0 < n_new && rc == MLN_OK; r0 += chunk) {
+    const int64_t rc_n = (n_new - r0 < chunk) ? (n_new - r0) : chunk;
+    rc = launch_kernel_matrix(ctx, dc, dx.dev + r0 * d, rc_n, dc_.dev, m, d, Kc, m, 0.0);
+    if (rc != MLN_OK) break;
+    double* oc = o.dev + r0 * p;
+    double beta = 0.0;
+    if (mus) {
+      rc = (hipMemcpyAsync(oc, mus, sizeof(double) * rc_n * p, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+      beta = 1.0;
+    }
+    if (rc != MLN_OK) break;
+    GemmArgs g{};
+    g.A = Kc; g.lda = m; g.B = dw.dev; g.ldb = p; g.C = oc; g.ldc = p;
+    g.M = rc_n; g.N = p; g.K = m; g.alpha = 1.0; g.beta = beta; g.ta = 0; g.tb = 0;
+    rc = launch_dgemm(ctx, g);
+  }
+  if (rc == MLN_OK) rc = o.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(Kc);
+  if (mus) (void)hipFree(mus);
+  return rc;
+}
+
+// ---- FunctionEstimator sparse solve ----------------------------------------------------------------
+extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                                int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
+                                double sigma, double jitter, double* W) {
+  if (!ctx || !xu || !W || (n_local > 0 && (!x || !y))) return MLN_ERR_ARG;
+  if (p < 1 || m < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (!(sigma > 0.0)) { mln_set_error(ctx, "sigma must be > 0 for the sparse solve (conditional.py:157-159 divides by sigma^2)"); return MLN_ERR_ARG; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  // A^T = cov(x, xu) Lp^-T is exactly the factor L of the density path   conditional.py:516-522
+  mln_fit* f = nullptr;
+  MLN_TRY(mln_fit_prepare(ctx, cov, x, n_local, d, xu, m, jitter, nullptr, &f));
+  const int64_t ldg = pad16(m), n = n_local;
+  const double s2 = sigma * sigma;
+  double *G = nullptr, *R = nullptr, *C = nullptr, *parts = nullptr;
+  TriInv tb;
+  int rc = MLN_OK;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "sparse_solve", __FILE__, __LINE__); };
+  chk(hipMalloc((void**)&G, sizeof(double) * (size_t)m * ldg));
+  chk(hipMalloc((void**)&C, sizeof(double) * (size_t)m * p));
+  DevIn dy;
+  if (rc == MLN_OK) rc = dy.init(ctx, y, (size_t)n * p);
+  // r = y - mu
+  if (rc == MLN_OK && n > 0) {
+    chk(hipMalloc((void**)&R, sizeof(double) * (size_t)n * p));
+    chk(hipMemcpyAsync(R, dy.dev, sizeof(double) * (size_t)n * p, hipMemcpyDeviceToDevice, ctx->stream));
+    if (rc == MLN_OK && mu != 0.0) {
+      std::vector<double> ones((size_t)n * p, 1.0);
+      double* d1 = nullptr;
+      chk(hipMalloc((void**)&d1, sizeof(double) * ones.size()));
+      chk(hipMemcpyAsync(d1, ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice, ctx->stream));
+      if (rc == MLN_OK) rc = launch_axpby(ctx, (int64_t)ones.size(), -mu, d1, 1.0, R);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (d1) (void)hipFree(d1);
+    }
+  }
+  // LBB = A A^T / sigma^2 + I                                      conditional.py:62 (stabilize(.., 1))
+  if (rc == MLN_OK) rc = fit_gram(f, G, ldg);
+  if (rc == MLN_OK) rc = launch_axpby(ctx, m * ldg, 0.0, G, 1.0 / s2, G);
+  if (rc == MLN_OK) rc = launch_add_diag(ctx, G, m, ldg, 1.0);
+  if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, G, m, ldg);
+  // C = A r / sigma^2 = L^T r / sigma^2   (m x p), split over cells
+  if (rc == MLN_OK) {
+    int split = (int)(n / 8192);
+    if (split < 1) split = 1;
+    if (split > 16) split = 16;
+    const size_t stride = (size_t)m * p;
+    if (split > 1) chk(hipMalloc((void**)&parts, sizeof(double) * stride * split));
+    if (rc == MLN_OK) chk(hipMemsetAsync(split > 1 ? parts : C, 0, sizeof(double) * stride * (split > 1 ? split : 1), ctx->stream));
+    GemmArgs g{};
+    g.A = f->L; g.lda = f->ldl; g.B = R; g.ldb = p; g.C = (split > 1) ? parts : C; g.ldc = p;
+    g.M = m; g.N = p; g.K = n; g.alpha = 1.0 / s2; g.beta = 0.0; g.ta = 1; g.tb = 0;
+    g.split_k = split; g.c_split_stride = (int64_t)stride;
+    if (rc == MLN_OK && n > 0) rc = launch_dgemm(ctx, g);
+    if (rc == MLN_OK && split > 1) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, C, (int64_t)stride, 0.0);
+    if (rc == MLN_OK) rc = dev_allreduce(ctx, C, (int64_t)stride);
+  }
+  // weights = Lp^-T L_B^-T L_B^-1 C                               conditional.py:64-65
+  if (rc == MLN_OK) rc = triinv_build(ctx, G, m, ldg, true, true, &tb);
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, tb, C, p, p);
+  if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, tb, C, p, p);
+  if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, C, p, p);
+  if (rc == MLN_OK) chk(hipMemcpyAsync(W, C, sizeof(double) * (size_t)m * p, hipMemcpyDefault, ctx->stream));
+  (void)hipStreamSynchronize(ctx->stream);
+  triinv_free(&tb);
+  void* ptrs[] = {G, R, C, parts};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  fit_free(f);
+  return rc;
+}

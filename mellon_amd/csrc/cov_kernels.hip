@@ -1,0 +1,279 @@
+// Pairwise-distance + covariance tiles (reference: mellon/util.py:351-366 `distance`,
+// mellon/cov.py k() of Matern32/52, ExpQuad, Exponential, RatQuad, Linear and
+// mellon/base_cov.py:301-453 Add/Mul/Pow), fp64, gfx950.
+//
+// Layout: 64 cells x 64 centres per 256-thread workgroup, 4x4 outputs per thread.  The cell and
+// centre tiles are staged k-major in LDS in chunks of 16 active dims (coalesced 128-B row reads),
+// the x.y dot product is an fp64 FMA chain in registers, and the sqrt/exp epilogue runs on the
+// same registers -- the n x m distance matrix never exists in HBM.  d <= 51 is too skinny for
+// the fp64 MFMA (same rate as v_fma_f64 on gfx950) to pay, so this is a VALU kernel.
+#include "mln_internal.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, DK = 16, PADT = 4;
+
+__device__ __forceinline__ double leaf_value(const DevLeaf& lf, double xx, double yy, double xy) {
+  if (lf.kind == MLN_K_LINEAR) return xy / lf.ls;           // cov.py:554
+  // util.py:362-366: sq = xx - 2 xy + yy + 1e-12 ; dist = sqrt(max(sq, 0))
+  double sq = xx - 2.0 * xy + yy + 1e-12;
+  double dist = sqrt(fmax(sq, 0.0));
+  switch (lf.kind) {
+    case MLN_K_MATERN32: {                                  // cov.py:64-65
+      double r = sqrt(3.0) * dist / lf.ls;
+      return (r + 1.0) * exp(-r);
+    }
+    case MLN_K_MATERN52: {                                  // cov.py:159-160
+      double r = sqrt(5.0) * dist / lf.ls;
+      return (r + r * r / 3.0 + 1.0) * exp(-r);
+    }
+    case MLN_K_EXPQUAD: {                                   // cov.py:257-258
+      double r = dist / lf.ls;
+      return exp(-(r * r) / 2.0);
+    }
+    case MLN_K_EXPONENTIAL: {                               // cov.py:354-355
+      double r = dist / lf.ls;
+      return exp(-r / 2.0);
+    }
+    default: {                                              // RatQuad cov.py:455-456
+      double r = dist / lf.ls;
+      return pow(r * r / (2.0 * lf.alpha) + 1.0, -lf.alpha);
+    }
+  }
+}
+
+// acc[i][j] = sum_k x[row0+ty*4+i][dims[k]] * y[col0+tx*4+j][dims[k]] over one leaf's active dims
+__device__ __forceinline__ void leaf_dot(const DevCov& cov, const DevLeaf& lf, const double* __restrict__ x,
+                                         int64_t n, const double* __restrict__ y, int64_t m, int d,
+                                         int64_t row0, int64_t col0, double (*xs)[TM + PADT],
+                                         double (*ys)[TN + PADT], double acc[4][4]) {
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int k0 = 0; k0 < lf.ndims; k0 += DK) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int idx = tid + 256 * q;
+      int r = idx >> 4, k = idx & 15;
+      double vx = 0.0, vy = 0.0;
+      if (k0 + k < lf.ndims) {
+        int col = cov.dims[lf.dims_off + k0 + k];
+        if (row0 + r < n) vx = x[(row0 + r) * (int64_t)d + col];
+        if (col0 + r < m) vy = y[(col0 + r) * (int64_t)d + col];
+      }
+      xs[k][r] = vx;
+      ys[k][r] = vy;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = xs[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = ys[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    }
+  }
+}
+
+// Evaluates the whole covariance program for this thread's 4x4 outputs into val.
+template <bool SINGLE>
+__device__ __forceinline__ void cov_tile(const DevCov& cov, const double* __restrict__ x, int64_t n,
+                                         const double* __restrict__ y, int64_t m, int d,
+                                         const double* __restrict__ xx, const double* __restrict__ yy,
+                                         int64_t row0, int64_t col0, double (*xs)[TM + PADT],
+                                         double (*ys)[TN + PADT], double val[4][4]) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double s1[4][4], s2[4][4];  // stack below the top (val is the top); max depth 3
+  int sp = 0;
+  const int ntok = SINGLE ? 1 : cov.n_toks;
+  for (int t = 0; t < ntok; ++t) {
+    const int op = SINGLE ? MLN_OP_LEAF : cov.tok_op[t];
+    if (op == MLN_OP_LEAF || op == MLN_OP_CONST) {
+      if (!SINGLE && sp > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s2[i][j] = s1[i][j]; s1[i][j] = val[i][j]; }
+      }
+      if (op == MLN_OP_CONST) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) val[i][j] = cov.tok_val[t];
+      } else {
+        const int li = SINGLE ? 0 : cov.tok_leaf[t];
+        const DevLeaf lf = cov.leaves[li];
+        double acc[4][4];
+        leaf_dot(cov, lf, x, n, y, m, d, row0, col0, xs, ys, acc);
+        double xr[4], yr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int64_t r = row0 + ty * 4 + i;
+          xr[i] = (r < n) ? xx[(int64_t)li * n + r] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int64_t c = col0 + tx * 4 + j;
+          yr[j] = (c < m) ? yy[(int64_t)li * m + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) val[i][j] = leaf_value(lf, xr[i], yr[j], acc[i][j]);
+      }
+      ++sp;
+    } else {
+      // binary op: left = s1, right = val (top)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double l = s1[i][j], r = val[i][j];
+          val[i][j] = (op == MLN_OP_ADD) ? (l + r) : (op == MLN_OP_MUL) ? (l * r) : pow(l, r);
+          s1[i][j] = s2[i][j];
+        }
+      --sp;
+    }
+  }
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double* __restrict__ x, int64_t n,
+                                                       const double* __restrict__ y, int64_t m, int d,
+                                                       const double* __restrict__ xx,
+                                                       const double* __restrict__ yy,
+                                                       double* __restrict__ out, int64_t ldo,
+                                                       double add_diag, int64_t tiles_n) {
+  __shared__ double xs[DK][TM + PADT];
+  __shared__ double ys[DK][TN + PADT];
+  const int64_t bid = blockIdx.x;
+  const int64_t row0 = (bid / tiles_n) * TM, col0 = (bid % tiles_n) * TN;
+  double val[4][4];
+  cov_tile<SINGLE>(cov, x, n, y, m, d, xx, yy, row0, col0, xs, ys, val);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t r = row0 + ty * 4 + i;
+    if (r >= n) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t c = col0 + tx * 4 + j;
+      if (c < m) out[r * ldo + c] = val[i][j] + ((r == c) ? add_diag : 0.0);
+    }
+  }
+}
+
+// mean_i = mu + sum_j cov(x_i, y_j) w_j   (conditional.py:899-906); K never leaves registers.
+template <bool SINGLE>
+__global__ __launch_bounds__(256) void k_predict_mean1(DevCov cov, const double* __restrict__ x, int64_t n,
+                                                       const double* __restrict__ y, int64_t m, int d,
+                                                       const double* __restrict__ xx,
+                                                       const double* __restrict__ yy,
+                                                       const double* __restrict__ w, double mu,
+                                                       double* __restrict__ out) {
+  __shared__ double xs[DK][TM + PADT];
+  __shared__ double ys[DK][TN + PADT];
+  __shared__ double red[TM][17];
+  const int64_t row0 = (int64_t)blockIdx.x * TM;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double part[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t col0 = 0; col0 < m; col0 += TN) {
+    double val[4][4];
+    cov_tile<SINGLE>(cov, x, n, y, m, d, xx, yy, row0, col0, xs, ys, val);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t c = col0 + tx * 4 + j;
+      double wj = (c < m) ? w[c] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) part[i] = fma(val[i][j], wj, part[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[ty * 4 + i][tx] = part[i];
+  __syncthreads();
+  if (threadIdx.x < TM) {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += red[threadIdx.x][t];
+    int64_t r = row0 + threadIdx.x;
+    if (r < n) out[r] = mu + s;
+  }
+}
+
+// xx[leaf][i] = sum over the leaf's active dims of x_i^2   (util.py:362)
+__global__ void k_row_sqnorms(DevCov cov, const double* __restrict__ x, int64_t n, int d,
+                              double* __restrict__ xx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int l = 0; l < cov.n_leaves; ++l) {
+    const DevLeaf lf = cov.leaves[l];
+    double s = 0.0;
+    for (int k = 0; k < lf.ndims; ++k) {
+      double v = x[i * (int64_t)d + cov.dims[lf.dims_off + k]];
+      s = fma(v, v, s);
+    }
+    xx[(int64_t)l * n + i] = s;
+  }
+}
+
+int sqnorms(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, double* xx) {
+  if (n == 0) return MLN_OK;
+  hipLaunchKernelGGL(k_row_sqnorms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cov, x, n, d, xx);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+}  // namespace
+
+int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
+                         int64_t m, int d, double* out, int64_t ldo, double add_diag) {
+  if (n == 0 || m == 0) return MLN_OK;
+  double* norms = nullptr;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)cov.n_leaves * (size_t)(n + m), (void**)&norms));
+  double* xx = norms;
+  double* yy = norms + (int64_t)cov.n_leaves * n;
+  MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
+  MLN_TRY(sqnorms(ctx, cov, y, m, d, yy));
+  const int64_t tiles_n = (m + TN - 1) / TN, tiles_m = (n + TM - 1) / TM;
+  const int64_t nblk = tiles_n * tiles_m;
+  if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "kernel matrix too large for one launch"); return MLN_ERR_UNSUPPORTED; }
+  const bool single = (cov.n_toks == 1);
+  if (single)
+    hipLaunchKernelGGL(k_kernel_matrix<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
+                       xx, yy, out, ldo, add_diag, tiles_n);
+  else
+    hipLaunchKernelGGL(k_kernel_matrix<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
+                       xx, yy, out, ldo, add_diag, tiles_n);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
+                         int64_t m, int d, const double* w, double mu, double* out) {
+  if (n == 0) return MLN_OK;
+  double* norms = nullptr;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)cov.n_leaves * (size_t)(n + m), (void**)&norms));
+  double* xx = norms;
+  double* yy = norms + (int64_t)cov.n_leaves * n;
+  MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
+  MLN_TRY(sqnorms(ctx, cov, y, m, d, yy));
+  const int64_t nblk = (n + TM - 1) / TM;
+  const bool single = (cov.n_toks == 1);
+  if (single)
+    hipLaunchKernelGGL(k_predict_mean1<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
+                       xx, yy, w, mu, out);
+  else
+    hipLaunchKernelGGL(k_predict_mean1<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
+                       xx, yy, w, mu, out);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}

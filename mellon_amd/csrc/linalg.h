@@ -1,0 +1,17 @@
+// Block-scaled triangular factors for GEMM-based triangular solves (see linalg.hip).
+#pragma once
+#include "mln_internal.h"
+
+struct TriInv {
+  double* W = nullptr;   // row-scaled    (forward solves, X Lf^-T)
+  double* W2 = nullptr;  // column-scaled (transposed / backward solves)
+  int64_t m = 0, ld = 0;
+};
+
+int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool need_w, bool need_w2, TriInv* out);
+void triinv_free(TriInv* t);
+int triinv_solve_right_T(mln_ctx* ctx, const TriInv& t, double* X, int64_t n, int64_t ldx);  // X <- X Lf^-T
+int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb);     // B <- Lf^-1 B
+int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb);   // B <- Lf^-T B
+int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows,
+                      int64_t cols);

@@ -1,0 +1,346 @@
+// Dense m x m factorisation and triangular solves on the device (fp64).
+//
+// Reference arithmetic: jnp.linalg.cholesky (decomposition.py:115, conditional.py:73) and
+// jax.scipy.linalg.solve_triangular (decomposition.py:209, conditional.py:63-65,264,818), i.e.
+// LAPACK potrf/trtrs semantics.  Here: right-looking blocked Cholesky (64-wide panels: LDS
+// factorisation of the diagonal block + its inverse, then panel-solve and trailing SYRK as fp64
+// MFMA GEMMs), and triangular solves as sequences of GEMMs against row-/column-scaled copies of
+// the factor whose 128x128 diagonal blocks are inverted explicitly (the standard GPU TRSM; only
+// diagonal blocks are ever inverted, so the conditioning that enters is that of a 128-block).
+#include "mln_internal.h"
+#include "linalg.h"
+
+namespace {
+
+constexpr int PB = 64;    // Cholesky panel width
+constexpr int TB = 128;   // triangular-solve block
+
+// Factorises the nb x nb (nb <= 64) lower block at A in LDS; writes the factor back (strict upper
+// part zeroed) and its inverse to Dinv (64 x 64, row-major, ld 64).  A non-positive or NaN pivot
+// sets *info = (global pivot index + 1) once and leaves the block unfactorised.
+__global__ __launch_bounds__(256) void k_potrf64(double* A, int64_t lda, int nb, double* __restrict__ Dinv,
+                                                 int* info, int64_t j0) {
+  __shared__ double T[PB][PB + 1];
+  __shared__ double X[PB][PB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < PB * PB; e += 256) {
+    int i = e / PB, j = e % PB;
+    T[i][j] = (i < nb && j <= i) ? A[(int64_t)i * lda + j] : ((i == j) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int k = 0; k < nb; ++k) {
+    const double d = T[k][k];
+    if (!(d > 0.0)) {  // uniform: every thread reads the same LDS word after a barrier
+      if (tid == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
+      return;
+    }
+    const double s = sqrt(d);
+    __syncthreads();
+    for (int i = k + tid; i < nb; i += 256) T[i][k] = (i == k) ? s : T[i][k] / s;
+    __syncthreads();
+    const int cnt = nb - k - 1;
+    for (int e = tid; e < cnt * cnt; e += 256) {
+      int ii = k + 1 + e / cnt, jj = k + 1 + e % cnt;
+      if (jj <= ii) T[ii][jj] = fma(-T[ii][k], T[jj][k], T[ii][jj]);
+    }
+    __syncthreads();
+  }
+  if (tid < PB) {  // column tid of T^-1 by forward substitution
+    const int j = tid;
+    for (int i = 0; i < PB; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      if (i < j) { X[i][j] = 0.0; continue; }
+      for (int k = j; k < i; ++k) s = fma(-T[i][k], X[k][j], s);
+      X[i][j] = s / T[i][i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < PB * PB; e += 256) {
+    int i = e / PB, j = e % PB;
+    if (i < nb && j < nb) A[(int64_t)i * lda + j] = (j <= i) ? T[i][j] : 0.0;
+    Dinv[e] = X[i][j];
+  }
+}
+
+// inverse of every 64 x 64 diagonal block of a lower-triangular factor, written into the same
+// position of W (blocks past m are padded with identity rows)
+__global__ __launch_bounds__(256) void k_trtri64(const double* __restrict__ Lf, int64_t m, int64_t ld,
+                                                 double* __restrict__ W, int64_t ldw) {
+  __shared__ double T[PB][PB + 1];
+  __shared__ double X[PB][PB + 1];
+  const int tid = threadIdx.x;
+  const int64_t j0 = (int64_t)blockIdx.x * PB;
+  const int nb = (int)((m - j0 < PB) ? (m - j0) : PB);
+  for (int e = tid; e < PB * PB; e += 256) {
+    int i = e / PB, j = e % PB;
+    T[i][j] = (i < nb && j <= i) ? Lf[(j0 + i) * ld + j0 + j] : ((i == j) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  if (tid < PB) {
+    const int j = tid;
+    for (int i = 0; i < PB; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      if (i < j) { X[i][j] = 0.0; continue; }
+      for (int k = j; k < i; ++k) s = fma(-T[i][k], X[k][j], s);
+      X[i][j] = s / T[i][i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < PB * PB; e += 256) {
+    int i = e / PB, j = e % PB;
+    if (i < nb && j < nb) W[(j0 + i) * ldw + j0 + j] = X[i][j];
+  }
+}
+
+// completes the inverse of each 128 x 128 diagonal block from its two 64-block inverses:
+// X21 = -X22 * T21 * X11
+__global__ __launch_bounds__(256) void k_trtri_merge128(const double* __restrict__ Lf, int64_t m, int64_t ld,
+                                                        double* W, int64_t ldw) {
+  __shared__ double Ta[PB][PB + 1];
+  __shared__ double Xa[PB][PB + 1];
+  __shared__ double Xb[PB][PB + 1];
+  const int tid = threadIdx.x;
+  const int64_t j0 = (int64_t)blockIdx.x * TB;
+  const int64_t r0 = j0 + PB;
+  if (r0 >= m) return;
+  const int nb2 = (int)((m - r0 < PB) ? (m - r0) : PB);
+  for (int e = tid; e < PB * PB; e += 256) {
+    int i = e / PB, j = e % PB;
+    Ta[i][j] = (i < nb2) ? Lf[(r0 + i) * ld + j0 + j] : 0.0;                 // T21
+    Xa[i][j] = W[(j0 + i) * ldw + j0 + j];                                   // X11 (full 64 block exists)
+    Xb[i][j] = (i < nb2 && j < nb2) ? W[(r0 + i) * ldw + r0 + j] : 0.0;      // X22
+  }
+  __syncthreads();
+  // tmp = T21 * X11 ; each thread 16 outputs: row i = tid / 4, cols (tid % 4) * 16 ..
+  const int ti = tid >> 2, tc = (tid & 3) * 16;
+  double tmp[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tmp[q] = 0.0;
+  for (int k = 0; k < PB; ++k) {
+    const double a = Ta[ti][k];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tmp[q] = fma(a, Xa[k][tc + q], tmp[q]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) Ta[ti][tc + q] = tmp[q];
+  __syncthreads();
+  double out[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) out[q] = 0.0;
+  for (int k = 0; k < PB; ++k) {
+    const double a = Xb[ti][k];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[q] = fma(a, Ta[k][tc + q], out[q]);
+  }
+  if (ti < nb2) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) W[(r0 + ti) * ldw + j0 + tc + q] = -out[q];
+  }
+}
+
+__global__ void k_add_diag(double* A, int64_t m, int64_t lda, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) A[i * lda + i] += v;
+}
+
+__global__ void k_zero_upper(double* A, int64_t m, int64_t lda) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = blockIdx.y;
+  if (j < m && j > i) A[i * lda + j] = 0.0;
+}
+
+__global__ void k_sym_from_lower(double* A, int64_t m, int64_t lda) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = blockIdx.y;
+  if (j < m && j > i) A[i * lda + j] = A[j * lda + i];
+}
+
+__global__ void k_axpby(int64_t n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + ((b != 0.0) ? b * y[i] : 0.0);
+}
+
+__global__ void k_copy_block(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd,
+                             int64_t rows, int64_t cols) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t i = blockIdx.y;
+  if (i < rows && j < cols) dst[i * ldd + j] = src[i * lds + j];
+}
+
+}  // namespace
+
+int launch_add_diag(mln_ctx* ctx, double* A, int64_t m, int64_t lda, double v) {
+  if (m <= 0) return MLN_OK;
+  hipLaunchKernelGGL(k_add_diag, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, A, m, lda, v);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_symmetrize_from_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
+  if (m <= 0) return MLN_OK;
+  hipLaunchKernelGGL(k_sym_from_lower, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, A, m, lda);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_axpby(mln_ctx* ctx, int64_t n, double a, const double* x, double b, double* y) {
+  if (n <= 0) return MLN_OK;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(k_axpby, dim3((unsigned)nb), dim3(256), 0, ctx->stream, n, a, x, b, y);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows,
+                      int64_t cols) {
+  if (rows <= 0 || cols <= 0) return MLN_OK;
+  if (rows > 65535) {
+    for (int64_t r = 0; r < rows; r += 65535) {
+      int64_t nr = (rows - r < 65535) ? rows - r : 65535;
+      MLN_TRY(launch_copy_block(ctx, src + r * lds, lds, dst + r * ldd, ldd, nr, cols));
+    }
+    return MLN_OK;
+  }
+  hipLaunchKernelGGL(k_copy_block, dim3((unsigned)((cols + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream,
+                     src, lds, dst, ldd, rows, cols);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+// In-place lower Cholesky of the m x m matrix at A (only the lower triangle is read).
+int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
+  if (m <= 0) return MLN_OK;
+  double* Dinv = nullptr;
+  MLN_HIP(ctx, hipMalloc((void**)&Dinv, sizeof(double) * PB * PB));
+  MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  int rc = MLN_OK;
+  for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += PB) {
+    const int nb = (int)((m - j0 < PB) ? (m - j0) : PB);
+    double* Ajj = A + j0 * lda + j0;
+    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, ctx->stream, Ajj, lda, nb, Dinv, ctx->d_info, j0);
+    const int64_t rem = m - j0 - nb;
+    if (rem > 0) {
+      double* P = A + (j0 + nb) * lda + j0;
+      GemmArgs g{};  // P <- P * Dinv^T   (in place: one 128-wide column tile per row tile)
+      g.A = P; g.lda = lda; g.B = Dinv; g.ldb = PB; g.C = P; g.ldc = lda;
+      g.M = rem; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
+      rc = launch_dgemm(ctx, g);
+      if (rc != MLN_OK) break;
+      GemmArgs s{};  // A22 -= P P^T on lower tiles
+      s.A = P; s.lda = lda; s.B = P; s.ldb = lda; s.C = A + (j0 + nb) * lda + (j0 + nb); s.ldc = lda;
+      s.M = rem; s.N = rem; s.K = nb; s.alpha = -1.0; s.beta = 1.0; s.ta = 0; s.tb = 1; s.lower_only = 1;
+      rc = launch_dgemm(ctx, s);
+    }
+  }
+  int info = 0;
+  if (rc == MLN_OK) {
+    hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, A, m, lda);
+    hipError_t e = hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "cholesky sync", __FILE__, __LINE__);
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(Dinv);
+  if (rc == MLN_OK && info != 0) {
+    mln_set_error(ctx, "Cholesky failed: non-positive or NaN pivot at index " + std::to_string(info - 1));
+    return MLN_ERR_NOT_PD;
+  }
+  return rc;
+}
+
+// ---- triangular solves through block-scaled copies of the factor ------------------------------
+void triinv_free(TriInv* t) {
+  if (t->W) (void)hipFree(t->W);
+  if (t->W2) (void)hipFree(t->W2);
+  t->W = t->W2 = nullptr;
+}
+
+// W  (row-scaled):    W[j, <=j]  = Dinv_j [ -Lf[j,<j] | I ]     -> forward solves and X Lf^-T
+// W2 (column-scaled): W2[>=j, j] = [ I ; -Lf[>j,j] ] Dinv_j     -> backward (transposed) solves
+int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool need_w, bool need_w2, TriInv* out) {
+  out->m = m;
+  out->ld = ((m + 15) / 16) * 16;
+  const size_t bytes = sizeof(double) * (size_t)m * (size_t)out->ld;
+  double* D = nullptr;  // block-diagonal inverse, stored in an m x ld matrix
+  MLN_HIP(ctx, hipMalloc((void**)&D, bytes));
+  MLN_HIP(ctx, hipMemsetAsync(D, 0, bytes, ctx->stream));
+  const int64_t nb64 = (m + PB - 1) / PB, nb128 = (m + TB - 1) / TB;
+  hipLaunchKernelGGL(k_trtri64, dim3((unsigned)nb64), dim3(256), 0, ctx->stream, Lf, m, ld, D, out->ld);
+  hipLaunchKernelGGL(k_trtri_merge128, dim3((unsigned)nb128), dim3(256), 0, ctx->stream, Lf, m, ld, D, out->ld);
+  MLN_HIP(ctx, hipGetLastError());
+  int rc = MLN_OK;
+  if (need_w2) {
+    rc = (hipMalloc((void**)&out->W2, bytes) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+    if (rc == MLN_OK) rc = (hipMemcpyAsync(out->W2, D, bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+    for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += TB) {
+      const int64_t nb = (m - j0 < TB) ? (m - j0) : TB;
+      const int64_t rem = m - j0 - nb;
+      if (rem <= 0) break;
+      GemmArgs g{};  // W2[>j, j] = -Lf[>j, j] * Dinv_j
+      g.A = Lf + (j0 + nb) * ld + j0; g.lda = ld; g.B = D + j0 * out->ld + j0; g.ldb = out->ld;
+      g.C = out->W2 + (j0 + nb) * out->ld + j0; g.ldc = out->ld;
+      g.M = rem; g.N = nb; g.K = nb; g.alpha = -1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+      rc = launch_dgemm(ctx, g);
+    }
+  }
+  if (need_w && rc == MLN_OK) {
+    for (int64_t j0 = TB; j0 < m && rc == MLN_OK; j0 += TB) {
+      const int64_t nb = (m - j0 < TB) ? (m - j0) : TB;
+      GemmArgs g{};  // W[j, <j] = -Dinv_j * Lf[j, <j]   (written next to the diagonal blocks in D)
+      g.A = D + j0 * out->ld + j0; g.lda = out->ld; g.B = Lf + j0 * ld; g.ldb = ld;
+      g.C = D + j0 * out->ld; g.ldc = out->ld;
+      g.M = nb; g.N = j0; g.K = nb; g.alpha = -1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+      rc = launch_dgemm(ctx, g);
+    }
+    out->W = D;
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(D);
+  }
+  if (rc != MLN_OK) { (void)hipStreamSynchronize(ctx->stream); triinv_free(out); mln_set_error(ctx, "triinv_build failed"); }
+  return rc;
+}
+
+// X (n x m, in place) <- X Lf^-T, left-looking over 128-wide block columns:
+//   X_j <- [X_<j | X_j] W_j^T      (decomposition.py:209:  L = solve_triangular(Lp, C.T, lower=True).T)
+int triinv_solve_right_T(mln_ctx* ctx, const TriInv& t, double* X, int64_t n, int64_t ldx) {
+  for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
+    const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.B = t.W + j0 * t.ld; g.ldb = t.ld; g.C = X + j0; g.ldc = ldx;
+    g.M = n; g.N = nb; g.K = j0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
+    MLN_TRY(launch_dgemm(ctx, g));
+  }
+  return MLN_OK;
+}
+
+// B (m x p, in place) <- Lf^-1 B (forward substitution by 128-row blocks): B_j <- W_j [B_<j ; B_j]
+int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb) {
+  for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
+    const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+    // in place: one row tile (nb <= 128), so each workgroup reads and writes only its own column tile
+    GemmArgs g{};
+    g.A = t.W + j0 * t.ld; g.lda = t.ld; g.B = B; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
+    g.M = nb; g.N = p; g.K = j0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+    MLN_TRY(launch_dgemm(ctx, g));
+  }
+  return MLN_OK;
+}
+
+// B (m x p, in place) <- Lf^-T B (backward substitution): B_j <- W2[>=j, j]^T B[>=j]
+int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb) {
+  const int64_t nblk = (t.m + TB - 1) / TB;
+  for (int64_t jb = nblk - 1; jb >= 0; --jb) {
+    const int64_t j0 = jb * TB;
+    const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+    GemmArgs g{};
+    g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb;
+    g.C = B + j0 * ldb; g.ldc = ldb;
+    g.M = nb; g.N = p; g.K = t.m - j0; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;
+    MLN_TRY(launch_dgemm(ctx, g));
+  }
+  return MLN_OK;
+}

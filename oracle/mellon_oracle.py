@@ -142,11 +142,18 @@ class Covariance:
 
 
 def _deserialize(v):
-    """util.py:95-132 subset: slices and arrays as tagged dicts."""
-    if isinstance(v, dict) and v.get("type") == "slice":
-        return slice(v["start"], v["stop"], v["step"])
-    if isinstance(v, dict) and v.get("type") == "jax.numpy":
-        return np.array(v["data"], dtype=v.get("dtype", None))
+    """util.py:95-132: tagged dicts for arrays / slices, the string "None" for None."""
+    if isinstance(v, dict):
+        if v["type"] == "jax.numpy":
+            return np.array(v["data"])
+        if v["type"] == "slice":
+            return slice(*[None if (isinstance(q, str) and q == "None") else q for q in v["data"]])
+        if v["type"] == "dict":
+            return {k: _deserialize(q) for k, q in v["data"].items()}
+        if v["type"] == "set":
+            return {_deserialize(q) for q in v["data"]}
+    if isinstance(v, str) and v == "None":
+        return None
     return v
 
 

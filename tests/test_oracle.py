@@ -195,11 +195,11 @@ def test_covariance_dict_round_trip():
     state = {
         "type": "mellon.Covariance",
         "left_data": {"type": "mellon.Covariance",
-                      "data": {"ls": 1.5, "active_dims": {"type": "slice", "start": None, "stop": -1, "step": None}},
+                      "data": {"ls": 1.5, "active_dims": {"type": "slice", "data": ["None", -1, "None"]}},
                       "metadata": {"classname": "Matern52", "module_name": "mellon.cov"}},
         "right_data": {"type": "mellon.Covariance", "data": {"ls": 0.4, "active_dims": -1},
                        "metadata": {"classname": "Matern52", "module_name": "mellon.cov"}},
-        "active_dims": None,
+        "active_dims": "None",
         "metadata": {"classname": "Mul", "module_name": "mellon"},
     }
     c2 = mo.Covariance.from_dict(state)
