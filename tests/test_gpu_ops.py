@@ -45,7 +45,15 @@ def test_kernel_matrix_leaves(ctx, name, shape):
     c = getattr(cov, name)(2.0, 1.7) if name == "RatQuad" else getattr(cov, name)(1.7)
     K = c(x, y)
     assert K.shape == (n, m)
-    assert relmax(K, _pair(c)(x, y)) < 1e-12
+    ref = _pair(c)(x, y)
+    # coincident points evaluate sqrt(1e-12 + rounding noise of xx - 2xy + yy) (util.py:365): the
+    # noise (~1e-15 |x|^2) is implementation-defined, so kernels with a cusp at 0 (Exponential)
+    # differ by up to ~1e-7 there in ANY two implementations; everywhere else rounding-level agreement.
+    co = np.zeros((n, m), dtype=bool)
+    h = min(n, m) // 2
+    co[np.arange(h), np.arange(h)] = True
+    assert np.abs(K - ref)[~co].max(initial=0.0) < 1e-12 * max(np.abs(ref).max(), 1.0)
+    assert np.abs(K - ref)[co].max(initial=0.0) < 1e-6
 
 
 def test_kernel_matrix_algebra_and_active_dims(ctx):
@@ -56,7 +64,8 @@ def test_kernel_matrix_algebra_and_active_dims(ctx):
     b = cov.Matern52(0.6, active_dims=-1)
     e = cov.ExpQuad(0.9, active_dims=[0, 2, 5])
     mask = cov.Matern32(1.1, active_dims=np.array([True, False, True, False, False, True]))
-    for c in (a * b, a + b, a + 2.0, 3.0 * a, a ** 2, (a * b) + e * 0.5, mask, cov.Mul(a, e, active_dims=[0, 1, 2, 3, 5])):
+    for c in (a * b, a + b, a + 2.0, 3.0 * a, a ** 2, (a * b) + e * 0.5, mask,
+              cov.Mul(a, cov.ExpQuad(0.9, active_dims=[0, 2, 4]), active_dims=[0, 1, 2, 3, 5])):
         assert relmax(c(x, y), _pair(c)(x, y)) < 1e-12, repr(c)
 
 
@@ -154,7 +163,7 @@ def test_fit_pipeline_sparse(ctx, n, d, m, kern):
     pred = ctx.predict_mean(c.lower(d), x[: n // 3], xu, w, mu)
     assert relmax(pred, f[: n // 3]) < 1e-8           # predict(X) == fit_predict(X)  (test_density_estimator.py:40-44)
     st = fit.stage_times()
-    assert st["objective_launches"] == 6 and st["objective_bytes_per_launch"] >= n * m * 8
+    assert st["objective_launches"] == 4 and st["objective_bytes_per_launch"] >= n * m * 8
 
 
 def test_fit_pipeline_full(ctx):
