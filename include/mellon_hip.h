@@ -126,6 +126,11 @@ int mln_trsm_lower(mln_ctx* ctx, const double* Lf, int64_t m, int32_t trans, dou
 int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                     int32_t d, const double* xu, int64_t m, double jitter, const double* Lp_in,
                     mln_fit** out);
+/* Adopt factors computed elsewhere (the estimator's `L=` / `Lp=` ctor arguments,
+ * density_estimator.py:180-205): L is n_local x m; Lp (m x m) may be NULL, in which case the
+ * predictor-weight entries are unavailable on this handle.                                      */
+int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, int64_t m, const double* Lp,
+                   mln_fit** out);
 void mln_fit_destroy(mln_fit* fit);
 int mln_fit_get_Lp(mln_fit* fit, double* out /* m x m */);
 int mln_fit_get_L(mln_fit* fit, int64_t row0, int64_t n_rows, double* out /* n_rows x m */);
@@ -146,8 +151,8 @@ int mln_fit_set_likelihood(mln_fit* fit, const double* V, const double* Vdr, dou
 int mln_objective(mln_fit* fit, const double* z, double* loss, double* grad /* m */,
                   double* hess_diag /* m or NULL */);
 
-/* a-11: f = L z + mu on this shard (inference.py:341-354).                                     */
-int mln_transform(mln_fit* fit, const double* z, double* f_out /* n_local */);
+/* a-11: f = L z + mu on this shard (inference.py:51-69,341-354).                                */
+int mln_transform(mln_fit* fit, const double* z, double mu, double* f_out /* n_local */);
 
 /* a-12: predictor weights.
  *   sparse-Cholesky:  w = Lp^-T z                       conditional.py:818

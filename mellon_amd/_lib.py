@@ -58,6 +58,7 @@ SYMBOLS = [
     ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
     ("mln_trsm_lower", C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64]),
     ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, C.POINTER(_vp)]),
+    ("mln_fit_from_L", C.c_int, [_vp, _dp, _i64, _i64, _dp, C.POINTER(_vp)]),
     ("mln_fit_destroy", None, [_vp]),
     ("mln_fit_get_Lp", C.c_int, [_vp, _dp]),
     ("mln_fit_get_L", C.c_int, [_vp, _i64, _i64, _dp]),
@@ -65,7 +66,7 @@ SYMBOLS = [
     ("mln_ridge_init", C.c_int, [_vp, _dp, _dp]),
     ("mln_fit_set_likelihood", C.c_int, [_vp, _dp, _dp, _dbl]),
     ("mln_objective", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
-    ("mln_transform", C.c_int, [_vp, _dp, _dp]),
+    ("mln_transform", C.c_int, [_vp, _dp, _dbl, _dp]),
     ("mln_weights_cholesky", C.c_int, [_vp, _dp, _dp]),
     ("mln_weights_full", C.c_int, [_vp, _dp, _i64, _dbl, _dp]),
     ("mln_sparse_solve", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp]),
@@ -287,6 +288,23 @@ def _as2d(a):
 class Fit:
     """Device-resident shard state of one estimator fit (mln_fit)."""
 
+    @classmethod
+    def from_L(cls, ctx, L, Lp=None):
+        """Adopt a precomputed factor (the estimator's `L=` ctor argument)."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self.handle = ctx, ctx.lib, None
+        L = L if isinstance(L, DeviceArray) else _as2d(L)
+        n, m = L.shape
+        Lp_ = None if Lp is None else _f64(Lp)
+        if Lp_ is not None and Lp_.shape != (m, m):
+            raise ValueError(f"Lp has shape {Lp_.shape}, expected {(m, m)}")
+        h = C.c_void_p()
+        ctx._check(self.lib.mln_fit_from_L(ctx.handle, _ptr(L), n, m, _ptr(Lp_), C.byref(h)))
+        self.handle = h.value
+        self.n, self.d, self.m, self.jitter = n, None, m, None
+        self._has_lp = Lp_ is not None
+        return self
+
     def __init__(self, ctx, desc, x, landmarks, jitter, Lp=None):
         self.ctx, self.lib, self.handle = ctx, ctx.lib, None
         x = x if isinstance(x, DeviceArray) else _as2d(x)
@@ -301,6 +319,7 @@ class Fit:
                                             _ptr(Lp_), C.byref(h)), jitter=jitter)
         self.handle = h.value
         self.n, self.d, self.m, self.jitter = n, d, m, jitter
+        self._has_lp = True
 
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
@@ -344,10 +363,10 @@ class Fit:
                                                _ptr(hess)))
         return (loss.value, grad, hess) if with_hess else (loss.value, grad)
 
-    def transform(self, z, out=None):
+    def transform(self, z, mu, out=None):
         z = _f64(z)
         ret = np.empty(self.n, dtype=np.float64) if out is None else out
-        self.ctx._check(self.lib.mln_transform(self.handle, z.ctypes.data, _ptr(ret)))
+        self.ctx._check(self.lib.mln_transform(self.handle, z.ctypes.data, float(mu), _ptr(ret)))
         return ret
 
     def weights_cholesky(self, z):

@@ -1,0 +1,194 @@
+"""BaseEstimator (mellon/base_model.py): constructor validation, the lazy `_prepare_attribute`
+pipeline and the optimiser switch.  Every attribute of the reference is kept and can be injected
+through the constructor; `Lp` / `L` are device-resident factors (decomposition.FactorLp/FactorL)."""
+import logging
+
+import numpy as np
+
+from . import _lib
+from .cov import Matern52
+from .decomposition import FactorL, FactorLp
+from .inference import (DEFAULT_INIT_LEARN_RATE, DEFAULT_JIT, DEFAULT_N_ITER, DEFAULT_OPTIMIZER,
+                        compute_laplace_std, minimize_adam, minimize_lbfgsb, run_advi)
+from .parameter_validation import validate_cov_func, validate_cov_func_curry, validate_params
+from .parameters import (DEFAULT_RANDOM_SEED, compute_cov_func, compute_gp_type, compute_landmarks,
+                         compute_ls, compute_n_landmarks, compute_nn_distances, compute_rank)
+from .util import DEFAULT_JITTER, GaussianProcessType, ensure_2d
+from .validation import (validate_array, validate_bool, validate_float, validate_float_or_int,
+                         validate_float_or_iterable_numerical, validate_nn_distances, validate_positive_float,
+                         validate_positive_int, validate_string)
+
+DEFAULT_COV_FUNC = Matern52
+RANK_FRACTION_THRESHOLD = 0.8
+SAMPLE_LANDMARK_RATIO = 10
+
+logger = logging.getLogger("mellon")
+
+
+class BaseEstimator:
+    """Base class of the estimators (reference base_model.py:56-446)."""
+
+    def __init__(self, cov_func_curry=DEFAULT_COV_FUNC, n_landmarks=None, rank=None, jitter=DEFAULT_JITTER,
+                 optimizer=DEFAULT_OPTIMIZER, n_iter=DEFAULT_N_ITER, init_learn_rate=DEFAULT_INIT_LEARN_RATE,
+                 landmarks=None, gp_type=None, nn_distances=None, d=None, mu=0, ls=None, ls_factor=1,
+                 cov_func=None, Lp=None, L=None, initial_value=None, predictor_with_uncertainty=False,
+                 jit=DEFAULT_JIT, check_rank=None, random_state=DEFAULT_RANDOM_SEED):
+        self.cov_func_curry = validate_cov_func_curry(cov_func_curry, cov_func, "cov_func_curry")
+        self.n_landmarks = validate_positive_int(n_landmarks, "n_landmarks", optional=True)
+        self.random_state = validate_positive_int(random_state, "random_state", optional=True)
+        self.rank = validate_float_or_int(rank, "rank", optional=True)
+        self.jitter = validate_positive_float(jitter, "jitter")
+        self.landmarks = validate_array(landmarks, "landmarks", optional=True)
+        self.gp_type = GaussianProcessType.from_string(gp_type, optional=True)
+        self.nn_distances = validate_nn_distances(validate_array(nn_distances, "nn_distances", optional=True),
+                                                  optional=True)
+        self.mu = validate_float(mu, "mu", optional=True)
+        self.ls = validate_positive_float(ls, "ls", optional=True)
+        self.ls_factor = validate_positive_float(ls_factor, "ls_factor")
+        self.cov_func = validate_cov_func(cov_func, "cov_func", optional=True)
+        self.Lp = Lp if isinstance(Lp, FactorLp) else validate_array(Lp, "Lp", optional=True)
+        self.L = L if isinstance(L, (FactorL, FactorLp)) else validate_array(L, "L", optional=True)
+        self.d = validate_float_or_iterable_numerical(d, "d", optional=True, positive=True)
+        self.initial_value = validate_array(initial_value, "initial_value", optional=True)
+        self.optimizer = validate_string(optimizer, "optimizer", choices={"adam", "advi", "L-BFGS-B"})
+        self.n_iter = validate_positive_int(n_iter, "n_iter")
+        self.init_learn_rate = validate_positive_float(init_learn_rate, "init_learn_rate")
+        self.predictor_with_uncertainty = validate_bool(predictor_with_uncertainty, "predictor_with_uncertainty")
+        self.jit = validate_bool(jit, "jit")
+        self.check_rank = validate_bool(check_rank, "check_rank", optional=True)
+        self.x = None
+        self.pre_transformation = None
+        self.pre_transformation_std = None
+        self.lbfgsb_options = None      # overrides of inference.LBFGSB_OPTIONS
+        self._fit = None                # mln_fit handle holding Lp and L
+
+    def __str__(self):
+        return self.__repr__()
+
+    def __repr__(self):
+        def s(v):
+            if v is None:
+                return "None"
+            return f"<array {tuple(v.shape)}>" if hasattr(v, "shape") else str(v)
+        keys = ("n_landmarks", "rank", "gp_type", "jitter", "d", "mu", "ls", "cov_func", "landmarks", "Lp", "L",
+                "nn_distances", "initial_value", "optimizer")
+        return self.__class__.__name__ + "(" + ", ".join(f"{k}={s(getattr(self, k, None))}" for k in keys) + ")"
+
+    def __call__(self, x=None):
+        return self.fit_predict(x=x)
+
+    # -- x -------------------------------------------------------------------------------------------
+    def set_x(self, x):
+        """reference base_model.py:176-213 (identity check: a second, different x raises)."""
+        if self.x is not None and x is not None and self.x is not x:
+            raise ValueError("self.x has been set already, but is not equal to the argument x.")
+        if self.x is None and x is None:
+            raise ValueError("Required argument x is missing and self.x has not been set.")
+        if x is None:
+            x = self.x
+        self.x = ensure_2d(validate_array(x, "x"))
+        return self.x
+
+    # -- lazy attribute pipeline ---------------------------------------------------------------------
+    def _prepare_attribute(self, attribute):
+        """reference base_model.py:433-446."""
+        if getattr(self, attribute) is not None:
+            return
+        setattr(self, attribute, getattr(self, "_compute_" + attribute)())
+
+    def _compute_n_landmarks(self):
+        return compute_n_landmarks(self.gp_type, self.x.shape[0], self.landmarks)
+
+    def _compute_rank(self):
+        return compute_rank(self.gp_type)
+
+    def _compute_gp_type(self):
+        return compute_gp_type(self.n_landmarks, self.rank, self.x.shape[0])
+
+    def _seed(self):
+        return self.random_state if self.random_state is not None else DEFAULT_RANDOM_SEED
+
+    def _compute_landmarks(self):
+        n = self.x.shape[0]
+        if n > 100 * self.n_landmarks and n > 1e6:
+            logger.info(f"Large number of {n:,} cells and small number of {self.n_landmarks:,} landmarks. Consider "
+                        "computing k-means on a subset of cells and passing the results as 'landmarks'.")
+        return compute_landmarks(self.x, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed())
+
+    def _compute_nn_distances(self):
+        logger.info("Computing nearest neighbor distances.")
+        return validate_nn_distances(compute_nn_distances(self.x, seed=self._seed()))
+
+    def _compute_ls(self):
+        return compute_ls(self.nn_distances) * self.ls_factor
+
+    def _compute_cov_func(self):
+        cov_func = compute_cov_func(self.cov_func_curry, self.ls)
+        logger.info("Using covariance function %s.", str(cov_func))
+        return cov_func
+
+    def _unsupported_gp_type(self):
+        if self.gp_type in (GaussianProcessType.FULL_NYSTROEM, GaussianProcessType.SPARSE_NYSTROEM):
+            raise NotImplementedError(
+                f"gp_type={self.gp_type}: Nystroem rank reduction is outside the accelerated path of this "
+                "build (SURVEY.md S8f rank 4); use 'full' or 'sparse_cholesky'.")
+
+    def _device_fit(self):
+        """One mln_fit handle computes Lp AND L (parameters.compute_Lp + compute_L of the reference)."""
+        if self._fit is not None:
+            return self._fit
+        self._unsupported_gp_type()
+        ctx = _lib.default_context()
+        given_L = self.L if not isinstance(self.L, (FactorL, FactorLp)) else None
+        if isinstance(self.L, (FactorL, FactorLp)):
+            self._fit = self.L.fit
+        elif given_L is not None:
+            Lp = None if self.Lp is None else np.asarray(self.Lp, dtype=np.float64)
+            if Lp is None and self.gp_type == GaussianProcessType.FULL:
+                Lp = np.asarray(given_L, dtype=np.float64)
+            self._fit = _lib.Fit.from_L(ctx, np.asarray(given_L, dtype=np.float64), Lp=Lp)
+        else:
+            Lp = None if self.Lp is None else np.asarray(self.Lp, dtype=np.float64)
+            full = self.gp_type == GaussianProcessType.FULL or self.landmarks is None
+            logger.info("Computing Lp.")
+            self._fit = ctx.fit_prepare(self.cov_func.lower(self.x.shape[1]), np.ascontiguousarray(self.x),
+                                        None if full else self.landmarks, self.jitter, Lp=Lp)
+        return self._fit
+
+    def _compute_Lp(self):
+        fit = self._device_fit()
+        return FactorLp(fit) if getattr(fit, "_has_lp", True) else None
+
+    def _compute_L(self):
+        fit = self._device_fit()
+        n_samples = self.x.shape[0]
+        n_landmarks = n_samples if self.landmarks is None else self.landmarks.shape[0]
+        if (self.check_rank is None and self.gp_type == GaussianProcessType.SPARSE_CHOLESKY
+                and SAMPLE_LANDMARK_RATIO * n_landmarks < n_samples) or self.check_rank:
+            logger.info("Rank diagnostic (numpy.linalg.matrix_rank of L, log only in the reference, "
+                        "base_model.py:344-355) is skipped: it does not affect any result.")
+        logger.info(f"Using rank {fit.m:,} covariance representation.")
+        return FactorLp(fit) if self.gp_type == GaussianProcessType.FULL and fit.m == fit.n and \
+            getattr(fit, "_has_lp", True) else FactorL(fit)
+
+    def validate_parameter(self):
+        validate_params(self.rank, self.gp_type, self.x.shape[0], self.n_landmarks, self.landmarks)
+
+    # -- optimiser switch (reference base_model.py:371-431) ----------------------------------------------
+    def _run_inference(self):
+        logger.info("Running inference using %s.", self.optimizer)
+        if self.optimizer == "adam":
+            minimize_adam()
+        elif self.optimizer == "advi":
+            run_advi()
+        elif self.optimizer == "L-BFGS-B":
+            results = minimize_lbfgsb(self.loss_func, self.initial_value, jit=self.jit, options=self.lbfgsb_options)
+            self.pre_transformation = results.pre_transformation
+            self.pre_transformation_std = None
+            self.opt_state = results.opt_state
+            self.losses = [results.loss]
+        else:
+            raise ValueError(f"Unknown optimizer {self.optimizer}.")
+        if self.optimizer != "advi" and self.predictor_with_uncertainty and self.pre_transformation_std is None:
+            logger.info("Computing Laplace approximation for posterior uncertainty.")
+            self.pre_transformation_std = compute_laplace_std(self.loss_func, self.pre_transformation, jit=self.jit)

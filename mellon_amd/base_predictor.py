@@ -1,0 +1,188 @@
+"""Predictor API (mellon/base_predictor.py): `mean` / `__call__` on the device, plus the
+reference's JSON wire format for the predictor state (base_predictor.py:541-734) so that
+predictors fitted here load in upstream Mellon and vice versa.  Covariance / gradient /
+uncertainty methods are outside the accelerated path and raise."""
+import bz2
+import gzip
+import json
+import logging
+import sys
+from datetime import datetime
+from importlib import import_module
+from math import log
+
+import numpy as np
+
+from . import _lib
+from .base_cov import Covariance
+from .util import deserialize, ensure_2d, make_serializable
+from .validation import validate_array, validate_bool, validate_time_x
+
+logger = logging.getLogger("mellon")
+_REF_MODULE = "mellon.conditional"
+
+
+class Predictor:
+    """Mean function of a conditioned GP: mean(x) = mu + K(x, centers) @ weights."""
+
+    n_obs = None
+    d = None
+    d_method = None
+    _center_name = "landmarks"
+
+    def __init__(self, cov_func, centers, weights, mu, n_obs=None, jitter=None, sigma=None):
+        self.cov_func = cov_func
+        setattr(self, self._center_name, np.ascontiguousarray(ensure_2d(centers), dtype=np.float64))
+        self.weights = np.ascontiguousarray(weights, dtype=np.float64)
+        self.mu = float(mu)
+        self.jitter = jitter
+        self.sigma = sigma
+        self.per_feature_sigma = False
+        self.n_input_features = getattr(self, self._center_name).shape[1]
+        self.n_obs = n_obs
+        self._state_variables = {self._center_name, "weights", "mu", "jitter", "sigma", "per_feature_sigma"}
+
+    @property
+    def centers(self):
+        return getattr(self, self._center_name)
+
+    def __repr__(self):
+        return (f'A predictor of class "{self.__class__.__name__}" with covariance function '
+                f'"{self.cov_func}" and data:\n' +
+                "\n".join(f"    {k}: {np.shape(getattr(self, k))}" for k in sorted(self._state_variables)))
+
+    # -- evaluation (conditional.py:366-373,651-658,899-906 through base_predictor.py:180-257) ------
+    def _mean(self, Xnew):
+        ctx = _lib.default_context()
+        return ctx.predict_mean(self.cov_func.lower(self.n_input_features), Xnew, self.centers,
+                                self.weights, self.mu)
+
+    def mean(self, x, normalize=False):
+        x = validate_array(x, "x")
+        if not isinstance(x, _lib.DeviceArray):
+            x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+        normalize = validate_bool(normalize, "normalize")
+        if x.shape[1] != self.n_input_features:
+            raise ValueError(
+                f"The predictor was trained on data with {self.n_input_features} features. "
+                f"However, the provided input data has {x.shape[1]} features. "
+                "Please ensure that the input data has the same number of features as the training data.")
+        if normalize:
+            if self.n_obs is None or self.n_obs == 0:
+                raise ValueError("Cannot normalize without n_obs. Please set self.n_obs to the number "
+                                 "of samples/cells trained on to enable normalization.")
+            return self._mean(x) - log(self.n_obs)
+        return self._mean(x)
+
+    __call__ = mean
+
+    def _unavailable(self, *a, **k):
+        raise NotImplementedError("Only the predictive mean is part of the accelerated path "
+                                  "(covariance / uncertainty / gradients: SURVEY.md S8f).")
+
+    covariance = mean_covariance = uncertainty = gradient = hessian = leverage = obs_variance = _unavailable
+
+    # -- serialization --------------------------------------------------------------------------------
+    def _data_dict(self):
+        return {k: getattr(self, k) for k in self._state_variables}
+
+    def __getstate__(self):
+        from . import __version__
+        data = self._data_dict()
+        data.update({"n_input_features": self.n_input_features, "n_obs": self.n_obs, "d": self.d,
+                     "d_method": self.d_method, "_state_variables": self._state_variables})
+        return {
+            "data": {k: make_serializable(v) for k, v in data.items()},
+            "cov_func": self.cov_func.__getstate__(),
+            "metadata": {"classname": self.__class__.__name__, "module_name": _REF_MODULE,
+                         "module_version": __version__, "serialization_date": datetime.now().isoformat(),
+                         "python_version": sys.version},
+        }
+
+    def __setstate__(self, state):
+        for name, value in state["data"].items():
+            setattr(self, name, deserialize(value))
+        self._state_variables = set(self._state_variables)
+        self.cov_func = Covariance.from_dict(state["cov_func"])
+        for k in (self._center_name, "weights"):
+            setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=np.float64))
+
+    def copy(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__setstate__(self.__getstate__())
+        return new
+
+    def to_dict(self):
+        return self.__getstate__()
+
+    def to_json(self, filename=None, compress=None):
+        json_str = json.dumps(self.to_dict())
+        if filename is None:
+            return json_str
+        if compress == "gzip":
+            filename = filename if str(filename).endswith(".gz") else str(filename) + ".gz"
+            with gzip.open(filename, "wt") as f:
+                f.write(json_str)
+        elif compress == "bz2":
+            filename = filename if str(filename).endswith(".bz2") else str(filename) + ".bz2"
+            with bz2.open(filename, "wt") as f:
+                f.write(json_str)
+        elif compress is None:
+            with open(filename, "w") as f:
+                f.write(json_str)
+        else:
+            raise ValueError(f'Unknown compression format {compress}.\nAvailabe formats are "gzip", "bz2" and None.')
+        logger.info(f"Written predictor to {filename}.")
+
+    @classmethod
+    def from_dict(cls, data_dict):
+        clsname = data_dict["metadata"]["classname"]
+        from . import conditional
+        Sub = getattr(conditional, clsname, None)
+        if Sub is None:
+            Sub = getattr(import_module(data_dict["metadata"]["module_name"]), clsname)
+        inst = Sub.__new__(Sub)
+        inst.__setstate__(data_dict)
+        return inst
+
+    @classmethod
+    def from_json_str(cls, json_str):
+        return cls.from_dict(json.loads(json_str))
+
+    @classmethod
+    def from_json(cls, filepath, compress=None):
+        filename = str(filepath)
+        if compress == "gzip" or filename.endswith(".gz"):
+            opener = gzip.open
+        elif compress == "bz2" or filename.endswith(".bz2"):
+            opener = bz2.open
+        else:
+            opener = open
+        with opener(filepath, "rt") as f:
+            return cls.from_json_str(f.read())
+
+
+class ExpPredictor(Predictor):
+    """exp of the mean (reference base_predictor.py ExpPredictor)."""
+
+    def mean(self, x, normalize=False):
+        return np.exp(super().mean(x, normalize=normalize))
+
+    __call__ = mean
+
+
+class PredictorTime(Predictor):
+    """Predictor whose last input column is time (reference base_predictor.py:872-948)."""
+
+    def mean(self, Xnew, time=None, normalize=False, multi_time=None):
+        if multi_time is not None:
+            if time is not None:
+                raise ValueError("Specify either `time` or `multi_time`, not both.")
+            times = np.asarray(multi_time, dtype=np.float64).reshape(-1)
+            return np.stack([self.mean(Xnew, time=t, normalize=normalize) for t in times], axis=1)
+        Xnew = validate_array(Xnew, "Xnew")
+        Xnew = np.ascontiguousarray(ensure_2d(Xnew), dtype=np.float64)
+        x = validate_time_x(Xnew, time, n_features=self.n_input_features, cast_scalar=True)
+        return super().mean(np.ascontiguousarray(x), normalize=normalize)
+
+    __call__ = mean

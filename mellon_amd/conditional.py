@@ -1,0 +1,141 @@
+"""Predictor builders (mellon/conditional.py): the weight solves run on the device.
+
+  FullConditional               weights = L^-T L^-1 (y - mu),  L = chol(K(x,x) + s I)     :183-264
+  LandmarksConditional          `_sparse_solve` with A = Lp^-1 K(xu, x)                    :455-547, :57-66
+  LandmarksConditionalCholesky  weights = Lp^-T z                                          :750-818
+Only scalar sigma is supported (per-feature sigma, covariance, leverage, obs_variance: S8f).
+"""
+import logging
+
+import numpy as np
+
+from . import _lib
+from .base_predictor import ExpPredictor, Predictor, PredictorTime
+from .decomposition import FactorL, FactorLp
+from .util import DEFAULT_JITTER, ensure_2d
+
+DEFAULT_SIGMA = 0
+logger = logging.getLogger("mellon")
+
+
+def _scalar_sigma(sigma):
+    if sigma is None:
+        return None
+    s = np.asarray(sigma, dtype=np.float64)
+    if s.ndim != 0:
+        raise NotImplementedError("Only scalar sigma is supported by the accelerated predictors "
+                                  "(per-feature / per-observation sigma: SURVEY.md S8f).")
+    return float(s)
+
+
+def _reject_extras(with_uncertainty, obs_variance):
+    if with_uncertainty or obs_variance:
+        raise NotImplementedError("with_uncertainty / obs_variance are outside the accelerated path (SURVEY.md S8f).")
+
+
+class _FullConditional:
+    _center_name = "x"
+
+    def __init__(self, x, y, mu, cov_func, L=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER, y_cov_factor=None,
+                 y_is_mean=False, with_uncertainty=False, obs_variance=False):
+        _reject_extras(with_uncertainty, obs_variance)
+        x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+        ctx = _lib.default_context()
+        if isinstance(L, (FactorLp, FactorL)) and L.fit.m == x.shape[0] and L.fit.handle is not None \
+                and getattr(L.fit, "_has_lp", True):
+            fit = L.fit
+        elif L is not None:
+            Lh = np.asarray(L, dtype=np.float64)
+            fit = _lib.Fit.from_L(ctx, Lh, Lp=Lh)
+        else:
+            logger.info("Recomputing covariance decomposition for predictive function.")
+            if y_is_mean:
+                diag = jitter                                            # _get_L(x, cov, jitter)
+            else:
+                s = _scalar_sigma(sigma)
+                if s is None and y_cov_factor is None:
+                    raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
+                                     "`pre_transformation_std` to quantify uncertainty of the prediction.")
+                if y_cov_factor is not None:
+                    raise NotImplementedError("y_cov_factor is outside the accelerated path.")
+                diag = max(s * s, jitter)                                # add_variance, util.py:296-331
+            fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
+        weights = fit.weights_full(np.asarray(y, dtype=np.float64), mu)  # conditional.py:263-264
+        Predictor.__init__(self, cov_func, x, weights, mu, n_obs=x.shape[0], jitter=jitter, sigma=sigma)
+
+
+class _LandmarksConditional:
+    _center_name = "landmarks"
+
+    def __init__(self, x, xu, y, mu, cov_func, L=None, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
+                 y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False):
+        _reject_extras(with_uncertainty, obs_variance)
+        if y_is_mean:
+            raise NotImplementedError("LandmarksConditional with y_is_mean=True is outside the accelerated path.")
+        s = _scalar_sigma(sigma)
+        if s is None or not s > 0:
+            raise ValueError("sigma must be a positive scalar for the landmark conditional "
+                             "(the reference divides by sigma^2, conditional.py:157-159).")
+        xh = x if isinstance(x, _lib.DeviceArray) else np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+        xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
+        weights = _lib.default_context().sparse_solve(cov_func.lower(xu.shape[1]), xh, xu,
+                                                      np.asarray(y, dtype=np.float64), mu, s, jitter)
+        Predictor.__init__(self, cov_func, xu, weights, mu, n_obs=xh.shape[0], jitter=jitter, sigma=sigma)
+
+
+class _LandmarksConditionalCholesky:
+    _center_name = "landmarks"
+
+    def __init__(self, xu, pre_transformation, mu, cov_func, n_obs, L=None, sigma=DEFAULT_SIGMA,
+                 jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False, obs_variance=False,
+                 obs_x=None, obs_y=None):
+        _reject_extras(with_uncertainty, obs_variance)
+        xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
+        z = np.asarray(pre_transformation, dtype=np.float64)
+        if isinstance(L, (FactorLp, FactorL)) and L.fit.handle is not None:
+            weights = L.fit.weights_cholesky(z)                          # conditional.py:818
+        else:
+            ctx = _lib.default_context()
+            if L is None:
+                logger.info("Recomputing covariance decomposition for predictive function.")
+                Lh = ctx.chol_lower(cov_func(xu, xu), add_diag=jitter, jitter=jitter)
+            else:
+                Lh = np.asarray(L, dtype=np.float64)
+            weights = ctx.trsm_lower(Lh, z, trans=True)
+        Predictor.__init__(self, cov_func, xu, weights, mu, n_obs=n_obs, jitter=jitter, sigma=sigma)
+
+
+class FullConditional(_FullConditional, Predictor):
+    pass
+
+
+class ExpFullConditional(_FullConditional, ExpPredictor):
+    pass
+
+
+class FullConditionalTime(_FullConditional, PredictorTime):
+    pass
+
+
+class LandmarksConditional(_LandmarksConditional, Predictor):
+    pass
+
+
+class ExpLandmarksConditional(_LandmarksConditional, ExpPredictor):
+    pass
+
+
+class LandmarksConditionalTime(_LandmarksConditional, PredictorTime):
+    pass
+
+
+class LandmarksConditionalCholesky(_LandmarksConditionalCholesky, Predictor):
+    pass
+
+
+class ExpLandmarksConditionalCholesky(_LandmarksConditionalCholesky, ExpPredictor):
+    pass
+
+
+class LandmarksConditionalCholeskyTime(_LandmarksConditionalCholesky, PredictorTime):
+    pass

@@ -486,6 +486,41 @@ extern "C" int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const d
   return MLN_OK;
 }
 
+extern "C" int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, int64_t m, const double* Lp,
+                              mln_fit** out) {
+  if (!ctx || !out || !L) return MLN_ERR_ARG;
+  *out = nullptr;
+  if (n_local < 1 || m < 1 || m > 65535) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (m > objective_max_m()) { mln_set_error(ctx, "m > 8192 columns is not supported by this build"); return MLN_ERR_UNSUPPORTED; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  mln_fit* f = new mln_fit();
+  f->ctx = ctx; f->n = n_local; f->m = m; f->d = 0; f->full = false;
+  f->ldl = pad16(m); f->ldp = pad16(m);
+  auto body = [&]() -> int {
+    DevIn dl;
+    MLN_TRY(dl.init(ctx, L, (size_t)n_local * m));
+    const size_t l_bytes = sizeof(double) * (size_t)n_local * f->ldl;
+    MLN_HIP(ctx, hipMalloc((void**)&f->L, l_bytes));
+    MLN_HIP(ctx, hipMemsetAsync(f->L, 0, l_bytes, ctx->stream));
+    MLN_TRY(launch_copy_block(ctx, dl.dev, m, f->L, f->ldl, n_local, m));
+    if (Lp) {
+      DevIn dp;
+      MLN_TRY(dp.init(ctx, Lp, (size_t)m * m));
+      const size_t lp_bytes = sizeof(double) * (size_t)m * f->ldp;
+      MLN_HIP(ctx, hipMalloc((void**)&f->Lp, lp_bytes));
+      MLN_HIP(ctx, hipMemsetAsync(f->Lp, 0, lp_bytes, ctx->stream));
+      MLN_TRY(launch_copy_block(ctx, dp.dev, m, f->Lp, f->ldp, m, m));
+      MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
+    }
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return fit_alloc_workspace(f);
+  };
+  int rc = body();
+  if (rc != MLN_OK) { fit_free(f); return rc; }
+  *out = f;
+  return MLN_OK;
+}
+
 extern "C" int mln_fit_rank(mln_fit* fit, int64_t* m_out) {
   if (!fit || !m_out) return MLN_ERR_ARG;
   *m_out = fit->m;
@@ -495,6 +530,7 @@ extern "C" int mln_fit_rank(mln_fit* fit, int64_t* m_out) {
 extern "C" int mln_fit_get_Lp(mln_fit* f, double* out) {
   if (!f || !out) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
+  if (!f->Lp) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevOut o;
   MLN_TRY(o.init(ctx, out, (size_t)f->m * f->m));
@@ -587,7 +623,7 @@ extern "C" int mln_objective(mln_fit* f, const double* z, double* loss, double* 
   return MLN_OK;
 }
 
-extern "C" int mln_transform(mln_fit* f, const double* z, double* f_out) {
+extern "C" int mln_transform(mln_fit* f, const double* z, double mu, double* f_out) {
   if (!f || !z || (f->n > 0 && !f_out)) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
@@ -597,6 +633,7 @@ extern "C" int mln_transform(mln_fit* f, const double* z, double* f_out) {
   MLN_TRY(o.init(ctx, f_out, (size_t)f->n));
   ObjArgs a = obj_args(f);
   a.f_out = o.dev;
+  a.mu = mu;
   MLN_TRY(launch_objective(ctx, a));
   return o.commit();
 }
@@ -678,6 +715,7 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
 extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
   if (!f || !z || !w) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
+  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevOut o;
   MLN_TRY(o.init(ctx, w, (size_t)f->m));
@@ -689,6 +727,7 @@ extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
 extern "C" int mln_weights_full(mln_fit* f, const double* y, int64_t p, double mu, double* w) {
   if (!f || !y || !w || p < 1) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
+  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t cnt = f->m * p;
   DevOut o;

@@ -1,0 +1,231 @@
+"""Parameter heuristics and wiring (mellon/parameters.py).  Scalar heuristics are host NumPy
+(O(n)); Lp / L / initial_value run on the device through libmellon_hip.so."""
+import logging
+
+import numpy as np
+
+from . import _lib
+from .decomposition import (DEFAULT_RANK, FactorL, FactorLp, _full_decomposition_low_rank, _full_rank,
+                            _modified_low_rank, _standard_low_rank)
+from .util import DEFAULT_JITTER, GaussianProcessType, ensure_2d, mle
+from .validation import (validate_array, validate_float_or_int, validate_k, validate_positive_float,
+                         validate_positive_int, validate_time_x)
+
+DEFAULT_N_LANDMARKS = 5000     # reference parameters.py:53
+DEFAULT_RANDOM_SEED = 42       # reference parameters.py:54
+DEFAULT_SIGMA = 0
+
+logger = logging.getLogger("mellon")
+
+
+def compute_rank(gp_type):
+    """reference parameters.py:88-115."""
+    if gp_type in (GaussianProcessType.FULL_NYSTROEM, GaussianProcessType.SPARSE_NYSTROEM):
+        return DEFAULT_RANK
+    return 1.0
+
+
+def compute_n_landmarks(gp_type, n_samples, landmarks):
+    """reference parameters.py:118-172."""
+    if landmarks is not None:
+        return landmarks.shape[0]
+    if gp_type is None or gp_type == GaussianProcessType.FIXED:
+        return min(n_samples, DEFAULT_N_LANDMARKS)
+    if gp_type in (GaussianProcessType.FULL, GaussianProcessType.FULL_NYSTROEM):
+        return n_samples
+    if gp_type in (GaussianProcessType.SPARSE_CHOLESKY, GaussianProcessType.SPARSE_NYSTROEM):
+        if n_samples <= DEFAULT_N_LANDMARKS:
+            logger.warning(
+                f"Gaussian Process type {gp_type} and default number of landmarks {DEFAULT_N_LANDMARKS:,} "
+                f"< number of cells {n_samples:,}. Reduce n_landmarks below the number of cells to use {gp_type}.")
+        return DEFAULT_N_LANDMARKS
+    n_landmarks = min(n_samples, DEFAULT_N_LANDMARKS)
+    logger.warning(f"Unknown Gaussian Process type {gp_type}, using default n_landmarks={n_landmarks:,}.")
+    return n_landmarks
+
+
+def _indicates_full_rank(rank, bound):
+    return (rank is None or (isinstance(rank, int) and rank >= bound)
+            or (isinstance(rank, float) and rank >= 1.0) or rank == 0)
+
+
+def compute_gp_type(n_landmarks, rank, n_samples):
+    """reference parameters.py:175-240 (decision table pinned by its tests/test_parameters.py:271-290)."""
+    rank = validate_float_or_int(rank, "rank", optional=True)
+    n_landmarks = validate_positive_int(n_landmarks, "n_landmarks")
+    n_samples = validate_positive_int(n_samples, "n_samples")
+    if n_landmarks == 0 or n_landmarks >= n_samples:
+        if _indicates_full_rank(rank, n_samples):
+            logger.info(f"Using non-sparse Gaussian Process since n_landmarks ({n_landmarks:,}) >= "
+                        f"n_samples ({n_samples:,}) and rank = {rank}.")
+            return GaussianProcessType.FULL
+        return GaussianProcessType.FULL_NYSTROEM
+    if _indicates_full_rank(rank, n_landmarks):
+        logger.info(f"Using sparse Gaussian Process since n_landmarks ({n_landmarks:,}) < "
+                    f"n_samples ({n_samples:,}) and rank = {rank}.")
+        return GaussianProcessType.SPARSE_CHOLESKY
+    return GaussianProcessType.SPARSE_NYSTROEM
+
+
+def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_state=DEFAULT_RANDOM_SEED):
+    """k-means centroids (reference parameters.py:243-291; sklearn, third party on both sides)."""
+    if n_landmarks == 0:
+        return None
+    x = ensure_2d(x)
+    n = x.shape[0]
+    assert n_landmarks > 1, "n_landmarks musst be larger 1 or euqual to 0"
+    if n_landmarks >= n:
+        if gp_type == GaussianProcessType.FIXED:
+            logger.info(f"Using all {n:,} datapoints as landmarks.")
+            return x
+        return None
+    from sklearn.cluster import k_means
+    logger.info(f"Computing {n_landmarks:,} landmarks with k-means clustering (random_state={random_state}).")
+    return k_means(x, n_landmarks, n_init=1, random_state=random_state)[0]
+
+
+def compute_landmarks_rescale_time(x, ls, ls_time, times=None, n_landmarks=DEFAULT_N_LANDMARKS,
+                                   random_state=DEFAULT_RANDOM_SEED):
+    """reference parameters.py:294-349: k-means with the time column rescaled by ls / ls_time."""
+    if n_landmarks == 0:
+        return None
+    ls = validate_positive_float(ls, "ls")
+    ls_time = validate_positive_float(ls_time, "ls_time")
+    x = np.array(validate_time_x(x, times), dtype=np.float64)
+    factor = ls / ls_time
+    x[:, -1] *= factor
+    landmarks = compute_landmarks(x, n_landmarks=n_landmarks, random_state=random_state)
+    if landmarks is not None:
+        landmarks = np.array(landmarks)
+        landmarks[:, -1] /= factor
+    return landmarks
+
+
+def compute_distances(x, k, seed=DEFAULT_RANDOM_SEED):
+    """Distances to the k nearest neighbours.  The reference uses pynndescent (approximate,
+    parameters.py:352-405); this is the exact Euclidean answer from a space-partitioning tree."""
+    x = ensure_2d(validate_array(x, "x"))
+    n = x.shape[0]
+    if n == 0:
+        raise ValueError("Input data x is empty.")
+    validate_k(k, n)
+    from sklearn.neighbors import BallTree, KDTree
+    tree = (KDTree if x.shape[1] <= 20 else BallTree)(x)
+    dist, _ = tree.query(x, k=k + 1)
+    return dist[:, 1:]
+
+
+def compute_nn_distances(x, seed=DEFAULT_RANDOM_SEED):
+    """reference parameters.py:408-433."""
+    return compute_distances(x, 1, seed=seed)[:, 0]
+
+
+def compute_nn_distances_within_time_points(x, times=None, d=None, normalize=False):
+    """reference parameters.py:444-531."""
+    x = validate_time_x(x, times)
+    unique_times = np.unique(x[:, -1])
+    nn = np.empty(x.shape[0])
+    n_cells = x.shape[0]
+    av = n_cells / len(unique_times)
+    for t in unique_times:
+        mask = x[:, -1] == t
+        n_t = int(mask.sum())
+        if n_t < 2:
+            raise ValueError(
+                f"Insufficient data: Only {n_t} sample(s) found at time point {t}. "
+                "Nearest neighbors cannot be computed with less than two samples per time point.")
+        nn_t = compute_nn_distances(x[mask, :-1])
+        if normalize is not False and normalize is not None:
+            target = av if isinstance(normalize, bool) else normalize[float(t)]
+            dd = np.asarray(d, dtype=np.float64)
+            nn_t = (n_t / target) ** (1 / dd if dd.ndim == 0 else 1 / dd[mask]) * nn_t
+        nn[mask] = nn_t
+    return nn
+
+
+def compute_d(x):
+    """reference parameters.py:534-549: the embedding dimensionality."""
+    x = np.asarray(x) if not isinstance(x, _lib.DeviceArray) else x
+    return 1 if len(x.shape) < 2 else x.shape[1]
+
+
+def compute_mu(nn_distances, d):
+    """reference parameters.py:586-599 (1st percentile, linear interpolation, minus 10)."""
+    return float(np.quantile(mle(nn_distances, d), 0.01)) - 10
+
+
+def compute_ls(nn_distances):
+    """reference parameters.py:602-613."""
+    return float(np.exp(np.log(nn_distances).mean() + 3.0))
+
+
+def compute_cov_func(cov_func_curry, ls, ls_time=None):
+    """reference parameters.py:616-645."""
+    if ls_time is not None:
+        return cov_func_curry(ls=ls, active_dims=slice(None, -1)) * cov_func_curry(ls=ls_time, active_dims=-1)
+    return cov_func_curry(ls=ls)
+
+
+def compute_average_cell_count(x, normalize):
+    """reference parameters.py:927-969."""
+    n_times = np.unique(x[:, -1]).shape[0]
+    if normalize is None or isinstance(normalize, bool):
+        return x.shape[0] / n_times
+    if isinstance(normalize, dict):
+        return sum(normalize.values()) / n_times
+    if isinstance(normalize, (list, np.ndarray)):
+        return float(np.sum(np.asarray(normalize)) / len(normalize))
+    raise ValueError(f"Unrecognized type for 'normalize': {type(normalize)}")
+
+
+def compute_Lp(x, cov_func, gp_type=None, landmarks=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER):
+    """reference parameters.py:648-714.  Returns a device-resident FactorLp (or None for Nystroem)."""
+    n_samples = x.shape[0]
+    n_landmarks = n_samples if landmarks is None else ensure_2d(landmarks).shape[0]
+    gp_type = GaussianProcessType.from_string(gp_type, optional=True)
+    if gp_type is None:
+        gp_type = compute_gp_type(n_landmarks, 1.0, n_samples)
+    if gp_type in (GaussianProcessType.FULL_NYSTROEM, GaussianProcessType.SPARSE_NYSTROEM):
+        return None
+    if gp_type == GaussianProcessType.FULL:
+        logger.info("Computing Lp.")
+        return _full_rank(x, cov_func, sigma=sigma, jitter=jitter)
+    if gp_type in (GaussianProcessType.SPARSE_CHOLESKY, GaussianProcessType.FIXED):
+        return _full_rank(landmarks, cov_func, sigma=sigma, jitter=jitter)
+    raise ValueError(f"Unknown Gaussian Process type {gp_type}.")
+
+
+def compute_L(x, cov_func, gp_type=None, landmarks=None, Lp=None, rank=None, sigma=DEFAULT_SIGMA,
+              jitter=DEFAULT_JITTER):
+    """reference parameters.py:783-874.  Returns a device-resident factor."""
+    n_samples = x.shape[0]
+    n_landmarks = n_samples if landmarks is None else ensure_2d(landmarks).shape[0]
+    gp_type = GaussianProcessType.from_string(gp_type, optional=True)
+    if gp_type is None:
+        gp_type = compute_gp_type(n_landmarks, rank, n_samples)
+    if Lp is not None and tuple(Lp.shape) != (n_landmarks, n_landmarks):
+        raise ValueError(f"Wrong shape of Lp {tuple(Lp.shape)}; expected {(n_landmarks, n_landmarks)}.")
+    if gp_type == GaussianProcessType.FULL:
+        if Lp is None:
+            return _full_rank(x, cov_func, sigma=sigma, jitter=jitter)
+        return Lp                                           # parameters.py:847-850
+    if gp_type == GaussianProcessType.FULL_NYSTROEM:
+        return _full_decomposition_low_rank(x, cov_func, rank=rank, sigma=sigma, jitter=jitter)
+    if gp_type in (GaussianProcessType.SPARSE_CHOLESKY, GaussianProcessType.FIXED):
+        return _standard_low_rank(x, cov_func, landmarks, Lp=Lp, sigma=sigma, jitter=jitter)
+    if gp_type == GaussianProcessType.SPARSE_NYSTROEM:
+        return _modified_low_rank(x, cov_func, landmarks, rank=rank, sigma=sigma, jitter=jitter)
+    raise ValueError(f"Unknown Gaussian Process type {gp_type}.")
+
+
+def _fit_of(L):
+    if isinstance(L, (FactorL, FactorLp)):
+        return L.fit
+    return _lib.Fit.from_L(_lib.default_context(), np.asarray(L, dtype=np.float64))
+
+
+def compute_initial_value(nn_distances, d, mu, L):
+    """Ridge(alpha=1, fit_intercept=False) of mle - mu on L (reference parameters.py:877-896),
+    solved on the device: (L^T L + I)^-1 L^T t."""
+    target = mle(np.asarray(nn_distances, dtype=np.float64), d) - mu
+    return _fit_of(L).ridge_init(target)

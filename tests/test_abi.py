@@ -44,12 +44,14 @@ def test_no_cpu_fallback(lib):
 
 
 def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: no product file may import, load or execute it."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|import_module\(\s*[\"']oracle|oracle[/\\][\w_]+\.(py|so|c)", re.M)
     pkg = os.path.join(ROOT, "mellon_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src or f == "_build.py", f
+                assert not pat.search(src), f
 
 
 def test_covariance_lowering_and_json():

@@ -156,7 +156,7 @@ def test_fit_pipeline_sparse(ctx, n, d, m, kern):
         assert loss2 == loss and np.array_equal(grad2, grad)      # deterministic reductions
     # transform + predictor weights + fused predict (conditional.py:818, 899-906)
     z = z0_ref
-    f = fit.transform(z)
+    f = fit.transform(z, mu)
     assert relmax(f, L @ z + mu) < 1e-12
     w = fit.weights_cholesky(z)
     assert relmax(w, sla.solve_triangular(Lp_ref.T, z, lower=False)) < 1e-7
