@@ -91,6 +91,10 @@ int mln_synchronize(mln_ctx* ctx);
 int mln_malloc(mln_ctx* ctx, int64_t bytes, void** dev_ptr);
 int mln_free(mln_ctx* ctx, void* dev_ptr);
 int mln_memcpy(mln_ctx* ctx, void* dst, const void* src, int64_t bytes); /* any host/device mix */
+/* Internal buffers (the 8*n*m-byte factor, Gram partials, ...) are recycled by a caching
+ * allocator so that repeated fits do not pay hipMalloc / page-mapping again; this returns all
+ * cached blocks to the driver.                                                                */
+int mln_release_cached_memory(void);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------------------------------
  * Cells (rows of x) are sharded; landmarks, Lp and z are replicated.  Collectives: all-reduce
@@ -104,6 +108,13 @@ int mln_comm_allreduce_sum(mln_ctx* ctx, double* buf, int64_t count); /* host or
  * x: n x d, y: m x d, out: n x m.                                                              */
 int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n,
                       const double* y, int64_t m, int32_t d, double* out);
+
+/* ---- feeding the path (S8f rank 1): exact Euclidean nearest-neighbour distance of each row of x
+ * (n x d) among the rows of y (m x d), excluding the pair (i, i + self_offset) -- pass y = x and
+ * self_offset = 0 for the estimator's nn_distances (parameters.py:408-433; the reference's
+ * pynndescent search is approximate), or y = all cells and self_offset = shard start when sharded. */
+int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int32_t d,
+                     int64_t self_offset, double* out /* n */);
 
 /* ---- a-4/a-5: in-place lower Cholesky of (A + add_diag * I), A m x m symmetric (lower read).
  * decomposition.py:111-123 (`stabilize` util.py:269-293 + jnp.linalg.cholesky).  Strict upper
@@ -139,6 +150,18 @@ int mln_fit_rank(mln_fit* fit, int64_t* m_out); /* number of columns of L */
 /* a-9: Ridge initial value  z0 = (L^T L + I)^-1 L^T target   (parameters.py:877-896;
  * sklearn Ridge(alpha=1, fit_intercept=False)).  target: n_local.  All-reduced over ranks.     */
 int mln_ridge_init(mln_fit* fit, const double* target, double* z0 /* m */);
+
+/* Preconditioned MAP variable (no counterpart in the reference, which runs L-BFGS-B on z directly):
+ * with C C^T = L^T L + I -- the Ridge matrix above, which equals the MAP Hessian wherever
+ * exp(f + V) = 1 -- the substitution z = C^-T u makes the strictly convex objective well conditioned,
+ * so the same optimiser reaches the same unique optimum in ~10x fewer passes over L.
+ *   mln_precond_build      factor C and C^-1 (done implicitly by mln_ridge_init)
+ *   mln_precond_apply      mode 0: u = C^T z;  mode 1: z = C^-T u;  mode 2: g_u = C^-1 g_z   (host m-vectors)
+ *   mln_objective_precond  loss(C^-T u) and its gradient in u; optionally also z = C^-T u      */
+int mln_precond_build(mln_fit* fit);
+int mln_precond_apply(mln_fit* fit, int32_t mode, const double* in, double* out);
+int mln_objective_precond(mln_fit* fit, const double* u, double* loss, double* grad_u /* m */,
+                          double* z_out /* m or NULL */);
 
 /* a-7: nearest-neighbour likelihood constants of this shard (inference.py:83-85), computed by
  * the caller from nn_distances and d:  V = d log r + c,  Vdr = log d + (d-1) log r + c.        */

@@ -51,10 +51,12 @@ SYMBOLS = [
     ("mln_malloc", C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     ("mln_free", C.c_int, [_vp, _vp]),
     ("mln_memcpy", C.c_int, [_vp, _vp, _vp, _i64]),
+    ("mln_release_cached_memory", C.c_int, []),
     ("mln_comm_unique_id", C.c_int, [_vp]),
     ("mln_comm_init", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     ("mln_comm_allreduce_sum", C.c_int, [_vp, _dp, _i64]),
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
+    ("mln_nn_distances", C.c_int, [_vp, _dp, _i64, _dp, _i64, _i32, _i64, _dp]),
     ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
     ("mln_trsm_lower", C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64]),
     ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, C.POINTER(_vp)]),
@@ -64,6 +66,9 @@ SYMBOLS = [
     ("mln_fit_get_L", C.c_int, [_vp, _i64, _i64, _dp]),
     ("mln_fit_rank", C.c_int, [_vp, C.POINTER(_i64)]),
     ("mln_ridge_init", C.c_int, [_vp, _dp, _dp]),
+    ("mln_precond_build", C.c_int, [_vp]),
+    ("mln_precond_apply", C.c_int, [_vp, _i32, _dp, _dp]),
+    ("mln_objective_precond", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
     ("mln_fit_set_likelihood", C.c_int, [_vp, _dp, _dp, _dbl]),
     ("mln_objective", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
     ("mln_transform", C.c_int, [_vp, _dp, _dbl, _dp]),
@@ -234,6 +239,15 @@ class Context:
                                                x.shape[1], out.ctypes.data))
         return out
 
+    def nn_distances(self, x, y=None, self_offset=0):
+        """Exact nearest-neighbour distance of each row of x among the rows of y (default: x itself)."""
+        x = x if isinstance(x, DeviceArray) else _as2d(x)
+        y = x if y is None else (y if isinstance(y, DeviceArray) else _as2d(y))
+        out = np.empty(x.shape[0], dtype=np.float64)
+        self._check(self.lib.mln_nn_distances(self.handle, _ptr(x), x.shape[0], _ptr(y), y.shape[0], x.shape[1],
+                                              int(self_offset), out.ctypes.data))
+        return out
+
     def chol_lower(self, A, add_diag=0.0, jitter=None):
         A = _f64(A).copy()
         if A.ndim != 2 or A.shape[0] != A.shape[1]:
@@ -363,6 +377,27 @@ class Fit:
                                                _ptr(hess)))
         return (loss.value, grad, hess) if with_hess else (loss.value, grad)
 
+    def precond_build(self):
+        self.ctx._check(self.lib.mln_precond_build(self.handle), jitter="ridge")
+
+    def precond_apply(self, mode, v):
+        """mode 0: u = C^T z; 1: z = C^-T u; 2: g_u = C^-1 g_z  (C C^T = L^T L + I)."""
+        v = _f64(v)
+        out = np.empty(self.m, dtype=np.float64)
+        self.ctx._check(self.lib.mln_precond_apply(self.handle, int(mode), v.ctypes.data, out.ctypes.data),
+                        jitter="ridge")
+        return out
+
+    def objective_precond(self, u):
+        """(loss, grad_u, z) of the preconditioned variable z = C^-T u."""
+        u = _f64(u)
+        loss = C.c_double()
+        grad = np.empty(self.m, dtype=np.float64)
+        z = np.empty(self.m, dtype=np.float64)
+        self.ctx._check(self.lib.mln_objective_precond(self.handle, u.ctypes.data, C.byref(loss), grad.ctypes.data,
+                                                       z.ctypes.data), jitter="ridge")
+        return loss.value, grad, z
+
     def transform(self, z, mu, out=None):
         z = _f64(z)
         ret = np.empty(self.n, dtype=np.float64) if out is None else out
@@ -388,6 +423,11 @@ class Fit:
         keys = ["kernel_matrix_s", "cholesky_s", "trsm_s", "ridge_gram_s", "ridge_solve_s",
                 "objective_kernel_s", "objective_launches", "objective_bytes_per_launch"]
         return dict(zip(keys, out.tolist()))
+
+
+def release_cached_memory():
+    """Return the library's cached device blocks to the driver."""
+    load_library().mln_release_cached_memory()
 
 
 _default_ctx = None

@@ -86,7 +86,8 @@ class BaseEstimator:
             raise ValueError("Required argument x is missing and self.x has not been set.")
         if x is None:
             x = self.x
-        self.x = ensure_2d(validate_array(x, "x"))
+        x = validate_array(x, "x")
+        self.x = x if isinstance(x, _lib.DeviceArray) else ensure_2d(x)   # HBM-resident x is used in place
         return self.x
 
     # -- lazy attribute pipeline ---------------------------------------------------------------------
@@ -108,7 +109,15 @@ class BaseEstimator:
     def _seed(self):
         return self.random_state if self.random_state is not None else DEFAULT_RANDOM_SEED
 
+    def _require_single_process(self, what):
+        from .distributed import current
+        if current().world_size > 1:
+            raise NotImplementedError(
+                f"{what} need all cells; when cells are sharded across ranks pass `{what}=` explicitly "
+                "(replicated landmarks / this rank's nn_distances).")
+
     def _compute_landmarks(self):
+        self._require_single_process("landmarks")
         n = self.x.shape[0]
         if n > 100 * self.n_landmarks and n > 1e6:
             logger.info(f"Large number of {n:,} cells and small number of {self.n_landmarks:,} landmarks. Consider "
@@ -116,6 +125,7 @@ class BaseEstimator:
         return compute_landmarks(self.x, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed())
 
     def _compute_nn_distances(self):
+        self._require_single_process("nn_distances")
         logger.info("Computing nearest neighbor distances.")
         return validate_nn_distances(compute_nn_distances(self.x, seed=self._seed()))
 
@@ -151,7 +161,8 @@ class BaseEstimator:
             Lp = None if self.Lp is None else np.asarray(self.Lp, dtype=np.float64)
             full = self.gp_type == GaussianProcessType.FULL or self.landmarks is None
             logger.info("Computing Lp.")
-            self._fit = ctx.fit_prepare(self.cov_func.lower(self.x.shape[1]), np.ascontiguousarray(self.x),
+            xin = self.x if isinstance(self.x, _lib.DeviceArray) else np.ascontiguousarray(self.x)
+            self._fit = ctx.fit_prepare(self.cov_func.lower(self.x.shape[1]), xin,
                                         None if full else self.landmarks, self.jitter, Lp=Lp)
         return self._fit
 

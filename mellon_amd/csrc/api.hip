@@ -2,6 +2,8 @@
 #include <dlfcn.h>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -86,13 +88,13 @@ struct DevIn {
     ctx = c;
     if (count == 0 || !p) { dev = p; return MLN_OK; }
     if (is_device_ptr(p)) { dev = p; return MLN_OK; }
-    MLN_HIP(ctx, hipMalloc((void**)&owned, count * sizeof(double)));
+    MLN_HIP(ctx, mln_dmalloc((void**)&owned, count * sizeof(double)));
     MLN_HIP(ctx, hipMemcpyAsync(owned, p, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     dev = owned;
     return MLN_OK;
   }
   ~DevIn() {
-    if (owned) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(owned); }
+    if (owned) { (void)hipStreamSynchronize(ctx->stream); (void)mln_dfree(owned); }
   }
 };
 
@@ -108,7 +110,7 @@ struct DevOut {
     if (n == 0) { dev = p; return MLN_OK; }
     if (is_device_ptr(p)) { dev = p; return MLN_OK; }
     host = p;
-    MLN_HIP(ctx, hipMalloc((void**)&owned, n * sizeof(double)));
+    MLN_HIP(ctx, mln_dmalloc((void**)&owned, n * sizeof(double)));
     if (copy_in) MLN_HIP(ctx, hipMemcpyAsync(owned, p, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     dev = owned;
     return MLN_OK;
@@ -121,15 +123,15 @@ struct DevOut {
     return MLN_OK;
   }
   ~DevOut() {
-    if (owned) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(owned); }
+    if (owned) { (void)hipStreamSynchronize(ctx->stream); (void)mln_dfree(owned); }
   }
 };
 
 int mln_scratch(mln_ctx* ctx, size_t bytes, void** out) {
   if (bytes > ctx->scratch_bytes) {
-    if (ctx->scratch) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; }
+    if (ctx->scratch) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, mln_dfree(ctx->scratch)); ctx->scratch = nullptr; }
     size_t want = bytes + bytes / 4 + 4096;
-    MLN_HIP(ctx, hipMalloc(&ctx->scratch, want));
+    MLN_HIP(ctx, mln_dmalloc(&ctx->scratch, want));
     ctx->scratch_bytes = want;
   }
   *out = ctx->scratch;
@@ -205,7 +207,7 @@ extern "C" int mln_ctx_create(int device, mln_ctx** out) {
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
-      hipMalloc((void**)&ctx->d_info, 4 * sizeof(int)) != hipSuccess) {
+      mln_dmalloc((void**)&ctx->d_info, 4 * sizeof(int)) != hipSuccess) {
     mln_set_error(nullptr, "failed to initialise the HIP context");
     delete ctx;
     return MLN_ERR_HIP;
@@ -219,8 +221,8 @@ extern "C" void mln_ctx_destroy(mln_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && rccl::CommDestroy) rccl::CommDestroy(ctx->comm);
-  if (ctx->scratch) (void)hipFree(ctx->scratch);
-  if (ctx->d_info) (void)hipFree(ctx->d_info);
+  if (ctx->scratch) (void)mln_dfree(ctx->scratch);
+  if (ctx->d_info) (void)mln_dfree(ctx->d_info);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -251,6 +253,11 @@ extern "C" int mln_malloc(mln_ctx* ctx, int64_t bytes, void** dev_ptr) {
 extern "C" int mln_free(mln_ctx* ctx, void* dev_ptr) {
   if (!ctx) return MLN_ERR_ARG;
   if (dev_ptr) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, hipFree(dev_ptr)); }
+  return MLN_OK;
+}
+
+extern "C" int mln_release_cached_memory(void) {
+  mln_dcache_flush();
   return MLN_OK;
 }
 
@@ -323,6 +330,22 @@ extern "C" int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const
   return o.commit();
 }
 
+extern "C" int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int32_t d,
+                                int64_t self_offset, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n < 0 || m < 0 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n == 0) return MLN_OK;
+  if (!x || !y || !out) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevIn dx, dy;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, x, (size_t)n * d));
+  if (y == x) dy.dev = dx.dev, dy.ctx = ctx; else MLN_TRY(dy.init(ctx, y, (size_t)m * d));
+  MLN_TRY(o.init(ctx, out, (size_t)n));
+  MLN_TRY(launch_nn_distances(ctx, dx.dev, n, dy.dev, m, d, self_offset, o.dev));
+  return o.commit();
+}
+
 static int64_t pad16(int64_t m) { return ((m + 15) / 16) * 16; }
 
 extern "C" int mln_chol_lower(mln_ctx* ctx, double* A, int64_t m, double add_diag) {
@@ -374,6 +397,10 @@ struct mln_fit {
   double *h_z = nullptr, *h_out = nullptr;  // pinned
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double times[MLN_N_STAGE_TIMES] = {0};
+  // preconditioner: C C^T = L^T L + I (the Ridge matrix) and C^-1, both m x ldl lower
+  double *C = nullptr, *Cinv = nullptr;
+  double *d_u = nullptr, *d_gu = nullptr, *d_tmp = nullptr;  // m ; m ; 1 + m
+  int n_wg_cap = 0;
 };
 
 static void fit_free(mln_fit* f) {
@@ -381,11 +408,12 @@ static void fit_free(mln_fit* f) {
   mln_ctx* ctx = f->ctx;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (f->L && f->L != f->Lp) (void)hipFree(f->L);
-  if (f->Lp) (void)hipFree(f->Lp);
+  if (f->L && f->L != f->Lp) (void)mln_dfree(f->L);
+  if (f->Lp) (void)mln_dfree(f->Lp);
   triinv_free(&f->tri);
-  void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
+  void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
+                  f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp};
+  for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (f->h_z) (void)hipHostFree(f->h_z);
   if (f->h_out) (void)hipHostFree(f->h_out);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
@@ -399,14 +427,19 @@ static int fit_alloc_workspace(mln_fit* f) {
   mln_ctx* ctx = f->ctx;
   int64_t steps = (f->n + 1) / 2;
   int n_wg = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  f->n_wg_cap = n_wg;                      // partial buffers are sized for this many workgroups
   if (steps < n_wg) n_wg = (int)(steps > 0 ? steps : 1);
   f->n_wg = n_wg;
+  n_wg = f->n_wg_cap;
   const size_t pm = (size_t)f->ldl;
-  MLN_HIP(ctx, hipMalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
-  MLN_HIP(ctx, hipMalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
-  MLN_HIP(ctx, hipMalloc((void**)&f->part_loss, sizeof(double) * n_wg));
-  MLN_HIP(ctx, hipMalloc((void**)&f->d_z, sizeof(double) * pm));
-  MLN_HIP(ctx, hipMalloc((void**)&f->d_out, sizeof(double) * (1 + 2 * pm)));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_u, sizeof(double) * pm));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_gu, sizeof(double) * pm));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_tmp, sizeof(double) * (1 + pm)));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->part_loss, sizeof(double) * n_wg));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_z, sizeof(double) * pm));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_out, sizeof(double) * (1 + 2 * pm)));
   MLN_HIP(ctx, hipHostMalloc((void**)&f->h_z, sizeof(double) * pm, hipHostMallocDefault));
   MLN_HIP(ctx, hipHostMalloc((void**)&f->h_out, sizeof(double) * (1 + 2 * pm), hipHostMallocDefault));
   MLN_HIP(ctx, hipEventCreate(&f->ev0));
@@ -434,7 +467,7 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
   // Lp = chol(cov(xu, xu) + max(sigma^2, jitter) I), sigma = 0     decomposition.py:111-123
   double t0 = now_s();
   const size_t lp_bytes = sizeof(double) * (size_t)m * f->ldp;
-  MLN_HIP(ctx, hipMalloc((void**)&f->Lp, lp_bytes));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->Lp, lp_bytes));
   MLN_HIP(ctx, hipMemsetAsync(f->Lp, 0, lp_bytes, ctx->stream));
   if (Lp_in) {
     DevIn dl;
@@ -458,10 +491,14 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
     // L = cov(x, xu) Lp^-T                                          decomposition.py:205-210
     t0 = now_s();
     const size_t l_bytes = sizeof(double) * (size_t)(n > 0 ? n : 1) * f->ldl;
-    MLN_HIP(ctx, hipMalloc((void**)&f->L, l_bytes));
+    const bool trace = std::getenv("MELLON_AMD_TRACE") != nullptr;
+    MLN_HIP(ctx, mln_dmalloc((void**)&f->L, l_bytes));
+    if (trace) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[trace] L alloc %.4f s\n", now_s() - t0); }
     MLN_HIP(ctx, hipMemsetAsync(f->L, 0, l_bytes, ctx->stream));
+    if (trace) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[trace] L memset done at %.4f s\n", now_s() - t0); }
     MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (trace) fprintf(stderr, "[trace] L kernel matrix done at %.4f s\n", now_s() - t0);
     f->times[0] += now_s() - t0;
     t0 = now_s();
     MLN_TRY(triinv_solve_right_T(ctx, f->tri, f->L, n, f->ldl));
@@ -500,14 +537,14 @@ extern "C" int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, in
     DevIn dl;
     MLN_TRY(dl.init(ctx, L, (size_t)n_local * m));
     const size_t l_bytes = sizeof(double) * (size_t)n_local * f->ldl;
-    MLN_HIP(ctx, hipMalloc((void**)&f->L, l_bytes));
+    MLN_HIP(ctx, mln_dmalloc((void**)&f->L, l_bytes));
     MLN_HIP(ctx, hipMemsetAsync(f->L, 0, l_bytes, ctx->stream));
     MLN_TRY(launch_copy_block(ctx, dl.dev, m, f->L, f->ldl, n_local, m));
     if (Lp) {
       DevIn dp;
       MLN_TRY(dp.init(ctx, Lp, (size_t)m * m));
       const size_t lp_bytes = sizeof(double) * (size_t)m * f->ldp;
-      MLN_HIP(ctx, hipMalloc((void**)&f->Lp, lp_bytes));
+      MLN_HIP(ctx, mln_dmalloc((void**)&f->Lp, lp_bytes));
       MLN_HIP(ctx, hipMemsetAsync(f->Lp, 0, lp_bytes, ctx->stream));
       MLN_TRY(launch_copy_block(ctx, dp.dev, m, f->Lp, f->ldp, m, m));
       MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
@@ -555,8 +592,8 @@ extern "C" int mln_fit_set_likelihood(mln_fit* f, const double* V, const double*
   mln_ctx* ctx = f->ctx;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   const size_t bytes = sizeof(double) * (size_t)(f->n > 0 ? f->n : 1);
-  if (!f->V) MLN_HIP(ctx, hipMalloc((void**)&f->V, bytes));
-  if (!f->Vdr) MLN_HIP(ctx, hipMalloc((void**)&f->Vdr, bytes));
+  if (!f->V) MLN_HIP(ctx, mln_dmalloc((void**)&f->V, bytes));
+  if (!f->Vdr) MLN_HIP(ctx, mln_dmalloc((void**)&f->Vdr, bytes));
   if (f->n > 0) {
     MLN_HIP(ctx, hipMemcpyAsync(f->V, V, sizeof(double) * f->n, hipMemcpyDefault, ctx->stream));
     MLN_HIP(ctx, hipMemcpyAsync(f->Vdr, Vdr, sizeof(double) * f->n, hipMemcpyDefault, ctx->stream));
@@ -647,7 +684,7 @@ static int fit_gram(mln_fit* f, double* G, int64_t ldg) {
   if (split > 16) split = 16;
   const size_t stride = (size_t)m * ldg;
   double* parts = nullptr;
-  if (split > 1) MLN_HIP(ctx, hipMalloc((void**)&parts, sizeof(double) * stride * split));
+  if (split > 1) MLN_HIP(ctx, mln_dmalloc((void**)&parts, sizeof(double) * stride * split));
   GemmArgs g{};
   g.A = f->L; g.lda = f->ldl; g.B = f->L; g.ldb = f->ldl;
   g.C = (split > 1) ? parts : G; g.ldc = ldg;
@@ -661,7 +698,7 @@ static int fit_gram(mln_fit* f, double* G, int64_t ldg) {
   if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
   if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)stride);
   (void)hipStreamSynchronize(ctx->stream);
-  if (parts) (void)hipFree(parts);
+  if (parts) (void)mln_dfree(parts);
   return rc;
 }
 
@@ -678,38 +715,134 @@ static int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev) {
   return MLN_OK;
 }
 
+// C C^T = L^T L + I and C^-1 (explicit, lower): the Ridge matrix of parameters.py:895-896 doubles as
+// the preconditioner of the MAP solve, because the MAP Hessian I + L^T diag(e^{f+V}) L equals it
+// wherever e^{f+V} = 1 (i.e. where f matches the nearest-neighbour estimate the Ridge regresses on).
+static int fit_build_precond(mln_fit* f) {
+  if (f->Cinv) return MLN_OK;
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, ldg = f->ldl;
+  const size_t bytes = sizeof(double) * (size_t)m * ldg;
+  double t0 = now_s();
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
+  int rc = fit_gram(f, f->C, ldg);
+  f->times[3] += now_s() - t0;
+  t0 = now_s();
+  if (rc == MLN_OK) rc = launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1
+  if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, f->C, m, ldg);
+  TriInv t;
+  if (rc == MLN_OK) rc = triinv_build(ctx, f->C, m, ldg, true, false, &t);
+  double* inv = nullptr;
+  if (rc == MLN_OK) {
+    hipError_t e = mln_dmalloc((void**)&inv, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(inv, 0, bytes, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc C^-1", __FILE__, __LINE__);
+  }
+  if (rc == MLN_OK) rc = launch_add_diag(ctx, inv, m, ldg, 1.0);
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg);   // C^-1 = C^-1 I
+  (void)hipStreamSynchronize(ctx->stream);
+  triinv_free(&t);
+  if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
+  f->times[4] += now_s() - t0;
+  return rc;
+}
+
+// y (m) = Minv^T w  (trans = 1)  or  Minv w  (trans = 0) for an m x ldl lower matrix M, via the
+// streaming kernels of objective.hip (GEMV-T mode / f-only mode); all pointers on the device.
+static int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* w, double* y) {
+  mln_ctx* ctx = f->ctx;
+  ObjArgs a{};
+  a.L = M; a.ldl = f->ldl; a.n = f->m; a.m = f->m; a.mu = 0.0;
+  a.part_grad = f->part_grad; a.part_hess = nullptr; a.part_loss = nullptr;
+  a.m_pad = f->ldl;
+  int64_t steps = (f->m + 1) / 2;
+  a.n_wg = (int)((steps < f->n_wg_cap) ? (steps > 0 ? steps : 1) : f->n_wg_cap);
+  if (trans) {
+    a.weights = w;
+    MLN_TRY(launch_objective(ctx, a));
+    MLN_TRY(launch_reduce_obj(ctx, a, f->d_tmp));
+    MLN_HIP(ctx, hipMemcpyAsync(y, f->d_tmp + 1, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    a.z = w;
+    a.f_out = y;
+    MLN_TRY(launch_objective(ctx, a));
+  }
+  return MLN_OK;
+}
+
+extern "C" int mln_precond_build(mln_fit* f) {
+  if (!f) return MLN_ERR_ARG;
+  MLN_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  return fit_build_precond(f);
+}
+
 extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
   if (!f || !z0 || (f->n > 0 && !target)) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  const int64_t m = f->m, ldg = pad16(m);
+  MLN_TRY(fit_build_precond(f));
   double t0 = now_s();
-  double* G = nullptr;
-  double* rhs = nullptr;
-  MLN_HIP(ctx, hipMalloc((void**)&G, sizeof(double) * (size_t)m * ldg));
-  MLN_HIP(ctx, hipMalloc((void**)&rhs, sizeof(double) * (size_t)ldg));
   DevIn dt;
-  int rc = dt.init(ctx, target, (size_t)f->n);
-  if (rc == MLN_OK) rc = fit_gram(f, G, ldg);
-  f->times[3] += now_s() - t0;
-  t0 = now_s();
-  if (rc == MLN_OK) rc = fit_gemvT(f, dt.dev, rhs);
-  if (rc == MLN_OK) rc = launch_add_diag(ctx, G, m, ldg, 1.0);  // Ridge alpha = 1
-  if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, G, m, ldg);
-  TriInv t;
-  if (rc == MLN_OK) rc = triinv_build(ctx, G, m, ldg, true, true, &t);
-  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, rhs, 1, 1);
-  if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, t, rhs, 1, 1);
-  if (rc == MLN_OK) {
-    hipError_t e = hipMemcpyAsync(z0, rhs, sizeof(double) * m, hipMemcpyDefault, ctx->stream);
-    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "copy z0", __FILE__, __LINE__);
-  }
-  (void)hipStreamSynchronize(ctx->stream);
-  triinv_free(&t);
-  (void)hipFree(G);
-  (void)hipFree(rhs);
+  MLN_TRY(dt.init(ctx, target, (size_t)f->n));
+  // z0 = (L^T L + I)^-1 L^T t = C^-T C^-1 (L^T t)
+  MLN_TRY(fit_gemvT(f, dt.dev, f->d_u));
+  MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_u, f->d_gu));
+  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_gu, f->d_u));
+  MLN_HIP(ctx, hipMemcpyAsync(z0, f->d_u, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   f->times[4] += now_s() - t0;
-  return rc;
+  return MLN_OK;
+}
+
+// u <-> z of the preconditioned variable  z = C^-T u
+extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, double* out) {
+  if (!f || !in || !out) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_build_precond(f));
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_u, in, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  if (mode == 0) MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));          // u = C^T z
+  else if (mode == 1) MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_gu));  // z = C^-T u
+  else if (mode == 2) MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_u, f->d_gu));  // g_u = C^-1 g_z
+  else { mln_set_error(ctx, "mln_precond_apply: unknown mode"); return MLN_ERR_ARG; }
+  MLN_HIP(ctx, hipMemcpyAsync(out, f->d_gu, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
+}
+
+// loss and gradient with respect to u, z = C^-T u; everything between the upload of u and the
+// download of (loss, grad_u, z) stays on the device.
+extern "C" int mln_objective_precond(mln_fit* f, const double* u, double* loss, double* grad_u, double* z_out) {
+  if (!f || !u || !loss || !grad_u) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_build_precond(f));
+  const int64_t m = f->m;
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
+  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_z));                       // z = C^-T u
+  ObjArgs a = obj_args(f);
+  MLN_HIP(ctx, hipEventRecord(f->ev0, ctx->stream));
+  MLN_TRY(launch_objective(ctx, a));
+  MLN_HIP(ctx, hipEventRecord(f->ev1, ctx->stream));
+  MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+  MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + m));
+  MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_z, 1.0, f->d_out + 1));                // + z (prior)
+  MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));                // g_u = C^-1 g_z
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->times[5] += 1e-3 * ms;
+  f->times[6] += 1.0;
+  f->times[7] = (double)f->n * (double)f->ldl * 8.0;
+  double zz = 0.0;
+  for (int64_t j = 0; j < m; ++j) zz += f->h_z[j] * f->h_z[j];
+  *loss = f->h_out[0] + 0.5 * zz + 0.5 * (double)m * std::log(2.0 * M_PI);
+  std::memcpy(grad_u, f->h_out + 1, sizeof(double) * m);
+  if (z_out) std::memcpy(z_out, f->h_z, sizeof(double) * m);
+  return MLN_OK;
 }
 
 extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
@@ -736,12 +869,12 @@ extern "C" int mln_weights_full(mln_fit* f, const double* y, int64_t p, double m
   // r = y - mu ; w = Lp^-T Lp^-1 r                                conditional.py:263-264
   if (mu != 0.0) {
     double* ones = nullptr;
-    MLN_HIP(ctx, hipMalloc((void**)&ones, sizeof(double) * cnt));
+    MLN_HIP(ctx, mln_dmalloc((void**)&ones, sizeof(double) * cnt));
     std::vector<double> h((size_t)cnt, 1.0);
     MLN_HIP(ctx, hipMemcpyAsync(ones, h.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, ctx->stream));
     int rc = launch_axpby(ctx, cnt, -mu, ones, 1.0, o.dev);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ones);
+    (void)mln_dfree(ones);
     if (rc != MLN_OK) return rc;
   }
   MLN_TRY(triinv_solve_left(ctx, f->tri, o.dev, p, p));
@@ -784,11 +917,11 @@ extern "C" int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const 
   if (chunk > n_new) chunk = n_new;
   double* Kc = nullptr;
   double* mus = nullptr;
-  MLN_HIP(ctx, hipMalloc((void**)&Kc, sizeof(double) * (size_t)chunk * m));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Kc, sizeof(double) * (size_t)chunk * m));
   int rc = MLN_OK;
   if (mu != 0.0) {
     std::vector<double> h((size_t)(chunk * p), mu);
-    rc = (hipMalloc((void**)&mus, sizeof(double) * h.size()) == hipSuccess &&
+    rc = (mln_dmalloc((void**)&mus, sizeof(double) * h.size()) == hipSuccess &&
           hipMemcpy(mus, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
   }
   for (int64_t r0 = 0; r0 < n_new && rc == MLN_OK; r0 += chunk) {
@@ -809,8 +942,8 @@ extern "C" int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const 
   }
   if (rc == MLN_OK) rc = o.commit();
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(Kc);
-  if (mus) (void)hipFree(mus);
+  (void)mln_dfree(Kc);
+  if (mus) (void)mln_dfree(mus);
   return rc;
 }
 
@@ -831,22 +964,22 @@ extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const 
   TriInv tb;
   int rc = MLN_OK;
   auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "sparse_solve", __FILE__, __LINE__); };
-  chk(hipMalloc((void**)&G, sizeof(double) * (size_t)m * ldg));
-  chk(hipMalloc((void**)&C, sizeof(double) * (size_t)m * p));
+  chk(mln_dmalloc((void**)&G, sizeof(double) * (size_t)m * ldg));
+  chk(mln_dmalloc((void**)&C, sizeof(double) * (size_t)m * p));
   DevIn dy;
   if (rc == MLN_OK) rc = dy.init(ctx, y, (size_t)n * p);
   // r = y - mu
   if (rc == MLN_OK && n > 0) {
-    chk(hipMalloc((void**)&R, sizeof(double) * (size_t)n * p));
+    chk(mln_dmalloc((void**)&R, sizeof(double) * (size_t)n * p));
     chk(hipMemcpyAsync(R, dy.dev, sizeof(double) * (size_t)n * p, hipMemcpyDeviceToDevice, ctx->stream));
     if (rc == MLN_OK && mu != 0.0) {
       std::vector<double> ones((size_t)n * p, 1.0);
       double* d1 = nullptr;
-      chk(hipMalloc((void**)&d1, sizeof(double) * ones.size()));
+      chk(mln_dmalloc((void**)&d1, sizeof(double) * ones.size()));
       chk(hipMemcpyAsync(d1, ones.data(), sizeof(double) * ones.size(), hipMemcpyHostToDevice, ctx->stream));
       if (rc == MLN_OK) rc = launch_axpby(ctx, (int64_t)ones.size(), -mu, d1, 1.0, R);
       (void)hipStreamSynchronize(ctx->stream);
-      if (d1) (void)hipFree(d1);
+      if (d1) (void)mln_dfree(d1);
     }
   }
   // LBB = A A^T / sigma^2 + I                                      conditional.py:62 (stabilize(.., 1))
@@ -860,7 +993,7 @@ extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const 
     if (split < 1) split = 1;
     if (split > 16) split = 16;
     const size_t stride = (size_t)m * p;
-    if (split > 1) chk(hipMalloc((void**)&parts, sizeof(double) * stride * split));
+    if (split > 1) chk(mln_dmalloc((void**)&parts, sizeof(double) * stride * split));
     if (rc == MLN_OK) chk(hipMemsetAsync(split > 1 ? parts : C, 0, sizeof(double) * stride * (split > 1 ? split : 1), ctx->stream));
     GemmArgs g{};
     g.A = f->L; g.lda = f->ldl; g.B = R; g.ldb = p; g.C = (split > 1) ? parts : C; g.ldc = p;
@@ -879,7 +1012,7 @@ extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const 
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&tb);
   void* ptrs[] = {G, R, C, parts};
-  for (void* q : ptrs) if (q) (void)hipFree(q);
+  for (void* q : ptrs) if (q) (void)mln_dfree(q);
   fit_free(f);
   return rc;
 }

@@ -225,6 +225,98 @@ __global__ void k_row_sqnorms(DevCov cov, const double* __restrict__ x, int64_t 
   }
 }
 
+
+// Exact Euclidean nearest-neighbour distance of every row of x among the rows of y, skipping the
+// pair (i, i + self_offset).  Replaces the approximate pynndescent search of the reference
+// (mellon/parameters.py:352-433) -- same tile structure as the covariance kernel; the running
+// minimum of the squared distance stays in registers across all centre tiles.
+__global__ __launch_bounds__(256) void k_nn_distances(const double* __restrict__ x, int64_t n,
+                                                      const double* __restrict__ y, int64_t m, int d,
+                                                      const double* __restrict__ xx,
+                                                      const double* __restrict__ yy, int64_t self_offset,
+                                                      double* __restrict__ out) {
+  __shared__ double xs[DK][TM + PADT];
+  __shared__ double ys[DK][TN + PADT];
+  __shared__ double red[TM][17];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * TM;
+  double best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+  double xr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t r = row0 + ty * 4 + i;
+    xr[i] = (r < n) ? xx[r] : 0.0;
+  }
+  for (int64_t col0 = 0; col0 < m; col0 += TN) {
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < d; k0 += DK) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int idx = tid + 256 * q;
+        int r = idx >> 4, k = idx & 15;
+        double vx = 0.0, vy = 0.0;
+        if (k0 + k < d) {
+          if (row0 + r < n) vx = x[(row0 + r) * (int64_t)d + k0 + k];
+          if (col0 + r < m) vy = y[(col0 + r) * (int64_t)d + k0 + k];
+        }
+        xs[k][r] = vx;
+        ys[k][r] = vy;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = xs[k][ty * 4 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = ys[k][tx * 4 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = col0 + tx * 4 + j;
+      const double yj = (c < m) ? yy[c] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t r = row0 + ty * 4 + i;
+        const double sq = fmax(xr[i] - 2.0 * acc[i][j] + yj, 0.0);
+        if (c < m && c != r + self_offset) best[i] = fmin(best[i], sq);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[ty * 4 + i][tx] = best[i];
+  __syncthreads();
+  if (tid < TM) {
+    double s = INFINITY;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s = fmin(s, red[tid][t]);
+    int64_t r = row0 + tid;
+    if (r < n) out[r] = sqrt(s);
+  }
+}
+
+__global__ void k_row_sqnorms_all(const double* __restrict__ x, int64_t n, int d, double* __restrict__ xx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) {
+    double v = x[i * (int64_t)d + k];
+    s = fma(v, v, s);
+  }
+  xx[i] = s;
+}
+
 int sqnorms(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, double* xx) {
   if (n == 0) return MLN_OK;
   hipLaunchKernelGGL(k_row_sqnorms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cov, x, n, d, xx);
@@ -274,6 +366,21 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   else
     hipLaunchKernelGGL(k_predict_mean1<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, w, mu, out);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                        int64_t self_offset, double* out) {
+  if (n == 0) return MLN_OK;
+  double* norms = nullptr;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)(n + m), (void**)&norms));
+  double* xx = norms;
+  double* yy = norms + n;
+  hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, d, xx);
+  hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, y, m, d, yy);
+  hipLaunchKernelGGL(k_nn_distances, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, ctx->stream, x, n, y, m, d,
+                     xx, yy, self_offset, out);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

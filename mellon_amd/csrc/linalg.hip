@@ -213,7 +213,7 @@ int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst,
 int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   if (m <= 0) return MLN_OK;
   double* Dinv = nullptr;
-  MLN_HIP(ctx, hipMalloc((void**)&Dinv, sizeof(double) * PB * PB));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Dinv, sizeof(double) * PB * PB));
   MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   int rc = MLN_OK;
   for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += PB) {
@@ -243,7 +243,7 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   } else {
     (void)hipStreamSynchronize(ctx->stream);
   }
-  (void)hipFree(Dinv);
+  (void)mln_dfree(Dinv);
   if (rc == MLN_OK && info != 0) {
     mln_set_error(ctx, "Cholesky failed: non-positive or NaN pivot at index " + std::to_string(info - 1));
     return MLN_ERR_NOT_PD;
@@ -253,8 +253,8 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
 
 // ---- triangular solves through block-scaled copies of the factor ------------------------------
 void triinv_free(TriInv* t) {
-  if (t->W) (void)hipFree(t->W);
-  if (t->W2) (void)hipFree(t->W2);
+  if (t->W) (void)mln_dfree(t->W);
+  if (t->W2) (void)mln_dfree(t->W2);
   t->W = t->W2 = nullptr;
 }
 
@@ -265,7 +265,7 @@ int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool nee
   out->ld = ((m + 15) / 16) * 16;
   const size_t bytes = sizeof(double) * (size_t)m * (size_t)out->ld;
   double* D = nullptr;  // block-diagonal inverse, stored in an m x ld matrix
-  MLN_HIP(ctx, hipMalloc((void**)&D, bytes));
+  MLN_HIP(ctx, mln_dmalloc((void**)&D, bytes));
   MLN_HIP(ctx, hipMemsetAsync(D, 0, bytes, ctx->stream));
   const int64_t nb64 = (m + PB - 1) / PB, nb128 = (m + TB - 1) / TB;
   hipLaunchKernelGGL(k_trtri64, dim3((unsigned)nb64), dim3(256), 0, ctx->stream, Lf, m, ld, D, out->ld);
@@ -273,7 +273,7 @@ int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool nee
   MLN_HIP(ctx, hipGetLastError());
   int rc = MLN_OK;
   if (need_w2) {
-    rc = (hipMalloc((void**)&out->W2, bytes) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+    rc = (mln_dmalloc((void**)&out->W2, bytes) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
     if (rc == MLN_OK) rc = (hipMemcpyAsync(out->W2, D, bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
     for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += TB) {
       const int64_t nb = (m - j0 < TB) ? (m - j0) : TB;
@@ -298,7 +298,7 @@ int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool nee
     out->W = D;
   } else {
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(D);
+    (void)mln_dfree(D);
   }
   if (rc != MLN_OK) { (void)hipStreamSynchronize(ctx->stream); triinv_free(out); mln_set_error(ctx, "triinv_build failed"); }
   return rc;

@@ -34,6 +34,11 @@ int mln_hip_fail(mln_ctx* ctx, hipError_t e, const char* what, const char* file,
     if (s__ != MLN_OK) return s__; \
   } while (0)
 
+// alloc.hip: caching device allocator (every internal device buffer goes through it)
+hipError_t mln_dmalloc(void** out, size_t bytes);
+hipError_t mln_dfree(void* p);
+void mln_dcache_flush();
+
 // ---- device-side covariance program (by-value kernel argument) ------------------------------
 struct DevLeaf {
   int kind;
@@ -60,6 +65,9 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
                          int64_t m, int d, double* out, int64_t ldo, double add_diag);
 int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
                          int64_t m, int d, const double* w, double mu, double* out);
+
+int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                        int64_t self_offset, double* out);
 
 // dgemm.hip : C = alpha * op(A) op(B) + beta * C   (row-major, fp64 MFMA 16x16x4)
 //   ta = 0: A is M x K (lda >= K);  ta = 1: A is stored K x M (lda >= M)

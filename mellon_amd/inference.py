@@ -83,10 +83,23 @@ class LossFunc:
             raise ValueError(f"{V.shape[0]} nearest-neighbour distances for {self.fit.n} rows of L")
         self.fit.set_likelihood(V, Vdr, transform.mu)
         self.n_eval = 0
+        self.preconditioned = True     # optimise u with z = C^-T u, C C^T = L^T L + I (see minimize_lbfgsb)
 
     def value_and_grad(self, z):
         self.n_eval += 1
         return self.fit.objective(z)
+
+    # preconditioned variable (include/mellon_hip.h: mln_objective_precond)
+    def value_and_grad_u(self, u):
+        self.n_eval += 1
+        loss, grad_u, self._last_z = self.fit.objective_precond(u)
+        return loss, grad_u
+
+    def u_from_z(self, z):
+        return self.fit.precond_apply(0, z)
+
+    def z_from_u(self, u):
+        return self.fit.precond_apply(1, u)
 
     def hessian_diagonal(self, z):
         return self.fit.objective(z, with_hess=True)[2]
@@ -105,12 +118,20 @@ def minimize_lbfgsb(loss_func, initial_value, jit=DEFAULT_JIT, options=None):
     opts = dict(LBFGSB_OPTIONS)
     if options:
         opts.update(options)
+    Results = namedtuple("Results", "pre_transformation opt_state loss")
+    z0 = np.asarray(initial_value, dtype=np.float64)
+    if getattr(loss_func, "preconditioned", False):
+        # Same optimiser, same objective, better-conditioned variable: z = C^-T u with
+        # C C^T = L^T L + I (the Ridge matrix = the MAP Hessian where e^{f+V} = 1).  The optimum is
+        # unique (strict convexity), so this only changes how many passes over L it takes (~10x fewer).
+        res = _sp_minimize(loss_func.value_and_grad_u, loss_func.u_from_z(z0), jac=True, method="L-BFGS-B",
+                           options=opts)
+        return Results(loss_func.z_from_u(res.x), res, float(res.fun))
     if hasattr(loss_func, "value_and_grad"):
         fun, jac = loss_func.value_and_grad, True
     else:
         fun, jac = loss_func, None                       # user callable: finite differences by SciPy
-    res = _sp_minimize(fun, np.asarray(initial_value, dtype=np.float64), jac=jac, method="L-BFGS-B", options=opts)
-    Results = namedtuple("Results", "pre_transformation opt_state loss")
+    res = _sp_minimize(fun, z0, jac=jac, method="L-BFGS-B", options=opts)
     return Results(res.x, res, float(res.fun))
 
 

@@ -116,8 +116,13 @@ def compute_distances(x, k, seed=DEFAULT_RANDOM_SEED):
 
 
 def compute_nn_distances(x, seed=DEFAULT_RANDOM_SEED):
-    """reference parameters.py:408-433."""
-    return compute_distances(x, 1, seed=seed)[:, 0]
+    """reference parameters.py:408-433 -- exact, brute force on the device (mln_nn_distances);
+    the reference's pynndescent search is approximate and `seed` only matters there."""
+    x = ensure_2d(validate_array(x, "x"))
+    if x.shape[0] == 0:
+        raise ValueError("Input data x is empty.")
+    validate_k(1, x.shape[0])
+    return _lib.default_context().nn_distances(np.ascontiguousarray(x, dtype=np.float64))
 
 
 def compute_nn_distances_within_time_points(x, times=None, d=None, normalize=False):
@@ -150,13 +155,16 @@ def compute_d(x):
 
 
 def compute_mu(nn_distances, d):
-    """reference parameters.py:586-599 (1st percentile, linear interpolation, minus 10)."""
-    return float(np.quantile(mle(nn_distances, d), 0.01)) - 10
+    """reference parameters.py:586-599 (1st percentile, linear interpolation, minus 10) -- over
+    the GLOBAL cell set when cells are sharded across ranks."""
+    from .distributed import current
+    return current().global_quantile(mle(np.asarray(nn_distances, dtype=np.float64), d), 0.01) - 10
 
 
 def compute_ls(nn_distances):
-    """reference parameters.py:602-613."""
-    return float(np.exp(np.log(nn_distances).mean() + 3.0))
+    """reference parameters.py:602-613 (global mean of log nn when sharded)."""
+    from .distributed import current
+    return float(np.exp(current().global_mean(np.log(np.asarray(nn_distances, dtype=np.float64))) + 3.0))
 
 
 def compute_cov_func(cov_func_curry, ls, ls_time=None):

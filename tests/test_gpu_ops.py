@@ -260,3 +260,26 @@ def test_reference_golden_function_estimator_on_gpu(ctx):
     W = ctx.sparse_solve(c.lower(2), X, xu, y, 0.0, 1.0, 1e-6)
     pred = ctx.predict_mean(c.lower(2), Xt, xu, W, 0.0)
     assert np.allclose(pred, np.array(gold["sparse"]["expected_pred"]), atol=1e-5)
+
+
+def test_preconditioned_objective(ctx):
+    """z = C^-T u with C C^T = L^T L + I: loss identical, gradient = C^-1 grad_z, round trips."""
+    from mellon_amd import cov
+    n, d, m = 6000, 12, 300
+    x, nn, ls, mu, xu = _problem(n, d, m, seed=77)
+    c = cov.Matern52(ls)
+    fit = ctx.fit_prepare(c.lower(d), x, xu, 1e-6)
+    V, Vdr = mo.nn_likelihood_constants(nn, d)
+    fit.set_likelihood(V, Vdr, mu)
+    L = fit.L()
+    C = sla.cholesky(L.T @ L + np.eye(m), lower=True)
+    z = fit.ridge_init(mo.mle(nn, d) - mu) + 0.01 * np.random.default_rng(1).normal(size=m)
+    u = fit.precond_apply(0, z)
+    assert relmax(u, C.T @ z) < 1e-9
+    assert relmax(fit.precond_apply(1, u), z) < 1e-9
+    loss_u, grad_u, z_back = fit.objective_precond(u)
+    loss_z, grad_z = fit.objective(z_back)
+    assert relmax(z_back, z) < 1e-9
+    assert abs(loss_u - loss_z) <= 1e-12 * abs(loss_z)
+    assert relmax(grad_u, sla.solve_triangular(C, grad_z, lower=True)) < 1e-8
+    assert relmax(fit.precond_apply(2, grad_z), sla.solve_triangular(C, grad_z, lower=True)) < 1e-8
