@@ -1,0 +1,104 @@
+"""world_size-2 `gloo` tests (CPU) of the cell-sharded path: shard layout, global heuristics,
+and the exchange contract the C-ABI implements on RCCL (sum of per-shard likelihood terms
+all-reduced, prior added once; Ridge Gram all-reduced)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import scipy.linalg as sla
+    from mellon_amd import distributed, parameters
+    from oracle import mellon_oracle as mo
+
+    comm = distributed.set_current(distributed.TorchCommunicator())
+    assert (comm.rank, comm.world_size) == (rank, world)
+    n, d, m = 4001, 6, 60                                   # odd n: uneven shards
+    x = mo.gaussian_mixture(n, d, seed=21)                  # identical on every rank
+    nn = mo.exact_nn_distances(x)
+    lo, hi = distributed.shard_bounds(n, world, rank)
+    xs, nns = x[lo:hi], nn[lo:hi]
+
+    # heuristics on shards == heuristics on all cells (parameters.py:599,613)
+    assert abs(parameters.compute_mu(nns, d) - mo.compute_mu(nn, d)) < 1e-12
+    assert abs(parameters.compute_ls(nns) - mo.compute_ls(nn)) < 1e-12 * mo.compute_ls(nn)
+    assert np.array_equal(comm.allgather_rows(nns), nn)
+    assert comm.broadcast_bytes(b"unique-id" if rank == 0 else b"") == b"unique-id"
+
+    ref = mo.density_fit(x, n_landmarks=m, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    cov, mu, lm = ref.cov_func, ref.mu, ref.landmarks
+    Ls = mo.standard_low_rank(xs, cov, lm, Lp=ref.Lp)       # this rank's rows of L; Lp replicated
+    Vs, Vdrs = mo.nn_likelihood_constants(nns, d)
+
+    # Ridge: all-reduce of the m x m Gram and of L^T t, then the replicated solve
+    G = comm.allreduce_sum(Ls.T @ Ls)
+    rhs = comm.allreduce_sum(Ls.T @ (mo.mle(nns, d) - mu))
+    C = sla.cholesky(G + np.eye(m), lower=True)
+    z0 = sla.solve_triangular(C.T, sla.solve_triangular(C, rhs, lower=True), lower=False)
+    assert np.abs(z0 - ref.initial_value).max() < 1e-9 * np.abs(ref.initial_value).max()
+
+    # objective: per-shard likelihood terms summed across ranks, prior added once
+    def sharded(z):
+        f = Ls @ z + mu
+        a = np.exp(f + Vs)
+        part = np.concatenate([[-np.sum((f + Vdrs) - a)], Ls.T @ (a - 1.0)])
+        tot = comm.allreduce_sum(part)
+        return tot[0] + 0.5 * z @ z + 0.5 * m * np.log(2 * np.pi), tot[1:] + z
+
+    V, Vdr = mo.nn_likelihood_constants(nn, d)
+    for z in (ref.initial_value, ref.pre_transformation):
+        l_s, g_s = sharded(z)
+        l_g, g_g = mo.loss_and_grad(z, ref.L, mu, V, Vdr)
+        assert abs(l_s - l_g) < 1e-8 * abs(l_g), (l_s, l_g)   # L rows recomputed per shard: cond(Lp)-amplified rounding
+        assert np.abs(g_s - g_g).max() < 1e-5 * max(np.abs(g_g).max(), 1.0), np.abs(g_s - g_g).max()
+
+    res = mo.minimize_lbfgsb(sharded, z0, mo.LBFGSB_TIGHT)  # every rank runs the same host optimiser
+    dens = comm.allgather_rows(Ls @ res.pre_transformation + mu)
+    err = np.abs(dens - ref.log_density_x).max() / np.abs(ref.log_density_x).max()
+    assert err < 1e-6, err
+    with open(os.path.join(out_dir, f"ok{rank}"), "w") as fh:
+        fh.write(repr(err))
+    dist.destroy_process_group()
+
+
+def test_cell_sharded_contract_world_size_2(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_sharded_estimator_requires_shared_inputs():
+    """Landmarks and nn_distances need all cells: in sharded mode they must be passed in."""
+    sys.path.insert(0, ROOT)
+    import mellon_amd
+    from mellon_amd import distributed
+
+    class Two(distributed.Communicator):
+        rank, world_size = 0, 2
+
+    distributed.set_current(Two())
+    try:
+        est = mellon_amd.DensityEstimator(n_landmarks=10)
+        est.set_x(np.zeros((40, 2)))
+        with pytest.raises(NotImplementedError):
+            est._compute_nn_distances()
+        with pytest.raises(NotImplementedError):
+            est._compute_landmarks()
+    finally:
+        distributed.set_current(distributed.Communicator())
