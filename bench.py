@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--m", type=int, default=5000)
     ap.add_argument("--kernel", default="Matern52")
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=8000, help="cells of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=50000, help="cells of the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -134,9 +134,12 @@ int mln_trsm_lower(mln_ctx* ctx, const double* Lf, int64_t m, int32_t trans, dou
  *   xu == NULL (full):            Lp = chol(cov(x,x) + jitter I);  L = Lp        parameters.py:847-850
  * Lp_in (optional, m x m) skips the factorisation (the estimator's `Lp=` ctor argument).
  * x is THIS RANK's shard (n_local x d); with a communicator the full-GP branch is refused.    */
+#define MLN_FIT_IMPLICIT 1 /* flags: keep K = cov(x,xu) in the n x m buffer and fold Lp^-T into the
+                             m-vectors (L z = K (Lp^-T z), L^T v = Lp^-1 (K^T v)): no n x m triangular
+                             solve; mln_fit_get_L materialises rows on demand; no Hessian diagonal.   */
 int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                     int32_t d, const double* xu, int64_t m, double jitter, const double* Lp_in,
-                    mln_fit** out);
+                    int32_t flags, mln_fit** out);
 /* Adopt factors computed elsewhere (the estimator's `L=` / `Lp=` ctor arguments,
  * density_estimator.py:180-205): L is n_local x m; Lp (m x m) may be NULL, in which case the
  * predictor-weight entries are unavailable on this handle.                                      */
@@ -155,10 +158,12 @@ int mln_ridge_init(mln_fit* fit, const double* target, double* z0 /* m */);
  * with C C^T = L^T L + I -- the Ridge matrix above, which equals the MAP Hessian wherever
  * exp(f + V) = 1 -- the substitution z = C^-T u makes the strictly convex objective well conditioned,
  * so the same optimiser reaches the same unique optimum in ~10x fewer passes over L.
- *   mln_precond_build      factor C and C^-1 (done implicitly by mln_ridge_init)
+ *   mln_precond_build      factor C and C^-1 (done implicitly, from all cells, by mln_ridge_init).  Any SPD
+ *                          matrix preconditions a strictly convex problem: estimating the Gram from every
+ *                          row_stride-th cell (~8 m rows suffice) costs 1/row_stride of the n m^2 flops
  *   mln_precond_apply      mode 0: u = C^T z;  mode 1: z = C^-T u;  mode 2: g_u = C^-1 g_z   (host m-vectors)
  *   mln_objective_precond  loss(C^-T u) and its gradient in u; optionally also z = C^-T u      */
-int mln_precond_build(mln_fit* fit);
+int mln_precond_build(mln_fit* fit, int64_t row_stride /* Gram from every row_stride-th cell; 1 = all */);
 int mln_precond_apply(mln_fit* fit, int32_t mode, const double* in, double* out);
 int mln_objective_precond(mln_fit* fit, const double* u, double* loss, double* grad_u /* m */,
                           double* z_out /* m or NULL */);
@@ -197,6 +202,13 @@ int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
 int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
                      int32_t d, const double* centers, int64_t m, const double* W, int64_t p,
                      double mu, double* out);
+
+/* ---- diagnostics: measured rooflines of this device and the GEMM kernel in isolation ----------
+ *   mln_diag_peak   what = 0: fp64 MFMA issue peak (TFLOP/s); what = 1: HBM streaming read (GB/s)
+ *   mln_diag_dgemm  milliseconds per call of C = op(A) op(B) (same arguments as the internal GEMM) */
+int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result);
+int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
+                   int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out);
 
 /* wall-clock seconds of the stages of the last mln_fit_prepare / mln_ridge_init and counters
  * of mln_objective: [0] kernel matrix, [1] cholesky, [2] trsm, [3] ridge gram, [4] ridge solve,

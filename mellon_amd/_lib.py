@@ -59,14 +59,14 @@ SYMBOLS = [
     ("mln_nn_distances", C.c_int, [_vp, _dp, _i64, _dp, _i64, _i32, _i64, _dp]),
     ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
     ("mln_trsm_lower", C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64]),
-    ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, C.POINTER(_vp)]),
+    ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, _i32, C.POINTER(_vp)]),
     ("mln_fit_from_L", C.c_int, [_vp, _dp, _i64, _i64, _dp, C.POINTER(_vp)]),
     ("mln_fit_destroy", None, [_vp]),
     ("mln_fit_get_Lp", C.c_int, [_vp, _dp]),
     ("mln_fit_get_L", C.c_int, [_vp, _i64, _i64, _dp]),
     ("mln_fit_rank", C.c_int, [_vp, C.POINTER(_i64)]),
     ("mln_ridge_init", C.c_int, [_vp, _dp, _dp]),
-    ("mln_precond_build", C.c_int, [_vp]),
+    ("mln_precond_build", C.c_int, [_vp, _i64]),
     ("mln_precond_apply", C.c_int, [_vp, _i32, _dp, _dp]),
     ("mln_objective_precond", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
     ("mln_fit_set_likelihood", C.c_int, [_vp, _dp, _dp, _dbl]),
@@ -77,6 +77,8 @@ SYMBOLS = [
     ("mln_sparse_solve", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp]),
     ("mln_predict_mean", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp]),
     ("mln_stage_times", C.c_int, [_vp, _dp]),
+    ("mln_diag_peak", C.c_int, [_vp, _i32, _i64, C.POINTER(_dbl)]),
+    ("mln_diag_dgemm", C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, C.POINTER(_dbl)]),
 ]
 
 _lib = None
@@ -288,8 +290,18 @@ class Context:
                                               float(jitter), W.ctypes.data), jitter=jitter)
         return W
 
-    def fit_prepare(self, desc, x, landmarks, jitter, Lp=None):
-        return Fit(self, desc, x, landmarks, jitter, Lp)
+    def diag_peak(self, what, nbytes=1 << 32):
+        r = C.c_double()
+        self._check(self.lib.mln_diag_peak(self.handle, int(what), int(nbytes), C.byref(r)))
+        return r.value
+
+    def diag_dgemm(self, ta, tb, M, N, K, lower_only=0, split_k=1, reps=3):
+        r = C.c_double()
+        self._check(self.lib.mln_diag_dgemm(self.handle, ta, tb, M, N, K, lower_only, split_k, reps, C.byref(r)))
+        return r.value
+
+    def fit_prepare(self, desc, x, landmarks, jitter, Lp=None, implicit=False):
+        return Fit(self, desc, x, landmarks, jitter, Lp, implicit)
 
 
 def _as2d(a):
@@ -316,11 +328,13 @@ class Fit:
         ctx._check(self.lib.mln_fit_from_L(ctx.handle, _ptr(L), n, m, _ptr(Lp_), C.byref(h)))
         self.handle = h.value
         self.n, self.d, self.m, self.jitter = n, None, m, None
+        self.implicit = False
         self._has_lp = Lp_ is not None
         return self
 
-    def __init__(self, ctx, desc, x, landmarks, jitter, Lp=None):
+    def __init__(self, ctx, desc, x, landmarks, jitter, Lp=None, implicit=False):
         self.ctx, self.lib, self.handle = ctx, ctx.lib, None
+        self.implicit = bool(implicit) and landmarks is not None
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         n, d = x.shape
         xu = None if landmarks is None else (landmarks if isinstance(landmarks, DeviceArray) else _as2d(landmarks))
@@ -330,7 +344,7 @@ class Fit:
             raise ValueError(f"Lp has shape {Lp_.shape}, expected {(m, m)}")
         h = C.c_void_p()
         ctx._check(self.lib.mln_fit_prepare(ctx.handle, desc.ref, _ptr(x), n, d, _ptr(xu), m, float(jitter),
-                                            _ptr(Lp_), C.byref(h)), jitter=jitter)
+                                            _ptr(Lp_), 1 if self.implicit else 0, C.byref(h)), jitter=jitter)
         self.handle = h.value
         self.n, self.d, self.m, self.jitter = n, d, m, jitter
         self._has_lp = True
@@ -377,8 +391,8 @@ class Fit:
                                                _ptr(hess)))
         return (loss.value, grad, hess) if with_hess else (loss.value, grad)
 
-    def precond_build(self):
-        self.ctx._check(self.lib.mln_precond_build(self.handle), jitter="ridge")
+    def precond_build(self, row_stride=1):
+        self.ctx._check(self.lib.mln_precond_build(self.handle, int(row_stride)), jitter="ridge")
 
     def precond_apply(self, mode, v):
         """mode 0: u = C^T z; 1: z = C^-T u; 2: g_u = C^-1 g_z  (C C^T = L^T L + I)."""

@@ -60,6 +60,7 @@ class BaseEstimator:
         self.pre_transformation = None
         self.pre_transformation_std = None
         self.lbfgsb_options = None      # overrides of inference.LBFGSB_OPTIONS
+        self.implicit_factor = True     # False: materialise L = K Lp^-T on the device like the reference does
         self._fit = None                # mln_fit handle holding Lp and L
 
     def __str__(self):
@@ -162,8 +163,11 @@ class BaseEstimator:
             full = self.gp_type == GaussianProcessType.FULL or self.landmarks is None
             logger.info("Computing Lp.")
             xin = self.x if isinstance(self.x, _lib.DeviceArray) else np.ascontiguousarray(self.x)
+            # implicit mode: stream K = cov(x, landmarks) and fold Lp^-T into the m-vectors (no n x m
+            # triangular solve); the explicit factor is only needed for the diagonal Laplace.
             self._fit = ctx.fit_prepare(self.cov_func.lower(self.x.shape[1]), xin,
-                                        None if full else self.landmarks, self.jitter, Lp=Lp)
+                                        None if full else self.landmarks, self.jitter, Lp=Lp,
+                                        implicit=self.implicit_factor and not self.predictor_with_uncertainty)
         return self._fit
 
     def _compute_Lp(self):

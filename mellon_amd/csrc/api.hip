@@ -296,7 +296,7 @@ extern "C" int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank
 }
 
 static int dev_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
-  if (ctx->n_ranks <= 1 || count <= 0) return MLN_OK;
+  if (!ctx->comm || count <= 0) return MLN_OK;   // a 1-rank communicator still goes through RCCL
   int rc = rccl::AllReduce(dev, dev, (size_t)count, rccl::kDouble, rccl::kSum, ctx->comm, ctx->stream);
   if (rc != 0) return rccl_fail(ctx, rc, "ncclAllReduce");
   return MLN_OK;
@@ -304,7 +304,7 @@ static int dev_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
 
 extern "C" int mln_comm_allreduce_sum(mln_ctx* ctx, double* buf, int64_t count) {
   if (!ctx || (count > 0 && !buf)) return MLN_ERR_ARG;
-  if (ctx->n_ranks <= 1) return MLN_OK;
+  if (!ctx->comm) return MLN_OK;
   DevOut o;
   MLN_TRY(o.init(ctx, buf, (size_t)count, true));
   MLN_TRY(dev_allreduce(ctx, o.dev, count));
@@ -401,6 +401,11 @@ struct mln_fit {
   double *C = nullptr, *Cinv = nullptr;
   double *d_u = nullptr, *d_gu = nullptr, *d_tmp = nullptr;  // m ; m ; 1 + m
   int n_wg_cap = 0;
+  // implicit ("K-space") mode: the n x m buffer holds K = cov(x, xu) itself and Lp^-T is folded
+  // into the m-vectors:  L z = K (Lp^-T z),  L^T v = Lp^-1 (K^T v).  No n x m triangular solve.
+  bool kspace = false;
+  double* P = nullptr;    // Lp^-T C^-T  (m x ldl), so that  w = Lp^-T z = P u  for z = C^-T u
+  double* d_w = nullptr;  // m
 };
 
 static void fit_free(mln_fit* f) {
@@ -412,7 +417,7 @@ static void fit_free(mln_fit* f) {
   if (f->Lp) (void)mln_dfree(f->Lp);
   triinv_free(&f->tri);
   void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
-                  f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp};
+                  f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (f->h_z) (void)hipHostFree(f->h_z);
   if (f->h_out) (void)hipHostFree(f->h_out);
@@ -435,6 +440,7 @@ static int fit_alloc_workspace(mln_fit* f) {
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_u, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_gu, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_tmp, sizeof(double) * (1 + pm)));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_w, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_loss, sizeof(double) * n_wg));
@@ -448,7 +454,8 @@ static int fit_alloc_workspace(mln_fit* f) {
 }
 
 static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, int32_t d,
-                            const double* xu, int64_t m, double jitter, const double* Lp_in, mln_fit* f) {
+                            const double* xu, int64_t m, double jitter, const double* Lp_in, int32_t flags,
+                            mln_fit* f) {
   f->ctx = ctx;
   MLN_TRY(mln_lower_cov(ctx, cov, d, &f->cov));
   f->d = d; f->n = n; f->full = (xu == nullptr);
@@ -500,10 +507,14 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) fprintf(stderr, "[trace] L kernel matrix done at %.4f s\n", now_s() - t0);
     f->times[0] += now_s() - t0;
-    t0 = now_s();
-    MLN_TRY(triinv_solve_right_T(ctx, f->tri, f->L, n, f->ldl));
-    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    f->times[2] += now_s() - t0;
+    if (flags & MLN_FIT_IMPLICIT) {
+      f->kspace = true;  // keep K; Lp^-T is applied to m-vectors instead of to n rows
+    } else {
+      t0 = now_s();
+      MLN_TRY(triinv_solve_right_T(ctx, f->tri, f->L, n, f->ldl));
+      MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      f->times[2] += now_s() - t0;
+    }
   }
   MLN_TRY(fit_alloc_workspace(f));
   return MLN_OK;
@@ -511,13 +522,13 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
 
 extern "C" int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                                int32_t d, const double* xu, int64_t m, double jitter, const double* Lp_in,
-                               mln_fit** out) {
+                               int32_t flags, mln_fit** out) {
   if (!ctx || !out) return MLN_ERR_ARG;
   *out = nullptr;
   if (n_local < 0 || d < 1 || (n_local > 0 && !x)) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   mln_fit* f = new mln_fit();
-  int rc = fit_prepare_impl(ctx, cov, x, n_local, d, xu, m, jitter, Lp_in, f);
+  int rc = fit_prepare_impl(ctx, cov, x, n_local, d, xu, m, jitter, Lp_in, flags, f);
   if (rc != MLN_OK) { fit_free(f); return rc; }
   *out = f;
   return MLN_OK;
@@ -583,6 +594,16 @@ extern "C" int mln_fit_get_L(mln_fit* f, int64_t row0, int64_t n_rows, double* o
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevOut o;
   MLN_TRY(o.init(ctx, out, (size_t)n_rows * f->m));
+  if (f->kspace) {  // materialise the requested rows of L = K Lp^-T on demand
+    double* tmp = nullptr;
+    MLN_HIP(ctx, mln_dmalloc((void**)&tmp, sizeof(double) * (size_t)n_rows * f->ldl));
+    int rc = launch_copy_block(ctx, f->L + row0 * f->ldl, f->ldl, tmp, f->ldl, n_rows, f->ldl);
+    if (rc == MLN_OK) rc = triinv_solve_right_T(ctx, f->tri, tmp, n_rows, f->ldl);
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, tmp, f->ldl, o.dev, f->m, n_rows, f->m);
+    if (rc == MLN_OK) rc = o.commit();
+    (void)mln_dfree(tmp);
+    return rc;
+  }
   MLN_TRY(launch_copy_block(ctx, f->L + row0 * f->ldl, f->ldl, o.dev, f->m, n_rows, f->m));
   return o.commit();
 }
@@ -613,21 +634,37 @@ static ObjArgs obj_args(mln_fit* f) {
   return a;
 }
 
+static void obj_account(mln_fit* f) {
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->times[5] += 1e-3 * ms;
+  f->times[6] += 1.0;
+  f->times[7] = (double)f->n * (double)f->ldl * 8.0;
+}
+
+// In implicit mode the streamed matrix is K and the kernel's vector is w = Lp^-T z (device, m).
+static int fit_w_from_z(mln_fit* f, const double* z_dev, double* w_dev) {
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipMemcpyAsync(w_dev, z_dev, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
+  return triinv_solve_left_T(ctx, f->tri, w_dev, 1, 1);
+}
+
 extern "C" int mln_objective(mln_fit* f, const double* z, double* loss, double* grad, double* hess_diag) {
   if (!f || !z || !loss || !grad) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
+  if (hess_diag && f->kspace) {
+    mln_set_error(ctx, "the Hessian diagonal needs the explicit factor L: prepare the fit without MLN_FIT_IMPLICIT");
+    return MLN_ERR_UNSUPPORTED;
+  }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t m = f->m;
-  const bool zdev = is_device_ptr(z);
-  if (zdev) {
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_z, z, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_HIP(ctx, hipMemcpyAsync(f->h_z, z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
-  } else {
-    std::memcpy(f->h_z, z, sizeof(double) * m);
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_z, f->h_z, sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
-  }
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_z, z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
   ObjArgs a = obj_args(f);
+  if (f->kspace) {
+    MLN_TRY(fit_w_from_z(f, f->d_z, f->d_w));
+    a.z = f->d_w;
+  }
   if (hess_diag) a.part_hess = f->part_hess;
   const int64_t nout = 1 + m + (hess_diag ? m : 0);
   MLN_HIP(ctx, hipEventRecord(f->ev0, ctx->stream));
@@ -635,12 +672,10 @@ extern "C" int mln_objective(mln_fit* f, const double* z, double* loss, double* 
   MLN_HIP(ctx, hipEventRecord(f->ev1, ctx->stream));
   MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
   MLN_TRY(dev_allreduce(ctx, f->d_out, nout));
+  if (f->kspace) MLN_TRY(triinv_solve_left(ctx, f->tri, f->d_out + 1, 1, 1));   // L^T v = Lp^-1 (K^T v)
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->times[5] += 1e-3 * ms;
-  f->times[6] += 1.0;
-  f->times[7] = (double)f->n * (double)f->ldl * 8.0;
+  obj_account(f);
   // prior terms, added once (inference.py:45-46): 1/2 |z|^2 + (k/2) log 2 pi ; d/dz = z ; d2/dz2 = 1
   double zz = 0.0;
   for (int64_t j = 0; j < m; ++j) zz += f->h_z[j] * f->h_z[j];
@@ -669,36 +704,56 @@ extern "C" int mln_transform(mln_fit* f, const double* z, double mu, double* f_o
   DevOut o;
   MLN_TRY(o.init(ctx, f_out, (size_t)f->n));
   ObjArgs a = obj_args(f);
+  if (f->kspace) {
+    MLN_TRY(fit_w_from_z(f, f->d_z, f->d_w));
+    a.z = f->d_w;
+  }
   a.f_out = o.dev;
   a.mu = mu;
   MLN_TRY(launch_objective(ctx, a));
   return o.commit();
 }
 
-// G (m x ldg, lower + upper filled) = L^T L over this rank's rows, all-reduced.
-static int fit_gram(mln_fit* f, double* G, int64_t ldg) {
-  mln_ctx* ctx = f->ctx;
-  const int64_t m = f->m, n = f->n;
-  int split = (int)(n / 8192);
+// G (m x ldg, full symmetric) = alpha * A^T A for the row-major A (rows x m, leading dim lda), all-reduced.
+static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
+                   int64_t ldg) {
+  int split = (int)(rows / 8192);
   if (split < 1) split = 1;
   if (split > 16) split = 16;
   const size_t stride = (size_t)m * ldg;
   double* parts = nullptr;
   if (split > 1) MLN_HIP(ctx, mln_dmalloc((void**)&parts, sizeof(double) * stride * split));
   GemmArgs g{};
-  g.A = f->L; g.lda = f->ldl; g.B = f->L; g.ldb = f->ldl;
+  g.A = A; g.lda = lda; g.B = A; g.ldb = lda;
   g.C = (split > 1) ? parts : G; g.ldc = ldg;
-  g.M = m; g.N = m; g.K = n; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0; g.lower_only = 1;
+  g.M = m; g.N = m; g.K = rows; g.alpha = alpha; g.beta = 0.0; g.ta = 1; g.tb = 0; g.lower_only = 1;
   g.split_k = split; g.c_split_stride = (int64_t)stride;
   int rc = MLN_OK;
   if (split > 1) rc = (hipMemsetAsync(parts, 0, sizeof(double) * stride * split, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
   else rc = (hipMemsetAsync(G, 0, sizeof(double) * stride, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-  if (rc == MLN_OK && n > 0) rc = launch_dgemm(ctx, g);
+  if (rc == MLN_OK && rows > 0) rc = launch_dgemm(ctx, g);
   if (rc == MLN_OK && split > 1) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, G, (int64_t)stride, 0.0);
   if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
   if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)stride);
   (void)hipStreamSynchronize(ctx->stream);
   if (parts) (void)mln_dfree(parts);
+  return rc;
+}
+
+// G ~ L^T L from every `row_stride`-th cell of this rank (scaled by row_stride), all-reduced.
+static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
+  mln_ctx* ctx = f->ctx;
+  if (row_stride < 1) row_stride = 1;
+  const int64_t rows = (f->n + row_stride - 1) / row_stride;
+  if (!f->kspace) return gram_of(ctx, f->L, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);
+  // implicit mode: solve only the sampled rows, L_s = K_s Lp^-T
+  double* Ls = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)(rows > 0 ? rows : 1) * f->ldl));
+  int rc = launch_copy_block(ctx, f->L, f->ldl * row_stride, Ls, f->ldl, rows, f->ldl);
+  if (rc == MLN_OK) rc = triinv_solve_right_T(ctx, f->tri, Ls, rows, f->ldl);
+  if (rc == MLN_OK) rc = gram_of(ctx, Ls, f->ldl, rows, f->m, (double)row_stride, G, ldg);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(Ls);
   return rc;
 }
 
@@ -711,6 +766,7 @@ static int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev) {
   MLN_TRY(launch_objective(ctx, a));
   MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
   MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
+  if (f->kspace) MLN_TRY(triinv_solve_left(ctx, f->tri, f->d_out + 1, 1, 1));   // Lp^-1 (K^T t)
   MLN_HIP(ctx, hipMemcpyAsync(rhs_dev, f->d_out + 1, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
   return MLN_OK;
 }
@@ -718,14 +774,17 @@ static int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev) {
 // C C^T = L^T L + I and C^-1 (explicit, lower): the Ridge matrix of parameters.py:895-896 doubles as
 // the preconditioner of the MAP solve, because the MAP Hessian I + L^T diag(e^{f+V}) L equals it
 // wherever e^{f+V} = 1 (i.e. where f matches the nearest-neighbour estimate the Ridge regresses on).
-static int fit_build_precond(mln_fit* f) {
+// With row_stride > 1 the Gram is estimated from every row_stride-th cell: any SPD matrix is a valid
+// preconditioner / initial guess for a strictly convex problem, and ~8 m rows already give the same
+// iteration count as all n (measured), at 1/row_stride of the n m^2 flops.
+static int fit_build_precond(mln_fit* f, int64_t row_stride) {
   if (f->Cinv) return MLN_OK;
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
   const size_t bytes = sizeof(double) * (size_t)m * ldg;
   double t0 = now_s();
   MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
-  int rc = fit_gram(f, f->C, ldg);
+  int rc = fit_gram(f, f->C, ldg, row_stride);
   f->times[3] += now_s() - t0;
   t0 = now_s();
   if (rc == MLN_OK) rc = launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1
@@ -740,6 +799,13 @@ static int fit_build_precond(mln_fit* f) {
   }
   if (rc == MLN_OK) rc = launch_add_diag(ctx, inv, m, ldg, 1.0);
   if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg);   // C^-1 = C^-1 I
+  if (rc == MLN_OK && f->kspace) {                                  // P = Lp^-T C^-T
+    hipError_t e = mln_dmalloc((void**)&f->P, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(f->P, 0, bytes, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
+    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);
+    if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, f->P, m, ldg);
+  }
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&t);
   if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
@@ -747,8 +813,8 @@ static int fit_build_precond(mln_fit* f) {
   return rc;
 }
 
-// y (m) = Minv^T w  (trans = 1)  or  Minv w  (trans = 0) for an m x ldl lower matrix M, via the
-// streaming kernels of objective.hip (GEMV-T mode / f-only mode); all pointers on the device.
+// y (m) = M^T w  (trans = 1)  or  M w  (trans = 0) for an m x ldl matrix M, via the streaming kernels
+// of objective.hip (GEMV-T mode / f-only mode); all pointers on the device.
 static int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* w, double* y) {
   mln_ctx* ctx = f->ctx;
   ObjArgs a{};
@@ -770,17 +836,17 @@ static int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* 
   return MLN_OK;
 }
 
-extern "C" int mln_precond_build(mln_fit* f) {
+extern "C" int mln_precond_build(mln_fit* f, int64_t row_stride) {
   if (!f) return MLN_ERR_ARG;
   MLN_HIP(f->ctx, hipSetDevice(f->ctx->device));
-  return fit_build_precond(f);
+  return fit_build_precond(f, row_stride);
 }
 
 extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
   if (!f || !z0 || (f->n > 0 && !target)) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  MLN_TRY(fit_build_precond(f));
+  MLN_TRY(fit_build_precond(f, 1));   // exact Ridge unless a (subsampled) factor was built before
   double t0 = now_s();
   DevIn dt;
   MLN_TRY(dt.init(ctx, target, (size_t)f->n));
@@ -799,7 +865,7 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
   if (!f || !in || !out) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  MLN_TRY(fit_build_precond(f));
+  MLN_TRY(fit_build_precond(f, 1));
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, in, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
   if (mode == 0) MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));          // u = C^T z
   else if (mode == 1) MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_gu));  // z = C^-T u
@@ -812,31 +878,40 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
 
 // loss and gradient with respect to u, z = C^-T u; everything between the upload of u and the
 // download of (loss, grad_u, z) stays on the device.
+//   explicit mode: f = L z + mu,            g_u = C^-1 (z + L^T (a - 1))
+//   implicit mode: f = K (P u) + mu,        g_u = C^-1 z + P^T (K^T (a - 1)),   P = Lp^-T C^-T
 extern "C" int mln_objective_precond(mln_fit* f, const double* u, double* loss, double* grad_u, double* z_out) {
   if (!f || !u || !loss || !grad_u) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  MLN_TRY(fit_build_precond(f));
+  MLN_TRY(fit_build_precond(f, 1));
   const int64_t m = f->m;
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_z));                       // z = C^-T u
   ObjArgs a = obj_args(f);
+  if (f->kspace) {
+    MLN_TRY(fit_small_gemv(f, f->P, 0, f->d_u, f->d_w));                        // w = P u
+    a.z = f->d_w;
+  }
   MLN_HIP(ctx, hipEventRecord(f->ev0, ctx->stream));
   MLN_TRY(launch_objective(ctx, a));
   MLN_HIP(ctx, hipEventRecord(f->ev1, ctx->stream));
   MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
   MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + m));
-  MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_z, 1.0, f->d_out + 1));                // + z (prior)
-  MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));                // g_u = C^-1 g_z
+  if (f->kspace) {
+    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_z, f->d_gu));                    // C^-1 z
+    MLN_TRY(fit_small_gemv(f, f->P, 1, f->d_out + 1, f->d_w));                  // P^T r
+    MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_w, 1.0, f->d_gu));
+  } else {
+    MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_z, 1.0, f->d_out + 1));              // + z (prior)
+    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));              // g_u = C^-1 g_z
+  }
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->times[5] += 1e-3 * ms;
-  f->times[6] += 1.0;
-  f->times[7] = (double)f->n * (double)f->ldl * 8.0;
+  obj_account(f);
   double zz = 0.0;
   for (int64_t j = 0; j < m; ++j) zz += f->h_z[j] * f->h_z[j];
   *loss = f->h_out[0] + 0.5 * zz + 0.5 * (double)m * std::log(2.0 * M_PI);
@@ -957,7 +1032,7 @@ extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const 
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   // A^T = cov(x, xu) Lp^-T is exactly the factor L of the density path   conditional.py:516-522
   mln_fit* f = nullptr;
-  MLN_TRY(mln_fit_prepare(ctx, cov, x, n_local, d, xu, m, jitter, nullptr, &f));
+  MLN_TRY(mln_fit_prepare(ctx, cov, x, n_local, d, xu, m, jitter, nullptr, 0, &f));
   const int64_t ldg = pad16(m), n = n_local;
   const double s2 = sigma * sigma;
   double *G = nullptr, *R = nullptr, *C = nullptr, *parts = nullptr;
@@ -983,7 +1058,7 @@ extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const 
     }
   }
   // LBB = A A^T / sigma^2 + I                                      conditional.py:62 (stabilize(.., 1))
-  if (rc == MLN_OK) rc = fit_gram(f, G, ldg);
+  if (rc == MLN_OK) rc = fit_gram(f, G, ldg, 1);
   if (rc == MLN_OK) rc = launch_axpby(ctx, m * ldg, 0.0, G, 1.0 / s2, G);
   if (rc == MLN_OK) rc = launch_add_diag(ctx, G, m, ldg, 1.0);
   if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, G, m, ldg);

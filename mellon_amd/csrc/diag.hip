@@ -1,0 +1,117 @@
+// Diagnostics exported through the C ABI: device microbenchmarks used to state rooflines from
+// measurement (fp64 MFMA issue rate, HBM read bandwidth) and to time the GEMM kernel in isolation.
+#include <vector>
+
+#include "mln_internal.h"
+
+namespace {
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_mfma_f64_peak(double* out, int iters, double seed) {
+  v4d acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (v4d){seed, 0.0, 0.0, 0.0};
+  double a = seed + threadIdx.x * 1e-9, b = seed - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) out[0] = s;  // keep the chain live
+}
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(512) void k_hbm_read(const d2* __restrict__ p, int64_t n2, double* out) {
+  d2 s = (d2){0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    d2 v = __builtin_nontemporal_load(p + i);
+    s.x += v.x;
+    s.y += v.y;
+  }
+  if (s.x + s.y == 123.456) out[0] = s.x;
+}
+}  // namespace
+
+// what: 0 = fp64 MFMA peak (TFLOP/s), 1 = HBM streaming read (GB/s over `bytes`)
+extern "C" int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result) {
+  if (!ctx || !result) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  hipEvent_t e0, e1;
+  MLN_HIP(ctx, hipEventCreate(&e0));
+  MLN_HIP(ctx, hipEventCreate(&e1));
+  double* out = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&out, 64));
+  float ms = 0.f;
+  if (what == 0) {
+    const int iters = 4000, grid = ctx->n_cu * 2;
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(grid), dim3(256), 0, ctx->stream, out, 10, 1.0);
+    MLN_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(grid), dim3(256), 0, ctx->stream, out, iters, 1.0);
+    MLN_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MLN_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)grid * 4.0 * iters * 8.0 * 2.0 * 16 * 16 * 4;
+    *result = flops / (ms * 1e-3) / 1e12;
+  } else {
+    if (bytes < (1 << 20)) bytes = 1 << 20;
+    double* buf = nullptr;
+    MLN_HIP(ctx, mln_dmalloc((void**)&buf, (size_t)bytes));
+    MLN_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)bytes, ctx->stream));
+    const int grid = ctx->n_cu * 4;
+    hipLaunchKernelGGL(k_hbm_read, dim3(grid), dim3(512), 0, ctx->stream, (const d2*)buf, bytes / 16, out);
+    MLN_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(k_hbm_read, dim3(grid), dim3(512), 0, ctx->stream, (const d2*)buf, bytes / 16, out);
+    MLN_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MLN_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *result = (double)bytes / (ms * 1e-3) / 1e9;
+    (void)mln_dfree(buf);
+  }
+  (void)mln_dfree(out);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return MLN_OK;
+}
+
+// Times C = op(A) op(B) on random-free (zero-initialised + diagonal) device data; returns ms per call.
+extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
+                              int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out) {
+  if (!ctx || !ms_out || M < 1 || N < 1 || K < 1 || reps < 1) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t lda = ((ta ? M : K) + 15) / 16 * 16, ldb = ((tb ? K : N) + 15) / 16 * 16, ldc = (N + 15) / 16 * 16;
+  const size_t a_bytes = sizeof(double) * (size_t)(ta ? K : M) * lda, b_bytes = sizeof(double) * (size_t)(tb ? N : K) * ldb;
+  const int split = split_k > 1 ? split_k : 1;
+  const size_t c_bytes = sizeof(double) * (size_t)M * ldc * split;
+  double *A = nullptr, *B = nullptr, *Cm = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&A, a_bytes));
+  MLN_HIP(ctx, mln_dmalloc((void**)&B, b_bytes));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Cm, c_bytes));
+  // non-trivial data: fill with a repeating host pattern (random-like, avoids the zero-data DVFS bonus)
+  std::vector<double> pat(1 << 20);
+  unsigned long long s = 88172645463325252ULL;
+  for (auto& v : pat) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
+  for (size_t off = 0; off < a_bytes; off += pat.size() * 8)
+    MLN_HIP(ctx, hipMemcpyAsync((char*)A + off, pat.data(), std::min(pat.size() * 8, a_bytes - off), hipMemcpyHostToDevice, ctx->stream));
+  for (size_t off = 0; off < b_bytes; off += pat.size() * 8)
+    MLN_HIP(ctx, hipMemcpyAsync((char*)B + off, pat.data(), std::min(pat.size() * 8, b_bytes - off), hipMemcpyHostToDevice, ctx->stream));
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = Cm; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.alpha = 1.0; g.beta = 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
+  g.c_split_stride = (int64_t)M * ldc;
+  hipEvent_t e0, e1;
+  MLN_HIP(ctx, hipEventCreate(&e0));
+  MLN_HIP(ctx, hipEventCreate(&e1));
+  MLN_TRY(launch_dgemm(ctx, g));
+  MLN_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int r = 0; r < reps; ++r) MLN_TRY(launch_dgemm(ctx, g));
+  MLN_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  MLN_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / reps;
+  (void)mln_dfree(A); (void)mln_dfree(B); (void)mln_dfree(Cm);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return MLN_OK;
+}

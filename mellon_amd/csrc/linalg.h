@@ -15,3 +15,4 @@ int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64
 int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb);   // B <- Lf^-T B
 int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows,
                       int64_t cols);
+int launch_transpose(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m);  // dst = src^T (m x m)

@@ -168,7 +168,30 @@ __global__ void k_copy_block(const double* __restrict__ src, int64_t lds, double
   if (i < rows && j < cols) dst[i * ldd + j] = src[i * lds + j];
 }
 
+__global__ void k_transpose(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd,
+                            int64_t m) {
+  __shared__ double tile[32][33];
+  const int64_t bx = (int64_t)blockIdx.x * 32, by = (int64_t)blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int64_t i = by + r, j = bx + threadIdx.x;
+    tile[r][threadIdx.x] = (i < m && j < m) ? src[i * lds + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int64_t i = bx + r, j = by + threadIdx.x;
+    if (i < m && j < m) dst[i * ldd + j] = tile[threadIdx.x][r];
+  }
+}
+
 }  // namespace
+
+int launch_transpose(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m) {
+  if (m <= 0) return MLN_OK;
+  const unsigned t = (unsigned)((m + 31) / 32);
+  hipLaunchKernelGGL(k_transpose, dim3(t, t), dim3(32, 8), 0, ctx->stream, src, lds, dst, ldd, m);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
 
 int launch_add_diag(mln_ctx* ctx, double* A, int64_t m, int64_t lda, double v) {
   if (m <= 0) return MLN_OK;

@@ -83,7 +83,9 @@ class LossFunc:
             raise ValueError(f"{V.shape[0]} nearest-neighbour distances for {self.fit.n} rows of L")
         self.fit.set_likelihood(V, Vdr, transform.mu)
         self.n_eval = 0
-        self.preconditioned = True     # optimise u with z = C^-T u, C C^T = L^T L + I (see minimize_lbfgsb)
+        self.preconditioned = True     # optimise u with z = C^-T u, C C^T ~ L^T L + I (see minimize_lbfgsb)
+        from .parameters import ridge_row_stride
+        self.fit.precond_build(ridge_row_stride(self.fit.n, self.fit.m))   # no-op if the Ridge init built it
 
     def value_and_grad(self, z):
         self.n_eval += 1
@@ -102,6 +104,9 @@ class LossFunc:
         return self.fit.precond_apply(1, u)
 
     def hessian_diagonal(self, z):
+        if getattr(self.fit, "implicit", False):
+            raise NotImplementedError("the Hessian diagonal needs the explicit factor L "
+                                      "(fit prepared with implicit=False; predictor_with_uncertainty does this)")
         return self.fit.objective(z, with_hess=True)[2]
 
     def __call__(self, z):

@@ -283,3 +283,86 @@ def test_preconditioned_objective(ctx):
     assert abs(loss_u - loss_z) <= 1e-12 * abs(loss_z)
     assert relmax(grad_u, sla.solve_triangular(C, grad_z, lower=True)) < 1e-8
     assert relmax(fit.precond_apply(2, grad_z), sla.solve_triangular(C, grad_z, lower=True)) < 1e-8
+
+
+def test_implicit_mode_matches_explicit(ctx):
+    """MLN_FIT_IMPLICIT streams K and folds Lp^-T into the m-vectors: every quantity must agree
+    with the explicit-L handle (same maths, different association)."""
+    from mellon_amd import cov
+    n, d, m = 9000, 15, 400
+    x, nn, ls, mu, xu = _problem(n, d, m, seed=91)
+    c = cov.Matern52(ls)
+    V, Vdr = mo.nn_likelihood_constants(nn, d)
+    target = mo.mle(nn, d) - mu
+    fe = ctx.fit_prepare(c.lower(d), x, xu, 1e-6)
+    fi = ctx.fit_prepare(c.lower(d), x, xu, 1e-6, implicit=True)
+    assert fi.stage_times()["trsm_s"] == 0.0
+    assert relmax(fi.L(100, 700), fe.L(100, 700)) < 1e-9              # rows materialised on demand
+    for f in (fe, fi):
+        f.set_likelihood(V, Vdr, mu)
+    z0e, z0i = fe.ridge_init(target), fi.ridge_init(target)
+    assert relmax(z0i, z0e) < 1e-6
+    z = z0e + 0.01 * np.random.default_rng(0).normal(size=m)
+    (le, ge), (li, gi) = fe.objective(z), fi.objective(z)
+    assert abs(li - le) < 1e-10 * abs(le) and relmax(gi, ge) < 1e-7
+    assert relmax(fi.transform(z, mu), fe.transform(z, mu)) < 1e-9
+    u = fe.precond_apply(0, z)
+    lue, gue, ze = fe.objective_precond(u)
+    lui, gui, zi = fi.objective_precond(fi.precond_apply(0, z))
+    assert abs(lui - lue) < 1e-9 * abs(lue) and relmax(gui, gue) < 1e-6 and relmax(zi, ze) < 1e-7
+    with pytest.raises(NotImplementedError):
+        fi.objective(z, with_hess=True)
+
+
+def test_subsampled_gram_preconditioner(ctx):
+    """A Gram from every k-th cell is a valid preconditioner: same optimum, similar pass count."""
+    from mellon_amd import cov
+    n, d, m = 40000, 10, 200
+    x, nn, ls, mu, xu = _problem(n, d, m, seed=17)
+    c = cov.Matern52(ls)
+    V, Vdr = mo.nn_likelihood_constants(nn, d)
+    opts = dict(maxiter=5000, maxcor=30, ftol=1e-13, gtol=1e-7)
+    out = []
+    for stride in (1, 20):
+        f = ctx.fit_prepare(c.lower(d), x, xu, 1e-6, implicit=True)
+        f.set_likelihood(V, Vdr, mu)
+        f.precond_build(stride)
+        z0 = f.ridge_init(mo.mle(nn, d) - mu)
+        calls = []
+        def fun(u, f=f, calls=calls):
+            l, g, z = f.objective_precond(u)
+            calls.append(z)
+            return l, g
+        res = mo.minimize_lbfgsb(fun, f.precond_apply(0, z0), opts)
+        out.append((f.transform(f.precond_apply(1, res.pre_transformation), mu), res.n_eval))
+    (fa, ea), (fb, eb) = out
+    assert relmax(fb, fa) < 1e-6
+    assert eb <= ea + 10
+
+
+def test_rccl_single_rank_communicator():
+    """The RCCL binding (dlopen, ncclGetUniqueId / CommInitRank / AllReduce, fp64 sum) on one GPU:
+    a 1-rank communicator must leave every result unchanged.  Uses its own context."""
+    from mellon_amd import _lib, cov
+    c2 = _lib.Context(0)
+    try:
+        uid = c2.comm_unique_id()
+        assert len(uid) == 128
+        c2.comm_init(uid, 1, 0)
+        v = np.arange(7.0)
+        assert np.array_equal(c2.allreduce_sum(v), v)
+        n, d, m = 3000, 6, 64
+        x, nn, ls, mu, xu = _problem(n, d, m, seed=8)
+        kern = cov.Matern52(ls)
+        V, Vdr = mo.nn_likelihood_constants(nn, d)
+        a = c2.fit_prepare(kern.lower(d), x, xu, 1e-6, implicit=True)
+        b = _lib.default_context().fit_prepare(kern.lower(d), x, xu, 1e-6, implicit=True)
+        for f in (a, b):
+            f.set_likelihood(V, Vdr, mu)
+        za, zb = a.ridge_init(mo.mle(nn, d) - mu), b.ridge_init(mo.mle(nn, d) - mu)
+        assert np.array_equal(za, zb)
+        (la, ga), (lb, gb) = a.objective(za), b.objective(zb)
+        assert la == lb and np.array_equal(ga, gb)
+        a.close()
+    finally:
+        c2.close()
