@@ -179,6 +179,22 @@ int mln_fit_set_likelihood(mln_fit* fit, const double* V, const double* Vdr, dou
 int mln_objective(mln_fit* fit, const double* z, double* loss, double* grad /* m */,
                   double* hess_diag /* m or NULL */);
 
+/* a-8: the MAP solve.  inference.minimize_lbfgsb (inference.py:272-288) is SciPy's L-BFGS-B without
+ * bounds behind jaxopt.ScipyMinimize; this is the same limited-memory BFGS with the same stopping
+ * tests (relative loss decrease <= ftol, max|grad| <= gtol, maxiter), run inside the library on the
+ * preconditioned variable so that one evaluation = one device pass with no host framework in between.
+ * status: 0 converged, 1 maxiter, 2 line search failed.                                         */
+typedef struct {
+  int32_t maxiter; /* 5000  */
+  int32_t maxcor;  /* 30    L-BFGS memory            */
+  int32_t maxls;   /* 30    line-search evaluations  */
+  double ftol;     /* 1e-13 (SciPy default 2.2e-9 leaves the log-density ~5e-5 off the optimum) */
+  double gtol;     /* 1e-7  on the preconditioned gradient */
+} mln_solver_opts;
+int mln_map_solve(mln_fit* fit, const double* z0, const mln_solver_opts* opts /* NULL = defaults */,
+                  double* z_out /* m */, double* loss_out, int32_t* n_eval_out, int32_t* n_iter_out,
+                  int32_t* status_out);
+
 /* a-11: f = L z + mu on this shard (inference.py:51-69,341-354).                                */
 int mln_transform(mln_fit* fit, const double* z, double mu, double* f_out /* n_local */);
 

@@ -34,6 +34,11 @@ class Tok(C.Structure):
     _fields_ = [("op", C.c_int32), ("leaf", C.c_int32), ("value", C.c_double)]
 
 
+class SolverOpts(C.Structure):
+    _fields_ = [("maxiter", C.c_int32), ("maxcor", C.c_int32), ("maxls", C.c_int32), ("ftol", C.c_double),
+                ("gtol", C.c_double)]
+
+
 class KernelDesc(C.Structure):
     _fields_ = [("n_leaves", C.c_int32), ("n_toks", C.c_int32), ("leaves", C.POINTER(Leaf)),
                 ("toks", C.POINTER(Tok))]
@@ -69,6 +74,8 @@ SYMBOLS = [
     ("mln_precond_build", C.c_int, [_vp, _i64]),
     ("mln_precond_apply", C.c_int, [_vp, _i32, _dp, _dp]),
     ("mln_objective_precond", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
+    ("mln_map_solve", C.c_int, [_vp, _dp, C.POINTER(SolverOpts), _dp, C.POINTER(_dbl), C.POINTER(_i32),
+                                C.POINTER(_i32), C.POINTER(_i32)]),
     ("mln_fit_set_likelihood", C.c_int, [_vp, _dp, _dp, _dbl]),
     ("mln_objective", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
     ("mln_transform", C.c_int, [_vp, _dp, _dbl, _dp]),
@@ -411,6 +418,17 @@ class Fit:
         self.ctx._check(self.lib.mln_objective_precond(self.handle, u.ctypes.data, C.byref(loss), grad.ctypes.data,
                                                        z.ctypes.data), jitter="ridge")
         return loss.value, grad, z
+
+    def map_solve(self, z0, maxiter=5000, maxcor=30, maxls=30, ftol=1e-13, gtol=1e-7):
+        """In-library L-BFGS on the preconditioned variable; returns (z, loss, n_eval, n_iter, status)."""
+        z0 = _f64(z0)
+        opts = SolverOpts(int(maxiter), int(maxcor), int(maxls), float(ftol), float(gtol))
+        z = np.empty(self.m, dtype=np.float64)
+        loss, nev, nit, st = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.ctx._check(self.lib.mln_map_solve(self.handle, z0.ctypes.data, C.byref(opts), z.ctypes.data,
+                                               C.byref(loss), C.byref(nev), C.byref(nit), C.byref(st)),
+                        jitter="ridge")
+        return z, loss.value, nev.value, nit.value, st.value
 
     def transform(self, z, mu, out=None):
         z = _f64(z)

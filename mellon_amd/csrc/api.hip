@@ -880,12 +880,8 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
 // download of (loss, grad_u, z) stays on the device.
 //   explicit mode: f = L z + mu,            g_u = C^-1 (z + L^T (a - 1))
 //   implicit mode: f = K (P u) + mu,        g_u = C^-1 z + P^T (K^T (a - 1)),   P = Lp^-T C^-T
-extern "C" int mln_objective_precond(mln_fit* f, const double* u, double* loss, double* grad_u, double* z_out) {
-  if (!f || !u || !loss || !grad_u) return MLN_ERR_ARG;
+static int fit_objective_u(mln_fit* f, const double* u, double* loss, double* grad_u, double* z_out) {
   mln_ctx* ctx = f->ctx;
-  if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
-  MLN_HIP(ctx, hipSetDevice(ctx->device));
-  MLN_TRY(fit_build_precond(f, 1));
   const int64_t m = f->m;
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_z));                       // z = C^-T u
@@ -917,6 +913,121 @@ extern "C" int mln_objective_precond(mln_fit* f, const double* u, double* loss, 
   *loss = f->h_out[0] + 0.5 * zz + 0.5 * (double)m * std::log(2.0 * M_PI);
   std::memcpy(grad_u, f->h_out + 1, sizeof(double) * m);
   if (z_out) std::memcpy(z_out, f->h_z, sizeof(double) * m);
+  return MLN_OK;
+}
+
+extern "C" int mln_objective_precond(mln_fit* f, const double* u, double* loss, double* grad_u, double* z_out) {
+  if (!f || !u || !loss || !grad_u) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_build_precond(f, 1));
+  return fit_objective_u(f, u, loss, grad_u, z_out);
+}
+
+// ---- a-8: the MAP solve, host-driven L-BFGS on the device objective ---------------------------------
+// Reference: inference.minimize_lbfgsb (inference.py:272-288) = SciPy L-BFGS-B without bounds.  Same
+// method (limited-memory BFGS two-loop recursion, H0 = s.y / y.y, sufficient-decrease line search
+// starting at step 1) and the same stopping tests as SciPy (relative decrease <= ftol, max|g| <= gtol,
+// maxiter), run on the preconditioned variable u.  The m-vectors live on the host (m <= 8192: the
+// two-loop recursion is microseconds); each evaluation is one fused pass over the n x m buffer.
+static double vdot(const std::vector<double>& a, const std::vector<double>& b) {
+  double s = 0.0;
+  for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
+  return s;
+}
+
+extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts* opts_in, double* z_out,
+                             double* loss_out, int32_t* n_eval_out, int32_t* n_iter_out, int32_t* status_out) {
+  if (!f || !z0 || !z_out) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_build_precond(f, 1));
+  mln_solver_opts o = {5000, 30, 30, 1e-13, 1e-7};
+  if (opts_in) o = *opts_in;
+  if (o.maxcor < 1) o.maxcor = 1;
+  const size_t m = (size_t)f->m;
+  std::vector<double> u(m), g(m), un(m), gn(m), d(m), q(m), z(m);
+  // u0 = C^T z0
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_u, z0, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
+  MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));
+  MLN_HIP(ctx, hipMemcpyAsync(u.data(), f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double fx = 0.0;
+  int n_eval = 0, it = 0, status = 1;
+  MLN_TRY(fit_objective_u(f, u.data(), &fx, g.data(), z.data()));
+  ++n_eval;
+  std::vector<std::vector<double>> S, Y;
+  std::vector<double> rho, alpha;
+  for (; it < o.maxiter; ++it) {
+    double gmax = 0.0;
+    for (double v : g) gmax = std::fmax(gmax, std::fabs(v));
+    if (!(gmax > o.gtol)) { status = 0; break; }
+    // two-loop recursion
+    q = g;
+    const int k = (int)S.size();
+    alpha.assign(k, 0.0);
+    for (int i = k - 1; i >= 0; --i) {
+      alpha[i] = rho[i] * vdot(S[i], q);
+      for (size_t j = 0; j < m; ++j) q[j] -= alpha[i] * Y[i][j];
+    }
+    if (k > 0) {
+      const double gamma = vdot(S[k - 1], Y[k - 1]) / vdot(Y[k - 1], Y[k - 1]);
+      for (size_t j = 0; j < m; ++j) q[j] *= gamma;
+    }
+    for (int i = 0; i < k; ++i) {
+      const double beta = rho[i] * vdot(Y[i], q);
+      for (size_t j = 0; j < m; ++j) q[j] += S[i][j] * (alpha[i] - beta);
+    }
+    for (size_t j = 0; j < m; ++j) d[j] = -q[j];
+    double gd = vdot(g, d);
+    if (!(gd < 0.0)) {  // not a descent direction (cannot happen for SPD pairs; guard anyway)
+      S.clear(); Y.clear(); rho.clear();
+      for (size_t j = 0; j < m; ++j) d[j] = -g[j];
+      gd = -vdot(g, g);
+    }
+    double t = 1.0;
+    if (S.empty()) {
+      double g1 = 0.0;
+      for (double v : g) g1 += std::fabs(v);
+      t = std::fmin(1.0, 1.0 / g1);
+    }
+    bool ok = false;
+    double fn = 0.0;
+    for (int ls = 0; ls < o.maxls; ++ls) {
+      for (size_t j = 0; j < m; ++j) un[j] = u[j] + t * d[j];
+      MLN_TRY(fit_objective_u(f, un.data(), &fn, gn.data(), z.data()));
+      ++n_eval;
+      if (std::isfinite(fn) && fn <= fx + 1e-4 * t * gd) { ok = true; break; }
+      if (std::isfinite(fn)) {
+        const double tq = -gd * t * t / (2.0 * (fn - fx - gd * t));   // minimiser of the quadratic model
+        t = std::fmin(std::fmax(tq, 0.1 * t), 0.5 * t);
+      } else {
+        t *= 0.1;
+      }
+    }
+    if (!ok) { status = 2; break; }
+    std::vector<double> s(m), y(m);
+    for (size_t j = 0; j < m; ++j) { s[j] = un[j] - u[j]; y[j] = gn[j] - g[j]; }
+    const double sy = vdot(s, y);
+    const double f_old = fx;
+    u.swap(un); g.swap(gn); fx = fn;
+    if (sy > 1e-10 * std::sqrt(vdot(s, s) * vdot(y, y))) {
+      S.push_back(std::move(s)); Y.push_back(std::move(y)); rho.push_back(1.0 / sy);
+      if ((int)S.size() > o.maxcor) { S.erase(S.begin()); Y.erase(Y.begin()); rho.erase(rho.begin()); }
+    }
+    if ((f_old - fx) <= o.ftol * std::fmax(std::fmax(std::fabs(f_old), std::fabs(fx)), 1.0)) { status = 0; ++it; break; }
+  }
+  // z = C^-T u at the accepted point
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u.data(), sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
+  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_z));
+  MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (loss_out) *loss_out = fx;
+  if (n_eval_out) *n_eval_out = n_eval;
+  if (n_iter_out) *n_iter_out = it;
+  if (status_out) *status_out = status;
   return MLN_OK;
 }
 

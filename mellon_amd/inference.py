@@ -84,6 +84,7 @@ class LossFunc:
         self.fit.set_likelihood(V, Vdr, transform.mu)
         self.n_eval = 0
         self.preconditioned = True     # optimise u with z = C^-T u, C C^T ~ L^T L + I (see minimize_lbfgsb)
+        self.native_solver = True      # L-BFGS inside the library; False: SciPy L-BFGS-B drives the device objective
         from .parameters import ridge_row_stride
         self.fit.precond_build(ridge_row_stride(self.fit.n, self.fit.m))   # no-op if the Ridge init built it
 
@@ -126,9 +127,17 @@ def minimize_lbfgsb(loss_func, initial_value, jit=DEFAULT_JIT, options=None):
     Results = namedtuple("Results", "pre_transformation opt_state loss")
     z0 = np.asarray(initial_value, dtype=np.float64)
     if getattr(loss_func, "preconditioned", False):
-        # Same optimiser, same objective, better-conditioned variable: z = C^-T u with
-        # C C^T = L^T L + I (the Ridge matrix = the MAP Hessian where e^{f+V} = 1).  The optimum is
+        # Same method, same objective, better-conditioned variable: z = C^-T u with
+        # C C^T ~ L^T L + I (the Ridge matrix = the MAP Hessian where e^{f+V} = 1).  The optimum is
         # unique (strict convexity), so this only changes how many passes over L it takes (~10x fewer).
+        if loss_func.native_solver:
+            # L-BFGS inside libmellon_hip.so (mln_map_solve): one device pass per evaluation, no
+            # Python / SciPy between evaluations
+            z, loss, n_eval, n_iter, status = loss_func.fit.map_solve(
+                z0, maxiter=opts["maxiter"], maxcor=opts["maxcor"], ftol=opts["ftol"], gtol=opts["gtol"])
+            loss_func.n_eval += n_eval
+            State = namedtuple("State", "fun_val nfev nit status success")
+            return Results(z, State(loss, n_eval, n_iter, status, status == 0), float(loss))
         res = _sp_minimize(loss_func.value_and_grad_u, loss_func.u_from_z(z0), jac=True, method="L-BFGS-B",
                            options=opts)
         return Results(loss_func.z_from_u(res.x), res, float(res.fun))

@@ -236,3 +236,27 @@ def test_full_size_properties_c2(mellon):
     loss0, _ = est.loss_func.value_and_grad(est.initial_value)
     loss1, g1 = est.loss_func.value_and_grad(est.pre_transformation)
     assert loss1 < loss0 and np.abs(g1).max() < 1e-2 * max(1.0, np.abs(est.pre_transformation).max())
+
+
+def test_native_and_scipy_solvers_agree(mellon):
+    """mln_map_solve (in-library L-BFGS) and SciPy L-BFGS-B on the device objective reach the same
+    unique optimum; the unpreconditioned explicit-L route (the reference's formulation) too."""
+    x = mo.gaussian_mixture(6000, 8, seed=31)
+    nn = mo.exact_nn_distances(x)
+    lm = mo.compute_landmarks(x[:3000], mo.SPARSE_CHOLESKY, 150, 42)
+    ref = mo.density_fit(x, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT).log_density_x
+    outs = {}
+    for name in ("native", "scipy", "plain"):
+        est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn)
+        if name == "plain":
+            est.implicit_factor = False
+        est.prepare_inference(x)
+        est.loss_func.native_solver = (name == "native")
+        if name == "plain":
+            est.loss_func.preconditioned = False
+        est.run_inference()
+        outs[name] = (est.process_inference(build_predict=False), est.loss_func.n_eval)
+    for name, (dens, n_eval) in outs.items():
+        assert rel_max(dens, ref) < 1e-5, name
+    assert outs["native"][1] < outs["plain"][1] / 2          # preconditioning pays
+    assert rel_max(outs["native"][0], outs["scipy"][0]) < 1e-6
