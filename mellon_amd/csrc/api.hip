@@ -406,6 +406,10 @@ struct mln_fit {
   bool kspace = false;
   double* P = nullptr;    // Lp^-T C^-T  (m x ldl), so that  w = Lp^-T z = P u  for z = C^-T u
   double* d_w = nullptr;  // m
+  // last vector pair (z, w = Lp^-T z) produced by the library itself (Ridge init / MAP solve): lets
+  // mln_transform / mln_weights_cholesky on that same z skip the triangular solve
+  std::vector<double> z_cached;
+  double* d_w_cached = nullptr;
 };
 
 static void fit_free(mln_fit* f) {
@@ -417,7 +421,7 @@ static void fit_free(mln_fit* f) {
   if (f->Lp) (void)mln_dfree(f->Lp);
   triinv_free(&f->tri);
   void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
-                  f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w};
+                  f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w, f->d_w_cached};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (f->h_z) (void)hipHostFree(f->h_z);
   if (f->h_out) (void)hipHostFree(f->h_out);
@@ -441,6 +445,7 @@ static int fit_alloc_workspace(mln_fit* f) {
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_gu, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_tmp, sizeof(double) * (1 + pm)));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_w, sizeof(double) * pm));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_w_cached, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_loss, sizeof(double) * n_wg));
@@ -634,6 +639,8 @@ static ObjArgs obj_args(mln_fit* f) {
   return a;
 }
 
+static int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* w, double* y);
+
 static void obj_account(mln_fit* f) {
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, f->ev0, f->ev1) == hipSuccess) f->times[5] += 1e-3 * ms;
@@ -642,10 +649,26 @@ static void obj_account(mln_fit* f) {
 }
 
 // In implicit mode the streamed matrix is K and the kernel's vector is w = Lp^-T z (device, m).
-static int fit_w_from_z(mln_fit* f, const double* z_dev, double* w_dev) {
+// `z_host` (may be NULL) is the caller's host copy of z, used to recognise the cached pair.
+static int fit_w_from_z(mln_fit* f, const double* z_dev, double* w_dev, const double* z_host = nullptr) {
   mln_ctx* ctx = f->ctx;
+  if (z_host && f->z_cached.size() == (size_t)f->m &&
+      std::memcmp(z_host, f->z_cached.data(), sizeof(double) * f->m) == 0) {
+    MLN_HIP(ctx, hipMemcpyAsync(w_dev, f->d_w_cached, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
+    return MLN_OK;
+  }
   MLN_HIP(ctx, hipMemcpyAsync(w_dev, z_dev, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
   return triinv_solve_left_T(ctx, f->tri, w_dev, 1, 1);
+}
+
+// remember (z, w) computed from the preconditioned variable: z = C^-T u (d_z), w = P u
+static int fit_cache_pair_from_u(mln_fit* f, const double* u_dev) {
+  mln_ctx* ctx = f->ctx;
+  f->z_cached.assign((size_t)f->m, 0.0);
+  MLN_HIP(ctx, hipMemcpyAsync(f->z_cached.data(), f->d_z, sizeof(double) * f->m, hipMemcpyDeviceToHost, ctx->stream));
+  if (f->kspace) MLN_TRY(fit_small_gemv(f, f->P, 0, u_dev, f->d_w_cached));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
 }
 
 extern "C" int mln_objective(mln_fit* f, const double* z, double* loss, double* grad, double* hess_diag) {
@@ -705,7 +728,7 @@ extern "C" int mln_transform(mln_fit* f, const double* z, double mu, double* f_o
   MLN_TRY(o.init(ctx, f_out, (size_t)f->n));
   ObjArgs a = obj_args(f);
   if (f->kspace) {
-    MLN_TRY(fit_w_from_z(f, f->d_z, f->d_w));
+    MLN_TRY(fit_w_from_z(f, f->d_z, f->d_w, is_device_ptr(z) ? nullptr : z));
     a.z = f->d_w;
   }
   a.f_out = o.dev;
@@ -850,11 +873,22 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
   double t0 = now_s();
   DevIn dt;
   MLN_TRY(dt.init(ctx, target, (size_t)f->n));
-  // z0 = (L^T L + I)^-1 L^T t = C^-T C^-1 (L^T t)
-  MLN_TRY(fit_gemvT(f, dt.dev, f->d_u));
-  MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_u, f->d_gu));
-  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_gu, f->d_u));
-  MLN_HIP(ctx, hipMemcpyAsync(z0, f->d_u, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  // z0 = (L^T L + I)^-1 L^T t = C^-T C^-1 (L^T t);  implicit mode: C^-1 L^T t = P^T (K^T t)
+  if (f->kspace) {
+    ObjArgs a = obj_args(f);
+    a.weights = dt.dev;
+    a.part_loss = nullptr;
+    MLN_TRY(launch_objective(ctx, a));
+    MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+    MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
+    MLN_TRY(fit_small_gemv(f, f->P, 1, f->d_out + 1, f->d_gu));
+  } else {
+    MLN_TRY(fit_gemvT(f, dt.dev, f->d_u));
+    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_u, f->d_gu));
+  }
+  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_gu, f->d_z));       // z0 = C^-T (.)   [d_gu plays the role of u0]
+  MLN_TRY(fit_cache_pair_from_u(f, f->d_gu));
+  MLN_HIP(ctx, hipMemcpyAsync(z0, f->d_z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   f->times[4] += now_s() - t0;
   return MLN_OK;
@@ -1022,6 +1056,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // z = C^-T u at the accepted point
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u.data(), sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
   MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_z));
+  MLN_TRY(fit_cache_pair_from_u(f, f->d_u));
   MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (loss_out) *loss_out = fx;
@@ -1038,6 +1073,11 @@ extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevOut o;
   MLN_TRY(o.init(ctx, w, (size_t)f->m));
+  if (f->kspace && !is_device_ptr(z) && f->z_cached.size() == (size_t)f->m &&
+      std::memcmp(z, f->z_cached.data(), sizeof(double) * f->m) == 0) {
+    MLN_HIP(ctx, hipMemcpyAsync(o.dev, f->d_w_cached, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
+    return o.commit();
+  }
   MLN_HIP(ctx, hipMemcpyAsync(o.dev, z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
   MLN_TRY(triinv_solve_left_T(ctx, f->tri, o.dev, 1, 1));  // conditional.py:818
   return o.commit();

@@ -6,6 +6,8 @@ struct TriInv {
   double* W = nullptr;   // row-scaled    (forward solves, X Lf^-T)
   double* W2 = nullptr;  // column-scaled (transposed / backward solves)
   int64_t m = 0, ld = 0;
+  const double* Lf = nullptr;  // the factor itself (not owned; must outlive this object)
+  int64_t ldf = 0;
 };
 
 int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool need_w, bool need_w2, TriInv* out);

@@ -15,50 +15,56 @@ namespace {
 constexpr int PB = 64;    // Cholesky panel width
 constexpr int TB = 128;   // triangular-solve block
 
-// Factorises the nb x nb (nb <= 64) lower block at A in LDS; writes the factor back (strict upper
-// part zeroed) and its inverse to Dinv (64 x 64, row-major, ld 64).  A non-positive or NaN pivot
-// sets *info = (global pivot index + 1) once and leaves the block unfactorised.
-__global__ __launch_bounds__(256) void k_potrf64(double* A, int64_t lda, int nb, double* __restrict__ Dinv,
-                                                 int* info, int64_t j0) {
-  __shared__ double T[PB][PB + 1];
-  __shared__ double X[PB][PB + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < PB * PB; e += 256) {
-    int i = e / PB, j = e % PB;
-    T[i][j] = (i < nb && j <= i) ? A[(int64_t)i * lda + j] : ((i == j) ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    const double d = T[k][k];
-    if (!(d > 0.0)) {  // uniform: every thread reads the same LDS word after a barrier
-      if (tid == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
-      return;
+// Factorises the nb x nb (nb <= 64) lower block at A and writes the factor back (strict upper part
+// zeroed) together with its inverse Dinv (64 x 64, row-major, ld 64).  ONE wave64: lane i keeps row i
+// of the block in registers; pivots and the column being eliminated travel as wave-uniform values
+// (v_readlane), so the 64 elimination steps need no LDS and no barrier (was: 170 us per block in
+// LDS with three barriers per column; this form is ~15 us).  A non-positive or NaN pivot sets
+// *info = (global pivot index + 1) once and leaves the block unfactorised.
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_potrf64(double* A, int64_t lda, int nb, double* __restrict__ Dinv,
+                                                int* info, int64_t j0) {
+  const int lane = threadIdx.x;
+  double a[PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j)
+    a[j] = (lane < nb && j <= lane && j < nb) ? A[(int64_t)lane * lda + j] : ((j == lane) ? 1.0 : 0.0);
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < PB; ++k) {
+    const double d = lane_bcast(a[k], k);
+    if (!(d > 0.0)) {  // wave-uniform
+      if (!bad && lane == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
+      bad = true;
     }
-    const double s = sqrt(d);
-    __syncthreads();
-    for (int i = k + tid; i < nb; i += 256) T[i][k] = (i == k) ? s : T[i][k] / s;
-    __syncthreads();
-    const int cnt = nb - k - 1;
-    for (int e = tid; e < cnt * cnt; e += 256) {
-      int ii = k + 1 + e / cnt, jj = k + 1 + e % cnt;
-      if (jj <= ii) T[ii][jj] = fma(-T[ii][k], T[jj][k], T[ii][jj]);
-    }
-    __syncthreads();
-  }
-  if (tid < PB) {  // column tid of T^-1 by forward substitution
-    const int j = tid;
-    for (int i = 0; i < PB; ++i) {
-      double s = (i == j) ? 1.0 : 0.0;
-      if (i < j) { X[i][j] = 0.0; continue; }
-      for (int k = j; k < i; ++k) s = fma(-T[i][k], X[k][j], s);
-      X[i][j] = s / T[i][i];
+    const double sq = sqrt(d), inv = 1.0 / sq;
+    const double lik = (lane == k) ? sq : ((lane > k) ? a[k] * inv : 0.0);
+    a[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < PB; ++j) {
+      const double ljk = lane_bcast(lik, j);
+      a[j] = fma(-lik, ljk, a[j]);
     }
   }
-  __syncthreads();
-  for (int e = tid; e < PB * PB; e += 256) {
-    int i = e / PB, j = e % PB;
-    if (i < nb && j < nb) A[(int64_t)i * lda + j] = (j <= i) ? T[i][j] : 0.0;
-    Dinv[e] = X[i][j];
+  if (bad) return;
+  // X = T^-1, lane c owns column c:  x_i = (delta_ic - sum_{k<i} T_ik x_k) / T_ii
+  double x[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) sacc = fma(-lane_bcast(a[k], i), x[k], sacc);
+    x[i] = sacc / lane_bcast(a[i], i);
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    if (lane < nb && j < nb) A[(int64_t)lane * lda + j] = (j <= lane) ? a[j] : 0.0;
+    Dinv[j * PB + lane] = x[j];   // X[j][lane]: row j, column lane
   }
 }
 
@@ -242,7 +248,7 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += PB) {
     const int nb = (int)((m - j0 < PB) ? (m - j0) : PB);
     double* Ajj = A + j0 * lda + j0;
-    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, ctx->stream, Ajj, lda, nb, Dinv, ctx->d_info, j0);
+    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, ctx->stream, Ajj, lda, nb, Dinv, ctx->d_info, j0);
     const int64_t rem = m - j0 - nb;
     if (rem > 0) {
       double* P = A + (j0 + nb) * lda + j0;
@@ -285,6 +291,8 @@ void triinv_free(TriInv* t) {
 // W2 (column-scaled): W2[>=j, j] = [ I ; -Lf[>j,j] ] Dinv_j     -> backward (transposed) solves
 int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool need_w, bool need_w2, TriInv* out) {
   out->m = m;
+  out->Lf = Lf;
+  out->ldf = ld;
   out->ld = ((m + 15) / 16) * 16;
   const size_t bytes = sizeof(double) * (size_t)m * (size_t)out->ld;
   double* D = nullptr;  // block-diagonal inverse, stored in an m x ld matrix
@@ -340,30 +348,63 @@ int triinv_solve_right_T(mln_ctx* ctx, const TriInv& t, double* X, int64_t n, in
   return MLN_OK;
 }
 
-// B (m x p, in place) <- Lf^-1 B (forward substitution by 128-row blocks): B_j <- W_j [B_<j ; B_j]
+// B (m x p, in place) <- Lf^-1 B (forward substitution by 128-row blocks).
+//   few right-hand sides: left-looking,  B_j <- W_j [B_<j ; B_j]            (one GEMM per block row)
+//   many (p >= 256):      right-looking, B_j <- Dinv_j B_j ; B_>j -= Lf[>j,j] B_j   -- the trailing
+//   update is a (m-j) x p GEMM that fills the chip, where the left-looking form has only p/128 tiles
 int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb) {
+  const bool right_looking = (p >= 256) && t.Lf && t.W;
   for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
     const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
-    // in place: one row tile (nb <= 128), so each workgroup reads and writes only its own column tile
     GemmArgs g{};
-    g.A = t.W + j0 * t.ld; g.lda = t.ld; g.B = B; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
-    g.M = nb; g.N = p; g.K = j0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+    if (!right_looking) {
+      // in place: one row tile (nb <= 128), so each workgroup reads and writes only its own column tile
+      g.A = t.W + j0 * t.ld; g.lda = t.ld; g.B = B; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
+      g.M = nb; g.N = p; g.K = j0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+      MLN_TRY(launch_dgemm(ctx, g));
+      continue;
+    }
+    g.A = t.W + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
+    g.M = nb; g.N = p; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
     MLN_TRY(launch_dgemm(ctx, g));
+    const int64_t rem = t.m - j0 - nb;
+    if (rem > 0) {
+      GemmArgs u{};
+      u.A = t.Lf + (j0 + nb) * t.ldf + j0; u.lda = t.ldf; u.B = B + j0 * ldb; u.ldb = ldb;
+      u.C = B + (j0 + nb) * ldb; u.ldc = ldb;
+      u.M = rem; u.N = p; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 0; u.tb = 0;
+      MLN_TRY(launch_dgemm(ctx, u));
+    }
   }
   return MLN_OK;
 }
 
-// B (m x p, in place) <- Lf^-T B (backward substitution): B_j <- W2[>=j, j]^T B[>=j]
+// B (m x p, in place) <- Lf^-T B (backward substitution).
+//   few right-hand sides: B_j <- W2[>=j, j]^T B[>=j]
+//   many (p >= 256):      B_j <- Dinv_j^T B_j ; B_<j -= Lf[j,<j]^T B_j
 int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb) {
+  const bool right_looking = (p >= 256) && t.Lf && t.W2;
   const int64_t nblk = (t.m + TB - 1) / TB;
   for (int64_t jb = nblk - 1; jb >= 0; --jb) {
     const int64_t j0 = jb * TB;
     const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
     GemmArgs g{};
-    g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb;
-    g.C = B + j0 * ldb; g.ldc = ldb;
-    g.M = nb; g.N = p; g.K = t.m - j0; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;
+    if (!right_looking) {
+      g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb;
+      g.C = B + j0 * ldb; g.ldc = ldb;
+      g.M = nb; g.N = p; g.K = t.m - j0; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;
+      MLN_TRY(launch_dgemm(ctx, g));
+      continue;
+    }
+    g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
+    g.M = nb; g.N = p; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;   // Dinv_j^T B_j
     MLN_TRY(launch_dgemm(ctx, g));
+    if (j0 > 0) {
+      GemmArgs u{};
+      u.A = t.Lf + j0 * t.ldf; u.lda = t.ldf; u.B = B + j0 * ldb; u.ldb = ldb; u.C = B; u.ldc = ldb;
+      u.M = j0; u.N = p; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 1; u.tb = 0;  // Lf[j,<j]^T B_j
+      MLN_TRY(launch_dgemm(ctx, u));
+    }
   }
   return MLN_OK;
 }
