@@ -506,8 +506,6 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
     const bool trace = std::getenv("MELLON_AMD_TRACE") != nullptr;
     MLN_HIP(ctx, mln_dmalloc((void**)&f->L, l_bytes));
     if (trace) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[trace] L alloc %.4f s\n", now_s() - t0); }
-    MLN_HIP(ctx, hipMemsetAsync(f->L, 0, l_bytes, ctx->stream));
-    if (trace) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[trace] L memset done at %.4f s\n", now_s() - t0); }
     MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) fprintf(stderr, "[trace] L kernel matrix done at %.4f s\n", now_s() - t0);

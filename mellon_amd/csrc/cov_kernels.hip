@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double*
     for (int j = 0; j < 4; ++j) {
       int64_t c = col0 + tx * 4 + j;
       if (c < m) out[r * ldo + c] = val[i][j] + ((r == c) ? add_diag : 0.0);
+      else if (c < ldo) out[r * ldo + c] = 0.0;   // pad columns of the leading dimension stay zero
     }
   }
 }
@@ -335,7 +336,7 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   double* yy = norms + (int64_t)cov.n_leaves * n;
   MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
   MLN_TRY(sqnorms(ctx, cov, y, m, d, yy));
-  const int64_t tiles_n = (m + TN - 1) / TN, tiles_m = (n + TM - 1) / TM;
+  const int64_t tiles_n = (ldo + TN - 1) / TN, tiles_m = (n + TM - 1) / TM;   // covers the pad columns too
   const int64_t nblk = tiles_n * tiles_m;
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "kernel matrix too large for one launch"); return MLN_ERR_UNSUPPORTED; }
   const bool single = (cov.n_toks == 1);

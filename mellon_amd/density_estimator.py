@@ -15,6 +15,28 @@ from .validation import validate_array, validate_float_or_iterable_numerical, va
 logger = logging.getLogger("mellon")
 
 
+class _Background:
+    """Run one call in a worker thread and re-raise its exception on join()."""
+
+    def __init__(self, fn):
+        import threading
+        self._exc, self._fn = None, fn
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        try:
+            self._fn()
+        except BaseException as e:     # noqa: BLE001 -- re-raised in join()
+            self._exc = e
+
+    def join(self):
+        self._t.join()
+        if self._exc is not None:
+            exc, self._exc = self._exc, None
+            raise exc
+
+
 class DensityEstimator(BaseEstimator):
     """Non-parametric cell-state density estimator (reference density_estimator.py:35-581)."""
 
@@ -59,13 +81,15 @@ class DensityEstimator(BaseEstimator):
         return compute_mu(self.nn_distances, self.d)
 
     def _compute_initial_value(self):
-        return compute_initial_value(self.nn_distances, self.d, self.mu, self.L)
+        return compute_initial_value(self.nn_distances, self.d, self.mu, self.L,
+                                     target=getattr(self, "_ridge_target", None))
 
     def _compute_transform(self):
         return compute_transform(self.mu, self.L)
 
     def _compute_loss_func(self):
-        return compute_loss_func(self.nn_distances, self.d, self.transform, self.initial_value.shape[0])
+        return compute_loss_func(self.nn_distances, self.d, self.transform, self.initial_value.shape[0],
+                                 constants=getattr(self, "_lik_constants", None))
 
     def _set_log_density_x(self):
         self.log_density_x = compute_log_density_x(self.pre_transformation, self.transform)
@@ -104,12 +128,38 @@ class DensityEstimator(BaseEstimator):
         elif self.x is not None and self.x is not x:
             raise ValueError("self.x has been set already, but is not equal to the argument x.")
         self.set_x(x)
+        worker = None
         for attr in self._PIPELINE:
             if attr is None:
                 self.validate_parameter()
+            elif attr == "mu" and worker is None:
+                # The device factorisation (Lp, K) only needs the covariance and the landmarks; the
+                # O(n) host heuristics behind mu / the likelihood constants do not depend on it.
+                # Run the former in a worker thread (ctypes drops the GIL) while the host does the latter.
+                for early in self._DEVICE_FIT_INPUTS:
+                    self._prepare_attribute(early)
+                worker = _Background(self._device_fit)
+                self._prepare_attribute("mu")
+                self._host_constants()
+            elif attr == "Lp" and worker is not None:
+                worker.join()
+                self._prepare_attribute(attr)
             else:
                 self._prepare_attribute(attr)
+        if worker is not None:
+            worker.join()
         return self.loss_func, self.initial_value
+
+    _DEVICE_FIT_INPUTS = ("ls", "cov_func", "landmarks")
+
+    def _host_constants(self):
+        """mle - mu and the likelihood constants (inference.py:83-85), computed once."""
+        from .inference import nn_likelihood_constants
+        from .util import mle
+        if self.nn_distances is not None and self.d is not None and self.mu is not None:
+            self._lik_constants = nn_likelihood_constants(self.nn_distances, self.d)
+            self._ridge_target = -self._lik_constants[0] - self.mu        # mle = -V  (util.py:348)
+        return None
 
     def run_inference(self, loss_func=None, initial_value=None, optimizer=None):
         if loss_func is not None:

@@ -73,12 +73,12 @@ class LossFunc:
     """loss(z) = -(prior(z) + likelihood(transform(z))) (inference.py:167-192).  Calling it
     returns the loss; `value_and_grad(z)` returns (loss, grad) from the same single device pass."""
 
-    def __init__(self, nn_distances, d, transform, k):
+    def __init__(self, nn_distances, d, transform, k, constants=None):
         self.fit = transform.fit
         self.k = int(k)
         if self.fit.m != self.k:
             raise ValueError(f"initial value has {k} entries but L has {self.fit.m} columns")
-        V, Vdr = nn_likelihood_constants(nn_distances, d)
+        V, Vdr = constants if constants is not None else nn_likelihood_constants(nn_distances, d)
         if V.shape[0] != self.fit.n:
             raise ValueError(f"{V.shape[0]} nearest-neighbour distances for {self.fit.n} rows of L")
         self.fit.set_likelihood(V, Vdr, transform.mu)
@@ -114,8 +114,8 @@ class LossFunc:
         return self.value_and_grad(z)[0]
 
 
-def compute_loss_func(nn_distances, d, transform, k):
-    return LossFunc(nn_distances, d, transform, k)
+def compute_loss_func(nn_distances, d, transform, k, constants=None):
+    return LossFunc(nn_distances, d, transform, k, constants)
 
 
 def minimize_lbfgsb(loss_func, initial_value, jit=DEFAULT_JIT, options=None):

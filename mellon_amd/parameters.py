@@ -247,11 +247,12 @@ def ridge_row_stride(n_local, m):
     return max(1, n_global // (per_m * int(m))) if n_global > 2 * per_m * int(m) else 1
 
 
-def compute_initial_value(nn_distances, d, mu, L, row_stride=None):
+def compute_initial_value(nn_distances, d, mu, L, row_stride=None, target=None):
     """Ridge(alpha=1, fit_intercept=False) of mle - mu on L (reference parameters.py:877-896),
     solved on the device: (L^T L + I)^-1 L^T t, the Gram taken over every `row_stride`-th cell
     (None = automatic, see ridge_row_stride; 1 = all cells, the reference's exact Ridge)."""
-    target = mle(np.asarray(nn_distances, dtype=np.float64), d) - mu
+    if target is None:
+        target = mle(np.asarray(nn_distances, dtype=np.float64), d) - mu
     fit = _fit_of(L)
     fit.precond_build(ridge_row_stride(fit.n, fit.m) if row_stride is None else row_stride)
     return fit.ridge_init(target)

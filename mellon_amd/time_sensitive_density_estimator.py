@@ -40,6 +40,8 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
     _PIPELINE = ("n_landmarks", "rank", "gp_type", None, "d", "nn_distances", "mu", "ls", "ls_time", "cov_func",
                  "landmarks", "Lp", "L", "initial_value", "transform", "loss_func")
 
+    _DEVICE_FIT_INPUTS = ("ls", "ls_time", "cov_func", "landmarks")
+
     def _compute_d(self):
         if self.d_method == "fractal":
             raise NotImplementedError("d_method='fractal' is outside the accelerated path.")
