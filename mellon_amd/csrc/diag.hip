@@ -1,5 +1,6 @@
 // Diagnostics exported through the C ABI: device microbenchmarks used to state rooflines from
 // measurement (fp64 MFMA issue rate, HBM read bandwidth) and to time the GEMM kernel in isolation.
+#include <cstdlib>
 #include <vector>
 
 #include "mln_internal.h"
@@ -11,7 +12,7 @@ __global__ __launch_bounds__(256) void k_mfma_f64_peak(double* out, int iters, d
   v4d acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = (v4d){seed, 0.0, 0.0, 0.0};
-  double a = seed + threadIdx.x * 1e-9, b = seed - threadIdx.x * 1e-9;
+  double a = seed * (1.0 + threadIdx.x * 1e-3), b = seed * (1.0 - threadIdx.x * 1e-3);
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
@@ -44,11 +45,13 @@ extern "C" int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* 
   double* out = nullptr;
   MLN_HIP(ctx, mln_dmalloc((void**)&out, 64));
   float ms = 0.f;
-  if (what == 0) {
-    const int iters = 4000, grid = ctx->n_cu * 2;
-    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(grid), dim3(256), 0, ctx->stream, out, 10, 1.0);
+  if (what == 0 || what == 2 || what == 3) {
+    // what = 0: non-trivial operands, 2 waves/SIMD; 2: all-zero operands (DVFS probe); 3: 4 waves/SIMD
+    const int iters = 4000, grid = ctx->n_cu * (what == 3 ? 4 : 2);
+    const double seed = (what == 2) ? 0.0 : 1.0;
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(grid), dim3(256), 0, ctx->stream, out, 10, seed);
     MLN_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(grid), dim3(256), 0, ctx->stream, out, iters, 1.0);
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(grid), dim3(256), 0, ctx->stream, out, iters, seed);
     MLN_HIP(ctx, hipEventRecord(e1, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MLN_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
@@ -75,11 +78,14 @@ extern "C" int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* 
   return MLN_OK;
 }
 
+void dgemm_set_bk(int bk);
+
 // Times C = op(A) op(B) on random-free (zero-initialised + diagonal) device data; returns ms per call.
 extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
                               int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out) {
   if (!ctx || !ms_out || M < 1 || N < 1 || K < 1 || reps < 1) return MLN_ERR_ARG;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
+  if (const char* e = std::getenv("MELLON_AMD_GEMM_BK")) dgemm_set_bk(std::atoi(e));
   const int64_t lda = ((ta ? M : K) + 15) / 16 * 16, ldb = ((tb ? K : N) + 15) / 16 * 16, ldc = (N + 15) / 16 * 16;
   const size_t a_bytes = sizeof(double) * (size_t)(ta ? K : M) * lda, b_bytes = sizeof(double) * (size_t)(tb ? N : K) * ldb;
   const int split = split_k > 1 ? split_k : 1;
