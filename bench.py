@@ -141,7 +141,7 @@ def main():
         t_free += time.perf_counter() - tb
     fence()
     elapsed = time.perf_counter() - t0
-    elapsed = float(comm.allreduce_sum(np.eye(world)[rank] * elapsed).max()) if world > 1 else elapsed
+    elapsed = float(comm.allreduce_sum(np.eye(world)[rank] * elapsed).max())   # MAX over ranks
 
     # ---- size-independent parity property at full size: predict(X) == fit_predict(X) -----------------
     k = min(20000, hi - lo)

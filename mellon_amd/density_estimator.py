@@ -138,7 +138,10 @@ class DensityEstimator(BaseEstimator):
                 # Run the former in a worker thread (ctypes drops the GIL) while the host does the latter.
                 for early in self._DEVICE_FIT_INPUTS:
                     self._prepare_attribute(early)
-                worker = _Background(self._device_fit)
+                from .distributed import current
+                # (single process only: with ranks the host heuristics issue collectives on the same
+                #  context, which is not thread-safe, and the host work is already 1/N per rank)
+                worker = _Background(self._device_fit if current().world_size == 1 else (lambda: None))
                 self._prepare_attribute("mu")
                 self._host_constants()
             elif attr == "Lp" and worker is not None:

@@ -127,7 +127,8 @@ def init_from_env(backend="gloo"):
     torch.distributed (gloo, 127.0.0.1 rendezvous from MASTER_ADDR/PORT) only carries the 128-byte
     RCCL unique id and barriers; every data-path collective runs in libmellon_hip.so."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    force = os.environ.get("MELLON_AMD_FORCE_COMM") == "1" and "RANK" in os.environ   # 1-rank RCCL (testing)
+    if world <= 1 and not force:
         return set_current(Communicator())
     import torch.distributed as dist
     from . import _lib
