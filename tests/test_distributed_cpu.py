@@ -23,6 +23,8 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import scipy.linalg as sla
+    from threadpoolctl import threadpool_limits
+    threadpool_limits(1)       # single-threaded BLAS: every rank must hold bit-identical replicated data
     from mellon_amd import distributed, parameters
     from oracle import mellon_oracle as mo
 
