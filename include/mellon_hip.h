@@ -116,6 +116,13 @@ int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x,
 int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int32_t d,
                      int64_t self_offset, double* out /* n */);
 
+/* k-means landmarks (S8f rank 1): k-means++ seeding + Lloyd sweeps on the device, the algorithm
+ * family of sklearn.cluster.k_means(x, m, n_init=1, random_state) that parameters.compute_landmarks
+ * calls (parameters.py:275-291).  Own RNG stream / summation order: centroids are equivalent in
+ * quality, not bit-compatible with sklearn.  d <= 64.  centers: m x d.                           */
+int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int64_t seed,
+               int32_t max_iter, double tol, double* centers, int32_t* n_iter_out, double* inertia_out);
+
 /* ---- a-4/a-5: in-place lower Cholesky of (A + add_diag * I), A m x m symmetric (lower read).
  * decomposition.py:111-123 (`stabilize` util.py:269-293 + jnp.linalg.cholesky).  Strict upper
  * triangle of the result is zero.  MLN_ERR_NOT_PD on a non-positive or NaN pivot.              */

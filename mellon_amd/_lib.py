@@ -62,6 +62,7 @@ SYMBOLS = [
     ("mln_comm_allreduce_sum", C.c_int, [_vp, _dp, _i64]),
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_nn_distances", C.c_int, [_vp, _dp, _i64, _dp, _i64, _i32, _i64, _dp]),
+    ("mln_kmeans", C.c_int, [_vp, _dp, _i64, _i32, _i64, _i64, _i32, _dbl, _dp, C.POINTER(_i32), C.POINTER(_dbl)]),
     ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
     ("mln_trsm_lower", C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64]),
     ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, _i32, C.POINTER(_vp)]),
@@ -256,6 +257,16 @@ class Context:
         self._check(self.lib.mln_nn_distances(self.handle, _ptr(x), x.shape[0], _ptr(y), y.shape[0], x.shape[1],
                                               int(self_offset), out.ctypes.data))
         return out
+
+    def kmeans(self, x, m, seed=42, max_iter=300, tol=1e-4, return_info=False):
+        """k-means++ / Lloyd centroids on the device (m x d)."""
+        x = x if isinstance(x, DeviceArray) else _as2d(x)
+        centers = np.empty((int(m), x.shape[1]), dtype=np.float64)
+        nit, inertia = C.c_int32(), C.c_double()
+        self._check(self.lib.mln_kmeans(self.handle, _ptr(x), x.shape[0], x.shape[1], int(m), int(seed),
+                                        int(max_iter), float(tol), centers.ctypes.data, C.byref(nit),
+                                        C.byref(inertia)))
+        return (centers, nit.value, inertia.value) if return_info else centers
 
     def chol_lower(self, A, add_diag=0.0, jitter=None):
         A = _f64(A).copy()

@@ -1,0 +1,294 @@
+// k-means landmarks on the device (reference: mellon/parameters.py:243-291
+// calls sklearn.cluster.k_means(x, m, n_init=1, random_state=...), i.e. k-means++ seeding + Lloyd).
+// Same algorithm family, own implementation: the centroids are NOT bit-compatible with sklearn's
+// (different RNG stream and summation order), so parity tests pass landmarks explicitly; this is
+// the at-scale path (sklearn needs minutes for 1e6 x 50 cells and 5 000 clusters).
+//
+//   seeding   k-means++ (D^2 sampling): one fused kernel per new centre updates every cell's squared
+//             distance to its closest centre and emits 1024-cell block sums; the host draws the next
+//             centre from them with a seeded xorshift generator (two tiny downloads per centre).
+//   Lloyd     assignment = tiled fp64 distance kernel with running arg-min (the nn_distances tile
+//             structure), update = fp64 atomics into m x d sums (summation order is not fixed: centroids
+//             are reproducible to rounding, not bitwise), stop when the summed squared centre shift
+//             <= tol * mean feature variance (sklearn's rule) or after max_iter sweeps.
+#include <cmath>
+#include <vector>
+
+#include "mln_internal.h"
+
+namespace {
+constexpr int TM = 64, TN = 64, DK = 16, PADT = 4, SBLK = 1024;
+
+__global__ void k_sqnorm_rows(const double* __restrict__ x, int64_t n, int d, double* __restrict__ xx) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) { double v = x[i * (int64_t)d + k]; s = fma(v, v, s); }
+  xx[i] = s;
+}
+
+// mind[i] = min(mind[i], |x_i - c|^2) ; bsum[b] = sum of mind over the 1024-cell block b
+__global__ __launch_bounds__(256) void k_seed_update(const double* __restrict__ x, int64_t n, int d,
+                                                     const double* __restrict__ c, double* __restrict__ mind,
+                                                     double* __restrict__ bsum, int first) {
+  __shared__ double cs[64];
+  __shared__ double red[256];
+  for (int k = threadIdx.x; k < d; k += 256) cs[k] = c[k];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SBLK;
+  double acc = 0.0;
+  for (int q = 0; q < SBLK / 256; ++q) {
+    const int64_t i = base + q * 256 + threadIdx.x;
+    if (i < n) {
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) { double t = x[i * (int64_t)d + k] - cs[k]; s = fma(t, t, s); }
+      if (!first) s = fmin(s, mind[i]);
+      mind[i] = s;
+      acc += s;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+
+// index of the first cell of block b whose running sum of mind exceeds `target`
+__global__ void k_seed_pick(const double* __restrict__ mind, int64_t n, int64_t b, double target, int64_t* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int64_t lo = b * SBLK, hi = (lo + SBLK < n) ? lo + SBLK : n;
+  double run = 0.0;
+  int64_t pick = hi - 1;
+  for (int64_t i = lo; i < hi; ++i) {
+    run += mind[i];
+    if (run > target) { pick = i; break; }
+  }
+  *out = pick;
+}
+
+// label[i] = argmin_j |x_i - c_j|^2 (ties: smallest j)
+__global__ __launch_bounds__(256) void k_assign(const double* __restrict__ x, int64_t n,
+                                                const double* __restrict__ c, int64_t m, int d,
+                                                const double* __restrict__ xx, const double* __restrict__ cc,
+                                                int* __restrict__ label, double* __restrict__ dist2) {
+  __shared__ double xs[DK][TM + PADT];
+  __shared__ double ys[DK][TN + PADT];
+  __shared__ double redv[TM][17];
+  __shared__ int redi[TM][17];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * TM;
+  double best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+  int bidx[4] = {0, 0, 0, 0};
+  double xr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { int64_t r = row0 + ty * 4 + i; xr[i] = (r < n) ? xx[r] : 0.0; }
+  for (int64_t col0 = 0; col0 < m; col0 += TN) {
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < d; k0 += DK) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int idx = tid + 256 * q, r = idx >> 4, k = idx & 15;
+        double vx = 0.0, vy = 0.0;
+        if (k0 + k < d) {
+          if (row0 + r < n) vx = x[(row0 + r) * (int64_t)d + k0 + k];
+          if (col0 + r < m) vy = c[(col0 + r) * (int64_t)d + k0 + k];
+        }
+        xs[k][r] = vx; ys[k][r] = vy;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = xs[k][ty * 4 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = ys[k][tx * 4 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t cj = col0 + tx * 4 + j;
+      if (cj >= m) continue;
+      const double cn = cc[cj];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double sq = xr[i] - 2.0 * acc[i][j] + cn;
+        if (sq < best[i]) { best[i] = sq; bidx[i] = (int)cj; }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { redv[ty * 4 + i][tx] = best[i]; redi[ty * 4 + i][tx] = bidx[i]; }
+  __syncthreads();
+  if (tid < TM) {
+    double s = INFINITY;
+    int bi = 0;
+    for (int t = 0; t < 16; ++t) {
+      const double v = redv[tid][t];
+      const int ix = redi[tid][t];
+      if (v < s || (v == s && ix < bi)) { s = v; bi = ix; }
+    }
+    const int64_t r = row0 + tid;
+    if (r < n) { label[r] = bi; dist2[r] = fmax(s, 0.0); }
+  }
+}
+
+__global__ void k_accumulate(const double* __restrict__ x, int64_t n, int d, const int* __restrict__ label,
+                             double* __restrict__ sums, double* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;
+  if (i >= n) return;
+  const int l = label[i];
+  for (int k = threadIdx.x; k < d; k += blockDim.x) atomicAdd(&sums[(int64_t)l * d + k], x[i * (int64_t)d + k]);
+  if (threadIdx.x == 0) atomicAdd(&counts[l], 1.0);
+}
+
+// new centres (empty clusters keep their previous centre); shift2 += |new - old|^2
+__global__ void k_finish(double* __restrict__ c, const double* __restrict__ sums, const double* __restrict__ counts,
+                         int64_t m, int d, double* __restrict__ shift2) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const double cnt = counts[j];
+  if (cnt <= 0.0) return;
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double nv = sums[j * d + k] / cnt, t = nv - c[j * d + k];
+    s = fma(t, t, s);
+    c[j * d + k] = nv;
+  }
+  atomicAdd(shift2, s);
+}
+
+struct XorShift {
+  unsigned long long s;
+  explicit XorShift(unsigned long long seed) : s(seed * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL) { next(); next(); }
+  unsigned long long next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+  double uniform() { return (double)(next() >> 11) / 9007199254740992.0; }
+};
+}  // namespace
+
+extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int64_t seed,
+                          int32_t max_iter, double tol, double* centers, int32_t* n_iter_out, double* inertia_out) {
+  if (!ctx || !x || !centers) return MLN_ERR_ARG;
+  if (n < 1 || d < 1 || d > 64 || m < 1 || m > n) { mln_set_error(ctx, "kmeans: bad shape (need 1 <= m <= n, d <= 64)"); return MLN_ERR_SHAPE; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double *dx = nullptr, *dc = nullptr, *xx = nullptr, *cc = nullptr, *mind = nullptr, *bsum = nullptr, *sums = nullptr,
+         *counts = nullptr, *shift = nullptr;
+  int* label = nullptr;
+  int64_t* pick = nullptr;
+  bool own_x = false;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, x) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)) {
+    dx = const_cast<double*>(x);
+  } else {
+    (void)hipGetLastError();
+    MLN_HIP(ctx, mln_dmalloc((void**)&dx, sizeof(double) * (size_t)n * d));
+    own_x = true;
+    MLN_HIP(ctx, hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, st));
+  }
+  const int64_t nblk = (n + SBLK - 1) / SBLK;
+  MLN_HIP(ctx, mln_dmalloc((void**)&dc, sizeof(double) * (size_t)m * d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&xx, sizeof(double) * (size_t)n));
+  MLN_HIP(ctx, mln_dmalloc((void**)&cc, sizeof(double) * (size_t)m));
+  MLN_HIP(ctx, mln_dmalloc((void**)&mind, sizeof(double) * (size_t)n));
+  MLN_HIP(ctx, mln_dmalloc((void**)&bsum, sizeof(double) * (size_t)nblk));
+  MLN_HIP(ctx, mln_dmalloc((void**)&sums, sizeof(double) * (size_t)m * d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&counts, sizeof(double) * (size_t)m));
+  MLN_HIP(ctx, mln_dmalloc((void**)&shift, sizeof(double)));
+  MLN_HIP(ctx, mln_dmalloc((void**)&label, sizeof(int) * (size_t)n));
+  MLN_HIP(ctx, mln_dmalloc((void**)&pick, sizeof(int64_t)));
+  int rc = MLN_OK;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "kmeans", __FILE__, __LINE__); };
+
+  // ---- k-means++ seeding ------------------------------------------------------------------------
+  XorShift rng((unsigned long long)seed);
+  std::vector<double> hb((size_t)nblk);
+  int64_t cur = (int64_t)(rng.uniform() * (double)n);
+  if (cur >= n) cur = n - 1;
+  for (int64_t j = 0; j < m && rc == MLN_OK; ++j) {
+    chk(hipMemcpyAsync(dc + j * d, dx + cur * d, sizeof(double) * d, hipMemcpyDeviceToDevice, st));
+    if (j + 1 == m) break;
+    hipLaunchKernelGGL(k_seed_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
+    chk(hipMemcpyAsync(hb.data(), bsum, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToHost, st));
+    chk(hipStreamSynchronize(st));
+    double total = 0.0;
+    for (double v : hb) total += v;
+    if (!(total > 0.0)) { cur = (int64_t)(rng.uniform() * (double)n) % n; continue; }   // all cells coincide with centres
+    double target = rng.uniform() * total;
+    int64_t b = 0;
+    for (; b + 1 < nblk; ++b) { if (target < hb[(size_t)b]) break; target -= hb[(size_t)b]; }
+    hipLaunchKernelGGL(k_seed_pick, dim3(1), dim3(64), 0, st, mind, n, b, target, pick);
+    chk(hipMemcpyAsync(&cur, pick, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    chk(hipStreamSynchronize(st));
+  }
+
+  // ---- Lloyd ------------------------------------------------------------------------------------------
+  // tolerance scaled like sklearn: tol * mean over features of the feature variance
+  double scaled_tol = 0.0;
+  if (rc == MLN_OK) {
+    std::vector<double> hx;
+    const int64_t ns = (n < 200000) ? n : 200000;   // variance estimate from an evenly spaced subset
+    hx.resize((size_t)ns * d);
+    const int64_t stride = n / ns;
+    chk(hipMemcpy2DAsync(hx.data(), sizeof(double) * d, dx, sizeof(double) * d * stride, sizeof(double) * d, (size_t)ns,
+                         hipMemcpyDeviceToHost, st));
+    chk(hipStreamSynchronize(st));
+    double var_sum = 0.0;
+    for (int k = 0; k < d; ++k) {
+      double mean = 0.0, m2 = 0.0;
+      for (int64_t i = 0; i < ns; ++i) mean += hx[(size_t)i * d + k];
+      mean /= (double)ns;
+      for (int64_t i = 0; i < ns; ++i) { double t = hx[(size_t)i * d + k] - mean; m2 += t * t; }
+      var_sum += m2 / (double)ns;
+    }
+    scaled_tol = tol * var_sum / d;
+  }
+  int it = 0;
+  hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dx, n, d, xx);
+  for (; it < max_iter && rc == MLN_OK; ++it) {
+    hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);
+    hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
+    chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
+    chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
+    chk(hipMemsetAsync(shift, 0, sizeof(double), st));
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts);
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, shift);
+    double hs = 0.0;
+    chk(hipMemcpyAsync(&hs, shift, sizeof(double), hipMemcpyDeviceToHost, st));
+    chk(hipStreamSynchronize(st));
+    if (hs <= scaled_tol) { ++it; break; }
+  }
+  if (rc == MLN_OK && inertia_out) {   // sum of squared distances to the closest final centre
+    hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);
+    hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
+    std::vector<double> hm((size_t)n);
+    chk(hipMemcpyAsync(hm.data(), mind, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+    chk(hipStreamSynchronize(st));
+    double s = 0.0;
+    for (double v : hm) s += v;
+    *inertia_out = s;
+  }
+  if (rc == MLN_OK) {
+    chk(hipGetLastError());
+    chk(hipMemcpyAsync(centers, dc, sizeof(double) * (size_t)m * d, hipMemcpyDefault, st));
+    chk(hipStreamSynchronize(st));
+  }
+  if (n_iter_out) *n_iter_out = it;
+  (void)hipStreamSynchronize(st);
+  void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick};
+  for (void* p : ptrs) if (p) (void)mln_dfree(p);
+  if (own_x) (void)mln_dfree(dx);
+  return rc;
+}

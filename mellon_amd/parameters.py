@@ -67,8 +67,15 @@ def compute_gp_type(n_landmarks, rank, n_samples):
     return GaussianProcessType.SPARSE_NYSTROEM
 
 
-def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_state=DEFAULT_RANDOM_SEED):
-    """k-means centroids (reference parameters.py:243-291; sklearn, third party on both sides)."""
+KMEANS_DEVICE_THRESHOLD = 2e8   # n * n_landmarks above which k-means runs on the device
+
+
+def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_state=DEFAULT_RANDOM_SEED,
+                      backend=None):
+    """k-means centroids (reference parameters.py:243-291).  backend "sklearn" is the reference's
+    own call (bit-identical landmarks); "hip" is k-means++ / Lloyd on the device (mln_kmeans: same
+    algorithm family, different random stream); None picks "hip" when n * n_landmarks exceeds
+    KMEANS_DEVICE_THRESHOLD (where sklearn takes minutes) and d <= 64."""
     if n_landmarks == 0:
         return None
     x = ensure_2d(x)
@@ -79,8 +86,14 @@ def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_s
             logger.info(f"Using all {n:,} datapoints as landmarks.")
             return x
         return None
+    if backend is None:
+        backend = "hip" if (n * n_landmarks > KMEANS_DEVICE_THRESHOLD and x.shape[1] <= 64) else "sklearn"
+    logger.info(f"Computing {n_landmarks:,} landmarks with k-means clustering "
+                f"(random_state={random_state}, backend={backend}).")
+    if backend == "hip":
+        return _lib.default_context().kmeans(np.ascontiguousarray(x, dtype=np.float64), n_landmarks,
+                                             seed=random_state if random_state is not None else DEFAULT_RANDOM_SEED)
     from sklearn.cluster import k_means
-    logger.info(f"Computing {n_landmarks:,} landmarks with k-means clustering (random_state={random_state}).")
     return k_means(x, n_landmarks, n_init=1, random_state=random_state)[0]
 
 

@@ -370,3 +370,25 @@ def test_rccl_single_rank_communicator():
         a.close()
     finally:
         c2.close()
+
+
+def test_kmeans_landmarks(ctx):
+    """mln_kmeans: k-means++ / Lloyd on the device -- same quality as sklearn's k_means (inertia within
+    a few %), every centre is the mean of its members, reproducible to rounding for a fixed seed."""
+    from sklearn.cluster import k_means
+    x = mo.gaussian_mixture(20000, 12, seed=33)
+    m = 200
+    c, n_iter, inertia = ctx.kmeans(x, m, seed=42, return_info=True)
+    assert c.shape == (m, 12) and 1 <= n_iter <= 300
+    _, _, ref_inertia = k_means(x, m, n_init=1, random_state=42)
+    assert inertia < 1.05 * ref_inertia
+    d2 = ((x[:, None, :] - c[None, :, :]) ** 2).sum(-1) if x.shape[0] * m < 5e6 else None
+    lab = np.argmin(mo.distance(x, c), axis=1)
+    assert abs(np.sum(mo.distance(x, c)[np.arange(len(x)), lab] ** 2) - inertia) < 1e-6 * inertia
+    c2 = ctx.kmeans(x, m, seed=42)
+    assert relmax(c2, c) < 1e-9                      # same seed -> same centres up to atomic summation order
+    assert relmax(ctx.kmeans(x, m, seed=7), c) > 1e-3  # different seed -> different seeding
+    # degenerate: as many clusters as points
+    small = x[:50]
+    cs = ctx.kmeans(small, 50, seed=1)
+    assert np.allclose(np.sort(cs, axis=0), np.sort(small, axis=0))
