@@ -233,6 +233,17 @@ int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result);
 int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
                    int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out);
 
+/* ---- predictive uncertainty (S8f rank 2) ----------------------------------------------------------
+ * covariance:       k(x*,x*) - A A^T with A = cov(x*, centers) Lf^-T      conditional.py:409-422,930-945
+ * mean covariance:  (K W)(K W)^T with K = cov(x*, centers), W m x q        conditional.py:423-440,947-963
+ * diag != 0: out has n_new entries (the variances); diag == 0: out is n_new x n_new (n_new <= 32768). */
+int mln_predict_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                           int32_t d, const double* centers, int64_t m, const double* Lf, int32_t diag,
+                           double* out);
+int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                                int32_t d, const double* centers, int64_t m, const double* W, int64_t q,
+                                int32_t diag, double* out);
+
 /* wall-clock seconds of the stages of the last mln_fit_prepare / mln_ridge_init and counters
  * of mln_objective: [0] kernel matrix, [1] cholesky, [2] trsm, [3] ridge gram, [4] ridge solve,
  * [5] objective kernel time (sum, HIP events), [6] objective launches, [7] bytes of L streamed

@@ -84,6 +84,8 @@ SYMBOLS = [
     ("mln_weights_full", C.c_int, [_vp, _dp, _i64, _dbl, _dp]),
     ("mln_sparse_solve", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp]),
     ("mln_predict_mean", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp]),
+    ("mln_predict_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i32, _dp]),
+    ("mln_predict_mean_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_stage_times", C.c_int, [_vp, _dp]),
     ("mln_diag_peak", C.c_int, [_vp, _i32, _i64, C.POINTER(_dbl)]),
     ("mln_diag_dgemm", C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, C.POINTER(_dbl)]),
@@ -295,6 +297,24 @@ class Context:
         out = np.empty((n_new,) if len(Wd.shape) == 1 else (n_new, p), dtype=np.float64)
         self._check(self.lib.mln_predict_mean(self.handle, desc.ref, _ptr(xnew), n_new, d, _ptr(centers), m,
                                               _ptr(Wd), p, float(mu), out.ctypes.data))
+        return out
+
+    def predict_covariance(self, desc, xnew, centers, Lf, diag=True):
+        xnew, centers, Lf = _as2d(xnew), _as2d(centers), _f64(Lf)
+        n = xnew.shape[0]
+        out = np.empty((n,) if diag else (n, n), dtype=np.float64)
+        self._check(self.lib.mln_predict_covariance(self.handle, desc.ref, _ptr(xnew), n, xnew.shape[1],
+                                                    _ptr(centers), centers.shape[0], _ptr(Lf), 1 if diag else 0,
+                                                    out.ctypes.data))
+        return out
+
+    def predict_mean_covariance(self, desc, xnew, centers, W, diag=True):
+        xnew, centers, W = _as2d(xnew), _as2d(centers), _as2d(W)
+        n = xnew.shape[0]
+        out = np.empty((n,) if diag else (n, n), dtype=np.float64)
+        self._check(self.lib.mln_predict_mean_covariance(self.handle, desc.ref, _ptr(xnew), n, xnew.shape[1],
+                                                         _ptr(centers), centers.shape[0], _ptr(W), W.shape[1],
+                                                         1 if diag else 0, out.ctypes.data))
         return out
 
     def sparse_solve(self, desc, x, xu, y, mu, sigma, jitter):

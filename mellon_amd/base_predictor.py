@@ -76,11 +76,46 @@ class Predictor:
 
     __call__ = mean
 
-    def _unavailable(self, *a, **k):
-        raise NotImplementedError("Only the predictive mean is part of the accelerated path "
-                                  "(covariance / uncertainty / gradients: SURVEY.md S8f).")
+    # -- predictive uncertainty (base_predictor.py:330-428; conditional.py _covariance / _mean_covariance) --
+    def _check_features(self, x):
+        x = validate_array(x, "x")
+        x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+        if x.shape[1] != self.n_input_features:
+            raise ValueError(
+                f"The predictor was trained on data with {self.n_input_features} features. "
+                f"However, the provided input data has {x.shape[1]} features. "
+                "Please ensure that the input data has the same number of features as the training data.")
+        return x
 
-    covariance = mean_covariance = uncertainty = gradient = hessian = leverage = obs_variance = _unavailable
+    def covariance(self, x, diag=True, noise_free=False):
+        """k(x,x) - A A^T with A = cov(x, centers) L^-T (variances when diag=True)."""
+        x = self._check_features(x)
+        if not hasattr(self, "L") or self.L is None:
+            raise ValueError("The predictor was computed without covariance. "
+                             "Recompute setting `with_uncertainty=True.`")
+        return _lib.default_context().predict_covariance(self.cov_func.lower(self.n_input_features), x,
+                                                         self.centers, np.asarray(self.L), diag=diag)
+
+    def mean_covariance(self, x, diag=True):
+        """(K W)(K W)^T: uncertainty of the mean inherited from the parameter uncertainty W."""
+        x = self._check_features(x)
+        if not hasattr(self, "W") or self.W is None:
+            raise ValueError(
+                "The predictor was computed without uncertainty, e.g., using ADVI. "
+                "Recompute setting `with_uncertainty=True.` and define `pre_transformation_std`"
+                ", e.g., by using `optimizer='advi'`.")
+        return _lib.default_context().predict_mean_covariance(self.cov_func.lower(self.n_input_features), x,
+                                                              self.centers, np.asarray(self.W), diag=diag)
+
+    def uncertainty(self, x, diag=True):
+        """covariance + mean_covariance (base_predictor.py:390-428)."""
+        return self.covariance(x, diag=diag) + self.mean_covariance(x, diag=diag)
+
+    def _unavailable(self, *a, **k):
+        raise NotImplementedError("This predictor method is outside the accelerated path "
+                                  "(gradients / leverage / obs_variance: SURVEY.md S8f).")
+
+    gradient = hessian = hessian_log_determinant = leverage = loo_residuals = obs_variance = _unavailable
 
     # -- serialization --------------------------------------------------------------------------------
     def _data_dict(self):
@@ -104,8 +139,9 @@ class Predictor:
             setattr(self, name, deserialize(value))
         self._state_variables = set(self._state_variables)
         self.cov_func = Covariance.from_dict(state["cov_func"])
-        for k in (self._center_name, "weights"):
-            setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=np.float64))
+        for k in (self._center_name, "weights", "L", "W"):
+            if getattr(self, k, None) is not None:
+                setattr(self, k, np.ascontiguousarray(getattr(self, k), dtype=np.float64))
 
     def copy(self):
         new = self.__class__.__new__(self.__class__)
@@ -186,3 +222,17 @@ class PredictorTime(Predictor):
         return super().mean(np.ascontiguousarray(x), normalize=normalize)
 
     __call__ = mean
+
+    def _with_time(self, Xnew, time):
+        Xnew = np.ascontiguousarray(ensure_2d(validate_array(Xnew, "Xnew")), dtype=np.float64)
+        return np.ascontiguousarray(validate_time_x(Xnew, time, n_features=self.n_input_features, cast_scalar=True))
+
+    def covariance(self, Xnew, time=None, diag=True):
+        return super().covariance(self._with_time(Xnew, time), diag=diag)
+
+    def mean_covariance(self, Xnew, time=None, diag=True):
+        return super().mean_covariance(self._with_time(Xnew, time), diag=diag)
+
+    def uncertainty(self, Xnew, time=None, diag=True):
+        x = self._with_time(Xnew, time)
+        return Predictor.covariance(self, x, diag=diag) + Predictor.mean_covariance(self, x, diag=diag)

@@ -29,15 +29,35 @@ def _scalar_sigma(sigma):
 
 
 def _reject_extras(with_uncertainty, obs_variance):
-    if with_uncertainty or obs_variance:
-        raise NotImplementedError("with_uncertainty / obs_variance are outside the accelerated path (SURVEY.md S8f).")
+    if obs_variance:
+        raise NotImplementedError("obs_variance is outside the accelerated path (SURVEY.md S8f).")
+
+
+def _parameter_std(sigma, m):
+    """Standard deviations of the m parameters as a vector (conditional.py:856-862: `diagonal(sigma)`
+    for a vector, `eye(m) * sigma` for a scalar)."""
+    s = np.asarray(0.0 if sigma is None else sigma, dtype=np.float64)
+    if s.ndim == 0:
+        return np.full(m, float(s))
+    if s.shape != (m,):
+        raise ValueError(f"pre_transformation_std has shape {s.shape}, expected {(m,)}")
+    return s
+
+
+def _attach_uncertainty(pred, Lf, std):
+    """with_uncertainty state: L (the factor) and W = L^-T diag(std)
+    (conditional.py:330-362 with y_cov_factor = L diag(std), and :853-867)."""
+    Lh = np.ascontiguousarray(np.asarray(Lf, dtype=np.float64))
+    pred.L = Lh
+    pred.W = _lib.default_context().trsm_lower(Lh, np.diag(std), trans=True)
+    pred._state_variables |= {"L", "W"}
 
 
 class _FullConditional:
     _center_name = "x"
 
     def __init__(self, x, y, mu, cov_func, L=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER, y_cov_factor=None,
-                 y_is_mean=False, with_uncertainty=False, obs_variance=False):
+                 y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None):
         _reject_extras(with_uncertainty, obs_variance)
         x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         ctx = _lib.default_context()
@@ -62,6 +82,9 @@ class _FullConditional:
             fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
         weights = fit.weights_full(np.asarray(y, dtype=np.float64), mu)  # conditional.py:263-264
         Predictor.__init__(self, cov_func, x, weights, mu, n_obs=x.shape[0], jitter=jitter, sigma=sigma)
+        if with_uncertainty:
+            # y_cov_factor = L diag(std) (inference.compute_parameter_cov_factor, inference.py:357-372)
+            _attach_uncertainty(self, fit.Lp(), _parameter_std(parameter_std, x.shape[0]))
 
 
 class _LandmarksConditional:
@@ -70,6 +93,9 @@ class _LandmarksConditional:
     def __init__(self, x, xu, y, mu, cov_func, L=None, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
                  y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False):
         _reject_extras(with_uncertainty, obs_variance)
+        if with_uncertainty:
+            raise NotImplementedError("uncertainty of the noisy landmark conditional (Cs = Lp L_B, "
+                                      "conditional.py:694-716) is outside the accelerated path.")
         if y_is_mean:
             raise NotImplementedError("LandmarksConditional with y_is_mean=True is outside the accelerated path.")
         s = _scalar_sigma(sigma)
@@ -103,6 +129,9 @@ class _LandmarksConditionalCholesky:
                 Lh = np.asarray(L, dtype=np.float64)
             weights = ctx.trsm_lower(Lh, z, trans=True)
         Predictor.__init__(self, cov_func, xu, weights, mu, n_obs=n_obs, jitter=jitter, sigma=sigma)
+        if with_uncertainty:
+            Lf = L.fit.Lp() if isinstance(L, (FactorLp, FactorL)) else Lh
+            _attach_uncertainty(self, Lf, _parameter_std(sigma, xu.shape[0]))
 
 
 class FullConditional(_FullConditional, Predictor):

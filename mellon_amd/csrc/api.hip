@@ -1182,6 +1182,111 @@ extern "C" int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const 
   return rc;
 }
 
+// ---- predictive uncertainty (S8f rank 2) ------------------------------------------------------------
+// covariance (conditional.py:409-440, 930-945):  k(x*,x*) - A A^T,  A = cov(x*, centers) Lf^-T
+extern "C" int mln_predict_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                                      int32_t d, const double* centers, int64_t m, const double* Lf, int32_t diag,
+                                      double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n_new < 0 || m < 1 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n_new == 0) return MLN_OK;
+  if (!xnew || !centers || !Lf || !out) return MLN_ERR_ARG;
+  if (!diag && n_new > 32768) { mln_set_error(ctx, "full covariance is limited to 32768 points"); return MLN_ERR_UNSUPPORTED; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, dcen, dl;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, xnew, (size_t)n_new * d));
+  MLN_TRY(dcen.init(ctx, centers, (size_t)m * d));
+  MLN_TRY(dl.init(ctx, Lf, (size_t)m * m));
+  MLN_TRY(o.init(ctx, out, diag ? (size_t)n_new : (size_t)n_new * n_new));
+  const int64_t ld = pad16(m);
+  TriInv t;
+  MLN_TRY(triinv_build(ctx, dl.dev, m, m, true, false, &t));
+  int64_t chunk = diag ? (int64_t)((1ull << 30) / (sizeof(double) * (size_t)ld)) : n_new;
+  if (chunk > n_new) chunk = n_new;
+  if (chunk < 1) chunk = 1;
+  double *A = nullptr, *kss = nullptr;
+  int rc = MLN_OK;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "predict_covariance", __FILE__, __LINE__); };
+  chk(mln_dmalloc((void**)&A, sizeof(double) * (size_t)chunk * ld));
+  chk(mln_dmalloc((void**)&kss, sizeof(double) * (size_t)chunk));
+  for (int64_t r0 = 0; r0 < n_new && rc == MLN_OK; r0 += chunk) {
+    const int64_t rows = (n_new - r0 < chunk) ? (n_new - r0) : chunk;
+    rc = launch_kernel_matrix(ctx, dc, dx.dev + r0 * d, rows, dcen.dev, m, d, A, ld, 0.0);
+    if (rc == MLN_OK) rc = triinv_solve_right_T(ctx, t, A, rows, ld);
+    if (rc != MLN_OK) break;
+    if (diag) {
+      rc = launch_cov_diag(ctx, dc, dx.dev + r0 * d, rows, d, kss);
+      if (rc == MLN_OK) rc = launch_row_sumsq(ctx, A, ld, rows, m, kss, -1.0, o.dev + r0);
+    } else {
+      rc = launch_kernel_matrix(ctx, dc, dx.dev, n_new, dx.dev, n_new, d, o.dev, n_new, 0.0);
+      GemmArgs g{};
+      g.A = A; g.lda = ld; g.B = A; g.ldb = ld; g.C = o.dev; g.ldc = n_new;
+      g.M = n_new; g.N = n_new; g.K = m; g.alpha = -1.0; g.beta = 1.0; g.ta = 0; g.tb = 1;
+      if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+    }
+  }
+  if (rc == MLN_OK) rc = o.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  triinv_free(&t);
+  if (A) (void)mln_dfree(A);
+  if (kss) (void)mln_dfree(kss);
+  return rc;
+}
+
+// mean covariance (conditional.py:423-440, 947-963):  (K W)(K W)^T,  K = cov(x*, centers), W: m x q
+extern "C" int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew,
+                                           int64_t n_new, int32_t d, const double* centers, int64_t m,
+                                           const double* W, int64_t q, int32_t diag, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n_new < 0 || m < 1 || d < 1 || q < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n_new == 0) return MLN_OK;
+  if (!xnew || !centers || !W || !out) return MLN_ERR_ARG;
+  if (!diag && n_new > 32768) { mln_set_error(ctx, "full covariance is limited to 32768 points"); return MLN_ERR_UNSUPPORTED; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, dcen, dw;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, xnew, (size_t)n_new * d));
+  MLN_TRY(dcen.init(ctx, centers, (size_t)m * d));
+  MLN_TRY(dw.init(ctx, W, (size_t)m * q));
+  MLN_TRY(o.init(ctx, out, diag ? (size_t)n_new : (size_t)n_new * n_new));
+  const int64_t ldq = pad16(q);
+  int64_t chunk = diag ? (int64_t)((1ull << 30) / (sizeof(double) * (size_t)(m + ldq))) : n_new;
+  if (chunk > n_new) chunk = n_new;
+  if (chunk < 1) chunk = 1;
+  double *Kc = nullptr, *T = nullptr;
+  int rc = MLN_OK;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "predict_mean_covariance", __FILE__, __LINE__); };
+  chk(mln_dmalloc((void**)&Kc, sizeof(double) * (size_t)chunk * m));
+  chk(mln_dmalloc((void**)&T, sizeof(double) * (size_t)chunk * ldq));
+  for (int64_t r0 = 0; r0 < n_new && rc == MLN_OK; r0 += chunk) {
+    const int64_t rows = (n_new - r0 < chunk) ? (n_new - r0) : chunk;
+    rc = launch_kernel_matrix(ctx, dc, dx.dev + r0 * d, rows, dcen.dev, m, d, Kc, m, 0.0);
+    GemmArgs g{};
+    g.A = Kc; g.lda = m; g.B = dw.dev; g.ldb = q; g.C = T; g.ldc = ldq;
+    g.M = rows; g.N = q; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+    if (rc != MLN_OK) break;
+    if (diag) {
+      rc = launch_row_sumsq(ctx, T, ldq, rows, q, nullptr, 1.0, o.dev + r0);
+    } else {
+      GemmArgs h{};
+      h.A = T; h.lda = ldq; h.B = T; h.ldb = ldq; h.C = o.dev; h.ldc = n_new;
+      h.M = n_new; h.N = n_new; h.K = q; h.alpha = 1.0; h.beta = 0.0; h.ta = 0; h.tb = 1;
+      rc = launch_dgemm(ctx, h);
+    }
+  }
+  if (rc == MLN_OK) rc = o.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  if (Kc) (void)mln_dfree(Kc);
+  if (T) (void)mln_dfree(T);
+  return rc;
+}
+
 // ---- FunctionEstimator sparse solve ----------------------------------------------------------------
 extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                                 int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,

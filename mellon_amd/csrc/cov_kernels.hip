@@ -318,6 +318,57 @@ __global__ void k_row_sqnorms_all(const double* __restrict__ x, int64_t n, int d
   xx[i] = s;
 }
 
+// diag_i = cov(x_i, x_i) (reference base_cov.py:71-93): the whole program with xy = xx = yy per leaf.
+__global__ void k_cov_diag(DevCov cov, const double* __restrict__ x, int64_t n, int d, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  int sp = 0;
+  for (int t = 0; t < cov.n_toks; ++t) {
+    const int op = cov.tok_op[t];
+    if (op == MLN_OP_LEAF || op == MLN_OP_CONST) {
+      double v;
+      if (op == MLN_OP_CONST) {
+        v = cov.tok_val[t];
+      } else {
+        const DevLeaf lf = cov.leaves[cov.tok_leaf[t]];
+        double xx = 0.0;
+        for (int k = 0; k < lf.ndims; ++k) {
+          const double q = x[i * (int64_t)d + cov.dims[lf.dims_off + k]];
+          xx = fma(q, q, xx);
+        }
+        v = leaf_value(lf, xx, xx, xx);
+      }
+      if (sp > 0) { s2 = s1; s1 = s0; }
+      s0 = v;
+      ++sp;
+    } else {
+      const double l = s1, r = s0;
+      s0 = (op == MLN_OP_ADD) ? (l + r) : (op == MLN_OP_MUL) ? (l * r) : pow(l, r);
+      s1 = s2;
+      --sp;
+    }
+  }
+  out[i] = s0;
+}
+
+// out_i = base_i + sign * sum_j T_ij^2 [* scale_j^2]
+__global__ void k_row_sumsq(const double* __restrict__ T, int64_t ld, int64_t rows, int64_t cols,
+                            const double* __restrict__ base, double sign, double* __restrict__ out) {
+  const int64_t i = blockIdx.x;
+  if (i >= rows) return;
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int64_t j = threadIdx.x; j < cols; j += 256) { const double v = T[i * ld + j]; s = fma(v, v, s); }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[i] = (base ? base[i] : 0.0) + sign * red[0];
+}
+
 int sqnorms(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, double* xx) {
   if (n == 0) return MLN_OK;
   hipLaunchKernelGGL(k_row_sqnorms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cov, x, n, d, xx);
@@ -382,6 +433,21 @@ int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* 
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, y, m, d, yy);
   hipLaunchKernelGGL(k_nn_distances, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, ctx->stream, x, n, y, m, d,
                      xx, yy, self_offset, out);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_cov_diag(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, double* out) {
+  if (n == 0) return MLN_OK;
+  hipLaunchKernelGGL(k_cov_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cov, x, n, d, out);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_row_sumsq(mln_ctx* ctx, const double* T, int64_t ld, int64_t rows, int64_t cols, const double* base,
+                     double sign, double* out) {
+  if (rows == 0) return MLN_OK;
+  hipLaunchKernelGGL(k_row_sumsq, dim3((unsigned)rows), dim3(256), 0, ctx->stream, T, ld, rows, cols, base, sign, out);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

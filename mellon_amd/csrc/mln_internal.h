@@ -66,6 +66,9 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
 int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
                          int64_t m, int d, const double* w, double mu, double* out);
 
+int launch_cov_diag(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, double* out);
+int launch_row_sumsq(mln_ctx* ctx, const double* T, int64_t ld, int64_t rows, int64_t cols, const double* base,
+                     double sign, double* out);
 int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
                         int64_t self_offset, double* out);
 

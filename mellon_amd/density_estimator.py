@@ -97,13 +97,11 @@ class DensityEstimator(BaseEstimator):
     def _build_conditional(self):
         return compute_conditional(self.x, self.landmarks, self.pre_transformation, self.pre_transformation_std,
                                    self.log_density_x, self.mu, self.cov_func, self.L, self.Lp, sigma=None,
-                                   jitter=self.jitter, y_is_mean=True, with_uncertainty=False)
+                                   jitter=self.jitter, y_is_mean=True,
+                                   with_uncertainty=self.predictor_with_uncertainty)
 
     def _set_log_density_func(self):
         logger.info("Computing predictive function.")
-        if self.predictor_with_uncertainty:
-            logger.warning("Predictive uncertainty is outside the accelerated path: building the mean predictor; "
-                           "`pre_transformation_std` (diagonal Laplace) is available on the estimator.")
         f = self._build_conditional()
         f.n_obs = self._n_obs()
         f.d = self.d

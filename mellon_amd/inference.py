@@ -180,13 +180,16 @@ def _dispatch(classes, x, landmarks, pre_transformation, pre_transformation_std,
     if landmarks is None:
         logger.debug("Using FullConditional GP.")
         return Full(x, y, mu, cov_func, Lp, sigma=sigma, jitter=jitter, y_is_mean=y_is_mean,
-                    with_uncertainty=with_uncertainty, obs_variance=obs_variance)
+                    with_uncertainty=with_uncertainty and pre_transformation_std is not None,
+                    obs_variance=obs_variance, parameter_std=pre_transformation_std)
     landmarks = ensure_2d(landmarks)
     if pre_transformation is not None and np.shape(pre_transformation)[0] == landmarks.shape[0]:
         logger.debug("Using LandmarksConditionalCholesky GP.")
         if pre_transformation_std is not None and sigma is not None and np.any(np.asarray(sigma) > 0):
             raise ValueError("One can specify either `sigma` or `pre_transformation_std` "
                              "to describe uncertainty, but not both.")
+        if pre_transformation_std is not None:
+            sigma = pre_transformation_std               # inference.py:470-471
         return Cholesky(landmarks, pre_transformation, mu, cov_func, x.shape[0], Lp, sigma=sigma, jitter=jitter,
                         y_is_mean=y_is_mean, with_uncertainty=with_uncertainty, obs_variance=obs_variance)
     logger.debug("Using LandmarksConditional GP.")

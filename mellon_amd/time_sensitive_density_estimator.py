@@ -79,7 +79,8 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
     def _build_conditional(self):
         return compute_conditional_times(self.x, self.landmarks, self.pre_transformation,
                                          self.pre_transformation_std, self.log_density_x, self.mu, self.cov_func,
-                                         self.L, self.Lp, sigma=None, jitter=self.jitter, y_is_mean=True)
+                                         self.L, self.Lp, sigma=None, jitter=self.jitter, y_is_mean=True,
+                                         with_uncertainty=self.predictor_with_uncertainty)
 
     def _n_obs(self):
         return compute_average_cell_count(self.x, self.normalize_per_time_point)

@@ -497,6 +497,34 @@ class Predictor:
 
     mean = __call__
 
+    # with_uncertainty state: L (factor on the centres) and W = L^-T diag(std)
+    L = None
+    W = None
+
+    def covariance(self, Xnew, diag=True):
+        """conditional.py:409-422,930-945."""
+        Xnew = ensure_2d(Xnew)
+        A = _sp_trsolve(self.L, self.cov_func(self.centers, Xnew), lower=True)
+        if diag:
+            return self.cov_func.diag(Xnew) - np.sum(np.square(A), axis=0)
+        return self.cov_func(Xnew, Xnew) - A.T @ A
+
+    def mean_covariance(self, Xnew, diag=True):
+        """conditional.py:423-440,947-963."""
+        cov_L = self.cov_func(ensure_2d(Xnew), self.centers) @ self.W
+        return np.sum(cov_L * cov_L, axis=1) if diag else cov_L @ cov_L.T
+
+    def uncertainty(self, Xnew, diag=True):
+        """base_predictor.py:390-428."""
+        return self.covariance(Xnew, diag) + self.mean_covariance(Xnew, diag)
+
+    def attach_uncertainty(self, Lf, std):
+        """conditional.py:853-867 (W = L^-T diag(std)); the full conditional reaches the same W through
+        y_cov_factor = L diag(std) (inference.py:357-372, conditional.py:340-362)."""
+        self.L = Lf
+        self.W = _sp_trsolve(Lf.T, np.diag(np.broadcast_to(std, (Lf.shape[0],))), lower=False)
+        return self
+
 
 def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTER,
                      y_is_mean=False):

@@ -260,3 +260,39 @@ def test_native_and_scipy_solvers_agree(mellon):
         assert rel_max(dens, ref) < 1e-5, name
     assert outs["native"][1] < outs["plain"][1] / 2          # preconditioning pays
     assert rel_max(outs["native"][0], outs["scipy"][0]) < 1e-6
+
+
+@pytest.mark.parametrize("n_landmarks", [0, 10])
+def test_predictor_with_uncertainty(mellon, small_x, n_landmarks, tmp_path):
+    """tests/test_density_estimator.py:165-234 (shapes + JSON round trip) with Laplace instead of ADVI,
+    plus parity of covariance / mean_covariance / uncertainty against the oracle."""
+    est = mellon.DensityEstimator(n_landmarks=n_landmarks, predictor_with_uncertainty=True)
+    est.fit(small_x)
+    pred = est.predict
+    n = small_x.shape[0]
+    cov, mcov, unc = pred.covariance(small_x), pred.mean_covariance(small_x), pred.uncertainty(small_x)
+    assert cov.shape == mcov.shape == unc.shape == (n,)
+    assert pred.covariance(small_x, diag=False).shape == (n, n)
+    assert pred.mean_covariance(small_x, diag=False).shape == (n, n)
+    assert pred.uncertainty(small_x, diag=False).shape == (n, n)
+    # oracle with the same factor / parameter std
+    ref = mo.density_fit(small_x, n_landmarks=n_landmarks, lbfgsb_options=mo.LBFGSB_TIGHT)
+    V, _ = mo.nn_likelihood_constants(ref.nn_distances, ref.d)
+    std = mo.laplace_std(ref.pre_transformation, ref.L, ref.mu, V)
+    assert rel_max(est.pre_transformation_std, std) < 1e-4
+    op = ref.predict.attach_uncertainty(ref.Lp, std)
+    xq = small_x[:37] * 1.1 + 0.05
+    assert np.abs(pred.covariance(xq) - op.covariance(xq)).max() < 1e-7
+    assert rel_max(pred.mean_covariance(xq), op.mean_covariance(xq)) < 1e-4
+    assert rel_max(pred.uncertainty(xq, diag=False), op.uncertainty(xq, diag=False)) < 1e-4
+    assert np.allclose(np.diag(pred.uncertainty(xq, diag=False)), pred.uncertainty(xq), rtol=1e-8, atol=1e-10)
+    # JSON round trip keeps L and W
+    path = str(tmp_path / "u.json")
+    pred.to_json(path)
+    again = mellon.Predictor.from_json(path)
+    assert np.allclose(again.uncertainty(xq), pred.uncertainty(xq), rtol=1e-10)
+    plain = mellon.DensityEstimator(n_landmarks=n_landmarks).fit(small_x).predict
+    with pytest.raises(ValueError):
+        plain.covariance(small_x)
+    with pytest.raises(ValueError):
+        plain.mean_covariance(small_x)

@@ -205,3 +205,18 @@ def test_covariance_dict_round_trip():
     c2 = mo.Covariance.from_dict(state)
     x, y = _data(7, 2), _data(3, 2, seed=5)
     assert np.allclose(c(x, y), c2(x, y))
+
+
+def test_predictive_uncertainty_identities():
+    """conditional.py:409-440: at the training cells of a full GP the posterior variance is
+    k(x,x) - sum((L^-1 K)^2) = jitter-level; mean covariance is PSD; diag == diagonal of the full form."""
+    x = _data(60)
+    fit = mo.density_fit(x)
+    std = mo.laplace_std(fit.pre_transformation, fit.L, fit.mu, mo.nn_likelihood_constants(fit.nn_distances, fit.d)[0])
+    p = fit.predict.attach_uncertainty(fit.Lp, std)
+    xq = _data(15, seed=9)
+    for f in (p.covariance, p.mean_covariance, p.uncertainty):
+        full = f(xq, diag=False)
+        assert full.shape == (15, 15) and np.allclose(np.diag(full), f(xq), rtol=1e-9, atol=1e-12)
+    assert np.all(p.covariance(x) < 1e-4) and np.all(p.covariance(xq) > -1e-9)
+    assert np.all(np.linalg.eigvalsh(p.mean_covariance(xq, diag=False)) > -1e-10)
