@@ -101,6 +101,8 @@ def main():
     t_gen = time.perf_counter()
     x_all = gaussian_mixture(n, d, args.seed)
     landmarks = make_landmarks(x_all, m)
+    if world > 1:   # replicated inputs must be BIT-identical on every rank (they steer the shared optimiser)
+        landmarks = comm.allreduce_sum(landmarks if rank == 0 else np.zeros_like(landmarks))
     lo, hi = distributed.shard_bounds(n, world, rank)
     x_all_dev = ctx.to_device(x_all)
     x_loc_dev = ctx.to_device(x_all[lo:hi]) if world > 1 else x_all_dev
