@@ -36,12 +36,14 @@ typedef int (*GetUniqueId_t)(UniqueId*);
 typedef int (*CommInitRank_t)(void**, int, UniqueId, int);
 typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*CommDestroy_t)(void*);
+typedef int (*Broadcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*GetErrorString_t)(int);
 static void* lib = nullptr;
 static GetUniqueId_t GetUniqueId = nullptr;
 static CommInitRank_t CommInitRank = nullptr;
 static AllReduce_t AllReduce = nullptr;
 static CommDestroy_t CommDestroy = nullptr;
+static Broadcast_t Broadcast = nullptr;
 static GetErrorString_t GetErrorString = nullptr;
 constexpr int kDouble = 8;  // ncclFloat64
 constexpr int kSum = 0;     // ncclSum
@@ -57,6 +59,7 @@ static bool load(std::string* why) {
   CommInitRank = (CommInitRank_t)dlsym(lib, "ncclCommInitRank");
   AllReduce = (AllReduce_t)dlsym(lib, "ncclAllReduce");
   CommDestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
+  Broadcast = (Broadcast_t)dlsym(lib, "ncclBroadcast");
   GetErrorString = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
   if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { *why = "librccl lacks nccl symbols"; return false; }
   return true;
@@ -299,6 +302,15 @@ static int dev_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
   if (!ctx->comm || count <= 0) return MLN_OK;   // a 1-rank communicator still goes through RCCL
   int rc = rccl::AllReduce(dev, dev, (size_t)count, rccl::kDouble, rccl::kSum, ctx->comm, ctx->stream);
   if (rc != 0) return rccl_fail(ctx, rc, "ncclAllReduce");
+  return MLN_OK;
+}
+
+// rank 0's copy becomes everybody's: replicated m-vectors that steer the shared optimiser are made
+// bit-identical on every rank, so that the ranks can never disagree on a line-search decision
+static int dev_bcast0(mln_ctx* ctx, double* dev, int64_t count) {
+  if (!ctx->comm || ctx->n_ranks <= 1 || count <= 0 || !rccl::Broadcast) return MLN_OK;
+  int rc = rccl::Broadcast(dev, dev, (size_t)count, rccl::kDouble, 0, ctx->comm, ctx->stream);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclBroadcast");
   return MLN_OK;
 }
 
@@ -946,6 +958,13 @@ static int fit_objective_u(mln_fit* f, const double* u, double* loss, double* gr
     MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_z, 1.0, f->d_out + 1));              // + z (prior)
     MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));              // g_u = C^-1 g_z
   }
+  if (ctx->n_ranks > 1) {   // [lik, g_u, z] of rank 0 for everyone (see dev_bcast0)
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_out + 1 + m, f->d_z, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+    MLN_TRY(dev_bcast0(ctx, f->d_out, 1 + 2 * m));
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_gu, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_z, f->d_out + 1 + m, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
@@ -995,6 +1014,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // u0 = C^T z0
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, z0, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));
+  MLN_TRY(dev_bcast0(ctx, f->d_gu, (int64_t)m));   // identical starting point on every rank
   MLN_HIP(ctx, hipMemcpyAsync(u.data(), f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   double fx = 0.0;
