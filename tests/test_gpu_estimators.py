@@ -296,3 +296,42 @@ def test_predictor_with_uncertainty(mellon, small_x, n_landmarks, tmp_path):
         plain.covariance(small_x)
     with pytest.raises(ValueError):
         plain.mean_covariance(small_x)
+
+
+def test_edge_cases(mellon):
+    """Ragged / degenerate inputs the reference's validators and tests care about."""
+    rng = np.random.default_rng(3)
+    # duplicated cells: zero nearest-neighbour distances are repaired (validation.py:563-592)
+    x = rng.normal(size=(60, 3))
+    xd = np.concatenate([x, x[:20]])
+    est = mellon.DensityEstimator(n_landmarks=12)
+    dens = est.fit_predict(xd)
+    assert np.all(np.isfinite(dens)) and np.all(est.nn_distances > 0)
+    ref = mo.density_fit(xd, landmarks=est.landmarks, nn_distances=est.nn_distances, lbfgsb_options=mo.LBFGSB_TIGHT)
+    assert rel_max(dens, ref.log_density_x) < 1e-5
+    # tiny problems: full GP with 5 cells; two landmarks
+    tiny = rng.normal(size=(5, 2))
+    d5 = mellon.DensityEstimator().fit_predict(tiny)
+    assert d5.shape == (5,) and rel_max(d5, mo.density_fit(tiny, lbfgsb_options=mo.LBFGSB_TIGHT).log_density_x) < 1e-5
+    two = mellon.DensityEstimator(n_landmarks=2)
+    d2 = two.fit_predict(x)
+    assert rel_max(d2, mo.density_fit(x, landmarks=two.landmarks, nn_distances=two.nn_distances,
+                                      lbfgsb_options=mo.LBFGSB_TIGHT).log_density_x) < 1e-5
+    # empty query, 1-row query
+    assert two.predict(np.zeros((0, 3))).shape == (0,)
+    assert two.predict(x[:1]).shape == (1,)
+    # n_landmarks >= n falls back to the full GP (parameters.py:199-240)
+    full = mellon.DensityEstimator(n_landmarks=100)
+    full.fit(x)
+    assert full.gp_type == mellon.GaussianProcessType.FULL and full.landmarks is None
+    # more landmarks than this build supports
+    big = rng.normal(size=(8300, 2))
+    with pytest.raises(NotImplementedError):
+        mellon.DensityEstimator(landmarks=big[:8200], nn_distances=np.ones(8300)).fit(big)
+    # ragged landmark count (not a multiple of any tile size) and odd d
+    odd = rng.normal(size=(777, 7))
+    eo = mellon.DensityEstimator(n_landmarks=129)
+    do = eo.fit_predict(odd)
+    assert rel_max(eo.predict(odd), do) < 1e-8
+    assert rel_max(do, mo.density_fit(odd, landmarks=eo.landmarks, nn_distances=eo.nn_distances,
+                                      lbfgsb_options=mo.LBFGSB_TIGHT).log_density_x) < 1e-5
