@@ -160,6 +160,7 @@ int mln_lower_cov(mln_ctx* ctx, const mln_kernel_desc* cov, int d, DevCov* out) 
     }
     out->leaves[l].kind = lf.kind; out->leaves[l].ndims = lf.ndims; out->leaves[l].dims_off = off;
     out->leaves[l].ls = lf.ls; out->leaves[l].alpha = lf.alpha;
+    out->leaves[l].alpha_inv_ls[0] = lf.alpha; out->leaves[l].alpha_inv_ls[1] = 1.0 / lf.ls;
     for (int k = 0; k < lf.ndims; ++k) {
       if (lf.dims[k] < 0 || lf.dims[k] >= d) { mln_set_error(ctx, "active dim out of range"); return MLN_ERR_SHAPE; }
       out->dims[off + k] = (short)lf.dims[k];

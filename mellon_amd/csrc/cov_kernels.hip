@@ -13,30 +13,33 @@ namespace {
 
 constexpr int TM = 64, TN = 64, DK = 16, PADT = 4;
 
+// Divisions by the length scale / by 3 are multiplications by the reciprocal (one rounding instead of
+// a ~20-instruction fp64 divide per element): values differ from the reference's `x / ls` by <= 1 ulp.
 __device__ __forceinline__ double leaf_value(const DevLeaf& lf, double xx, double yy, double xy) {
-  if (lf.kind == MLN_K_LINEAR) return xy / lf.ls;           // cov.py:554
+  const double inv_ls = lf.alpha_inv_ls[1];
+  if (lf.kind == MLN_K_LINEAR) return xy * inv_ls;          // cov.py:554
   // util.py:362-366: sq = xx - 2 xy + yy + 1e-12 ; dist = sqrt(max(sq, 0))
   double sq = xx - 2.0 * xy + yy + 1e-12;
   double dist = sqrt(fmax(sq, 0.0));
   switch (lf.kind) {
     case MLN_K_MATERN32: {                                  // cov.py:64-65
-      double r = sqrt(3.0) * dist / lf.ls;
+      double r = 1.7320508075688772 * dist * inv_ls;
       return (r + 1.0) * exp(-r);
     }
     case MLN_K_MATERN52: {                                  // cov.py:159-160
-      double r = sqrt(5.0) * dist / lf.ls;
-      return (r + r * r / 3.0 + 1.0) * exp(-r);
+      double r = 2.23606797749979 * dist * inv_ls;
+      return (r + r * r * 0.3333333333333333 + 1.0) * exp(-r);
     }
     case MLN_K_EXPQUAD: {                                   // cov.py:257-258
-      double r = dist / lf.ls;
-      return exp(-(r * r) / 2.0);
+      double r = dist * inv_ls;
+      return exp(-0.5 * (r * r));
     }
     case MLN_K_EXPONENTIAL: {                               // cov.py:354-355
-      double r = dist / lf.ls;
-      return exp(-r / 2.0);
+      double r = dist * inv_ls;
+      return exp(-0.5 * r);
     }
     default: {                                              // RatQuad cov.py:455-456
-      double r = dist / lf.ls;
+      double r = dist * inv_ls;
       return pow(r * r / (2.0 * lf.alpha) + 1.0, -lf.alpha);
     }
   }

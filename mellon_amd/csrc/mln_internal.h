@@ -47,6 +47,7 @@ struct DevLeaf {
   int pad;
   double ls;
   double alpha;
+  double alpha_inv_ls[2];  // [1] = 1 / ls
 };
 struct DevCov {
   int n_leaves;
@@ -76,7 +77,6 @@ int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* 
 //   ta = 0: A is M x K (lda >= K);  ta = 1: A is stored K x M (lda >= M)
 //   tb = 0: B is K x N (ldb >= N);  tb = 1: B is stored N x K (ldb >= K)
 //   lower_only: skip 128x128 tiles strictly above the diagonal (square C)
-//   ktri: 0 none; 1: for output-column tile J only k < min(K, (J+1)*128 + koff) contributes (B lower-tri NT)
 //   split_k > 1: writes split_k partial C's at C + s * c_split_stride (beta ignored, alpha applied)
 struct GemmArgs {
   const double* A; int64_t lda;
@@ -92,13 +92,8 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g);
 int launch_sum_partials(mln_ctx* ctx, const double* parts, int n_parts, int64_t stride, double* out,
                         int64_t count, double beta);
 
-// linalg.hip
+// linalg.hip (block-solve helpers are declared in linalg.h)
 int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda);       // in place; zeroes upper
-int dev_trsv_lower(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, int trans, double* b);
-int dev_trsm_left_lower(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, int trans, double* B,
-                        int64_t p, int64_t ldb);                                // B (m x p) <- op(Lf)^-1 B
-int dev_trsm_right_lowerT(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, double* Xm, int64_t n,
-                          int64_t ldx);                                         // X (n x m) <- X Lf^-T
 int launch_add_diag(mln_ctx* ctx, double* A, int64_t m, int64_t lda, double v);
 int launch_symmetrize_from_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda);
 int launch_axpby(mln_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);
