@@ -123,10 +123,15 @@ def main():
         comm.barrier()
         ctx.synchronize()
 
+    def release(est):
+        """Return the fit's device buffers (to the library's cache) deterministically."""
+        est._fit.close()
+
     for _ in range(args.warmup):
         est, dens = one_step()
+        release(est)
         del est
-        gc.collect()
+    gc.collect()
     fence()
     t_fit = t_free = 0.0
     t0 = time.perf_counter()
@@ -137,8 +142,8 @@ def main():
         stats = est._fit.stage_times()
         n_eval = est.loss_func.n_eval
         if _ + 1 < args.steps:
+            release(est)
             del est
-            gc.collect()
         t_fit += tb - ta
         t_free += time.perf_counter() - tb
     fence()
