@@ -392,3 +392,26 @@ def test_kmeans_landmarks(ctx):
     small = x[:50]
     cs = ctx.kmeans(small, 50, seed=1)
     assert np.allclose(np.sort(cs, axis=0), np.sort(small, axis=0))
+
+
+@pytest.mark.parametrize("m", [2100, 6000, 8100])
+def test_objective_wide_landmark_counts(ctx, m):
+    """Every column-per-thread specialisation of k_objective (m up to the 8192 limit) against NumPy."""
+    from mellon_amd import _lib
+    rng = np.random.default_rng(m)
+    n = 1500
+    L = rng.normal(size=(n, m)) * (0.5 / np.sqrt(m))
+    nn = rng.uniform(0.2, 1.0, size=n)
+    V, Vdr = mo.nn_likelihood_constants(nn, 5)
+    fit = _lib.Fit.from_L(ctx, L)
+    fit.set_likelihood(V, Vdr, -3.0)
+    z = rng.normal(size=m) * 0.3
+    loss, grad, hess = fit.objective(z, with_hess=True)
+    loss_ref, grad_ref = mo.loss_and_grad(z, L, -3.0, V, Vdr)
+    a = np.exp(L @ z - 3.0 + V)
+    assert abs(loss - loss_ref) < 1e-12 * abs(loss_ref)
+    assert relmax(grad, grad_ref) < 1e-11 and relmax(hess, 1.0 + (L * L).T @ a) < 1e-11
+    assert relmax(fit.transform(z, -3.0), L @ z - 3.0) < 1e-12
+    u = fit.precond_apply(0, z)
+    lu, gu, zb = fit.objective_precond(u)
+    assert abs(lu - loss_ref) < 1e-10 * abs(loss_ref) and relmax(zb, z) < 1e-9
