@@ -38,7 +38,8 @@ typedef enum {
   MLN_ERR_HIP = 3,         /* HIP runtime failure (text in mln_last_error)                  */
   MLN_ERR_RCCL = 4,        /* RCCL failure                                                  */
   MLN_ERR_ARG = 5,         /* null pointer / bad enum / unsupported descriptor              */
-  MLN_ERR_UNSUPPORTED = 6  /* valid request this build cannot serve (e.g. m too large)      */
+  MLN_ERR_UNSUPPORTED = 6, /* valid request this build cannot serve (e.g. m too large)      */
+  MLN_ERR_NOCONV = 7       /* an iterative kernel (Jacobi eigensolver) did not converge     */
 } mln_status;
 
 /* ---- kernel-plugin surface: mellon/base_cov.py:17-497 + mellon/cov.py ------------------- */
@@ -156,6 +157,24 @@ void mln_fit_destroy(mln_fit* fit);
 int mln_fit_get_Lp(mln_fit* fit, double* out /* m x m */);
 int mln_fit_get_L(mln_fit* fit, int64_t row0, int64_t n_rows, double* out /* n_rows x m */);
 int mln_fit_rank(mln_fit* fit, int64_t* m_out); /* number of columns of L */
+
+/* ---- Nystroem rank reduction (decomposition.py:23-76,126-171,213-266) ---------------------------
+ * mln_eigh replaces jax.numpy.linalg.eigh at decomposition.py:50 (_eigendecomposition): A (m x m,
+ * symmetrised as (A + A^T)/2 like jax's symmetrize_input default) -> w (m, ascending) and V (m x m
+ * row-major, COLUMN j = eigenvector j; sign of each column is arbitrary as in LAPACK).  Block
+ * one-sided Jacobi on the device; MLN_ERR_NOCONV if 40 sweeps do not orthogonalise.
+ *
+ * _modified_low_rank (:213-266: QR of C = cov(x,xu), eigh of W = cov(xu,xu)+sigma2 I, eigh of
+ * R W^-1 R^T, L = Q V sqrt(S)) is computed through the identity  L L^T = B U_p U_p^T B^T  with
+ * B = C Lp^-T (the factor of an explicit mln_fit_prepare handle, Lp Lp^T = W) and (S, U) the
+ * eigenpairs of the m x m Gram B^T B = Lp^-1 C^T C Lp^-T  (same non-zero spectrum as R W^-1 R^T):
+ *   mln_fit_gram_eigh : S (m, ascending) to the host, U kept in the handle   [all-reduce of the Gram]
+ *   mln_fit_project   : new handle with L = B U[:, m-p:]  (n_local x p; columns ordered like the
+ *                       reference's s[-p:], v[:, -p:]; column signs arbitrary)
+ * The rank rule of _eigendecomposition (:51-76) is host logic on S (mellon_amd/decomposition.py).   */
+int mln_eigh(mln_ctx* ctx, const double* A, int64_t m, double* w, double* V, int32_t* n_sweeps);
+int mln_fit_gram_eigh(mln_fit* fit, double* w /* m */, int32_t* n_sweeps);
+int mln_fit_project(mln_fit* fit, int64_t p, mln_fit** out);
 
 /* a-9: Ridge initial value  z0 = (L^T L + I)^-1 L^T target   (parameters.py:877-896;
  * sklearn Ridge(alpha=1, fit_intercept=False)).  target: n_local.  All-reduced over ranks.     */

@@ -71,6 +71,9 @@ SYMBOLS = [
     ("mln_fit_get_Lp", C.c_int, [_vp, _dp]),
     ("mln_fit_get_L", C.c_int, [_vp, _i64, _i64, _dp]),
     ("mln_fit_rank", C.c_int, [_vp, C.POINTER(_i64)]),
+    ("mln_eigh", C.c_int, [_vp, _dp, _i64, _dp, _dp, C.POINTER(_i32)]),
+    ("mln_fit_gram_eigh", C.c_int, [_vp, _dp, C.POINTER(_i32)]),
+    ("mln_fit_project", C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     ("mln_ridge_init", C.c_int, [_vp, _dp, _dp]),
     ("mln_precond_build", C.c_int, [_vp, _i64]),
     ("mln_precond_apply", C.c_int, [_vp, _i32, _dp, _dp]),
@@ -278,6 +281,17 @@ class Context:
                     jitter=add_diag if jitter is None else jitter)
         return A
 
+    def eigh(self, A):
+        """(w ascending, V with eigenvectors as columns) of the symmetric A -- jnp.linalg.eigh."""
+        A = _f64(A)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("A must be square")
+        m = A.shape[0]
+        w, V, sw = np.empty(m), np.empty((m, m)), _i32(0)
+        self._check(self.lib.mln_eigh(self.handle, A.ctypes.data, m, w.ctypes.data, V.ctypes.data, C.byref(sw)))
+        self.last_eigh_sweeps = int(sw.value)
+        return w, V
+
     def trsm_lower(self, Lf, B, trans=False):
         Lf = _f64(Lf)
         B2 = _f64(B).copy()
@@ -369,6 +383,25 @@ class Fit:
         self.implicit = False
         self._has_lp = Lp_ is not None
         return self
+
+    def gram_eigh(self):
+        """Eigenvalues (ascending) of L^T L over all cells of all ranks; eigenvectors stay on the device."""
+        w, sw = np.empty(self.m), _i32(0)
+        self.ctx._check(self.lib.mln_fit_gram_eigh(self.handle, w.ctypes.data, C.byref(sw)))
+        self.last_eigh_sweeps = int(sw.value)
+        return w
+
+    def project(self, p):
+        """New handle with L <- L U[:, -p:] (top-p eigenvectors of L^T L, after gram_eigh)."""
+        new = Fit.__new__(Fit)
+        new.ctx, new.lib, new.handle = self.ctx, self.lib, None
+        h = C.c_void_p()
+        self.ctx._check(self.lib.mln_fit_project(self.handle, int(p), C.byref(h)))
+        new.handle = h.value
+        new.n, new.d, new.m, new.jitter = self.n, None, int(p), None
+        new.implicit = False
+        new._has_lp = False
+        return new
 
     def __init__(self, ctx, desc, x, landmarks, jitter, Lp=None, implicit=False):
         self.ctx, self.lib, self.handle = ctx, ctx.lib, None

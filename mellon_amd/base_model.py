@@ -7,7 +7,7 @@ import numpy as np
 
 from . import _lib
 from .cov import Matern52
-from .decomposition import FactorL, FactorLp
+from .decomposition import FactorL, FactorLp, _full_decomposition_low_rank, _modified_low_rank
 from .inference import (DEFAULT_INIT_LEARN_RATE, DEFAULT_JIT, DEFAULT_N_ITER, DEFAULT_OPTIMIZER,
                         compute_laplace_std, minimize_adam, minimize_lbfgsb, run_advi)
 from .parameter_validation import validate_cov_func, validate_cov_func_curry, validate_params
@@ -138,21 +138,23 @@ class BaseEstimator:
         logger.info("Using covariance function %s.", str(cov_func))
         return cov_func
 
-    def _unsupported_gp_type(self):
-        if self.gp_type in (GaussianProcessType.FULL_NYSTROEM, GaussianProcessType.SPARSE_NYSTROEM):
-            raise NotImplementedError(
-                f"gp_type={self.gp_type}: Nystroem rank reduction is outside the accelerated path of this "
-                "build (SURVEY.md S8f rank 4); use 'full' or 'sparse_cholesky'.")
-
     def _device_fit(self):
         """One mln_fit handle computes Lp AND L (parameters.compute_Lp + compute_L of the reference)."""
         if self._fit is not None:
             return self._fit
-        self._unsupported_gp_type()
         ctx = _lib.default_context()
         given_L = self.L if not isinstance(self.L, (FactorL, FactorLp)) else None
         if isinstance(self.L, (FactorL, FactorLp)):
             self._fit = self.L.fit
+        elif given_L is None and self.gp_type == GaussianProcessType.FULL_NYSTROEM:
+            self._require_single_process("full_nystroem factor")
+            logger.info("Computing rank reduction using all cells (full Nystroem).")
+            self._fit = _full_decomposition_low_rank(self.x, self.cov_func, rank=self.rank, jitter=self.jitter).fit
+        elif given_L is None and self.gp_type == GaussianProcessType.SPARSE_NYSTROEM:
+            logger.info("Computing improved Nystroem rank reduction on the landmarks.")
+            xin = self.x if isinstance(self.x, _lib.DeviceArray) else np.ascontiguousarray(self.x)
+            self._fit = _modified_low_rank(xin, self.cov_func, self.landmarks, rank=self.rank,
+                                           jitter=self.jitter).fit
         elif given_L is not None:
             Lp = None if self.Lp is None else np.asarray(self.Lp, dtype=np.float64)
             if Lp is None and self.gp_type == GaussianProcessType.FULL:

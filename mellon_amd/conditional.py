@@ -96,9 +96,9 @@ class _LandmarksConditional:
         if with_uncertainty:
             raise NotImplementedError("uncertainty of the noisy landmark conditional (Cs = Lp L_B, "
                                       "conditional.py:694-716) is outside the accelerated path.")
-        if y_is_mean:
-            raise NotImplementedError("LandmarksConditional with y_is_mean=True is outside the accelerated path.")
-        s = _scalar_sigma(sigma)
+        # y_is_mean (conditional.py:536-537) feeds _sparse_solve with (r, A) unscaled, which is what
+        # _process_sigma produces for sigma = 1: L_B L_B^T = A A^T + I, c = L_B^-1 A r.
+        s = 1.0 if y_is_mean else _scalar_sigma(sigma)
         if s is None or not s > 0:
             raise ValueError("sigma must be a positive scalar for the landmark conditional "
                              "(the reference divides by sigma^2, conditional.py:157-159).")

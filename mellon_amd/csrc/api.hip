@@ -423,6 +423,12 @@ struct mln_fit {
   // mln_transform / mln_weights_cholesky on that same z skip the triangular solve
   std::vector<double> z_cached;
   double* d_w_cached = nullptr;
+  // stacked preconditioner operators, so that one evaluation needs two row-GEMVs and no reductions:
+  //   Q1 = [C^-T ; P]  (2m x ldl, implicit) or C^-T (m x ldl):   [z ; w] = Q1 u
+  //   Q2 = [C^-1 | P^T] (m x 2 ldl, implicit) or C^-1:            g_u = Q2 [z ; K^T(a-1)]
+  double *Q1 = nullptr, *Q2 = nullptr, *d_zw = nullptr, *d_zr = nullptr;
+  // eigenvectors of L^T L (rows, ascending eigenvalue), m x ldl: Nystroem rank reduction
+  double* eigU = nullptr;
 };
 
 static void fit_free(mln_fit* f) {
@@ -434,7 +440,8 @@ static void fit_free(mln_fit* f) {
   if (f->Lp) (void)mln_dfree(f->Lp);
   triinv_free(&f->tri);
   void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
-                  f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w, f->d_w_cached};
+                  f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w, f->d_w_cached,
+                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (f->h_z) (void)hipHostFree(f->h_z);
   if (f->h_out) (void)hipHostFree(f->h_out);
@@ -459,6 +466,9 @@ static int fit_alloc_workspace(mln_fit* f) {
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_tmp, sizeof(double) * (1 + pm)));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_w, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_w_cached, sizeof(double) * pm));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_zw, sizeof(double) * 2 * pm));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_zr, sizeof(double) * 2 * pm));
+  MLN_HIP(ctx, hipMemsetAsync(f->d_zr, 0, sizeof(double) * 2 * pm, ctx->stream));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_loss, sizeof(double) * n_wg));
@@ -582,6 +592,93 @@ extern "C" int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, in
   int rc = body();
   if (rc != MLN_OK) { fit_free(f); return rc; }
   *out = f;
+  return MLN_OK;
+}
+
+static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
+                   int64_t ldg);
+
+extern "C" int mln_eigh(mln_ctx* ctx, const double* A, int64_t m, double* w, double* V, int32_t* n_sweeps) {
+  if (!ctx || (m > 0 && (!A || !w || !V))) return MLN_ERR_ARG;
+  if (m < 0 || m > 32768) { mln_set_error(ctx, "eigh: m out of range"); return MLN_ERR_SHAPE; }
+  if (n_sweeps) *n_sweeps = 0;
+  if (m == 0) return MLN_OK;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevIn a;
+  DevOut v;
+  MLN_TRY(a.init(ctx, A, (size_t)m * m));
+  MLN_TRY(v.init(ctx, V, (size_t)m * m));
+  double* rows = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&rows, sizeof(double) * (size_t)m * m));
+  std::vector<double> wh((size_t)m);
+  int sweeps = 0;
+  int rc = dev_eigh(ctx, a.dev, m, m, wh.data(), rows, m, &sweeps);
+  if (rc == MLN_OK) rc = launch_transpose(ctx, rows, m, v.dev, m, m);   // eigenvectors as columns
+  if (rc == MLN_OK) rc = v.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(rows);
+  if (rc != MLN_OK) return rc;
+  if (n_sweeps) *n_sweeps = sweeps;
+  if (is_device_ptr(w)) MLN_HIP(ctx, hipMemcpy(w, wh.data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice));
+  else std::memcpy(w, wh.data(), sizeof(double) * (size_t)m);
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_gram_eigh(mln_fit* f, double* w, int32_t* n_sweeps) {
+  if (!f || !w) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (f->kspace) {
+    mln_set_error(ctx, "gram_eigh needs the explicit factor (prepare without MLN_FIT_IMPLICIT)");
+    return MLN_ERR_UNSUPPORTED;
+  }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t m = f->m, ld = f->ldl;
+  double* G = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * (size_t)m * ld));
+  int rc = gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld);   // all cells, all ranks
+  if (rc == MLN_OK && !f->eigU) {
+    hipError_t e = mln_dmalloc((void**)&f->eigU, sizeof(double) * (size_t)m * ld);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc eigenvectors", __FILE__, __LINE__);
+  }
+  std::vector<double> wh((size_t)m);
+  int sweeps = 0;
+  if (rc == MLN_OK) rc = dev_eigh(ctx, G, m, ld, wh.data(), f->eigU, ld, &sweeps);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(G);
+  if (rc != MLN_OK) return rc;
+  if (n_sweeps) *n_sweeps = sweeps;
+  std::memcpy(w, wh.data(), sizeof(double) * (size_t)m);
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_project(mln_fit* f, int64_t p, mln_fit** out) {
+  if (!f || !out) return MLN_ERR_ARG;
+  *out = nullptr;
+  mln_ctx* ctx = f->ctx;
+  if (!f->eigU) { mln_set_error(ctx, "project: call mln_fit_gram_eigh first"); return MLN_ERR_ARG; }
+  if (p < 1 || p > f->m) { mln_set_error(ctx, "project: rank out of range"); return MLN_ERR_SHAPE; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  mln_fit* g = new mln_fit();
+  g->ctx = ctx; g->n = f->n; g->m = p; g->d = 0; g->full = false;
+  g->ldl = pad16(p); g->ldp = pad16(p);
+  auto body = [&]() -> int {
+    const size_t l_bytes = sizeof(double) * (size_t)(g->n > 0 ? g->n : 1) * g->ldl;
+    MLN_HIP(ctx, mln_dmalloc((void**)&g->L, l_bytes));
+    MLN_HIP(ctx, hipMemsetAsync(g->L, 0, l_bytes, ctx->stream));
+    if (g->n > 0) {
+      GemmArgs a{};
+      a.A = f->L; a.lda = f->ldl; a.ta = 0;                                   // B (n x m)
+      a.B = f->eigU + (f->m - p) * f->ldl; a.ldb = f->ldl; a.tb = 1;          // top-p eigenvectors as rows
+      a.C = g->L; a.ldc = g->ldl;
+      a.M = g->n; a.N = p; a.K = f->m; a.alpha = 1.0; a.beta = 0.0; a.split_k = 1;
+      MLN_TRY(launch_dgemm(ctx, a));
+    }
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return fit_alloc_workspace(g);
+  };
+  int rc = body();
+  if (rc != MLN_OK) { fit_free(g); return rc; }
+  *out = g;
   return MLN_OK;
 }
 
@@ -851,6 +948,29 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
     if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);
     if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, f->P, m, ldg);
   }
+  if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs
+    const int64_t ld = ldg;
+    const size_t blk = (size_t)m * ld;
+    const int nq = f->kspace ? 2 : 1;
+    hipError_t e = mln_dmalloc((void**)&f->Q1, sizeof(double) * blk * nq);
+    if (e == hipSuccess) e = mln_dmalloc((void**)&f->Q2, sizeof(double) * blk * nq);
+    if (e == hipSuccess) e = hipMemsetAsync(f->Q1, 0, sizeof(double) * blk * nq, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(f->Q2, 0, sizeof(double) * blk * nq, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc stacked operators", __FILE__, __LINE__);
+    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ld, f->Q1, ld, m);                      // C^-T
+    if (rc == MLN_OK && f->kspace) rc = launch_copy_block(ctx, f->P, ld, f->Q1 + blk, ld, m, ld);   // P below it
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2, ld * nq, m, ld);             // C^-1
+    if (rc == MLN_OK && f->kspace) {                                                           // P^T beside it
+      double* Pt = nullptr;
+      e = mln_dmalloc((void**)&Pt, sizeof(double) * blk);
+      if (e == hipSuccess) e = hipMemsetAsync(Pt, 0, sizeof(double) * blk, ctx->stream);
+      if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P^T", __FILE__, __LINE__);
+      if (rc == MLN_OK) rc = launch_transpose(ctx, f->P, ld, Pt, ld, m);
+      if (rc == MLN_OK) rc = launch_copy_block(ctx, Pt, ld, f->Q2 + ld, ld * 2, m, ld);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (Pt) (void)mln_dfree(Pt);
+    }
+  }
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&t);
   if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
@@ -939,25 +1059,28 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
 static int fit_objective_u(mln_fit* f, const double* u, double* loss, double* grad_u, double* z_out) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m;
+  const int64_t ld = f->ldl;
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
-  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_z));                       // z = C^-T u
+  // [z ; w] = Q1 u   (z = C^-T u ; implicit mode: w = P u = Lp^-T z)
+  MLN_TRY(launch_gemv_rows(ctx, f->Q1, ld, f->kspace ? 2 * m : m, m, f->d_u, f->d_zw));
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_z, f->d_zw, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
   ObjArgs a = obj_args(f);
-  if (f->kspace) {
-    MLN_TRY(fit_small_gemv(f, f->P, 0, f->d_u, f->d_w));                        // w = P u
-    a.z = f->d_w;
-  }
+  a.z = f->kspace ? (f->d_zw + m) : f->d_zw;
   MLN_HIP(ctx, hipEventRecord(f->ev0, ctx->stream));
   MLN_TRY(launch_objective(ctx, a));
   MLN_HIP(ctx, hipEventRecord(f->ev1, ctx->stream));
   MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
   MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + m));
   if (f->kspace) {
-    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_z, f->d_gu));                    // C^-1 z
-    MLN_TRY(fit_small_gemv(f, f->P, 1, f->d_out + 1, f->d_w));                  // P^T r
-    MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_w, 1.0, f->d_gu));
+    // g_u = C^-1 z + P^T r = Q2 [z ; r]
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_zr, f->d_zw, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_zr + ld, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+    MLN_TRY(launch_gemv_rows(ctx, f->Q2, 2 * ld, m, 2 * ld, f->d_zr, f->d_gu));
   } else {
-    MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_z, 1.0, f->d_out + 1));              // + z (prior)
-    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));              // g_u = C^-1 g_z
+    // g_u = C^-1 (z + L^T (a - 1))
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_zr, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
+    MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_zw, 1.0, f->d_zr));
+    MLN_TRY(launch_gemv_rows(ctx, f->Q2, ld, m, m, f->d_zr, f->d_gu));
   }
   if (ctx->n_ranks > 1) {   // [lik, g_u, z] of rank 0 for everyone (see dev_bcast0)
     MLN_HIP(ctx, hipMemcpyAsync(f->d_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));

@@ -98,6 +98,10 @@ int launch_add_diag(mln_ctx* ctx, double* A, int64_t m, int64_t lda, double v);
 int launch_symmetrize_from_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda);
 int launch_axpby(mln_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);
 
+// eigh.hip: symmetric eigensolver (block one-sided Jacobi); w_host ascending, Vrows row j = eigenvector j
+int dev_eigh(mln_ctx* ctx, const double* A, int64_t m, int64_t lda, double* w_host, double* Vrows, int64_t ldv,
+             int* n_sweeps_out);
+
 // objective.hip
 struct ObjArgs {
   const double* L; int64_t ldl; int64_t n; int64_t m;
@@ -112,6 +116,8 @@ struct ObjArgs {
 int objective_max_m();
 int launch_objective(mln_ctx* ctx, const ObjArgs& a);
 int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out_loss_grad /* 1 + m [+ m] */);
+int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x,
+                     double* y);   // y = M x, one wave per row
 
 // helpers (api.hip)
 int mln_scratch(mln_ctx* ctx, size_t bytes, void** out);

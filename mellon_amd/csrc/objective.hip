@@ -159,24 +159,59 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
 }
 
 // out[0] = sum_wg loss ; out[1 + j] = sum_wg grad[wg][j] ; out[1 + m + j] = sum_wg hess[wg][j]
-__global__ void k_reduce_obj(ObjArgs a, double* __restrict__ out, int with_hess) {
-  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// 64 columns x 4 groups of workgroup-partials per block; each group sums its partials in ascending
+// workgroup order and the 4 group sums are added in fixed order -> bit-reproducible.
+__global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restrict__ out, int with_hess) {
+  __shared__ double red[2][4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + c;
+  double s = 0.0, t = 0.0;
   if (j < a.m) {
-    double s = 0.0;
-    for (int w = 0; w < a.n_wg; ++w) s += a.part_grad[(int64_t)w * a.m_pad + j];
-    out[1 + j] = s;
-    if (with_hess) {
-      double t = 0.0;
-      for (int w = 0; w < a.n_wg; ++w) t += a.part_hess[(int64_t)w * a.m_pad + j];
-      out[1 + a.m + j] = t;
-    }
+    const int per = (a.n_wg + 3) / 4;
+    const int w0 = grp * per, w1 = (w0 + per < a.n_wg) ? (w0 + per) : a.n_wg;
+    for (int w = w0; w < w1; ++w) s += a.part_grad[(int64_t)w * a.m_pad + j];
+    if (with_hess)
+      for (int w = w0; w < w1; ++w) t += a.part_hess[(int64_t)w * a.m_pad + j];
   }
-  if (j == 0) {
-    double s = 0.0;
+  red[0][grp][c] = s;
+  red[1][grp][c] = t;
+  __syncthreads();
+  if (grp == 0 && j < a.m) {
+    out[1 + j] = ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c];
+    if (with_hess) out[1 + a.m + j] = ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double l = 0.0;
     if (a.part_loss)
-      for (int w = 0; w < a.n_wg; ++w) s += a.part_loss[w];
-    out[0] = s;
+      for (int w = 0; w < a.n_wg; ++w) l += a.part_loss[w];
+    out[0] = l;
   }
+}
+
+// y[r] = sum_j M[r][j] x[j] for a row-major M (rows x cols, leading dimension ld, all even and 16-byte
+// aligned): one wave per row, 16-byte loads, wave64 shuffle reduction.  Used for the m x m (and stacked
+// 2m x m / m x 2m) preconditioner products of every objective evaluation: no partial buffers, no
+// separate reduction launch.
+__global__ __launch_bounds__(256) void k_gemv_rows(const double* __restrict__ M, int64_t ld, int64_t rows,
+                                                   int64_t cols, const double* __restrict__ x,
+                                                   double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const d2* __restrict__ row = reinterpret_cast<const d2*>(M + r * ld);
+  const d2* __restrict__ xv = reinterpret_cast<const d2*>(x);
+  const int64_t pairs = cols / 2;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t p = lane; p < pairs; p += 64) {
+    const d2 a = row[p], b = xv[p];
+    s0 = fma(a.x, b.x, s0);
+    s1 = fma(a.y, b.y, s1);
+  }
+  double s = s0 + s1;
+  if ((cols & 1) && lane == 0) s = fma(M[r * ld + cols - 1], x[cols - 1], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) y[r] = s;
 }
 
 template <int CPT, int R>
@@ -220,8 +255,17 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   }
 }
 
+int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x,
+                     double* y) {
+  if (rows <= 0) return MLN_OK;
+  if ((ld & 1) || ((uintptr_t)M & 15) || ((uintptr_t)x & 15)) { mln_set_error(ctx, "gemv_rows: unaligned operands"); return MLN_ERR_ARG; }
+  hipLaunchKernelGGL(k_gemv_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, M, ld, rows, cols, x, y);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
 int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out) {
-  hipLaunchKernelGGL(k_reduce_obj, dim3((unsigned)((a.m + 255) / 256)), dim3(256), 0, ctx->stream, a, out,
+  hipLaunchKernelGGL(k_reduce_obj, dim3((unsigned)((a.m + 63) / 64)), dim3(256), 0, ctx->stream, a, out,
                      a.part_hess ? 1 : 0);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;

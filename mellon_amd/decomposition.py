@@ -5,6 +5,8 @@ in HBM behind one `mln_fit` handle and are exposed as array-likes: `FactorL` (n 
 cell-sharded factor the optimiser streams) and `FactorLp` (m x m).  `np.asarray(factor)` downloads
 (chunked for L); nothing is copied to the host unless asked.
 """
+import logging
+
 import numpy as np
 
 from . import _lib
@@ -12,6 +14,7 @@ from .util import DEFAULT_JITTER, ensure_2d
 
 DEFAULT_RANK = 0.99   # reference decomposition.py:17
 DEFAULT_SIGMA = 0
+logger = logging.getLogger("mellon")
 
 
 class _DeviceFactor:
@@ -93,11 +96,68 @@ def _standard_low_rank(x, cov_func, xu, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEF
     return FactorL(fit)
 
 
-def _nystroem_unavailable(*args, **kwargs):
-    raise NotImplementedError(
-        "Nystroem rank reduction (gp_type full_nystroem / sparse_nystroem, decomposition.py:126-171,213-266) "
-        "is outside the accelerated path of this build (SURVEY.md S8f rank 4).")
+def _select_rank(s, rank):
+    """Number p of leading eigenpairs `_eigendecomposition` keeps (decomposition.py:51-76), from the
+    ascending eigenvalues s: int rank -> min(rank, #positive); float rank -> position of
+    rank * (sum of positive eigenvalues) in their descending cumulative sum, at least 1."""
+    s = np.asarray(s, dtype=np.float64)
+    if np.any(s <= 0):
+        logger.warning("Singularity detected in covariance matrix (non-positive eigenvalues). "
+                       "This can complicate prediction. Consider raising the jitter.")
+    p = int(np.count_nonzero(s > 0))
+    if p == 0:
+        raise ValueError("The covariance matrix has no positive eigenvalue; increase the jitter.")
+    summed = np.cumsum(s[: -p - 1: -1])
+    if isinstance(rank, float):
+        p = int(np.searchsorted(summed, summed[-1] * rank))
+        if p == 0:
+            logger.warning(f"Low variance percentage {rank:%} indicated rank=0. Bumping rank to 1.")
+            p = 1
+    else:
+        p = min(int(rank), p)
+    if (isinstance(rank, float) and rank < 1) or rank < len(summed):
+        frac = summed[min(p, len(summed) - 1)] / summed[-1]
+        logger.info(f"Recovering {frac:%} variance in eigendecomposition.")
+    return p
 
 
-_full_decomposition_low_rank = _nystroem_unavailable
-_modified_low_rank = _nystroem_unavailable
+def _eigendecomposition(A, rank=DEFAULT_RANK, ctx=None):
+    """Top eigenpairs (s, v) of the symmetric A (decomposition.py:23-76); the eigensolver is the
+    block-Jacobi kernel behind mln_eigh."""
+    ctx = ctx or _lib.default_context()
+    s, v = ctx.eigh(np.asarray(A, dtype=np.float64))
+    p = _select_rank(s, rank)
+    return s[-p:], v[:, -p:]
+
+
+def _full_decomposition_low_rank(x, cov_func, rank=DEFAULT_RANK, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
+                                 ctx=None):
+    """L = v sqrt(s) from the leading eigenpairs of K(x,x) + max(sigma^2, jitter) I
+    (decomposition.py:126-171).  Column signs are arbitrary, as with any eigensolver."""
+    ctx = ctx or _lib.default_context()
+    x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+    W = ctx.kernel_matrix(cov_func.lower(x.shape[1]), x, x)
+    W[np.diag_indices_from(W)] += _diag_value(sigma, jitter)
+    s, v = _eigendecomposition(W, rank=rank, ctx=ctx)
+    fit = _lib.Fit.from_L(ctx, v * np.sqrt(s))
+    return FactorL(fit)
+
+
+def _modified_low_rank(x, cov_func, xu, rank=DEFAULT_RANK, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER, ctx=None):
+    """Improved Nystroem factor (decomposition.py:213-266).
+
+    The reference forms QR(C), eigh(W), T = R v and eigh(T / s T^T) = eigh(R W^-1 R^T), L = Q V sqrt(S).
+    With W = Lp Lp^T and B = C Lp^-T (the standard low-rank factor), R W^-1 R^T and B^T B share their
+    non-zero spectrum S and  Q V sqrt(S) = B U  for the matching eigenvectors U of B^T B, so the same L
+    (up to column signs) is  B U[:, -p:]:  one Gram, one m x m eigensolve, one GEMM -- no n x m QR."""
+    ctx = ctx or _lib.default_context()
+    if not isinstance(x, _lib.DeviceArray):
+        x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+    xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
+    base = ctx.fit_prepare(cov_func.lower(xu.shape[1]), x, xu, _diag_value(sigma, jitter))
+    try:
+        S = base.gram_eigh()
+        fit = base.project(_select_rank(S, rank))
+    finally:
+        base.close()
+    return FactorL(fit)

@@ -301,6 +301,45 @@ def standard_low_rank(x, cov_func, xu, Lp=None, sigma=0.0, jitter=DEFAULT_JITTER
     return _sp_trsolve(Lp, C.T, lower=True, check_finite=False).T
 
 
+def eigendecomposition(A, rank=DEFAULT_RANK):
+    """decomposition.py:23-76 -- top eigenpairs of A.  int rank: min(rank, #positive);
+    float rank: searchsorted of rank * (sum of positive eigenvalues) in their descending
+    cumulative sum (at least 1)."""
+    s, v = np.linalg.eigh(A)
+    p = int(np.count_nonzero(s > 0))
+    summed = np.cumsum(s[: -p - 1: -1])
+    if isinstance(rank, float):
+        target = summed[-1] * rank
+        p = int(np.searchsorted(summed, target))
+        if p == 0:
+            p = 1
+    else:
+        p = min(int(rank), p)
+    return s[-p:], v[:, -p:]
+
+
+def full_decomposition_low_rank(x, cov_func, rank=DEFAULT_RANK, sigma=0.0, jitter=DEFAULT_JITTER):
+    """decomposition.py:126-171 -- L = v sqrt(s) from the eigenpairs of K(x,x) + sigma2 I."""
+    sigma2 = np.square(sigma)
+    sigma2 = np.where(sigma2 < jitter, jitter, sigma2)
+    W = stabilize(cov_func(x, x), sigma2)
+    s, v = eigendecomposition(W, rank=rank)
+    return v * np.sqrt(s)
+
+
+def modified_low_rank(x, cov_func, xu, rank=DEFAULT_RANK, sigma=0.0, jitter=DEFAULT_JITTER):
+    """decomposition.py:213-266 -- improved Nystroem: QR of C, eigh of W, eigh of R W^-1 R^T."""
+    sigma2 = np.square(sigma)
+    sigma2 = np.where(sigma2 < jitter, jitter, sigma2)
+    W = stabilize(cov_func(xu, xu), sigma2)
+    C = cov_func(x, xu)
+    Q, R = np.linalg.qr(C, mode="reduced")
+    s, v = eigendecomposition(W, rank=xu.shape[0])
+    T = R @ v
+    S, V = eigendecomposition(T / s @ T.T, rank=rank)
+    return Q @ V * np.sqrt(S)
+
+
 # --------------------------------------------------------------------------
 # parameters.py -- heuristics and decision tables
 # --------------------------------------------------------------------------
@@ -596,7 +635,7 @@ def density_fit(x, cov_func_curry=Matern52, n_landmarks=None, rank=None, landmar
                 jitter=DEFAULT_JITTER, initial_value=None, lbfgsb_options=None,
                 ls_time=None, random_state=DEFAULT_RANDOM_SEED):
     """DensityEstimator.fit_predict with the attribute pipeline of
-    density_estimator.py:404-444 (sparse_cholesky and full gp types)."""
+    density_estimator.py:404-444 (all four gp types)."""
     x = ensure_2d(x)
     n = x.shape[0]
     if n_landmarks is None:
@@ -604,8 +643,6 @@ def density_fit(x, cov_func_curry=Matern52, n_landmarks=None, rank=None, landmar
     if rank is None:
         rank = compute_rank(None)
     gp_type = compute_gp_type(n_landmarks, rank, n)
-    if gp_type not in (FULL, SPARSE_CHOLESKY):
-        raise NotImplementedError("oracle covers gp_type full and sparse_cholesky only")
     if nn_distances is None:
         nn_distances = exact_nn_distances(x)
     nn_distances = validate_nn_distances(nn_distances)
@@ -619,12 +656,19 @@ def density_fit(x, cov_func_curry=Matern52, n_landmarks=None, rank=None, landmar
         ls = compute_ls(nn_distances) * ls_factor
     if cov_func is None:
         cov_func = compute_cov_func(cov_func_curry, ls, ls_time)
-    if landmarks is None and gp_type == SPARSE_CHOLESKY:
+    if landmarks is None and gp_type in (SPARSE_CHOLESKY, SPARSE_NYSTROEM):
         landmarks = compute_landmarks(x, gp_type, n_landmarks, random_state)
     if gp_type == FULL:
         landmarks = None
         Lp = full_rank(x, cov_func, sigma=0.0, jitter=jitter)
         L = Lp                                              # parameters.py:847-850
+    elif gp_type == FULL_NYSTROEM:                          # parameters.py:851-854; Lp stays None (:686-714)
+        landmarks = None
+        Lp = None
+        L = full_decomposition_low_rank(x, cov_func, rank=rank, jitter=jitter)
+    elif gp_type == SPARSE_NYSTROEM:                        # parameters.py:866-874
+        Lp = None
+        L = modified_low_rank(x, cov_func, landmarks, rank=rank, jitter=jitter)
     else:
         Lp = full_rank(landmarks, cov_func, sigma=0.0, jitter=jitter)
         L = standard_low_rank(x, cov_func, landmarks, Lp=Lp)

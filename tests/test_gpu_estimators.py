@@ -68,9 +68,40 @@ def test_density_estimator_approximations(mellon, small_x, rank, n_landmarks):
     assert rel_std(dens, ref.log_density_x) < 1e-5
 
 
-def test_density_estimator_nystroem_is_refused(mellon, small_x):
-    with pytest.raises(NotImplementedError):
-        mellon.DensityEstimator(rank=0.99, n_landmarks=80, gp_type="sparse_nystroem").fit(small_x)
+@pytest.mark.parametrize("rank,n_landmarks,gp_type", [(0.99, 80, "sparse_nystroem"), (0.999, 80, "sparse_nystroem"),
+                                                     (25, 80, "sparse_nystroem"), (0.99, 0, "full_nystroem"),
+                                                     (30, 0, "full_nystroem")])
+def test_density_estimator_nystroem(mellon, small_x, rank, n_landmarks, gp_type):
+    # tests/test_density_estimator.py:80-96 row (0.99, 80, 2e-1) and the other Nystroem decision-table rows
+    base = mellon.DensityEstimator().fit_predict(small_x)
+    est = mellon.DensityEstimator(rank=rank, n_landmarks=n_landmarks)
+    dens = est.fit_predict(small_x)
+    assert est.gp_type == mellon.GaussianProcessType.from_string(gp_type)
+    assert est.Lp is None                                        # parameters.py:686-714: no Lp for Nystroem
+    assert rel_std(est.predict(small_x), base) < 2e-1
+    ref = mo.density_fit(small_x, n_landmarks=n_landmarks, rank=rank, lbfgsb_options=mo.LBFGSB_TIGHT)
+    assert ref.gp_type == gp_type
+    assert est.L.shape == ref.L.shape                            # same rank decision
+    # the factor itself is defined up to column signs / rotations inside eigenvalue clusters: compare L L^T
+    Ld = np.asarray(est.L)
+    assert np.abs(Ld @ Ld.T - ref.L @ ref.L.T).max() < 1e-9 * np.abs(ref.L @ ref.L.T).max()
+    assert rel_std(dens, ref.log_density_x) < 1e-5 and rel_max(dens, ref.log_density_x) < 1e-5
+    pr, pd = ref.predict(small_x), est.predict(small_x)
+    assert rel_std(pd, pr) < 1e-5 and rel_max(pd, pr) < 1e-5
+
+
+def test_density_estimator_nystroem_larger(mellon):
+    # 3000 cells x 8 dims, 300 landmarks, rank 0.995: Gram over 3000 rows, 300 x 300 eigensolve, GEMM projection
+    x = mo.gaussian_mixture(3000, 8, 11)
+    rng = np.random.default_rng(5)
+    lm = x[rng.choice(3000, 300, replace=False)]
+    nn = mo.exact_nn_distances(x)
+    est = mellon.DensityEstimator(rank=0.995, landmarks=lm, nn_distances=nn)
+    dens = est.fit_predict(x)
+    ref = mo.density_fit(x, rank=0.995, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    assert est.gp_type == mellon.GaussianProcessType.SPARSE_NYSTROEM and est.L.shape == ref.L.shape
+    assert rel_std(dens, ref.log_density_x) < 1e-5 and rel_max(dens, ref.log_density_x) < 1e-5
+    assert rel_max(est.predict(x[:500]), ref.predict(x[:500])) < 1e-5
 
 
 def test_density_estimator_single_dimension(mellon, small_x):

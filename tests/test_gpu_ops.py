@@ -415,3 +415,90 @@ def test_objective_wide_landmark_counts(ctx, m):
     u = fit.precond_apply(0, z)
     lu, gu, zb = fit.objective_precond(u)
     assert abs(lu - loss_ref) < 1e-10 * abs(loss_ref) and relmax(zb, z) < 1e-9
+
+
+# ---- symmetric eigensolver (mln_eigh) and the Nystroem factors (decomposition.py:23-76,126-171,213-266) ----
+def _kernel_like(m, seed, jitter=1e-6):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=(m, 4))
+    xx = (x * x).sum(1)
+    d2 = np.maximum(xx[:, None] - 2 * x @ x.T + xx[None, :], 0.0)
+    return np.exp(-0.5 * d2 / 4.0) + jitter * np.eye(m)     # spectrum spans >= 6 decades, heavy clustering
+
+
+@pytest.mark.parametrize("m", [1, 2, 5, 16, 17, 33, 100, 257, 600])
+def test_eigh_kernel_matrices(ctx, m):
+    A = _kernel_like(m, m)
+    w, V = ctx.eigh(A)
+    w_ref = np.linalg.eigvalsh(A)
+    scale = np.abs(w_ref).max()
+    assert np.all(np.diff(w) >= 0)                                        # ascending, LAPACK order
+    assert np.abs(w - w_ref).max() < 1e-11 * scale                        # absolute accuracy ~ eps |A|
+    assert np.abs(V.T @ V - np.eye(m)).max() < 1e-11                      # product of plane rotations
+    assert np.abs(A @ V - V * w).max() < 1e-11 * scale                    # residual
+
+
+def test_eigh_special_matrices(ctx):
+    rng = np.random.default_rng(3)
+    # indefinite, with a repeated eigenvalue and a zero eigenvalue
+    Q, _ = np.linalg.qr(rng.normal(size=(40, 40)))
+    lam = np.concatenate([[-3.0, -3.0, 0.0], rng.uniform(-1, 5, 37)])
+    A = (Q * lam) @ Q.T
+    w, V = ctx.eigh(A)
+    assert np.abs(w - np.sort(lam)).max() < 1e-12 and np.abs(A @ V - V * w).max() < 1e-12
+    # identity (all eigenvalues equal), zero matrix, diagonal matrix: no rotation at all
+    for D in (np.eye(20), np.zeros((20, 20)), np.diag(np.arange(20.0)[::-1])):
+        w, V = ctx.eigh(D)
+        assert np.array_equal(w, np.sort(np.diag(D))) and np.abs(V.T @ V - np.eye(20)).max() < 1e-15
+    # only the symmetric part counts (jax eigh symmetrize_input default)
+    B = rng.normal(size=(30, 30))
+    w, _ = ctx.eigh(B)
+    assert np.abs(w - np.linalg.eigvalsh(0.5 * (B + B.T))).max() < 1e-12
+    with pytest.raises(Exception):
+        ctx.eigh(np.full((4, 4), np.nan))
+
+
+@pytest.mark.parametrize("rank", [0.99, 0.9999, 1.0, 7, 40, 1000])
+def test_modified_low_rank_matches_reference_algorithm(ctx, rank):
+    from mellon_amd import cov
+    from mellon_amd.decomposition import _modified_low_rank
+    x = mo.gaussian_mixture(700, 6, 21)
+    xu = x[np.random.default_rng(2).choice(700, 64, replace=False)]
+    k = cov.Matern52(ls=2.5)
+    L = np.asarray(_modified_low_rank(x, k, xu, rank=rank, jitter=1e-6))
+    ref = mo.modified_low_rank(x, _pair(k), xu, rank=rank, jitter=1e-6)      # QR + two eigh, as the reference
+    assert L.shape == ref.shape
+    G, Gr = L @ L.T, ref @ ref.T
+    assert np.abs(G - Gr).max() < 1e-10 * np.abs(Gr).max()
+    # columns are eigen-directions in ascending order: equal up to sign wherever the eigenvalue is isolated
+    assert np.abs((L * L).sum(0) - (ref * ref).sum(0)).max() < 1e-9 * (ref * ref).sum(0).max()
+
+
+@pytest.mark.parametrize("rank", [0.99, 12, 1.0])
+def test_full_decomposition_low_rank_matches_reference_algorithm(ctx, rank):
+    from mellon_amd import cov
+    from mellon_amd.decomposition import _full_decomposition_low_rank
+    x = mo.gaussian_mixture(300, 5, 22)
+    k = cov.ExpQuad(ls=2.0)
+    L = np.asarray(_full_decomposition_low_rank(x, k, rank=rank, jitter=1e-6))
+    ref = mo.full_decomposition_low_rank(x, _pair(k), rank=rank, jitter=1e-6)
+    assert L.shape == ref.shape
+    assert np.abs(L @ L.T - ref @ ref.T).max() < 1e-10 * np.abs(ref @ ref.T).max()
+
+
+def test_gram_eigh_requires_explicit_factor(ctx):
+    from mellon_amd import cov
+    x = mo.gaussian_mixture(200, 3, 1)
+    fit = ctx.fit_prepare(cov.Matern52(ls=1.5).lower(3), x, x[:20], 1e-6, implicit=True)
+    with pytest.raises(NotImplementedError):
+        fit.gram_eigh()
+    fit2 = ctx.fit_prepare(cov.Matern52(ls=1.5).lower(3), x, x[:20], 1e-6)
+    with pytest.raises(Exception):
+        fit2.project(5)                                       # no eigenvectors yet
+    S = fit2.gram_eigh()
+    Lb = fit2.L()
+    assert np.abs(S - np.linalg.eigvalsh(Lb.T @ Lb)).max() < 1e-11 * S.max()
+    with pytest.raises(ValueError):
+        fit2.project(21)
+    p5 = fit2.project(5)
+    assert p5.m == 5 and p5.L().shape == (200, 5)

@@ -220,3 +220,52 @@ def test_predictive_uncertainty_identities():
         assert full.shape == (15, 15) and np.allclose(np.diag(full), f(xq), rtol=1e-9, atol=1e-12)
     assert np.all(p.covariance(x) < 1e-4) and np.all(p.covariance(xq) > -1e-9)
     assert np.all(np.linalg.eigvalsh(p.mean_covariance(xq, diag=False)) > -1e-10)
+
+
+# ---- Nystroem rank reduction (decomposition.py:23-76,126-171,213-266) -----------------------------------
+def test_eigendecomposition_rank_rule():
+    A = np.diag([5.0, 3.0, 1.0, 0.5, 0.25, -1e-9, 0.0])
+    for rank, want in [(3, [1.0, 3.0, 5.0]), (10, [0.25, 0.5, 1.0, 3.0, 5.0]),
+                       (0.5, [5.0]),              # cumsum 5, 8, 9, 9.5, 9.75; target 4.875 -> index 0 -> bumped to 1
+                       (0.9, [3.0, 5.0]),         # target 8.775 -> index 2
+                       (1.0, [0.5, 1.0, 3.0, 5.0])]:   # target 9.75 -> index 4 (the quirk: one short of all)
+        s, v = mo.eigendecomposition(A, rank)
+        assert np.allclose(s, want), (rank, s)
+        assert v.shape == (7, len(want))
+
+
+def test_select_rank_mirrors_oracle_rule():
+    from mellon_amd.decomposition import _select_rank
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        s = np.sort(np.concatenate([rng.lognormal(size=12) * 10.0 ** rng.uniform(-8, 2, 12), -rng.random(2) * 1e-12]))
+        for rank in (0.5, 0.9, 0.99, 0.99999, 1.0, 1, 5, 12, 100):
+            want = mo.eigendecomposition(np.diag(s), rank)[0].shape[0]
+            assert _select_rank(s, rank) == want
+
+
+def test_modified_low_rank_equals_projected_cholesky_factor():
+    """The identity the device path uses: Q V sqrt(S) (reference) == B U_p with B = C Lp^-T and (S, U) the
+    eigenpairs of B^T B."""
+    x = mo.gaussian_mixture(400, 4, 3)
+    xu = x[np.random.default_rng(1).choice(400, 50, replace=False)]
+    cov = mo.Matern52(ls=2.0)
+    B = mo.standard_low_rank(x, cov, xu)
+    S, U = np.linalg.eigh(B.T @ B)
+    for rank in (0.99, 0.999, 10, 50):
+        ref = mo.modified_low_rank(x, cov, xu, rank=rank)
+        p = ref.shape[1]
+        mine = B @ U[:, -p:]
+        assert np.abs(ref @ ref.T - mine @ mine.T).max() < 1e-12
+        assert np.abs(np.abs(ref) - np.abs(mine)).max() < 1e-10          # column-wise, up to sign
+        assert np.allclose((ref * ref).sum(0), S[-p:], rtol=1e-9)
+
+
+def test_density_fit_nystroem_types():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(100, 2)) @ np.array([[2.0, 0.0], [1.0, 1.0]]).T
+    base = mo.density_fit(x).log_density_x
+    for kw, gp in [(dict(rank=0.99, n_landmarks=80), "sparse_nystroem"), (dict(rank=0.99, n_landmarks=0), "full_nystroem")]:
+        f = mo.density_fit(x, **kw)
+        assert f.gp_type == gp and f.Lp is None and f.L.shape[1] < 80
+        assert np.std(f.predict(x) - base) / np.std(base) < 2e-1      # tests/test_density_estimator.py:80-96
