@@ -158,6 +158,19 @@ int mln_fit_get_Lp(mln_fit* fit, double* out /* m x m */);
 int mln_fit_get_L(mln_fit* fit, int64_t row0, int64_t n_rows, double* out /* n_rows x m */);
 int mln_fit_rank(mln_fit* fit, int64_t* m_out); /* number of columns of L */
 
+/* ---- analytic gradients ---------------------------------------------------------------------------
+ * mln_kernel_grad: Covariance.k_grad (cov.py:68-100,163-202,261-299,358-396,459-499,558-596 and the
+ * Add/Mul/Pow rules of base_cov.py:317-497): out[i][j][:] = d cov(x_i, y_j) / d y_j, zero on inactive
+ * dims, with util.distance_grad's denominator (dist + 1e-12) (util.py:416-423).
+ * mln_predict_gradient: Predictor.gradient (base_predictor.py:490-505 -> derivatives.gradient, the
+ * jax.jacrev of `_mean`): out[i][:] = sum_j W[j] d cov(x_i, c_j) / d x_i, the exact derivative of the
+ * mean mln_predict_mean evaluates (denominator dist); the n x m x d tensor is never formed.          */
+int mln_kernel_grad(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, const double* y,
+                    int64_t m, int32_t d, double* out /* n x m x d */);
+int mln_predict_gradient(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                         int32_t d, const double* centers, int64_t m, const double* W /* m */,
+                         double* out /* n_new x d */);
+
 /* ---- Nystroem rank reduction (decomposition.py:23-76,126-171,213-266) ---------------------------
  * mln_eigh replaces jax.numpy.linalg.eigh at decomposition.py:50 (_eigendecomposition): A (m x m,
  * symmetrised as (A + A^T)/2 like jax's symmetrize_input default) -> w (m, ascending) and V (m x m

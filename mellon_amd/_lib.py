@@ -61,6 +61,8 @@ SYMBOLS = [
     ("mln_comm_init", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     ("mln_comm_allreduce_sum", C.c_int, [_vp, _dp, _i64]),
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
+    ("mln_kernel_grad", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
+    ("mln_predict_gradient", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _dp]),
     ("mln_nn_distances", C.c_int, [_vp, _dp, _i64, _dp, _i64, _i32, _i64, _dp]),
     ("mln_kmeans", C.c_int, [_vp, _dp, _i64, _i32, _i64, _i64, _i32, _dbl, _dp, C.POINTER(_i32), C.POINTER(_dbl)]),
     ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
@@ -252,6 +254,29 @@ class Context:
         out = np.empty((x.shape[0], y.shape[0]), dtype=np.float64)
         self._check(self.lib.mln_kernel_matrix(self.handle, desc.ref, _ptr(x), x.shape[0], _ptr(y), y.shape[0],
                                                x.shape[1], out.ctypes.data))
+        return out
+
+    def kernel_grad(self, desc, x, y):
+        """d cov(x_i, y_j) / d y_j as an (n, m, d) array (Covariance.k_grad)."""
+        x, y = _as2d(x), _as2d(y)
+        if x.shape[1] != y.shape[1]:
+            raise ValueError("x and y must have the same number of features")
+        out = np.empty((x.shape[0], y.shape[0], x.shape[1]), dtype=np.float64)
+        self._check(self.lib.mln_kernel_grad(self.handle, desc.ref, _ptr(x), x.shape[0], _ptr(y), y.shape[0],
+                                             x.shape[1], out.ctypes.data))
+        return out
+
+    def predict_gradient(self, desc, xnew, centers, W):
+        """Gradient of the predictive mean with respect to each query point: (n_new, d)."""
+        xnew = xnew if isinstance(xnew, DeviceArray) else _as2d(xnew)
+        centers = centers if isinstance(centers, DeviceArray) else _as2d(centers)
+        Wd = _f64(W)
+        if Wd.ndim != 1 or Wd.shape[0] != centers.shape[0]:
+            raise NotImplementedError("gradients are available for single-output predictors (weights of shape (m,))")
+        n_new, d = xnew.shape
+        out = np.empty((n_new, d), dtype=np.float64)
+        self._check(self.lib.mln_predict_gradient(self.handle, desc.ref, _ptr(xnew), n_new, d, _ptr(centers),
+                                                  centers.shape[0], Wd.ctypes.data, out.ctypes.data))
         return out
 
     def nn_distances(self, x, y=None, self_offset=0):

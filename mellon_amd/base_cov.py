@@ -80,7 +80,17 @@ class Covariance(ABC):
         return self.k(x, y)
 
     def k_grad(self, x):
-        raise NotImplementedError("k_grad is outside the accelerated path (SURVEY.md S8: predictor gradients).")
+        """Callable y -> d k(x, y) / d y of shape (n, m, d), zeros on inactive dims (reference
+        cov.py k_grad of every kernel, base_cov.py:317-497 for Add/Mul/Pow): the analytic rules are
+        evaluated by one HIP kernel over the lowered program instead of nested Python closures."""
+        x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+        lowered = self.lower(x.shape[1])
+
+        def k_grad(y):
+            y = np.ascontiguousarray(ensure_2d(y), dtype=np.float64)
+            return _lib.default_context().kernel_grad(lowered, x, y)
+
+        return k_grad
 
     def diag(self, x):
         """reference base_cov.py:71-93: k(x_i, x_i) for every sample."""

@@ -76,6 +76,14 @@ class Predictor:
 
     __call__ = mean
 
+    def gradient(self, x, jit=True):
+        """Gradient of the predicted mean at each row of x, shape == x.shape (base_predictor.py:490-505).
+        The reference differentiates `_mean` with jax.jacrev; here the analytic kernel gradient is
+        contracted with the weights on the device.  `jit` is accepted and ignored."""
+        x = self._check_features(x)
+        return _lib.default_context().predict_gradient(self.cov_func.lower(self.n_input_features), x,
+                                                       self.centers, self.weights)
+
     # -- predictive uncertainty (base_predictor.py:330-428; conditional.py _covariance / _mean_covariance) --
     def _check_features(self, x):
         x = validate_array(x, "x")
@@ -113,9 +121,9 @@ class Predictor:
 
     def _unavailable(self, *a, **k):
         raise NotImplementedError("This predictor method is outside the accelerated path "
-                                  "(gradients / leverage / obs_variance: SURVEY.md S8f).")
+                                  "(hessians / leverage / obs_variance: SURVEY.md S8f).")
 
-    gradient = hessian = hessian_log_determinant = leverage = loo_residuals = obs_variance = _unavailable
+    hessian = hessian_log_determinant = leverage = loo_residuals = obs_variance = _unavailable
 
     # -- serialization --------------------------------------------------------------------------------
     def _data_dict(self):
@@ -206,6 +214,9 @@ class ExpPredictor(Predictor):
 
     __call__ = mean
 
+    def gradient(self, x, jit=True):
+        return np.exp(Predictor.mean(self, x))[:, None] * Predictor.gradient(self, x)
+
 
 class PredictorTime(Predictor):
     """Predictor whose last input column is time (reference base_predictor.py:872-948)."""
@@ -222,6 +233,14 @@ class PredictorTime(Predictor):
         return super().mean(np.ascontiguousarray(x), normalize=normalize)
 
     __call__ = mean
+
+    def gradient(self, x, time=None, jit=True):
+        """Gradient with respect to the state columns at the given time(s) (base_predictor.py:1094-1124)."""
+        return Predictor.gradient(self, self._with_time(x, time))[:, :-1]
+
+    def time_derivative(self, x, time=None, jit=True):
+        """Derivative with respect to time (base_predictor.py:1052-1091)."""
+        return Predictor.gradient(self, self._with_time(x, time))[:, -1]
 
     def _with_time(self, Xnew, time):
         Xnew = np.ascontiguousarray(ensure_2d(validate_array(Xnew, "Xnew")), dtype=np.float64)

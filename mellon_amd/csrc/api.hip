@@ -343,6 +343,43 @@ extern "C" int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const
   return o.commit();
 }
 
+extern "C" int mln_kernel_grad(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n,
+                               const double* y, int64_t m, int32_t d, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n < 0 || m < 0 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n == 0 || m == 0) return MLN_OK;
+  if (!x || !y || !out) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, dy;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, x, (size_t)n * d));
+  MLN_TRY(dy.init(ctx, y, (size_t)m * d));
+  MLN_TRY(o.init(ctx, out, (size_t)n * m * d));
+  MLN_TRY(launch_kernel_grad(ctx, dc, dx.dev, n, dy.dev, m, d, 0, o.dev));
+  return o.commit();
+}
+
+extern "C" int mln_predict_gradient(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                                    int32_t d, const double* centers, int64_t m, const double* W, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n_new < 0 || m < 0 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n_new == 0) return MLN_OK;
+  if (!xnew || !out || (m > 0 && (!centers || !W))) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, dc_, dw;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, xnew, (size_t)n_new * d));
+  MLN_TRY(dc_.init(ctx, centers, (size_t)m * d));
+  MLN_TRY(dw.init(ctx, W, (size_t)m));
+  MLN_TRY(o.init(ctx, out, (size_t)n_new * d));
+  MLN_TRY(launch_predict_gradient(ctx, dc, dx.dev, n_new, dc_.dev, m, d, dw.dev, o.dev));
+  return o.commit();
+}
+
 extern "C" int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int32_t d,
                                 int64_t self_offset, double* out) {
   if (!ctx) return MLN_ERR_ARG;

@@ -98,6 +98,12 @@ int launch_add_diag(mln_ctx* ctx, double* A, int64_t m, int64_t lda, double v);
 int launch_symmetrize_from_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda);
 int launch_axpby(mln_ctx* ctx, int64_t n, double a, const double* x, double b, double* y);
 
+// cov_grad.hip
+int launch_kernel_grad(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y, int64_t m,
+                       int d, int exact_denominator, double* out);
+int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c, int64_t m,
+                            int d, const double* w, double* out);
+
 // eigh.hip: symmetric eigensolver (block one-sided Jacobi); w_host ascending, Vrows row j = eigenvector j
 int dev_eigh(mln_ctx* ctx, const double* A, int64_t m, int64_t lda, double* w_host, double* Vrows, int64_t ldv,
              int* n_sweeps_out);

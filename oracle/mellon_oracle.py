@@ -71,6 +71,31 @@ def distance(x, y):
     return np.sqrt(np.maximum(sq, 0.0))
 
 
+def distance_grad(x, eps=1e-12):
+    """util.py:369-425 -- y -> (distance (n, m), gradient of the distance w.r.t. y (n, m, d))."""
+    xx = np.sum(x * x, axis=1)[:, None]
+
+    def grad(y):
+        yy = np.sum(y * y, axis=1)[None, :]
+        sq = xx - 2 * np.tensordot(x, y, axes=(1, 1)) + yy + eps
+        dist = np.sqrt(np.maximum(sq, 0))
+        delta = y[None, :] - x[:, None]
+        return dist, delta / (dist[..., None] + eps)
+
+    return grad
+
+
+def expand_to_inactive(values, target_shape, active_dims):
+    """util.py:174-203 -- scatter gradient values into the active columns, zeros elsewhere."""
+    if active_dims is None:
+        return values
+    if np.isscalar(active_dims):
+        active_dims = [active_dims]
+    full = np.zeros(target_shape, dtype=values.dtype)
+    full[..., active_dims] = values
+    return full
+
+
 def stabilize(A, jitter=DEFAULT_JITTER):
     """util.py:269-293."""
     return A + np.eye(A.shape[0]) * jitter
@@ -167,12 +192,33 @@ class _Stationary(Covariance):
         y = select_active_dims(y, self.active_dims)
         return distance(x, y)
 
+    def k_grad(self, x):
+        """The common frame of every stationary k_grad (e.g. cov.py:83-100): select dims, distance_grad,
+        radial rule `_radial_grad(dist[..., None], dgrad)`, expand to the inactive dims."""
+        x_shape = x.shape
+        xs = select_active_dims(x, self.active_dims)
+        dg = distance_grad(xs)
+
+        def k_grad(y):
+            y_shape = y.shape
+            dist, grad = dg(select_active_dims(y, self.active_dims))
+            return expand_to_inactive(self._radial_grad(dist[..., None], grad), x_shape[:-1] + y_shape,
+                                      self.active_dims)
+
+        return k_grad
+
 
 class Matern32(_Stationary):
     def k(self, x, y):
         """cov.py:62-66."""
         r = np.sqrt(3.0) * self._dist(x, y) / self.ls
         return (r + 1) * np.exp(-r)
+
+    def _radial_grad(self, dist, grad):
+        """cov.py:86-95."""
+        factor = np.sqrt(3.0) / self.ls
+        r = -factor * dist
+        return r * (factor * grad) * np.exp(r)
 
 
 class Matern52(_Stationary):
@@ -181,6 +227,12 @@ class Matern52(_Stationary):
         r = np.sqrt(5.0) * self._dist(x, y) / self.ls
         return (r + np.square(r) / 3 + 1) * np.exp(-r)
 
+    def _radial_grad(self, dist, grad):
+        """cov.py:188-197."""
+        factor = np.sqrt(5.0) / self.ls
+        r = factor * dist
+        return -1 / 3 * np.exp(-r) * r * (r + 1) * (factor * grad)
+
 
 class ExpQuad(_Stationary):
     def k(self, x, y):
@@ -188,12 +240,22 @@ class ExpQuad(_Stationary):
         r = self._dist(x, y) / self.ls
         return np.exp(-np.square(r) / 2)
 
+    def _radial_grad(self, dist, grad):
+        """cov.py:288-294."""
+        r = dist / self.ls
+        return -r * (grad / self.ls) * np.exp(-np.square(r) / 2)
+
 
 class Exponential(_Stationary):
     def k(self, x, y):
         """cov.py:352-356 (note the non-standard /2)."""
         r = self._dist(x, y) / self.ls
         return np.exp(-r / 2)
+
+    def _radial_grad(self, dist, grad):
+        """cov.py:385-391."""
+        r = dist / self.ls
+        return -1 / 2 * (grad / self.ls) * np.exp(-r / 2)
 
 
 class RatQuad(_Stationary):
@@ -208,6 +270,11 @@ class RatQuad(_Stationary):
         r = self._dist(x, y) / self.ls
         return (np.square(r) / (2 * self.alpha) + 1) ** -self.alpha
 
+    def _radial_grad(self, dist, grad):
+        """cov.py:486-494."""
+        r = dist / self.ls
+        return -r * (grad / self.ls) * (np.square(r) / (2 * self.alpha) + 1) ** (-self.alpha - 1)
+
 
 class Linear(_Stationary):
     def k(self, x, y):
@@ -215,6 +282,18 @@ class Linear(_Stationary):
         x = select_active_dims(x, self.active_dims)
         y = select_active_dims(y, self.active_dims)
         return (x @ y.T) / self.ls
+
+    def k_grad(self, x):
+        """cov.py:558-596 -- d (x.y / ls) / dy = x / ls for every y."""
+        x_shape = x.shape
+        xs = select_active_dims(x, self.active_dims)
+
+        def k_grad(y):
+            ys = select_active_dims(y, self.active_dims)
+            g = np.repeat(xs[:, None, :], ys.shape[0], axis=1) / self.ls
+            return expand_to_inactive(g, x_shape[:-1] + y.shape, self.active_dims)
+
+        return k_grad
 
 
 class _Pair(Covariance):
@@ -237,6 +316,20 @@ class Add(_Pair):
             return self.left(x, y) + self.right(x, y)
         return self.left(x, y) + self.right
 
+    def k_grad(self, x):
+        """base_cov.py:317-364."""
+        x_shape = x.shape
+        xs = select_active_dims(x, self.active_dims)
+        lg = self.left.k_grad(xs)
+        rg = self.right.k_grad(xs) if callable(self.right) else None
+
+        def k_grad(y):
+            ys = select_active_dims(y, self.active_dims)
+            g = lg(ys) + (rg(ys) if rg is not None else 0.0)
+            return expand_to_inactive(g, x_shape[:-1] + y.shape, self.active_dims)
+
+        return k_grad
+
 
 class Mul(_Pair):
     def k(self, x, y):
@@ -246,12 +339,42 @@ class Mul(_Pair):
             return self.left(x, y) * self.right(x, y)
         return self.left(x, y) * self.right
 
+    def k_grad(self, x):
+        """base_cov.py:383-438 -- product rule (scalar right: scaled left gradient)."""
+        x_shape = x.shape
+        xs = select_active_dims(x, self.active_dims)
+        lg = self.left.k_grad(xs)
+        rg = self.right.k_grad(xs) if callable(self.right) else None
+
+        def k_grad(y):
+            ys = select_active_dims(y, self.active_dims)
+            if rg is None:
+                g = lg(ys) * self.right
+            else:
+                g = lg(ys) * self.right.k(xs, ys)[..., None] + self.left.k(xs, ys)[..., None] * rg(ys)
+            return expand_to_inactive(g, x_shape[:-1] + y.shape, self.active_dims)
+
+        return k_grad
+
 
 class Pow(_Pair):
     def k(self, x, y):
         """base_cov.py:449-453."""
         x, y = self._sel(x, y)
         return self.left(x, y) ** self.right
+
+    def k_grad(self, x):
+        """base_cov.py:455-497 -- n k^(n-1) k'."""
+        x_shape = x.shape
+        xs = select_active_dims(x, self.active_dims)
+        bg = self.left.k_grad(xs)
+
+        def k_grad(y):
+            ys = select_active_dims(y, self.active_dims)
+            g = self.right * (self.left.k(xs, ys)[..., None] ** (self.right - 1)) * bg(ys)
+            return expand_to_inactive(g, x_shape[:-1] + y.shape, self.active_dims)
+
+        return k_grad
 
 
 _CLASSES = {c.__name__: c for c in
@@ -535,6 +658,23 @@ class Predictor:
         return out
 
     mean = __call__
+
+    def gradient(self, Xnew, h=None):
+        """base_predictor.py:490-505: d mean / d x per row.  The reference uses jax.jacrev of `_mean`;
+        the restatement differentiates the same function by Richardson-extrapolated central differences
+        (error ~ h^4 |f^(5)|), independent of any analytic rule -- so it checks the rules."""
+        Xnew = ensure_2d(np.asarray(Xnew, dtype=np.float64))
+        n, d = Xnew.shape
+        scale = np.maximum(np.abs(Xnew).max(), 1.0)
+        h = 1e-3 * scale if h is None else h
+        out = np.empty((n, d))
+        for k in range(d):
+            e = np.zeros(d)
+            e[k] = h
+            d1 = (self(Xnew + e) - self(Xnew - e)) / (2 * h)
+            d2 = (self(Xnew + 2 * e) - self(Xnew - 2 * e)) / (4 * h)
+            out[:, k] = (4 * d1 - d2) / 3
+        return out
 
     # with_uncertainty state: L (factor on the centres) and W = L^-T diag(std)
     L = None

@@ -104,6 +104,29 @@ def test_density_estimator_nystroem_larger(mellon):
     assert rel_max(est.predict(x[:500]), ref.predict(x[:500])) < 1e-5
 
 
+def test_predictor_gradient(mellon, small_x):
+    # tests/test_density_estimator.py:46-49 (shape) + parity with the numerically differentiated oracle mean
+    est = mellon.DensityEstimator()
+    est.fit(small_x)
+    g = est.predict.gradient(small_x)
+    assert g.shape == small_x.shape
+    ref = mo.density_fit(small_x, lbfgsb_options=mo.LBFGSB_TIGHT)
+    gr = ref.predict.gradient(small_x)
+    assert np.abs(g - gr).max() < 1e-5 * np.abs(gr).max()
+    # sparse model, and finite differences of the device mean itself (independent of the oracle)
+    est2 = mellon.DensityEstimator(n_landmarks=10)
+    est2.fit(small_x)
+    g2 = est2.predict.gradient(small_x[:20])
+    h = 1e-4
+    for k in range(2):
+        e = np.zeros(2)
+        e[k] = h
+        fd = (est2.predict(small_x[:20] + e) - est2.predict(small_x[:20] - e)) / (2 * h)
+        assert np.abs(g2[:, k] - fd).max() < 1e-6 * max(np.abs(fd).max(), 1.0)
+    with pytest.raises(ValueError):
+        est.predict.gradient(np.zeros((3, 5)))
+
+
 def test_density_estimator_single_dimension(mellon, small_x):
     # tests/test_density_estimator.py:257-269
     est = mellon.DensityEstimator()

@@ -502,3 +502,64 @@ def test_gram_eigh_requires_explicit_factor(ctx):
         fit2.project(21)
     p5 = fit2.project(5)
     assert p5.m == 5 and p5.L().shape == (200, 5)
+
+
+# ---- analytic gradients: Covariance.k_grad and Predictor.gradient -----------------------------------------
+_ACTIVE_DIMS = [None, slice(2), 1, slice(None, None, 2), [1, 2]]
+
+
+@pytest.mark.parametrize("name", ["Matern32", "Matern52", "ExpQuad", "Exponential", "RatQuad", "Linear"])
+@pytest.mark.parametrize("active_dims", _ACTIVE_DIMS)
+def test_k_grad_leaves(ctx, name, active_dims):
+    # tests/test_cov.py:21-64 (x = 1, y in {2, 1.5}, ls = 1.2)
+    from mellon_amd import cov
+    cls = getattr(cov, name)
+    k = cls(3, 1.2, active_dims=active_dims) if name == "RatQuad" else cls(1.2, active_dims=active_dims)
+    x = np.ones((5, 4))
+    y = np.ones((6, 4)) * 2
+    y[1] = 1.5
+    g = k.k_grad(x)(y)
+    ref = _pair(k).k_grad(x)(y)
+    assert g.shape == (5, 6, 4)
+    assert np.abs(g - ref).max() < 1e-13 * max(np.abs(ref).max(), 1.0)
+    # random, non-degenerate points and coincident points (distance floor 1e-6, delta = 0)
+    rng = np.random.default_rng(1)
+    x2, y2 = rng.normal(size=(37, 4)), rng.normal(size=(29, 4))
+    y2[:5] = x2[:5]
+    g2, r2 = k.k_grad(x2)(y2), _pair(k).k_grad(x2)(y2)
+    assert np.abs(g2 - r2).max() < 1e-9 * max(np.abs(r2).max(), 1.0)
+
+
+@pytest.mark.parametrize("active_dims", _ACTIVE_DIMS)
+def test_k_grad_composites(ctx, active_dims):
+    # tests/test_base_cov.py:41-53,87-99,132-144,173-185
+    from mellon_amd import cov
+    x = np.ones((2, 3))
+    for k in (cov.Add(cov.Matern32(1.4), cov.Exponential(3.4), active_dims=active_dims),
+              cov.Mul(cov.Matern32(1.4), cov.Exponential(3.4), active_dims=active_dims),
+              cov.Pow(cov.Matern32(1.4), 3.2, active_dims=active_dims)):
+        g, ref = k.k_grad(x)(2 * x), _pair(k).k_grad(x)(2 * x)
+        assert np.abs(g - ref).max() < 1e-13
+    h = 0.2 + 1.1 * cov.Matern52(1.4, active_dims=0) + \
+        2.1 * cov.Exponential(3.4, active_dims=[1, 2]) * cov.RatQuad(1.1, 3.4, active_dims=slice(0, 2, 1)) + \
+        cov.Matern52(1.0, active_dims=[False, True, True])
+    rng = np.random.default_rng(2)
+    xr, yr = rng.normal(size=(40, 3)), rng.normal(size=(33, 3))
+    g, ref = h.k_grad(xr)(yr), _pair(h).k_grad(xr)(yr)
+    assert np.abs(g - ref).max() < 1e-12 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n,m,d", [(1, 1, 1), (130, 70, 3), (300, 257, 20), (129, 64, 50)])
+def test_predict_gradient_matches_contracted_k_grad(ctx, n, m, d):
+    from mellon_amd import cov
+    rng = np.random.default_rng(n + m + d)
+    xq, c, w = rng.normal(size=(n, d)), rng.normal(size=(m, d)), rng.normal(size=m)
+    kernels = [cov.Matern52(1.7 * np.sqrt(d)), cov.ExpQuad(2.0 * np.sqrt(d))]
+    if d >= 3:
+        kernels.append(cov.Matern52(1.5 * np.sqrt(d), active_dims=slice(None, -1)) * cov.ExpQuad(1.2, active_dims=-1))
+        kernels.append(cov.Matern32(2.0, active_dims=[0, 2]) + 0.5 * cov.Linear(3.0))
+    for k in kernels:
+        g = ctx.predict_gradient(k.lower(d), xq, c, w)
+        ref = np.einsum("j,jik->ik", w, _pair(k).k_grad(c)(xq))     # d k(x_i, c_j)/dx_i = k_grad(c)(x)[j, i]
+        assert g.shape == (n, d)
+        assert np.abs(g - ref).max() < 1e-10 * max(np.abs(ref).max(), 1e-300)

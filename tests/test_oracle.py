@@ -269,3 +269,54 @@ def test_density_fit_nystroem_types():
         f = mo.density_fit(x, **kw)
         assert f.gp_type == gp and f.Lp is None and f.L.shape[1] < 80
         assert np.std(f.predict(x) - base) / np.std(base) < 2e-1      # tests/test_density_estimator.py:80-96
+
+
+# ---- analytic kernel gradients (tests/test_cov.py:17-64, tests/test_base_cov.py:41-53,87-99,132-144,173-185) ----
+_ACTIVE_DIMS = [None, slice(2), 1, slice(None, None, 2), [1, 2]]
+
+
+def _fd_k_grad(cov, x, y, h=1e-5):
+    out = np.zeros((x.shape[0], y.shape[0], y.shape[1]))
+    for k in range(y.shape[1]):
+        e = np.zeros(y.shape[1])
+        e[k] = h
+        out[:, :, k] = (cov.k(x, y + e) - cov.k(x, y - e)) / (2 * h)
+    return out
+
+
+@pytest.mark.parametrize("name", ["Matern32", "Matern52", "ExpQuad", "Exponential", "RatQuad", "Linear"])
+@pytest.mark.parametrize("active_dims", _ACTIVE_DIMS)
+def test_k_grad_matches_numerical_derivative(name, active_dims):
+    # the reference compares k_grad with jax.jacfwd at these very points (atol 1e-6); central differences
+    # of the restated k() stand in for autodiff
+    cls = getattr(mo, name)
+    cov = cls(3, 1.2, active_dims=active_dims) if name == "RatQuad" else cls(1.2, active_dims=active_dims)
+    x = np.ones((5, 4))
+    y = np.ones((6, 4)) * 2
+    y[1] = 1.5
+    g = cov.k_grad(x)(y)
+    assert g.shape == (5, 6, 4)
+    assert np.allclose(g, _fd_k_grad(cov, x, y), atol=1e-6)
+
+
+@pytest.mark.parametrize("active_dims", _ACTIVE_DIMS)
+def test_k_grad_composites(active_dims):
+    x = np.ones((2, 3))
+    for cov in (mo.Add(mo.Matern32(1.4), mo.Exponential(3.4), active_dims=active_dims),
+                mo.Mul(mo.Matern32(1.4), mo.Exponential(3.4), active_dims=active_dims),
+                mo.Pow(mo.Matern32(1.4), 3.2, active_dims=active_dims)):
+        assert np.allclose(cov.k_grad(x)(2 * x), _fd_k_grad(cov, x, 2 * x), atol=1e-6)
+    h = 0.2 + 1.1 * mo.Matern52(1.4, active_dims=0) + \
+        2.1 * mo.Exponential(3.4, active_dims=[1, 2]) * mo.RatQuad(1.1, 3.4, active_dims=slice(0, 2, 1)) + \
+        mo.Matern52(1.0, active_dims=[False, True, True])
+    y = 2 * x ** 2
+    assert np.allclose(h.k_grad(x)(y), _fd_k_grad(h, x, y), atol=1e-6)
+
+
+def test_predictor_gradient_restatement_is_consistent():
+    rng = np.random.default_rng(0)
+    c, w = rng.normal(size=(30, 3)), rng.normal(size=30)
+    pred = mo.Predictor(mo.Matern52(1.3), c, w, -2.0, 30)
+    xq = rng.normal(size=(7, 3))
+    analytic = np.einsum("j,jik->ik", w, pred.cov_func.k_grad(c)(xq))    # symmetry: d k(x, c_j)/dx = k_grad(c)(x)[j]
+    assert np.abs(pred.gradient(xq) - analytic).max() < 1e-8
