@@ -4,9 +4,11 @@
 One "step" = one complete fit_predict pass of the hot path over the synthetic workload
 (covariance tiles -> Cholesky -> triangular-solve panels -> Ridge init -> L-BFGS-B MAP solve on
 the fused device objective -> log-density), inputs already resident in HBM when the timed
-region starts.  Workload at every N: BASELINE config 3 -- 1e6 cells x 50 dims Gaussian mixture,
-5 000 landmarks, Matern52 -- cell-sharded over the N ranks (strong scaling, one process per GPU,
-RCCL all-reduce of (loss, grad) per evaluation and of the Ridge Gram once per fit).
+region starts.  Workload: BASELINE config 3 -- 1e6 cells x 50 dims Gaussian mixture, 5 000 landmarks,
+Matern52 -- per GPU: ONE model is fitted on all N x 1e6 cells, cell-sharded over the N ranks (weak
+scaling: fixed cells per GPU; one process per GPU, RCCL all-reduce of (loss, grad) per evaluation and
+of the Ridge Gram once per fit).  `--scaling strong` shards the same 1e6 cells over the N ranks instead
+(Amdahl-limited by the replicated m x m factorisations).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -30,11 +32,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def gaussian_mixture(n, d, seed, k=10):
-    """BASELINE.md S2 synthetic cells: 10 isotropic Gaussian components, PCG64(seed), float64."""
+def gaussian_mixture(n, d, seed, k=10, shard=0):
+    """BASELINE.md S2 synthetic cells: 10 isotropic Gaussian components, PCG64(seed), float64.
+    shard > 0: n further cells of the SAME mixture from an independent stream (weak scaling)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     means = rng.normal(0.0, 3.0, size=(k, d))
     sig = rng.uniform(0.5, 1.5, size=k)
+    if shard > 0:
+        rng = np.random.Generator(np.random.PCG64([seed, shard]))
     comp = rng.integers(0, k, size=n)
     x = means[comp] + rng.normal(size=(n, d)) * sig[comp][:, None]
     return np.ascontiguousarray(x[rng.permutation(n)])
@@ -75,9 +80,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--d", type=int, default=50)
-    ap.add_argument("--m", type=int, default=5000)
+    ap.add_argument("--cells", dest="n", type=int, default=1_000_000, help="cells per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--dims", dest="d", type=int, default=50)
+    ap.add_argument("--landmarks", dest="m", type=int, default=5000)
     ap.add_argument("--kernel", default="Matern52")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=50000, help="cells of the CPU-baseline sample (0 = skip)")
@@ -96,21 +102,44 @@ def main():
     ctx = _lib.default_context()
     info = ctx.device_info()
 
-    # ---- synthetic workload (identical on every rank; each rank keeps its row block) ---------------
+    # ---- synthetic workload -----------------------------------------------------------------------------
     n, d, m = args.n, args.d, args.m
+    weak = args.scaling == "weak"
     t_gen = time.perf_counter()
-    x_all = gaussian_mixture(n, d, args.seed)
-    landmarks = make_landmarks(x_all, m)
+    x0 = gaussian_mixture(n, d, args.seed)                # shard 0 == the BASELINE C3 data set
+    landmarks = make_landmarks(x0, m)
     if world > 1:   # replicated inputs must be BIT-identical on every rank (they steer the shared optimiser)
         landmarks = comm.allreduce_sum(landmarks if rank == 0 else np.zeros_like(landmarks))
-    lo, hi = distributed.shard_bounds(n, world, rank)
-    x_all_dev = ctx.to_device(x_all)
-    x_loc_dev = ctx.to_device(x_all[lo:hi]) if world > 1 else x_all_dev
-    t0 = time.perf_counter()
-    nn_loc = ctx.nn_distances(x_loc_dev, x_all_dev, self_offset=lo)      # exact 1-NN, excluded from timing
-    t_nn = time.perf_counter() - t0
-    if world > 1:
-        x_all_dev.free()
+    t_nn = 0.0
+    if weak:
+        # rank r owns shard r (n cells); exact 1-NN among ALL world * n cells: every rank regenerates the
+        # other shards (deterministic streams, no communication) and keeps the running minimum
+        n_total = n * world
+        lo, hi = 0, n
+        x_loc = x0 if rank == 0 else gaussian_mixture(n, d, args.seed, shard=rank)
+        x_loc_dev = ctx.to_device(x_loc)
+        nn_loc = None
+        for s_ in range(world):
+            xs = x_loc if s_ == rank else (x0 if s_ == 0 else gaussian_mixture(n, d, args.seed, shard=s_))
+            xs_dev = x_loc_dev if s_ == rank else ctx.to_device(xs)
+            t0 = time.perf_counter()
+            part = ctx.nn_distances(x_loc_dev, xs_dev, self_offset=0 if s_ == rank else -(n + 1))
+            t_nn += time.perf_counter() - t0
+            nn_loc = part if nn_loc is None else np.minimum(nn_loc, part)
+            if s_ != rank:
+                xs_dev.free()
+            del xs
+    else:
+        n_total = n
+        lo, hi = distributed.shard_bounds(n, world, rank)
+        x_loc = x0[lo:hi]
+        x_all_dev = ctx.to_device(x0)
+        x_loc_dev = ctx.to_device(x_loc) if world > 1 else x_all_dev
+        t0 = time.perf_counter()
+        nn_loc = ctx.nn_distances(x_loc_dev, x_all_dev, self_offset=lo)      # exact 1-NN, excluded from timing
+        t_nn = time.perf_counter() - t0
+        if world > 1:
+            x_all_dev.free()
     t_gen = time.perf_counter() - t_gen
     kern = getattr(mellon_amd.cov, args.kernel)
 
@@ -152,13 +181,13 @@ def main():
 
     # ---- size-independent parity property at full size: predict(X) == fit_predict(X) -----------------
     k = min(20000, hi - lo)
-    xq = x_all[lo:lo + k]
+    xq = x_loc[:k]
     prop = float(np.abs(est.predict(xq) - dens[:k]).max() / np.abs(dens[:k]).max())
 
     if rank != 0:
         return
     ms_per_step = 1e3 * elapsed / args.steps
-    value = n * args.steps / elapsed
+    value = n_total * args.steps / elapsed
     per_launch = stats["objective_kernel_s"] / max(stats["objective_launches"], 1.0)
     ach = stats["objective_bytes_per_launch"] / per_launch / 1e9
     traffic = None
@@ -173,10 +202,12 @@ def main():
     out = {
         "metric": "cells/sec fit_predict", "value": value, "unit": "cells/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C3 DensityEstimator.fit_predict: {n} cells x {d} dims Gaussian mixture "
-                               f"(seed {args.seed}), {m} landmarks, {args.kernel}, cell-sharded over {world} GPU(s)",
-                   "n": n, "d": d, "m": m, "kernel": args.kernel, "parallelism": f"cells/{world}",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C3 DensityEstimator.fit_predict: {n_total} cells x {d} dims Gaussian mixture "
+                               f"(seed {args.seed}), {m} landmarks, {args.kernel}, one model, cells sharded over "
+                               f"{world} GPU(s) ({hi - lo} cells per GPU)",
+                   "n": n_total, "n_per_gpu": hi - lo, "d": d, "m": m, "kernel": args.kernel,
+                   "parallelism": f"cells/{world}",
                    "objective_evaluations": int(n_eval),
                    "optimizer": "L-BFGS-B maxcor=30 ftol=1e-13 gtol=1e-7 (converged to the unique MAP optimum)",
                    "landmarks": "k-means (random init, 10 Lloyd iterations, 20k-cell subsample), host, untimed",
@@ -192,7 +223,7 @@ def main():
     if world == 1 and args.cpu_sample > 0:
         del est
         gc.collect()
-        base, _ = cpu_baseline(x_all, landmarks, nn_loc, args.kernel, min(args.cpu_sample, n))
+        base, _ = cpu_baseline(x0, landmarks, nn_loc, args.kernel, min(args.cpu_sample, n))
         out["cpu_baseline"] = base
     print(json.dumps(out))
 
