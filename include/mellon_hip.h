@@ -250,6 +250,11 @@ int mln_weights_full(mln_fit* fit, const double* y, int64_t p, double mu, double
 int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                      int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
                      double sigma, double jitter, double* W /* m x p */);
+/* Same solve, additionally returning the with_uncertainty state of the noisy landmark conditional
+ * (conditional.py:571-577): Lp (m x m) and Cs = Lp L_B (m x m, lower), either may be NULL.          */
+int mln_sparse_solve_factors(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                             int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
+                             double sigma, double jitter, double* W, double* Lp_out, double* Cs_out);
 
 /* a-13: mean(Xnew) = mu + cov(Xnew, centers) W   (conditional.py:366-373,651-658,899-906).
  * centers: m x d (landmarks or, full GP, the training cells); W: m x p; out: n_new x p.

@@ -88,6 +88,8 @@ SYMBOLS = [
     ("mln_weights_cholesky", C.c_int, [_vp, _dp, _dp]),
     ("mln_weights_full", C.c_int, [_vp, _dp, _i64, _dbl, _dp]),
     ("mln_sparse_solve", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp]),
+    ("mln_sparse_solve_factors", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp,
+                                           _dp, _dp]),
     ("mln_predict_mean", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp]),
     ("mln_predict_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i32, _dp]),
     ("mln_predict_mean_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _i32, _dp]),
@@ -356,16 +358,25 @@ class Context:
                                                          1 if diag else 0, out.ctypes.data))
         return out
 
-    def sparse_solve(self, desc, x, xu, y, mu, sigma, jitter):
+    def sparse_solve(self, desc, x, xu, y, mu, sigma, jitter, return_factors=False):
+        """Weights of the noisy landmark conditional; with return_factors also (Lp, Cs = Lp L_B)."""
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
         y2 = _f64(y)
+        m = xu.shape[0]
         p = 1 if y2.ndim == 1 else y2.shape[1]
-        W = np.empty((xu.shape[0],) if y2.ndim == 1 else (xu.shape[0], p), dtype=np.float64)
-        self._check(self.lib.mln_sparse_solve(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1], _ptr(xu),
-                                              xu.shape[0], y2.ctypes.data, p, float(mu), float(sigma),
-                                              float(jitter), W.ctypes.data), jitter=jitter)
-        return W
+        W = np.empty((m,) if y2.ndim == 1 else (m, p), dtype=np.float64)
+        if not return_factors:
+            self._check(self.lib.mln_sparse_solve(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1], _ptr(xu),
+                                                  m, y2.ctypes.data, p, float(mu), float(sigma),
+                                                  float(jitter), W.ctypes.data), jitter=jitter)
+            return W
+        Lp, Cs = np.empty((m, m)), np.empty((m, m))
+        self._check(self.lib.mln_sparse_solve_factors(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1],
+                                                      _ptr(xu), m, y2.ctypes.data, p, float(mu), float(sigma),
+                                                      float(jitter), W.ctypes.data, Lp.ctypes.data,
+                                                      Cs.ctypes.data), jitter=jitter)
+        return W, Lp, Cs
 
     def diag_peak(self, what, nbytes=1 << 32):
         r = C.c_double()

@@ -101,8 +101,15 @@ class Predictor:
         if not hasattr(self, "L") or self.L is None:
             raise ValueError("The predictor was computed without covariance. "
                              "Recompute setting `with_uncertainty=True.`")
-        return _lib.default_context().predict_covariance(self.cov_func.lower(self.n_input_features), x,
-                                                         self.centers, np.asarray(self.L), diag=diag)
+        ctx = _lib.default_context()
+        desc = self.cov_func.lower(self.n_input_features)
+        cov = ctx.predict_covariance(desc, x, self.centers, np.asarray(self.L), diag=diag)
+        Cs = getattr(self, "Cs", None)
+        if Cs is not None:
+            # noisy landmark conditional (conditional.py:707-716): + |Cs^-1 K_ux|^2, i.e. k - (k - |Cs^-1 K|^2)
+            kss = self.cov_func.diag(x) if diag else self.cov_func(x, x)
+            cov = cov + (kss - ctx.predict_covariance(desc, x, self.centers, np.asarray(Cs), diag=diag))
+        return cov
 
     def mean_covariance(self, x, diag=True):
         """(K W)(K W)^T: uncertainty of the mean inherited from the parameter uncertainty W."""

@@ -82,9 +82,21 @@ class _FullConditional:
             fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
         weights = fit.weights_full(np.asarray(y, dtype=np.float64), mu)  # conditional.py:263-264
         Predictor.__init__(self, cov_func, x, weights, mu, n_obs=x.shape[0], jitter=jitter, sigma=sigma)
-        if with_uncertainty:
+        if with_uncertainty and parameter_std is not None:
             # y_cov_factor = L diag(std) (inference.compute_parameter_cov_factor, inference.py:357-372)
             _attach_uncertainty(self, fit.Lp(), _parameter_std(parameter_std, x.shape[0]))
+        elif with_uncertainty:
+            # noisy observations (conditional.py:285-304): L = chol(K + sigma^2 I) and
+            # W = L^-T L^-1 y_cov_factor with y_cov_factor = sigma I
+            s_ = _scalar_sigma(sigma)
+            if s_ is None:
+                raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
+                                 "`pre_transformation_std` to quantify uncertainty of the prediction.")
+            Lh = fit.Lp()
+            ctx_ = _lib.default_context()
+            self.L = Lh
+            self.W = ctx_.trsm_lower(Lh, ctx_.trsm_lower(Lh, np.eye(x.shape[0]) * s_), trans=True)
+            self._state_variables |= {"L", "W"}
 
 
 class _LandmarksConditional:
@@ -93,9 +105,9 @@ class _LandmarksConditional:
     def __init__(self, x, xu, y, mu, cov_func, L=None, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
                  y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False):
         _reject_extras(with_uncertainty, obs_variance)
-        if with_uncertainty:
-            raise NotImplementedError("uncertainty of the noisy landmark conditional (Cs = Lp L_B, "
-                                      "conditional.py:694-716) is outside the accelerated path.")
+        if with_uncertainty and y_is_mean:
+            raise NotImplementedError("with_uncertainty for a landmark conditional on a mean (needs y_cov_factor, "
+                                      "conditional.py:579-587) is outside the accelerated path.")
         # y_is_mean (conditional.py:536-537) feeds _sparse_solve with (r, A) unscaled, which is what
         # _process_sigma produces for sigma = 1: L_B L_B^T = A A^T + I, c = L_B^-1 A r.
         s = 1.0 if y_is_mean else _scalar_sigma(sigma)
@@ -104,9 +116,14 @@ class _LandmarksConditional:
                              "(the reference divides by sigma^2, conditional.py:157-159).")
         xh = x if isinstance(x, _lib.DeviceArray) else np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
-        weights = _lib.default_context().sparse_solve(cov_func.lower(xu.shape[1]), xh, xu,
-                                                      np.asarray(y, dtype=np.float64), mu, s, jitter)
+        out = _lib.default_context().sparse_solve(cov_func.lower(xu.shape[1]), xh, xu,
+                                                  np.asarray(y, dtype=np.float64), mu, s, jitter,
+                                                  return_factors=bool(with_uncertainty))
+        weights = out[0] if with_uncertainty else out
         Predictor.__init__(self, cov_func, xu, weights, mu, n_obs=xh.shape[0], jitter=jitter, sigma=sigma)
+        if with_uncertainty:      # conditional.py:571-577: L = Lp, Cs = Lp L_B
+            self.L, self.Cs = out[1], out[2]
+            self._state_variables |= {"L", "Cs"}
 
 
 class _LandmarksConditionalCholesky:

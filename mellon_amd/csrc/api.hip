@@ -1469,9 +1469,9 @@ extern "C" int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* 
 }
 
 // ---- FunctionEstimator sparse solve ----------------------------------------------------------------
-extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
-                                int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
-                                double sigma, double jitter, double* W) {
+static int sparse_solve_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                             int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
+                             double sigma, double jitter, double* W, double* Lp_out, double* Cs_out) {
   if (!ctx || !xu || !W || (n_local > 0 && (!x || !y))) return MLN_ERR_ARG;
   if (p < 1 || m < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
   if (!(sigma > 0.0)) { mln_set_error(ctx, "sigma must be > 0 for the sparse solve (conditional.py:157-159 divides by sigma^2)"); return MLN_ERR_ARG; }
@@ -1530,10 +1530,45 @@ extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const 
   if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, tb, C, p, p);
   if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, C, p, p);
   if (rc == MLN_OK) chk(hipMemcpyAsync(W, C, sizeof(double) * (size_t)m * p, hipMemcpyDefault, ctx->stream));
+  // with_uncertainty state of the noisy landmark conditional: L = Lp and Cs = Lp L_B   conditional.py:571-577
+  if (rc == MLN_OK && Lp_out) {
+    DevOut o;
+    rc = o.init(ctx, Lp_out, (size_t)m * m);
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, f->Lp, f->ldp, o.dev, m, m, m);
+    if (rc == MLN_OK) rc = o.commit();
+  }
+  if (rc == MLN_OK && Cs_out) {
+    double* cs = nullptr;
+    chk(mln_dmalloc((void**)&cs, sizeof(double) * (size_t)m * ldg));
+    if (rc == MLN_OK) chk(hipMemsetAsync(cs, 0, sizeof(double) * (size_t)m * ldg, ctx->stream));
+    GemmArgs g{};
+    g.A = f->Lp; g.lda = f->ldp; g.B = G; g.ldb = ldg; g.C = cs; g.ldc = ldg;
+    g.M = m; g.N = m; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.split_k = 1;
+    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+    DevOut o;
+    if (rc == MLN_OK) rc = o.init(ctx, Cs_out, (size_t)m * m);
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, cs, ldg, o.dev, m, m, m);
+    if (rc == MLN_OK) rc = o.commit();
+    (void)hipStreamSynchronize(ctx->stream);
+    if (cs) (void)mln_dfree(cs);
+  }
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&tb);
   void* ptrs[] = {G, R, C, parts};
   for (void* q : ptrs) if (q) (void)mln_dfree(q);
   fit_free(f);
   return rc;
+}
+
+extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                                int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
+                                double sigma, double jitter, double* W) {
+  return sparse_solve_impl(ctx, cov, x, n_local, d, xu, m, y, p, mu, sigma, jitter, W, nullptr, nullptr);
+}
+
+extern "C" int mln_sparse_solve_factors(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                                        int32_t d, const double* xu, int64_t m, const double* y, int64_t p,
+                                        double mu, double sigma, double jitter, double* W, double* Lp_out,
+                                        double* Cs_out) {
+  return sparse_solve_impl(ctx, cov, x, n_local, d, xu, m, y, p, mu, sigma, jitter, W, Lp_out, Cs_out);
 }

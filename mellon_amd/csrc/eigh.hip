@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
   const bool have_j = vi && vj;
   const int64_t row_i = (int64_t)bi * EB, row_j = (int64_t)bj * EB;
   auto grow = [&](int r) -> int64_t { return r < EB ? row_i + r : row_j + (r - EB); };
-  const int n_rows = have_j ? ER : EB;
 
   // ---- 1. S = V_rows . X_rows^T (block of V A V^T), symmetrised ------------------------------------
   // v_mfma_f64_16x16x4: A[m = li][k = lk], B[k = lk][n = li], D[row = lk + 4 reg][col = li].  The k index

@@ -679,11 +679,18 @@ class Predictor:
     # with_uncertainty state: L (factor on the centres) and W = L^-T diag(std)
     L = None
     W = None
+    Cs = None
 
     def covariance(self, Xnew, diag=True):
         """conditional.py:409-422,930-945."""
         Xnew = ensure_2d(Xnew)
-        A = _sp_trsolve(self.L, self.cov_func(self.centers, Xnew), lower=True)
+        Kus = self.cov_func(self.centers, Xnew)
+        A = _sp_trsolve(self.L, Kus, lower=True)
+        if self.Cs is not None:                               # conditional.py:707-716
+            Cc = _sp_trsolve(self.Cs, Kus, lower=True)
+            if diag:
+                return self.cov_func.diag(Xnew) - np.sum(np.square(A), axis=0) + np.sum(np.square(Cc), axis=0)
+            return self.cov_func(Xnew, Xnew) - A.T @ A + Cc.T @ Cc
         if diag:
             return self.cov_func.diag(Xnew) - np.sum(np.square(A), axis=0)
         return self.cov_func(Xnew, Xnew) - A.T @ A
@@ -706,8 +713,8 @@ class Predictor:
 
 
 def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTER,
-                     y_is_mean=False):
-    """conditional.py:183-264 (non per-feature sigma)."""
+                     y_is_mean=False, with_uncertainty=False):
+    """conditional.py:183-304 (non per-feature sigma)."""
     x = ensure_2d(x)
     if L is None:
         if y_is_mean:
@@ -716,11 +723,16 @@ def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTE
             L = _get_L(x, cov_func, jitter, sigma_to_y_cov_factor(sigma, None, x.shape[0]))
     r = y - mu
     w = _sp_trsolve(L.T, _sp_trsolve(L, r, lower=True), lower=False)
-    return Predictor(cov_func, x, w, mu, x.shape[0])
+    pred = Predictor(cov_func, x, w, mu, x.shape[0])
+    if with_uncertainty:                                      # conditional.py:285-304
+        ycf = sigma_to_y_cov_factor(sigma, None, x.shape[0])
+        pred.L = L
+        pred.W = _sp_trsolve(L.T, _sp_trsolve(L, ycf, lower=True), lower=False)
+    return pred
 
 
 def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
-                          jitter=DEFAULT_JITTER, y_is_mean=False):
+                          jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False):
     """conditional.py:455-547 (scalar / element-wise sigma)."""
     x, xu = ensure_2d(x), ensure_2d(xu)
     Kuf = cov_func(xu, x)
@@ -733,8 +745,12 @@ def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
     else:
         sigma2 = np.square(sigma)            # conditional.py:155-159
         r_l, A_l = r / sigma2, A / sigma2
-    w, _ = sparse_solve(Lp, A, r_l, A_l)
-    return Predictor(cov_func, xu, w, mu, x.shape[0])
+    w, L_B = sparse_solve(Lp, A, r_l, A_l)
+    pred = Predictor(cov_func, xu, w, mu, x.shape[0])
+    if with_uncertainty:                                      # conditional.py:571-577
+        pred.L = Lp
+        pred.Cs = Lp @ L_B
+    return pred
 
 
 def landmarks_conditional_cholesky(xu, z, mu, cov_func, n_obs, L=None,
@@ -748,16 +764,16 @@ def landmarks_conditional_cholesky(xu, z, mu, cov_func, n_obs, L=None,
 
 
 def compute_conditional(x, landmarks, z, y, mu, cov_func, L, Lp=None, sigma=0.0,
-                        jitter=DEFAULT_JITTER, y_is_mean=False):
+                        jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False):
     """inference.py:375-508 dispatch."""
     if landmarks is None:
         return full_conditional(x, y, mu, cov_func, Lp, sigma=sigma, jitter=jitter,
-                                y_is_mean=y_is_mean)
+                                y_is_mean=y_is_mean, with_uncertainty=with_uncertainty)
     if z is not None and z.shape[0] == landmarks.shape[0]:
         return landmarks_conditional_cholesky(landmarks, z, mu, cov_func, x.shape[0], Lp,
                                               jitter=jitter)
     return landmarks_conditional(x, landmarks, y, mu, cov_func, None, sigma=sigma,
-                                 jitter=jitter, y_is_mean=y_is_mean)
+                                 jitter=jitter, y_is_mean=y_is_mean, with_uncertainty=with_uncertainty)
 
 
 # --------------------------------------------------------------------------
@@ -827,7 +843,8 @@ def density_fit(x, cov_func_curry=Matern52, n_landmarks=None, rank=None, landmar
 
 def function_fit(x, y, sigma, cov_func_curry=Matern52, n_landmarks=None, landmarks=None,
                  nn_distances=None, mu=0.0, ls=None, ls_factor=1.0, cov_func=None,
-                 jitter=DEFAULT_JITTER, y_is_mean=False, random_state=DEFAULT_RANDOM_SEED):
+                 jitter=DEFAULT_JITTER, y_is_mean=False, random_state=DEFAULT_RANDOM_SEED,
+                 with_uncertainty=False):
     """FunctionEstimator.fit (function_estimator.py:295-374) -> Predictor."""
     x = ensure_2d(x)
     n = x.shape[0]
@@ -844,7 +861,7 @@ def function_fit(x, y, sigma, cov_func_curry=Matern52, n_landmarks=None, landmar
         landmarks = compute_landmarks(x, gp_type, n_landmarks, random_state)
     return compute_conditional(x, landmarks, None, np.asarray(y, dtype=np.float64), mu,
                                cov_func, None, None, sigma, jitter=jitter,
-                               y_is_mean=y_is_mean)
+                               y_is_mean=y_is_mean, with_uncertainty=with_uncertainty)
 
 
 def per_time_nn_distances(x, times):

@@ -352,6 +352,35 @@ def test_predictor_with_uncertainty(mellon, small_x, n_landmarks, tmp_path):
         plain.mean_covariance(small_x)
 
 
+@pytest.mark.parametrize("n_landmarks", [0, 15])
+def test_function_estimator_with_uncertainty(mellon, n_landmarks):
+    # noisy conditionals: FullConditional keeps L = chol(K + sigma^2 I), W = sigma (K + sigma^2 I)^-1
+    # (conditional.py:285-304); LandmarksConditional keeps L = Lp and Cs = Lp L_B (conditional.py:571-577,694-716)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-2, 2, size=(60, 2))
+    y = np.sin(x[:, 0]) * np.cos(x[:, 1]) + 0.1 * rng.normal(size=60)
+    xq = rng.uniform(-2, 2, size=(25, 2))
+    est = mellon.FunctionEstimator(sigma=0.1, n_landmarks=n_landmarks, predictor_with_uncertainty=True)
+    est.fit(x, y)
+    ref = mo.function_fit(x, y, 0.1, n_landmarks=n_landmarks, landmarks=est.landmarks, ls=est.ls, with_uncertainty=True)
+    p = est.predict
+    assert rel_max(p(xq), ref(xq)) < 1e-8
+    for diag in (True, False):
+        c, cr = p.covariance(xq, diag=diag), ref.covariance(xq, diag=diag)
+        assert c.shape == cr.shape and np.abs(c - cr).max() < 1e-7 * max(np.abs(cr).max(), 1e-12)
+    if n_landmarks == 0:
+        mc, mcr = p.mean_covariance(xq), ref.mean_covariance(xq)
+        assert np.abs(mc - mcr).max() < 1e-7 * np.abs(mcr).max()
+        assert np.abs(p.uncertainty(xq) - ref.uncertainty(xq)).max() < 1e-7 * np.abs(ref.uncertainty(xq)).max()
+    else:
+        assert {"L", "Cs"} <= set(p._state_variables)
+        with pytest.raises(ValueError):
+            p.mean_covariance(xq)                      # no W without y_cov_factor, as in the reference
+    # JSON round trip keeps the uncertainty state
+    q = mellon.Predictor.from_json_str(p.to_json())
+    assert np.abs(q.covariance(xq) - p.covariance(xq)).max() < 1e-12
+
+
 def test_edge_cases(mellon):
     """Ragged / degenerate inputs the reference's validators and tests care about."""
     rng = np.random.default_rng(3)
