@@ -190,6 +190,11 @@ def main():
     value = n_total * args.steps / elapsed
     per_launch = stats["objective_kernel_s"] / max(stats["objective_launches"], 1.0)
     ach = stats["objective_bytes_per_launch"] / per_launch / 1e9
+    # fp32 warm-up passes of the MAP solve (mixed precision): same rows, 4 bytes per element
+    n32 = stats.get("objective32_launches", 0.0)
+    per_launch32 = stats.get("objective32_kernel_s", 0.0) / max(n32, 1.0)
+    bytes32 = stats["objective_bytes_per_launch"] / 2.0
+    ach32 = bytes32 / per_launch32 / 1e9 if n32 > 0 else 0.0
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "objective_traffic.json")
     if os.path.exists(tfile):
@@ -208,7 +213,7 @@ def main():
                                f"{world} GPU(s) ({hi - lo} cells per GPU)",
                    "n": n_total, "n_per_gpu": hi - lo, "d": d, "m": m, "kernel": args.kernel,
                    "parallelism": f"cells/{world}",
-                   "objective_evaluations": int(n_eval),
+                   "objective_evaluations": int(n_eval), "objective_evaluations_fp32": int(n32),
                    "optimizer": "L-BFGS-B maxcor=30 ftol=1e-13 gtol=1e-7 (converged to the unique MAP optimum)",
                    "landmarks": "k-means (random init, 10 Lloyd iterations, 20k-cell subsample), host, untimed",
                    "nn_distances": f"exact 1-NN on device, untimed ({t_nn:.2f} s)",
@@ -216,7 +221,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_objective (fused loss+grad, one pass over L)",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": stats["objective_bytes_per_launch"],
-                     "avg_launch_ms": 1e3 * per_launch, "launches": int(stats["objective_launches"])},
+                     "avg_launch_ms": 1e3 * per_launch, "launches": int(stats["objective_launches"]),
+                     "share_of_step": stats["objective_kernel_s"] / (elapsed / args.steps) if world == 1 else None},
+        "roofline_fp32_passes": {"bound": "hbm", "kernel": "k_objective32 (same pass over the fp32 copy of K: warm-up "
+                                 "iterations of the MAP solve)", "achieved": ach32, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach32 / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_launch": bytes32, "avg_launch_ms": 1e3 * per_launch32,
+                                 "launches": int(n32)},
         "stages_s": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
         "host_s": {"fit_predict_per_step": round(t_fit / args.steps, 4), "release_per_step": round(t_free / args.steps, 4)},
     }

@@ -144,7 +144,10 @@ int mln_trsm_lower(mln_ctx* ctx, const double* Lf, int64_t m, int32_t trans, dou
  * x is THIS RANK's shard (n_local x d); with a communicator the full-GP branch is refused.    */
 #define MLN_FIT_IMPLICIT 1 /* flags: keep K = cov(x,xu) in the n x m buffer and fold Lp^-T into the
                              m-vectors (L z = K (Lp^-T z), L^T v = Lp^-1 (K^T v)): no n x m triangular
-                             solve; mln_fit_get_L materialises rows on demand; no Hessian diagonal.   */
+                             solve; mln_fit_get_L materialises rows on demand; no Hessian diagonal.
+                             For n_local * m >= 2^27 the kernel-matrix pass also keeps an fp32 copy of K
+                             (n_local x ld x 4 bytes) for the warm-up passes of mln_map_solve; environment
+                             MELLON_AMD_MIXED=0 disables, MELLON_AMD_MIXED_MIN_ELEMS moves the threshold. */
 int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                     int32_t d, const double* xu, int64_t m, double jitter, const double* Lp_in,
                     int32_t flags, mln_fit** out);
@@ -284,8 +287,9 @@ int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const 
 /* wall-clock seconds of the stages of the last mln_fit_prepare / mln_ridge_init and counters
  * of mln_objective: [0] kernel matrix, [1] cholesky, [2] trsm, [3] ridge gram, [4] ridge solve,
  * [5] objective kernel time (sum, HIP events), [6] objective launches, [7] bytes of L streamed
- * per objective launch.                                                                        */
-#define MLN_N_STAGE_TIMES 8
+ * per objective launch; [8] / [9] the same time / launch count for the fp32 warm-up passes of
+ * mln_map_solve (mixed precision: they stream 4 bytes per element, half of [7]).                */
+#define MLN_N_STAGE_TIMES 10
 int mln_stage_times(mln_fit* fit, double* out /* MLN_N_STAGE_TIMES */);
 
 #ifdef __cplusplus

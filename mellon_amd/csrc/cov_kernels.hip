@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double*
                                                        const double* __restrict__ xx,
                                                        const double* __restrict__ yy,
                                                        double* __restrict__ out, int64_t ldo,
-                                                       double add_diag, int64_t tiles_n) {
+                                                       double add_diag, int64_t tiles_n,
+                                                       float* __restrict__ out32) {
   __shared__ double xs[DK][TM + PADT];
   __shared__ double ys[DK][TN + PADT];
   const int64_t bid = blockIdx.x;
@@ -170,8 +171,11 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double*
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int64_t c = col0 + tx * 4 + j;
-      if (c < m) out[r * ldo + c] = val[i][j] + ((r == c) ? add_diag : 0.0);
-      else if (c < ldo) out[r * ldo + c] = 0.0;   // pad columns of the leading dimension stay zero
+      const double v = (c < m) ? val[i][j] + ((r == c) ? add_diag : 0.0) : 0.0;
+      if (c < ldo) {   // pad columns of the leading dimension stay zero
+        out[r * ldo + c] = v;
+        if (out32) out32[r * ldo + c] = (float)v;   // fp32 copy for the warm-up passes of the MAP solve
+      }
     }
   }
 }
@@ -382,7 +386,7 @@ int sqnorms(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, 
 }  // namespace
 
 int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
-                         int64_t m, int d, double* out, int64_t ldo, double add_diag) {
+                         int64_t m, int d, double* out, int64_t ldo, double add_diag, float* out32) {
   if (n == 0 || m == 0) return MLN_OK;
   double* norms = nullptr;
   MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)cov.n_leaves * (size_t)(n + m), (void**)&norms));
@@ -396,10 +400,10 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   const bool single = (cov.n_toks == 1);
   if (single)
     hipLaunchKernelGGL(k_kernel_matrix<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
-                       xx, yy, out, ldo, add_diag, tiles_n);
+                       xx, yy, out, ldo, add_diag, tiles_n, out32);
   else
     hipLaunchKernelGGL(k_kernel_matrix<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
-                       xx, yy, out, ldo, add_diag, tiles_n);
+                       xx, yy, out, ldo, add_diag, tiles_n, out32);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

@@ -63,7 +63,7 @@ int mln_lower_cov(mln_ctx* ctx, const mln_kernel_desc* cov, int d, DevCov* out);
 // ---- kernel launchers (all asynchronous on ctx->stream; device pointers only) ---------------
 // cov_kernels.hip
 int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
-                         int64_t m, int d, double* out, int64_t ldo, double add_diag);
+                         int64_t m, int d, double* out, int64_t ldo, double add_diag, float* out32 = nullptr);
 int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
                          int64_t m, int d, const double* w, double mu, double* out);
 
@@ -118,8 +118,10 @@ struct ObjArgs {
   const double* weights;  // if non-null: "gemv-T" mode, grad_j = sum_i weights_i L_ij (V, Vdr, z unused)
   double* f_out;          // if non-null: store f_i = L_i . z + mu
   int n_wg; int64_t m_pad;
+  const float* L32;       // if non-null: stream this fp32 copy of L instead (same shape / leading dimension)
 };
 int objective_max_m();
+int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count);
 int launch_objective(mln_ctx* ctx, const ObjArgs& a);
 int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out_loss_grad /* 1 + m [+ m] */);
 int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x,

@@ -27,6 +27,10 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 template <int CPT, int R>
 __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2, int64_t row, int64_t row_end,
                                           unsigned tid, d2 (&v)[R][CPT]) {
+  // Loads are unconditional (no exec-masked branches, so the compiler keeps exact vmcnt counts and the
+  // next register set really is in flight while the current one is consumed): rows past the end re-read
+  // the first row of the step (their coefficient is 0), lanes past the row end re-read its last pair
+  // (their z is 0 and their partial sums are never stored).
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool rok = (row + r) < row_end;
@@ -34,9 +38,9 @@ __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2
     const d2* rowp = L2 + (rok ? (row + r) : row) * ld2;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
-      const unsigned off = (unsigned)c * WG + tid;
-      const bool ok = rok && off < (unsigned)ld2;
-      v[r][c] = ok ? __builtin_nontemporal_load(rowp + off) : (d2){0.0, 0.0};
+      unsigned off = (unsigned)c * WG + tid;
+      off = (off < (unsigned)ld2) ? off : (unsigned)ld2 - 1u;
+      v[r][c] = __builtin_nontemporal_load(rowp + off);
     }
   }
 }
@@ -132,11 +136,15 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   }
   double loss = 0.0;
   d2 va[R][CPT], vb[R][CPT];
+  // Software pipeline with UNCONDITIONAL loads (steps past the end re-read the last step): the load
+  // count between any use and the loads it depends on is then static, so the compiler waits with
+  // vmcnt(loads of one set) instead of vmcnt(0) and one set is always in flight behind the one consumed.
+  const int64_t s_last = s_end - 1;
   if (s_beg < s_end) load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va);
   for (int64_t s = s_beg; s < s_end; s += 2) {
-    if (s + 1 < s_end) load_rows<CPT, R>(L2, ld2, (s + 1) * R, a.n, tid, vb);
+    load_rows<CPT, R>(L2, ld2, ((s + 1 < s_end) ? s + 1 : s_last) * R, a.n, tid, vb);
     process_rows<CPT, R, MODE>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red);
-    if (s + 2 < s_end) load_rows<CPT, R>(L2, ld2, (s + 2) * R, a.n, tid, va);
+    load_rows<CPT, R>(L2, ld2, ((s + 2 < s_end) ? s + 2 : s_last) * R, a.n, tid, va);
     if (s + 1 < s_end) process_rows<CPT, R, MODE>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red);
   }
   if (MODE != MODE_FONLY) {
@@ -155,6 +163,137 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
       }
     }
     if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss;
+  }
+}
+
+// ---- fp32 copy of the streamed buffer: warm-up passes of the MAP solve ------------------------------------
+// Same structure as k_objective<MODE_OBJ>, but a lane load is 16 bytes = 4 consecutive fp32 columns
+// (thread t owns the column quads {t, t+512, ...}); rows stay in registers as floats and are widened
+// where they are used; every sum is fp64.  Half the HBM bytes per pass.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int CQ, int R>
+__device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t ld4, int64_t row, int64_t row_end,
+                                            unsigned tid, f4 (&v)[R][CQ]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool rok = (row + r) < row_end;
+    const f4* rowp = L4 + (rok ? (row + r) : row) * ld4;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {   // unconditional, clamped: see load_rows
+      unsigned off = (unsigned)c * WG + tid;
+      off = (off < (unsigned)ld4) ? off : (unsigned)ld4 - 1u;
+      v[r][c] = __builtin_nontemporal_load(rowp + off);
+    }
+  }
+}
+
+template <int CQ, int R>
+__device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
+                                               const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
+                                               double& loss, double (*red)[8][R]) {
+  double coef[R], dot[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      s = fma((double)v[r][c].x, z[c][0], s);
+      s = fma((double)v[r][c].y, z[c][1], s);
+      s = fma((double)v[r][c].z, z[c][2], s);
+      s = fma((double)v[r][c].w, z[c][3], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    dot[r] = s;
+  }
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) red[par][wave][r] = dot[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[par][w][r];
+    const bool rok = (row + r) < row_end;
+    const double f = s + a.mu;
+    const double Vi = rok ? a.V[row + r] : 0.0;
+    const double e = rok ? exp(f + Vi) : 0.0;
+    coef[r] = rok ? (e - 1.0) : 0.0;
+    if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) {
+      g[c][0] = fma(coef[r], (double)v[r][c].x, g[c][0]);
+      g[c][1] = fma(coef[r], (double)v[r][c].y, g[c][1]);
+      g[c][2] = fma(coef[r], (double)v[r][c].z, g[c][2]);
+      g[c][3] = fma(coef[r], (double)v[r][c].w, g[c][3]);
+    }
+  }
+}
+
+template <int CQ, int R>
+__global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
+  __shared__ double red[2][8][R];
+  const int tid = threadIdx.x;
+  const int64_t ld4 = a.ldl / 4;
+  const f4* __restrict__ L4 = reinterpret_cast<const f4*>(a.L32);
+  const int64_t nsteps = (a.n + R - 1) / R;
+  const int64_t per = (nsteps + a.n_wg - 1) / a.n_wg;
+  const int64_t s_beg = (int64_t)blockIdx.x * per;
+  int64_t s_end = s_beg + per;
+  if (s_end > nsteps) s_end = nsteps;
+  double z[CQ][4], g[CQ][4];
+#pragma unroll
+  for (int c = 0; c < CQ; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t col = 4 * ((int64_t)c * WG + tid) + e;
+      z[c][e] = (col < a.m) ? a.z[col] : 0.0;
+      g[c][e] = 0.0;
+    }
+  double loss = 0.0;
+  f4 va[R][CQ], vb[R][CQ];
+  const int64_t s_last = s_end - 1;
+  if (s_beg < s_end) load_rows32<CQ, R>(L4, ld4, s_beg * R, a.n, tid, va);
+  for (int64_t s = s_beg; s < s_end; s += 2) {   // unconditional loads: see k_objective
+    load_rows32<CQ, R>(L4, ld4, ((s + 1 < s_end) ? s + 1 : s_last) * R, a.n, tid, vb);
+    process_rows32<CQ, R>(a, s * R, a.n, tid, 0, va, z, g, loss, red);
+    load_rows32<CQ, R>(L4, ld4, ((s + 2 < s_end) ? s + 2 : s_last) * R, a.n, tid, va);
+    if (s + 1 < s_end) process_rows32<CQ, R>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red);
+  }
+  double* pg = a.part_grad + (int64_t)blockIdx.x * a.m_pad;
+#pragma unroll
+  for (int c = 0; c < CQ; ++c) {
+    const int64_t col = 4 * ((int64_t)c * WG + tid);
+    if (col < a.m_pad) {   // m_pad is a multiple of 16
+      *reinterpret_cast<d2*>(pg + col) = (d2){g[c][0], g[c][1]};
+      *reinterpret_cast<d2*>(pg + col + 2) = (d2){g[c][2], g[c][3]};
+    }
+  }
+  if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss;
+}
+
+template <int CQ, int R>
+int launch_f32(mln_ctx* ctx, const ObjArgs& a) {
+  hipLaunchKernelGGL((k_objective32<CQ, R>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+__global__ void k_to_f32(const double* __restrict__ src, float* __restrict__ dst, int64_t count) {
+  const int64_t i = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i + 1 < count) {
+    const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2*>(src + i));
+    dst[i] = (float)v.x;
+    dst[i + 1] = (float)v.y;
+  } else if (i < count) {
+    dst[i] = (float)src[i];
   }
 }
 
@@ -229,6 +368,14 @@ int launch_mode(mln_ctx* ctx, const ObjArgs& a, int mode) {
 
 }  // namespace
 
+int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count) {
+  if (count <= 0) return MLN_OK;
+  const int64_t blocks = (count / 2 + 256) / 256;
+  hipLaunchKernelGGL(k_to_f32, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, src, dst, count);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
 int objective_max_m() { return 1024 * 8; }
 
 int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
@@ -237,6 +384,15 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   if (a.weights) mode = MODE_GEMVT;
   else if (a.f_out) mode = MODE_FONLY;
   else if (a.part_hess) mode = MODE_OBJ_HESS;
+  if (a.L32 && mode == MODE_OBJ && a.ldl % 4 == 0) {   // fp32 copy: 4 columns per 16-byte lane load
+    const int cq = (int)((a.ldl / 4 + WG - 1) / WG);
+    switch (cq) {
+      case 1: return launch_f32<1, 8>(ctx, a);
+      case 2: return launch_f32<2, 4>(ctx, a);
+      case 3: return launch_f32<3, 3>(ctx, a);
+      default: return launch_f32<4, 2>(ctx, a);
+    }
+  }
   const int64_t pairs = a.ldl / 2;
   const int cpt = (int)((pairs + WG - 1) / WG);
   // rows per step chosen so that one register set holds <= 12 double2 per thread

@@ -381,6 +381,28 @@ def test_function_estimator_with_uncertainty(mellon, n_landmarks):
     assert np.abs(q.covariance(xq) - p.covariance(xq)).max() < 1e-12
 
 
+def test_mixed_precision_warmup_reaches_the_same_optimum(mellon, monkeypatch):
+    """The fp32 copy of K only serves the first passes of the MAP solve; the final answer is the fp64
+    optimum.  MELLON_AMD_MIXED_MIN_ELEMS=0 forces the mixed path at oracle-checkable sizes."""
+    x = mo.gaussian_mixture(6000, 10, 17)
+    rng = np.random.default_rng(2)
+    lm = x[rng.choice(6000, 300, replace=False)]
+    nn = mo.exact_nn_distances(x)
+    ref = mo.density_fit(x, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    out = {}
+    for mixed in ("1", "0"):
+        monkeypatch.setenv("MELLON_AMD_MIXED", mixed)
+        monkeypatch.setenv("MELLON_AMD_MIXED_MIN_ELEMS", "0")
+        est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn)
+        out[mixed] = est.fit_predict(x)
+        st = est._fit.stage_times()
+        assert (st["objective32_launches"] > 0) == (mixed == "1")
+        assert st["objective_launches"] > 0                       # the solve always finishes on the fp64 buffer
+        assert rel_std(out[mixed], ref.log_density_x) < 1e-5 and rel_max(out[mixed], ref.log_density_x) < 1e-5
+        assert rel_max(est.predict(x[:500]), out[mixed][:500]) < 1e-9
+    assert rel_max(out["1"], out["0"]) < 2e-6
+
+
 def test_edge_cases(mellon):
     """Ragged / degenerate inputs the reference's validators and tests care about."""
     rng = np.random.default_rng(3)
