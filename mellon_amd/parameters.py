@@ -245,11 +245,11 @@ def _fit_of(L):
     return _lib.Fit.from_L(_lib.default_context(), np.asarray(L, dtype=np.float64))
 
 
-RIDGE_ROWS_PER_LANDMARK = 16    # measured at C3: 16 m cells minimise Gram time + extra passes
+RIDGE_ROWS_PER_LANDMARK = 12    # measured at C3 with the mixed-precision solve: 12 m cells minimise Gram time + extra passes
 
 
 def ridge_row_stride(n_local, m):
-    """Cells used for the Ridge / preconditioner Gram: every k-th cell such that ~16 m cells remain
+    """Cells used for the Ridge / preconditioner Gram: every k-th cell such that ~12 m cells remain
     (all cells when n <= 32 m).  The Gram only seeds and preconditions a strictly convex solve, so
     the subsample changes the iteration count (measured: not at all down to 2 m rows), never the
     optimum; `row_stride=1` reproduces the reference's exact Ridge on all cells."""
