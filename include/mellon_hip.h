@@ -272,6 +272,9 @@ int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xne
 int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result);
 int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
                    int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out);
+/* ms of: kernel-matrix pass alone, Gram GEMM alone, both on two streams, Cholesky alone, kernel matrix ||
+ * Cholesky, kernel matrix || (Cholesky then Gram) -- the measurement behind the two-stream set-up phase. */
+int mln_diag_overlap(mln_ctx* ctx, int64_t n, int64_t m, int32_t d, int64_t gram_rows, double* out /* 6 */);
 
 /* ---- predictive uncertainty (S8f rank 2) ----------------------------------------------------------
  * covariance:       k(x*,x*) - A A^T with A = cov(x*, centers) Lf^-T      conditional.py:409-422,930-945

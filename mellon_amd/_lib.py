@@ -95,6 +95,7 @@ SYMBOLS = [
     ("mln_predict_mean_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_stage_times", C.c_int, [_vp, _dp]),
     ("mln_diag_peak", C.c_int, [_vp, _i32, _i64, C.POINTER(_dbl)]),
+    ("mln_diag_overlap", C.c_int, [_vp, _i64, _i64, _i32, _i64, _dp]),
     ("mln_diag_dgemm", C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, C.POINTER(_dbl)]),
 ]
 
@@ -377,6 +378,11 @@ class Context:
                                                       float(jitter), W.ctypes.data, Lp.ctypes.data,
                                                       Cs.ctypes.data), jitter=jitter)
         return W, Lp, Cs
+
+    def diag_overlap(self, n, m, d, gram_rows):
+        out = np.zeros(6)
+        self._check(self.lib.mln_diag_overlap(self.handle, int(n), int(m), int(d), int(gram_rows), out.ctypes.data))
+        return dict(zip(["k_ms", "gram_ms", "k_par_gram_ms", "chol_ms", "k_par_chol_ms", "k_par_chol_gram_ms"], out))
 
     def diag_peak(self, what, nbytes=1 << 32):
         r = C.c_double()

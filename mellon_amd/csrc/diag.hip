@@ -121,3 +121,65 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return MLN_OK;
 }
+
+// ---- stream-overlap probe: does a second stream's MFMA-bound GEMM / latency-bound Cholesky run concurrently
+// with the VALU-bound kernel-matrix pass?  out[0..5] = ms: K alone, Gram alone, K||Gram, chol alone, K||chol,
+// and (K_s rows first) is not modelled here.
+#include <chrono>
+#include <thread>
+static double wall_ms() {
+  return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+extern "C" int mln_diag_overlap(mln_ctx* ctx, int64_t n, int64_t m, int32_t d, int64_t gram_rows, double* out) {
+  if (!ctx || !out) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  mln_kernel_desc kd{};
+  mln_leaf leaf{}; leaf.kind = MLN_K_MATERN52; leaf.ndims = 0; leaf.ls = 20.0; leaf.alpha = 1.0; leaf.dims = nullptr;
+  mln_tok tok{}; tok.op = MLN_OP_LEAF; tok.leaf = 0;
+  kd.n_leaves = 1; kd.n_toks = 1; kd.leaves = &leaf; kd.toks = &tok;
+  DevCov cov;
+  MLN_TRY(mln_lower_cov(ctx, &kd, d, &cov));
+  const int64_t ld = (m + 15) / 16 * 16;
+  double *X = nullptr, *Xu = nullptr, *K = nullptr, *G = nullptr, *A = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&X, sizeof(double) * n * d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Xu, sizeof(double) * m * d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&K, sizeof(double) * n * ld));
+  MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * m * ld));
+  MLN_HIP(ctx, mln_dmalloc((void**)&A, sizeof(double) * m * ld));
+  std::vector<double> pat((size_t)1 << 20);
+  unsigned long long s = 88172645463325252ULL;
+  for (auto& v : pat) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = 3.0 * ((double)(s >> 11) / 9007199254740992.0 - 0.5); }
+  for (size_t off = 0; off < sizeof(double) * (size_t)n * d; off += pat.size() * 8)
+    MLN_HIP(ctx, hipMemcpyAsync((char*)X + off, pat.data(), std::min(pat.size() * 8, sizeof(double) * (size_t)n * d - off), hipMemcpyHostToDevice, ctx->stream));
+  MLN_HIP(ctx, hipMemcpyAsync(Xu, pat.data() + 777, sizeof(double) * m * d, hipMemcpyHostToDevice, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  mln_ctx side = *ctx;   // second stream, own status word
+  side.scratch = nullptr; side.scratch_bytes = 0; side.err.clear();
+  MLN_HIP(ctx, hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking));
+  MLN_HIP(ctx, mln_dmalloc((void**)&side.d_info, 4 * sizeof(int)));
+  auto run_k = [&]() { (void)launch_kernel_matrix(ctx, cov, X, n, Xu, m, d, K, ld, 0.0); (void)hipStreamSynchronize(ctx->stream); };
+  auto run_gram = [&](mln_ctx* c) {
+    GemmArgs g{};
+    g.A = K; g.lda = ld * (n / gram_rows); g.B = K; g.ldb = g.lda; g.C = G; g.ldc = ld;
+    g.M = m; g.N = m; g.K = gram_rows; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0; g.lower_only = 1; g.split_k = 1;
+    (void)launch_dgemm(c, g);
+    (void)hipStreamSynchronize(c->stream);
+  };
+  auto run_chol = [&](mln_ctx* c) {
+    (void)launch_kernel_matrix(c, cov, Xu, m, Xu, m, d, A, ld, 1.0);
+    (void)dev_cholesky_lower(c, A, m, ld);
+  };
+  run_k(); run_gram(ctx); run_chol(ctx);   // warm up
+  double t0 = wall_ms(); run_k(); out[0] = wall_ms() - t0;
+  t0 = wall_ms(); run_gram(&side); out[1] = wall_ms() - t0;
+  t0 = wall_ms(); { std::thread th([&]() { (void)hipSetDevice(ctx->device); run_gram(&side); }); run_k(); th.join(); } out[2] = wall_ms() - t0;
+  t0 = wall_ms(); run_chol(&side); out[3] = wall_ms() - t0;
+  t0 = wall_ms(); { std::thread th([&]() { (void)hipSetDevice(ctx->device); run_chol(&side); }); run_k(); th.join(); } out[4] = wall_ms() - t0;
+  t0 = wall_ms(); { std::thread th([&]() { (void)hipSetDevice(ctx->device); run_chol(&side); run_gram(&side); }); run_k(); th.join(); } out[5] = wall_ms() - t0;
+  (void)hipDeviceSynchronize();
+  if (side.scratch) (void)mln_dfree(side.scratch);
+  (void)mln_dfree(side.d_info);
+  (void)hipStreamDestroy(side.stream);
+  for (void* p : {(void*)X, (void*)Xu, (void*)K, (void*)G, (void*)A}) (void)mln_dfree(p);
+  return MLN_OK;
+}
