@@ -241,6 +241,9 @@ int launch_kernel_grad(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t
 int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c, int64_t m,
                             int d, const double* w, double* out) {
   if (n == 0) return MLN_OK;
+  // single stationary leaf and enough pairs: covariance-tile pass + GEMM on the matrix cores (cov_kernels.hip)
+  if (cov.n_toks == 1 && cov.leaves[0].kind != MLN_K_LINEAR && n * m >= (int64_t)1 << 16)
+    return launch_predict_gradient_gemm(ctx, cov, x, n, c, m, d, w, out);
   const size_t lds = sizeof(double) * ((size_t)2 * d * GR + (size_t)GC * d + GC + (size_t)MLN_MAX_LEAVES * GC);
   if (lds > 160 * 1024) { mln_set_error(ctx, "predict_gradient: too many dimensions for the LDS layout"); return MLN_ERR_UNSUPPORTED; }
   MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gradient),

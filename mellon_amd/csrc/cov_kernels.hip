@@ -47,6 +47,38 @@ __device__ __forceinline__ double leaf_value(const DevLeaf& lf, double xx, doubl
   }
 }
 
+// Radial factor g of d leaf(x, y)/dx = g * (x - y)|dims (stationary leaves), the exact derivative of what
+// leaf_value evaluates (denominator dist, 0 where the clamp of util.distance is active): the formulas of
+// cov.py k_grad (cov.py:84-97,186-199,283-296,380-393,481-496) with util.distance_grad's +1e-12 dropped.
+__device__ __forceinline__ double leaf_grad_coeff(const DevLeaf& lf, double xx, double yy, double xy) {
+  const double inv_ls = lf.alpha_inv_ls[1];
+  const double sq = xx - 2.0 * xy + yy + 1e-12;
+  const double dist = sqrt(fmax(sq, 0.0));
+  const double inv = (sq > 0.0) ? 1.0 / dist : 0.0;
+  switch (lf.kind) {
+    case MLN_K_MATERN32: {
+      const double f = 1.7320508075688772 * inv_ls, r = f * dist;
+      return -f * r * exp(-r) * inv;
+    }
+    case MLN_K_MATERN52: {
+      const double f = 2.23606797749979 * inv_ls, r = f * dist;
+      return -0.3333333333333333 * exp(-r) * r * (r + 1.0) * f * inv;
+    }
+    case MLN_K_EXPQUAD: {
+      const double r = dist * inv_ls;
+      return -r * inv_ls * exp(-0.5 * (r * r)) * inv;
+    }
+    case MLN_K_EXPONENTIAL: {
+      const double r = dist * inv_ls;
+      return -0.5 * inv_ls * exp(-0.5 * r) * inv;
+    }
+    default: {
+      const double r = dist * inv_ls, b = r * r / (2.0 * lf.alpha) + 1.0;
+      return -r * inv_ls * pow(b, -lf.alpha - 1.0) * inv;
+    }
+  }
+}
+
 // acc[i][j] = sum_k x[row0+ty*4+i][dims[k]] * y[col0+tx*4+j][dims[k]] over one leaf's active dims
 __device__ __forceinline__ void leaf_dot(const DevCov& cov, const DevLeaf& lf, const double* __restrict__ x,
                                          int64_t n, const double* __restrict__ y, int64_t m, int d,
@@ -90,7 +122,7 @@ __device__ __forceinline__ void leaf_dot(const DevCov& cov, const DevLeaf& lf, c
 }
 
 // Evaluates the whole covariance program for this thread's 4x4 outputs into val.
-template <bool SINGLE>
+template <bool SINGLE, bool GRADC = false>
 __device__ __forceinline__ void cov_tile(const DevCov& cov, const double* __restrict__ x, int64_t n,
                                          const double* __restrict__ y, int64_t m, int d,
                                          const double* __restrict__ xx, const double* __restrict__ yy,
@@ -133,7 +165,8 @@ __device__ __forceinline__ void cov_tile(const DevCov& cov, const double* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) val[i][j] = leaf_value(lf, xr[i], yr[j], acc[i][j]);
+          for (int j = 0; j < 4; ++j)
+            val[i][j] = GRADC ? leaf_grad_coeff(lf, xr[i], yr[j], acc[i][j]) : leaf_value(lf, xr[i], yr[j], acc[i][j]);
       }
       ++sp;
     } else {
@@ -242,6 +275,60 @@ __global__ __launch_bounds__(256) void k_kernel_matrix_mfma(DevCov cov, const do
       }
     }
   }
+}
+
+// ---- predictor gradient, single stationary leaf: grad_i = sum_j w_j g_ij (x_i - c_j)|dims -------------------
+//   Q (rows x m) = w_j g_ij                     one covariance-tile pass (this kernel)
+//   T = Q [C|dims , 1]                          one GEMM on the matrix cores
+//   grad_i[dims] = x_i[dims] T_i,last - T_i,k   (k_grad_combine)
+__global__ __launch_bounds__(256) void k_grad_coeff(DevCov cov, const double* __restrict__ x, int64_t n,
+                                                    const double* __restrict__ y, int64_t m, int d,
+                                                    const double* __restrict__ xx, const double* __restrict__ yy,
+                                                    const double* __restrict__ w, double* __restrict__ out,
+                                                    int64_t ldo, int64_t tiles_n) {
+  __shared__ double xs[DK][TM + PADT];
+  __shared__ double ys[DK][TN + PADT];
+  const int64_t bid = blockIdx.x;
+  const int64_t row0 = (bid / tiles_n) * TM, col0 = (bid % tiles_n) * TN;
+  double val[4][4];
+  cov_tile<true, true>(cov, x, n, y, m, d, xx, yy, row0, col0, xs, ys, val);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = row0 + ty * 4 + i;
+    if (r >= n) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = col0 + tx * 4 + j;
+      if (c < ldo) out[r * ldo + c] = (c < m) ? val[i][j] * w[c] : 0.0;
+    }
+  }
+}
+
+// Cext[j][k] = c_j[dims[k]] (k < nd), Cext[j][nd] = 1, zero up to ldc
+__global__ void k_grad_centres(DevCov cov, const double* __restrict__ c, int64_t m, int d, double* __restrict__ cext,
+                               int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * ldc) return;
+  const int64_t j = idx / ldc;
+  const int k = (int)(idx % ldc);
+  const DevLeaf lf = cov.leaves[0];
+  double v = 0.0;
+  if (k < lf.ndims) v = c[j * d + cov.dims[lf.dims_off + k]];
+  else if (k == lf.ndims) v = 1.0;
+  cext[idx] = v;
+}
+
+__global__ void k_grad_combine(DevCov cov, const double* __restrict__ T, int64_t ldt, const double* __restrict__ x,
+                               int64_t rows, int d, double* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * d) return;
+  out[idx] = 0.0;   // inactive dims
+  const int64_t i = idx / d;
+  const int dim = (int)(idx % d);
+  const DevLeaf lf = cov.leaves[0];
+  for (int k = 0; k < lf.ndims; ++k)
+    if (cov.dims[lf.dims_off + k] == dim) out[idx] = x[idx] * T[i * ldt + lf.ndims] - T[i * ldt + k];
 }
 
 // mean_i = mu + sum_j cov(x_i, y_j) w_j   (conditional.py:899-906); K never leaves registers.
@@ -528,4 +615,45 @@ int launch_row_sumsq(mln_ctx* ctx, const double* T, int64_t ld, int64_t rows, in
   hipLaunchKernelGGL(k_row_sumsq, dim3((unsigned)rows), dim3(256), 0, ctx->stream, T, ld, rows, cols, base, sign, out);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
+}
+
+
+// Fast predictor gradient for single stationary-leaf kernels (see k_grad_coeff): row chunks of 32768.
+int launch_predict_gradient_gemm(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,
+                                 int64_t m, int d, const double* w, double* out) {
+  if (n == 0) return MLN_OK;
+  const DevLeaf& lf = cov.leaves[0];
+  const int64_t ldq = ((m + 15) / 16) * 16, ldc = ((lf.ndims + 1 + 15) / 16) * 16;
+  const int64_t chunk = (n < 32768) ? n : 32768;
+  double *norms = nullptr, *Q = nullptr, *T = nullptr, *cext = nullptr;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)(n + m), (void**)&norms));
+  double* xx = norms;
+  double* yy = norms + n;
+  MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
+  MLN_TRY(sqnorms(ctx, cov, c, m, d, yy));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Q, sizeof(double) * (size_t)chunk * ldq));
+  MLN_HIP(ctx, mln_dmalloc((void**)&T, sizeof(double) * (size_t)chunk * ldc));
+  MLN_HIP(ctx, mln_dmalloc((void**)&cext, sizeof(double) * (size_t)m * ldc));
+  int rc = MLN_OK;
+  hipLaunchKernelGGL(k_grad_centres, dim3((unsigned)((m * ldc + 255) / 256)), dim3(256), 0, ctx->stream, cov, c, m, d,
+                     cext, ldc);
+  const int64_t tiles_n = (ldq + TN - 1) / TN;
+  for (int64_t r0 = 0; r0 < n && rc == MLN_OK; r0 += chunk) {
+    const int64_t rows = (n - r0 < chunk) ? (n - r0) : chunk;
+    const int64_t nblk = tiles_n * ((rows + TM - 1) / TM);
+    hipLaunchKernelGGL(k_grad_coeff, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x + r0 * d, rows, c, m, d,
+                       xx + r0, yy, w, Q, ldq, tiles_n);
+    GemmArgs g{};
+    g.A = Q; g.lda = ldq; g.ta = 0; g.B = cext; g.ldb = ldc; g.tb = 0; g.C = T; g.ldc = ldc;
+    g.M = rows; g.N = lf.ndims + 1; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.split_k = 1;
+    rc = launch_dgemm(ctx, g);
+    if (rc != MLN_OK) break;
+    hipLaunchKernelGGL(k_grad_combine, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, ctx->stream, cov, T, ldc,
+                       x + r0 * d, rows, d, out + r0 * d);
+  }
+  hipError_t e = hipGetLastError();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(Q); (void)mln_dfree(T); (void)mln_dfree(cext);
+  if (rc == MLN_OK && e != hipSuccess) rc = mln_hip_fail(ctx, e, "predict_gradient_gemm", __FILE__, __LINE__);
+  return rc;
 }

@@ -101,6 +101,8 @@ int launch_axpby(mln_ctx* ctx, int64_t n, double a, const double* x, double b, d
 // cov_grad.hip
 int launch_kernel_grad(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y, int64_t m,
                        int d, int exact_denominator, double* out);
+int launch_predict_gradient_gemm(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,
+                                 int64_t m, int d, const double* w, double* out);   // single stationary leaf
 int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c, int64_t m,
                             int d, const double* w, double* out);
 

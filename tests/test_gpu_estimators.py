@@ -403,6 +403,28 @@ def test_mixed_precision_warmup_reaches_the_same_optimum(mellon, monkeypatch):
     assert rel_max(out["1"], out["0"]) < 2e-6
 
 
+def test_c3_subsample_golden(mellon):
+    """SURVEY.md S8d parity gate "C3 subsample (n = 1e5)": 1e5 x 50 cells, 5000 landmarks, Matern52 against the
+    oracle's optimum (tests/golden/make_c3_subsample.py).  n m = 5e8 >= 2^27: the mixed-precision solve runs."""
+    path = os.path.join(GOLD, "c3_sub_density.npz")
+    if not os.path.exists(path):
+        pytest.skip("c3_sub_density.npz not generated")
+    g = np.load(path)
+    n, d, m, keep = int(g["n"]), int(g["dims"]), int(g["m"]), int(g["keep_every"])
+    x = mo.gaussian_mixture(n, d, seed=int(g["seed"]))
+    idx = np.sort(np.random.default_rng(int(g["landmark_seed"])).choice(n, m, replace=False))
+    from mellon_amd import _lib
+    nn = _lib.default_context().nn_distances(x)                      # exact 1-NN on the device
+    assert np.abs(nn[::keep] - g["nn_sub"]).max() < 1e-9 * g["nn_sub"].max()
+    est = mellon.DensityEstimator(landmarks=x[idx], nn_distances=nn)
+    dens = est.fit_predict(x)
+    assert abs(est.mu - float(g["mu"])) < 1e-9 and abs(est.ls - float(g["ls"])) < 1e-9 * float(g["ls"])
+    ref = g["log_density_sub"]
+    assert rel_std(dens[::keep], ref) < 1e-5 and rel_max(dens[::keep], ref) < 1e-5
+    assert est._fit.stage_times()["objective32_launches"] > 0
+    assert rel_max(est.predict(x[:2000]), dens[:2000]) < 1e-9
+
+
 def test_edge_cases(mellon):
     """Ragged / degenerate inputs the reference's validators and tests care about."""
     rng = np.random.default_rng(3)
