@@ -200,15 +200,16 @@ def main():
     per_launch32 = stats.get("objective32_kernel_s", 0.0) / max(n32, 1.0)
     bytes32 = stats["objective_bytes_per_launch"] / 2.0
     ach32 = bytes32 / per_launch32 / 1e9 if n32 > 0 else 0.0
-    traffic = None
+    traffic = traffic32 = None
     tfile = os.path.join(ROOT, "profiles", "objective_traffic.json")
     if os.path.exists(tfile):
         try:
             t = json.load(open(tfile))
             if t.get("n_local") == hi - lo and t.get("m") == m:
                 traffic = t.get("hbm_bytes_per_launch")
+                traffic32 = t.get("fp32_passes", {}).get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            traffic = traffic32 = None
     out = {
         "metric": "cells/sec fit_predict", "value": value, "unit": "cells/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -230,7 +231,7 @@ def main():
                      "share_of_step": stats["objective_kernel_s"] / (elapsed / args.steps) if world == 1 else None},
         "roofline_fp32_passes": {"bound": "hbm", "kernel": "k_objective32 (same pass over the fp32 copy of K: warm-up "
                                  "iterations of the MAP solve)", "achieved": ach32, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ach32 / HBM_PEAK_GBS, "traffic": None,
+                                 "frac": ach32 / HBM_PEAK_GBS, "traffic": traffic32,
                                  "algorithmic_bytes_per_launch": bytes32, "avg_launch_ms": 1e3 * per_launch32,
                                  "launches": int(n32)},
         "stages_s": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
