@@ -368,6 +368,64 @@ __global__ __launch_bounds__(256) void k_predict_mean1(DevCov cov, const double*
   }
 }
 
+// Fused predictive mean on the matrix cores (single leaf over all d columns, one output): the tile scheme of
+// k_kernel_matrix_mfma, but a wave keeps its 16 rows and walks ALL centre tiles, multiplying each covariance
+// value by its weight and summing along the row -- the n' x m matrix never exists (conditional.py:899-906).
+__global__ __launch_bounds__(256) void k_predict_mean_mfma(DevCov cov, const double* __restrict__ x, int64_t n,
+                                                           const double* __restrict__ y, int64_t m, int d,
+                                                           const double* __restrict__ xx,
+                                                           const double* __restrict__ yy,
+                                                           const double* __restrict__ w, double mu,
+                                                           double* __restrict__ out) {
+  const DevLeaf lf = cov.leaves[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * TM + wave * 16;
+  const int64_t ar = (row0 + li < n) ? row0 + li : n - 1;
+  const double* __restrict__ xa = x + ar * d;
+  double xr[4], part[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = row0 + lk + 4 * r;
+    xr[r] = (row < n) ? xx[row] : 0.0;
+    part[r] = 0.0;
+  }
+  for (int64_t col0 = 0; col0 < m; col0 += TN) {
+    const double* yb[4];
+    double yc[4], wc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t c = col0 + 16 * t + li;
+      const int64_t cc = (c < m) ? c : m - 1;
+      yb[t] = y + cc * d;
+      yc[t] = yy[cc];
+      wc[t] = (c < m) ? w[cc] : 0.0;
+    }
+    v4d_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < d; k0 += 4) {
+      const int k = k0 + lk;
+      const int kc = (k < d) ? k : d - 1;
+      const double mask = (k < d) ? 1.0 : 0.0;
+      const double a = xa[kc] * mask;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, yb[t][kc], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[r] = fma(leaf_value(lf, xr[r], yc[t], acc[t][r]), wc[t], part[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double s_ = part[r];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s_ += __shfl_xor(s_, off, 64);   // over the 16 columns (li) of a row
+    const int64_t row = row0 + lk + 4 * r;
+    if (li == 0 && row < n) out[row] = mu + s_;
+  }
+}
+
 // xx[leaf][i] = sum over the leaf's active dims of x_i^2   (util.py:362)
 __global__ void k_row_sqnorms(DevCov cov, const double* __restrict__ x, int64_t n, int d,
                               double* __restrict__ xx) {
@@ -577,7 +635,14 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   MLN_TRY(sqnorms(ctx, cov, y, m, d, yy));
   const int64_t nblk = (n + TM - 1) / TM;
   const bool single = (cov.n_toks == 1);
-  if (single)
+  bool contiguous = single && cov.leaves[0].ndims == d;
+  if (contiguous)
+    for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
+  static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
+  if (contiguous && !no_mfma && n * m >= 4096)
+    hipLaunchKernelGGL(k_predict_mean_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
+                       xx, yy, w, mu, out);
+  else if (single)
     hipLaunchKernelGGL(k_predict_mean1<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, w, mu, out);
   else
