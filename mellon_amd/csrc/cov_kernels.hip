@@ -523,6 +523,91 @@ __global__ __launch_bounds__(256) void k_nn_distances(const double* __restrict__
   }
 }
 
+// Exact 1-NN on the matrix cores (d <= 64): a workgroup of 8 waves owns 128 query rows, every wave keeps the
+// MFMA A operands of its 16 rows in registers for the whole pass and walks all tiles of 64 candidate rows,
+// which are staged through LDS once per workgroup (double-buffered, coalesced in, [row][k] with a
+// 68-double row stride out) and shared by the 8 waves.  Only xx - 2 x.y + yy and a running minimum per
+// element: the pass is bound by the fp64 matrix pipe (2 n m d flops).
+constexpr int NNS = 68;   // LDS row stride (doubles): = 4 mod 32, 16 rows x 4 k touch every bank pair twice
+
+__global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restrict__ x, int64_t n,
+                                                           const double* __restrict__ y, int64_t m, int d,
+                                                           const double* __restrict__ xx,
+                                                           const double* __restrict__ yy, int64_t self_offset,
+                                                           double* __restrict__ out) {
+  __shared__ double ys[2][TN * NNS];
+  __shared__ double yn[2][TN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
+  const int ksteps = (d + 3) / 4;
+  // A operands of this wave's 16 rows: a[ks] = x[row0 + li][4 ks + lk]
+  double a[16];
+  {
+    const int64_t ar = (row0 + li < n) ? row0 + li : n - 1;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = 4 * ks + lk;
+      a[ks] = (ks < ksteps && k < d) ? x[ar * d + k] : 0.0;
+    }
+  }
+  double xr[4], best[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = row0 + lk + 4 * r;
+    xr[r] = (row < n) ? xx[row] : 0.0;
+    best[r] = INFINITY;
+  }
+  for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;   // zero incl. the k padding
+  __syncthreads();
+  auto stage = [&](int buf, int64_t col0) {
+    const int cnt = TN * d;
+    for (int e = tid; e < cnt; e += 512) {
+      const int r = e / d, k = e - r * d;
+      ys[buf][r * NNS + k] = (col0 + r < m) ? y[(col0 + r) * d + k] : 0.0;
+    }
+    if (tid < TN) yn[buf][tid] = (col0 + tid < m) ? yy[col0 + tid] : 0.0;
+  };
+  stage(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t col0 = 0; col0 < m; col0 += TN, buf ^= 1) {
+    if (col0 + TN < m) stage(buf ^ 1, col0 + TN);
+    v4d_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = v4d_t{0.0, 0.0, 0.0, 0.0};
+    const double* yb = &ys[buf][li * NNS + lk];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks < ksteps) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], yb[16 * t * NNS + 4 * ks], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t c = col0 + 16 * t + li;
+      const double yc = yn[buf][16 * t + li];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + lk + 4 * r;
+        const double sq = fmax(xr[r] - 2.0 * acc[t][r] + yc, 0.0);
+        if (c < m && c != row + self_offset) best[r] = fmin(best[r], sq);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double s_ = best[r];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s_ = fmin(s_, __shfl_xor(s_, off, 64));
+    const int64_t row = row0 + lk + 4 * r;
+    if (li == 0 && row < n) out[row] = sqrt(s_);
+  }
+}
+
 __global__ void k_row_sqnorms_all(const double* __restrict__ x, int64_t n, int d, double* __restrict__ xx) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -661,8 +746,13 @@ int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* 
   double* yy = norms + n;
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, d, xx);
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, y, m, d, yy);
-  hipLaunchKernelGGL(k_nn_distances, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, ctx->stream, x, n, y, m, d,
-                     xx, yy, self_offset, out);
+  static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
+  if (d <= 64 && !no_mfma && n * m >= 4096)
+    hipLaunchKernelGGL(k_nn_distances_mfma, dim3((unsigned)((n + 127) / 128)), dim3(512), 0, ctx->stream, x, n, y, m, d,
+                       xx, yy, self_offset, out);
+  else
+    hipLaunchKernelGGL(k_nn_distances, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, ctx->stream, x, n, y, m, d,
+                       xx, yy, self_offset, out);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
