@@ -267,7 +267,7 @@ int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xne
                      double mu, double* out);
 
 /* ---- diagnostics: measured rooflines of this device and the GEMM kernel in isolation ----------
- *   mln_diag_peak   what = 0: fp64 MFMA issue peak (TFLOP/s); what = 1: HBM streaming read (GB/s)
+ *   mln_diag_peak   what = 0: fp64 MFMA issue peak (TFLOP/s); 1: HBM streaming read, 4: streaming write (GB/s)
  *   mln_diag_dgemm  milliseconds per call of C = op(A) op(B) (same arguments as the internal GEMM) */
 int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result);
 int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double*
 // of the 64 x 64 tile (4 accumulators); the sqrt/exp epilogue and the fp64 (+ optional fp32) stores run on
 // the accumulator layout D[row = lk + 4 reg][col = li].  Measured at 1e6 x 5000 x 50: 32 ms against 35 ms for
 // the LDS-tiled VALU kernel above (PMC: VALU ~50 % busy on ~130 instructions per element, matrix pipe 20 %);
-// staging the operands through LDS (38 ms) and hand-written sqrt/exp (no change) were tried and dropped.
+// staging the operands through LDS (38 ms), the persistent 128-row form of k_nn_distances_mfma (37 ms) and
+// hand-written sqrt/exp (no change) were tried and dropped: dot product, epilogue and stores each cost
+// ~10 ms and do not overlap within a wave.
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_kernel_matrix_mfma(DevCov cov, const double* __restrict__ x, int64_t n,

@@ -33,9 +33,13 @@ __global__ __launch_bounds__(512) void k_hbm_read(const d2* __restrict__ p, int6
   }
   if (s.x + s.y == 123.456) out[0] = s.x;
 }
+__global__ __launch_bounds__(512) void k_hbm_write(d2* __restrict__ p, int64_t n2, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = (d2){v, v + (double)i};
+}
 }  // namespace
 
-// what: 0 = fp64 MFMA peak (TFLOP/s), 1 = HBM streaming read (GB/s over `bytes`)
+// what: 0 = fp64 MFMA peak (TFLOP/s), 1 = HBM streaming read, 4 = HBM streaming write (GB/s over `bytes`)
 extern "C" int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result) {
   if (!ctx || !result) return MLN_ERR_ARG;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
@@ -63,10 +67,17 @@ extern "C" int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* 
     MLN_HIP(ctx, mln_dmalloc((void**)&buf, (size_t)bytes));
     MLN_HIP(ctx, hipMemsetAsync(buf, 0, (size_t)bytes, ctx->stream));
     const int grid = ctx->n_cu * 4;
-    hipLaunchKernelGGL(k_hbm_read, dim3(grid), dim3(512), 0, ctx->stream, (const d2*)buf, bytes / 16, out);
-    MLN_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(k_hbm_read, dim3(grid), dim3(512), 0, ctx->stream, (const d2*)buf, bytes / 16, out);
-    MLN_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    if (what == 4) {
+      hipLaunchKernelGGL(k_hbm_write, dim3(grid), dim3(512), 0, ctx->stream, (d2*)buf, bytes / 16, 1.0);
+      MLN_HIP(ctx, hipEventRecord(e0, ctx->stream));
+      hipLaunchKernelGGL(k_hbm_write, dim3(grid), dim3(512), 0, ctx->stream, (d2*)buf, bytes / 16, 2.0);
+      MLN_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    } else {
+      hipLaunchKernelGGL(k_hbm_read, dim3(grid), dim3(512), 0, ctx->stream, (const d2*)buf, bytes / 16, out);
+      MLN_HIP(ctx, hipEventRecord(e0, ctx->stream));
+      hipLaunchKernelGGL(k_hbm_read, dim3(grid), dim3(512), 0, ctx->stream, (const d2*)buf, bytes / 16, out);
+      MLN_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    }
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MLN_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     *result = (double)bytes / (ms * 1e-3) / 1e9;
