@@ -72,6 +72,16 @@ def _worker(rank, world, port, out_dir):
         assert abs(l_s - l_g) < 1e-9 * abs(l_g), (l_s, l_g)      # re-association of sums whose terms reach 1e3
         assert np.abs(g_s - g_g).max() < 1e-7 * max(np.abs(g_g).max(), 1.0), np.abs(g_s - g_g).max()
 
+    # sparse Nystroem (decomposition.py:213-266) shards the same way: the m x m Gram B^T B is all-reduced, its
+    # eigenpairs are replicated, and every rank projects its own rows  L_rows = B_rows U[:, -p:]
+    from mellon_amd.decomposition import _select_rank
+    Sg, Ug = np.linalg.eigh(comm.allreduce_sum(Ls.T @ Ls))
+    p = _select_rank(Sg, 0.99)
+    ref_nys = mo.modified_low_rank(x, cov, lm, rank=0.99)
+    assert ref_nys.shape[1] == p
+    rows = Ls @ Ug[:, -p:]
+    assert np.abs(rows @ rows.T - ref_nys[lo:hi] @ ref_nys[lo:hi].T).max() < 1e-9 * np.abs(ref_nys @ ref_nys.T).max()
+
     Ls = Ls_own                                             # the real thing: every rank factors its own cells
     res = mo.minimize_lbfgsb(sharded, z0, mo.LBFGSB_TIGHT)  # every rank runs the same host optimiser
     dens = comm.allgather_rows(Ls @ res.pre_transformation + mu)
