@@ -145,6 +145,94 @@ __global__ __launch_bounds__(256) void k_assign(const double* __restrict__ x, in
   }
 }
 
+// The same assignment on the matrix cores (d <= 64), in the form of k_nn_distances_mfma (cov_kernels.hip):
+// 8 waves x 16 cells per workgroup keep their MFMA A operands in registers; centre tiles of 64 are staged
+// through LDS once per workgroup (double-buffered); running (min, argmin) per accumulator element.
+typedef double v4d_k __attribute__((ext_vector_type(4)));
+constexpr int KAS = 68;
+
+__global__ __launch_bounds__(512) void k_assign_mfma(const double* __restrict__ x, int64_t n,
+                                                     const double* __restrict__ c, int64_t m, int d,
+                                                     const double* __restrict__ xx, const double* __restrict__ cc,
+                                                     int* __restrict__ label, double* __restrict__ dist2) {
+  __shared__ double ys[2][TN * KAS];
+  __shared__ double yn[2][TN];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
+  const int ksteps = (d + 3) / 4;
+  double a[16];
+  {
+    const int64_t ar = (row0 + li < n) ? row0 + li : n - 1;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = 4 * ks + lk;
+      a[ks] = (ks < ksteps && k < d) ? x[ar * d + k] : 0.0;
+    }
+  }
+  double xr[4], best[4];
+  int bidx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = row0 + lk + 4 * r;
+    xr[r] = (row < n) ? xx[row] : 0.0;
+    best[r] = INFINITY;
+    bidx[r] = 0;
+  }
+  for (int e = tid; e < 2 * TN * KAS; e += 512) (&ys[0][0])[e] = 0.0;
+  __syncthreads();
+  auto stage = [&](int buf, int64_t col0) {
+    const int cnt = TN * d;
+    for (int e = tid; e < cnt; e += 512) {
+      const int r = e / d, k = e - r * d;
+      ys[buf][r * KAS + k] = (col0 + r < m) ? c[(col0 + r) * d + k] : 0.0;
+    }
+    if (tid < TN) yn[buf][tid] = (col0 + tid < m) ? cc[col0 + tid] : 0.0;
+  };
+  stage(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t col0 = 0; col0 < m; col0 += TN, buf ^= 1) {
+    if (col0 + TN < m) stage(buf ^ 1, col0 + TN);
+    v4d_k acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = v4d_k{0.0, 0.0, 0.0, 0.0};
+    const double* yb = &ys[buf][li * KAS + lk];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      if (ks < ksteps) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], yb[16 * t * KAS + 4 * ks], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {   // ascending column order: strict < keeps the smallest index on ties
+      const int64_t cj = col0 + 16 * t + li;
+      const double cn = yn[buf][16 * t + li];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double sq = xr[r] - 2.0 * acc[t][r] + cn;
+        if (cj < m && sq < best[r]) { best[r] = sq; bidx[r] = (int)cj; }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double s_ = best[r];
+    int bi = bidx[r];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      const double so = __shfl_xor(s_, off, 64);
+      const int io = __shfl_xor(bi, off, 64);
+      if (so < s_ || (so == s_ && io < bi)) { s_ = so; bi = io; }
+    }
+    const int64_t row = row0 + lk + 4 * r;
+    if (li == 0 && row < n) { label[row] = bi; dist2[row] = fmax(s_, 0.0); }
+  }
+}
+
 __global__ void k_accumulate(const double* __restrict__ x, int64_t n, int d, const int* __restrict__ label,
                              double* __restrict__ sums, double* __restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;
@@ -259,7 +347,10 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dx, n, d, xx);
   for (; it < max_iter && rc == MLN_OK; ++it) {
     hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);
-    hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
+    if (d <= 64 && n * m >= 4096)
+      hipLaunchKernelGGL(k_assign_mfma, dim3((unsigned)((n + 127) / 128)), dim3(512), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
+    else
+      hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
     chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
     chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
     chk(hipMemsetAsync(shift, 0, sizeof(double), st));
@@ -272,7 +363,10 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   }
   if (rc == MLN_OK && inertia_out) {   // sum of squared distances to the closest final centre
     hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);
-    hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
+    if (d <= 64 && n * m >= 4096)
+      hipLaunchKernelGGL(k_assign_mfma, dim3((unsigned)((n + 127) / 128)), dim3(512), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
+    else
+      hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, st, dx, n, dc, m, d, xx, cc, label, mind);
     std::vector<double> hm((size_t)n);
     chk(hipMemcpyAsync(hm.data(), mind, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
     chk(hipStreamSynchronize(st));
