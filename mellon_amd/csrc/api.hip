@@ -1075,6 +1075,7 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
     ObjArgs a = obj_args(f);
     a.weights = dt.dev;
     a.part_loss = nullptr;
+    a.L32 = f->L32;   // the Ridge solution only seeds the solve: its right-hand side may come from the fp32 copy
     MLN_TRY(launch_objective(ctx, a));
     MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
     MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));

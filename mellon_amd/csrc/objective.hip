@@ -188,11 +188,26 @@ __device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t l
   }
 }
 
-template <int CQ, int R>
+template <int CQ, int R, bool GEMVT>
 __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                                const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
                                                double& loss, double (*red)[8][R]) {
   double coef[R], dot[R];
+  if (GEMVT) {   // grad_j = sum_i weights_i L_ij  (Ridge right-hand side): no row dots, no barrier
+#pragma unroll
+    for (int r = 0; r < R; ++r) coef[r] = (row + r < row_end) ? a.weights[row + r] : 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        g[c][0] = fma(coef[r], (double)v[r][c].x, g[c][0]);
+        g[c][1] = fma(coef[r], (double)v[r][c].y, g[c][1]);
+        g[c][2] = fma(coef[r], (double)v[r][c].z, g[c][2]);
+        g[c][3] = fma(coef[r], (double)v[r][c].w, g[c][3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
@@ -237,7 +252,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
   }
 }
 
-template <int CQ, int R>
+template <int CQ, int R, bool GEMVT = false>
 __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
   __shared__ double red[2][8][R];
   const int tid = threadIdx.x;
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t col = 4 * ((int64_t)c * WG + tid) + e;
-      z[c][e] = (col < a.m) ? a.z[col] : 0.0;
+      z[c][e] = (!GEMVT && col < a.m) ? a.z[col] : 0.0;
       g[c][e] = 0.0;
     }
   double loss = 0.0;
@@ -263,9 +278,9 @@ __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
   if (s_beg < s_end) load_rows32<CQ, R>(L4, ld4, s_beg * R, a.n, tid, va);
   for (int64_t s = s_beg; s < s_end; s += 2) {   // unconditional loads: see k_objective
     load_rows32<CQ, R>(L4, ld4, ((s + 1 < s_end) ? s + 1 : s_last) * R, a.n, tid, vb);
-    process_rows32<CQ, R>(a, s * R, a.n, tid, 0, va, z, g, loss, red);
+    process_rows32<CQ, R, GEMVT>(a, s * R, a.n, tid, 0, va, z, g, loss, red);
     load_rows32<CQ, R>(L4, ld4, ((s + 2 < s_end) ? s + 2 : s_last) * R, a.n, tid, va);
-    if (s + 1 < s_end) process_rows32<CQ, R>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red);
+    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red);
   }
   double* pg = a.part_grad + (int64_t)blockIdx.x * a.m_pad;
 #pragma unroll
@@ -281,7 +296,8 @@ __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
 
 template <int CQ, int R>
 int launch_f32(mln_ctx* ctx, const ObjArgs& a) {
-  hipLaunchKernelGGL((k_objective32<CQ, R>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
+  if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_objective32<CQ, R, false>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -384,7 +400,7 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   if (a.weights) mode = MODE_GEMVT;
   else if (a.f_out) mode = MODE_FONLY;
   else if (a.part_hess) mode = MODE_OBJ_HESS;
-  if (a.L32 && mode == MODE_OBJ && a.ldl % 4 == 0) {   // fp32 copy: 4 columns per 16-byte lane load
+  if (a.L32 && (mode == MODE_OBJ || mode == MODE_GEMVT) && a.ldl % 4 == 0) {   // fp32 copy: 4 columns per 16-byte lane load
     const int cq = (int)((a.ldl / 4 + WG - 1) / WG);
     switch (cq) {
       case 1: return launch_f32<1, 8>(ctx, a);
