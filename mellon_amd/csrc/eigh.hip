@@ -52,8 +52,11 @@ __device__ __forceinline__ void circle_pair(int n_players, int round, int slot, 
   else { *a = (round + slot) % n1; *b = (round - slot + n1) % n1; }
 }
 
-__global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
-  __shared__ double part[4][ER][SP];
+constexpr int JW = 8;            // waves per block pair (phases 1 and 3 split the columns over them)
+constexpr int JT = 64 * JW;
+
+__global__ __launch_bounds__(JT) void k_jacobi_round(JacArgs a) {
+  __shared__ double part[JW][ER][SP];
   __shared__ double S[ER][SP];
   __shared__ double Q[ER][SP];
   __shared__ double rot_c[EB], rot_s[EB];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
       for (int j = 0; j < 2; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
     const double* r0 = a.Y + grow(li) * a.ld;
     const double* r1 = have_j ? a.Y + grow(EB + li) * a.ld : r0;
-    for (int64_t k0 = (int64_t)wave * 16; k0 < a.mp; k0 += 64) {
+    for (int64_t k0 = (int64_t)wave * 16; k0 < a.mp; k0 += 16 * JW) {
       const int64_t k = k0 + 4 * lk;
       double x[2][4], v[2][4];
       const d2v xa = *reinterpret_cast<const d2v*>(r0 + k), xb = *reinterpret_cast<const d2v*>(r0 + k + 2);
@@ -116,10 +119,11 @@ __global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
         for (int r = 0; r < 4; ++r) part[wave][i * EB + lk + 4 * r][j * EB + li] = acc[i][j][r];
   }
   __syncthreads();
-  for (int idx = t; idx < ER * ER; idx += 256) {
+  for (int idx = t; idx < ER * ER; idx += JT) {
     const int r = idx >> 5, c = idx & 31;
-    const double s_rc = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
-    const double s_cr = (part[0][c][r] + part[1][c][r]) + (part[2][c][r] + part[3][c][r]);
+    double s_rc = 0.0, s_cr = 0.0;
+#pragma unroll
+    for (int w = 0; w < JW; ++w) { s_rc += part[w][r][c]; s_cr += part[w][c][r]; }
     S[r][c] = 0.5 * (s_rc + s_cr);
     Q[r][c] = (r == c) ? 1.0 : 0.0;
   }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
   // ---- 2. local symmetric Jacobi: Q^T S Q -> diagonal ----------------------------------------------
   for (int sweep = 0; sweep < a.max_local; ++sweep) {
     int mine = 0;
-    for (int idx = t; idx < ER * ER; idx += 256) {
+    for (int idx = t; idx < ER * ER; idx += JT) {
       const int r = idx >> 5, c = idx & 31;
       if (r < c && fabs(S[r][c]) > a.tol) mine = 1;
     }
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
       __syncthreads();
       // columns: S <- S J, Q <- Q J
 #pragma unroll
-      for (int it = t; it < ER * EB; it += 256) {
+      for (int it = t; it < ER * EB; it += JT) {
         const int i = it & 31, l = it >> 5;
         const double c = rot_c[l], s = rot_s[l];
         if (s != 0.0) {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
       __syncthreads();
       // rows: S <- J^T S
 #pragma unroll
-      for (int it = t; it < ER * EB; it += 256) {
+      for (int it = t; it < ER * EB; it += JT) {
         const int j = it & 31, l = it >> 5;
         const double c = rot_c[l], s = rot_s[l];
         if (s != 0.0) {
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void k_jacobi_round(JacArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qa[mt][ks] = Q[ks * 4 + lk][mt * EB + li];
   const int n_ks = have_j ? 8 : 4;
-  for (int64_t c0 = (int64_t)wave * 16; c0 < a.ld; c0 += 64) {
+  for (int64_t c0 = (int64_t)wave * 16; c0 < a.ld; c0 += 16 * JW) {
     double b[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) b[ks] = (ks < n_ks) ? a.Y[grow(ks * 4 + lk) * a.ld + c0 + li] : 0.0;
@@ -345,7 +349,7 @@ int dev_eigh(mln_ctx* ctx, const double* A, int64_t m, int64_t lda, double* w_ho
     }
     for (int r = 0; r < rounds; ++r) {
       a.round = r;
-      hipLaunchKernelGGL(k_jacobi_round, dim3((unsigned)(nbp / 2 > 0 ? nbp / 2 : 1)), dim3(256), 0, ctx->stream, a);
+      hipLaunchKernelGGL(k_jacobi_round, dim3((unsigned)(nbp / 2 > 0 ? nbp / 2 : 1)), dim3(JT), 0, ctx->stream, a);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return fail2(e, "k_jacobi_round");
