@@ -665,8 +665,13 @@ class Predictor:
         (error ~ h^4 |f^(5)|), independent of any analytic rule -- so it checks the rules."""
         Xnew = ensure_2d(np.asarray(Xnew, dtype=np.float64))
         n, d = Xnew.shape
-        scale = np.maximum(np.abs(Xnew).max(), 1.0)
-        h = 1e-3 * scale if h is None else h
+        if h is None:       # a step well inside the shortest length scale of the kernel (and of the data range)
+            def _min_ls(c):
+                if hasattr(c, "left"):
+                    r = _min_ls(c.right) if callable(c.right) else np.inf
+                    return min(_min_ls(c.left), r)
+                return float(getattr(c, "ls", np.inf))
+            h = 1e-3 * min(np.maximum(np.abs(Xnew).max(), 1.0), _min_ls(self.cov_func))
         out = np.empty((n, d))
         for k in range(d):
             e = np.zeros(d)
