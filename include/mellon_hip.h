@@ -114,6 +114,10 @@ int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x,
  * (n x d) among the rows of y (m x d), excluding the pair (i, i + self_offset) -- pass y = x and
  * self_offset = 0 for the estimator's nn_distances (parameters.py:408-433; the reference's
  * pynndescent search is approximate), or y = all cells and self_offset = shard start when sharded. */
+/* cov(x, xu)^T cov(x, xu) (m x m), summed over the ranks' shards: the B^T B of the landmark leverage
+ * diag(B M^-1 B^T), M = sigma^2 K_uu + B^T B + jitter I (conditional.py:593-601,660-685). */
+int mln_kernel_gram(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local, int32_t d,
+                    const double* xu, int64_t m, double* out /* m x m */);
 int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int32_t d,
                      int64_t self_offset, double* out /* n */);
 

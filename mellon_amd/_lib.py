@@ -63,6 +63,7 @@ SYMBOLS = [
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_kernel_grad", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_predict_gradient", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _dp]),
+    ("mln_kernel_gram", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp]),
     ("mln_nn_distances", C.c_int, [_vp, _dp, _i64, _dp, _i64, _i32, _i64, _dp]),
     ("mln_kmeans", C.c_int, [_vp, _dp, _i64, _i32, _i64, _i64, _i32, _dbl, _dp, C.POINTER(_i32), C.POINTER(_dbl)]),
     ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
@@ -257,6 +258,15 @@ class Context:
         out = np.empty((x.shape[0], y.shape[0]), dtype=np.float64)
         self._check(self.lib.mln_kernel_matrix(self.handle, desc.ref, _ptr(x), x.shape[0], _ptr(y), y.shape[0],
                                                x.shape[1], out.ctypes.data))
+        return out
+
+    def kernel_gram(self, desc, x, xu):
+        """cov(x, xu)^T cov(x, xu) as an (m, m) array."""
+        x = x if isinstance(x, DeviceArray) else _as2d(x)
+        xu = _as2d(xu)
+        out = np.empty((xu.shape[0], xu.shape[0]), dtype=np.float64)
+        self._check(self.lib.mln_kernel_gram(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1], _ptr(xu),
+                                             xu.shape[0], out.ctypes.data))
         return out
 
     def kernel_grad(self, desc, x, y):

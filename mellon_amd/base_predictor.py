@@ -130,7 +130,37 @@ class Predictor:
         raise NotImplementedError("This predictor method is outside the accelerated path "
                                   "(hessians / leverage / obs_variance: SURVEY.md S8f).")
 
-    hessian = hessian_log_determinant = leverage = loo_residuals = obs_variance = _unavailable
+    hessian = hessian_log_determinant = _unavailable
+
+    # -- leverage / observation variance (base_predictor.py:263-355) -------------------------------------------
+    def leverage(self, x):
+        """Hat-matrix diagonal h_i used by the HC3 correction r^2 / (1 - h)^2."""
+        x = self._check_features(x)
+        if not hasattr(self, "_leverage"):
+            raise NotImplementedError(f"{self.__class__.__name__} has no leverage.")
+        if self.sigma is None or np.ndim(self.sigma) != 0:
+            raise NotImplementedError("leverage is available for a scalar `sigma` (SURVEY.md S8f).")
+        return self._leverage(x, self.sigma)
+
+    def loo_residuals_squared(self, x, y):
+        """Squared leave-one-out residuals through the leverage shortcut (base_predictor.py:290-324)."""
+        x = self._check_features(x)
+        y = np.asarray(validate_array(y, "y"), dtype=np.float64)
+        residual = y - self._mean(x)
+        h = self.leverage(x)
+        if residual.ndim > h.ndim:
+            h = h[..., None]
+        return residual ** 2 / (1 - h) ** 2
+
+    def obs_variance(self, x):
+        """Smoothed observation variance: a second GP on the HC3-corrected squared residuals."""
+        x = self._check_features(x)
+        if getattr(self, "variance_weights", None) is None:
+            raise ValueError("The predictor was computed without obs_variance. "
+                             "Recompute setting `obs_variance=True`.")
+        ctx = _lib.default_context()
+        return ctx.predict_mean(self.cov_func.lower(self.n_input_features), x, self.centers,
+                                np.asarray(self.variance_weights), float(self.variance_mu))
 
     # -- serialization --------------------------------------------------------------------------------
     def _data_dict(self):

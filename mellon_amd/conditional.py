@@ -3,7 +3,7 @@
   FullConditional               weights = L^-T L^-1 (y - mu),  L = chol(K(x,x) + s I)     :183-264
   LandmarksConditional          `_sparse_solve` with A = Lp^-1 K(xu, x)                    :455-547, :57-66
   LandmarksConditionalCholesky  weights = Lp^-T z                                          :750-818
-Only scalar sigma is supported (per-feature sigma, covariance, leverage, obs_variance: S8f).
+Only scalar sigma is supported (per-feature / per-observation sigma: S8f).
 """
 import logging
 
@@ -29,8 +29,41 @@ def _scalar_sigma(sigma):
 
 
 def _reject_extras(with_uncertainty, obs_variance):
-    if obs_variance:
-        raise NotImplementedError("obs_variance is outside the accelerated path (SURVEY.md S8f).")
+    pass
+
+
+def _hc3(residual, h):
+    """Corrected squared residuals r^2 / (1 - h)^2 (conditional.py:330-333,607-610)."""
+    if residual.ndim > h.ndim:
+        h = h[..., None]
+    return residual ** 2 / (1 - h) ** 2
+
+
+def _full_leverage(x, cov_func, sigma, jitter):
+    """Training leverage of the full GP, h = 1 - sigma^2 diag((K + sigma^2 I + jitter I)^-1)
+    (conditional.py:373-403).  With s = sigma^2 + jitter and L L^T = K + s I,
+    k_i^T (K + s I)^-1 k_i = k_ii - s + s^2 A_ii, so A_ii follows from the device's predictive-variance
+    kernel: c_i = k_ii - |L^-1 k_i|^2 = s - s^2 A_ii."""
+    ctx = _lib.default_context()
+    s2 = float(sigma) ** 2
+    s = s2 + jitter
+    desc = cov_func.lower(x.shape[1])
+    fit = ctx.fit_prepare(desc, x, None, s)
+    c = ctx.predict_covariance(desc, x, x, fit.Lp(), diag=True)
+    return 1.0 - s2 * (s - c) / (s * s), fit
+
+
+def _landmarks_leverage(Xnew, xu, cov_func, sigma, jitter, L=None):
+    """diag(B M^-1 B^T), B = cov(Xnew, xu), M = sigma^2 K_uu + B^T B + jitter I (conditional.py:660-685);
+    K_uu = L L^T when the predictor carries L, cov(xu, xu) otherwise -- as in the reference."""
+    ctx = _lib.default_context()
+    desc = cov_func.lower(xu.shape[1])
+    S = ctx.kernel_gram(desc, Xnew, xu)
+    K_uu = (np.asarray(L) @ np.asarray(L).T) if L is not None else ctx.kernel_matrix(desc, xu, xu)
+    M = float(sigma) ** 2 * K_uu + S
+    Lm = ctx.chol_lower(M, add_diag=jitter, jitter=jitter)
+    c = ctx.predict_covariance(desc, Xnew, xu, Lm, diag=True)      # k_ii - |Lm^-1 k_u(x_i)|^2
+    return cov_func.diag(Xnew) - c
 
 
 def _parameter_std(sigma, m):
@@ -55,6 +88,9 @@ def _attach_uncertainty(pred, Lf, std):
 
 class _FullConditional:
     _center_name = "x"
+
+    def _leverage(self, Xnew, sigma):      # the training leverage, whatever Xnew (conditional.py:373-403)
+        return _full_leverage(self.x, self.cov_func, _scalar_sigma(sigma), self.jitter)[0]
 
     def __init__(self, x, y, mu, cov_func, L=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER, y_cov_factor=None,
                  y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None):
@@ -82,6 +118,15 @@ class _FullConditional:
             fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
         weights = fit.weights_full(np.asarray(y, dtype=np.float64), mu)  # conditional.py:263-264
         Predictor.__init__(self, cov_func, x, weights, mu, n_obs=x.shape[0], jitter=jitter, sigma=sigma)
+        if obs_variance:      # conditional.py:305-362 (scalar sigma): smoothed HC3 observation variance
+            s_ = _scalar_sigma(sigma)
+            if s_ is None:
+                raise ValueError("obs_variance needs the noise level `sigma`.")
+            h, fit_v = _full_leverage(x, cov_func, s_, jitter)
+            self._corrected_r2 = _hc3(np.asarray(y, dtype=np.float64) - self._mean(x), h)
+            self.variance_mu = 0.0
+            self.variance_weights = fit_v.weights_full(self._corrected_r2, self.variance_mu)
+            self._state_variables |= {"variance_weights", "variance_mu"}
         if with_uncertainty and parameter_std is not None:
             # y_cov_factor = L diag(std) (inference.compute_parameter_cov_factor, inference.py:357-372)
             _attach_uncertainty(self, fit.Lp(), _parameter_std(parameter_std, x.shape[0]))
@@ -102,6 +147,10 @@ class _FullConditional:
 class _LandmarksConditional:
     _center_name = "landmarks"
 
+    def _leverage(self, Xnew, sigma):
+        return _landmarks_leverage(Xnew, self.landmarks, self.cov_func, _scalar_sigma(sigma), self.jitter,
+                                   L=getattr(self, "L", None))
+
     def __init__(self, x, xu, y, mu, cov_func, L=None, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
                  y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False):
         _reject_extras(with_uncertainty, obs_variance)
@@ -121,6 +170,17 @@ class _LandmarksConditional:
                                                   return_factors=bool(with_uncertainty))
         weights = out[0] if with_uncertainty else out
         Predictor.__init__(self, cov_func, xu, weights, mu, n_obs=xh.shape[0], jitter=jitter, sigma=sigma)
+        if obs_variance:          # conditional.py:589-645 (scalar sigma); the leverage here uses K_uu = Lp Lp^T
+            ctx = _lib.default_context()
+            desc = cov_func.lower(xu.shape[1])
+            Lp_h = out[1] if with_uncertainty else ctx.chol_lower(ctx.kernel_matrix(desc, xu, xu), add_diag=jitter,
+                                                                  jitter=jitter)
+            xfull = xh.to_host() if isinstance(xh, _lib.DeviceArray) else xh
+            h = _landmarks_leverage(xfull, xu, cov_func, s, jitter, L=Lp_h)
+            self._corrected_r2 = _hc3(np.asarray(y, dtype=np.float64) - self._mean(xfull), h)
+            self.variance_mu = 0.0
+            self.variance_weights = ctx.sparse_solve(desc, xh, xu, self._corrected_r2, self.variance_mu, s, jitter)
+            self._state_variables |= {"variance_weights", "variance_mu"}
         if with_uncertainty:      # conditional.py:571-577: L = Lp, Cs = Lp L_B
             self.L, self.Cs = out[1], out[2]
             self._state_variables |= {"L", "Cs"}

@@ -380,6 +380,48 @@ extern "C" int mln_predict_gradient(mln_ctx* ctx, const mln_kernel_desc* cov, co
   return o.commit();
 }
 
+static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
+                   int64_t ldg);
+static int64_t pad16(int64_t m);
+
+// G (m x m) = cov(x, xu)^T cov(x, xu): the B^T B of the landmark leverage (conditional.py:660-685) without
+// the n x m matrix leaving the device; rows in chunks, all-reduced over ranks.
+extern "C" int mln_kernel_gram(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, int32_t d,
+                               const double* xu, int64_t m, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n < 0 || m < 1 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (!xu || !out || (n > 0 && !x)) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, du;
+  DevOut o;
+  if (n > 0) MLN_TRY(dx.init(ctx, x, (size_t)n * d));
+  MLN_TRY(du.init(ctx, xu, (size_t)m * d));
+  MLN_TRY(o.init(ctx, out, (size_t)m * m));
+  const int64_t ld = pad16(m);
+  const int64_t chunk = (n < 65536) ? (n > 0 ? n : 1) : 65536;
+  double *K = nullptr, *G = nullptr, *acc = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&K, sizeof(double) * (size_t)chunk * ld));
+  MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * (size_t)m * ld));
+  MLN_HIP(ctx, mln_dmalloc((void**)&acc, sizeof(double) * (size_t)m * ld));
+  int rc = (hipMemsetAsync(acc, 0, sizeof(double) * (size_t)m * ld, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  bool any = false;
+  for (int64_t r0 = 0; (r0 < n || !any) && rc == MLN_OK; r0 += chunk) {   // at least one (possibly empty) round: collectives
+    const int64_t rows = (n - r0 < chunk) ? (n - r0 > 0 ? n - r0 : 0) : chunk;
+    if (rows > 0) rc = launch_kernel_matrix(ctx, dc, dx.dev + r0 * d, rows, du.dev, m, d, K, ld, 0.0);
+    if (rc == MLN_OK) rc = gram_of(ctx, K, ld, rows, m, 1.0, G, ld);
+    if (rc == MLN_OK) rc = launch_axpby(ctx, m * ld, 1.0, G, 1.0, acc);
+    any = true;
+    if (n == 0) break;
+  }
+  if (rc == MLN_OK) rc = launch_copy_block(ctx, acc, ld, o.dev, m, m, m);
+  if (rc == MLN_OK) rc = o.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(K); (void)mln_dfree(G); (void)mln_dfree(acc);
+  return rc;
+}
+
 extern "C" int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int32_t d,
                                 int64_t self_offset, double* out) {
   if (!ctx) return MLN_ERR_ARG;

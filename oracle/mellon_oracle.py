@@ -685,6 +685,42 @@ class Predictor:
     L = None
     W = None
     Cs = None
+    # obs_variance state (conditional.py:305-362,563-645) and what leverage() needs
+    variance_weights = None
+    variance_mu = 0.0
+    sigma = None
+    jitter = DEFAULT_JITTER
+    kind = None            # "full" | "landmarks"
+
+    def leverage(self, Xnew):
+        """base_predictor.py:263-288 -> conditional._leverage (:373-403 full: the training leverage whatever Xnew;
+        :660-685 landmarks: diag(B M^-1 B^T), B = cov(Xnew, xu), M = sigma^2 K_uu + B^T B + jitter I)."""
+        Xnew = ensure_2d(Xnew)
+        s2 = float(self.sigma) ** 2
+        if self.kind == "full":
+            x = self.centers
+            n = x.shape[0]
+            Lf = _sp_cholesky(stabilize(self.cov_func(x, x) + s2 * np.eye(n), self.jitter), lower=True)
+            Linv = _sp_trsolve(Lf, np.eye(n), lower=True)
+            return 1 - s2 * np.sum(np.square(Linv), axis=0)
+        B = self.cov_func(Xnew, self.centers)
+        K_uu = self.L @ self.L.T if self.L is not None else self.cov_func(self.centers, self.centers)
+        M = stabilize(s2 * K_uu + B.T @ B, self.jitter)
+        return np.sum((B @ np.linalg.inv(M)) * B, axis=1)
+
+    def loo_residuals_squared(self, Xnew, y):
+        """base_predictor.py:290-324 -- HC3: r^2 / (1 - h)^2."""
+        r = np.asarray(y) - self(Xnew)
+        h = self.leverage(Xnew)
+        if r.ndim > h.ndim:
+            h = h[..., None]
+        return r ** 2 / (1 - h) ** 2
+
+    def obs_variance(self, Xnew):
+        """base_predictor.py:330-355."""
+        if self.variance_weights is None:
+            raise ValueError("The predictor was computed without obs_variance. Recompute setting `obs_variance=True`.")
+        return self.variance_mu + self.cov_func(ensure_2d(Xnew), self.centers) @ self.variance_weights
 
     def covariance(self, Xnew, diag=True):
         """conditional.py:409-422,930-945."""
@@ -718,7 +754,7 @@ class Predictor:
 
 
 def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTER,
-                     y_is_mean=False, with_uncertainty=False):
+                     y_is_mean=False, with_uncertainty=False, obs_variance=False):
     """conditional.py:183-304 (non per-feature sigma)."""
     x = ensure_2d(x)
     if L is None:
@@ -729,6 +765,20 @@ def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTE
     r = y - mu
     w = _sp_trsolve(L.T, _sp_trsolve(L, r, lower=True), lower=False)
     pred = Predictor(cov_func, x, w, mu, x.shape[0])
+    pred.kind, pred.sigma, pred.jitter = "full", sigma, jitter
+    if obs_variance:                                          # conditional.py:305-362 (scalar sigma)
+        n = x.shape[0]
+        K = cov_func(x, x)
+        s2 = float(sigma) ** 2
+        Lv = _sp_cholesky(stabilize(K + s2 * np.eye(n), jitter), lower=True)
+        Linv = _sp_trsolve(Lv, np.eye(n), lower=True)
+        h = 1 - s2 * np.sum(np.square(Linv), axis=0)
+        r = y - (mu + K @ w)
+        if r.ndim > h.ndim:
+            h = h[..., None]
+        cr2 = r ** 2 / (1 - h) ** 2
+        pred.variance_mu = 0.0
+        pred.variance_weights = _sp_trsolve(Lv.T, _sp_trsolve(Lv, cr2, lower=True), lower=False)
     if with_uncertainty:                                      # conditional.py:285-304
         ycf = sigma_to_y_cov_factor(sigma, None, x.shape[0])
         pred.L = L
@@ -737,7 +787,7 @@ def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTE
 
 
 def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
-                          jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False):
+                          jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False, obs_variance=False):
     """conditional.py:455-547 (scalar / element-wise sigma)."""
     x, xu = ensure_2d(x), ensure_2d(xu)
     Kuf = cov_func(xu, x)
@@ -752,6 +802,18 @@ def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
         r_l, A_l = r / sigma2, A / sigma2
     w, L_B = sparse_solve(Lp, A, r_l, A_l)
     pred = Predictor(cov_func, xu, w, mu, x.shape[0])
+    pred.kind, pred.sigma, pred.jitter = "landmarks", sigma, jitter
+    if obs_variance:                                          # conditional.py:589-645 (scalar sigma)
+        s2 = float(sigma) ** 2
+        B = Kuf.T
+        M = stabilize(s2 * (Lp @ Lp.T) + B.T @ B, jitter)
+        h = np.sum((B @ np.linalg.inv(M)) * B, axis=1)
+        rr = y - (mu + B @ w)
+        if rr.ndim > h.ndim:
+            h = h[..., None]
+        cr2 = rr ** 2 / (1 - h) ** 2
+        pred.variance_mu = 0.0
+        pred.variance_weights, _ = sparse_solve(Lp, A, cr2 / s2, A / s2)
     if with_uncertainty:                                      # conditional.py:571-577
         pred.L = Lp
         pred.Cs = Lp @ L_B
@@ -769,16 +831,17 @@ def landmarks_conditional_cholesky(xu, z, mu, cov_func, n_obs, L=None,
 
 
 def compute_conditional(x, landmarks, z, y, mu, cov_func, L, Lp=None, sigma=0.0,
-                        jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False):
+                        jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False, obs_variance=False):
     """inference.py:375-508 dispatch."""
     if landmarks is None:
         return full_conditional(x, y, mu, cov_func, Lp, sigma=sigma, jitter=jitter,
-                                y_is_mean=y_is_mean, with_uncertainty=with_uncertainty)
+                                y_is_mean=y_is_mean, with_uncertainty=with_uncertainty, obs_variance=obs_variance)
     if z is not None and z.shape[0] == landmarks.shape[0]:
         return landmarks_conditional_cholesky(landmarks, z, mu, cov_func, x.shape[0], Lp,
                                               jitter=jitter)
     return landmarks_conditional(x, landmarks, y, mu, cov_func, None, sigma=sigma,
-                                 jitter=jitter, y_is_mean=y_is_mean, with_uncertainty=with_uncertainty)
+                                 jitter=jitter, y_is_mean=y_is_mean, with_uncertainty=with_uncertainty,
+                                 obs_variance=obs_variance)
 
 
 # --------------------------------------------------------------------------
@@ -849,7 +912,7 @@ def density_fit(x, cov_func_curry=Matern52, n_landmarks=None, rank=None, landmar
 def function_fit(x, y, sigma, cov_func_curry=Matern52, n_landmarks=None, landmarks=None,
                  nn_distances=None, mu=0.0, ls=None, ls_factor=1.0, cov_func=None,
                  jitter=DEFAULT_JITTER, y_is_mean=False, random_state=DEFAULT_RANDOM_SEED,
-                 with_uncertainty=False):
+                 with_uncertainty=False, obs_variance=False):
     """FunctionEstimator.fit (function_estimator.py:295-374) -> Predictor."""
     x = ensure_2d(x)
     n = x.shape[0]
@@ -866,7 +929,7 @@ def function_fit(x, y, sigma, cov_func_curry=Matern52, n_landmarks=None, landmar
         landmarks = compute_landmarks(x, gp_type, n_landmarks, random_state)
     return compute_conditional(x, landmarks, None, np.asarray(y, dtype=np.float64), mu,
                                cov_func, None, None, sigma, jitter=jitter,
-                               y_is_mean=y_is_mean, with_uncertainty=with_uncertainty)
+                               y_is_mean=y_is_mean, with_uncertainty=with_uncertainty, obs_variance=obs_variance)
 
 
 def per_time_nn_distances(x, times):

@@ -258,6 +258,49 @@ def test_function_estimator_reference_golden(mellon):
     assert np.allclose(est.predict(Xt), np.array(gold["sparse"]["expected_pred"]), atol=1e-5)
 
 
+@pytest.mark.parametrize("kind,n_landmarks", [("full", 0), ("sparse", 15)])
+def test_reference_golden_leverage_and_obs_variance(mellon, kind, n_landmarks):
+    """The remaining hard-coded outputs of tests/test_reference_results.py:21-63,103-140 -- `predict.leverage(X)`
+    and `predict.obs_variance(X_test)` of `FunctionEstimator(sigma=1, obs_variance=True)` -- reproduced by the
+    device path at the reference's own tolerance (atol 1e-5)."""
+    gold = json.load(open(os.path.join(GOLD, "reference_results.json")))[kind]
+    k1, k2, k3 = jp.split(jp.prng_key(42), 3, True)
+    X, y, Xt = jp.normal64(k1, (50, 2), True), jp.normal64(k2, (50, 3), True), jp.normal64(k3, (10, 2), True)
+    est = mellon.FunctionEstimator(sigma=1.0, n_landmarks=n_landmarks, obs_variance=True)
+    est.fit(X, y)
+    p = est.predict
+    assert np.allclose(p(Xt), np.array(gold["expected_pred"]), atol=1e-5)
+    lev = p.leverage(X)
+    assert lev.shape == (50,) and np.allclose(lev, np.array(gold["expected_lev"]), atol=1e-5)
+    ov = p.obs_variance(Xt)
+    assert ov.shape == (10, 3) and np.allclose(ov, np.array(gold["expected_obsvar"]), atol=1e-5)
+    # and against the oracle, tighter; HC3 identity of loo_residuals_squared
+    ref = mo.function_fit(X, y, 1.0, n_landmarks=n_landmarks, landmarks=est.landmarks, ls=est.ls, obs_variance=True)
+    assert np.abs(lev - ref.leverage(X)).max() < 1e-9 and np.abs(ov - ref.obs_variance(Xt)).max() < 1e-8
+    loo = p.loo_residuals_squared(X, y)
+    assert np.allclose(loo, (y - p(X)) ** 2 / (1 - lev[:, None]) ** 2, rtol=1e-12)
+    q = mellon.Predictor.from_json_str(p.to_json())
+    assert np.abs(q.obs_variance(Xt) - ov).max() < 1e-12
+    with pytest.raises(ValueError):
+        mellon.FunctionEstimator(sigma=1.0, n_landmarks=n_landmarks).fit(X, y).predict.obs_variance(Xt)
+
+
+def test_leverage_larger_case_vs_oracle(mellon):
+    # tests/test_leverage.py:26-44 pattern at a size where the landmark system is ill-conditioned
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(1500, 3))
+    y = np.sin(X[:, 0]) + 0.1 * rng.normal(size=1500)
+    for n_landmarks in (0, 120):
+        est = mellon.FunctionEstimator(sigma=0.3, n_landmarks=n_landmarks, obs_variance=True)
+        est.fit(X, y)
+        ref = mo.function_fit(X, y, 0.3, n_landmarks=n_landmarks, landmarks=est.landmarks, ls=est.ls, obs_variance=True)
+        lev, lr = est.predict.leverage(X), ref.leverage(X)
+        assert np.all(lev > 0) and np.all(lev < 1)
+        assert np.abs(lev - lr).max() < 1e-6 * max(lr.max(), 1e-3)
+        xq = rng.normal(size=(40, 3))
+        assert np.abs(est.predict.obs_variance(xq) - ref.obs_variance(xq)).max() < 1e-6 * np.abs(ref.obs_variance(xq)).max()
+
+
 def test_function_estimator_vs_oracle(mellon):
     # tests/test_function_estimator.py pattern: fit_predict shape, multi-output, Xnew
     rng = np.random.default_rng(5)

@@ -52,6 +52,22 @@ def test_full_gp_reference_leverage():
     assert np.allclose(lev, np.array(GOLD["full"]["expected_lev"]), atol=1e-5)
 
 
+def test_full_gp_reference_obs_variance_and_leverage_method():
+    # tests/test_reference_results.py:21-63: est.predict.leverage(X), est.predict.obs_variance(X_test)
+    X, y, Xt = _inputs()
+    pred = mo.function_fit(X, y, 1.0, n_landmarks=0, obs_variance=True)
+    assert np.allclose(pred.leverage(X), np.array(GOLD["full"]["expected_lev"]), atol=1e-5)
+    assert np.allclose(pred.obs_variance(Xt), np.array(GOLD["full"]["expected_obsvar"]), atol=1e-5)
+
+
+def test_sparse_gp_reference_leverage_and_obs_variance():
+    # tests/test_reference_results.py:88-130 (15 k-means landmarks)
+    X, y, Xt = _inputs()
+    pred = mo.function_fit(X, y, 1.0, n_landmarks=15, obs_variance=True)
+    assert np.allclose(pred.leverage(X), np.array(GOLD["sparse"]["expected_lev"]), atol=1e-5)
+    assert np.allclose(pred.obs_variance(Xt), np.array(GOLD["sparse"]["expected_obsvar"]), atol=1e-5)
+
+
 def test_sparse_gp_reference_predictions():
     X, y, Xt = _inputs()
     pred = mo.function_fit(X, y, 1.0, n_landmarks=15)(Xt)
