@@ -263,6 +263,21 @@ int mln_sparse_solve_factors(mln_ctx* ctx, const mln_kernel_desc* cov, const dou
                              int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
                              double sigma, double jitter, double* W, double* Lp_out, double* Cs_out);
 
+/* Noise models of the landmark conditional beyond one scalar (conditional.py:13-43,140-159,529-545):
+ *   MLN_SIGMA_SCALAR      sigma[1]        the solve above
+ *   MLN_SIGMA_PER_OUTPUT  sigma[p]        one noise level per output column ("per-gene" sigma, the vmap of
+ *                                         conditional.py:529-545); A A^T and A (y - mu) are formed once; adjacent
+ *                                         columns with equal sigma share one L_B, and beyond 32 such runs one
+ *                                         eigendecomposition A A^T = U diag(lam) U^T serves every level:
+ *                                         (A A^T / s^2 + I)^-1 = U diag(1 / (lam / s^2 + 1)) U^T
+ *   MLN_SIGMA_PER_CELL    sigma[n_local]  element-wise standard deviation of this rank's cells
+ *                                         (`sigma.shape == r.shape`, conditional.py:155-159):
+ *                                         L_B L_B^T = A diag(1/sigma^2) A^T + I, c = L_B^-1 A ((y - mu) / sigma^2)   */
+enum { MLN_SIGMA_SCALAR = 0, MLN_SIGMA_PER_OUTPUT = 1, MLN_SIGMA_PER_CELL = 2 };
+int mln_sparse_solve_noise(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                           int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
+                           const double* sigma, int32_t sigma_kind, double jitter, double* W /* m x p */);
+
 /* a-13: mean(Xnew) = mu + cov(Xnew, centers) W   (conditional.py:366-373,651-658,899-906).
  * centers: m x d (landmarks or, full GP, the training cells); W: m x p; out: n_new x p.
  * cov(Xnew, centers) is never materialised for p == 1.                                         */

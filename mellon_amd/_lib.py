@@ -91,6 +91,7 @@ SYMBOLS = [
     ("mln_sparse_solve", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp]),
     ("mln_sparse_solve_factors", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp,
                                            _dp, _dp]),
+    ("mln_sparse_solve_noise", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp, _i32, _dbl, _dp]),
     ("mln_predict_mean", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp]),
     ("mln_predict_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i32, _dp]),
     ("mln_predict_mean_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _i32, _dp]),
@@ -388,6 +389,25 @@ class Context:
                                                       float(jitter), W.ctypes.data, Lp.ctypes.data,
                                                       Cs.ctypes.data), jitter=jitter)
         return W, Lp, Cs
+
+    SIGMA_SCALAR, SIGMA_PER_OUTPUT, SIGMA_PER_CELL = 0, 1, 2
+
+    def sparse_solve_noise(self, desc, x, xu, y, mu, sigma, kind, jitter):
+        """Landmark-conditional weights under per-output (sigma[p]) or per-cell (sigma[n]) noise."""
+        x = x if isinstance(x, DeviceArray) else _as2d(x)
+        xu = _as2d(xu)
+        y2 = _f64(y)
+        sig = _f64(np.atleast_1d(sigma))
+        m = xu.shape[0]
+        p = 1 if y2.ndim == 1 else y2.shape[1]
+        want = {self.SIGMA_SCALAR: 1, self.SIGMA_PER_OUTPUT: p, self.SIGMA_PER_CELL: x.shape[0]}[kind]
+        if sig.shape != (want,):
+            raise ValueError(f"sigma has shape {sig.shape}, expected {(want,)} for noise kind {kind}")
+        W = np.empty((m,) if y2.ndim == 1 else (m, p), dtype=np.float64)
+        self._check(self.lib.mln_sparse_solve_noise(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1], _ptr(xu),
+                                                    m, y2.ctypes.data, p, float(mu), sig.ctypes.data, int(kind),
+                                                    float(jitter), W.ctypes.data), jitter=jitter)
+        return W
 
     def diag_overlap(self, n, m, d, gram_rows):
         out = np.zeros(6)

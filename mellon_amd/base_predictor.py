@@ -138,8 +138,8 @@ class Predictor:
         x = self._check_features(x)
         if not hasattr(self, "_leverage"):
             raise NotImplementedError(f"{self.__class__.__name__} has no leverage.")
-        if self.sigma is None or np.ndim(self.sigma) != 0:
-            raise NotImplementedError("leverage is available for a scalar `sigma` (SURVEY.md S8f).")
+        if self.sigma is None:
+            raise ValueError("leverage needs the noise level `sigma` of the fit.")
         return self._leverage(x, self.sigma)
 
     def loo_residuals_squared(self, x, y):

@@ -3,7 +3,9 @@
   FullConditional               weights = L^-T L^-1 (y - mu),  L = chol(K(x,x) + s I)     :183-264
   LandmarksConditional          `_sparse_solve` with A = Lp^-1 K(xu, x)                    :455-547, :57-66
   LandmarksConditionalCholesky  weights = Lp^-T z                                          :750-818
-Only scalar sigma is supported (per-feature / per-observation sigma: S8f).
+Noise models (conditional.py:13-43,100-159): one scalar sigma; one sigma per output column ("per-gene",
+shape (p,) or (1, p)); one per cell (shape (n,), element-wise std) and one per cell and output ((n, p)).
+A full covariance matrix as sigma and `y_cov_factor` stay outside the accelerated path.
 """
 import logging
 
@@ -23,9 +25,42 @@ def _scalar_sigma(sigma):
         return None
     s = np.asarray(sigma, dtype=np.float64)
     if s.ndim != 0:
-        raise NotImplementedError("Only scalar sigma is supported by the accelerated predictors "
-                                  "(per-feature / per-observation sigma: SURVEY.md S8f).")
+        raise NotImplementedError("This code path takes one scalar sigma.")
     return float(s)
+
+
+def _is_per_feature_sigma(sigma, y):
+    """One sigma per output column of a 2-D y -- shapes (p,), (1, p), (n, p) (conditional.py:13-36)."""
+    if sigma is None or np.ndim(sigma) == 0:
+        return False
+    sigma, y = np.asarray(sigma), np.asarray(y)
+    if sigma.ndim == 2 and sigma.shape[0] == 1 and y.ndim == 2 and sigma.shape[1] == y.shape[1]:
+        return True
+    if sigma.ndim == 2 and y.ndim == 2 and sigma.shape == y.shape:
+        return True
+    if sigma.ndim == 1 and y.ndim == 2 and sigma.shape[0] == y.shape[1]:
+        if sigma.shape[0] == y.shape[0]:
+            logger.warning(f"sigma length {sigma.shape[0]} matches both n_obs and n_features. "
+                           "Interpreting as per-feature. Pass sigma with shape (n, 1) for per-observation.")
+        return True
+    return False
+
+
+def _normalize_per_feature_sigma(sigma):
+    """(1, p) -> (p,) (conditional.py:39-43)."""
+    sigma = np.asarray(sigma, dtype=np.float64)
+    return sigma[0] if sigma.ndim == 2 and sigma.shape[0] == 1 else sigma
+
+
+def _per_output_levels(sigma):
+    """The distinct noise levels of a per-output sigma and, for each, the output columns that carry it."""
+    sig = _normalize_per_feature_sigma(sigma)
+    if sig.ndim != 1:
+        raise NotImplementedError("leverage / obs_variance take one sigma per output column; the reference's "
+                                  "(n, p) sigma only defines the weights (conditional.py:313-323 needs a scalar "
+                                  "per column).")
+    levels, inverse = np.unique(sig, return_inverse=True)
+    return sig, [(float(v), np.flatnonzero(inverse == k)) for k, v in enumerate(levels)]
 
 
 def _reject_extras(with_uncertainty, obs_variance):
@@ -66,6 +101,54 @@ def _landmarks_leverage(Xnew, xu, cov_func, sigma, jitter, L=None):
     return cov_func.diag(Xnew) - c
 
 
+def _full_leverage_any(x, cov_func, sigma, jitter):
+    """Scalar sigma -> (n,); per-output sigma -> (n, p), one column per output (conditional.py:385-403)."""
+    if np.ndim(sigma) == 0:
+        return _full_leverage(x, cov_func, float(sigma), jitter)[0]
+    sig, levels = _per_output_levels(sigma)
+    h = np.empty((x.shape[0], sig.shape[0]))
+    for value, cols in levels:
+        h[:, cols] = _full_leverage(x, cov_func, value, jitter)[0][:, None]
+    return h
+
+
+def _landmarks_leverage_any(Xnew, xu, cov_func, sigma, jitter, L=None):
+    """Scalar sigma -> (n,); per-output sigma -> (n, p) (conditional.py:660-685).  B^T B and K_uu are formed
+    once; each distinct noise level costs one m x m Cholesky and one pass over the cells."""
+    if np.ndim(sigma) == 0:
+        return _landmarks_leverage(Xnew, xu, cov_func, float(sigma), jitter, L=L)
+    sig, levels = _per_output_levels(sigma)
+    ctx = _lib.default_context()
+    desc = cov_func.lower(xu.shape[1])
+    S = ctx.kernel_gram(desc, Xnew, xu)
+    K_uu = (np.asarray(L) @ np.asarray(L).T) if L is not None else ctx.kernel_matrix(desc, xu, xu)
+    kdiag = cov_func.diag(Xnew)
+    h = np.empty((Xnew.shape[0], sig.shape[0]))
+    for value, cols in levels:
+        Lm = ctx.chol_lower(value ** 2 * K_uu + S, add_diag=jitter, jitter=jitter)
+        h[:, cols] = (kdiag - ctx.predict_covariance(desc, Xnew, xu, Lm, diag=True))[:, None]
+    return h
+
+
+def _sparse_solve_per_output(ctx, desc, x, xu, y, mu, sigma, jitter):
+    """`_sparse_solve` for every output column with its own sigma (conditional.py:526-545).  Inside
+    mln_sparse_solve_noise adjacent columns with one level share an L_B; beyond 32 runs one eigendecomposition of
+    A A^T serves every level."""
+    sig = _normalize_per_feature_sigma(sigma)
+    y = np.asarray(y, dtype=np.float64)
+    if sig.ndim == 2:       # (n, p): an element-wise noise vector per output, one pass per output
+        return np.stack([ctx.sparse_solve_noise(desc, x, xu, np.ascontiguousarray(y[:, g]), mu,
+                                                np.ascontiguousarray(sig[:, g]), ctx.SIGMA_PER_CELL, jitter)
+                         for g in range(y.shape[1])], axis=1)
+    return ctx.sparse_solve_noise(desc, x, xu, y, mu, sig, ctx.SIGMA_PER_OUTPUT, jitter)
+
+
+def _chol_with_diag(ctx, K, diag_values, jitter):
+    M = np.array(K, dtype=np.float64)
+    M[np.diag_indices_from(M)] += diag_values
+    return ctx.chol_lower(M, jitter=jitter)
+
+
 def _parameter_std(sigma, m):
     """Standard deviations of the m parameters as a vector (conditional.py:856-862: `diagonal(sigma)`
     for a vector, `eye(m) * sigma` for a scalar)."""
@@ -90,57 +173,107 @@ class _FullConditional:
     _center_name = "x"
 
     def _leverage(self, Xnew, sigma):      # the training leverage, whatever Xnew (conditional.py:373-403)
-        return _full_leverage(self.x, self.cov_func, _scalar_sigma(sigma), self.jitter)[0]
+        return _full_leverage_any(self.x, self.cov_func, sigma, self.jitter)
 
     def __init__(self, x, y, mu, cov_func, L=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER, y_cov_factor=None,
                  y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None):
         _reject_extras(with_uncertainty, obs_variance)
         x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         ctx = _lib.default_context()
-        if isinstance(L, (FactorLp, FactorL)) and L.fit.m == x.shape[0] and L.fit.handle is not None \
-                and getattr(L.fit, "_has_lp", True):
-            fit = L.fit
-        elif L is not None:
-            Lh = np.asarray(L, dtype=np.float64)
-            fit = _lib.Fit.from_L(ctx, Lh, Lp=Lh)
-        else:
-            logger.info("Recomputing covariance decomposition for predictive function.")
-            if y_is_mean:
-                diag = jitter                                            # _get_L(x, cov, jitter)
+        yh = np.asarray(y, dtype=np.float64)
+        n = x.shape[0]
+        per_feature = _is_per_feature_sigma(sigma, yh)
+        per_cell = (not per_feature and sigma is not None and np.ndim(sigma) == 1 and L is None and not y_is_mean)
+        fit = None
+        var_state = None
+        if per_feature:
+            # one solve per output with chol(K + sigma_g^2 I + jitter I) (conditional.py:239-251); outputs that share
+            # a noise level share the factorisation, and everything a level needs is done while its factor is resident
+            sig = _normalize_per_feature_sigma(sigma)
+            desc = cov_func.lower(x.shape[1])
+            weights = np.empty((n, yh.shape[1]))
+            if sig.ndim == 1:
+                if obs_variance:
+                    var_state = (np.empty_like(yh), np.empty_like(weights))      # corrected r^2, variance weights
+                for value, cols in _per_output_levels(sigma)[1]:
+                    if obs_variance:       # conditional.py:305-362, column by column
+                        h_v, fit_v = _full_leverage(x, cov_func, value, jitter)
+                    else:
+                        fit_v = ctx.fit_prepare(desc, x, None, value ** 2 + jitter)
+                    y_c = np.ascontiguousarray(yh[:, cols])
+                    weights[:, cols] = w_c = fit_v.weights_full(y_c, mu)
+                    if obs_variance:
+                        cr2 = _hc3(y_c - ctx.predict_mean(desc, x, x, w_c, float(mu)), h_v)
+                        var_state[0][:, cols] = cr2
+                        var_state[1][:, cols] = fit_v.weights_full(cr2, 0.0)
+                    fit_v.close()
             else:
-                s = _scalar_sigma(sigma)
-                if s is None and y_cov_factor is None:
-                    raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
-                                     "`pre_transformation_std` to quantify uncertainty of the prediction.")
-                if y_cov_factor is not None:
-                    raise NotImplementedError("y_cov_factor is outside the accelerated path.")
-                diag = max(s * s, jitter)                                # add_variance, util.py:296-331
-            fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
-        weights = fit.weights_full(np.asarray(y, dtype=np.float64), mu)  # conditional.py:263-264
+                K = ctx.kernel_matrix(desc, x, x)
+                for g in range(yh.shape[1]):
+                    Lg = _chol_with_diag(ctx, K, sig[:, g] ** 2 + jitter, jitter)
+                    weights[:, g] = ctx.trsm_lower(Lg, ctx.trsm_lower(Lg, yh[:, g] - mu), trans=True)
+        elif per_cell:
+            # y_cov_factor = diag(sigma): K + diag(max(sigma_i^2, jitter)) (conditional.py:118-119, util.py:326-329)
+            sig = np.asarray(sigma, dtype=np.float64)
+            if sig.shape != (n,):
+                raise ValueError(f"sigma has shape {sig.shape}; expected a scalar, ({n},) or one value per output.")
+            K = ctx.kernel_matrix(cov_func.lower(x.shape[1]), x, x)
+            Lh = _chol_with_diag(ctx, K, np.maximum(sig ** 2, jitter), jitter)
+            weights = ctx.trsm_lower(Lh, ctx.trsm_lower(Lh, yh - mu), trans=True)
+        else:
+            if isinstance(L, (FactorLp, FactorL)) and L.fit.m == x.shape[0] and L.fit.handle is not None \
+                    and getattr(L.fit, "_has_lp", True):
+                fit = L.fit
+            elif L is not None:
+                Lh = np.asarray(L, dtype=np.float64)
+                fit = _lib.Fit.from_L(ctx, Lh, Lp=Lh)
+            else:
+                logger.info("Recomputing covariance decomposition for predictive function.")
+                if y_is_mean:
+                    diag = jitter                                            # _get_L(x, cov, jitter)
+                else:
+                    s = _scalar_sigma(sigma)
+                    if s is None and y_cov_factor is None:
+                        raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
+                                         "`pre_transformation_std` to quantify uncertainty of the prediction.")
+                    if y_cov_factor is not None:
+                        raise NotImplementedError("y_cov_factor is outside the accelerated path.")
+                    diag = max(s * s, jitter)                                # add_variance, util.py:296-331
+                fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
+            weights = fit.weights_full(yh, mu)                               # conditional.py:263-264
         Predictor.__init__(self, cov_func, x, weights, mu, n_obs=x.shape[0], jitter=jitter, sigma=sigma)
-        if obs_variance:      # conditional.py:305-362 (scalar sigma): smoothed HC3 observation variance
-            s_ = _scalar_sigma(sigma)
-            if s_ is None:
+        self.per_feature_sigma = bool(per_feature)
+        if obs_variance:      # conditional.py:305-362: smoothed HC3 observation variance
+            if sigma is None:
                 raise ValueError("obs_variance needs the noise level `sigma`.")
-            h, fit_v = _full_leverage(x, cov_func, s_, jitter)
-            self._corrected_r2 = _hc3(np.asarray(y, dtype=np.float64) - self._mean(x), h)
             self.variance_mu = 0.0
-            self.variance_weights = fit_v.weights_full(self._corrected_r2, self.variance_mu)
+            if np.ndim(sigma) >= 1:
+                if var_state is None:
+                    raise NotImplementedError("obs_variance takes a scalar sigma or one sigma per output column.")
+                self._corrected_r2, self.variance_weights = var_state
+            else:
+                h, fit_v = _full_leverage(x, cov_func, float(sigma), jitter)
+                self._corrected_r2 = _hc3(yh - self._mean(x), h)
+                self.variance_weights = fit_v.weights_full(self._corrected_r2, self.variance_mu)
             self._state_variables |= {"variance_weights", "variance_mu"}
         if with_uncertainty and parameter_std is not None:
             # y_cov_factor = L diag(std) (inference.compute_parameter_cov_factor, inference.py:357-372)
             _attach_uncertainty(self, fit.Lp(), _parameter_std(parameter_std, x.shape[0]))
+        elif with_uncertainty and per_feature:
+            # noise-free covariance, no mean covariance (conditional.py:288-291)
+            self.L = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, jitter).Lp()
+            self._state_variables |= {"L"}
         elif with_uncertainty:
             # noisy observations (conditional.py:285-304): L = chol(K + sigma^2 I) and
-            # W = L^-T L^-1 y_cov_factor with y_cov_factor = sigma I
-            s_ = _scalar_sigma(sigma)
-            if s_ is None:
+            # W = L^-T L^-1 y_cov_factor with y_cov_factor = sigma I (diag(sigma) for one sigma per cell)
+            if sigma is None:
                 raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
                                  "`pre_transformation_std` to quantify uncertainty of the prediction.")
-            Lh = fit.Lp()
-            ctx_ = _lib.default_context()
+            if not per_cell:
+                Lh = fit.Lp()
             self.L = Lh
-            self.W = ctx_.trsm_lower(Lh, ctx_.trsm_lower(Lh, np.eye(x.shape[0]) * s_), trans=True)
+            ycf = np.diag(np.broadcast_to(np.asarray(sigma, dtype=np.float64), (n,)))
+            self.W = ctx.trsm_lower(Lh, ctx.trsm_lower(Lh, ycf), trans=True)
             self._state_variables |= {"L", "W"}
 
 
@@ -148,8 +281,8 @@ class _LandmarksConditional:
     _center_name = "landmarks"
 
     def _leverage(self, Xnew, sigma):
-        return _landmarks_leverage(Xnew, self.landmarks, self.cov_func, _scalar_sigma(sigma), self.jitter,
-                                   L=getattr(self, "L", None))
+        return _landmarks_leverage_any(Xnew, self.landmarks, self.cov_func, sigma, self.jitter,
+                                       L=getattr(self, "L", None))
 
     def __init__(self, x, xu, y, mu, cov_func, L=None, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
                  y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False):
@@ -157,33 +290,69 @@ class _LandmarksConditional:
         if with_uncertainty and y_is_mean:
             raise NotImplementedError("with_uncertainty for a landmark conditional on a mean (needs y_cov_factor, "
                                       "conditional.py:579-587) is outside the accelerated path.")
-        # y_is_mean (conditional.py:536-537) feeds _sparse_solve with (r, A) unscaled, which is what
-        # _process_sigma produces for sigma = 1: L_B L_B^T = A A^T + I, c = L_B^-1 A r.
-        s = 1.0 if y_is_mean else _scalar_sigma(sigma)
-        if s is None or not s > 0:
-            raise ValueError("sigma must be a positive scalar for the landmark conditional "
-                             "(the reference divides by sigma^2, conditional.py:157-159).")
+        ctx = _lib.default_context()
         xh = x if isinstance(x, _lib.DeviceArray) else np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
-        out = _lib.default_context().sparse_solve(cov_func.lower(xu.shape[1]), xh, xu,
-                                                  np.asarray(y, dtype=np.float64), mu, s, jitter,
-                                                  return_factors=bool(with_uncertainty))
-        weights = out[0] if with_uncertainty else out
+        yh = np.asarray(y, dtype=np.float64)
+        desc = cov_func.lower(xu.shape[1])
+        per_feature = _is_per_feature_sigma(sigma, yh)
+        vector = (not per_feature) and (not y_is_mean) and sigma is not None and np.ndim(sigma) >= 1
+        Lp_h = Cs_h = None
+
+        def solve(target, mean, want_factors=False):
+            """`_sparse_solve` of `target - mean` under this conditional's noise model."""
+            if per_feature:
+                return _sparse_solve_per_output(ctx, desc, xh, xu, target, mean, sigma, jitter)
+            if vector:
+                return ctx.sparse_solve_noise(desc, xh, xu, target, mean, sig_cell, ctx.SIGMA_PER_CELL, jitter)
+            return ctx.sparse_solve(desc, xh, xu, target, mean, s, jitter, return_factors=want_factors)
+
+        if vector:
+            # element-wise standard deviation of the cells (conditional.py:155-159); y must be 1-D there
+            sig_cell = np.asarray(sigma, dtype=np.float64)
+            if yh.ndim > 1 and sig_cell.shape == yh.shape:
+                raise NotImplementedError("FunctionEstimator not implemented for multiple noises.")
+            if sig_cell.ndim == 2 and sig_cell.shape == (xh.shape[0], xh.shape[0]):
+                raise NotImplementedError("A full covariance matrix as sigma is outside the accelerated path.")
+            if sig_cell.shape != yh.shape or yh.ndim != 1:
+                raise ValueError("Unsupported sigma configuration.")
+            if not np.all(sig_cell > 0):
+                raise ValueError("sigma must be positive for the landmark conditional.")
+        elif per_feature:
+            if not np.all(np.asarray(sigma, dtype=np.float64) > 0):
+                raise ValueError("sigma must be positive for the landmark conditional.")
+        else:
+            # y_is_mean (conditional.py:536-537) feeds _sparse_solve with (r, A) unscaled, which is what
+            # _process_sigma produces for sigma = 1: L_B L_B^T = A A^T + I, c = L_B^-1 A r.
+            s = 1.0 if y_is_mean else _scalar_sigma(sigma)
+            if s is None or not s > 0:
+                raise ValueError("sigma must be positive for the landmark conditional "
+                                 "(the reference divides by sigma^2, conditional.py:157-159).")
+        want_factors = bool(with_uncertainty) and not per_feature and not vector
+        out = solve(yh, mu, want_factors)
+        if want_factors:
+            weights, Lp_h, Cs_h = out
+        else:
+            weights = out
         Predictor.__init__(self, cov_func, xu, weights, mu, n_obs=xh.shape[0], jitter=jitter, sigma=sigma)
-        if obs_variance:          # conditional.py:589-645 (scalar sigma); the leverage here uses K_uu = Lp Lp^T
-            ctx = _lib.default_context()
-            desc = cov_func.lower(xu.shape[1])
-            Lp_h = out[1] if with_uncertainty else ctx.chol_lower(ctx.kernel_matrix(desc, xu, xu), add_diag=jitter,
-                                                                  jitter=jitter)
+        self.per_feature_sigma = bool(per_feature)
+        if (obs_variance or with_uncertainty) and Lp_h is None:
+            Lp_h = ctx.chol_lower(ctx.kernel_matrix(desc, xu, xu), add_diag=jitter, jitter=jitter)
+        if obs_variance:          # conditional.py:589-645; the leverage here uses K_uu = Lp Lp^T
+            if vector or (per_feature and _normalize_per_feature_sigma(sigma).ndim != 1):
+                raise NotImplementedError("obs_variance takes a scalar sigma or one sigma per output column.")
             xfull = xh.to_host() if isinstance(xh, _lib.DeviceArray) else xh
-            h = _landmarks_leverage(xfull, xu, cov_func, s, jitter, L=Lp_h)
-            self._corrected_r2 = _hc3(np.asarray(y, dtype=np.float64) - self._mean(xfull), h)
+            h = _landmarks_leverage_any(xfull, xu, cov_func, 1.0 if y_is_mean else sigma, jitter, L=Lp_h)
+            self._corrected_r2 = _hc3(yh - self._mean(xfull), h)
             self.variance_mu = 0.0
-            self.variance_weights = ctx.sparse_solve(desc, xh, xu, self._corrected_r2, self.variance_mu, s, jitter)
+            self.variance_weights = solve(self._corrected_r2, self.variance_mu)
             self._state_variables |= {"variance_weights", "variance_mu"}
-        if with_uncertainty:      # conditional.py:571-577: L = Lp, Cs = Lp L_B
-            self.L, self.Cs = out[1], out[2]
-            self._state_variables |= {"L", "Cs"}
+        if with_uncertainty:      # conditional.py:571-577: L = Lp, Cs = Lp L_B (scalar sigma only)
+            self.L = Lp_h
+            self._state_variables |= {"L"}
+            if Cs_h is not None:
+                self.Cs = Cs_h
+                self._state_variables |= {"Cs"}
 
 
 class _LandmarksConditionalCholesky:

@@ -1576,23 +1576,85 @@ extern "C" int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* 
 }
 
 // ---- FunctionEstimator sparse solve ----------------------------------------------------------------
+// C[i][j] *= (row ? row[i] : 1) * (col ? col[j] : 1)
+__global__ void k_scale_rows_cols(double* __restrict__ A, int64_t ld, int64_t rows, int64_t cols,
+                                  const double* __restrict__ row, const double* __restrict__ col) {
+  const int64_t i = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (i >= rows) return;
+  const double ri = row ? row[i] : 1.0;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cols; j += (int64_t)gridDim.x * blockDim.x)
+    A[i * ld + j] *= ri * (col ? col[j] : 1.0);
+}
+
+// T[k][j] /= lam[k] * inv_s2[j] + 1  -- the resolvent (G / s_j^2 + I)^-1 in the eigenbasis of G
+__global__ void k_resolvent_scale(double* __restrict__ T, int64_t ld, int64_t rows, int64_t cols,
+                                  const double* __restrict__ lam, const double* __restrict__ inv_s2) {
+  const int64_t k = blockIdx.y + (int64_t)blockIdx.z * 65535;
+  if (k >= rows) return;
+  const double l = lam[k] > 0.0 ? lam[k] : 0.0;       // A A^T is positive semi-definite; rounding may say -1e-13
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cols; j += (int64_t)gridDim.x * blockDim.x)
+    T[k * ld + j] /= l * inv_s2[j] + 1.0;
+}
+
+static int launch_scale_rows_cols(mln_ctx* ctx, double* A, int64_t ld, int64_t rows, int64_t cols, const double* row,
+                                  const double* col) {
+  if (rows <= 0 || cols <= 0) return MLN_OK;
+  int64_t bx = (cols + 255) / 256;
+  if (bx > 64) bx = 64;
+  const int64_t by = rows < 65535 ? rows : 65535, bz = (rows + 65534) / 65535;
+  hipLaunchKernelGGL(k_scale_rows_cols, dim3((unsigned)bx, (unsigned)by, (unsigned)bz), dim3(256), 0, ctx->stream, A, ld,
+                     rows, cols, row, col);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+// Noise models of the landmark conditional (conditional.py:140-159, 529-545):
+//   MLN_SIGMA_SCALAR      sigma[1]        r / s^2, A / s^2
+//   MLN_SIGMA_PER_OUTPUT  sigma[p]        one scalar solve per output column ("per-gene", the vmap of :529-545);
+//                                         A A^T and A r are formed once, columns with equal sigma share L_B
+//   MLN_SIGMA_PER_CELL    sigma[n_local]  element-wise std of the cells: A diag(1/s^2) A^T and A (r / s^2)
+static constexpr int SPECTRAL_MIN_LEVELS = 32;   // runs of equal sigma above which the per-output solve goes spectral
+
 static int sparse_solve_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                              int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
-                             double sigma, double jitter, double* W, double* Lp_out, double* Cs_out) {
-  if (!ctx || !xu || !W || (n_local > 0 && (!x || !y))) return MLN_ERR_ARG;
+                             const double* sigmas, int32_t kind, double jitter, double* W, double* Lp_out,
+                             double* Cs_out) {
+  if (!ctx || !xu || !W || !sigmas || (n_local > 0 && (!x || !y))) return MLN_ERR_ARG;
   if (p < 1 || m < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
-  if (!(sigma > 0.0)) { mln_set_error(ctx, "sigma must be > 0 for the sparse solve (conditional.py:157-159 divides by sigma^2)"); return MLN_ERR_ARG; }
+  if (kind < MLN_SIGMA_SCALAR || kind > MLN_SIGMA_PER_CELL) { mln_set_error(ctx, "unknown sigma kind"); return MLN_ERR_ARG; }
+  if (kind != MLN_SIGMA_SCALAR && (Lp_out || Cs_out)) {
+    mln_set_error(ctx, "the L_B factor is only defined for one scalar sigma (conditional.py:574-577)");
+    return MLN_ERR_ARG;
+  }
+  const int64_t n_sig = (kind == MLN_SIGMA_SCALAR) ? 1 : (kind == MLN_SIGMA_PER_OUTPUT ? p : n_local);
+  for (int64_t i = 0; i < n_sig; ++i)
+    if (!(sigmas[i] > 0.0)) {
+      mln_set_error(ctx, "sigma must be > 0 for the sparse solve (conditional.py:157-159 divides by sigma^2)");
+      return MLN_ERR_ARG;
+    }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   // A^T = cov(x, xu) Lp^-T is exactly the factor L of the density path   conditional.py:516-522
   mln_fit* f = nullptr;
   MLN_TRY(mln_fit_prepare(ctx, cov, x, n_local, d, xu, m, jitter, nullptr, 0, &f));
   const int64_t ldg = pad16(m), n = n_local;
-  const double s2 = sigma * sigma;
-  double *G = nullptr, *R = nullptr, *C = nullptr, *parts = nullptr;
+  // groups of adjacent output columns with one noise level
+  std::vector<int64_t> g_begin;
+  std::vector<double> g_s2;
+  if (kind == MLN_SIGMA_PER_OUTPUT) {
+    for (int64_t j = 0; j < p; ++j)
+      if (j == 0 || sigmas[j] != sigmas[j - 1]) { g_begin.push_back(j); g_s2.push_back(sigmas[j] * sigmas[j]); }
+  } else {
+    g_begin.push_back(0);
+    g_s2.push_back(kind == MLN_SIGMA_SCALAR ? sigmas[0] * sigmas[0] : 1.0);
+  }
+  g_begin.push_back(p);
+  const size_t n_groups = g_s2.size();
+  double *G = nullptr, *G0 = nullptr, *R = nullptr, *C = nullptr, *parts = nullptr, *d_scale = nullptr, *d_col = nullptr;
   TriInv tb;
   int rc = MLN_OK;
   auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "sparse_solve", __FILE__, __LINE__); };
   chk(mln_dmalloc((void**)&G, sizeof(double) * (size_t)m * ldg));
+  if (n_groups > 1) chk(mln_dmalloc((void**)&G0, sizeof(double) * (size_t)m * ldg));
   chk(mln_dmalloc((void**)&C, sizeof(double) * (size_t)m * p));
   DevIn dy;
   if (rc == MLN_OK) rc = dy.init(ctx, y, (size_t)n * p);
@@ -1610,12 +1672,19 @@ static int sparse_solve_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const dou
       if (d1) (void)mln_dfree(d1);
     }
   }
-  // LBB = A A^T / sigma^2 + I                                      conditional.py:62 (stabilize(.., 1))
-  if (rc == MLN_OK) rc = fit_gram(f, G, ldg, 1);
-  if (rc == MLN_OK) rc = launch_axpby(ctx, m * ldg, 0.0, G, 1.0 / s2, G);
-  if (rc == MLN_OK) rc = launch_add_diag(ctx, G, m, ldg, 1.0);
-  if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, G, m, ldg);
-  // C = A r / sigma^2 = L^T r / sigma^2   (m x p), split over cells
+  // per-cell noise: rows of A^T and of r divided by sigma_i, after which the solve is the sigma = 1 one
+  if (rc == MLN_OK && kind == MLN_SIGMA_PER_CELL && n > 0) {
+    std::vector<double> inv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) inv[(size_t)i] = 1.0 / sigmas[i];
+    chk(mln_dmalloc((void**)&d_scale, sizeof(double) * (size_t)n));
+    chk(hipMemcpyAsync(d_scale, inv.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (rc == MLN_OK) rc = launch_scale_rows_cols(ctx, f->L, f->ldl, n, m, d_scale, nullptr);
+    if (rc == MLN_OK) rc = launch_scale_rows_cols(ctx, R, p, n, p, d_scale, nullptr);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  // A A^T (all-reduced), kept when several noise levels need it
+  if (rc == MLN_OK) rc = fit_gram(f, n_groups > 1 ? G0 : G, ldg, 1);
+  // C = A r = L^T r   (m x p), split over cells; the 1 / sigma^2 is applied per group below
   if (rc == MLN_OK) {
     int split = (int)(n / 8192);
     if (split < 1) split = 1;
@@ -1625,16 +1694,64 @@ static int sparse_solve_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const dou
     if (rc == MLN_OK) chk(hipMemsetAsync(split > 1 ? parts : C, 0, sizeof(double) * stride * (split > 1 ? split : 1), ctx->stream));
     GemmArgs g{};
     g.A = f->L; g.lda = f->ldl; g.B = R; g.ldb = p; g.C = (split > 1) ? parts : C; g.ldc = p;
-    g.M = m; g.N = p; g.K = n; g.alpha = 1.0 / s2; g.beta = 0.0; g.ta = 1; g.tb = 0;
+    g.M = m; g.N = p; g.K = n; g.alpha = (n_groups == 1) ? 1.0 / g_s2[0] : 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;
     g.split_k = split; g.c_split_stride = (int64_t)stride;
     if (rc == MLN_OK && n > 0) rc = launch_dgemm(ctx, g);
     if (rc == MLN_OK && split > 1) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, C, (int64_t)stride, 0.0);
     if (rc == MLN_OK) rc = dev_allreduce(ctx, C, (int64_t)stride);
+    if (rc == MLN_OK && n_groups > 1) {
+      std::vector<double> inv((size_t)p);
+      for (int64_t j = 0; j < p; ++j) inv[(size_t)j] = 1.0 / (sigmas[j] * sigmas[j]);
+      chk(mln_dmalloc((void**)&d_col, sizeof(double) * (size_t)p));
+      chk(hipMemcpyAsync(d_col, inv.data(), sizeof(double) * (size_t)p, hipMemcpyHostToDevice, ctx->stream));
+      if (rc == MLN_OK) rc = launch_scale_rows_cols(ctx, C, p, m, p, nullptr, d_col);
+      (void)hipStreamSynchronize(ctx->stream);
+    }
   }
-  // weights = Lp^-T L_B^-T L_B^-1 C                               conditional.py:64-65
-  if (rc == MLN_OK) rc = triinv_build(ctx, G, m, ldg, true, true, &tb);
-  if (rc == MLN_OK) rc = triinv_solve_left(ctx, tb, C, p, p);
-  if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, tb, C, p, p);
+  if (rc == MLN_OK && n_groups > (size_t)SPECTRAL_MIN_LEVELS) {
+    // Many noise levels: one eigendecomposition A A^T = U diag(lam) U^T serves them all,
+    //   (A A^T / s^2 + I)^-1 c = U diag(1 / (lam / s^2 + 1)) U^T c,
+    // O(m^3 + m^2 p) instead of one m^3/3 Cholesky per level.  The matrix inverted has eigenvalues >= 1, so the
+    // spectral form is as well conditioned as the factorisation it replaces.
+    double *V = nullptr, *T = nullptr, *d_lam = nullptr;
+    std::vector<double> lam((size_t)m);
+    int sweeps = 0;
+    chk(mln_dmalloc((void**)&V, sizeof(double) * (size_t)m * ldg));
+    chk(mln_dmalloc((void**)&T, sizeof(double) * (size_t)m * p));
+    chk(mln_dmalloc((void**)&d_lam, sizeof(double) * (size_t)m));
+    if (rc == MLN_OK) rc = dev_eigh(ctx, G0, m, ldg, lam.data(), V, ldg, &sweeps);     // row k of V = eigenvector k
+    if (rc == MLN_OK) chk(hipMemcpyAsync(d_lam, lam.data(), sizeof(double) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    GemmArgs g{};
+    g.A = V; g.lda = ldg; g.B = C; g.ldb = p; g.C = T; g.ldc = p;
+    g.M = m; g.N = p; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.split_k = 1;
+    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);                                      // U^T c
+    if (rc == MLN_OK) {
+      int64_t bx = (p + 255) / 256;
+      if (bx > 64) bx = 64;
+      hipLaunchKernelGGL(k_resolvent_scale, dim3((unsigned)bx, (unsigned)(m < 65535 ? m : 65535), (unsigned)((m + 65534) / 65535)),
+                         dim3(256), 0, ctx->stream, T, p, m, p, d_lam, d_col);
+      chk(hipGetLastError());
+    }
+    g.A = V; g.B = T; g.C = C; g.ta = 1;
+    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);                                      // U (.)
+    (void)hipStreamSynchronize(ctx->stream);
+    void* tmp[] = {V, T, d_lam};
+    for (void* q : tmp) if (q) (void)mln_dfree(q);
+  } else {
+    for (size_t gi = 0; gi < n_groups && rc == MLN_OK; ++gi) {
+      const int64_t c0 = g_begin[gi], nc = g_begin[gi + 1] - c0;
+      // LBB = A A^T / sigma^2 + I                                      conditional.py:62 (stabilize(.., 1))
+      rc = launch_axpby(ctx, m * ldg, 1.0 / g_s2[gi], n_groups > 1 ? G0 : G, 0.0, G);
+      if (rc == MLN_OK) rc = launch_add_diag(ctx, G, m, ldg, 1.0);
+      if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, G, m, ldg);
+      // L_B^-T L_B^-1 C                                                conditional.py:64-65
+      if (rc == MLN_OK) rc = triinv_build(ctx, G, m, ldg, true, true, &tb);
+      if (rc == MLN_OK) rc = triinv_solve_left(ctx, tb, C + c0, nc, p);
+      if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, tb, C + c0, nc, p);
+      if (gi + 1 < n_groups) { (void)hipStreamSynchronize(ctx->stream); triinv_free(&tb); }
+    }
+  }
+  // weights = Lp^-T (.)
   if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, C, p, p);
   if (rc == MLN_OK) chk(hipMemcpyAsync(W, C, sizeof(double) * (size_t)m * p, hipMemcpyDefault, ctx->stream));
   // with_uncertainty state of the noisy landmark conditional: L = Lp and Cs = Lp L_B   conditional.py:571-577
@@ -1661,7 +1778,7 @@ static int sparse_solve_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const dou
   }
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&tb);
-  void* ptrs[] = {G, R, C, parts};
+  void* ptrs[] = {G, G0, R, C, parts, d_scale, d_col};
   for (void* q : ptrs) if (q) (void)mln_dfree(q);
   fit_free(f);
   return rc;
@@ -1670,12 +1787,18 @@ static int sparse_solve_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const dou
 extern "C" int mln_sparse_solve(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                                 int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
                                 double sigma, double jitter, double* W) {
-  return sparse_solve_impl(ctx, cov, x, n_local, d, xu, m, y, p, mu, sigma, jitter, W, nullptr, nullptr);
+  return sparse_solve_impl(ctx, cov, x, n_local, d, xu, m, y, p, mu, &sigma, MLN_SIGMA_SCALAR, jitter, W, nullptr, nullptr);
 }
 
 extern "C" int mln_sparse_solve_factors(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                                         int32_t d, const double* xu, int64_t m, const double* y, int64_t p,
                                         double mu, double sigma, double jitter, double* W, double* Lp_out,
                                         double* Cs_out) {
-  return sparse_solve_impl(ctx, cov, x, n_local, d, xu, m, y, p, mu, sigma, jitter, W, Lp_out, Cs_out);
+  return sparse_solve_impl(ctx, cov, x, n_local, d, xu, m, y, p, mu, &sigma, MLN_SIGMA_SCALAR, jitter, W, Lp_out, Cs_out);
+}
+
+extern "C" int mln_sparse_solve_noise(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
+                                      int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
+                                      const double* sigma, int32_t sigma_kind, double jitter, double* W) {
+  return sparse_solve_impl(ctx, cov, x, n_local, d, xu, m, y, p, mu, sigma, sigma_kind, jitter, W, nullptr, nullptr);
 }

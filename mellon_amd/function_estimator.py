@@ -83,6 +83,26 @@ class FunctionEstimator(BaseEstimator):
             raise ValueError("The estimator has not been fitted: call fit(x, y) first.")
         return self.conditional
 
+    def leverage(self, X=None):
+        """Leverage with the fitted sigma, at the training cells by default (function_estimator.py:443-459)."""
+        return self.predict.leverage(self.x if X is None else X)
+
+    def loo_residuals_squared(self, X=None, y=None):
+        """Squared leave-one-out residuals r^2 / (1 - h)^2; without arguments the values cached by an
+        `obs_variance=True` fit (function_estimator.py:461-487)."""
+        if X is None and y is None:
+            if hasattr(self.predict, "_corrected_r2"):
+                return self.predict._corrected_r2
+            X, y = self.x, self.y
+        else:
+            X = self.x if X is None else X
+            y = self.y if y is None else y
+        return self.predict.loo_residuals_squared(X, y)
+
+    def get_obs_variance(self, X=None):
+        """Smoothed observation variance of the fitted predictor (function_estimator.py:489-505)."""
+        return self.predict.obs_variance(self.x if X is None else X)
+
     def fit_predict(self, x=None, y=None, Xnew=None):
         self.fit(x, y)
         return self.predict(self.x if Xnew is None else validate_array(Xnew, "Xnew"))

@@ -629,6 +629,43 @@ def sigma_to_y_cov_factor(sigma, y_cov_factor, n):
     raise ValueError("Unsupported sigma dimensions in the oracle.")
 
 
+def is_per_feature_sigma(sigma, y):
+    """conditional.py:13-36: sigma of shape (p,), (1, p) or (n, p) against a 2-D y of shape (n, p)."""
+    if sigma is None or np.ndim(sigma) == 0:
+        return False
+    sigma, y = np.asarray(sigma), np.asarray(y)
+    if sigma.ndim == 2 and sigma.shape[0] == 1 and y.ndim == 2 and sigma.shape[1] == y.shape[1]:
+        return True
+    if sigma.ndim == 2 and y.ndim == 2 and sigma.shape == y.shape:
+        return True
+    return bool(sigma.ndim == 1 and y.ndim == 2 and sigma.shape[0] == y.shape[1])
+
+
+def normalize_per_feature_sigma(sigma):
+    """conditional.py:39-43: (1, p) -> (p,)."""
+    sigma = np.asarray(sigma, dtype=np.float64)
+    return sigma[0] if sigma.ndim == 2 and sigma.shape[0] == 1 else sigma
+
+
+def _sigma_columns(sigma_pf, p):
+    """The per-column noise the reference's vmap hands to each solve: sigma_pf[g] for (p,), sigma_pf[:, g] for (n, p)."""
+    return [sigma_pf[:, g] if sigma_pf.ndim == 2 else sigma_pf[g] for g in range(p)]
+
+
+def _full_leverage_one(K, sigma_g, jitter):
+    """conditional.py:313-323,385-403: 1 - sigma^2 diag((K + sigma^2 I + jitter I)^-1)."""
+    n = K.shape[0]
+    Lf = _sp_cholesky(stabilize(K + sigma_g ** 2 * np.eye(n), jitter), lower=True)
+    Linv = _sp_trsolve(Lf, np.eye(n), lower=True)
+    return 1 - sigma_g ** 2 * np.sum(np.square(Linv), axis=0)
+
+
+def _landmarks_leverage_one(B, K_uu, sigma_g, jitter):
+    """conditional.py:600-605,672-685: diag(B M^-1 B^T), M = sigma^2 K_uu + B^T B + jitter I."""
+    M = stabilize(sigma_g ** 2 * K_uu + B.T @ B, jitter)
+    return np.sum((B @ np.linalg.inv(M)) * B, axis=1)
+
+
 def sparse_solve(Lp, A, r_l, A_l):
     """conditional.py:57-66."""
     LBB = stabilize(A_l @ A.T, 1.0)
@@ -696,6 +733,14 @@ class Predictor:
         """base_predictor.py:263-288 -> conditional._leverage (:373-403 full: the training leverage whatever Xnew;
         :660-685 landmarks: diag(B M^-1 B^T), B = cov(Xnew, xu), M = sigma^2 K_uu + B^T B + jitter I)."""
         Xnew = ensure_2d(Xnew)
+        if np.ndim(self.sigma) >= 1:       # per-feature sigma: one column per output (conditional.py:389-397,672-680)
+            sig = normalize_per_feature_sigma(self.sigma)
+            if self.kind == "full":
+                K = self.cov_func(self.centers, self.centers)
+                return np.stack([_full_leverage_one(K, sg, self.jitter) for sg in sig], axis=1)
+            B = self.cov_func(Xnew, self.centers)
+            K_uu = self.L @ self.L.T if self.L is not None else self.cov_func(self.centers, self.centers)
+            return np.stack([_landmarks_leverage_one(B, K_uu, sg, self.jitter) for sg in sig], axis=1)
         s2 = float(self.sigma) ** 2
         if self.kind == "full":
             x = self.centers
@@ -755,32 +800,56 @@ class Predictor:
 
 def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTER,
                      y_is_mean=False, with_uncertainty=False, obs_variance=False):
-    """conditional.py:183-304 (non per-feature sigma)."""
+    """conditional.py:183-362, scalar and per-feature sigma."""
     x = ensure_2d(x)
-    if L is None:
-        if y_is_mean:
-            L = _get_L(x, cov_func, jitter)
-        else:
-            L = _get_L(x, cov_func, jitter, sigma_to_y_cov_factor(sigma, None, x.shape[0]))
-    r = y - mu
-    w = _sp_trsolve(L.T, _sp_trsolve(L, r, lower=True), lower=False)
-    pred = Predictor(cov_func, x, w, mu, x.shape[0])
-    pred.kind, pred.sigma, pred.jitter = "full", sigma, jitter
-    if obs_variance:                                          # conditional.py:305-362 (scalar sigma)
-        n = x.shape[0]
+    n = x.shape[0]
+    per_feature = is_per_feature_sigma(sigma, y)
+    if per_feature:                                            # conditional.py:239-251: one solve per output
         K = cov_func(x, x)
-        s2 = float(sigma) ** 2
-        Lv = _sp_cholesky(stabilize(K + s2 * np.eye(n), jitter), lower=True)
-        Linv = _sp_trsolve(Lv, np.eye(n), lower=True)
-        h = 1 - s2 * np.sum(np.square(Linv), axis=0)
-        r = y - (mu + K @ w)
-        if r.ndim > h.ndim:
-            h = h[..., None]
-        cr2 = r ** 2 / (1 - h) ** 2
+        sig_pf = normalize_per_feature_sigma(sigma)
+        r = y - mu
+        cols = []
+        for g, sg in enumerate(_sigma_columns(sig_pf, r.shape[1])):
+            Lg = _sp_cholesky(stabilize(K + np.diag(np.broadcast_to(sg ** 2, (n,))), jitter), lower=True)
+            cols.append(_sp_trsolve(Lg.T, _sp_trsolve(Lg, r[:, g], lower=True), lower=False))
+        w = np.stack(cols, axis=1)
+    else:
+        if L is None:
+            if y_is_mean:
+                L = _get_L(x, cov_func, jitter)
+            else:
+                L = _get_L(x, cov_func, jitter, sigma_to_y_cov_factor(sigma, None, n))
+        r = y - mu
+        w = _sp_trsolve(L.T, _sp_trsolve(L, r, lower=True), lower=False)
+    pred = Predictor(cov_func, x, w, mu, n)
+    pred.kind, pred.sigma, pred.jitter = "full", sigma, jitter
+    if obs_variance:                                          # conditional.py:305-362
+        K = cov_func(x, x)
+        resid = y - (mu + K @ w)
         pred.variance_mu = 0.0
-        pred.variance_weights = _sp_trsolve(Lv.T, _sp_trsolve(Lv, cr2, lower=True), lower=False)
-    if with_uncertainty:                                      # conditional.py:285-304
-        ycf = sigma_to_y_cov_factor(sigma, None, x.shape[0])
+        if np.ndim(sigma) >= 1:
+            sig_pf = normalize_per_feature_sigma(sigma)
+            h = np.stack([_full_leverage_one(K, sg, jitter) for sg in sig_pf], axis=1)
+            cr2 = resid ** 2 / (1 - h) ** 2
+            cols = []
+            for g, sg in enumerate(sig_pf):
+                Lv = _sp_cholesky(stabilize(K + sg ** 2 * np.eye(n), jitter), lower=True)
+                cols.append(_sp_trsolve(Lv.T, _sp_trsolve(Lv, cr2[:, g], lower=True), lower=False))
+            pred.variance_weights = np.stack(cols, axis=1)
+        else:
+            s2 = float(sigma) ** 2
+            Lv = _sp_cholesky(stabilize(K + s2 * np.eye(n), jitter), lower=True)
+            Linv = _sp_trsolve(Lv, np.eye(n), lower=True)
+            h = 1 - s2 * np.sum(np.square(Linv), axis=0)
+            if resid.ndim > h.ndim:
+                h = h[..., None]
+            cr2 = resid ** 2 / (1 - h) ** 2
+            pred.variance_weights = _sp_trsolve(Lv.T, _sp_trsolve(Lv, cr2, lower=True), lower=False)
+        pred.corrected_r2 = cr2
+    if with_uncertainty and per_feature:                       # conditional.py:288-291: noise-free covariance, no W
+        pred.L = _get_L(x, cov_func, jitter)
+    elif with_uncertainty:                                     # conditional.py:292-304
+        ycf = sigma_to_y_cov_factor(sigma, None, n)
         pred.L = L
         pred.W = _sp_trsolve(L.T, _sp_trsolve(L, ycf, lower=True), lower=False)
     return pred
@@ -788,35 +857,54 @@ def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTE
 
 def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
                           jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False, obs_variance=False):
-    """conditional.py:455-547 (scalar / element-wise sigma)."""
+    """conditional.py:455-645 (scalar, element-wise and per-feature sigma)."""
     x, xu = ensure_2d(x), ensure_2d(xu)
     Kuf = cov_func(xu, x)
     if Lp is None:
         Lp = _get_L(xu, cov_func, jitter)
     A = _sp_trsolve(Lp, Kuf, lower=True)
     r = y - mu
-    if y_is_mean:
-        r_l, A_l = r, A
+    per_feature = is_per_feature_sigma(sigma, y)
+    L_B = None
+    if per_feature:                                            # conditional.py:526-545
+        sig_pf = normalize_per_feature_sigma(sigma)
+        cols = []
+        for g, sg in enumerate(_sigma_columns(sig_pf, r.shape[1])):
+            s2 = np.square(sg)
+            cols.append(sparse_solve(Lp, A, r[:, g] / s2, A / s2)[0])
+        w = np.stack(cols, axis=1)
     else:
-        sigma2 = np.square(sigma)            # conditional.py:155-159
-        r_l, A_l = r / sigma2, A / sigma2
-    w, L_B = sparse_solve(Lp, A, r_l, A_l)
+        if y_is_mean:
+            r_l, A_l = r, A
+        else:
+            sigma2 = np.square(sigma)        # conditional.py:155-159
+            r_l, A_l = r / sigma2, A / sigma2
+        w, L_B = sparse_solve(Lp, A, r_l, A_l)
     pred = Predictor(cov_func, xu, w, mu, x.shape[0])
     pred.kind, pred.sigma, pred.jitter = "landmarks", sigma, jitter
-    if obs_variance:                                          # conditional.py:589-645 (scalar sigma)
-        s2 = float(sigma) ** 2
+    if obs_variance:                                          # conditional.py:589-645
         B = Kuf.T
-        M = stabilize(s2 * (Lp @ Lp.T) + B.T @ B, jitter)
-        h = np.sum((B @ np.linalg.inv(M)) * B, axis=1)
+        K_uu = Lp @ Lp.T
         rr = y - (mu + B @ w)
-        if rr.ndim > h.ndim:
-            h = h[..., None]
-        cr2 = rr ** 2 / (1 - h) ** 2
         pred.variance_mu = 0.0
-        pred.variance_weights, _ = sparse_solve(Lp, A, cr2 / s2, A / s2)
+        if np.ndim(sigma) >= 1:
+            sig_pf = normalize_per_feature_sigma(sigma)
+            h = np.stack([_landmarks_leverage_one(B, K_uu, sg, jitter) for sg in sig_pf], axis=1)
+            cr2 = rr ** 2 / (1 - h) ** 2
+            pred.variance_weights = np.stack(
+                [sparse_solve(Lp, A, cr2[:, g] / sg ** 2, A / sg ** 2)[0] for g, sg in enumerate(sig_pf)], axis=1)
+        else:
+            s2 = float(sigma) ** 2
+            h = _landmarks_leverage_one(B, K_uu, float(sigma), jitter)
+            if rr.ndim > h.ndim:
+                h = h[..., None]
+            cr2 = rr ** 2 / (1 - h) ** 2
+            pred.variance_weights, _ = sparse_solve(Lp, A, cr2 / s2, A / s2)
+        pred.corrected_r2 = cr2
     if with_uncertainty:                                      # conditional.py:571-577
         pred.L = Lp
-        pred.Cs = Lp @ L_B
+        if not per_feature:
+            pred.Cs = Lp @ L_B
     return pred
 
 

@@ -505,3 +505,105 @@ def test_edge_cases(mellon):
     assert rel_max(eo.predict(odd), do) < 1e-8
     assert rel_max(do, mo.density_fit(odd, landmarks=eo.landmarks, nn_distances=eo.nn_distances,
                                       lbfgsb_options=mo.LBFGSB_TIGHT).log_density_x) < 1e-5
+
+
+# --- noise models beyond one scalar: per-output ("per-gene"), per-cell, per-cell-and-output sigma -------------------
+def _noise_case(n=300, d=4, p=5, seed=11):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, p))) + 0.2 * rng.normal(size=(n, p))
+    sigma = np.array([0.5, 1.0, 0.5, 2.0, 1.0])[:p]          # repeated levels exercise the grouping
+    return X, Y, sigma
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_landmarks", [0, 40])
+def test_per_output_sigma_matches_oracle_and_per_column_fits(mellon, n_landmarks):
+    """One fit with a sigma per output (conditional.py:239-251,526-545) against the oracle, and -- the reference's own
+    property, tests/test_pergene_sigma.py:34-122 -- against scalar fits column by column at atol 1e-5."""
+    X, Y, sigma = _noise_case()
+    est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=n_landmarks, obs_variance=True).fit(X, Y)
+    ref = mo.function_fit(X, Y, sigma, n_landmarks=n_landmarks, landmarks=est.landmarks, ls=est.ls,
+                           obs_variance=True)
+    assert est.predict.per_feature_sigma
+    np.testing.assert_allclose(est.predict(X), ref(X), rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(est.leverage(), ref.leverage(X), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(est.loo_residuals_squared(), ref.corrected_r2, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(est.predict.loo_residuals_squared(X, Y), ref.loo_residuals_squared(X, Y),
+                               rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(est.get_obs_variance(), ref.obs_variance(X), rtol=1e-5, atol=1e-7)
+    lev = est.leverage(X)
+    assert lev.shape == Y.shape and np.all(lev >= 0) and np.all(lev < 1)
+    for g in range(Y.shape[1]):
+        one = mellon.FunctionEstimator(sigma=float(sigma[g]), n_landmarks=n_landmarks, landmarks=est.landmarks,
+                                           ls=est.ls, obs_variance=True).fit(X, Y[:, g])
+        np.testing.assert_allclose(est.predict(X)[:, g], one.predict(X), atol=1e-5)
+        np.testing.assert_allclose(lev[:, g], one.leverage(X), atol=1e-5)
+        np.testing.assert_allclose(est.get_obs_variance()[:, g], one.get_obs_variance(), atol=1e-5)
+    # (1, p) is the same model (tests/test_pergene_sigma.py:181-204)
+    row = mellon.FunctionEstimator(sigma=sigma[None, :], n_landmarks=n_landmarks, landmarks=est.landmarks,
+                                       ls=est.ls).fit(X, Y)
+    np.testing.assert_allclose(row.predict(X), est.predict(X), atol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_landmarks", [0, 40])
+def test_per_cell_and_per_cell_output_sigma_match_oracle(mellon, n_landmarks):
+    """Element-wise sigma (n,) with a 1-D y (conditional.py:155-159; full GP: y_cov_factor = diag(sigma), :118-119)
+    and sigma of y's shape (n, p) (the vmap over outputs of :239-251,526-545)."""
+    X, Y, _ = _noise_case()
+    rng = np.random.default_rng(5)
+    s_cell = rng.uniform(0.3, 1.5, size=X.shape[0])
+    est = mellon.FunctionEstimator(sigma=s_cell, n_landmarks=n_landmarks).fit(X, Y[:, 0])
+    ref = mo.function_fit(X, Y[:, 0], s_cell, n_landmarks=n_landmarks, landmarks=est.landmarks, ls=est.ls)
+    np.testing.assert_allclose(est.predict(X), ref(X), rtol=1e-7, atol=1e-8)
+    s_full = rng.uniform(0.3, 1.5, size=Y.shape)
+    est2 = mellon.FunctionEstimator(sigma=s_full, n_landmarks=n_landmarks, landmarks=est.landmarks,
+                                        ls=est.ls).fit(X, Y)
+    ref2 = mo.function_fit(X, Y, s_full, n_landmarks=n_landmarks, landmarks=est.landmarks, ls=est.ls)
+    np.testing.assert_allclose(est2.predict(X), ref2(X), rtol=1e-7, atol=1e-8)
+    assert est2.predict.per_feature_sigma and not est.predict.per_feature_sigma
+
+
+@pytest.mark.gpu
+def test_per_output_sigma_with_uncertainty_state(mellon):
+    """with_uncertainty under a per-output sigma keeps the noise-free factor and no W / Cs (conditional.py:288-291,
+    571-577)."""
+    X, Y, sigma = _noise_case(n=200)
+    for m in (0, 30):
+        est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=m, predictor_with_uncertainty=True).fit(X, Y)
+        ref = mo.function_fit(X, Y, sigma, n_landmarks=m, landmarks=est.landmarks, ls=est.ls, with_uncertainty=True)
+        np.testing.assert_allclose(est.predict.covariance(X, diag=True), ref.covariance(X, diag=True),
+                                   rtol=1e-6, atol=1e-8)
+        assert not hasattr(est.predict, "Cs") and not hasattr(est.predict, "W")
+
+
+@pytest.mark.gpu
+def test_per_output_sigma_survives_the_json_wire_format(mellon):
+    """sigma, per_feature_sigma and the variance weights are predictor state (conditional.py:266-275,549-559)."""
+    X, Y, sigma = _noise_case(n=120)
+    est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=25, obs_variance=True).fit(X, Y)
+    back = mellon.Predictor.from_json_str(est.predict.to_json())
+    assert back.per_feature_sigma and np.allclose(back.sigma, sigma)
+    np.testing.assert_allclose(back(X), est.predict(X), rtol=1e-12)
+    np.testing.assert_allclose(back.leverage(X), est.predict.leverage(X), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(back.obs_variance(X), est.predict.obs_variance(X), rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_many_noise_levels_take_the_spectral_route_and_match_oracle(mellon):
+    """More than 32 distinct per-output levels: mln_sparse_solve_noise replaces the per-level Cholesky of
+    A A^T / s^2 + I by one eigendecomposition of A A^T; same weights as the reference's per-column `_sparse_solve`."""
+    rng = np.random.default_rng(21)
+    n, d, p, m = 500, 3, 48, 60
+    X = rng.normal(size=(n, d))
+    Y = np.cos(X @ rng.normal(size=(d, p))) + 0.1 * rng.normal(size=(n, p))
+    sigma = rng.uniform(0.05, 2.0, size=p)
+    est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=m).fit(X, Y)
+    ref = mo.function_fit(X, Y, sigma, n_landmarks=m, landmarks=est.landmarks, ls=est.ls)
+    np.testing.assert_allclose(est.predict(X), ref(X), rtol=1e-7, atol=1e-8)
+    # and the same numbers as the per-level route, reached by repeating each level so that runs stay <= 32
+    few = np.repeat(sigma[:24], 2)
+    a = mellon.FunctionEstimator(sigma=few, n_landmarks=m, landmarks=est.landmarks, ls=est.ls).fit(X, Y).predict(X)
+    b = mo.function_fit(X, Y, few, n_landmarks=m, landmarks=est.landmarks, ls=est.ls)(X)
+    np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-8)

@@ -320,3 +320,48 @@ def test_predictor_gradient_restatement_is_consistent():
     xq = rng.normal(size=(7, 3))
     analytic = np.einsum("j,jik->ik", w, pred.cov_func.k_grad(c)(xq))    # symmetry: d k(x, c_j)/dx = k_grad(c)(x)[j]
     assert np.abs(pred.gradient(xq) - analytic).max() < 1e-8
+
+
+# --- per-feature ("per-gene") and per-cell noise: the reference's own properties (tests/test_pergene_sigma.py) ---------
+def _multi_output_data(n=50, d=2, p=3, seed=42):
+    rng = np.random.default_rng(seed)
+    return rng.normal(size=(n, d)), rng.normal(size=(n, p)), np.array([0.5, 1.0, 2.0])[:p]
+
+
+@pytest.mark.parametrize("n_landmarks", [0, 15])
+def test_oracle_pergene_matches_per_column_scalar(n_landmarks):
+    """tests/test_pergene_sigma.py:34-132: predictions, leverage, obs_variance and loo residuals of one fit with a
+    sigma per output equal the per-column scalar fits at atol 1e-5."""
+    X, Y, sigma = _multi_output_data()
+    pg = mo.function_fit(X, Y, sigma, n_landmarks=n_landmarks, obs_variance=True)
+    assert pg.leverage(X).shape == Y.shape
+    for g in range(Y.shape[1]):
+        sc = mo.function_fit(X, Y[:, g], float(sigma[g]), n_landmarks=n_landmarks, obs_variance=True)
+        np.testing.assert_allclose(pg(X)[:, g], sc(X), atol=1e-5)
+        np.testing.assert_allclose(pg.leverage(X)[:, g], sc.leverage(X), atol=1e-5)
+        np.testing.assert_allclose(pg.obs_variance(X)[:, g], sc.obs_variance(X), atol=1e-5)
+        np.testing.assert_allclose(pg.loo_residuals_squared(X, Y)[:, g], sc.loo_residuals_squared(X, Y[:, g]), atol=1e-5)
+    lev = pg.leverage(X)
+    assert np.all(lev >= 0) and np.all(lev < 1)                     # test_pergene_sigma.py:125-135
+
+
+def test_oracle_sigma_shape_rules():
+    """tests/test_pergene_sigma.py:160-220: (p,) with n == p is per-feature, (1, p) == (p,), (n, 1) is not."""
+    y = np.ones((30, 3))
+    assert mo.is_per_feature_sigma(np.ones(3), y) and mo.is_per_feature_sigma(np.ones((1, 3)), y)
+    assert mo.is_per_feature_sigma(np.ones((30, 3)), y)
+    assert not mo.is_per_feature_sigma(np.ones((30, 1)), y) and not mo.is_per_feature_sigma(0.5, y)
+    assert mo.is_per_feature_sigma(np.ones(20), np.ones((20, 20)))
+    X, Y, sigma = _multi_output_data(30)
+    a = mo.function_fit(X, Y, sigma[None, :], n_landmarks=0)(X)
+    b = mo.function_fit(X, Y, sigma, n_landmarks=0)(X)
+    np.testing.assert_allclose(a, b, atol=1e-10)
+
+
+@pytest.mark.parametrize("n_landmarks", [0, 15])
+def test_oracle_per_cell_sigma_constant_equals_scalar(n_landmarks):
+    """An element-wise sigma vector that happens to be constant is the scalar model (conditional.py:155-159)."""
+    X, Y, _ = _multi_output_data()
+    a = mo.function_fit(X, Y[:, 0], np.full(50, 0.7), n_landmarks=n_landmarks)(X)
+    b = mo.function_fit(X, Y[:, 0], 0.7, n_landmarks=n_landmarks)(X)
+    np.testing.assert_allclose(a, b, atol=1e-9)
