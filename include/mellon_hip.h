@@ -278,6 +278,22 @@ int mln_sparse_solve_noise(mln_ctx* ctx, const mln_kernel_desc* cov, const doubl
                            int32_t d, const double* xu, int64_t m, const double* y, int64_t p, double mu,
                            const double* sigma, int32_t sigma_kind, double jitter, double* W /* m x p */);
 
+/* Full GP conditioned on p outputs with one noise level each (conditional.py:239-251; leverage :313-323,385-403;
+ * HC3 residuals :330-333; variance weights :338-350) from ONE eigendecomposition K = U diag(lam) U^T of the n x n
+ * kernel matrix: (K + (sigma_j^2 + jitter) I)^-1 = U diag(1 / (lam + sigma_j^2 + jitter)) U^T.
+ * W: n x p.  leverage, corrected_r2, variance_W: n x p or NULL (each needs the one before it).                         */
+int mln_full_conditional_noise(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, int32_t d,
+                               const double* y, int64_t p, double mu, const double* sigma /* p */, double jitter,
+                               double* W, double* leverage, double* corrected_r2, double* variance_W);
+
+/* Leverage of the landmark conditional for p noise levels at once (conditional.py:660-685 applied per level by the
+ * vmap of :672-680):  out[i][j] = b_i^T (sigma_j^2 K_uu + B^T B + jitter I)^-1 b_i  with B = cov(x, xu) over the cells
+ * of all ranks, b_i the rows of this rank, and K_uu = Lk Lk^T given by its lower factor Lk (m x m; the predictor's L).
+ * One eigendecomposition of L^T L + jitter Lk^-1 Lk^-T (L = B Lk^-T) serves every level.                              */
+int mln_landmark_leverage(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local, int32_t d,
+                          const double* xu, int64_t m, const double* Lk, const double* sigma, int64_t p,
+                          double jitter, double* out /* n_local x p */);
+
 /* a-13: mean(Xnew) = mu + cov(Xnew, centers) W   (conditional.py:366-373,651-658,899-906).
  * centers: m x d (landmarks or, full GP, the training cells); W: m x p; out: n_new x p.
  * cov(Xnew, centers) is never materialised for p == 1.                                         */

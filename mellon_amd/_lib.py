@@ -92,6 +92,8 @@ SYMBOLS = [
     ("mln_sparse_solve_factors", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dbl, _dbl, _dp,
                                            _dp, _dp]),
     ("mln_sparse_solve_noise", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp, _i32, _dbl, _dp]),
+    ("mln_full_conditional_noise", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, _dbl, _dp, _dp, _dp, _dp]),
+    ("mln_landmark_leverage", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _dp, _i64, _dbl, _dp]),
     ("mln_predict_mean", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _dbl, _dp]),
     ("mln_predict_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i32, _dp]),
     ("mln_predict_mean_covariance", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _i64, _i32, _dp]),
@@ -408,6 +410,42 @@ class Context:
                                                     m, y2.ctypes.data, p, float(mu), sig.ctypes.data, int(kind),
                                                     float(jitter), W.ctypes.data), jitter=jitter)
         return W
+
+    def full_conditional_noise(self, desc, x, y, mu, sigma, jitter, leverage=False, obs_variance=False):
+        """Full-GP weights for outputs with one noise level each, from one eigendecomposition of K(x, x).
+        Returns W, or (W, leverage), or (W, leverage, corrected_r2, variance_W)."""
+        x = _as2d(x)
+        y2 = np.ascontiguousarray(_f64(y))
+        sig = _f64(np.atleast_1d(sigma))
+        n, p = y2.shape
+        if sig.shape != (p,) or x.shape[0] != n:
+            raise ValueError("sigma must hold one value per output column and x, y must agree in length")
+        leverage = leverage or obs_variance
+        W = np.empty((n, p))
+        H = np.empty((n, p)) if leverage else None
+        Cr, VW = (np.empty((n, p)), np.empty((n, p))) if obs_variance else (None, None)
+        ptr = lambda a: None if a is None else a.ctypes.data
+        self._check(self.lib.mln_full_conditional_noise(self.handle, desc.ref, _ptr(x), n, x.shape[1], y2.ctypes.data, p,
+                                                        float(mu), sig.ctypes.data, float(jitter), W.ctypes.data,
+                                                        ptr(H), ptr(Cr), ptr(VW)), jitter=jitter)
+        if obs_variance:
+            return W, H, Cr, VW
+        return (W, H) if leverage else W
+
+    def landmark_leverage(self, desc, x, xu, Lk, sigma, jitter):
+        """(n, p) leverage of the landmark conditional for the p noise levels `sigma`, K_uu = Lk Lk^T."""
+        x = x if isinstance(x, DeviceArray) else _as2d(x)
+        xu = _as2d(xu)
+        Lk = _f64(Lk)
+        sig = _f64(np.atleast_1d(sigma))
+        m = xu.shape[0]
+        if Lk.shape != (m, m):
+            raise ValueError(f"Lk has shape {Lk.shape}, expected {(m, m)}")
+        out = np.empty((x.shape[0], sig.shape[0]), dtype=np.float64)
+        self._check(self.lib.mln_landmark_leverage(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1], _ptr(xu), m,
+                                                   Lk.ctypes.data, sig.ctypes.data, sig.shape[0], float(jitter),
+                                                   out.ctypes.data), jitter=jitter)
+        return out
 
     def diag_overlap(self, n, m, d, gram_rows):
         out = np.zeros(6)

@@ -17,6 +17,7 @@ from .decomposition import FactorL, FactorLp
 from .util import DEFAULT_JITTER, ensure_2d
 
 DEFAULT_SIGMA = 0
+SPECTRAL_MIN_LEVELS = 8      # distinct noise levels above which the landmark leverage goes spectral
 logger = logging.getLogger("mellon")
 
 
@@ -106,6 +107,10 @@ def _full_leverage_any(x, cov_func, sigma, jitter):
     if np.ndim(sigma) == 0:
         return _full_leverage(x, cov_func, float(sigma), jitter)[0]
     sig, levels = _per_output_levels(sigma)
+    if len(levels) > SPECTRAL_MIN_LEVELS:
+        ctx = _lib.default_context()
+        return ctx.full_conditional_noise(cov_func.lower(x.shape[1]), x, np.zeros((x.shape[0], sig.shape[0])), 0.0,
+                                          sig, jitter, leverage=True)[1]
     h = np.empty((x.shape[0], sig.shape[0]))
     for value, cols in levels:
         h[:, cols] = _full_leverage(x, cov_func, value, jitter)[0][:, None]
@@ -120,6 +125,13 @@ def _landmarks_leverage_any(Xnew, xu, cov_func, sigma, jitter, L=None):
     sig, levels = _per_output_levels(sigma)
     ctx = _lib.default_context()
     desc = cov_func.lower(xu.shape[1])
+    if L is not None and len(levels) > SPECTRAL_MIN_LEVELS:
+        # many levels and K_uu = L L^T with a known factor: one eigendecomposition for all of them
+        per_level = ctx.landmark_leverage(desc, Xnew, xu, np.asarray(L), [v for v, _ in levels], jitter)
+        h = np.empty((Xnew.shape[0], sig.shape[0]))
+        for k, (_, cols) in enumerate(levels):
+            h[:, cols] = per_level[:, k:k + 1]
+        return h
     S = ctx.kernel_gram(desc, Xnew, xu)
     K_uu = (np.asarray(L) @ np.asarray(L).T) if L is not None else ctx.kernel_matrix(desc, xu, xu)
     kdiag = cov_func.diag(Xnew)
@@ -192,7 +204,14 @@ class _FullConditional:
             sig = _normalize_per_feature_sigma(sigma)
             desc = cov_func.lower(x.shape[1])
             weights = np.empty((n, yh.shape[1]))
-            if sig.ndim == 1:
+            if sig.ndim == 1 and len(_per_output_levels(sigma)[1]) > SPECTRAL_MIN_LEVELS:
+                # many levels: one eigendecomposition of K(x, x) serves them all
+                out = ctx.full_conditional_noise(desc, x, yh, mu, sig, jitter, obs_variance=bool(obs_variance))
+                if obs_variance:
+                    weights, var_state = out[0], (out[2], out[3])
+                else:
+                    weights = out
+            elif sig.ndim == 1:
                 if obs_variance:
                     var_state = (np.empty_like(yh), np.empty_like(weights))      # corrected r^2, variance weights
                 for value, cols in _per_output_levels(sigma)[1]:

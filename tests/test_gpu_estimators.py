@@ -607,3 +607,45 @@ def test_many_noise_levels_take_the_spectral_route_and_match_oracle(mellon):
     a = mellon.FunctionEstimator(sigma=few, n_landmarks=m, landmarks=est.landmarks, ls=est.ls).fit(X, Y).predict(X)
     b = mo.function_fit(X, Y, few, n_landmarks=m, landmarks=est.landmarks, ls=est.ls)(X)
     np.testing.assert_allclose(a, b, rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_spectral_landmark_leverage_matches_the_literal_formula(mellon):
+    """mln_landmark_leverage (one eigendecomposition for every level) against conditional.py:660-685 evaluated level
+    by level in NumPy, and the per-output obs_variance fit that uses it against the oracle."""
+    from mellon_amd import _lib
+    rng = np.random.default_rng(33)
+    n, d, p, m = 600, 3, 20, 50
+    X = rng.normal(size=(n, d))
+    Y = np.cos(X @ rng.normal(size=(d, p))) + 0.1 * rng.normal(size=(n, p))
+    sigma = rng.uniform(0.05, 2.0, size=p)
+    est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=m, obs_variance=True).fit(X, Y)
+    cov, xu = est.cov_func, est.landmarks
+    Lp = mo._get_L(xu, mo.Matern52(ls=est.ls), 1e-6)
+    B = mo.Matern52(ls=est.ls)(X, xu)
+    want = np.stack([mo._landmarks_leverage_one(B, Lp @ Lp.T, s, 1e-6) for s in sigma], axis=1)
+    got = _lib.default_context().landmark_leverage(cov.lower(d), X, xu, Lp, sigma, 1e-6)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+    ref = mo.function_fit(X, Y, sigma, n_landmarks=m, landmarks=xu, ls=est.ls, obs_variance=True)
+    np.testing.assert_allclose(est.loo_residuals_squared(), ref.corrected_r2, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(est.get_obs_variance(), ref.obs_variance(X), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_full_gp_many_noise_levels_spectral_route_matches_oracle(mellon):
+    """More than 8 distinct per-output levels on the full GP: mln_full_conditional_noise (one eigendecomposition of
+    K(x, x)) against the reference's one-Cholesky-per-output arithmetic, for weights, leverage, HC3 residuals and the
+    variance GP; and against the per-level device route on a sigma with few levels."""
+    rng = np.random.default_rng(8)
+    n, d, p = 250, 3, 12
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, p))) + 0.2 * rng.normal(size=(n, p))
+    sigma = rng.uniform(0.1, 2.0, size=p)
+    est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=0, obs_variance=True).fit(X, Y)
+    ref = mo.function_fit(X, Y, sigma, n_landmarks=0, ls=est.ls, obs_variance=True)
+    np.testing.assert_allclose(est.predict(X), ref(X), rtol=1e-7, atol=1e-8)
+    np.testing.assert_allclose(est.leverage(), ref.leverage(X), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(est.loo_residuals_squared(), ref.corrected_r2, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(est.get_obs_variance(), ref.obs_variance(X), rtol=1e-5, atol=1e-7)
+    plain = mellon.FunctionEstimator(sigma=sigma, n_landmarks=0, ls=est.ls).fit(X, Y)
+    np.testing.assert_allclose(plain.predict(X), ref(X), rtol=1e-7, atol=1e-8)

@@ -32,3 +32,13 @@ print(f"scalar sigma: {time.perf_counter() - t0:.3f} s")
 sigma = np.full(p, 0.1)
 W1 = _sparse_solve_per_output(ctx, desc, xd, xu, Y, 0.0, sigma, 1e-6)
 print("max |W_per_output(const) - W_scalar| / max|W| =", np.abs(W1 - W0).max() / np.abs(W0).max())
+
+# whole per-gene fit with smoothed observation variance: weights, leverage (n x p), HC3 residuals, variance weights
+sigma = 0.1 * (1 + np.arange(p) / p)
+for rep in range(2):
+    t0 = time.perf_counter()
+    est = mellon_amd.FunctionEstimator(sigma=sigma, n_landmarks=m, landmarks=xu, ls=8.0, obs_variance=True).fit(X, Y)
+    print(f"FunctionEstimator(sigma[p], obs_variance=True).fit: {time.perf_counter() - t0:.3f} s")
+t0 = time.perf_counter()
+est = mellon_amd.FunctionEstimator(sigma=0.1, n_landmarks=m, landmarks=xu, ls=8.0, obs_variance=True).fit(X, Y)
+print(f"FunctionEstimator(scalar sigma, obs_variance=True).fit: {time.perf_counter() - t0:.3f} s")
