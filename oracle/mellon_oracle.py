@@ -18,9 +18,14 @@ path is mapped as follows (all unpinned in the reference's pyproject.toml:24-27)
 
 PARITY PINNING.  The reference holds exactly one set of absolute golden numbers
 on this path: tests/test_reference_results.py:26-63,93-130 (FunctionEstimator,
-n=50).  tests/test_oracle_golden.py reproduces them with this file plus
-oracle/jax_prng.py (distance, Matern52, ls heuristic, full Cholesky solve and
-the sparse `_sparse_solve` are pinned that way).  The DensityEstimator
+n=50: predictions, leverage and smoothed observation variance, full and sparse).
+tests/test_oracle_golden.py reproduces all six arrays with this file plus
+oracle/jax_prng.py (distance, Matern52, ls heuristic, full Cholesky solve, the
+sparse `_sparse_solve`, both hat-matrix diagonals and the HC3 variance GP are
+pinned that way).  The per-feature ("per-gene") sigma branches are pinned by the
+reference's own property -- one fit with a sigma per output equals the scalar
+fits column by column, tests/test_pergene_sigma.py -- re-expressed in
+tests/test_oracle.py on top of the golden-pinned scalar branches.  The DensityEstimator
 log-density itself has no absolute golden vector anywhere in the reference
 ("parity unpinned" for that output): it is anchored by the pinned building
 blocks above, by the reference's analytic/property tests re-expressed in
