@@ -95,8 +95,21 @@ class Predictor:
                 "Please ensure that the input data has the same number of features as the training data.")
         return x
 
+    def _has_per_feature_sigma(self):
+        """Whether the predictor was fitted with a sigma per output (base_predictor.py:360-362)."""
+        return bool(getattr(self, "per_feature_sigma", False))
+
     def covariance(self, x, diag=True, noise_free=False):
-        """k(x,x) - A A^T with A = cov(x, centers) L^-T (variances when diag=True)."""
+        """k(x,x) - A A^T with A = cov(x, centers) L^-T (variances when diag=True).  A predictor fitted with a
+        per-feature sigma only has the noise-free covariance and asks for `noise_free=True`
+        (base_predictor.py:364-420)."""
+        if self._has_per_feature_sigma() and not noise_free:
+            raise ValueError(
+                "This predictor was fitted with per-feature sigma, so the "
+                "covariance is noise-free (sigma=0) and does not include "
+                "observation noise. Pass noise_free=True to acknowledge this "
+                "and obtain the noise-free covariance, then account for "
+                "observation noise separately (e.g., via obs_variance).")
         x = self._check_features(x)
         if not hasattr(self, "L") or self.L is None:
             raise ValueError("The predictor was computed without covariance. "

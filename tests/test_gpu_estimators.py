@@ -573,9 +573,24 @@ def test_per_output_sigma_with_uncertainty_state(mellon):
     for m in (0, 30):
         est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=m, predictor_with_uncertainty=True).fit(X, Y)
         ref = mo.function_fit(X, Y, sigma, n_landmarks=m, landmarks=est.landmarks, ls=est.ls, with_uncertainty=True)
-        np.testing.assert_allclose(est.predict.covariance(X, diag=True), ref.covariance(X, diag=True),
+        with pytest.raises(ValueError, match="noise_free=True"):        # tests/test_perobservation_sigma.py:57-66
+            est.predict.covariance(X[:5], diag=True)
+        np.testing.assert_allclose(est.predict.covariance(X, diag=True, noise_free=True), ref.covariance(X, diag=True),
                                    rtol=1e-6, atol=1e-8)
+        assert est.predict.covariance(X[:5], diag=False, noise_free=True).shape == (5, 5)
         assert not hasattr(est.predict, "Cs") and not hasattr(est.predict, "W")
+        # (n, p) sigma: same noise-free covariance whatever the noise (tests/test_perobservation_sigma.py:69-112)
+        s_np = np.random.default_rng(2).uniform(0.3, 2.0, size=Y.shape)
+        a = mellon.FunctionEstimator(sigma=s_np, n_landmarks=m, landmarks=est.landmarks, ls=est.ls,
+                                     predictor_with_uncertainty=True).fit(X, Y)
+        assert a.predict._has_per_feature_sigma()
+        cov_a = a.predict.covariance(X[:10], diag=True, noise_free=True)
+        assert cov_a.shape == (10,) and np.all(cov_a > 0)
+        np.testing.assert_allclose(cov_a, est.predict.covariance(X[:10], diag=True, noise_free=True), atol=1e-9)
+        for g in range(Y.shape[1]):                                     # :40-54: (n, p) == column-wise (n,) fits
+            one = mellon.FunctionEstimator(sigma=s_np[:, g], n_landmarks=m, landmarks=est.landmarks,
+                                           ls=est.ls).fit(X, Y[:, g])
+            np.testing.assert_allclose(a.predict(X)[:, g], one.predict(X), atol=1e-5)
 
 
 @pytest.mark.gpu
