@@ -304,11 +304,15 @@ class _LandmarksConditional:
                                        L=getattr(self, "L", None))
 
     def __init__(self, x, xu, y, mu, cov_func, L=None, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
-                 y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False):
+                 y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None):
         _reject_extras(with_uncertainty, obs_variance)
-        if with_uncertainty and y_is_mean:
-            raise NotImplementedError("with_uncertainty for a landmark conditional on a mean (needs y_cov_factor, "
-                                      "conditional.py:579-587) is outside the accelerated path.")
+        if with_uncertainty and y_is_mean and y_cov_factor is None:
+            # y_cov_factor = L diag(std): the factor of the covariance of the mean on the training cells
+            # (inference.compute_parameter_cov_factor, inference.py:357-372)
+            if parameter_std is None or L is None:
+                raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
+                                 "`pre_transformation_std` to quantify uncertainty of the prediction.")
+            y_cov_factor = np.asarray(L, dtype=np.float64) * np.asarray(parameter_std, dtype=np.float64)[None, :]
         ctx = _lib.default_context()
         xh = x if isinstance(x, _lib.DeviceArray) else np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
@@ -372,6 +376,10 @@ class _LandmarksConditional:
             if Cs_h is not None:
                 self.Cs = Cs_h
                 self._state_variables |= {"Cs"}
+            if y_is_mean:     # conditional.py:579-587: W = Lp^-T L_B^-T L_B^-1 A y_cov_factor, the sigma = 1 solve
+                self.W = ctx.sparse_solve(desc, xh, xu, np.ascontiguousarray(y_cov_factor, dtype=np.float64), 0.0,
+                                          1.0, jitter)
+                self._state_variables |= {"W"}
 
 
 class _LandmarksConditionalCholesky:

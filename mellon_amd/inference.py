@@ -193,8 +193,10 @@ def _dispatch(classes, x, landmarks, pre_transformation, pre_transformation_std,
         return Cholesky(landmarks, pre_transformation, mu, cov_func, x.shape[0], Lp, sigma=sigma, jitter=jitter,
                         y_is_mean=y_is_mean, with_uncertainty=with_uncertainty, obs_variance=obs_variance)
     logger.debug("Using LandmarksConditional GP.")
+    # inference.py:488-492: y_cov_factor = L diag(pre_transformation_std) -- formed where it is consumed
     return Landmarks(x, landmarks, y, mu, cov_func, L, sigma=sigma, jitter=jitter, y_is_mean=y_is_mean,
-                     with_uncertainty=with_uncertainty, obs_variance=obs_variance)
+                     with_uncertainty=with_uncertainty, obs_variance=obs_variance,
+                     parameter_std=pre_transformation_std if with_uncertainty else None)
 
 
 def compute_conditional(x, landmarks, pre_transformation, pre_transformation_std, y, mu, cov_func, L, Lp=None,

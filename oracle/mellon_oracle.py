@@ -861,7 +861,8 @@ def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTE
 
 
 def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
-                          jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False, obs_variance=False):
+                          jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False, obs_variance=False,
+                          y_cov_factor=None):
     """conditional.py:455-645 (scalar, element-wise and per-feature sigma)."""
     x, xu = ensure_2d(x), ensure_2d(xu)
     Kuf = cov_func(xu, x)
@@ -910,6 +911,9 @@ def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
         pred.L = Lp
         if not per_feature:
             pred.Cs = Lp @ L_B
+        if y_is_mean:                                         # conditional.py:579-587
+            Cm = _sp_trsolve(L_B, A @ y_cov_factor, lower=True)
+            pred.W = _sp_trsolve(Lp.T, _sp_trsolve(L_B.T, Cm, lower=False), lower=False)
     return pred
 
 

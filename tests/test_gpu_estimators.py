@@ -664,3 +664,25 @@ def test_full_gp_many_noise_levels_spectral_route_matches_oracle(mellon):
     np.testing.assert_allclose(est.get_obs_variance(), ref.obs_variance(X), rtol=1e-5, atol=1e-7)
     plain = mellon.FunctionEstimator(sigma=sigma, n_landmarks=0, ls=est.ls).fit(X, Y)
     np.testing.assert_allclose(plain.predict(X), ref(X), rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_nystroem_predictor_with_uncertainty(mellon, small_x):
+    """gp_type sparse_nystroem with predictor_with_uncertainty: the landmark conditional on a mean carries
+    L = Lp, Cs = Lp L_B and W = Lp^-T L_B^-T L_B^-1 A (L diag(std)) (conditional.py:571-587, inference.py:357-372,
+    488-492); invariant to the column signs of the Nystroem factor."""
+    est = mellon.DensityEstimator(n_landmarks=20, rank=8, predictor_with_uncertainty=True).fit(small_x)
+    assert str(est.gp_type).endswith("sparse_nystroem") or "nystroem" in str(est.gp_type).lower()
+    pred = est.predict
+    ref = mo.density_fit(small_x, n_landmarks=20, rank=8, landmarks=est.landmarks, lbfgsb_options=mo.LBFGSB_TIGHT)
+    V, _ = mo.nn_likelihood_constants(ref.nn_distances, ref.d)
+    std = mo.laplace_std(ref.pre_transformation, ref.L, ref.mu, V)
+    op = mo.landmarks_conditional(small_x, est.landmarks, ref.log_density_x, ref.mu, ref.cov_func, None, sigma=0.0,
+                                  y_is_mean=True, with_uncertainty=True, y_cov_factor=ref.L * std[None, :])
+    xq = small_x[:41] * 1.05 - 0.02
+    assert rel_max(pred(xq), op(xq)) < 1e-5
+    assert np.abs(pred.covariance(xq) - op.covariance(xq)).max() < 1e-6
+    assert rel_max(pred.mean_covariance(xq), op.mean_covariance(xq)) < 1e-4
+    assert rel_max(pred.uncertainty(xq, diag=False), op.uncertainty(xq, diag=False)) < 1e-4
+    again = mellon.Predictor.from_json_str(pred.to_json())
+    assert np.allclose(again.uncertainty(xq), pred.uncertainty(xq), rtol=1e-10)
