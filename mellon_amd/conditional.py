@@ -188,7 +188,7 @@ class _FullConditional:
         return _full_leverage_any(self.x, self.cov_func, sigma, self.jitter)
 
     def __init__(self, x, y, mu, cov_func, L=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER, y_cov_factor=None,
-                 y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None):
+                 y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None, factor=None):
         _reject_extras(with_uncertainty, obs_variance)
         x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         ctx = _lib.default_context()
@@ -275,7 +275,16 @@ class _FullConditional:
                 self._corrected_r2 = _hc3(yh - self._mean(x), h)
                 self.variance_weights = fit_v.weights_full(self._corrected_r2, self.variance_mu)
             self._state_variables |= {"variance_weights", "variance_mu"}
-        if with_uncertainty and parameter_std is not None:
+        if with_uncertainty and parameter_std is not None and fit is not None \
+                and np.ndim(parameter_std) == 1 and np.shape(parameter_std)[0] != n and factor is not None:
+            # low-rank factor (full_nystroem): y_cov_factor = L_lowrank diag(std) is n x rank and
+            # W = Lf^-T Lf^-1 y_cov_factor with Lf the recomputed full factor (conditional.py:292-304)
+            Lh = fit.Lp()
+            ycf = np.asarray(factor, dtype=np.float64) * np.asarray(parameter_std, dtype=np.float64)[None, :]
+            self.L = Lh
+            self.W = ctx.trsm_lower(Lh, ctx.trsm_lower(Lh, np.ascontiguousarray(ycf)), trans=True)
+            self._state_variables |= {"L", "W"}
+        elif with_uncertainty and parameter_std is not None:
             # y_cov_factor = L diag(std) (inference.compute_parameter_cov_factor, inference.py:357-372)
             _attach_uncertainty(self, fit.Lp(), _parameter_std(parameter_std, x.shape[0]))
         elif with_uncertainty and per_feature:

@@ -181,7 +181,7 @@ def _dispatch(classes, x, landmarks, pre_transformation, pre_transformation_std,
         logger.debug("Using FullConditional GP.")
         return Full(x, y, mu, cov_func, Lp, sigma=sigma, jitter=jitter, y_is_mean=y_is_mean,
                     with_uncertainty=with_uncertainty and (pre_transformation_std is not None or not y_is_mean),
-                    obs_variance=obs_variance, parameter_std=pre_transformation_std)
+                    obs_variance=obs_variance, parameter_std=pre_transformation_std, factor=L)
     landmarks = ensure_2d(landmarks)
     if pre_transformation is not None and np.shape(pre_transformation)[0] == landmarks.shape[0]:
         logger.debug("Using LandmarksConditionalCholesky GP.")

@@ -686,3 +686,22 @@ def test_nystroem_predictor_with_uncertainty(mellon, small_x):
     assert rel_max(pred.uncertainty(xq, diag=False), op.uncertainty(xq, diag=False)) < 1e-4
     again = mellon.Predictor.from_json_str(pred.to_json())
     assert np.allclose(again.uncertainty(xq), pred.uncertainty(xq), rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_full_nystroem_predictor_with_uncertainty(mellon, small_x):
+    """gp_type full_nystroem with predictor_with_uncertainty: the full conditional recomputes chol(K + jitter I) and
+    W = Lf^-T Lf^-1 (L diag(std)) with the n x rank Nystroem factor L (conditional.py:292-304, inference.py:442-445)."""
+    est = mellon.DensityEstimator(n_landmarks=0, rank=12, predictor_with_uncertainty=True).fit(small_x)
+    assert "nystroem" in str(est.gp_type).lower()
+    pred = est.predict
+    ref = mo.density_fit(small_x, n_landmarks=0, rank=12, lbfgsb_options=mo.LBFGSB_TIGHT)
+    V, _ = mo.nn_likelihood_constants(ref.nn_distances, ref.d)
+    std = mo.laplace_std(ref.pre_transformation, ref.L, ref.mu, V)
+    Lf = mo._get_L(small_x, ref.cov_func, 1e-6)
+    op = ref.predict
+    op.L = Lf
+    op.W = np.linalg.solve(Lf.T, np.linalg.solve(Lf, ref.L * std[None, :]))
+    xq = small_x[:33] * 1.05 - 0.02
+    assert np.abs(pred.covariance(xq) - op.covariance(xq)).max() < 1e-6
+    assert rel_max(pred.mean_covariance(xq), op.mean_covariance(xq)) < 1e-4
