@@ -705,3 +705,19 @@ def test_full_nystroem_predictor_with_uncertainty(mellon, small_x):
     xq = small_x[:33] * 1.05 - 0.02
     assert np.abs(pred.covariance(xq) - op.covariance(xq)).max() < 1e-6
     assert rel_max(pred.mean_covariance(xq), op.mean_covariance(xq)) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,p,m", [(45, 1, 40, 17), (33, 3, 9, 0), (70, 2, 1, 16), (129, 5, 35, 33)])
+def test_noise_models_on_odd_shapes(mellon, n, d, p, m):
+    """Ragged sizes (m, n, p not multiples of any tile; p = 1; 1-D inputs) through every per-output route --
+    per-level and spectral, landmarks and full -- against the oracle."""
+    rng = np.random.default_rng(n + p)
+    X = rng.normal(size=(n, d))
+    Y = np.sin(X @ rng.normal(size=(d, p))) + 0.3 * rng.normal(size=(n, p))
+    sigma = rng.uniform(0.2, 1.5, size=p)
+    est = mellon.FunctionEstimator(sigma=sigma, n_landmarks=m, obs_variance=True).fit(X, Y)
+    ref = mo.function_fit(X, Y, sigma, n_landmarks=m, landmarks=est.landmarks, ls=est.ls, obs_variance=True)
+    np.testing.assert_allclose(est.predict(X), ref(X), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(est.leverage(), ref.leverage(X), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(est.get_obs_variance(), ref.obs_variance(X), rtol=1e-4, atol=1e-7)
