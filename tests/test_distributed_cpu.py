@@ -82,6 +82,25 @@ def _worker(rank, world, port, out_dir):
     rows = Ls @ Ug[:, -p:]
     assert np.abs(rows @ rows.T - ref_nys[lo:hi] @ ref_nys[lo:hi].T).max() < 1e-9 * np.abs(ref_nys @ ref_nys.T).max()
 
+    # landmark conditional of the function estimator (config 5; conditional.py:57-66,526-545,660-685): A A^T and
+    # A (y - mu) are all-reduced once; with one sigma per output the replicated eigendecomposition of A A^T serves
+    # every level, and the leverage of a rank's own cells comes from the all-reduced  L^T L + jitter Lp^-1 Lp^-T
+    pq = 5
+    rng = np.random.default_rng(3)
+    Yall = np.sin(x @ rng.normal(size=(d, pq))) + 0.1 * rng.normal(size=(n, pq))
+    sig = np.array([0.3, 0.5, 0.3, 1.0, 2.0])
+    want = mo.landmarks_conditional(x, lm, Yall, 0.0, cov, Lp=ref.Lp, sigma=sig, with_uncertainty=True)   # carries L = Lp
+    G0 = comm.allreduce_sum(Ls.T @ Ls)
+    C0 = comm.allreduce_sum(Ls.T @ Yall[lo:hi])
+    lam, U = np.linalg.eigh(G0)
+    Wsh = sla.solve_triangular(ref.Lp.T, U @ ((U.T @ (C0 / sig ** 2)) / (np.maximum(lam, 0)[:, None] / sig ** 2 + 1)),
+                               lower=False)
+    assert np.abs(Wsh - want.weights).max() < 1e-8 * np.abs(want.weights).max()
+    Li = sla.solve_triangular(ref.Lp, np.eye(m), lower=True)
+    theta, Vv = np.linalg.eigh(G0 + 1e-6 * (Li @ Li.T))
+    h_own = ((Ls @ Vv) ** 2) @ (1.0 / (sig[None, :] ** 2 + theta[:, None]))
+    assert np.abs(h_own - want.leverage(x)[lo:hi]).max() < 1e-7
+
     Ls = Ls_own                                             # the real thing: every rank factors its own cells
     res = mo.minimize_lbfgsb(sharded, z0, mo.LBFGSB_TIGHT)  # every rank runs the same host optimiser
     dens = comm.allgather_rows(Ls @ res.pre_transformation + mu)
