@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmellon_hip.so")
 SOURCES = ["api.hip", "alloc.hip", "cov_grad.hip", "cov_kernels.hip", "dgemm.hip", "diag.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "objective.hip"]
-HEADERS = ["mln_internal.h", "linalg.h", os.path.join("..", "..", "include", "mellon_hip.h")]
+HEADERS = ["mln_internal.h", "linalg.h", "cov_program.h", os.path.join("..", "..", "include", "mellon_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

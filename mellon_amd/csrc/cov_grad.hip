@@ -11,7 +11,9 @@
 // the d-long dot products.  The n x m x d tensor of k_grad exists only because the API returns it;
 // the predictor gradient contracts it with the weights on the fly: one thread per query row, the row
 // and its gradient accumulator in LDS ([dim][row]: conflict-free), centre tiles broadcast from LDS.
+#include <cstdlib>
 #include "mln_internal.h"
+#include "cov_program.h"
 
 namespace {
 
@@ -58,40 +60,6 @@ __device__ __forceinline__ void leaf_value_grad(const DevLeaf& lf, double xx, do
       *k = pow(b, -lf.alpha);
       *g = -r * inv_ls * pow(b, -lf.alpha - 1.0) * inv;
     }
-  }
-}
-
-__device__ __forceinline__ double pick4(const double v[MLN_MAX_LEAVES], int id) {
-  double r = v[0];
-#pragma unroll
-  for (int l = 1; l < MLN_MAX_LEAVES; ++l) r = (id == l) ? v[l] : r;
-  return r;
-}
-
-// a[l] = dP/dk_l by forward-mode evaluation of the postfix program (base_cov.py:341-364 Add,
-// :407-438 Mul, :481-497 Pow with a scalar exponent).
-__device__ __forceinline__ void program_adjoints(const DevCov& cov, const double kv[MLN_MAX_LEAVES],
-                                                 double a[MLN_MAX_LEAVES]) {
-#pragma unroll
-  for (int l = 0; l < MLN_MAX_LEAVES; ++l) {
-    a[l] = 0.0;
-    if (l >= cov.n_leaves) continue;
-    double v0 = 0.0, t0 = 0.0, v1 = 0.0, t1 = 0.0, v2 = 0.0, t2 = 0.0;   // top, below, below
-    for (int t = 0; t < cov.n_toks; ++t) {
-      const int op = cov.tok_op[t];
-      if (op == MLN_OP_LEAF || op == MLN_OP_CONST) {
-        v2 = v1; t2 = t1; v1 = v0; t1 = t0;
-        if (op == MLN_OP_CONST) { v0 = cov.tok_val[t]; t0 = 0.0; }
-        else { const int id = cov.tok_leaf[t]; v0 = pick4(kv, id); t0 = (id == l) ? 1.0 : 0.0; }
-      } else {
-        const double lv = v1, lt = t1, rv = v0, rt = t0;
-        if (op == MLN_OP_ADD) { v0 = lv + rv; t0 = lt + rt; }
-        else if (op == MLN_OP_MUL) { v0 = lv * rv; t0 = lt * rv + lv * rt; }
-        else { v0 = pow(lv, rv); t0 = rv * pow(lv, rv - 1.0) * lt; }
-        v1 = v2; t1 = t2;
-      }
-    }
-    a[l] = t0;
   }
 }
 
@@ -244,6 +212,11 @@ int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, in
   // single stationary leaf and enough pairs: covariance-tile pass + GEMM on the matrix cores (cov_kernels.hip)
   if (cov.n_toks == 1 && cov.leaves[0].kind != MLN_K_LINEAR && n * m >= (int64_t)1 << 16)
     return launch_predict_gradient_gemm(ctx, cov, x, n, c, m, d, w, out);
+  // composite program whose leaves are all stationary: the same idea with one coefficient matrix per leaf
+  bool stationary = cov.n_leaves >= 1;
+  for (int l = 0; l < cov.n_leaves; ++l) stationary = stationary && cov.leaves[l].kind != MLN_K_LINEAR;
+  if (stationary && n * m >= (int64_t)1 << 16 && !std::getenv("MELLON_AMD_GRAD_NO_GEMM"))
+    return launch_predict_gradient_gemm_multi(ctx, cov, x, n, c, m, d, w, out);
   const size_t lds = sizeof(double) * ((size_t)2 * d * GR + (size_t)GC * d + GC + (size_t)MLN_MAX_LEAVES * GC);
   if (lds > 160 * 1024) { mln_set_error(ctx, "predict_gradient: too many dimensions for the LDS layout"); return MLN_ERR_UNSUPPORTED; }
   MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_predict_gradient),

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "mln_internal.h"
+#include "cov_program.h"
 
 namespace {
 
@@ -331,6 +332,88 @@ __global__ void k_grad_combine(DevCov cov, const double* __restrict__ T, int64_t
   const DevLeaf lf = cov.leaves[0];
   for (int k = 0; k < lf.ndims; ++k)
     if (cov.dims[lf.dims_off + k] == dim) out[idx] = x[idx] * T[i * ldt + lf.ndims] - T[i * ldt + k];
+}
+
+// ---- predictor gradient, composite programs of stationary leaves (Add / Mul / Pow, e.g. the time-sensitive
+// product kernel):  grad_i = sum_l sum_j w_j (dP/dk_l)_ij g_l,ij (x_i - c_j)|dims_l.  One covariance-tile pass
+// writes Q_l = w_j (dP/dk_l) g_l for every leaf l (the leaf dot products stay in registers, the adjoints come
+// from the forward-mode evaluation of the program per element), then one GEMM T_l = Q_l [C|dims_l, 1] per leaf.
+__global__ __launch_bounds__(256) void k_grad_coeff_multi(DevCov cov, const double* __restrict__ x, int64_t n,
+                                                          const double* __restrict__ y, int64_t m, int d,
+                                                          const double* __restrict__ xx, int64_t xx_stride,
+                                                          const double* __restrict__ yy,
+                                                          const double* __restrict__ w, double* __restrict__ out,
+                                                          int64_t ldo, int64_t leaf_stride, int64_t tiles_n) {
+  __shared__ double xs[DK][TM + PADT];
+  __shared__ double ys[DK][TN + PADT];
+  const int64_t bid = blockIdx.x;
+  const int64_t row0 = (bid / tiles_n) * TM, col0 = (bid % tiles_n) * TN;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double acc[MLN_MAX_LEAVES][4][4], xr[MLN_MAX_LEAVES][4], yr[MLN_MAX_LEAVES][4];
+#pragma unroll
+  for (int l = 0; l < MLN_MAX_LEAVES; ++l) {
+    if (l >= cov.n_leaves) continue;            // uniform over the workgroup
+    leaf_dot(cov, cov.leaves[l], x, n, y, m, d, row0, col0, xs, ys, acc[l]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = row0 + ty * 4 + i;
+      xr[l][i] = (r < n) ? xx[(int64_t)l * xx_stride + r] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = col0 + tx * 4 + j;
+      yr[l][j] = (c < m) ? yy[(int64_t)l * m + c] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = row0 + ty * 4 + i;
+    if (r >= n) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = col0 + tx * 4 + j;
+      if (c >= ldo) continue;
+      double kv[MLN_MAX_LEAVES], gf[MLN_MAX_LEAVES], a[MLN_MAX_LEAVES];
+#pragma unroll
+      for (int l = 0; l < MLN_MAX_LEAVES; ++l) {
+        kv[l] = 0.0; gf[l] = 0.0;
+        if (l >= cov.n_leaves) continue;
+        kv[l] = leaf_value(cov.leaves[l], xr[l][i], yr[l][j], acc[l][i][j]);
+        gf[l] = leaf_grad_coeff(cov.leaves[l], xr[l][i], yr[l][j], acc[l][i][j]);
+      }
+      program_adjoints(cov, kv, a);
+      const double wc = (c < m) ? w[c] : 0.0;
+#pragma unroll
+      for (int l = 0; l < MLN_MAX_LEAVES; ++l)
+        if (l < cov.n_leaves) out[(int64_t)l * leaf_stride + r * ldo + c] = wc * a[l] * gf[l];
+    }
+  }
+}
+
+// Cext[j][k] = c_j[dims_l[k]] (k < nd_l), Cext[j][nd_l] = 1, zero up to ldc -- for leaf `leaf`
+__global__ void k_grad_centres_leaf(DevCov cov, int leaf, const double* __restrict__ c, int64_t m, int d,
+                                    double* __restrict__ cext, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * ldc) return;
+  const int64_t j = idx / ldc;
+  const int k = (int)(idx % ldc);
+  const DevLeaf lf = cov.leaves[leaf];
+  double v = 0.0;
+  if (k < lf.ndims) v = c[j * d + cov.dims[lf.dims_off + k]];
+  else if (k == lf.ndims) v = 1.0;
+  cext[idx] = v;
+}
+
+// out[i][dims_l[k]] += x_i[dims_l[k]] T_i,nd - T_i,k   (one thread per (i, k); leaves run one after the other)
+__global__ void k_grad_combine_leaf(DevCov cov, int leaf, const double* __restrict__ T, int64_t ldt,
+                                    const double* __restrict__ x, int64_t rows, int d, double* __restrict__ out) {
+  const DevLeaf lf = cov.leaves[leaf];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * lf.ndims) return;
+  const int64_t i = idx / lf.ndims;
+  const int k = (int)(idx % lf.ndims);
+  const int dim = cov.dims[lf.dims_off + k];
+  out[i * d + dim] += x[i * d + dim] * T[i * ldt + lf.ndims] - T[i * ldt + k];
 }
 
 // mean_i = mu + sum_j cov(x_i, y_j) w_j   (conditional.py:899-906); K never leaves registers.
@@ -1029,6 +1112,54 @@ int launch_row_sumsq(mln_ctx* ctx, const double* T, int64_t ld, int64_t rows, in
   return MLN_OK;
 }
 
+
+// Predictor gradient of a composite program of stationary leaves through the matrix cores (see k_grad_coeff_multi).
+int launch_predict_gradient_gemm_multi(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,
+                                       int64_t m, int d, const double* w, double* out) {
+  if (n == 0) return MLN_OK;
+  const int L = cov.n_leaves;
+  int nd_max = 0;
+  for (int l = 0; l < L; ++l) nd_max = cov.leaves[l].ndims > nd_max ? cov.leaves[l].ndims : nd_max;
+  const int64_t ldq = ((m + 15) / 16) * 16, ldc = ((nd_max + 1 + 15) / 16) * 16;
+  const int64_t chunk = (n < 32768) ? n : 32768;
+  double *norms = nullptr, *Q = nullptr, *T = nullptr, *cext = nullptr;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)L * (size_t)(n + m), (void**)&norms));
+  double* xx = norms;                        // [L][n]
+  double* yy = norms + (size_t)L * n;        // [L][m]
+  MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
+  MLN_TRY(sqnorms(ctx, cov, c, m, d, yy));
+  const int64_t leaf_stride = chunk * ldq;
+  MLN_HIP(ctx, mln_dmalloc((void**)&Q, sizeof(double) * (size_t)L * leaf_stride));
+  MLN_HIP(ctx, mln_dmalloc((void**)&T, sizeof(double) * (size_t)chunk * ldc));
+  MLN_HIP(ctx, mln_dmalloc((void**)&cext, sizeof(double) * (size_t)L * m * ldc));
+  int rc = MLN_OK;
+  for (int l = 0; l < L; ++l)
+    hipLaunchKernelGGL(k_grad_centres_leaf, dim3((unsigned)((m * ldc + 255) / 256)), dim3(256), 0, ctx->stream, cov, l, c,
+                       m, d, cext + (size_t)l * m * ldc, ldc);
+  MLN_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double) * (size_t)n * d, ctx->stream));
+  const int64_t tiles_n = (ldq + TN - 1) / TN;
+  for (int64_t r0 = 0; r0 < n && rc == MLN_OK; r0 += chunk) {
+    const int64_t rows = (n - r0 < chunk) ? (n - r0) : chunk;
+    const int64_t nblk = tiles_n * ((rows + TM - 1) / TM);
+    hipLaunchKernelGGL(k_grad_coeff_multi, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x + r0 * d, rows, c, m,
+                       d, xx + r0, n, yy, w, Q, ldq, leaf_stride, tiles_n);
+    for (int l = 0; l < L && rc == MLN_OK; ++l) {
+      const int nd = cov.leaves[l].ndims;
+      GemmArgs g{};
+      g.A = Q + (size_t)l * leaf_stride; g.lda = ldq; g.ta = 0; g.B = cext + (size_t)l * m * ldc; g.ldb = ldc; g.tb = 0;
+      g.C = T; g.ldc = ldc; g.M = rows; g.N = nd + 1; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.split_k = 1;
+      rc = launch_dgemm(ctx, g);
+      if (rc != MLN_OK) break;
+      hipLaunchKernelGGL(k_grad_combine_leaf, dim3((unsigned)((rows * nd + 255) / 256)), dim3(256), 0, ctx->stream, cov, l,
+                         T, ldc, x + r0 * d, rows, d, out + r0 * d);
+    }
+  }
+  hipError_t e = hipGetLastError();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(Q); (void)mln_dfree(T); (void)mln_dfree(cext);
+  if (rc == MLN_OK && e != hipSuccess) rc = mln_hip_fail(ctx, e, "predict_gradient_gemm_multi", __FILE__, __LINE__);
+  return rc;
+}
 
 // Fast predictor gradient for single stationary-leaf kernels (see k_grad_coeff): row chunks of 32768.
 int launch_predict_gradient_gemm(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,

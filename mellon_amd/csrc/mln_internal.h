@@ -103,6 +103,8 @@ int launch_kernel_grad(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t
                        int d, int exact_denominator, double* out);
 int launch_predict_gradient_gemm(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,
                                  int64_t m, int d, const double* w, double* out);   // single stationary leaf
+int launch_predict_gradient_gemm_multi(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,
+                                       int64_t m, int d, const double* w, double* out);   // stationary leaves, any program
 int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c, int64_t m,
                             int d, const double* w, double* out);
 

@@ -558,6 +558,10 @@ def test_predict_gradient_matches_contracted_k_grad(ctx, n, m, d):
     if d >= 3:
         kernels.append(cov.Matern52(1.5 * np.sqrt(d), active_dims=slice(None, -1)) * cov.ExpQuad(1.2, active_dims=-1))
         kernels.append(cov.Matern32(2.0, active_dims=[0, 2]) + 0.5 * cov.Linear(3.0))
+        # composite programs of stationary leaves take the one-coefficient-matrix-per-leaf GEMM route above 2^16 pairs
+        kernels.append((cov.Matern52(2.0 * np.sqrt(d)) * cov.RatQuad(1.5, 3.0 * np.sqrt(d))) ** 2.0)
+        kernels.append(cov.Matern52(2.0, active_dims=slice(0, 2)) * cov.ExpQuad(1.0, active_dims=slice(1, 3))
+                       + 0.3 * cov.Matern32(0.7 * np.sqrt(d)))
     for k in kernels:
         g = ctx.predict_gradient(k.lower(d), xq, c, w)
         ref = np.einsum("j,jik->ik", w, _pair(k).k_grad(c)(xq))     # d k(x_i, c_j)/dx_i = k_grad(c)(x)[j, i]
