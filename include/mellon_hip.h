@@ -177,6 +177,11 @@ int mln_kernel_grad(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, i
 int mln_predict_gradient(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
                          int32_t d, const double* centers, int64_t m, const double* W /* m */,
                          double* out /* n_new x d */);
+/* Hessian of the mean at every row of xnew, out: n_new x d x d (base_predictor.py:507-521: jacfwd(jacrev(_mean));
+ * here the closed-form second derivatives of the kernels, contracted with the weights on the matrix cores).      */
+int mln_predict_hessian(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new, int32_t d,
+                        const double* centers, int64_t m, const double* W /* m */, double* out);
+
 
 /* ---- Nystroem rank reduction (decomposition.py:23-76,126-171,213-266) ---------------------------
  * mln_eigh replaces jax.numpy.linalg.eigh at decomposition.py:50 (_eigendecomposition): A (m x m,

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_kernel_grad", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_predict_gradient", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _dp]),
+    ("mln_predict_hessian", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _dp]),
     ("mln_kernel_gram", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp]),
     ("mln_nn_distances", C.c_int, [_vp, _dp, _i64, _dp, _i64, _i32, _i64, _dp]),
     ("mln_kmeans", C.c_int, [_vp, _dp, _i64, _i32, _i64, _i64, _i32, _dbl, _dp, C.POINTER(_i32), C.POINTER(_dbl)]),
@@ -293,6 +294,20 @@ class Context:
         out = np.empty((n_new, d), dtype=np.float64)
         self._check(self.lib.mln_predict_gradient(self.handle, desc.ref, _ptr(xnew), n_new, d, _ptr(centers),
                                                   centers.shape[0], Wd.ctypes.data, out.ctypes.data))
+        return out
+
+
+    def predict_hessian(self, desc, xnew, centers, W):
+        """Hessian of the predictive mean at each query point: (n_new, d, d)."""
+        xnew = xnew if isinstance(xnew, DeviceArray) else _as2d(xnew)
+        centers = centers if isinstance(centers, DeviceArray) else _as2d(centers)
+        Wd = _f64(W)
+        if Wd.ndim != 1 or Wd.shape[0] != centers.shape[0]:
+            raise NotImplementedError("hessians are available for single-output predictors (weights of shape (m,))")
+        n_new, d = xnew.shape
+        out = np.empty((n_new, d, d), dtype=np.float64)
+        self._check(self.lib.mln_predict_hessian(self.handle, desc.ref, _ptr(xnew), n_new, d, _ptr(centers),
+                                                 centers.shape[0], Wd.ctypes.data, out.ctypes.data))
         return out
 
     def nn_distances(self, x, y=None, self_offset=0):

@@ -139,11 +139,18 @@ class Predictor:
         """covariance + mean_covariance (base_predictor.py:390-428)."""
         return self.covariance(x, diag=diag) + self.mean_covariance(x, diag=diag)
 
-    def _unavailable(self, *a, **k):
-        raise NotImplementedError("This predictor method is outside the accelerated path "
-                                  "(hessians / leverage / obs_variance: SURVEY.md S8f).")
+    def hessian(self, x, jit=True):
+        """Hessian of the predicted mean at each row of x, shape x.shape + (d,) (base_predictor.py:507-521).  The
+        reference applies jacfwd(jacrev(.)); here the closed-form second derivatives of the kernels are contracted
+        with the weights on the device.  `jit` is accepted and ignored."""
+        x = self._check_features(x)
+        return _lib.default_context().predict_hessian(self.cov_func.lower(self.n_input_features), x, self.centers,
+                                                      self.weights)
 
-    hessian = hessian_log_determinant = _unavailable
+    def hessian_log_determinant(self, x, jit=True):
+        """(signs, log |det|) of the Hessian at each row of x (base_predictor.py:523-539)."""
+        sign, logdet = np.linalg.slogdet(self.hessian(x))
+        return sign, logdet
 
     # -- leverage / observation variance (base_predictor.py:263-355) -------------------------------------------
     def leverage(self, x):
@@ -267,6 +274,11 @@ class ExpPredictor(Predictor):
     def gradient(self, x, jit=True):
         return np.exp(Predictor.mean(self, x))[:, None] * Predictor.gradient(self, x)
 
+    def hessian(self, x, jit=True):
+        """Hessian of exp(f): e^f (H_f + grad f grad f^T)."""
+        g = Predictor.gradient(self, x)
+        return np.exp(Predictor.mean(self, x))[:, None, None] * (Predictor.hessian(self, x) + g[:, :, None] * g[:, None, :])
+
 
 class PredictorTime(Predictor):
     """Predictor whose last input column is time (reference base_predictor.py:872-948)."""
@@ -287,6 +299,15 @@ class PredictorTime(Predictor):
     def gradient(self, x, time=None, jit=True):
         """Gradient with respect to the state columns at the given time(s) (base_predictor.py:1094-1124)."""
         return Predictor.gradient(self, self._with_time(x, time))[:, :-1]
+
+    def hessian(self, x, time=None, jit=True):
+        """Hessian with respect to the state columns at the given time(s) (base_predictor.py:1127-1159)."""
+        return Predictor.hessian(self, self._with_time(x, time))[:, :-1, :-1]
+
+    def hessian_log_determinant(self, x, time=None, jit=True):
+        """base_predictor.py:1162-1194."""
+        sign, logdet = np.linalg.slogdet(self.hessian(x, time))
+        return sign, logdet
 
     def time_derivative(self, x, time=None, jit=True):
         """Derivative with respect to time (base_predictor.py:1052-1091)."""

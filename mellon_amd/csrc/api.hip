@@ -380,6 +380,25 @@ extern "C" int mln_predict_gradient(mln_ctx* ctx, const mln_kernel_desc* cov, co
   return o.commit();
 }
 
+extern "C" int mln_predict_hessian(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xnew, int64_t n_new,
+                                   int32_t d, const double* centers, int64_t m, const double* W, double* out) {
+  if (!ctx) return MLN_ERR_ARG;
+  if (n_new < 0 || m < 1 || d < 1) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (n_new == 0) return MLN_OK;
+  if (!xnew || !out || !centers || !W) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevCov dc;
+  MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  DevIn dx, dc_, dw;
+  DevOut o;
+  MLN_TRY(dx.init(ctx, xnew, (size_t)n_new * d));
+  MLN_TRY(dc_.init(ctx, centers, (size_t)m * d));
+  MLN_TRY(dw.init(ctx, W, (size_t)m));
+  MLN_TRY(o.init(ctx, out, (size_t)n_new * d * d));
+  MLN_TRY(launch_predict_hessian(ctx, dc, dx.dev, n_new, dc_.dev, m, d, dw.dev, o.dev));
+  return o.commit();
+}
+
 static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
                    int64_t ldg);
 static int64_t pad16(int64_t m);

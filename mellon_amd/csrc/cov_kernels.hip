@@ -8,6 +8,7 @@
 // same registers -- the n x m distance matrix never exists in HBM.  d <= 51 is too skinny for
 // the fp64 MFMA (same rate as v_fma_f64 on gfx950) to pay, so this is a VALU kernel.
 #include <cstdlib>
+#include <vector>
 
 #include "mln_internal.h"
 #include "cov_program.h"
@@ -414,6 +415,172 @@ __global__ void k_grad_combine_leaf(DevCov cov, int leaf, const double* __restri
   const int k = (int)(idx % lf.ndims);
   const int dim = cov.dims[lf.dims_off + k];
   out[i * d + dim] += x[i * d + dim] * T[i * ldt + lf.ndims] - T[i * ldt + k];
+}
+
+// ---- predictor Hessian (base_predictor.py:507-521: jacfwd(jacrev(mean))) --------------------------------------
+// With leaf gradients  grad k_l = gam_l (sig_l x - c)|dims_l  (stationary: gam = g, sig = 1; Linear: gam = -1/ls,
+// sig = 0) and leaf Hessians  g_l I|dims_l + h_l (x - c)(x - c)^T|dims_l  (stationary only):
+//   H_i = sum_j w_j [ sum_l a_l g_l I_l + sum_l (a_l h_l + a_ll gam_l^2) dl dl^T
+//                     + sum_{l<l'} a_ll' gam_l gam_l' (dl dl'^T + dl' dl^T) ],   a_l = dP/dk_l, a_ll' = d2P/dk_l dk_l'
+// One covariance-tile pass writes the coefficient matrices (Qd_l and one Qp per leaf pair); every pair then is
+// ONE GEMM against [vec(c_l c_l'^T) | c_l | c_l' | 1] and an expansion of (sig x - c)(sig' x - c)^T.
+__device__ __forceinline__ double leaf_hess_coeff(const DevLeaf& lf, double xx, double yy, double xy) {
+  const double inv_ls = lf.alpha_inv_ls[1];
+  const double sq = xx - 2.0 * xy + yy + 1e-12;
+  if (!(sq > 0.0) || lf.kind == MLN_K_LINEAR) return 0.0;
+  const double dist = sqrt(sq), il2 = inv_ls * inv_ls;
+  switch (lf.kind) {
+    case MLN_K_MATERN32: {                  // g = -f^2 e^{-f r}
+      const double f = 1.7320508075688772 * inv_ls;
+      return f * f * f * exp(-f * dist) / dist;
+    }
+    case MLN_K_MATERN52: {                  // g = -(f^2 / 3)(1 + f r) e^{-f r}
+      const double f = 2.23606797749979 * inv_ls, f2 = f * f;
+      return f2 * f2 * exp(-f * dist) * 0.3333333333333333;
+    }
+    case MLN_K_EXPQUAD: {                   // g = -k / ls^2
+      const double r = dist * inv_ls;
+      return exp(-0.5 * (r * r)) * il2 * il2;
+    }
+    case MLN_K_EXPONENTIAL: {               // g = -k / (2 ls r)
+      const double e = exp(-0.5 * dist * inv_ls);
+      return e * (0.25 * il2 / sq + 0.5 * inv_ls / (sq * dist));
+    }
+    default: {                              // RatQuad: g = -b^{-alpha-1} / ls^2
+      const double r = dist * inv_ls, b = r * r / (2.0 * lf.alpha) + 1.0;
+      return (lf.alpha + 1.0) / lf.alpha * pow(b, -lf.alpha - 2.0) * il2 * il2;
+    }
+  }
+}
+
+__host__ __device__ inline int hess_pair_slot(int L, int l, int lp) {   // l <= lp: slots after the L diagonal ones
+  return L + l * L - (l * (l - 1)) / 2 + (lp - l);
+}
+
+__global__ __launch_bounds__(256) void k_hess_coeff(DevCov cov, const double* __restrict__ x, int64_t n,
+                                                    const double* __restrict__ y, int64_t m, int d,
+                                                    const double* __restrict__ xx, int64_t xx_stride,
+                                                    const double* __restrict__ yy,
+                                                    const double* __restrict__ w, double* __restrict__ out,
+                                                    int64_t ldo, int64_t slot_stride, int64_t tiles_n) {
+  __shared__ double xs[DK][TM + PADT];
+  __shared__ double ys[DK][TN + PADT];
+  const int64_t bid = blockIdx.x;
+  const int64_t row0 = (bid / tiles_n) * TM, col0 = (bid % tiles_n) * TN;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int L = cov.n_leaves;
+  double acc[MLN_MAX_LEAVES][4][4], xr[MLN_MAX_LEAVES][4], yr[MLN_MAX_LEAVES][4];
+#pragma unroll
+  for (int l = 0; l < MLN_MAX_LEAVES; ++l) {
+    if (l >= L) continue;
+    leaf_dot(cov, cov.leaves[l], x, n, y, m, d, row0, col0, xs, ys, acc[l]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t r = row0 + ty * 4 + i;
+      xr[l][i] = (r < n) ? xx[(int64_t)l * xx_stride + r] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = col0 + tx * 4 + j;
+      yr[l][j] = (c < m) ? yy[(int64_t)l * m + c] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = row0 + ty * 4 + i;
+    if (r >= n) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t c = col0 + tx * 4 + j;
+      if (c >= ldo) continue;
+      double kv[MLN_MAX_LEAVES], gam[MLN_MAX_LEAVES], gd[MLN_MAX_LEAVES], hc[MLN_MAX_LEAVES];
+      double a1[MLN_MAX_LEAVES], a2[MLN_MAX_LEAVES][MLN_MAX_LEAVES];
+#pragma unroll
+      for (int l = 0; l < MLN_MAX_LEAVES; ++l) {
+        kv[l] = 0.0; gam[l] = 0.0; gd[l] = 0.0; hc[l] = 0.0;
+        if (l >= L) continue;
+        const DevLeaf lf = cov.leaves[l];
+        kv[l] = leaf_value(lf, xr[l][i], yr[l][j], acc[l][i][j]);
+        if (lf.kind == MLN_K_LINEAR) { gam[l] = -lf.alpha_inv_ls[1]; continue; }
+        gam[l] = gd[l] = leaf_grad_coeff(lf, xr[l][i], yr[l][j], acc[l][i][j]);
+        hc[l] = leaf_hess_coeff(lf, xr[l][i], yr[l][j], acc[l][i][j]);
+      }
+      program_second(cov, kv, a1, a2);
+      const double wc = (c < m) ? w[c] : 0.0;
+      const int64_t at = r * ldo + c;
+#pragma unroll
+      for (int l = 0; l < MLN_MAX_LEAVES; ++l) {
+        if (l >= L) continue;
+        out[(int64_t)l * slot_stride + at] = wc * a1[l] * gd[l];
+#pragma unroll
+        for (int lp = l; lp < MLN_MAX_LEAVES; ++lp) {
+          if (lp >= L) continue;
+          const double v = (lp == l) ? a1[l] * hc[l] + a2[l][l] * gam[l] * gam[l] : a2[l][lp] * gam[l] * gam[lp];
+          out[(int64_t)hess_pair_slot(L, l, lp) * slot_stride + at] = wc * v;
+        }
+      }
+    }
+  }
+}
+
+// Cp[j] = [ c_j[dl[a]] c_j[dlp[b]] (a * nlp + b) | c_j[dl[a]] | c_j[dlp[b]] | 1 ], zero up to ldc
+__global__ void k_hess_centres(DevCov cov, int l, int lp, const double* __restrict__ c, int64_t m, int d,
+                               double* __restrict__ cp, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * ldc) return;
+  const int64_t j = idx / ldc;
+  const int k = (int)(idx % ldc);
+  const DevLeaf la = cov.leaves[l], lb = cov.leaves[lp];
+  const int na = la.ndims, nb = lb.ndims;
+  const double* cj = c + j * d;
+  double v = 0.0;
+  if (k < na * nb) v = cj[cov.dims[la.dims_off + k / nb]] * cj[cov.dims[lb.dims_off + k % nb]];
+  else if (k < na * nb + na) v = cj[cov.dims[la.dims_off + (k - na * nb)]];
+  else if (k < na * nb + na + nb) v = cj[cov.dims[lb.dims_off + (k - na * nb - na)]];
+  else if (k == na * nb + na + nb) v = 1.0;
+  cp[idx] = v;
+}
+
+// H_i[dl[a]][dlp[b]] (transpose = 0) or H_i[dlp[b]][dl[a]] (transpose = 1)
+//   += sig sig' s x_a x_b - sig x_a (Q c')_b - sig' (Q c)_a x_b + (Q c c'^T)_ab
+__global__ void k_hess_combine(DevCov cov, int l, int lp, int transpose, const double* __restrict__ T, int64_t ldt,
+                               const double* __restrict__ x, int64_t rows, int d, double* __restrict__ H) {
+  const DevLeaf la = cov.leaves[l], lb = cov.leaves[lp];
+  const int na = la.ndims, nb = lb.ndims;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * na * nb) return;
+  const int64_t i = idx / (na * nb);
+  const int ab = (int)(idx % (na * nb)), a = ab / nb, b = ab % nb;
+  const int da = cov.dims[la.dims_off + a], db = cov.dims[lb.dims_off + b];
+  const double sa = (la.kind == MLN_K_LINEAR) ? 0.0 : 1.0, sb = (lb.kind == MLN_K_LINEAR) ? 0.0 : 1.0;
+  const double* Ti = T + i * ldt;
+  const double xa = x[i * d + da], xb = x[i * d + db];
+  const double val = sa * sb * Ti[na * nb + na + nb] * xa * xb - sa * xa * Ti[na * nb + na + b]
+                     - sb * Ti[na * nb + a] * xb + Ti[ab];
+  double* Hi = H + i * (int64_t)d * d;
+  if (transpose) Hi[db * d + da] += val; else Hi[da * d + db] += val;
+}
+
+// H_i[dim][dim] += sum_j Qd[i][j] for the dims of one stationary leaf
+__global__ __launch_bounds__(256) void k_hess_diag(DevCov cov, int l, const double* __restrict__ Qd, int64_t ldq,
+                                                   int64_t m, int64_t rows, int d, double* __restrict__ H) {
+  __shared__ double red[256];
+  const int64_t i = blockIdx.x;
+  if (i >= rows) return;
+  double s = 0.0;
+  for (int64_t j = threadIdx.x; j < m; j += 256) s += Qd[i * ldq + j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  const DevLeaf lf = cov.leaves[l];
+  if (lf.kind == MLN_K_LINEAR) return;
+  for (int k = threadIdx.x; k < lf.ndims; k += 256) {
+    const int dim = cov.dims[lf.dims_off + k];
+    H[i * (int64_t)d * d + (int64_t)dim * d + dim] += red[0];
+  }
 }
 
 // mean_i = mu + sum_j cov(x_i, y_j) w_j   (conditional.py:899-906); K never leaves registers.
@@ -1112,6 +1279,80 @@ int launch_row_sumsq(mln_ctx* ctx, const double* T, int64_t ld, int64_t rows, in
   return MLN_OK;
 }
 
+
+// Hessian of the predicted mean at every row of x (see k_hess_coeff): out is n x d x d.
+int launch_predict_hessian(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c, int64_t m,
+                           int d, const double* w, double* out) {
+  if (n == 0) return MLN_OK;
+  const int L = cov.n_leaves;
+  const int n_slots = L + (L * (L + 1)) / 2;
+  const int64_t ldq = ((m + 15) / 16) * 16;
+  int64_t chunk = ((int64_t)1 << 28) / (ldq * n_slots);        // <= 2 GiB of coefficient matrices per chunk
+  if (chunk > 16384) chunk = 16384;
+  if (chunk < 64) chunk = 64;
+  if (chunk > n) chunk = n;
+  // centre operands of the pair GEMMs
+  std::vector<int64_t> cp_off((size_t)L * L, 0), cp_ld((size_t)L * L, 0);
+  int64_t cp_total = 0, ldt_max = 0;
+  for (int l = 0; l < L; ++l)
+    for (int lp = l; lp < L; ++lp) {
+      const int64_t ncol = (int64_t)cov.leaves[l].ndims * cov.leaves[lp].ndims + cov.leaves[l].ndims + cov.leaves[lp].ndims + 1;
+      const int64_t ld = ((ncol + 15) / 16) * 16;
+      cp_off[(size_t)l * L + lp] = cp_total; cp_ld[(size_t)l * L + lp] = ld;
+      cp_total += m * ld;
+      if (ld > ldt_max) ldt_max = ld;
+    }
+  double *norms = nullptr, *Q = nullptr, *T = nullptr, *cp = nullptr;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)L * (size_t)(n + m), (void**)&norms));
+  double* xx = norms;
+  double* yy = norms + (size_t)L * n;
+  MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
+  MLN_TRY(sqnorms(ctx, cov, c, m, d, yy));
+  const int64_t slot_stride = chunk * ldq;
+  MLN_HIP(ctx, mln_dmalloc((void**)&Q, sizeof(double) * (size_t)n_slots * slot_stride));
+  MLN_HIP(ctx, mln_dmalloc((void**)&T, sizeof(double) * (size_t)chunk * ldt_max));
+  MLN_HIP(ctx, mln_dmalloc((void**)&cp, sizeof(double) * (size_t)cp_total));
+  for (int l = 0; l < L; ++l)
+    for (int lp = l; lp < L; ++lp) {
+      const int64_t ld = cp_ld[(size_t)l * L + lp];
+      hipLaunchKernelGGL(k_hess_centres, dim3((unsigned)((m * ld + 255) / 256)), dim3(256), 0, ctx->stream, cov, l, lp, c, m,
+                         d, cp + cp_off[(size_t)l * L + lp], ld);
+    }
+  int rc = MLN_OK;
+  hipError_t e0 = hipMemsetAsync(out, 0, sizeof(double) * (size_t)n * d * d, ctx->stream);
+  if (e0 != hipSuccess) rc = mln_hip_fail(ctx, e0, "predict_hessian", __FILE__, __LINE__);
+  const int64_t tiles_n = (ldq + TN - 1) / TN;
+  for (int64_t r0 = 0; r0 < n && rc == MLN_OK; r0 += chunk) {
+    const int64_t rows = (n - r0 < chunk) ? (n - r0) : chunk;
+    const int64_t nblk = tiles_n * ((rows + TM - 1) / TM);
+    double* Hc = out + r0 * (int64_t)d * d;
+    hipLaunchKernelGGL(k_hess_coeff, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x + r0 * d, rows, c, m, d,
+                       xx + r0, n, yy, w, Q, ldq, slot_stride, tiles_n);
+    for (int l = 0; l < L && rc == MLN_OK; ++l) {
+      hipLaunchKernelGGL(k_hess_diag, dim3((unsigned)rows), dim3(256), 0, ctx->stream, cov, l, Q + (size_t)l * slot_stride,
+                         ldq, m, rows, d, Hc);
+      for (int lp = l; lp < L && rc == MLN_OK; ++lp) {
+        const int na = cov.leaves[l].ndims, nb = cov.leaves[lp].ndims;
+        const int64_t ld = cp_ld[(size_t)l * L + lp];
+        GemmArgs g{};
+        g.A = Q + (size_t)hess_pair_slot(L, l, lp) * slot_stride; g.lda = ldq; g.ta = 0;
+        g.B = cp + cp_off[(size_t)l * L + lp]; g.ldb = ld; g.tb = 0; g.C = T; g.ldc = ld;
+        g.M = rows; g.N = (int64_t)na * nb + na + nb + 1; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.split_k = 1;
+        rc = launch_dgemm(ctx, g);
+        if (rc != MLN_OK) break;
+        const unsigned nb_ = (unsigned)((rows * na * nb + 255) / 256);
+        hipLaunchKernelGGL(k_hess_combine, dim3(nb_), dim3(256), 0, ctx->stream, cov, l, lp, 0, T, ld, x + r0 * d, rows, d, Hc);
+        if (lp != l)
+          hipLaunchKernelGGL(k_hess_combine, dim3(nb_), dim3(256), 0, ctx->stream, cov, l, lp, 1, T, ld, x + r0 * d, rows, d, Hc);
+      }
+    }
+  }
+  hipError_t e = hipGetLastError();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(Q); (void)mln_dfree(T); (void)mln_dfree(cp);
+  if (rc == MLN_OK && e != hipSuccess) rc = mln_hip_fail(ctx, e, "predict_hessian", __FILE__, __LINE__);
+  return rc;
+}
 
 // Predictor gradient of a composite program of stationary leaves through the matrix cores (see k_grad_coeff_multi).
 int launch_predict_gradient_gemm_multi(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,

@@ -105,6 +105,8 @@ int launch_predict_gradient_gemm(mln_ctx* ctx, const DevCov& cov, const double* 
                                  int64_t m, int d, const double* w, double* out);   // single stationary leaf
 int launch_predict_gradient_gemm_multi(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c,
                                        int64_t m, int d, const double* w, double* out);   // stationary leaves, any program
+int launch_predict_hessian(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c, int64_t m,
+                           int d, const double* w, double* out);              // out: n x d x d
 int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* c, int64_t m,
                             int d, const double* w, double* out);
 

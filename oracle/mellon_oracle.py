@@ -723,6 +723,40 @@ class Predictor:
             out[:, k] = (4 * d1 - d2) / 3
         return out
 
+    def analytic_gradient(self, Xnew):
+        """sum_j w_j d k(x_i, c_j) / d x_i from the covariance's own `k_grad` rules (cov.py:68-596,
+        base_cov.py:317-497): k_grad(c)(x)[j, i] is the derivative with respect to x_i."""
+        Xnew = ensure_2d(np.asarray(Xnew, dtype=np.float64))
+        return np.einsum("j,jik->ik", self.weights, self.cov_func.k_grad(self.centers)(Xnew))
+
+    def hessian(self, Xnew, h=None):
+        """base_predictor.py:507-521: jacfwd(jacrev(mean)) per row.  The restatement differentiates the analytic
+        gradient above once more by Richardson-extrapolated central differences (error ~ h^4), so the closed-form
+        second derivatives of the device path are checked against rules they do not share."""
+        Xnew = ensure_2d(np.asarray(Xnew, dtype=np.float64))
+        n, d = Xnew.shape
+        if h is None:
+            def _min_ls(c):
+                if hasattr(c, "left"):
+                    r = _min_ls(c.right) if callable(c.right) else np.inf
+                    return min(_min_ls(c.left), r)
+                return float(getattr(c, "ls", np.inf))
+            # the differentiated function is analytic and known to ~1e-16, so a small step is affordable: truncation
+            # ~ h^4 f^(5) matters near the centres, where Matern32 / Exponential have unbounded higher derivatives
+            h = 1e-4 * min(np.maximum(np.abs(Xnew).max(), 1.0), _min_ls(self.cov_func))
+        out = np.empty((n, d, d))
+        for k in range(d):
+            e = np.zeros(d)
+            e[k] = h
+            d1 = (self.analytic_gradient(Xnew + e) - self.analytic_gradient(Xnew - e)) / (2 * h)
+            d2 = (self.analytic_gradient(Xnew + 2 * e) - self.analytic_gradient(Xnew - 2 * e)) / (4 * h)
+            out[:, :, k] = (4 * d1 - d2) / 3
+        return 0.5 * (out + np.swapaxes(out, 1, 2))
+
+    def hessian_log_determinant(self, Xnew):
+        """base_predictor.py:523-539."""
+        return np.linalg.slogdet(self.hessian(Xnew))
+
     # with_uncertainty state: L (factor on the centres) and W = L^-T diag(std)
     L = None
     W = None

@@ -721,3 +721,32 @@ def test_noise_models_on_odd_shapes(mellon, n, d, p, m):
     np.testing.assert_allclose(est.predict(X), ref(X), rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(est.leverage(), ref.leverage(X), rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(est.get_obs_variance(), ref.obs_variance(X), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_predictor_hessian_and_log_determinant(mellon, small_x):
+    """tests/test_density_estimator.py:47-62: hessian (n, d, d), hessian_log_determinant -> (signs, log|det|), plus
+    parity with the oracle's finite-difference Hessian; the time-sensitive predictor differentiates the state
+    columns only (base_predictor.py:1127-1194)."""
+    est = mellon.DensityEstimator(n_landmarks=25).fit(small_x)
+    n, d = small_x.shape
+    H = est.predict.hessian(small_x)
+    assert H.shape == (n, d, d)
+    sng, ld = est.predict.hessian_log_determinant(small_x)
+    assert sng.shape == (n,) and ld.shape == (n,)
+    ref = mo.Predictor(mo.Matern52(ls=est.ls), est.landmarks, est.predict.weights, est.mu, n)
+    Hr = ref.hessian(small_x)
+    assert np.abs(H - Hr).max() < 1e-6 * np.abs(Hr).max()
+    s2, l2 = np.linalg.slogdet(Hr)
+    assert np.array_equal(sng, s2) and np.abs(ld - l2).max() < 1e-5
+    # time-sensitive: product kernel, Hessian over the state columns at a fixed time
+    times = np.repeat(np.arange(4.0), n // 4)
+    test = mellon.TimeSensitiveDensityEstimator(n_landmarks=20, ls_time=1.3).fit(small_x[:times.size], times)
+    Ht = test.predict.hessian(small_x[:10], 1.5)
+    assert Ht.shape == (10, d, d)
+    xt = np.column_stack([small_x[:10], np.full(10, 1.5)])
+    full = mo.Predictor(mo.compute_cov_func(mo.Matern52, test.ls, 1.3), test.landmarks, test.predict.weights, test.mu,
+                        times.size).hessian(xt)
+    assert np.abs(Ht - full[:, :d, :d]).max() < 1e-6 * np.abs(full).max()
+    st, lt = test.predict.hessian_log_determinant(small_x[:10], 1.5)
+    assert st.shape == lt.shape == (10,)

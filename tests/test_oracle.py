@@ -365,3 +365,21 @@ def test_oracle_per_cell_sigma_constant_equals_scalar(n_landmarks):
     a = mo.function_fit(X, Y[:, 0], np.full(50, 0.7), n_landmarks=n_landmarks)(X)
     b = mo.function_fit(X, Y[:, 0], 0.7, n_landmarks=n_landmarks)(X)
     np.testing.assert_allclose(a, b, atol=1e-9)
+
+
+def test_oracle_hessian_is_the_derivative_of_the_fd_gradient():
+    """The oracle Hessian (FD of the analytic k_grad contraction) agrees with second differences of the mean itself."""
+    rng = np.random.default_rng(4)
+    c, w = rng.normal(size=(30, 3)), rng.normal(size=30)
+    pred = mo.Predictor(mo.Matern52(ls=1.7), c, w, 0.3, 30)
+    X = rng.normal(size=(6, 3))
+    H = pred.hessian(X)
+    assert H.shape == (6, 3, 3) and np.allclose(H, np.swapaxes(H, 1, 2))
+    h = 1e-3
+    for a in range(3):
+        for b in range(3):
+            ea, eb = np.eye(3)[a] * h, np.eye(3)[b] * h
+            fd = (pred(X + ea + eb) - pred(X + ea - eb) - pred(X - ea + eb) + pred(X - ea - eb)) / (4 * h * h)
+            assert np.abs(fd - H[:, a, b]).max() < 1e-5 * max(np.abs(H).max(), 1.0)
+    s, ld = pred.hessian_log_determinant(X)
+    assert s.shape == ld.shape == (6,)
