@@ -24,9 +24,9 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
                  jitter=DEFAULT_JITTER, optimizer=DEFAULT_OPTIMIZER, n_iter=DEFAULT_N_ITER,
                  init_learn_rate=DEFAULT_INIT_LEARN_RATE, landmarks=None, nn_distances=None,
                  normalize_per_time_point=False, d=None, mu=None, ls=None, ls_factor=1, ls_time=None,
-                 ls_time_factor=1, cov_func=None, Lp=None, L=None, initial_value=None,
+                 ls_time_factor=1, density_estimator_kwargs=None, cov_func=None, Lp=None, L=None, initial_value=None,
                  predictor_with_uncertainty=False, jit=DEFAULT_JIT, check_rank=None,
-                 random_state=DEFAULT_RANDOM_SEED):
+                 random_state=DEFAULT_RANDOM_SEED, _save_intermediate_ls_times=False):
         super().__init__(cov_func_curry=cov_func_curry, n_landmarks=n_landmarks, rank=rank, gp_type=gp_type,
                          d_method=d_method, jitter=jitter, optimizer=optimizer, n_iter=n_iter,
                          init_learn_rate=init_learn_rate, landmarks=landmarks, nn_distances=nn_distances, d=d,
@@ -36,6 +36,12 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
         self.normalize_per_time_point = normalize_per_time_point
         self.ls_time = validate_positive_float(ls_time, "ls_time", optional=True)
         self.ls_time_factor = validate_positive_float(ls_time_factor, "ls_time_factor")
+        if density_estimator_kwargs is None:
+            density_estimator_kwargs = {}
+        if not isinstance(density_estimator_kwargs, dict):
+            raise ValueError("density_estimator_kwargs needs to be a dictionary.")
+        self.density_estimator_kwargs = density_estimator_kwargs
+        self._save_intermediate_ls_times = _save_intermediate_ls_times
 
     _PIPELINE = ("n_landmarks", "rank", "gp_type", None, "d", "nn_distances", "mu", "ls", "ls_time", "cov_func",
                  "landmarks", "Lp", "L", "initial_value", "transform", "loss_func")
@@ -63,9 +69,21 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
         return compute_ls(nn) * self.ls_factor
 
     def _compute_ls_time(self):
-        raise NotImplementedError(
-            "Automatic ls_time (compute_ls_time.py:66-99, a nested loop of per-time-point estimators) is outside "
-            "the accelerated path: pass ls_time= explicitly, as the reference's tutorial does.")
+        """time_sensitive_density_estimator.py:503-536: one density fit per time point, then the kernel length scale
+        that best explains the correlation of the densities across time."""
+        from .compute_ls_time import compute_ls_time
+        kwargs = {"cov_func_curry": self.cov_func_curry, "d_method": self.d_method, "d": self.d,
+                  "optimizer": self.optimizer, "ls": self.ls, "ls_factor": self.ls_factor, "jit": self.jit,
+                  "mu": self.mu}
+        kwargs.update(self.density_estimator_kwargs)
+        logger.info("Initiating density computation for each time point to estimate the 'ls_time' parameter. "
+                    "You can directly specify 'ls_time' to bypass this computation-intensive step.")
+        ls = compute_ls_time(self.nn_distances, self.x, self.cov_func_curry,
+                             return_data=self._save_intermediate_ls_times, density_estimator_kwargs=kwargs)
+        if self._save_intermediate_ls_times:
+            logger.info("Storing `self.densities`, `self.predictors`, and `self.numeric_stages`.")
+            ls, self.densities, self.predictors, self.numeric_stages = ls
+        return ls * self.ls_time_factor
 
     def _compute_landmarks(self):
         return compute_landmarks_rescale_time(self.x, self.ls, self.ls_time, n_landmarks=self.n_landmarks,

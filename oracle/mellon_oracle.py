@@ -1063,6 +1063,35 @@ def function_fit(x, y, sigma, cov_func_curry=Matern52, n_landmarks=None, landmar
                                y_is_mean=y_is_mean, with_uncertainty=with_uncertainty, obs_variance=obs_variance)
 
 
+def compute_ls_time(nn_distances, x_with_time, cov_func_curry=Matern52, density_fit_kwargs=None):
+    """compute_ls_time.py:12-105: a density fit per time point, the correlation matrix of the predicted log-densities
+    (each evaluated on ALL states), and the length scale minimising |cov(ls)(dt, 0) - corr|_F over log ls by
+    L-BFGS-B from log ls = 0 (jaxopt.ScipyMinimize defaults; central-difference gradient here)."""
+    x_with_time = np.asarray(x_with_time, dtype=np.float64)
+    times, states = x_with_time[:, -1], x_with_time[:, :-1]
+    unique_times = np.unique(times)
+    dens = []
+    for t in unique_times:
+        mask = times == t
+        fit = density_fit(states[mask], cov_func_curry=cov_func_curry, nn_distances=nn_distances[mask],
+                          **(density_fit_kwargs or {}))
+        dens.append(fit.predict(states))
+    corrs = np.corrcoef(np.stack(dens))
+    nt = len(unique_times)
+    delta_t = np.abs(unique_times.reshape(-1, 1) - unique_times.reshape(1, -1)).reshape(-1, 1)
+
+    def loss(log_ls):
+        covs = cov_func_curry(ls=float(np.exp(log_ls[0])))(delta_t, np.zeros((1, 1))).reshape(nt, nt)
+        return float(np.linalg.norm(covs - corrs))
+
+    def loss_grad(log_ls):
+        h = 1e-6
+        return loss(log_ls), np.array([(loss(log_ls + h) - loss(log_ls - h)) / (2 * h)])
+
+    res = _sp_minimize(loss_grad, np.array([0.0]), jac=True, method="L-BFGS-B")
+    return float(np.exp(res.x[0]))
+
+
 def per_time_nn_distances(x, times):
     """parameters.py:444-531 -- nearest neighbour within each time point."""
     x = ensure_2d(x)

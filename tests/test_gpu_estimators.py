@@ -750,3 +750,22 @@ def test_predictor_hessian_and_log_determinant(mellon, small_x):
     assert np.abs(Ht - full[:, :d, :d]).max() < 1e-6 * np.abs(full).max()
     st, lt = test.predict.hessian_log_determinant(small_x[:10], 1.5)
     assert st.shape == lt.shape == (10,)
+
+
+@pytest.mark.gpu
+def test_automatic_ls_time_matches_oracle(mellon):
+    """TimeSensitiveDensityEstimator without ls_time (compute_ls_time.py:12-105): per-time-point device fits, the
+    correlation of their densities, the best-fitting time length scale -- against the oracle's restatement."""
+    rng = np.random.default_rng(12)
+    n_per, d, T = 150, 3, 4
+    centre = rng.normal(size=d)
+    X = np.concatenate([rng.normal(size=(n_per, d)) * 0.8 + centre + 0.25 * t for t in range(T)])
+    times = np.repeat(np.arange(float(T)), n_per)
+    est = mellon.TimeSensitiveDensityEstimator(n_landmarks=40, _save_intermediate_ls_times=True)
+    est.fit(X, times)
+    assert est.densities.shape == (T, X.shape[0]) and len(est.predictors) == T
+    want = mo.compute_ls_time(np.asarray(est.nn_distances), np.column_stack([X, times]),
+                              density_fit_kwargs=dict(d=est.d, mu=est.mu, ls=est.ls, lbfgsb_options=mo.LBFGSB_TIGHT))
+    assert abs(est.ls_time - want) < 1e-3 * want, (est.ls_time, want)
+    scaled = mellon.TimeSensitiveDensityEstimator(n_landmarks=40, ls_time_factor=2.0).fit(X, times)
+    assert abs(scaled.ls_time - 2.0 * est.ls_time) < 1e-6 * est.ls_time
