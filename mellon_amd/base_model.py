@@ -195,7 +195,12 @@ class BaseEstimator:
     def _run_inference(self):
         logger.info("Running inference using %s.", self.optimizer)
         if self.optimizer == "adam":
-            minimize_adam()
+            results = minimize_adam(self.loss_func, self.initial_value, n_iter=self.n_iter,
+                                    init_learn_rate=self.init_learn_rate, jit=self.jit)
+            self.pre_transformation = results.pre_transformation
+            self.pre_transformation_std = None
+            self.opt_state = results.opt_state
+            self.losses = results.losses
         elif self.optimizer == "advi":
             run_advi()
         elif self.optimizer == "L-BFGS-B":

@@ -156,7 +156,30 @@ def _unavailable_optimizer(name):
     return f
 
 
-minimize_adam = _unavailable_optimizer("adam")
+def minimize_adam(loss_func, initial_value, n_iter=DEFAULT_N_ITER, init_learn_rate=DEFAULT_INIT_LEARN_RATE,
+                  jit=DEFAULT_JIT):
+    """inference.py:222-269: `n_iter` Adam steps (jax.example_libraries.optimizers.adam: b1 = 0.9, b2 = 0.999,
+    eps = 1e-8, bias-corrected moments) with the learning rate exp(-0.01 i) * init_learn_rate; every step is one
+    fused loss-and-gradient pass on the device.  Returns (pre_transformation, opt_state, losses)."""
+    z = np.array(initial_value, dtype=np.float64)
+    m1, m2 = np.zeros_like(z), np.zeros_like(z)
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    losses = []
+    fun = loss_func.value_and_grad if hasattr(loss_func, "value_and_grad") else None
+    if fun is None:
+        raise TypeError("minimize_adam needs a loss with value_and_grad (compute_loss_func returns one)")
+    for i in range(int(n_iter)):
+        value, g = fun(z)
+        losses.append(float(value))
+        m1 = (1 - b1) * g + b1 * m1
+        m2 = (1 - b2) * np.square(g) + b2 * m2
+        mhat = m1 / (1 - b1 ** (i + 1))
+        vhat = m2 / (1 - b2 ** (i + 1))
+        z = z - np.exp(-1e-2 * i) * init_learn_rate * mhat / (np.sqrt(vhat) + eps)
+    Results = namedtuple("Results", "pre_transformation opt_state losses")
+    return Results(z, (z, m1, m2), np.asarray(losses))
+
+
 run_advi = _unavailable_optimizer("advi")
 
 

@@ -600,6 +600,23 @@ def minimize_lbfgsb(fun_and_grad, z0, options=None):
     return MapResult(res.x, float(res.fun), int(res.nfev), int(res.nit), int(res.status))
 
 
+def minimize_adam(fun_and_grad, z0, n_iter=100, init_learn_rate=1e-1):    # inference.py:28-29 defaults
+    """inference.py:222-269 with jax.example_libraries.optimizers.adam restated (b1 = 0.9, b2 = 0.999, eps = 1e-8,
+    bias-corrected moments; step size exp(-0.01 i) * init_learn_rate).  JAX is absent here, so the update rule is the
+    published one, not checked against the library: parity for optimizer="adam" is pinned only through the
+    reference's own property (tests/test_density_estimator.py:66-74: within 2e-3 of the L-BFGS-B density)."""
+    z = np.array(z0, dtype=np.float64)
+    m1, m2 = np.zeros_like(z), np.zeros_like(z)
+    losses = []
+    for i in range(n_iter):
+        value, g = fun_and_grad(z)
+        losses.append(value)
+        m1 = 0.1 * g + 0.9 * m1
+        m2 = 0.001 * np.square(g) + 0.999 * m2
+        z = z - np.exp(-1e-2 * i) * init_learn_rate * (m1 / (1 - 0.9 ** (i + 1))) / (np.sqrt(m2 / (1 - 0.999 ** (i + 1))) + 1e-8)
+    return z, np.asarray(losses)
+
+
 def laplace_std(z, L, mu, V):
     """inference.py:291-338 -- diag of the Hessian in closed form:
     1 + sum_i L_ij^2 exp(f_i+V_i), clipped at 1e-8, std = 1/sqrt."""

@@ -769,3 +769,20 @@ def test_automatic_ls_time_matches_oracle(mellon):
     assert abs(est.ls_time - want) < 1e-3 * want, (est.ls_time, want)
     scaled = mellon.TimeSensitiveDensityEstimator(n_landmarks=40, ls_time_factor=2.0).fit(X, times)
     assert abs(scaled.ls_time - 2.0 * est.ls_time) < 1e-6 * est.ls_time
+
+
+@pytest.mark.gpu
+def test_adam_optimizer(mellon, small_x):
+    """optimizer="adam" (inference.py:222-269): 100 Adam steps on the device objective.  The reference's property
+    (tests/test_density_estimator.py:66-74): within 2e-3 of the default optimiser's density; and step-for-step
+    agreement with the oracle's restatement of the same update rule."""
+    base = mellon.DensityEstimator().fit_predict(small_x)
+    est = mellon.DensityEstimator(optimizer="adam")
+    dens = est.fit_predict(small_x)
+    assert rel_std(dens, base) < 2e-3
+    assert len(est.losses) == 100 and est.losses[-1] < est.losses[0]
+    ref = mo.density_fit(small_x)
+    V, Vdr = mo.nn_likelihood_constants(ref.nn_distances, ref.d)
+    z, losses = mo.minimize_adam(lambda zz: mo.loss_and_grad(zz, ref.L, ref.mu, V, Vdr), ref.initial_value)
+    assert np.abs(np.asarray(est.losses) - losses).max() < 1e-7 * np.abs(losses).max()
+    assert rel_max(dens, ref.L @ z + ref.mu) < 1e-6
