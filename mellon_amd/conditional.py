@@ -64,10 +64,6 @@ def _per_output_levels(sigma):
     return sig, [(float(v), np.flatnonzero(inverse == k)) for k, v in enumerate(levels)]
 
 
-def _reject_extras(with_uncertainty, obs_variance):
-    pass
-
-
 def _hc3(residual, h):
     """Corrected squared residuals r^2 / (1 - h)^2 (conditional.py:330-333,607-610)."""
     if residual.ndim > h.ndim:
@@ -189,7 +185,6 @@ class _FullConditional:
 
     def __init__(self, x, y, mu, cov_func, L=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER, y_cov_factor=None,
                  y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None, factor=None):
-        _reject_extras(with_uncertainty, obs_variance)
         x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         ctx = _lib.default_context()
         yh = np.asarray(y, dtype=np.float64)
@@ -314,7 +309,6 @@ class _LandmarksConditional:
 
     def __init__(self, x, xu, y, mu, cov_func, L=None, Lp=None, sigma=DEFAULT_SIGMA, jitter=DEFAULT_JITTER,
                  y_cov_factor=None, y_is_mean=False, with_uncertainty=False, obs_variance=False, parameter_std=None):
-        _reject_extras(with_uncertainty, obs_variance)
         if with_uncertainty and y_is_mean and y_cov_factor is None:
             # y_cov_factor = L diag(std): the factor of the covariance of the mean on the training cells
             # (inference.compute_parameter_cov_factor, inference.py:357-372)
@@ -394,10 +388,13 @@ class _LandmarksConditional:
 class _LandmarksConditionalCholesky:
     _center_name = "landmarks"
 
+    def _leverage(self, Xnew, sigma):       # conditional.py:908-922 (scalar sigma)
+        return _landmarks_leverage(Xnew, self.landmarks, self.cov_func, _scalar_sigma(sigma), self.jitter,
+                                   L=getattr(self, "L", None))
+
     def __init__(self, xu, pre_transformation, mu, cov_func, n_obs, L=None, sigma=DEFAULT_SIGMA,
                  jitter=DEFAULT_JITTER, y_is_mean=False, with_uncertainty=False, obs_variance=False,
                  obs_x=None, obs_y=None):
-        _reject_extras(with_uncertainty, obs_variance)
         xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
         z = np.asarray(pre_transformation, dtype=np.float64)
         if isinstance(L, (FactorLp, FactorL)) and L.fit.handle is not None:
@@ -411,6 +408,23 @@ class _LandmarksConditionalCholesky:
                 Lh = np.asarray(L, dtype=np.float64)
             weights = ctx.trsm_lower(Lh, z, trans=True)
         Predictor.__init__(self, cov_func, xu, weights, mu, n_obs=n_obs, jitter=jitter, sigma=sigma)
+        if obs_variance:          # conditional.py:842-851,870-897: HC3 residuals of (obs_x, obs_y), second landmark GP
+            if obs_x is None or obs_y is None:
+                raise ValueError("obs_x and obs_y are required when obs_variance=True "
+                                 "for LandmarksConditionalCholesky.")
+            s = _scalar_sigma(sigma)
+            if s is None or not s > 0:
+                raise ValueError("obs_variance needs a positive noise level `sigma` "
+                                 "(the reference divides by sigma^2, conditional.py:157-159).")
+            ctx = _lib.default_context()
+            ox = np.ascontiguousarray(ensure_2d(obs_x), dtype=np.float64)
+            oy = np.asarray(obs_y, dtype=np.float64)
+            h = self._leverage(ox, s)          # before `L` is attached: K_uu = cov(xu, xu), as in the reference
+            self._corrected_r2 = _hc3(oy - self._mean(ox), h)
+            self.variance_mu = 0.0
+            self.variance_weights = ctx.sparse_solve(cov_func.lower(xu.shape[1]), ox, xu, self._corrected_r2,
+                                                     self.variance_mu, s, jitter)
+            self._state_variables |= {"variance_weights", "variance_mu"}
         if with_uncertainty:
             Lf = L.fit.Lp() if isinstance(L, (FactorLp, FactorL)) else Lh
             _attach_uncertainty(self, Lf, _parameter_std(sigma, xu.shape[0]))

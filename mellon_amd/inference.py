@@ -214,7 +214,8 @@ def _dispatch(classes, x, landmarks, pre_transformation, pre_transformation_std,
         if pre_transformation_std is not None:
             sigma = pre_transformation_std               # inference.py:470-471
         return Cholesky(landmarks, pre_transformation, mu, cov_func, x.shape[0], Lp, sigma=sigma, jitter=jitter,
-                        y_is_mean=y_is_mean, with_uncertainty=with_uncertainty, obs_variance=obs_variance)
+                        y_is_mean=y_is_mean, with_uncertainty=with_uncertainty, obs_variance=obs_variance,
+                        obs_x=x if obs_variance else None, obs_y=y if obs_variance else None)
     logger.debug("Using LandmarksConditional GP.")
     # inference.py:488-492: y_cov_factor = L diag(pre_transformation_std) -- formed where it is consumed
     return Landmarks(x, landmarks, y, mu, cov_func, L, sigma=sigma, jitter=jitter, y_is_mean=y_is_mean,

@@ -969,13 +969,29 @@ def landmarks_conditional(x, xu, y, mu, cov_func, Lp=None, sigma=0.0,
 
 
 def landmarks_conditional_cholesky(xu, z, mu, cov_func, n_obs, L=None,
-                                   jitter=DEFAULT_JITTER):
-    """conditional.py:750-818 -- weights = Lp^-T z."""
+                                   jitter=DEFAULT_JITTER, sigma=0.0, obs_variance=False, obs_x=None, obs_y=None):
+    """conditional.py:750-897 -- weights = Lp^-T z; with obs_variance the HC3 residuals of (obs_x, obs_y) feed a
+    second landmark GP (:870-897; the leverage there still sees K_uu = cov(xu, xu) because `L` is attached later)."""
     xu = ensure_2d(xu)
     if L is None:
         L = _get_L(xu, cov_func, jitter)
     w = _sp_trsolve(L.T, z, lower=False)
-    return Predictor(cov_func, xu, w, mu, n_obs)
+    pred = Predictor(cov_func, xu, w, mu, n_obs)
+    pred.kind, pred.sigma, pred.jitter = "landmarks", sigma, jitter
+    if obs_variance:
+        x = ensure_2d(obs_x)
+        B = cov_func(x, xu)
+        h = _landmarks_leverage_one(B, cov_func(xu, xu), float(sigma), jitter)
+        r = obs_y - (mu + B @ w)
+        if r.ndim > h.ndim:
+            h = h[..., None]
+        cr2 = r ** 2 / (1 - h) ** 2
+        A = _sp_trsolve(L, B.T, lower=True)
+        s2 = float(sigma) ** 2
+        pred.variance_mu = 0.0
+        pred.variance_weights, _ = sparse_solve(L, A, cr2 / s2, A / s2)
+        pred.corrected_r2 = cr2
+    return pred
 
 
 def compute_conditional(x, landmarks, z, y, mu, cov_func, L, Lp=None, sigma=0.0,
