@@ -49,7 +49,8 @@ typedef enum {
   MLN_K_EXPQUAD = 3,     /* cov.py:255-259 */
   MLN_K_EXPONENTIAL = 4, /* cov.py:352-356 */
   MLN_K_RATQUAD = 5,     /* cov.py:453-457 */
-  MLN_K_LINEAR = 6       /* cov.py:551-556 */
+  MLN_K_LINEAR = 6,      /* cov.py:551-556 */
+  MLN_K_DISTANCE = 7     /* util.py:351-366: the pairwise distance itself, dist / ls (values only, no gradients) */
 } mln_kind;
 
 /* A covariance tree (Covariance / Add / Mul / Pow, base_cov.py:301-453) is lowered to a postfix

@@ -17,7 +17,7 @@ MLN_OK, MLN_ERR_NOT_PD, MLN_ERR_SHAPE, MLN_ERR_HIP, MLN_ERR_RCCL, MLN_ERR_ARG, M
 MLN_UNIQUE_ID_BYTES = 128
 MLN_N_STAGE_TIMES = 10
 
-K_MATERN32, K_MATERN52, K_EXPQUAD, K_EXPONENTIAL, K_RATQUAD, K_LINEAR = 1, 2, 3, 4, 5, 6
+K_MATERN32, K_MATERN52, K_EXPQUAD, K_EXPONENTIAL, K_RATQUAD, K_LINEAR, K_DISTANCE = 1, 2, 3, 4, 5, 6, 7
 OP_LEAF, OP_CONST, OP_ADD, OP_MUL, OP_POW = 0, 1, 2, 3, 4
 
 
@@ -446,6 +446,13 @@ class Context:
         if obs_variance:
             return W, H, Cr, VW
         return (W, H) if leverage else W
+
+    def pairwise_distance(self, x, y):
+        """util.distance (util.py:351-366) through the kernel-matrix pass with the value-only DISTANCE leaf."""
+        from .base_cov import LoweredCov
+        d = _as2d(x).shape[1]
+        desc = LoweredCov([(K_DISTANCE, 1.0, 1.0, np.arange(d))], [(OP_LEAF, 0, 0.0)])
+        return self.kernel_matrix(desc, x, y)
 
     def landmark_leverage(self, desc, x, xu, Lk, sigma, jitter):
         """(n, p) leverage of the landmark conditional for the p noise levels `sigma`, K_uu = Lk Lk^T."""

@@ -180,10 +180,20 @@ class BaseEstimator:
         fit = self._device_fit()
         n_samples = self.x.shape[0]
         n_landmarks = n_samples if self.landmarks is None else self.landmarks.shape[0]
-        if (self.check_rank is None and self.gp_type == GaussianProcessType.SPARSE_CHOLESKY
-                and SAMPLE_LANDMARK_RATIO * n_landmarks < n_samples) or self.check_rank:
-            logger.info("Rank diagnostic (numpy.linalg.matrix_rank of L, log only in the reference, "
-                        "base_model.py:344-355) is skipped: it does not affect any result.")
+        if self.gp_type in (GaussianProcessType.SPARSE_NYSTROEM, GaussianProcessType.FULL_NYSTROEM) \
+                and fit.m > self.rank * RANK_FRACTION_THRESHOLD * n_landmarks:          # base_model.py:333-342
+            logger.warning(f"Shallow rank reduction from {n_landmarks:,} to {fit.m:,} indicates underrepresentation "
+                           "by landmarks. Consider increasing n_landmarks!")
+        if self.check_rank:                                                              # base_model.py:344-355
+            from .util import test_rank
+            logger.info(f"Estimating approximation accuracy since {n_samples:,} samples are more than "
+                        f"{SAMPLE_LANDMARK_RATIO} x {n_landmarks:,} landmarks.")
+            test_rank(FactorL(fit), threshold=RANK_FRACTION_THRESHOLD)
+        elif (self.check_rank is None and self.gp_type == GaussianProcessType.SPARSE_CHOLESKY
+                and SAMPLE_LANDMARK_RATIO * n_landmarks < n_samples):
+            logger.info("Rank diagnostic (matrix_rank of L; log only in the reference, base_model.py:344-355) is run "
+                        "on request only (check_rank=True): an n m^2 Gram and an m x m eigensolve that change no "
+                        "result.")
         logger.info(f"Using rank {fit.m:,} covariance representation.")
         return FactorLp(fit) if self.gp_type == GaussianProcessType.FULL and fit.m == fit.n and \
             getattr(fit, "_has_lp", True) else FactorL(fit)

@@ -154,7 +154,7 @@ int mln_lower_cov(mln_ctx* ctx, const mln_kernel_desc* cov, int d, DevCov* out) 
   int off = 0;
   for (int l = 0; l < cov->n_leaves; ++l) {
     const mln_leaf& lf = cov->leaves[l];
-    if (lf.kind < MLN_K_MATERN32 || lf.kind > MLN_K_LINEAR) { mln_set_error(ctx, "unknown kernel kind"); return MLN_ERR_ARG; }
+    if (lf.kind < MLN_K_MATERN32 || lf.kind > MLN_K_DISTANCE) { mln_set_error(ctx, "unknown kernel kind"); return MLN_ERR_ARG; }
     if (lf.ndims < 0 || off + lf.ndims > MLN_MAX_DIMS || (lf.ndims > 0 && !lf.dims)) {
       mln_set_error(ctx, "covariance descriptor: active dims overflow"); return MLN_ERR_UNSUPPORTED;
     }
@@ -343,6 +343,15 @@ extern "C" int mln_kernel_matrix(mln_ctx* ctx, const mln_kernel_desc* cov, const
   return o.commit();
 }
 
+static int reject_distance_leaf(mln_ctx* ctx, const DevCov& dc) {
+  for (int l = 0; l < dc.n_leaves; ++l)
+    if (dc.leaves[l].kind == MLN_K_DISTANCE) {
+      mln_set_error(ctx, "MLN_K_DISTANCE is a value-only leaf: no derivatives");
+      return MLN_ERR_UNSUPPORTED;
+    }
+  return MLN_OK;
+}
+
 extern "C" int mln_kernel_grad(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n,
                                const double* y, int64_t m, int32_t d, double* out) {
   if (!ctx) return MLN_ERR_ARG;
@@ -352,6 +361,7 @@ extern "C" int mln_kernel_grad(mln_ctx* ctx, const mln_kernel_desc* cov, const d
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevCov dc;
   MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  MLN_TRY(reject_distance_leaf(ctx, dc));
   DevIn dx, dy;
   DevOut o;
   MLN_TRY(dx.init(ctx, x, (size_t)n * d));
@@ -370,6 +380,7 @@ extern "C" int mln_predict_gradient(mln_ctx* ctx, const mln_kernel_desc* cov, co
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevCov dc;
   MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  MLN_TRY(reject_distance_leaf(ctx, dc));
   DevIn dx, dc_, dw;
   DevOut o;
   MLN_TRY(dx.init(ctx, xnew, (size_t)n_new * d));
@@ -389,6 +400,7 @@ extern "C" int mln_predict_hessian(mln_ctx* ctx, const mln_kernel_desc* cov, con
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevCov dc;
   MLN_TRY(mln_lower_cov(ctx, cov, d, &dc));
+  MLN_TRY(reject_distance_leaf(ctx, dc));
   DevIn dx, dc_, dw;
   DevOut o;
   MLN_TRY(dx.init(ctx, xnew, (size_t)n_new * d));
@@ -734,18 +746,18 @@ extern "C" int mln_eigh(mln_ctx* ctx, const double* A, int64_t m, double* w, dou
   return MLN_OK;
 }
 
+static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride);
+
 extern "C" int mln_fit_gram_eigh(mln_fit* f, double* w, int32_t* n_sweeps) {
   if (!f || !w) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
-  if (f->kspace) {
-    mln_set_error(ctx, "gram_eigh needs the explicit factor (prepare without MLN_FIT_IMPLICIT)");
-    return MLN_ERR_UNSUPPORTED;
-  }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t m = f->m, ld = f->ldl;
   double* G = nullptr;
   MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * (size_t)m * ld));
-  int rc = gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld);   // all cells, all ranks
+  // all cells, all ranks; an implicit fit forms Lp^-1 (K^T K) Lp^-T (eigenvalues only are meaningful then:
+  // mln_fit_project needs the explicit factor)
+  int rc = f->kspace ? fit_gram(f, G, ld, 1) : gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld);
   if (rc == MLN_OK && !f->eigU) {
     hipError_t e = mln_dmalloc((void**)&f->eigU, sizeof(double) * (size_t)m * ld);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc eigenvectors", __FILE__, __LINE__);
@@ -766,6 +778,7 @@ extern "C" int mln_fit_project(mln_fit* f, int64_t p, mln_fit** out) {
   *out = nullptr;
   mln_ctx* ctx = f->ctx;
   if (!f->eigU) { mln_set_error(ctx, "project: call mln_fit_gram_eigh first"); return MLN_ERR_ARG; }
+  if (f->kspace) { mln_set_error(ctx, "project needs the explicit factor (prepare without MLN_FIT_IMPLICIT)"); return MLN_ERR_UNSUPPORTED; }
   if (p < 1 || p > f->m) { mln_set_error(ctx, "project: rank out of range"); return MLN_ERR_SHAPE; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   mln_fit* g = new mln_fit();

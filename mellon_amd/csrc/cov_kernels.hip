@@ -26,6 +26,7 @@ __device__ __forceinline__ double leaf_value(const DevLeaf& lf, double xx, doubl
   double sq = xx - 2.0 * xy + yy + 1e-12;
   double dist = sqrt(fmax(sq, 0.0));
   switch (lf.kind) {
+    case MLN_K_DISTANCE: return dist * inv_ls;              // util.py:366
     case MLN_K_MATERN32: {                                  // cov.py:64-65
       double r = 1.7320508075688772 * dist * inv_ls;
       return (r + 1.0) * exp(-r);
@@ -1166,7 +1167,8 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
     for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
   static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
   static const bool no_rows = std::getenv("MELLON_AMD_KM_NO_ROWS") != nullptr;
-  if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR) {
+  if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
+      cov.leaves[0].kind != MLN_K_DISTANCE) {
     const dim3 grid((unsigned)((n + 127) / 128)), block(512);
 #define MLN_KM_ROWS2(KIND, KS)                                                                                       \
   if (out32) hipLaunchKernelGGL((k_kernel_matrix_rows<KIND, true, KS>), grid, block, 0, ctx->stream, cov, x, n, y, m, d, \
@@ -1214,7 +1216,8 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   if (contiguous)
     for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
   static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
-  if (contiguous && !no_mfma && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR) {
+  if (contiguous && !no_mfma && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
+      cov.leaves[0].kind != MLN_K_DISTANCE) {
     const dim3 grid((unsigned)((n + 127) / 128)), block(512);
 #define MLN_PM_ROWS2(KIND, KS) \
   hipLaunchKernelGGL((k_predict_mean_rows<KIND, KS>), grid, block, 0, ctx->stream, cov, x, n, y, m, d, xx, yy, w, mu, out);

@@ -112,3 +112,83 @@ class GaussianProcessType(str, Enum):
 def set_verbosity(verbose):
     """reference util.py:539-569."""
     logger.setLevel(logging.INFO if verbose else logging.WARNING)
+
+
+DEFAULT_RANK_TOL = 5e-1        # util.py:49
+
+
+def stabilize(A, jitter=DEFAULT_JITTER):
+    """A + jitter I (util.py:269-275)."""
+    A = np.asarray(A, dtype=np.float64)
+    return A + np.eye(A.shape[0]) * jitter
+
+
+def add_diagonal(A, value):
+    """A + value I (util.py:278-293)."""
+    A = np.asarray(A, dtype=np.float64)
+    return A + np.eye(A.shape[0]) * value
+
+
+def add_variance(K, M=None, jitter=DEFAULT_JITTER):
+    """K + M M^T with the diagonal of M M^T floored at jitter (util.py:296-331)."""
+    if M is None:
+        return stabilize(K, jitter)
+    if np.isscalar(M):
+        return add_diagonal(K, max(jitter, M ** 2))
+    M = np.asarray(M, dtype=np.float64)
+    noise = M @ M.T
+    dn = np.diagonal(noise)
+    return np.asarray(K, dtype=np.float64) + noise + np.diag(np.where(dn < jitter, jitter - dn, 0.0))
+
+
+def distance(x, y, eps=1e-12):
+    """Pairwise Euclidean distances sqrt(max(|x|^2 - 2 x.y + |y|^2 + eps, 0)) (util.py:351-366), evaluated by the
+    device's kernel-matrix pass (the `+ 1e-12` is part of the device arithmetic; other eps are not supported)."""
+    if eps != 1e-12:
+        raise ValueError("the device distance uses the reference's eps = 1e-12")
+    from . import _lib
+    x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+    y = np.ascontiguousarray(ensure_2d(y), dtype=np.float64)
+    return _lib.default_context().pairwise_distance(x, y)
+
+
+def test_rank(input, tol=DEFAULT_RANK_TOL, threshold=None):
+    """Approximate rank of the transformation L: the number of singular values above tol * the largest
+    (numpy.linalg.matrix_rank(L, rtol=tol), util.py:429-483).  The singular values are the square roots of the
+    eigenvalues of the m x m Gram L^T L, formed and diagonalised on the device."""
+    from . import _lib
+    from .decomposition import FactorL, FactorLp
+    L = input if (hasattr(input, "shape") or isinstance(input, (FactorL, FactorLp))) else getattr(input, "L", input)
+    if L is None:
+        raise AttributeError("Matrix L is not found in the estimator object. Consider running `.prepare_inference()`.")
+    if not hasattr(L, "shape"):
+        raise TypeError("Input must be either a matrix or a mellon enstimator with a transformation L.")
+    if len(L.shape) != 2:
+        raise ValueError("Matrix L must be 2D.")
+    if isinstance(L, (FactorL, FactorLp)) and L.fit.handle is not None and not isinstance(L, FactorLp):
+        ev = L.fit.gram_eigh()
+    else:
+        Lh = np.asarray(L, dtype=np.float64)
+        if Lh.shape[0] < Lh.shape[1]:
+            Lh = Lh.T                       # same singular values, smaller Gram
+        fit = _lib.Fit.from_L(_lib.default_context(), np.ascontiguousarray(Lh))
+        try:
+            ev = fit.gram_eigh()
+        finally:
+            fit.close()
+    sv = np.sqrt(np.maximum(ev, 0.0))
+    approx_rank = int(np.count_nonzero(sv > tol * sv.max()))
+    max_rank = int(min(L.shape))
+    rank_fraction = approx_rank / max_rank
+    if threshold is not None:
+        if rank_fraction > threshold:
+            logger.warning(f"High approx. rank fraction ({rank_fraction:.1%}). Consider increasing 'n_landmarks'.")
+        else:
+            logger.info(f"Rank fraction ({rank_fraction:.1%}, lower is better) is within acceptable range. "
+                        "Current settings should provide satisfactory model performance.")
+    else:
+        print(f"The approx. rank fraction is {rank_fraction:.1%} ({approx_rank:,} of {max_rank:,}). Lower is better.")
+    return approx_rank
+
+
+test_rank.__test__ = False       # a utility of the reference's API, not a pytest case

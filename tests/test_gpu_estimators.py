@@ -808,3 +808,19 @@ def test_cholesky_conditional_leverage_and_obs_variance(mellon, small_x):
         from mellon_amd.conditional import LandmarksConditionalCholesky
         LandmarksConditionalCholesky(est.landmarks, est.pre_transformation, est.mu, est.cov_func, 100, est.Lp, sigma=0.7,
                                      obs_variance=True)
+
+
+@pytest.mark.gpu
+def test_check_rank_runs_the_device_diagnostic(mellon, small_x, caplog):
+    """check_rank=True (base_model.py:344-355): rank fraction of L logged from the device's Gram eigenvalues, for the
+    implicit factor too; results unchanged."""
+    import logging
+    base = mellon.DensityEstimator(n_landmarks=20).fit_predict(small_x)
+    with caplog.at_level(logging.INFO, logger="mellon"):
+        est = mellon.DensityEstimator(n_landmarks=20, check_rank=True)
+        dens = est.fit_predict(small_x)
+    assert any("ank fraction" in r.getMessage() for r in caplog.records)
+    np.testing.assert_allclose(dens, base, rtol=1e-10)
+    from mellon_amd import util
+    want = np.linalg.matrix_rank(np.asarray(est.L), rtol=0.5)
+    assert util.test_rank(est, threshold=0.8) == want

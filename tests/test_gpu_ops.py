@@ -486,18 +486,20 @@ def test_full_decomposition_low_rank_matches_reference_algorithm(ctx, rank):
     assert np.abs(L @ L.T - ref @ ref.T).max() < 1e-10 * np.abs(ref @ ref.T).max()
 
 
-def test_gram_eigh_requires_explicit_factor(ctx):
+def test_gram_eigh_explicit_and_implicit_factor(ctx):
     from mellon_amd import cov
     x = mo.gaussian_mixture(200, 3, 1)
     fit = ctx.fit_prepare(cov.Matern52(ls=1.5).lower(3), x, x[:20], 1e-6, implicit=True)
+    Si = fit.gram_eigh()                                      # eigenvalues of Lp^-1 (K^T K) Lp^-T: the same spectrum
     with pytest.raises(NotImplementedError):
-        fit.gram_eigh()
+        fit.project(5)                                        # projecting needs the explicit rows
     fit2 = ctx.fit_prepare(cov.Matern52(ls=1.5).lower(3), x, x[:20], 1e-6)
     with pytest.raises(Exception):
         fit2.project(5)                                       # no eigenvectors yet
     S = fit2.gram_eigh()
     Lb = fit2.L()
     assert np.abs(S - np.linalg.eigvalsh(Lb.T @ Lb)).max() < 1e-11 * S.max()
+    assert np.abs(Si - S).max() < 1e-6 * S.max()
     with pytest.raises(ValueError):
         fit2.project(21)
     p5 = fit2.project(5)
@@ -596,3 +598,28 @@ def test_predict_hessian_matches_oracle(ctx, n, m, d):
         # the finite-difference oracle, not the closed forms
         tol = 2e-5 if "Exponential" in repr(k) else 2e-6 if "Matern32" in repr(k) else 2e-7
         assert np.abs(H - ref).max() < tol * max(np.abs(ref).max(), 1e-300), (repr(k), np.abs(H - ref).max(), np.abs(ref).max())
+
+
+def test_util_helpers_distance_and_rank(ctx):
+    """util.distance (util.py:351-366) via the value-only DISTANCE leaf; util.test_rank = matrix_rank(L, rtol) from the
+    device's Gram eigenvalues (util.py:429-483); stabilize / add_variance (util.py:269-331)."""
+    from mellon_amd import util
+    rng = np.random.default_rng(0)
+    x, y = rng.normal(size=(77, 5)), rng.normal(size=(33, 5))
+    y[:4] = x[:4]
+    # coincident rows: sqrt(1e-12 + cancellation residue of |x|^2 - 2 x.y + |y|^2), equal to ~1e-9 only
+    np.testing.assert_allclose(util.distance(x, y), mo.distance(x, y), rtol=1e-12, atol=5e-9)
+    big = rng.normal(size=(5000, 7))
+    np.testing.assert_allclose(util.distance(big, big[:300]), mo.distance(big, big[:300]), rtol=1e-11, atol=1e-7)
+    L = rng.normal(size=(400, 12)) @ np.diag([10, 9, 8, 6, 5.5, 4, 1, 0.5, 0.2, 0.1, 0.01, 1e-4])
+    for tol in (0.5, 0.05, 1e-3):
+        assert util.test_rank(L, tol=tol, threshold=0.8) == np.linalg.matrix_rank(L, rtol=tol)
+    assert util.test_rank(L.T, tol=0.5, threshold=0.8) == np.linalg.matrix_rank(L, rtol=0.5)
+    K = rng.normal(size=(6, 6)); K = K @ K.T
+    np.testing.assert_allclose(util.stabilize(K, 1e-3), mo.stabilize(K, 1e-3))
+    M = rng.normal(size=(6, 2)) * 1e-4
+    np.testing.assert_allclose(util.add_variance(K, M), mo.add_variance(K, M))
+    np.testing.assert_allclose(util.add_variance(K, 0.3), mo.add_variance(K, 0.3))
+    with pytest.raises(Exception):
+        ctx.predict_gradient(__import__("mellon_amd").base_cov.LoweredCov([(7, 1.0, 1.0, np.arange(5))], [(0, 0, 0.0)]),
+                             x, y, np.ones(33))
