@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 from .base_cov import Covariance
-from .util import deserialize, ensure_2d, make_serializable
+from .util import deserialize, ensure_2d, make_multi_time_argument, make_serializable
 from .validation import validate_array, validate_bool, validate_time_x
 
 logger = logging.getLogger("mellon")
@@ -283,32 +283,32 @@ class ExpPredictor(Predictor):
 class PredictorTime(Predictor):
     """Predictor whose last input column is time (reference base_predictor.py:872-948)."""
 
-    def mean(self, Xnew, time=None, normalize=False, multi_time=None):
-        if multi_time is not None:
-            if time is not None:
-                raise ValueError("Specify either `time` or `multi_time`, not both.")
-            times = np.asarray(multi_time, dtype=np.float64).reshape(-1)
-            return np.stack([self.mean(Xnew, time=t, normalize=normalize) for t in times], axis=1)
+    @make_multi_time_argument
+    def mean(self, Xnew, time=None, normalize=False):
         Xnew = validate_array(Xnew, "Xnew")
         Xnew = np.ascontiguousarray(ensure_2d(Xnew), dtype=np.float64)
         x = validate_time_x(Xnew, time, n_features=self.n_input_features, cast_scalar=True)
-        return super().mean(np.ascontiguousarray(x), normalize=normalize)
+        return Predictor.mean(self, np.ascontiguousarray(x), normalize=normalize)
 
     __call__ = mean
 
+    @make_multi_time_argument
     def gradient(self, x, time=None, jit=True):
         """Gradient with respect to the state columns at the given time(s) (base_predictor.py:1094-1124)."""
         return Predictor.gradient(self, self._with_time(x, time))[:, :-1]
 
+    @make_multi_time_argument
     def hessian(self, x, time=None, jit=True):
         """Hessian with respect to the state columns at the given time(s) (base_predictor.py:1127-1159)."""
         return Predictor.hessian(self, self._with_time(x, time))[:, :-1, :-1]
 
+    @make_multi_time_argument
     def hessian_log_determinant(self, x, time=None, jit=True):
         """base_predictor.py:1162-1194."""
-        sign, logdet = np.linalg.slogdet(self.hessian(x, time))
+        sign, logdet = np.linalg.slogdet(Predictor.hessian(self, self._with_time(x, time))[:, :-1, :-1])
         return sign, logdet
 
+    @make_multi_time_argument
     def time_derivative(self, x, time=None, jit=True):
         """Derivative with respect to time (base_predictor.py:1052-1091)."""
         return Predictor.gradient(self, self._with_time(x, time))[:, -1]
@@ -317,12 +317,15 @@ class PredictorTime(Predictor):
         Xnew = np.ascontiguousarray(ensure_2d(validate_array(Xnew, "Xnew")), dtype=np.float64)
         return np.ascontiguousarray(validate_time_x(Xnew, time, n_features=self.n_input_features, cast_scalar=True))
 
-    def covariance(self, Xnew, time=None, diag=True):
-        return super().covariance(self._with_time(Xnew, time), diag=diag)
+    @make_multi_time_argument
+    def covariance(self, Xnew, time=None, diag=True, noise_free=False):
+        return Predictor.covariance(self, self._with_time(Xnew, time), diag=diag, noise_free=noise_free)
 
+    @make_multi_time_argument
     def mean_covariance(self, Xnew, time=None, diag=True):
-        return super().mean_covariance(self._with_time(Xnew, time), diag=diag)
+        return Predictor.mean_covariance(self, self._with_time(Xnew, time), diag=diag)
 
+    @make_multi_time_argument
     def uncertainty(self, Xnew, time=None, diag=True):
         x = self._with_time(Xnew, time)
         return Predictor.covariance(self, x, diag=diag) + Predictor.mean_covariance(self, x, diag=diag)

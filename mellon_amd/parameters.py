@@ -269,3 +269,31 @@ def compute_initial_value(nn_distances, d, mu, L, row_stride=None, target=None):
     fit = _fit_of(L)
     fit.precond_build(ridge_row_stride(fit.n, fit.m) if row_stride is None else row_stride)
     return fit.ridge_init(target)
+
+
+# -- thin helpers over a predictor (parameters.py:59-86) ---------------------------------------------------------
+def compute_initial_zeros(x, L):
+    return np.zeros((np.shape(x)[0], np.shape(L)[1]))
+
+
+def compute_initial_ones(x, L):
+    return np.ones(np.shape(x)[0])
+
+
+def compute_time_derivatives(predictor, x, times=None):
+    if hasattr(predictor, "time_derivative"):
+        return predictor.time_derivative(x, times)
+    return np.zeros(np.shape(x)[0])
+
+
+def compute_density_gradient(predictor, x, times=None):
+    if hasattr(predictor, "time_derivative"):
+        return predictor.gradient(x, times)
+    return predictor.gradient(x)
+
+
+def compute_density_diffusion(predictor, x, times=None):
+    """parameters.py:81-85 evaluates the Hessian log-determinant and returns nothing; the pair is returned here."""
+    if hasattr(predictor, "time_derivative"):
+        return predictor.hessian_log_determinant(x, times)
+    return predictor.hessian_log_determinant(x)

@@ -1,4 +1,6 @@
 """Host-side helpers mirroring mellon/util.py (NumPy only; no device code here)."""
+import functools
+import inspect
 import logging
 from enum import Enum
 
@@ -192,3 +194,28 @@ def test_rank(input, tol=DEFAULT_RANK_TOL, threshold=None):
 
 
 test_rank.__test__ = False       # a utility of the reference's API, not a pytest case
+
+
+def make_multi_time_argument(func):
+    """Decorator adding an optional `multi_time` argument to a method that takes `time` (util.py:206-265): the method
+    runs once per value and the results are stacked along axis 1 (element-wise for tuple results), the layout of the
+    reference's `vmap(..., out_axes=1)`."""
+    sig = inspect.signature(func)
+    new_sig = sig.replace(parameters=list(sig.parameters.values()) + [
+        inspect.Parameter("multi_time", inspect.Parameter.POSITIONAL_OR_KEYWORD, default=None)])
+
+    @functools.wraps(func)
+    def wrapper(self, *args, **kwargs):
+        multi_time = kwargs.pop("multi_time", None)
+        if multi_time is None:
+            return func(self, *args, **kwargs)
+        if kwargs.get("time", None) is not None:
+            raise ValueError("Cannot specify both 'time' and 'multi_time' arguments")
+        times = np.asarray(multi_time, dtype=np.float64).reshape(-1)
+        outs = [func(self, *args, **kwargs, time=float(t)) for t in times]
+        if isinstance(outs[0], tuple):
+            return tuple(np.stack([o[k] for o in outs], axis=1) for k in range(len(outs[0])))
+        return np.stack(outs, axis=1)
+
+    wrapper.__signature__ = new_sig
+    return wrapper

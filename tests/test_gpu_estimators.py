@@ -824,3 +824,29 @@ def test_check_rank_runs_the_device_diagnostic(mellon, small_x, caplog):
     from mellon_amd import util
     want = np.linalg.matrix_rank(np.asarray(est.L), rtol=0.5)
     assert util.test_rank(est, threshold=0.8) == want
+
+
+@pytest.mark.gpu
+def test_multi_time_argument_on_every_time_predictor_method(mellon, small_x):
+    """util.make_multi_time_argument (util.py:206-265): one evaluation per time, stacked along axis 1, for the mean,
+    gradient, time derivative, Hessian and its log-determinant, and the uncertainties."""
+    n, d = small_x.shape
+    times = np.repeat(np.arange(4.0), n // 4)
+    est = mellon.TimeSensitiveDensityEstimator(n_landmarks=20, ls_time=1.3, predictor_with_uncertainty=True)
+    est.fit(small_x[:times.size], times)
+    p, xq, mt = est.predict, small_x[:12], np.array([0.5, 1.5, 2.5])
+    for name, shape in (("mean", (12, 3)), ("gradient", (12, 3, d)), ("time_derivative", (12, 3)),
+                        ("hessian", (12, 3, d, d)), ("covariance", (12, 3)), ("mean_covariance", (12, 3)),
+                        ("uncertainty", (12, 3))):
+        out = getattr(p, name)(xq, multi_time=mt)
+        assert out.shape == shape, (name, out.shape)
+        for k, t in enumerate(mt):
+            np.testing.assert_allclose(out[:, k], getattr(p, name)(xq, time=float(t)), rtol=1e-12, atol=1e-14)
+    s, l = p.hessian_log_determinant(xq, multi_time=mt)
+    assert s.shape == l.shape == (12, 3)
+    with pytest.raises(ValueError):
+        p.mean(xq, time=1.0, multi_time=mt)
+    from mellon_amd.parameters import compute_density_gradient, compute_time_derivatives, compute_density_diffusion
+    np.testing.assert_allclose(compute_density_gradient(p, xq, 1.5), p.gradient(xq, 1.5))
+    np.testing.assert_allclose(compute_time_derivatives(p, xq, 1.5), p.time_derivative(xq, 1.5))
+    assert compute_density_diffusion(p, xq, 1.5)[0].shape == (12,)
