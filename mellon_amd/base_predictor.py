@@ -266,8 +266,11 @@ class Predictor:
 class ExpPredictor(Predictor):
     """exp of the mean (reference base_predictor.py ExpPredictor)."""
 
-    def mean(self, x, normalize=False):
-        return np.exp(super().mean(x, normalize=normalize))
+    def mean(self, x, logscale=False):
+        """exp(mean), or the mean itself with `logscale=True` (base_predictor.py:748-787)."""
+        logscale = validate_bool(logscale, "logscale")
+        log_value = Predictor.mean(self, x)
+        return log_value if logscale else np.exp(log_value)
 
     __call__ = mean
 

@@ -850,3 +850,22 @@ def test_multi_time_argument_on_every_time_predictor_method(mellon, small_x):
     np.testing.assert_allclose(compute_density_gradient(p, xq, 1.5), p.gradient(xq, 1.5))
     np.testing.assert_allclose(compute_time_derivatives(p, xq, 1.5), p.time_derivative(xq, 1.5))
     assert compute_density_diffusion(p, xq, 1.5)[0].shape == (12,)
+
+
+@pytest.mark.gpu
+def test_exp_predictor(mellon, small_x):
+    """compute_conditional_explog (inference.py:643-765): the predictor of exp(f) -- `logscale`, and the chain rule
+    for its gradient and Hessian against differences of the predictor itself."""
+    from mellon_amd.inference import compute_conditional_explog
+    est = mellon.DensityEstimator(n_landmarks=20).fit(small_x)
+    p = compute_conditional_explog(small_x, est.landmarks, est.pre_transformation, None, est.log_density_x,
+                                   est.mu * 0.05, est.cov_func, None, est.Lp)
+    xq = small_x[:9]
+    np.testing.assert_allclose(p(xq), np.exp(p(xq, logscale=True)), rtol=1e-13)
+    np.testing.assert_allclose(p.mean(xq, logscale=True), est.predict(xq) - est.mu + est.mu * 0.05, rtol=1e-9)
+    h = 1e-5
+    g, H = p.gradient(xq), p.hessian(xq)
+    for a in range(xq.shape[1]):
+        e = np.eye(xq.shape[1])[a] * h
+        np.testing.assert_allclose(g[:, a], (p(xq + e) - p(xq - e)) / (2 * h), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(H[:, :, a], (p.gradient(xq + e) - p.gradient(xq - e)) / (2 * h), rtol=1e-5, atol=1e-8)
