@@ -81,8 +81,11 @@ class Predictor:
         The reference differentiates `_mean` with jax.jacrev; here the analytic kernel gradient is
         contracted with the weights on the device.  `jit` is accepted and ignored."""
         x = self._check_features(x)
-        return _lib.default_context().predict_gradient(self.cov_func.lower(self.n_input_features), x,
-                                                       self.centers, self.weights)
+        ctx, desc = _lib.default_context(), self.cov_func.lower(self.n_input_features)
+        if self.weights.ndim == 2:      # p outputs: (n, p, d), the layout derivatives.gradient gives (derivatives.py:76-80)
+            return np.stack([ctx.predict_gradient(desc, x, self.centers, np.ascontiguousarray(self.weights[:, c]))
+                             for c in range(self.weights.shape[1])], axis=1)
+        return ctx.predict_gradient(desc, x, self.centers, self.weights)
 
     # -- predictive uncertainty (base_predictor.py:330-428; conditional.py _covariance / _mean_covariance) --
     def _check_features(self, x):
@@ -144,8 +147,11 @@ class Predictor:
         reference applies jacfwd(jacrev(.)); here the closed-form second derivatives of the kernels are contracted
         with the weights on the device.  `jit` is accepted and ignored."""
         x = self._check_features(x)
-        return _lib.default_context().predict_hessian(self.cov_func.lower(self.n_input_features), x, self.centers,
-                                                      self.weights)
+        ctx, desc = _lib.default_context(), self.cov_func.lower(self.n_input_features)
+        if self.weights.ndim == 2:      # p outputs: (n, p, d, d) (derivatives.py:114-117)
+            return np.stack([ctx.predict_hessian(desc, x, self.centers, np.ascontiguousarray(self.weights[:, c]))
+                             for c in range(self.weights.shape[1])], axis=1)
+        return ctx.predict_hessian(desc, x, self.centers, self.weights)
 
     def hessian_log_determinant(self, x, jit=True):
         """(signs, log |det|) of the Hessian at each row of x (base_predictor.py:523-539)."""

@@ -869,3 +869,16 @@ def test_exp_predictor(mellon, small_x):
         e = np.eye(xq.shape[1])[a] * h
         np.testing.assert_allclose(g[:, a], (p(xq + e) - p(xq - e)) / (2 * h), rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(H[:, :, a], (p.gradient(xq + e) - p.gradient(xq - e)) / (2 * h), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_multi_output_gradient_and_hessian(mellon):
+    """A predictor with p outputs: gradient (n, p, d) and hessian (n, p, d, d), column by column the single-output
+    results (the shapes jacrev / jacfwd give in derivatives.py:76-80,114-117)."""
+    X, Y, _ = _noise_case(n=150, d=3, p=4)
+    est = mellon.FunctionEstimator(sigma=0.3, n_landmarks=30).fit(X, Y)
+    g, H = est.predict.gradient(X[:20]), est.predict.hessian(X[:20])
+    assert g.shape == (20, 4, 3) and H.shape == (20, 4, 3, 3)
+    one = mellon.FunctionEstimator(sigma=0.3, n_landmarks=30, landmarks=est.landmarks, ls=est.ls).fit(X, Y[:, 2])
+    np.testing.assert_allclose(g[:, 2], one.predict.gradient(X[:20]), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(H[:, 2], one.predict.hessian(X[:20]), rtol=1e-9, atol=1e-12)
