@@ -30,6 +30,7 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 __global__ __launch_bounds__(64) void k_potrf64(double* A, int64_t lda, int nb, double* __restrict__ Dinv,
                                                 int* info, int64_t j0) {
   const int lane = threadIdx.x;
+  __shared__ double dinv_s[PB];          // 1 / T_kk for the inverse below
   double a[PB];
 #pragma unroll
   for (int j = 0; j < PB; ++j)
@@ -42,30 +43,50 @@ __global__ __launch_bounds__(64) void k_potrf64(double* A, int64_t lda, int nb, 
       if (!bad && lane == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
       bad = true;
     }
-    const double sq = sqrt(d), inv = 1.0 / sq;
+    // 1/sqrt(d) from the hardware estimate and two Newton steps, sqrt(d) = d * that with one Heron correction:
+    // a few dependent FMAs on the critical path instead of a square-root and a division sequence
+    double inv = __builtin_amdgcn_rsq(d);
+    inv = inv * fma(-0.5 * d, inv * inv, 1.5);
+    inv = inv * fma(-0.5 * d, inv * inv, 1.5);
+    double sq = d * inv;
+    sq = fma(0.5 * inv, fma(-sq, sq, d), sq);
     const double lik = (lane == k) ? sq : ((lane > k) ? a[k] * inv : 0.0);
+    if (lane == k) dinv_s[k] = inv;
     a[k] = lik;
+    double lk = lik;
 #pragma unroll
     for (int j = k + 1; j < PB; ++j) {
-      const double ljk = lane_bcast(lik, j);
-      a[j] = fma(-lik, ljk, a[j]);
+      const double ljk = lane_bcast(lk, j);
+      a[j] = fma(-lk, ljk, a[j]);
+      // Every 8 columns tie the broadcast source to the update just made: the next broadcasts then cannot be
+      // issued before these updates, so at most 8 broadcast values (16 SGPRs) are alive.  Without it the whole
+      // column is broadcast first and most of it spills (3262 v_writelane spills of SGPRs).
+      if (((j - k) & 1) == 0) asm volatile("" : "+v"(lk), "+v"(a[j]));
     }
   }
   if (bad) return;
+  // The factor goes to global memory and to LDS; the inverse below then reads T_ik as uniform (broadcast) LDS
+  // loads with only x[] in registers.  Keeping a[] AND x[] (256 VGPRs) live made the compiler turn whole columns
+  // of a[] into scalar registers at once: 7356 spilled SGPRs, 16 k v_readlane and 130 us per block.
+  __shared__ double Ts[PB][PB];
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const double v = (j <= lane) ? a[j] : 0.0;
+    Ts[lane][j] = v;
+    if (lane < nb && j < nb) A[(int64_t)lane * lda + j] = v;
+  }
+  __syncthreads();
   // X = T^-1, lane c owns column c:  x_i = (delta_ic - sum_{k<i} T_ik x_k) / T_ii
   double x[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     double sacc = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = 0; k < i; ++k) sacc = fma(-lane_bcast(a[k], i), x[k], sacc);
-    x[i] = sacc / lane_bcast(a[i], i);
+    for (int k = 0; k < i; ++k) sacc = fma(-Ts[i][k], x[k], sacc);
+    x[i] = sacc * dinv_s[i];
   }
 #pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    if (lane < nb && j < nb) A[(int64_t)lane * lda + j] = (j <= lane) ? a[j] : 0.0;
-    Dinv[j * PB + lane] = x[j];   // X[j][lane]: row j, column lane
-  }
+  for (int j = 0; j < PB; ++j) Dinv[j * PB + lane] = x[j];   // X[j][lane]: row j, column lane
 }
 
 // inverse of every 64 x 64 diagonal block of a lower-triangular factor, written into the same
