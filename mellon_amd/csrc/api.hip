@@ -1069,13 +1069,13 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc C^-1", __FILE__, __LINE__);
   }
   if (rc == MLN_OK) rc = launch_add_diag(ctx, inv, m, ldg, 1.0);
-  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg);   // C^-1 = C^-1 I
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg, true);   // C^-1 = C^-1 I (lower triangular B)
   if (rc == MLN_OK && f->kspace) {                                  // P = Lp^-T C^-T
     hipError_t e = mln_dmalloc((void**)&f->P, bytes);
     if (e == hipSuccess) e = hipMemsetAsync(f->P, 0, bytes, ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
     if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);
-    if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, f->P, m, ldg);
+    if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, f->P, m, ldg, true);   // C^-T is upper triangular
   }
   if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs
     const int64_t ld = ldg;

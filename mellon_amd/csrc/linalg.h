@@ -13,8 +13,10 @@ struct TriInv {
 int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool need_w, bool need_w2, TriInv* out);
 void triinv_free(TriInv* t);
 int triinv_solve_right_T(mln_ctx* ctx, const TriInv& t, double* X, int64_t n, int64_t ldx);  // X <- X Lf^-T
-int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb);     // B <- Lf^-1 B
-int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb);   // B <- Lf^-T B
+// `tri_b`: B is itself lower triangular (solve_left) / upper triangular (solve_left_T) with m columns: the result has
+// the same shape and only the columns that can be non-zero in each row block are computed (half the flops).
+int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb, bool tri_b = false);     // B <- Lf^-1 B
+int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb, bool tri_b = false);   // B <- Lf^-T B
 int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows,
                       int64_t cols);
 int launch_transpose(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m);  // dst = src^T (m x m)

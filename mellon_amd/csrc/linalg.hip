@@ -373,8 +373,9 @@ int triinv_solve_right_T(mln_ctx* ctx, const TriInv& t, double* X, int64_t n, in
 //   few right-hand sides: left-looking,  B_j <- W_j [B_<j ; B_j]            (one GEMM per block row)
 //   many (p >= 256):      right-looking, B_j <- Dinv_j B_j ; B_>j -= Lf[>j,j] B_j   -- the trailing
 //   update is a (m-j) x p GEMM that fills the chip, where the left-looking form has only p/128 tiles
-int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb) {
+int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb, bool tri_b) {
   const bool right_looking = (p >= 256) && t.Lf && t.W;
+  tri_b = tri_b && right_looking && p == t.m;
   for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
     const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
     GemmArgs g{};
@@ -385,15 +386,16 @@ int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64
       MLN_TRY(launch_dgemm(ctx, g));
       continue;
     }
+    const int64_t ncol = tri_b ? (j0 + nb) : p;      // lower-triangular B: rows of this block end at column j0 + nb
     g.A = t.W + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
-    g.M = nb; g.N = p; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+    g.M = nb; g.N = ncol; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
     MLN_TRY(launch_dgemm(ctx, g));
     const int64_t rem = t.m - j0 - nb;
     if (rem > 0) {
       GemmArgs u{};
       u.A = t.Lf + (j0 + nb) * t.ldf + j0; u.lda = t.ldf; u.B = B + j0 * ldb; u.ldb = ldb;
       u.C = B + (j0 + nb) * ldb; u.ldc = ldb;
-      u.M = rem; u.N = p; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 0; u.tb = 0;
+      u.M = rem; u.N = ncol; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 0; u.tb = 0;
       MLN_TRY(launch_dgemm(ctx, u));
     }
   }
@@ -403,8 +405,9 @@ int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64
 // B (m x p, in place) <- Lf^-T B (backward substitution).
 //   few right-hand sides: B_j <- W2[>=j, j]^T B[>=j]
 //   many (p >= 256):      B_j <- Dinv_j^T B_j ; B_<j -= Lf[j,<j]^T B_j
-int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb) {
+int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb, bool tri_b) {
   const bool right_looking = (p >= 256) && t.Lf && t.W2;
+  tri_b = tri_b && right_looking && p == t.m;
   const int64_t nblk = (t.m + TB - 1) / TB;
   for (int64_t jb = nblk - 1; jb >= 0; --jb) {
     const int64_t j0 = jb * TB;
@@ -417,13 +420,14 @@ int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int
       MLN_TRY(launch_dgemm(ctx, g));
       continue;
     }
-    g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
-    g.M = nb; g.N = p; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;   // Dinv_j^T B_j
+    const int64_t c0 = tri_b ? j0 : 0;                // upper-triangular B: rows of this block start at column j0
+    g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb + c0; g.ldb = ldb; g.C = B + j0 * ldb + c0; g.ldc = ldb;
+    g.M = nb; g.N = p - c0; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;   // Dinv_j^T B_j
     MLN_TRY(launch_dgemm(ctx, g));
     if (j0 > 0) {
       GemmArgs u{};
-      u.A = t.Lf + j0 * t.ldf; u.lda = t.ldf; u.B = B + j0 * ldb; u.ldb = ldb; u.C = B; u.ldc = ldb;
-      u.M = j0; u.N = p; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 1; u.tb = 0;  // Lf[j,<j]^T B_j
+      u.A = t.Lf + j0 * t.ldf; u.lda = t.ldf; u.B = B + j0 * ldb + c0; u.ldb = ldb; u.C = B + c0; u.ldc = ldb;
+      u.M = j0; u.N = p - c0; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 1; u.tb = 0;  // Lf[j,<j]^T B_j
       MLN_TRY(launch_dgemm(ctx, u));
     }
   }
