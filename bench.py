@@ -107,11 +107,11 @@ def main():
     weak = args.scaling == "weak"
     t_gen = time.perf_counter()
     x0 = gaussian_mixture(n, d, args.seed)                # shard 0 == the BASELINE C3 data set
-    if world > 1:   # N ranks share the host: keep the (untimed) k-means from oversubscribing the cores N-fold
-        from threadpoolctl import threadpool_limits
-        with threadpool_limits(limits=max(1, (os.cpu_count() or 1) // world)):
-            landmarks = make_landmarks(x0, m)
-    else:
+    # single-threaded k-means (3.6 s, untimed): bit-reproducible landmarks -- with threads they differ in the last
+    # bits from run to run, which is enough to move the L-BFGS pass count by a few evaluations -- and no
+    # oversubscription of the host when N ranks share it
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):
         landmarks = make_landmarks(x0, m)
     if world > 1:   # replicated inputs must be BIT-identical on every rank (they steer the shared optimiser)
         landmarks = comm.allreduce_sum(landmarks if rank == 0 else np.zeros_like(landmarks))
