@@ -882,3 +882,29 @@ def test_multi_output_gradient_and_hessian(mellon):
     one = mellon.FunctionEstimator(sigma=0.3, n_landmarks=30, landmarks=est.landmarks, ls=est.ls).fit(X, Y[:, 2])
     np.testing.assert_allclose(g[:, 2], one.predict.gradient(X[:20]), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(H[:, 2], one.predict.hessian(X[:20]), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_landmarks", [0, 25])
+def test_sigma_input_forms(mellon, n_landmarks):
+    """sigma as a Python list, as a length-1 vector against an (n, 1) y, as an int; y_is_mean with obs_variance."""
+    X, Y, _ = _noise_case(n=160, d=3, p=3)
+    a = mellon.FunctionEstimator(sigma=[0.5, 1.0, 2.0], n_landmarks=n_landmarks).fit(X, Y)
+    b = mellon.FunctionEstimator(sigma=np.array([0.5, 1.0, 2.0]), n_landmarks=n_landmarks, landmarks=a.landmarks,
+                                 ls=a.ls).fit(X, Y)
+    np.testing.assert_allclose(a.predict(X), b.predict(X), rtol=1e-12)
+    one = mellon.FunctionEstimator(sigma=np.array([0.7]), n_landmarks=n_landmarks, landmarks=a.landmarks, ls=a.ls)
+    one.fit(X, Y[:, :1])
+    ref = mo.function_fit(X, Y[:, :1], np.array([0.7]), n_landmarks=n_landmarks, landmarks=a.landmarks, ls=a.ls)
+    assert one.predict(X).shape == (160, 1) and one.predict.per_feature_sigma
+    np.testing.assert_allclose(one.predict(X), ref(X), rtol=1e-7, atol=1e-9)
+    i = mellon.FunctionEstimator(sigma=1, n_landmarks=n_landmarks, landmarks=a.landmarks, ls=a.ls).fit(X, Y[:, 0])
+    f = mellon.FunctionEstimator(sigma=1.0, n_landmarks=n_landmarks, landmarks=a.landmarks, ls=a.ls).fit(X, Y[:, 0])
+    np.testing.assert_allclose(i.predict(X), f.predict(X), rtol=1e-13)
+    if n_landmarks:
+        ym = mellon.FunctionEstimator(sigma=0.5, n_landmarks=n_landmarks, landmarks=a.landmarks, ls=a.ls,
+                                      y_is_mean=True, obs_variance=True).fit(X, Y[:, 0])
+        rm = mo.function_fit(X, Y[:, 0], 1.0, n_landmarks=n_landmarks, landmarks=a.landmarks, ls=a.ls,
+                             y_is_mean=True)
+        np.testing.assert_allclose(ym.predict(X), rm(X), rtol=1e-7, atol=1e-9)
+        assert ym.get_obs_variance().shape == (160,)
