@@ -17,6 +17,7 @@ of the Ridge Gram once per fit).  `--scaling strong` shards the same 1e6 cells o
 Prints ONE JSON line on rank 0 (fields documented in DESIGN.md S6).
 """
 import argparse
+import ctypes
 import gc
 import json
 import os
@@ -78,7 +79,27 @@ def cpu_baseline(x, landmarks, nn, kern_name, sample):
                       f"os.cpu_count()={os.cpu_count()}"}, fit
 
 
+def _stdout_to_stderr():
+    """Route file descriptor 1 to stderr and return a handle on the real stdout.  Libraries loaded by the run print
+    to the C-level stdout on their own ("[Gloo] Rank 0 is connected ...", RCCL's version banner at communicator
+    set-up, which C stdio only flushes at exit, i.e. AFTER Python's output); the contract is ONE JSON line there."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
+def _print_result_line(real_stdout, line):
+    """Flush everything buffered so far to stderr, emit `line` alone on the real stdout, then keep stdout pointed at
+    stderr for whatever libraries print while shutting down."""
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    os.write(real_stdout, (line + "\n").encode())
+    os.close(real_stdout)
+
+
 def main():
+    real_stdout = _stdout_to_stderr()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -245,7 +266,7 @@ def main():
         gc.collect()
         base, _ = cpu_baseline(x0, landmarks, nn_loc, args.kernel, min(args.cpu_sample, n))
         out["cpu_baseline"] = base
-    print(json.dumps(out))
+    _print_result_line(real_stdout, json.dumps(out))
 
 
 if __name__ == "__main__":
