@@ -1193,7 +1193,7 @@ static int fit_objective_u(mln_fit* f, const double* u, double* loss, double* gr
   const int64_t ld = f->ldl;
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   // [z ; w] = Q1 u   (z = C^-T u ; implicit mode: w = P u = Lp^-T z)
-  MLN_TRY(launch_gemv_rows(ctx, f->Q1, ld, f->kspace ? 2 * m : m, m, f->d_u, f->d_zw));
+  MLN_TRY(launch_gemv_rows_tri(ctx, f->Q1, ld, f->kspace ? 2 * m : m, f->d_u, f->d_zw, 1, m, m, 0));   // C^-T, P: upper
   MLN_HIP(ctx, hipMemcpyAsync(f->d_z, f->d_zw, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
   ObjArgs a = obj_args(f);
   a.z = f->kspace ? (f->d_zw + m) : f->d_zw;
@@ -1207,12 +1207,12 @@ static int fit_objective_u(mln_fit* f, const double* u, double* loss, double* gr
     // g_u = C^-1 z + P^T r = Q2 [z ; r]
     MLN_HIP(ctx, hipMemcpyAsync(f->d_zr, f->d_zw, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
     MLN_HIP(ctx, hipMemcpyAsync(f->d_zr + ld, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_TRY(launch_gemv_rows(ctx, f->Q2, 2 * ld, m, 2 * ld, f->d_zr, f->d_gu));
+    MLN_TRY(launch_gemv_rows_tri(ctx, f->Q2, 2 * ld, m, f->d_zr, f->d_gu, 0, m, m, ld));                  // C^-1 | P^T: lower
   } else {
     // g_u = C^-1 (z + L^T (a - 1))
     MLN_HIP(ctx, hipMemcpyAsync(f->d_zr, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
     MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_zw, 1.0, f->d_zr));
-    MLN_TRY(launch_gemv_rows(ctx, f->Q2, ld, m, m, f->d_zr, f->d_gu));
+    MLN_TRY(launch_gemv_rows_tri(ctx, f->Q2, ld, m, f->d_zr, f->d_gu, 0, m, m, 0));
   }
   if (ctx->n_ranks > 1) {   // [lik, g_u, z] of rank 0 for everyone (see dev_bcast0)
     MLN_HIP(ctx, hipMemcpyAsync(f->d_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));

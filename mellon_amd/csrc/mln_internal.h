@@ -132,6 +132,8 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a);
 int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out_loss_grad /* 1 + m [+ m] */);
 int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x,
                      double* y);   // y = M x, one wave per row
+int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, const double* x, double* y,
+                         int upper, int64_t blk, int64_t ncol, int64_t seg);   // triangular blocks: non-zero part only
 
 // helpers (api.hip)
 int mln_scratch(mln_ctx* ctx, size_t bytes, void** out);

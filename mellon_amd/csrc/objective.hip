@@ -369,6 +369,37 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const double* __restrict__ M,
   if (lane == 0) y[r] = s;
 }
 
+// The same product for the stacked preconditioner operators, whose m x m blocks are triangular: only the non-zero
+// part of each row is read (half the bytes).  upper: row i of every block of `blk` rows holds columns [i, ncol);
+// lower: columns [0, i] -- in each of the (1 or 2) column segments, the second one starting at column `seg`.
+__global__ __launch_bounds__(256) void k_gemv_rows_tri(const double* __restrict__ M, int64_t ld, int64_t rows,
+                                                       const double* __restrict__ x, double* __restrict__ y,
+                                                       int upper, int64_t blk, int64_t ncol, int64_t seg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t i = r % blk;
+  const int64_t c_lo = upper ? (i & ~(int64_t)1) : 0, c_hi = upper ? ncol : i + 1;
+  const double* __restrict__ rowp = M + r * ld;
+  double s0 = 0.0, s1 = 0.0;
+  const int nseg = seg ? 2 : 1;
+  for (int sg = 0; sg < nseg; ++sg) {
+    const int64_t base = sg * seg;
+    const d2* __restrict__ row = reinterpret_cast<const d2*>(rowp + base);
+    const d2* __restrict__ xv = reinterpret_cast<const d2*>(x + base);
+    for (int64_t p = c_lo / 2 + lane; 2 * p + 1 < c_hi; p += 64) {
+      const d2 a = row[p], b = xv[p];
+      s0 = fma(a.x, b.x, s0);
+      s1 = fma(a.y, b.y, s1);
+    }
+    if ((c_hi & 1) && lane == 0) s0 = fma(rowp[base + c_hi - 1], x[base + c_hi - 1], s0);
+  }
+  double s = s0 + s1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) y[r] = s;
+}
+
 template <int CPT, int R>
 int launch_mode(mln_ctx* ctx, const ObjArgs& a, int mode) {
   dim3 grid((unsigned)a.n_wg), block(WG);
@@ -432,6 +463,16 @@ int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, in
   if (rows <= 0) return MLN_OK;
   if ((ld & 1) || ((uintptr_t)M & 15) || ((uintptr_t)x & 15)) { mln_set_error(ctx, "gemv_rows: unaligned operands"); return MLN_ERR_ARG; }
   hipLaunchKernelGGL(k_gemv_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, M, ld, rows, cols, x, y);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, const double* x, double* y,
+                         int upper, int64_t blk, int64_t ncol, int64_t seg) {
+  if (rows <= 0) return MLN_OK;
+  if ((ld & 1) || (seg & 1) || ((uintptr_t)M & 15) || ((uintptr_t)x & 15)) { mln_set_error(ctx, "gemv_rows_tri: unaligned operands"); return MLN_ERR_ARG; }
+  hipLaunchKernelGGL(k_gemv_rows_tri, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, M, ld, rows, x, y,
+                     upper, blk, ncol, seg);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
