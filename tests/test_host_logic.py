@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror (no GPU, no compute calls through the C-ABI):
 validators, decision tables, active-dims composition, heuristics, wire formats."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -183,3 +184,22 @@ def test_default_tolerance_floor():
     t0, t1 = solve(L, mo.LBFGSB_TIGHT), solve(Lq, mo.LBFGSB_TIGHT)
     assert rel(t1, t0) < 1e-6 < loose
     assert rel(solve(L, None), t0) < 1e-3
+
+
+def test_bench_prints_exactly_one_stdout_line():
+    """bench.py's contract: ONE JSON line on stdout, whatever Python or C-level code prints before or after."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, ctypes, bench\n"
+            "real = bench._stdout_to_stderr()\n"
+            "print('python noise')\n"
+            "ctypes.CDLL(None).puts(b'buffered C noise')\n"
+            "os.system('echo child noise')\n"
+            "bench._print_result_line(real, '{\"metric\": 1}')\n"
+            "print('late python noise')\n"
+            "ctypes.CDLL(None).puts(b'late C noise')\n")
+    out = subprocess.run([_sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == '{"metric": 1}\n', out.stdout
+    assert "buffered C noise" in out.stderr and "late C noise" in out.stderr
