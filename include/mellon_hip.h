@@ -105,6 +105,15 @@ int mln_release_cached_memory(void);
 int mln_comm_unique_id(void* id_out /* MLN_UNIQUE_ID_BYTES */);
 int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank);
 int mln_comm_allreduce_sum(mln_ctx* ctx, double* buf, int64_t count); /* host or device buffer */
+/* Loopback communicator: n_ranks contexts of ONE process (one host thread per rank; the contexts may all sit
+ * on the same GPU) exchange through device memory and a host barrier, every rank summing the contributions in
+ * rank order.  Same call sites, same results as RCCL -- it runs the N-rank sharded path on a single GPU.
+ * Every rank must enter each collective; the group outlives the contexts attached to it.                       */
+typedef struct mln_loopback mln_loopback;
+int mln_loopback_create(int n_ranks /* <= 16 */, mln_loopback** out);
+void mln_loopback_destroy(mln_loopback* group);
+int mln_comm_init_loopback(mln_ctx* ctx, mln_loopback* group, int rank);
+void mln_loopback_abort(mln_loopback* group); /* a rank failed outside a collective: wake the others with MLN_ERR_RCCL */
 
 /* ---- a-1..a-3: K = cov(x, y)   (util.py:351-366 distance, cov.py k(), base_cov.py Add/Mul/Pow)
  * x: n x d, y: m x d, out: n x m.                                                              */
@@ -216,6 +225,9 @@ int mln_ridge_init(mln_fit* fit, const double* target, double* z0 /* m */);
  *   mln_precond_apply      mode 0: u = C^T z;  mode 1: z = C^-T u;  mode 2: g_u = C^-1 g_z   (host m-vectors)
  *   mln_objective_precond  loss(C^-T u) and its gradient in u; optionally also z = C^-T u      */
 int mln_precond_build(mln_fit* fit, int64_t row_stride /* Gram from every row_stride-th cell; 1 = all */);
+/* Cell-sharded fits: the global index of this shard's first cell (default 0).  The row subsample above takes the cells
+ * whose GLOBAL index is a multiple of row_stride, so the preconditioner does not depend on the sharding.             */
+int mln_fit_set_row_offset(mln_fit* fit, int64_t global_row0);
 int mln_precond_apply(mln_fit* fit, int32_t mode, const double* in, double* out);
 int mln_objective_precond(mln_fit* fit, const double* u, double* loss, double* grad_u /* m */,
                           double* z_out /* m or NULL */);

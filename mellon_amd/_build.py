@@ -1,4 +1,7 @@
-"""Build libmellon_hip.so in-tree with hipcc for gfx950 (no GPU needed to compile)."""
+"""Build libmellon_hip.so in-tree with hipcc for gfx950 (no GPU needed to compile).
+
+Every source is compiled with -MMD, so that a later build recompiles exactly the translation units whose own
+text or one of the headers they really include has changed (the persistent-row covariance kernels take minutes)."""
 import os
 import subprocess
 import sys
@@ -7,45 +10,55 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmellon_hip.so")
-SOURCES = ["api.hip", "alloc.hip", "cov_grad.hip", "cov_kernels.hip", "dgemm.hip", "diag.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "objective.hip"]
-HEADERS = ["mln_internal.h", "linalg.h", "cov_program.h", os.path.join("..", "..", "include", "mellon_hip.h")]
+SOURCES = ["api.hip", "alloc.hip", "comm.hip", "cov_grad.hip", "cov_kernels.hip", "cov_rows.hip", "predict_rows.hip",
+           "dgemm.hip", "diag.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def _deps(depfile, src):
+    """Prerequisites recorded by -MMD (the source itself if there is no record yet)."""
+    if not os.path.exists(depfile):
+        return None
+    text = open(depfile).read().replace("\\\n", " ")
+    _, _, rhs = text.partition(":")
+    deps = [d for d in rhs.split() if d]
+    return deps or [src]
+
+
 def _stale(target, deps):
-    if not os.path.exists(target):
+    if not os.path.exists(target) or deps is None:
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any((not os.path.exists(d)) or os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append((src, obj))
+        dep = obj[:-2] + ".d"
+        if force or _stale(obj, _deps(dep, src)):
+            jobs.append((src, obj, dep))
 
     def cc(job):
-        src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        src, obj, dep = job
+        cmd = [hipcc] + FLAGS + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
-        for (src, obj), r in ex.map(cc, jobs):
+        for (src, obj, dep), r in ex.map(cc, jobs):
             if verbose and (r.stdout or r.stderr):
                 sys.stderr.write(r.stdout + r.stderr)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc failed on {src}")
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if verbose and (r.stdout or r.stderr):
             sys.stderr.write(r.stdout + r.stderr)

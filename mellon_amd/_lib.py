@@ -60,6 +60,10 @@ SYMBOLS = [
     ("mln_comm_unique_id", C.c_int, [_vp]),
     ("mln_comm_init", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     ("mln_comm_allreduce_sum", C.c_int, [_vp, _dp, _i64]),
+    ("mln_loopback_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
+    ("mln_loopback_destroy", None, [_vp]),
+    ("mln_comm_init_loopback", C.c_int, [_vp, _vp, C.c_int]),
+    ("mln_loopback_abort", None, [_vp]),
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_kernel_grad", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_predict_gradient", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _dp]),
@@ -80,6 +84,7 @@ SYMBOLS = [
     ("mln_fit_project", C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     ("mln_ridge_init", C.c_int, [_vp, _dp, _dp]),
     ("mln_precond_build", C.c_int, [_vp, _i64]),
+    ("mln_fit_set_row_offset", C.c_int, [_vp, _i64]),
     ("mln_precond_apply", C.c_int, [_vp, _i32, _dp, _dp]),
     ("mln_objective_precond", C.c_int, [_vp, _dp, C.POINTER(_dbl), _dp, _dp]),
     ("mln_map_solve", C.c_int, [_vp, _dp, C.POINTER(SolverOpts), _dp, C.POINTER(_dbl), C.POINTER(_i32),
@@ -245,6 +250,12 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), MLN_UNIQUE_ID_BYTES)
         self._check(self.lib.mln_comm_init(self.handle, buf, int(n_ranks), int(rank)))
         self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def comm_init_loopback(self, group, rank):
+        """Join the in-process loopback communicator `group` (a LoopbackGroup) as `rank`."""
+        self._check(self.lib.mln_comm_init_loopback(self.handle, group.handle, int(rank)))
+        self._loop_group = group          # keeps the group alive as long as this context
+        self.n_ranks, self.rank = group.n_ranks, int(rank)
 
     def allreduce_sum(self, a):
         if isinstance(a, DeviceArray):
@@ -488,6 +499,30 @@ class Context:
         return Fit(self, desc, x, landmarks, jitter, Lp, implicit)
 
 
+class LoopbackGroup:
+    """mln_loopback: the device side of n thread-ranks of one process (distributed.run_loopback)."""
+
+    def __init__(self, n_ranks):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if self.lib.mln_loopback_create(int(n_ranks), C.byref(h)) != MLN_OK:
+            raise MellonHipError(f"mln_loopback_create({n_ranks}) failed")
+        self.handle, self.n_ranks = h.value, int(n_ranks)
+
+    def abort(self):
+        """Release every rank waiting in a collective with an error (a peer failed elsewhere)."""
+        if self.handle is not None:
+            self.lib.mln_loopback_abort(self.handle)
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                self.lib.mln_loopback_destroy(self.handle)
+            self.handle = None
+        except Exception:
+            pass
+
+
 def _as2d(a):
     a = _f64(a)
     if a.ndim == 1:
@@ -594,7 +629,10 @@ class Fit:
                                                _ptr(hess)))
         return (loss.value, grad, hess) if with_hess else (loss.value, grad)
 
-    def precond_build(self, row_stride=1):
+    def precond_build(self, row_stride=1, row_offset=0):
+        """Factor the Ridge / preconditioner matrix from the cells whose global index (row_offset + local index) is a
+        multiple of row_stride; a no-op once built."""
+        self.ctx._check(self.lib.mln_fit_set_row_offset(self.handle, int(row_offset)))
         self.ctx._check(self.lib.mln_precond_build(self.handle, int(row_stride)), jitter="ridge")
 
     def precond_apply(self, mode, v):
@@ -663,8 +701,13 @@ _default_ctx = None
 
 
 def default_context():
-    """Process-wide context on GPU ``LOCAL_RANK`` (or ``MELLON_AMD_DEVICE``)."""
+    """The context of the calling thread's communicator (thread-ranks, distributed.run_loopback), else the
+    process-wide context on GPU ``LOCAL_RANK`` (or ``MELLON_AMD_DEVICE``)."""
     global _default_ctx
+    from . import distributed
+    comm = distributed.thread_state()
+    if comm is not None and comm.ctx is not None:
+        return comm.ctx
     if _default_ctx is None or _default_ctx.handle is None:
         _default_ctx = Context()
     return _default_ctx

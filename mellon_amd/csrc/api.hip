@@ -1,14 +1,16 @@
 // C ABI of libmellon_hip.so (see include/mellon_hip.h for the reference citations per entry).
-#include <dlfcn.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
 #include "linalg.h"
 #include "mln_internal.h"
+#include "objective.h"
+#include "solver.h"
 
 // ---- errors -------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
@@ -27,50 +29,6 @@ int mln_hip_fail(mln_ctx* ctx, hipError_t e, const char* what, const char* file,
 
 static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// ---- RCCL, bound lazily so single-GPU use never touches it ------------------------------------
-namespace rccl {
-typedef struct { char internal[128]; } UniqueId;
-typedef int (*GetUniqueId_t)(UniqueId*);
-typedef int (*CommInitRank_t)(void**, int, UniqueId, int);
-typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*CommDestroy_t)(void*);
-typedef int (*Broadcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef const char* (*GetErrorString_t)(int);
-static void* lib = nullptr;
-static GetUniqueId_t GetUniqueId = nullptr;
-static CommInitRank_t CommInitRank = nullptr;
-static AllReduce_t AllReduce = nullptr;
-static CommDestroy_t CommDestroy = nullptr;
-static Broadcast_t Broadcast = nullptr;
-static GetErrorString_t GetErrorString = nullptr;
-constexpr int kDouble = 8;  // ncclFloat64
-constexpr int kSum = 0;     // ncclSum
-static bool load(std::string* why) {
-  if (lib) return true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (lib) break;
-  }
-  if (!lib) { *why = std::string("cannot load librccl: ") + dlerror(); return false; }
-  GetUniqueId = (GetUniqueId_t)dlsym(lib, "ncclGetUniqueId");
-  CommInitRank = (CommInitRank_t)dlsym(lib, "ncclCommInitRank");
-  AllReduce = (AllReduce_t)dlsym(lib, "ncclAllReduce");
-  CommDestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
-  Broadcast = (Broadcast_t)dlsym(lib, "ncclBroadcast");
-  GetErrorString = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
-  if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) { *why = "librccl lacks nccl symbols"; return false; }
-  return true;
-}
-}  // namespace rccl
-
-static int rccl_fail(mln_ctx* ctx, int code, const char* what) {
-  std::string s = std::string("RCCL error in ") + what + ": ";
-  s += rccl::GetErrorString ? rccl::GetErrorString(code) : std::to_string(code);
-  mln_set_error(ctx, s);
-  return MLN_ERR_RCCL;
 }
 
 // ---- pointer helpers ------------------------------------------------------------------------------
@@ -224,7 +182,7 @@ extern "C" void mln_ctx_destroy(mln_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->comm && rccl::CommDestroy) rccl::CommDestroy(ctx->comm);
+  comm_release(ctx);
   if (ctx->scratch) (void)mln_dfree(ctx->scratch);
   if (ctx->d_info) (void)mln_dfree(ctx->d_info);
   (void)hipStreamDestroy(ctx->stream);
@@ -273,51 +231,14 @@ extern "C" int mln_memcpy(mln_ctx* ctx, void* dst, const void* src, int64_t byte
   return MLN_OK;
 }
 
-// ---- communicator -----------------------------------------------------------------------------------
-extern "C" int mln_comm_unique_id(void* id_out) {
-  std::string why;
-  if (!id_out) return MLN_ERR_ARG;
-  if (!rccl::load(&why)) { mln_set_error(nullptr, why); return MLN_ERR_RCCL; }
-  rccl::UniqueId id;
-  int rc = rccl::GetUniqueId(&id);
-  if (rc != 0) return rccl_fail(nullptr, rc, "ncclGetUniqueId");
-  std::memcpy(id_out, &id, MLN_UNIQUE_ID_BYTES);
-  return MLN_OK;
-}
-
-extern "C" int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank) {
-  if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MLN_ERR_ARG;
-  std::string why;
-  if (!rccl::load(&why)) { mln_set_error(ctx, why); return MLN_ERR_RCCL; }
-  MLN_HIP(ctx, hipSetDevice(ctx->device));
-  rccl::UniqueId uid;
-  std::memcpy(&uid, id, MLN_UNIQUE_ID_BYTES);
-  int rc = rccl::CommInitRank(&ctx->comm, n_ranks, uid, rank);
-  if (rc != 0) return rccl_fail(ctx, rc, "ncclCommInitRank");
-  ctx->n_ranks = n_ranks;
-  ctx->rank = rank;
-  return MLN_OK;
-}
-
-static int dev_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
-  if (!ctx->comm || count <= 0) return MLN_OK;   // a 1-rank communicator still goes through RCCL
-  int rc = rccl::AllReduce(dev, dev, (size_t)count, rccl::kDouble, rccl::kSum, ctx->comm, ctx->stream);
-  if (rc != 0) return rccl_fail(ctx, rc, "ncclAllReduce");
-  return MLN_OK;
-}
-
-// rank 0's copy becomes everybody's: replicated m-vectors that steer the shared optimiser are made
-// bit-identical on every rank, so that the ranks can never disagree on a line-search decision
-static int dev_bcast0(mln_ctx* ctx, double* dev, int64_t count) {
-  if (!ctx->comm || ctx->n_ranks <= 1 || count <= 0 || !rccl::Broadcast) return MLN_OK;
-  int rc = rccl::Broadcast(dev, dev, (size_t)count, rccl::kDouble, 0, ctx->comm, ctx->stream);
-  if (rc != 0) return rccl_fail(ctx, rc, "ncclBroadcast");
-  return MLN_OK;
-}
+// ---- communicator (comm.hip) ---------------------------------------------------------------------------
+static int dev_allreduce(mln_ctx* ctx, double* dev, int64_t count) { return comm_allreduce(ctx, dev, count); }
+static int dev_bcast0(mln_ctx* ctx, double* dev, int64_t count) { return comm_bcast0(ctx, dev, count); }
 
 extern "C" int mln_comm_allreduce_sum(mln_ctx* ctx, double* buf, int64_t count) {
   if (!ctx || (count > 0 && !buf)) return MLN_ERR_ARG;
-  if (!ctx->comm) return MLN_OK;
+  if (!ctx->comm && !ctx->loop) return MLN_OK;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevOut o;
   MLN_TRY(o.init(ctx, buf, (size_t)count, true));
   MLN_TRY(dev_allreduce(ctx, o.dev, count));
@@ -543,6 +464,16 @@ struct mln_fit {
   float* L32 = nullptr;
   int evals32 = 0;
   double times32 = 0.0;
+  // evaluation buffers of the preconditioned objective: d_zr = [z (ld2) | r (ld2)] with the likelihood sum at
+  // d_zr[ld2 + m], so that one all-reduce of m + 1 values covers [r ; lik];  ld2 = pad16(m + 1)
+  int64_t ld2 = 0;
+  int64_t row0 = 0;     // global index of this shard's first cell (subsampling is by global index)
+  // device-resident L-BFGS (solver.hip)
+  SolverBuffers sv{};
+  void* sv_block = nullptr;       // one allocation behind every pointer of sv
+  SolverState* h_state = nullptr; // pinned mirror
+  int sv_maxcor = 0;
+  std::vector<hipEvent_t> evs;    // three per evaluation: before the fp32 pass, between, after the fp64 pass
 };
 
 static void fit_free(mln_fit* f) {
@@ -555,8 +486,10 @@ static void fit_free(mln_fit* f) {
   triinv_free(&f->tri);
   void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
                   f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w, f->d_w_cached,
-                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32};
+                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
+  if (f->h_state) (void)hipHostFree(f->h_state);
+  for (hipEvent_t e : f->evs) (void)hipEventDestroy(e);
   if (f->h_z) (void)hipHostFree(f->h_z);
   if (f->h_out) (void)hipHostFree(f->h_out);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
@@ -575,14 +508,15 @@ static int fit_alloc_workspace(mln_fit* f) {
   f->n_wg = n_wg;
   n_wg = f->n_wg_cap;
   const size_t pm = (size_t)f->ldl;
+  f->ld2 = pad16(f->m + 1);
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_u, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_gu, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_tmp, sizeof(double) * (1 + pm)));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_w, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_w_cached, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_zw, sizeof(double) * 2 * pm));
-  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_zr, sizeof(double) * 2 * pm));
-  MLN_HIP(ctx, hipMemsetAsync(f->d_zr, 0, sizeof(double) * 2 * pm, ctx->stream));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_zr, sizeof(double) * 2 * (size_t)f->ld2));
+  MLN_HIP(ctx, hipMemsetAsync(f->d_zr, 0, sizeof(double) * 2 * (size_t)f->ld2, ctx->stream));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_loss, sizeof(double) * n_wg));
@@ -1004,14 +938,18 @@ static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int
 static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
   mln_ctx* ctx = f->ctx;
   if (row_stride < 1) row_stride = 1;
-  const int64_t rows = (f->n + row_stride - 1) / row_stride;
-  if (!f->kspace) return gram_of(ctx, f->L, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);
+  // cells whose GLOBAL index is a multiple of row_stride: the sample -- and with it the preconditioner and the
+  // iteration path -- does not depend on how the cells are sharded (up to the order of the all-reduce sum)
+  const int64_t first = (row_stride - f->row0 % row_stride) % row_stride;
+  const int64_t rows = (f->n > first) ? (f->n - first + row_stride - 1) / row_stride : 0;
+  const double* Ls = f->L + first * f->ldl;
+  if (!f->kspace) return gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);
   // implicit mode: G = Lp^-1 (K_s^T K_s) Lp^-T -- the Gram of the sampled rows of K itself (strided
   // rows read in place) followed by two m x m block solves.  Rounding in K_s^T K_s is amplified by
   // |Lp^-1|^2, which would matter for a quantity that enters the result; as a preconditioner the
   // outcome is spectrally equivalent to the row-solved Gram within 1e-3 (measured), at none of the
   // n_s m^2 triangular-solve flops.
-  int rc = gram_of(ctx, f->L, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);   // all-reduced
+  int rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);   // all-reduced
   double* T = nullptr;
   if (rc == MLN_OK) {
     hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)f->m * ldg);
@@ -1080,15 +1018,17 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
   if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs
     const int64_t ld = ldg;
     const size_t blk = (size_t)m * ld;
-    const int nq = f->kspace ? 2 : 1;
-    hipError_t e = mln_dmalloc((void**)&f->Q1, sizeof(double) * blk * nq);
-    if (e == hipSuccess) e = mln_dmalloc((void**)&f->Q2, sizeof(double) * blk * nq);
-    if (e == hipSuccess) e = hipMemsetAsync(f->Q1, 0, sizeof(double) * blk * nq, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(f->Q2, 0, sizeof(double) * blk * nq, ctx->stream);
+    const int nq1 = f->kspace ? 2 : 1;
+    hipError_t e = mln_dmalloc((void**)&f->Q1, sizeof(double) * blk * nq1);
+    if (e == hipSuccess) e = mln_dmalloc((void**)&f->Q2, sizeof(double) * blk * 2);
+    if (e == hipSuccess) e = hipMemsetAsync(f->Q1, 0, sizeof(double) * blk * nq1, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(f->Q2, 0, sizeof(double) * blk * 2, ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc stacked operators", __FILE__, __LINE__);
     if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ld, f->Q1, ld, m);                      // C^-T
     if (rc == MLN_OK && f->kspace) rc = launch_copy_block(ctx, f->P, ld, f->Q1 + blk, ld, m, ld);   // P below it
-    if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2, ld * nq, m, ld);             // C^-1
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2, ld * 2, m, ld);             // C^-1
+    // explicit factor: g_u = C^-1 (z + L^T(a-1)) = [C^-1 | C^-1] [z ; r] -- the same two-segment product
+    if (rc == MLN_OK && !f->kspace) rc = launch_copy_block(ctx, inv, ld, f->Q2 + ld, ld * 2, m, ld);
     if (rc == MLN_OK && f->kspace) {                                                           // P^T beside it
       double* Pt = nullptr;
       e = mln_dmalloc((void**)&Pt, sizeof(double) * blk);
@@ -1127,6 +1067,12 @@ static int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* 
     a.f_out = y;
     MLN_TRY(launch_objective(ctx, a));
   }
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_set_row_offset(mln_fit* f, int64_t global_row0) {
+  if (!f || global_row0 < 0) return MLN_ERR_ARG;
+  f->row0 = global_row0;
   return MLN_OK;
 }
 
@@ -1182,48 +1128,54 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
   return MLN_OK;
 }
 
-// loss and gradient with respect to u, z = C^-T u; everything between the upload of u and the
-// download of (loss, grad_u, z) stays on the device.
-//   explicit mode: f = L z + mu,            g_u = C^-1 (z + L^T (a - 1))
-//   implicit mode: f = K (P u) + mu,        g_u = C^-1 z + P^T (K^T (a - 1)),   P = Lp^-T C^-T
+// One evaluation of the preconditioned objective at the device vector `u`, enqueued without any host wait:
+//   [z ; w] = Q1 u  ->  one pass over the n x m buffer  ->  fixed-order reduction  ->  all-reduce of [r ; lik]
+//   ->  g_u = Q2 [z ; r]                                     (z -> d_zr, r -> d_zr + ld2, lik -> d_zr[ld2 + m], g_u -> gn)
+//   explicit mode: f = L z + mu,            g_u = C^-1 (z + L^T (a - 1))             Q2 = [C^-1 | C^-1]
+//   implicit mode: f = K (P u) + mu,        g_u = C^-1 z + P^T (K^T (a - 1)),        Q2 = [C^-1 | P^T],  P = Lp^-T C^-T
+// gate == nullptr: `use32` picks the streamed copy.  gate != nullptr (device-resident solver): both objective kernels
+// are launched and the one the solver's state does not select returns at once; everything is a no-op after DONE.
+// ev (optional): three events -- before the fp32 pass, between the two, after the fp64 pass.
+static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32, const int* gate,
+                            hipEvent_t* ev) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, ld = f->ldl, ld2 = f->ld2;
+  GemvTri g1{f->Q1, ld, f->kspace ? 2 * m : m, u_dev, f->d_zr, f->kspace ? f->d_w : nullptr, 1, m, m, 0, 0, gate};
+  MLN_TRY(launch_gemv_tri(ctx, g1));                                   // C^-T, P: upper triangular blocks
+  ObjArgs a = obj_args(f);
+  a.z = f->kspace ? f->d_w : f->d_zr;
+  a.gate = gate;
+  if (ev) MLN_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+  if (f->L32 && (gate || use32)) {
+    ObjArgs a32 = a;
+    a32.L32 = f->L32;
+    a32.gate_want = MLN_GATE_F32;
+    MLN_TRY(launch_objective(ctx, a32));
+  }
+  if (ev) MLN_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+  if (gate || !use32 || !f->L32) {
+    a.gate_want = MLN_GATE_F64;
+    MLN_TRY(launch_objective(ctx, a));
+  }
+  if (ev) MLN_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+  MLN_TRY(launch_reduce_obj2(ctx, a, f->d_zr + ld2 + m, f->d_zr + ld2));
+  MLN_TRY(dev_allreduce(ctx, f->d_zr + ld2, m + 1));
+  GemvTri g2{f->Q2, 2 * ld, m, f->d_zr, gn_dev, nullptr, 0, m, m, ld, ld2, gate};
+  MLN_TRY(launch_gemv_tri(ctx, g2));                                   // C^-1 | P^T: lower triangular blocks
+  return MLN_OK;
+}
+
+// host-synchronous form (SciPy-driven route, mln_objective_precond)
 static int fit_objective_u(mln_fit* f, const double* u, double* loss, double* grad_u, double* z_out,
                            bool use32 = false) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m;
-  const int64_t ld = f->ldl;
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
-  // [z ; w] = Q1 u   (z = C^-T u ; implicit mode: w = P u = Lp^-T z)
-  MLN_TRY(launch_gemv_rows_tri(ctx, f->Q1, ld, f->kspace ? 2 * m : m, f->d_u, f->d_zw, 1, m, m, 0));   // C^-T, P: upper
-  MLN_HIP(ctx, hipMemcpyAsync(f->d_z, f->d_zw, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-  ObjArgs a = obj_args(f);
-  a.z = f->kspace ? (f->d_zw + m) : f->d_zw;
-  if (use32) a.L32 = f->L32;
-  MLN_HIP(ctx, hipEventRecord(f->ev0, ctx->stream));
-  MLN_TRY(launch_objective(ctx, a));
-  MLN_HIP(ctx, hipEventRecord(f->ev1, ctx->stream));
-  MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
-  MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + m));
-  if (f->kspace) {
-    // g_u = C^-1 z + P^T r = Q2 [z ; r]
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_zr, f->d_zw, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_zr + ld, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_TRY(launch_gemv_rows_tri(ctx, f->Q2, 2 * ld, m, f->d_zr, f->d_gu, 0, m, m, ld));                  // C^-1 | P^T: lower
-  } else {
-    // g_u = C^-1 (z + L^T (a - 1))
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_zr, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_TRY(launch_axpby(ctx, m, 1.0, f->d_zw, 1.0, f->d_zr));
-    MLN_TRY(launch_gemv_rows_tri(ctx, f->Q2, ld, m, f->d_zr, f->d_gu, 0, m, m, 0));
-  }
-  if (ctx->n_ranks > 1) {   // [lik, g_u, z] of rank 0 for everyone (see dev_bcast0)
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_out + 1 + m, f->d_z, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_TRY(dev_bcast0(ctx, f->d_out, 1 + 2 * m));
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_gu, f->d_out + 1, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_z, f->d_out + 1 + m, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream));
-  }
-  MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  hipEvent_t ev[3] = {f->ev0, use32 ? f->ev1 : f->ev0, f->ev1};
+  MLN_TRY(fit_enqueue_eval(f, f->d_u, f->d_gu, use32, nullptr, ev));
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_zr + f->ld2 + m, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
-  MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_zr, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   obj_account(f, use32);
   double zz = 0.0;
@@ -1243,26 +1195,34 @@ extern "C" int mln_objective_precond(mln_fit* f, const double* u, double* loss, 
   return fit_objective_u(f, u, loss, grad_u, z_out);
 }
 
-// ---- a-8: the MAP solve, host-driven L-BFGS on the device objective ---------------------------------
-// Reference: inference.minimize_lbfgsb (inference.py:272-288) = SciPy L-BFGS-B without bounds.  Same
-// method (limited-memory BFGS two-loop recursion, H0 = s.y / y.y, sufficient-decrease line search
-// starting at step 1) and the same stopping tests as SciPy (relative decrease <= ftol, max|g| <= gtol,
-// maxiter), run on the preconditioned variable u.  The m-vectors live on the host (m <= 8192: the
-// two-loop recursion is microseconds); each evaluation is one fused pass over the n x m buffer.
-// Eight independent partial sums: a single running sum is one 4-cycle add chain per element (7 us for m = 5000, and
-// the two-loop recursion does up to 60 of them per iteration -- most of the gap between two objective kernels).
-// The order of the partial sums is fixed, so results stay bit-reproducible.
-static double vdot(const std::vector<double>& a, const std::vector<double>& b) {
-  const size_t n = a.size();
-  const double* __restrict__ pa = a.data();
-  const double* __restrict__ pb = b.data();
-  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  size_t i = 0;
-  for (; i + 8 <= n; i += 8)
-    for (int k = 0; k < 8; ++k) s[k] += pa[i + k] * pb[i + k];
-  double tail = 0.0;
-  for (; i < n; ++i) tail += pa[i] * pb[i];
-  return (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) + tail;
+// ---- a-8: the MAP solve: device-resident L-BFGS (solver.hip) --------------------------------------------------
+// Reference: inference.minimize_lbfgsb (inference.py:272-288) = SciPy L-BFGS-B without bounds.  Same method
+// (limited-memory BFGS two-loop recursion, H0 = s.y / y.y, sufficient-decrease backtracking from step 1 -- Armijo
+// only: SciPy's dcsrch also enforces the curvature condition, so iteration counts are not comparable one to one) and
+// SciPy's stopping tests (relative decrease <= ftol, max|g| <= gtol, maxiter) on the preconditioned variable u.
+// The optimiser's vectors and decisions live on the device; the host only enqueues evaluation chains in batches
+// and looks at the solver's state once per batch.
+static int fit_solver_alloc(mln_fit* f, int maxcor) {
+  mln_ctx* ctx = f->ctx;
+  if (f->sv_block && f->sv_maxcor >= maxcor) return MLN_OK;
+  if (f->sv_block) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, mln_dfree(f->sv_block)); f->sv_block = nullptr; }
+  const size_t ld = (size_t)f->ldl;
+  const size_t n_dbl = 5 * ld + 2 * (size_t)maxcor * ld + 2 * 64 + 4 * 512 + 32;
+  MLN_HIP(ctx, mln_dmalloc(&f->sv_block, sizeof(double) * n_dbl));
+  MLN_HIP(ctx, hipMemsetAsync(f->sv_block, 0, sizeof(double) * n_dbl, ctx->stream));
+  double* p = (double*)f->sv_block;
+  SolverBuffers& b = f->sv;
+  b.u = p; p += ld; b.g = p; p += ld; b.un = p; p += ld; b.gn = p; p += ld; b.d = p; p += ld;
+  b.S = p; p += (size_t)maxcor * ld; b.Y = p; p += (size_t)maxcor * ld;
+  b.rho = p; p += 64; b.yy = p; p += 64;
+  b.trace = p; p += 4 * 512;
+  b.st = (SolverState*)p;
+  b.ld = (int64_t)ld;
+  b.z = f->d_zr;
+  b.lik = f->d_zr + f->ld2 + f->m;
+  f->sv_maxcor = maxcor;
+  if (!f->h_state) MLN_HIP(ctx, hipHostMalloc((void**)&f->h_state, sizeof(SolverState), hipHostMallocDefault));
+  return MLN_OK;
 }
 
 extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts* opts_in, double* z_out,
@@ -1275,131 +1235,96 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   mln_solver_opts o = {5000, 30, 30, 1e-13, 1e-7};
   if (opts_in) o = *opts_in;
   if (o.maxcor < 1) o.maxcor = 1;
-  const size_t m = (size_t)f->m;
-  std::vector<double> u(m), g(m), un(m), gn(m), d(m), q(m), z(m);
-  // u0 = C^T z0
+  if (o.maxcor > 64) o.maxcor = 64;
+  if (o.maxls < 1) o.maxls = 1;
+  const int64_t m = f->m;
+  MLN_TRY(fit_solver_alloc(f, o.maxcor));
+  // u0 = C^T z0, identical on every rank
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, z0, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));
-  MLN_TRY(dev_bcast0(ctx, f->d_gu, (int64_t)m));   // identical starting point on every rank
-  MLN_HIP(ctx, hipMemcpyAsync(u.data(), f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
-  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  double fx = 0.0;
-  int n_eval = 0, it = 0, status = 1;
-  // Mixed precision: while an fp32 copy of the n x m buffer exists, the first passes stream it (half the
-  // bytes).  The fp32 objective is a smooth surrogate whose optimum sits ~5e-5 (relative loss) from the
-  // true one, so once its progress per iteration falls below ftol32 the solve continues on the fp64
-  // buffer, with the curvature pairs collected so far, to the same final tolerances as a pure fp64 run.
-  const bool trace_it = std::getenv("MELLON_AMD_TRACE") && std::atoi(std::getenv("MELLON_AMD_TRACE")) >= 2;
-  bool phase32 = f->kspace && f->L32 != nullptr;
-  double ftol32 = 3e-6;
-  if (const char* ev = std::getenv("MELLON_AMD_MIXED_FTOL")) ftol32 = std::atof(ev);
-  MLN_TRY(fit_objective_u(f, u.data(), &fx, g.data(), z.data(), phase32));
-  ++n_eval;
-  std::vector<std::vector<double>> S, Y;
-  std::vector<double> rho, alpha;
-  for (; it < o.maxiter; ++it) {
-    double gmax = 0.0;
-    for (double v : g) gmax = std::fmax(gmax, std::fabs(v));
-    if (!(gmax > o.gtol)) {
-      if (phase32) {
-        phase32 = false;
-        MLN_TRY(fit_objective_u(f, u.data(), &fx, g.data(), z.data(), false));
-        ++n_eval;
-        continue;
-      }
-      status = 0;
-      break;
+  MLN_TRY(dev_bcast0(ctx, f->d_gu, m));
+  // Mixed precision: while an fp32 copy of the n x m buffer exists, the first passes stream it (half the bytes);
+  // the solver switches to the fp64 buffer by itself (see k_solver_step) and finishes at the same tolerances as
+  // a pure fp64 run.
+  const int trace_lvl = std::getenv("MELLON_AMD_TRACE") ? std::atoi(std::getenv("MELLON_AMD_TRACE")) : 0;
+  const bool phase32 = f->kspace && f->L32 != nullptr;
+  SolverState init{};
+  init.gate = phase32 ? MLN_GATE_F32 : MLN_GATE_F64;
+  init.mode = MLN_SOLVE_FIRST;
+  init.status = 1;
+  init.maxiter = o.maxiter; init.maxcor = o.maxcor; init.maxls = o.maxls;
+  init.m = (int)m;
+  init.ftol = o.ftol; init.gtol = o.gtol; init.ftol32 = 3e-6;
+  if (const char* ev = std::getenv("MELLON_AMD_MIXED_FTOL")) init.ftol32 = std::atof(ev);
+  init.prior_const = 0.5 * (double)m * std::log(2.0 * M_PI);
+  MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
+  const int* gate = &f->sv.st->gate;
+  static const bool timing = !(std::getenv("MELLON_AMD_TIMING") && std::atoi(std::getenv("MELLON_AMD_TIMING")) == 0);
+  int n_enq = 0;
+  auto events_for = [&](int i) -> hipEvent_t* {
+    if (!timing || i >= 512) return nullptr;
+    while ((int)f->evs.size() < 3 * (i + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      f->evs.push_back(e);
     }
-    // two-loop recursion
-    q = g;
-    const int k = (int)S.size();
-    alpha.assign(k, 0.0);
-    for (int i = k - 1; i >= 0; --i) {
-      alpha[i] = rho[i] * vdot(S[i], q);
-      for (size_t j = 0; j < m; ++j) q[j] -= alpha[i] * Y[i][j];
+    return &f->evs[3 * i];
+  };
+  MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq)));
+  ++n_enq;
+  int batch = 8;
+  if (const char* ev = std::getenv("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
+  const int64_t hard_cap = (int64_t)o.maxiter * o.maxls + 16;
+  for (;;) {
+    for (int b = 0; b < batch; ++b) {
+      MLN_TRY(launch_solver_step(ctx, f->sv, (int)m));
+      MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq)));
+      ++n_enq;
     }
-    if (k > 0) {
-      const double gamma = vdot(S[k - 1], Y[k - 1]) / vdot(Y[k - 1], Y[k - 1]);
-      for (size_t j = 0; j < m; ++j) q[j] *= gamma;
-    }
-    for (int i = 0; i < k; ++i) {
-      const double beta = rho[i] * vdot(Y[i], q);
-      for (size_t j = 0; j < m; ++j) q[j] += S[i][j] * (alpha[i] - beta);
-    }
-    for (size_t j = 0; j < m; ++j) d[j] = -q[j];
-    double gd = vdot(g, d);
-    if (!(gd < 0.0)) {  // not a descent direction (cannot happen for SPD pairs; guard anyway)
-      S.clear(); Y.clear(); rho.clear();
-      for (size_t j = 0; j < m; ++j) d[j] = -g[j];
-      gd = -vdot(g, g);
-    }
-    double t = 1.0;
-    if (S.empty()) {
-      double g1 = 0.0;
-      for (double v : g) g1 += std::fabs(v);
-      t = std::fmin(1.0, 1.0 / g1);
-    }
-    bool ok = false;
-    double fn = 0.0;
-    int ls_used = 0;
-    for (int ls = 0; ls < o.maxls; ++ls) {
-      ls_used = ls + 1;
-      for (size_t j = 0; j < m; ++j) un[j] = u[j] + t * d[j];
-      MLN_TRY(fit_objective_u(f, un.data(), &fn, gn.data(), z.data(), phase32));
-      ++n_eval;
-      if (std::isfinite(fn) && fn <= fx + 1e-4 * t * gd) { ok = true; break; }
-      if (std::isfinite(fn)) {
-        const double tq = -gd * t * t / (2.0 * (fn - fx - gd * t));   // minimiser of the quadratic model
-        t = std::fmin(std::fmax(tq, 0.1 * t), 0.5 * t);
-      } else {
-        t *= 0.1;
-      }
-    }
-    if (trace_it) fprintf(stderr, "[it %d] %s ls_evals=%d t=%.3g f=%.15g df=%.3g gd=%.3g ok=%d\n", it, phase32 ? "f32" : "f64",
-                          ls_used, t, fn, fx - fn, gd, (int)ok);
-    if (!ok) {
-      if (phase32) {   // the fp32 surrogate is exhausted: continue in fp64 from the current point
-        phase32 = false;
-        MLN_TRY(fit_objective_u(f, u.data(), &fx, g.data(), z.data(), false));
-        ++n_eval;
-        continue;
-      }
-      status = 2;
-      break;
-    }
-    std::vector<double> s(m), y(m);
-    for (size_t j = 0; j < m; ++j) { s[j] = un[j] - u[j]; y[j] = gn[j] - g[j]; }
-    const double sy = vdot(s, y);
-    const double f_old = fx;
-    u.swap(un); g.swap(gn); fx = fn;
-    if (sy > 1e-10 * std::sqrt(vdot(s, s) * vdot(y, y))) {
-      S.push_back(std::move(s)); Y.push_back(std::move(y)); rho.push_back(1.0 / sy);
-      if ((int)S.size() > o.maxcor) { S.erase(S.begin()); Y.erase(Y.begin()); rho.erase(rho.begin()); }
-    }
-    const double fscale = std::fmax(std::fmax(std::fabs(f_old), std::fabs(fx)), 1.0);
-    if (phase32) {
-      if ((f_old - fx) <= ftol32 * fscale) {
-        phase32 = false;
-        MLN_TRY(fit_objective_u(f, u.data(), &fx, g.data(), z.data(), false));
-        ++n_eval;
-      }
-      continue;
-    }
-    if ((f_old - fx) <= o.ftol * fscale) { status = 0; ++it; break; }
+    // rank 0's state decides for everyone (it is the same state on every rank by construction: identical inputs,
+    // identical all-reduced sums, deterministic kernels -- this only rules out a hang should that ever fail)
+    MLN_TRY(dev_bcast0(ctx, (double*)f->sv.st, (int64_t)(sizeof(SolverState) / sizeof(double))));
+    MLN_HIP(ctx, hipMemcpyAsync(f->h_state, f->sv.st, sizeof(SolverState), hipMemcpyDeviceToHost, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (f->h_state->gate == MLN_GATE_DONE) break;
+    if (n_enq > hard_cap) { mln_set_error(ctx, "map_solve: the device solver did not terminate"); return MLN_ERR_NOCONV; }
+    if (batch < 16 && f->h_state->gate == MLN_GATE_F64) batch = std::min(batch, 6);
   }
-  // z = C^-T u at the accepted point
-  MLN_HIP(ctx, hipMemcpyAsync(f->d_u, u.data(), sizeof(double) * m, hipMemcpyHostToDevice, ctx->stream));
-  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_z));
-  MLN_TRY(fit_cache_pair_from_u(f, f->d_u));
-  MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
-  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (std::getenv("MELLON_AMD_TRACE"))
-    fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the fp32 copy, %.1f ms), %d iterations\n", n_eval,
-            f->evals32, 1e3 * f->times32, it);
-  if (loss_out) *loss_out = fx;
-  if (n_eval_out) *n_eval_out = n_eval;
-  if (n_iter_out) *n_iter_out = it;
-  if (status_out) *status_out = status;
+  const SolverState st = *f->h_state;
+  // kernel-time accounting from the per-evaluation events (the pass the solver did not select is a ~2 us no-op)
+  std::vector<double> tr;
+  const int n_done = st.n_eval < 512 ? st.n_eval : 512;
+  if (n_done > 0) {
+    tr.resize((size_t)4 * n_done);
+    MLN_HIP(ctx, hipMemcpy(tr.data(), f->sv.trace, sizeof(double) * 4 * n_done, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_done && timing && 3 * (i + 1) <= (int)f->evs.size(); ++i) {
+      const bool was32 = (int)tr[4 * i + 3] == MLN_GATE_F32;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, f->evs[3 * i + (was32 ? 0 : 1)], f->evs[3 * i + (was32 ? 1 : 2)]) != hipSuccess) continue;
+      if (was32) { f->times32 += 1e-3 * ms; f->evals32 += 1; }
+      else { f->times[5] += 1e-3 * ms; f->times[6] += 1.0; f->times[7] = (double)f->n * (double)f->ldl * 8.0; }
+    }
+    if (trace_lvl >= 2)
+      for (int i = 0; i < n_done; ++i)
+        fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, (int)tr[4 * i + 3] == MLN_GATE_F32 ? "f32" : "f64",
+                (int)tr[4 * i + 2], tr[4 * i + 1], tr[4 * i]);
+  }
+  // z = C^-T u and w = P u at the accepted point (one stacked product), remembered for transform / predictor weights
+  {
+    GemvTri g1{f->Q1, f->ldl, f->kspace ? 2 * m : m, f->sv.u, f->d_z, f->kspace ? f->d_w_cached : nullptr, 1, m, m, 0, 0, nullptr};
+    MLN_TRY(launch_gemv_tri(ctx, g1));
+    f->z_cached.assign((size_t)m, 0.0);
+    MLN_HIP(ctx, hipMemcpyAsync(f->z_cached.data(), f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (trace_lvl)
+    fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the fp32 copy), %d iterations, %d enqueued, status %d\n",
+            st.n_eval, st.n_eval32, st.it, n_enq, st.status);
+  if (loss_out) *loss_out = st.fx;
+  if (n_eval_out) *n_eval_out = st.n_eval;
+  if (n_iter_out) *n_iter_out = st.it;
+  if (status_out) *status_out = st.status;
   return MLN_OK;
 }
 

@@ -1,0 +1,281 @@
+// Communicators of libmellon_hip.so: the exchange steps of the cell-sharded path.
+//
+// The reference has no distributed code; the collectives follow from the maths of the path:
+//   all-reduce(sum) of [loss, K^T(a-1)] per objective evaluation      inference.py:167-192
+//   all-reduce(sum) of the m x m Ridge Gram once per fit             parameters.py:895-896
+//   broadcast of rank 0's copy of replicated m-vectors (bit-identical optimiser state)
+//
+// Two transports behind the same three calls (comm_allreduce / comm_bcast0 / comm_allgather):
+//   * RCCL over xGMI: one process per GPU, bound lazily with dlopen so single-GPU use never loads it
+//   * loopback: n_ranks contexts of ONE process, one host thread per rank, exchanging through device
+//     memory and a host barrier.  Every rank sums the n_ranks buffers in rank order, so all ranks get
+//     the same bits, as RCCL's all-reduce guarantees.  It exists so that the N-rank code path (sharded
+//     Gram, per-evaluation reductions, the replicated solver) runs, under test, on a single GPU.
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "mln_internal.h"
+
+// ---- RCCL ------------------------------------------------------------------------------------------
+namespace rccl {
+typedef struct { char internal[128]; } UniqueId;
+typedef int (*GetUniqueId_t)(UniqueId*);
+typedef int (*CommInitRank_t)(void**, int, UniqueId, int);
+typedef int (*AllReduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*AllGather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*CommDestroy_t)(void*);
+typedef int (*Broadcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*GetErrorString_t)(int);
+static void* lib = nullptr;
+static GetUniqueId_t GetUniqueId = nullptr;
+static CommInitRank_t CommInitRank = nullptr;
+static AllReduce_t AllReduce = nullptr;
+static AllGather_t AllGather = nullptr;
+static CommDestroy_t CommDestroy = nullptr;
+static Broadcast_t Broadcast = nullptr;
+static GetErrorString_t GetErrorString = nullptr;
+constexpr int kDouble = 8;  // ncclFloat64
+constexpr int kSum = 0;     // ncclSum
+static std::mutex load_mu;
+static bool load(std::string* why) {
+  std::lock_guard<std::mutex> lk(load_mu);
+  if (lib) return true;
+  // ROCm's own library by absolute path first: a host framework imported earlier may have mapped a
+  // bundled, older librccl under the same soname, which a bare dlopen("librccl.so.1") would return.
+  const char* names[] = {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
+  if (const char* ev = std::getenv("MELLON_AMD_RCCL")) lib = dlopen(ev, RTLD_NOW | RTLD_LOCAL);
+  for (const char* n : names) {
+    if (lib) break;
+    lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!lib) { *why = std::string("cannot load librccl: ") + dlerror(); return false; }
+  GetUniqueId = (GetUniqueId_t)dlsym(lib, "ncclGetUniqueId");
+  CommInitRank = (CommInitRank_t)dlsym(lib, "ncclCommInitRank");
+  AllReduce = (AllReduce_t)dlsym(lib, "ncclAllReduce");
+  AllGather = (AllGather_t)dlsym(lib, "ncclAllGather");
+  CommDestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
+  Broadcast = (Broadcast_t)dlsym(lib, "ncclBroadcast");
+  GetErrorString = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
+  if (!GetUniqueId || !CommInitRank || !AllReduce || !AllGather || !Broadcast || !CommDestroy) {
+    *why = "librccl lacks nccl symbols";
+    dlclose(lib);
+    lib = nullptr;
+    return false;
+  }
+  return true;
+}
+}  // namespace rccl
+
+static int rccl_fail(mln_ctx* ctx, int code, const char* what) {
+  std::string s = std::string("RCCL error in ") + what + ": ";
+  s += rccl::GetErrorString ? rccl::GetErrorString(code) : std::to_string(code);
+  mln_set_error(ctx, s);
+  return MLN_ERR_RCCL;
+}
+
+// ---- loopback ----------------------------------------------------------------------------------------
+struct mln_loopback {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  bool broken = false;               // a rank failed inside a collective: release everybody with an error
+  std::vector<const double*> ptr;    // the buffer each rank contributes to the collective in flight
+  std::vector<int> attached;
+  // false if the group was marked broken
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (broken) return false;
+    const uint64_t g = gen;
+    if (++arrived == n) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(lk, [&] { return gen != g || broken; });
+    return !broken;
+  }
+  void fail() {
+    std::lock_guard<std::mutex> lk(mu);
+    broken = true;
+    cv.notify_all();
+  }
+};
+
+namespace {
+
+constexpr int kMaxLoopRanks = 16;
+struct LoopPtrs { const double* p[kMaxLoopRanks]; };
+
+// out[i] = sum_r in[r][i], ranks in ascending order (the same order on every rank)
+__global__ __launch_bounds__(256) void k_loop_sum(LoopPtrs in, int n_ranks, double* __restrict__ out, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = in.p[0][i];
+    for (int r = 1; r < n_ranks; ++r) s += in.p[r][i];
+    out[i] = s;
+  }
+}
+
+int loop_fail(mln_ctx* ctx, const char* what) {
+  ctx->loop->fail();
+  mln_set_error(ctx, std::string("loopback communicator: ") + what);
+  return MLN_ERR_RCCL;
+}
+
+int loop_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
+  mln_loopback* g = ctx->loop;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return loop_fail(ctx, "stream failure before all-reduce");
+  g->ptr[ctx->rank] = dev;
+  if (!g->barrier()) return loop_fail(ctx, "a peer rank failed");
+  double* tmp = nullptr;
+  if (mln_dmalloc((void**)&tmp, sizeof(double) * (size_t)count) != hipSuccess) return loop_fail(ctx, "out of memory");
+  LoopPtrs in;
+  for (int r = 0; r < g->n; ++r) in.p[r] = g->ptr[r];
+  int64_t nb = (count + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_loop_sum, dim3((unsigned)nb), dim3(256), 0, ctx->stream, in, g->n, tmp, count);
+  const bool ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+  if (!ok) { (void)mln_dfree(tmp); return loop_fail(ctx, "summation kernel failed"); }
+  if (!g->barrier()) { (void)mln_dfree(tmp); return loop_fail(ctx, "a peer rank failed"); }   // everybody has read every buffer
+  hipError_t e = hipMemcpyAsync(dev, tmp, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(tmp);
+  if (e != hipSuccess) return loop_fail(ctx, "copy-back failed");
+  return MLN_OK;
+}
+
+int loop_bcast0(mln_ctx* ctx, double* dev, int64_t count) {
+  mln_loopback* g = ctx->loop;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return loop_fail(ctx, "stream failure before broadcast");
+  g->ptr[ctx->rank] = dev;
+  if (!g->barrier()) return loop_fail(ctx, "a peer rank failed");
+  if (ctx->rank != 0) {
+    hipError_t e = hipMemcpyAsync(dev, g->ptr[0], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return loop_fail(ctx, "broadcast copy failed");
+  }
+  if (!g->barrier()) return loop_fail(ctx, "a peer rank failed");
+  return MLN_OK;
+}
+
+// recv (n_ranks * count) <- concatenation of every rank's send (count) in rank order; send may alias its own slot
+int loop_allgather(mln_ctx* ctx, const double* send, double* recv, int64_t count) {
+  mln_loopback* g = ctx->loop;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return loop_fail(ctx, "stream failure before all-gather");
+  g->ptr[ctx->rank] = send;
+  if (!g->barrier()) return loop_fail(ctx, "a peer rank failed");
+  hipError_t e = hipSuccess;
+  for (int r = 0; r < g->n && e == hipSuccess; ++r) {
+    double* dst = recv + (int64_t)r * count;
+    if (dst != g->ptr[r])
+      e = hipMemcpyAsync(dst, g->ptr[r], sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return loop_fail(ctx, "all-gather copy failed");
+  if (!g->barrier()) return loop_fail(ctx, "a peer rank failed");
+  return MLN_OK;
+}
+
+}  // namespace
+
+// ---- the three collectives the path uses --------------------------------------------------------------
+int comm_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
+  if (count <= 0) return MLN_OK;
+  if (ctx->loop) return loop_allreduce(ctx, dev, count);
+  if (!ctx->comm) return MLN_OK;   // a 1-rank RCCL communicator still goes through RCCL
+  int rc = rccl::AllReduce(dev, dev, (size_t)count, rccl::kDouble, rccl::kSum, ctx->comm, ctx->stream);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclAllReduce");
+  return MLN_OK;
+}
+
+// rank 0's copy becomes everybody's: replicated m-vectors that steer the shared optimiser are made
+// bit-identical on every rank, so that the ranks can never disagree on a line-search decision
+int comm_bcast0(mln_ctx* ctx, double* dev, int64_t count) {
+  if (count <= 0 || ctx->n_ranks <= 1) return MLN_OK;
+  if (ctx->loop) return loop_bcast0(ctx, dev, count);
+  if (!ctx->comm) return MLN_OK;
+  int rc = rccl::Broadcast(dev, dev, (size_t)count, rccl::kDouble, 0, ctx->comm, ctx->stream);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclBroadcast");
+  return MLN_OK;
+}
+
+int comm_allgather(mln_ctx* ctx, const double* send, double* recv, int64_t count) {
+  if (count <= 0) return MLN_OK;
+  if (ctx->loop) return loop_allgather(ctx, send, recv, count);
+  if (!ctx->comm) {
+    if (recv != send) MLN_HIP(ctx, hipMemcpyAsync(recv, send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
+    return MLN_OK;
+  }
+  int rc = rccl::AllGather(send, recv, (size_t)count, rccl::kDouble, ctx->comm, ctx->stream);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclAllGather");
+  return MLN_OK;
+}
+
+void comm_release(mln_ctx* ctx) {
+  if (ctx->comm && rccl::CommDestroy) rccl::CommDestroy(ctx->comm);
+  ctx->comm = nullptr;
+  ctx->loop = nullptr;   // the group belongs to whoever created it
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------------
+extern "C" int mln_comm_unique_id(void* id_out) {
+  std::string why;
+  if (!id_out) return MLN_ERR_ARG;
+  if (!rccl::load(&why)) { mln_set_error(nullptr, why); return MLN_ERR_RCCL; }
+  rccl::UniqueId id;
+  int rc = rccl::GetUniqueId(&id);
+  if (rc != 0) return rccl_fail(nullptr, rc, "ncclGetUniqueId");
+  std::memcpy(id_out, &id, MLN_UNIQUE_ID_BYTES);
+  return MLN_OK;
+}
+
+extern "C" int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank) {
+  if (!ctx || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MLN_ERR_ARG;
+  if (ctx->comm || ctx->loop) { mln_set_error(ctx, "this context already has a communicator"); return MLN_ERR_ARG; }
+  std::string why;
+  if (!rccl::load(&why)) { mln_set_error(ctx, why); return MLN_ERR_RCCL; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  rccl::UniqueId uid;
+  std::memcpy(&uid, id, MLN_UNIQUE_ID_BYTES);
+  int rc = rccl::CommInitRank(&ctx->comm, n_ranks, uid, rank);
+  if (rc != 0) return rccl_fail(ctx, rc, "ncclCommInitRank");
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return MLN_OK;
+}
+
+extern "C" int mln_loopback_create(int n_ranks, mln_loopback** out) {
+  if (!out || n_ranks < 1 || n_ranks > kMaxLoopRanks) return MLN_ERR_ARG;
+  mln_loopback* g = new mln_loopback();
+  g->n = n_ranks;
+  g->ptr.assign((size_t)n_ranks, nullptr);
+  g->attached.assign((size_t)n_ranks, 0);
+  *out = g;
+  return MLN_OK;
+}
+
+extern "C" void mln_loopback_destroy(mln_loopback* g) { delete g; }
+
+extern "C" void mln_loopback_abort(mln_loopback* g) {
+  if (g) g->fail();
+}
+
+extern "C" int mln_comm_init_loopback(mln_ctx* ctx, mln_loopback* g, int rank) {
+  if (!ctx || !g || rank < 0 || rank >= g->n) return MLN_ERR_ARG;
+  if (ctx->comm || ctx->loop) { mln_set_error(ctx, "this context already has a communicator"); return MLN_ERR_ARG; }
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->attached[rank]) { mln_set_error(ctx, "loopback rank already attached"); return MLN_ERR_ARG; }
+    g->attached[rank] = 1;
+  }
+  ctx->loop = g;
+  ctx->n_ranks = g->n;
+  ctx->rank = rank;
+  return MLN_OK;
+}

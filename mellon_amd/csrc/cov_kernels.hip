@@ -12,10 +12,12 @@
 
 #include "mln_internal.h"
 #include "cov_program.h"
+#include "cov_rows.h"
 
 namespace {
 
-constexpr int TM = 64, TN = 64, DK = 16, PADT = 4;
+constexpr int TM = 64, TN = covrows::TN, DK = 16, PADT = 4;
+constexpr int NNS = covrows::NNS;
 
 // Divisions by the length scale / by 3 are multiplications by the reciprocal (one rounding instead of
 // a ~20-instruction fp64 divide per element): values differ from the reference's `x / ls` by <= 1 ulp.
@@ -228,7 +230,6 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double*
 // staging this one-tile-per-workgroup form through LDS (38 ms) and hand-written sqrt/exp (no change) were
 // tried and dropped; large shapes use k_kernel_matrix_rows below, which overlaps the matrix pipe with the
 // epilogue inside each wave (27 ms).
-typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_kernel_matrix_mfma(DevCov cov, const double* __restrict__ x, int64_t n,
                                                             const double* __restrict__ y, int64_t m, int d,
@@ -781,7 +782,6 @@ __global__ __launch_bounds__(256) void k_nn_distances(const double* __restrict__
 // which are staged through LDS once per workgroup (double-buffered, coalesced in, [row][k] with a
 // 68-double row stride out) and shared by the 8 waves.  Only xx - 2 x.y + yy and a running minimum per
 // element: the pass is bound by the fp64 matrix pipe (2 n m d flops).
-constexpr int NNS = 68;   // LDS row stride (doubles): = 4 mod 32, 16 rows x 4 k touch every bank pair twice
 
 __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restrict__ x, int64_t n,
                                                            const double* __restrict__ y, int64_t m, int d,
@@ -858,223 +858,6 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
     for (int off = 8; off > 0; off >>= 1) s_ = fmin(s_, __shfl_xor(s_, off, 64));
     const int64_t row = row0 + lk + 4 * r;
     if (li == 0 && row < n) out[row] = sqrt(s_);
-  }
-}
-
-// Kernel matrix, single leaf over all d <= 64 columns, persistent-row form with the matrix pipe and the VALU
-// working at the same time: a workgroup of 8 waves owns 128 rows; every wave keeps the MFMA A operands of its
-// 16 rows in registers and walks all centre tiles (staged through LDS, three buffers).  In one loop body the
-// wave issues the 4 x ksteps MFMAs of tile t+1 into one accumulator set while the sqrt/exp epilogue and the
-// stores of tile t run on the other set -- independent instruction streams in one basic block, interleaved
-// with sched_group_barrier (1 MFMA : 24 VALU), so neither pipe waits for the other.
-template <int KIND>
-__device__ __forceinline__ double leaf_value_k(const DevLeaf& lf, double xx, double yy, double xy) {
-  const double inv_ls = lf.alpha_inv_ls[1];
-  const double sq = xx - 2.0 * xy + yy + 1e-12;
-  const double dist = sqrt(fmax(sq, 0.0));
-  if (KIND == MLN_K_MATERN32) { const double r = 1.7320508075688772 * dist * inv_ls; return (r + 1.0) * exp(-r); }
-  if (KIND == MLN_K_MATERN52) { const double r = 2.23606797749979 * dist * inv_ls; return (r + r * r * 0.3333333333333333 + 1.0) * exp(-r); }
-  if (KIND == MLN_K_EXPQUAD) { const double r = dist * inv_ls; return exp(-0.5 * (r * r)); }
-  if (KIND == MLN_K_EXPONENTIAL) { const double r = dist * inv_ls; return exp(-0.5 * r); }
-  const double r = dist * inv_ls;
-  return pow(r * r / (2.0 * lf.alpha) + 1.0, -lf.alpha);
-}
-
-template <int KIND, bool HAS32, int KSTEPS>
-__global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const double* __restrict__ x, int64_t n,
-                                                            const double* __restrict__ y, int64_t m, int d,
-                                                            const double* __restrict__ xx,
-                                                            const double* __restrict__ yy,
-                                                            double* __restrict__ out, int64_t ldo, double add_diag,
-                                                            float* __restrict__ out32) {
-  __shared__ double ys[2][TN * NNS];   // tile t+1 is consumed while tile t+2 lands in the buffer tile t left
-  __shared__ double yn[3][TN];
-  const DevLeaf lf = cov.leaves[0];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
-  double a[16];
-  {
-    const int64_t ar = (row0 + li < n) ? row0 + li : n - 1;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int k = 4 * ks + lk;
-      a[ks] = (k < d) ? x[ar * d + k] : 0.0;
-    }
-  }
-  double xr[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t row = row0 + lk + 4 * r;
-    xr[r] = (row < n) ? xx[row] : 0.0;
-  }
-  for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;
-  __syncthreads();
-  auto stage = [&](int64_t tile) {
-    const int64_t col0 = tile * TN;
-    const int buf = (int)(tile & 1), nb = (int)(tile % 3);
-    const int cnt = TN * d;
-    for (int e = tid; e < cnt; e += 512) {
-      const int r = e / d, k = e - r * d;
-      ys[buf][r * NNS + k] = (col0 + r < m) ? y[(col0 + r) * d + k] : 0.0;
-    }
-    if (tid < TN) yn[nb][tid] = (col0 + tid < m) ? yy[col0 + tid] : 0.0;   // norms: three buffers (the epilogue of tile t reads them one step later)
-  };
-  auto mma = [&](int buf, v4d_t (&acc)[4]) {
-    const double* yb = &ys[buf][li * NNS + lk];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = v4d_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)   // 4 KSTEPS >= d; k columns past d are zero in both operands
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], yb[16 * t * NNS + 4 * ks], acc[t], 0, 0, 0);
-  };
-  const int64_t ntiles = (ldo + TN - 1) / TN;   // covers the pad columns of the leading dimension
-  const bool interior_rows = (int64_t)blockIdx.x * 128 + 128 <= n;
-  stage(0);
-  if (ntiles > 1) stage(1);
-  __syncthreads();
-  v4d_t accA[4], accB[4];
-  mma(0, accA);
-  __syncthreads();
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const int cur = (int)(t % 3), nxt = (int)((t + 1) & 1);
-    if (t + 2 < ntiles) stage(t + 2);                 // into the ys buffer of tile t, whose MFMAs finished last step
-    mma(nxt, accB);                                   // tile t + 1 (the last one is a dummy on stale data)
-    const int64_t col0 = t * TN;
-    if (interior_rows && col0 + TN <= m && add_diag == 0.0) {
-      // branch-free epilogue: one basic block together with the MFMAs above
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int64_t c = col0 + 16 * tt + li;
-        const double yc = yn[cur][16 * tt + li];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t row = row0 + lk + 4 * r;
-          const double v = leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]);
-          out[row * ldo + c] = v;
-          if (HAS32) out32[row * ldo + c] = (float)v;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4 * KSTEPS; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 1280 / (4 * KSTEPS), 0);   // its share of the epilogue VALU
-      }
-    } else {
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int64_t c = col0 + 16 * tt + li;
-        const double yc = yn[cur][16 * tt + li];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t row = row0 + lk + 4 * r;
-          if (row < n && c < ldo) {
-            const double v = (c < m) ? leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]) + ((row == c) ? add_diag : 0.0) : 0.0;
-            out[row * ldo + c] = v;
-            if (HAS32) out32[row * ldo + c] = (float)v;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) accA[tt] = accB[tt];
-    __syncthreads();
-  }
-}
-
-// Fused predictive mean in the same persistent-row form (conditional.py:899-906, one output): the epilogue of
-// tile t multiplies each covariance value by its weight and adds it to the row sums while the MFMAs of tile
-// t+1 run; the n' x m matrix never exists.
-template <int KIND, int KSTEPS>
-__global__ __launch_bounds__(512) void k_predict_mean_rows(DevCov cov, const double* __restrict__ x, int64_t n,
-                                                           const double* __restrict__ y, int64_t m, int d,
-                                                           const double* __restrict__ xx,
-                                                           const double* __restrict__ yy,
-                                                           const double* __restrict__ w, double mu,
-                                                           double* __restrict__ out) {
-  __shared__ double ys[2][TN * NNS];
-  __shared__ double yn[3][TN];
-  __shared__ double yw[3][TN];
-  const DevLeaf lf = cov.leaves[0];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
-  double a[16];
-  {
-    const int64_t ar = (row0 + li < n) ? row0 + li : n - 1;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int k = 4 * ks + lk;
-      a[ks] = (k < d) ? x[ar * d + k] : 0.0;
-    }
-  }
-  double xr[4], part[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t row = row0 + lk + 4 * r;
-    xr[r] = (row < n) ? xx[row] : 0.0;
-    part[r] = 0.0;
-  }
-  for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;
-  __syncthreads();
-  auto stage = [&](int64_t tile) {
-    const int64_t col0 = tile * TN;
-    const int buf = (int)(tile & 1), nb = (int)(tile % 3);
-    const int cnt = TN * d;
-    for (int e = tid; e < cnt; e += 512) {
-      const int r = e / d, k = e - r * d;
-      ys[buf][r * NNS + k] = (col0 + r < m) ? y[(col0 + r) * d + k] : 0.0;
-    }
-    if (tid < TN) {
-      yn[nb][tid] = (col0 + tid < m) ? yy[col0 + tid] : 0.0;
-      yw[nb][tid] = (col0 + tid < m) ? w[col0 + tid] : 0.0;     // weight 0 masks the columns past m
-    }
-  };
-  auto mma = [&](int buf, v4d_t (&acc)[4]) {
-    const double* yb = &ys[buf][li * NNS + lk];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = v4d_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], yb[16 * t * NNS + 4 * ks], acc[t], 0, 0, 0);
-  };
-  const int64_t ntiles = (m + TN - 1) / TN;
-  stage(0);
-  if (ntiles > 1) stage(1);
-  __syncthreads();
-  v4d_t accA[4], accB[4];
-  mma(0, accA);
-  __syncthreads();
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const int cur = (int)(t % 3), nxt = (int)((t + 1) & 1);
-    if (t + 2 < ntiles) stage(t + 2);
-    mma(nxt, accB);
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const double yc = yn[cur][16 * tt + li], wc = yw[cur][16 * tt + li];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part[r] = fma(leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]), wc, part[r]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4 * KSTEPS; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1100 / (4 * KSTEPS), 0);
-    }
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) accA[tt] = accB[tt];
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    double s_ = part[r];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) s_ += __shfl_xor(s_, off, 64);
-    const int64_t row = row0 + lk + 4 * r;
-    if (li == 0 && row < n) out[row] = mu + s_;
   }
 }
 
@@ -1169,25 +952,7 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   static const bool no_rows = std::getenv("MELLON_AMD_KM_NO_ROWS") != nullptr;
   if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE) {
-    const dim3 grid((unsigned)((n + 127) / 128)), block(512);
-#define MLN_KM_ROWS2(KIND, KS)                                                                                       \
-  if (out32) hipLaunchKernelGGL((k_kernel_matrix_rows<KIND, true, KS>), grid, block, 0, ctx->stream, cov, x, n, y, m, d, \
-                                xx, yy, out, ldo, add_diag, out32);                                                 \
-  else hipLaunchKernelGGL((k_kernel_matrix_rows<KIND, false, KS>), grid, block, 0, ctx->stream, cov, x, n, y, m, d, xx, \
-                          yy, out, ldo, add_diag, out32);
-#define MLN_KM_ROWS(KIND)                                  \
-  if (d <= 32) { MLN_KM_ROWS2(KIND, 8) }                   \
-  else if (d <= 52) { MLN_KM_ROWS2(KIND, 13) }             \
-  else { MLN_KM_ROWS2(KIND, 16) }
-    switch (cov.leaves[0].kind) {
-      case MLN_K_MATERN32: MLN_KM_ROWS(MLN_K_MATERN32) break;
-      case MLN_K_MATERN52: MLN_KM_ROWS(MLN_K_MATERN52) break;
-      case MLN_K_EXPQUAD: MLN_KM_ROWS(MLN_K_EXPQUAD) break;
-      case MLN_K_EXPONENTIAL: MLN_KM_ROWS(MLN_K_EXPONENTIAL) break;
-      default: MLN_KM_ROWS(MLN_K_RATQUAD) break;
-    }
-#undef MLN_KM_ROWS2
-#undef MLN_KM_ROWS
+    MLN_TRY(launch_kernel_matrix_rows(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32));
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_kernel_matrix_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, out, ldo, add_diag, tiles_n, out32);
@@ -1218,22 +983,7 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
   if (contiguous && !no_mfma && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE) {
-    const dim3 grid((unsigned)((n + 127) / 128)), block(512);
-#define MLN_PM_ROWS2(KIND, KS) \
-  hipLaunchKernelGGL((k_predict_mean_rows<KIND, KS>), grid, block, 0, ctx->stream, cov, x, n, y, m, d, xx, yy, w, mu, out);
-#define MLN_PM_ROWS(KIND)                                  \
-  if (d <= 32) { MLN_PM_ROWS2(KIND, 8) }                   \
-  else if (d <= 52) { MLN_PM_ROWS2(KIND, 13) }             \
-  else { MLN_PM_ROWS2(KIND, 16) }
-    switch (cov.leaves[0].kind) {
-      case MLN_K_MATERN32: MLN_PM_ROWS(MLN_K_MATERN32) break;
-      case MLN_K_MATERN52: MLN_PM_ROWS(MLN_K_MATERN52) break;
-      case MLN_K_EXPQUAD: MLN_PM_ROWS(MLN_K_EXPQUAD) break;
-      case MLN_K_EXPONENTIAL: MLN_PM_ROWS(MLN_K_EXPONENTIAL) break;
-      default: MLN_PM_ROWS(MLN_K_RATQUAD) break;
-    }
-#undef MLN_PM_ROWS
-#undef MLN_PM_ROWS2
+    MLN_TRY(launch_predict_mean_rows(ctx, cov, x, n, y, m, d, xx, yy, w, mu, out));
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_predict_mean_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, w, mu, out);

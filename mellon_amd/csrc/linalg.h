@@ -20,3 +20,6 @@ int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int
 int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows,
                       int64_t cols);
 int launch_transpose(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m);  // dst = src^T (m x m)
+// potrf.hip: Cholesky of one nb x nb (nb <= 128) diagonal block in place + the inverse of its factor (Dinv: 128 x 128,
+// leading dimension 128, strictly-upper blocks untouched); *info = global pivot index + 1 on a bad pivot
+int launch_potrf128(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, int* info, int64_t j0);

@@ -2,9 +2,9 @@
 //
 // Reference arithmetic: jnp.linalg.cholesky (decomposition.py:115, conditional.py:73) and
 // jax.scipy.linalg.solve_triangular (decomposition.py:209, conditional.py:63-65,264,818), i.e.
-// LAPACK potrf/trtrs semantics.  Here: right-looking blocked Cholesky (64-wide panels: LDS
-// factorisation of the diagonal block + its inverse, then panel-solve and trailing SYRK as fp64
-// MFMA GEMMs), and triangular solves as sequences of GEMMs against row-/column-scaled copies of
+// LAPACK potrf/trtrs semantics.  Here: right-looking blocked Cholesky (128-wide block columns: the
+// diagonal block and its inverse by one workgroup in LDS (potrf.hip), then the panel solve and the trailing
+// SYRK as fp64 MFMA GEMMs), and triangular solves as sequences of GEMMs against row-/column-scaled copies of
 // the factor whose 128x128 diagonal blocks are inverted explicitly (the standard GPU TRSM; only
 // diagonal blocks are ever inverted, so the conditioning that enters is that of a 128-block).
 #include "mln_internal.h"
@@ -14,80 +14,6 @@ namespace {
 
 constexpr int PB = 64;    // Cholesky panel width
 constexpr int TB = 128;   // triangular-solve block
-
-// Factorises the nb x nb (nb <= 64) lower block at A and writes the factor back (strict upper part
-// zeroed) together with its inverse Dinv (64 x 64, row-major, ld 64).  ONE wave64: lane i keeps row i
-// of the block in registers; pivots and the column being eliminated travel as wave-uniform values
-// (v_readlane), so the 64 elimination steps need no LDS and no barrier (was: 170 us per block in
-// LDS with three barriers per column; this form is ~15 us).  A non-positive or NaN pivot sets
-// *info = (global pivot index + 1) once and leaves the block unfactorised.
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(64) void k_potrf64(double* A, int64_t lda, int nb, double* __restrict__ Dinv,
-                                                int* info, int64_t j0) {
-  const int lane = threadIdx.x;
-  __shared__ double dinv_s[PB];          // 1 / T_kk for the inverse below
-  double a[PB];
-#pragma unroll
-  for (int j = 0; j < PB; ++j)
-    a[j] = (lane < nb && j <= lane && j < nb) ? A[(int64_t)lane * lda + j] : ((j == lane) ? 1.0 : 0.0);
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < PB; ++k) {
-    const double d = lane_bcast(a[k], k);
-    if (!(d > 0.0)) {  // wave-uniform
-      if (!bad && lane == 0) atomicCAS(info, 0, (int)(j0 + k + 1));
-      bad = true;
-    }
-    // 1/sqrt(d) from the hardware estimate and two Newton steps, sqrt(d) = d * that with one Heron correction:
-    // a few dependent FMAs on the critical path instead of a square-root and a division sequence
-    double inv = __builtin_amdgcn_rsq(d);
-    inv = inv * fma(-0.5 * d, inv * inv, 1.5);
-    inv = inv * fma(-0.5 * d, inv * inv, 1.5);
-    double sq = d * inv;
-    sq = fma(0.5 * inv, fma(-sq, sq, d), sq);
-    const double lik = (lane == k) ? sq : ((lane > k) ? a[k] * inv : 0.0);
-    if (lane == k) dinv_s[k] = inv;
-    a[k] = lik;
-    double lk = lik;
-#pragma unroll
-    for (int j = k + 1; j < PB; ++j) {
-      const double ljk = lane_bcast(lk, j);
-      a[j] = fma(-lk, ljk, a[j]);
-      // Every 8 columns tie the broadcast source to the update just made: the next broadcasts then cannot be
-      // issued before these updates, so at most 8 broadcast values (16 SGPRs) are alive.  Without it the whole
-      // column is broadcast first and most of it spills (3262 v_writelane spills of SGPRs).
-      if (((j - k) & 1) == 0) asm volatile("" : "+v"(lk), "+v"(a[j]));
-    }
-  }
-  if (bad) return;
-  // The factor goes to global memory and to LDS; the inverse below then reads T_ik as uniform (broadcast) LDS
-  // loads with only x[] in registers.  Keeping a[] AND x[] (256 VGPRs) live made the compiler turn whole columns
-  // of a[] into scalar registers at once: 7356 spilled SGPRs, 16 k v_readlane and 130 us per block.
-  __shared__ double Ts[PB][PB];
-#pragma unroll
-  for (int j = 0; j < PB; ++j) {
-    const double v = (j <= lane) ? a[j] : 0.0;
-    Ts[lane][j] = v;
-    if (lane < nb && j < nb) A[(int64_t)lane * lda + j] = v;
-  }
-  __syncthreads();
-  // X = T^-1, lane c owns column c:  x_i = (delta_ic - sum_{k<i} T_ik x_k) / T_ii
-  double x[PB];
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    double sacc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < i; ++k) sacc = fma(-Ts[i][k], x[k], sacc);
-    x[i] = sacc * dinv_s[i];
-  }
-#pragma unroll
-  for (int j = 0; j < PB; ++j) Dinv[j * PB + lane] = x[j];   // X[j][lane]: row j, column lane
-}
 
 // inverse of every 64 x 64 diagonal block of a lower-triangular factor, written into the same
 // position of W (blocks past m are padded with identity rows)
@@ -259,22 +185,27 @@ int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst,
   return MLN_OK;
 }
 
-// In-place lower Cholesky of the m x m matrix at A (only the lower triangle is read).
+// In-place lower Cholesky of the m x m matrix at A (only the lower triangle is read): right-looking over 128-wide
+// block columns.  Per step: k_potrf128 (potrf.hip: the diagonal block and its inverse, one workgroup), the rest of
+// the block column as one GEMM  P <- P T^-T,  the trailing update as one lower-tiles-only GEMM  A22 -= P P^T.
 int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   if (m <= 0) return MLN_OK;
+  constexpr int CB = 128;
   double* Dinv = nullptr;
-  MLN_HIP(ctx, mln_dmalloc((void**)&Dinv, sizeof(double) * PB * PB));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Dinv, sizeof(double) * CB * CB));
+  MLN_HIP(ctx, hipMemsetAsync(Dinv, 0, sizeof(double) * CB * CB, ctx->stream));
   MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   int rc = MLN_OK;
-  for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += PB) {
-    const int nb = (int)((m - j0 < PB) ? (m - j0) : PB);
+  for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += CB) {
+    const int nb = (int)((m - j0 < CB) ? (m - j0) : CB);
     double* Ajj = A + j0 * lda + j0;
-    hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, ctx->stream, Ajj, lda, nb, Dinv, ctx->d_info, j0);
+    rc = launch_potrf128(ctx, Ajj, lda, nb, Dinv, ctx->d_info, j0);
+    if (rc != MLN_OK) break;
     const int64_t rem = m - j0 - nb;
     if (rem > 0) {
       double* P = A + (j0 + nb) * lda + j0;
       GemmArgs g{};  // P <- P * Dinv^T   (in place: one 128-wide column tile per row tile)
-      g.A = P; g.lda = lda; g.B = Dinv; g.ldb = PB; g.C = P; g.ldc = lda;
+      g.A = P; g.lda = lda; g.B = Dinv; g.ldb = CB; g.C = P; g.ldc = lda;
       g.M = rem; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
       rc = launch_dgemm(ctx, g);
       if (rc != MLN_OK) break;

@@ -1,64 +1,12 @@
 // Internal declarations shared by the translation units of libmellon_hip.so (gfx950 only).
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <string>
-#include "../../include/mellon_hip.h"
+#include "mln_core.h"
 
-struct mln_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  int n_cu = 0;
-  void* comm = nullptr;  // ncclComm_t when multi-GPU
-  int n_ranks = 1;
-  int rank = 0;
-  std::string err;
-  // grow-only device scratch
-  void* scratch = nullptr;
-  size_t scratch_bytes = 0;
-  int* d_info = nullptr;  // device int[4] for factorisation status
-};
-
-void mln_set_error(mln_ctx* ctx, const std::string& msg);
-int mln_hip_fail(mln_ctx* ctx, hipError_t e, const char* what, const char* file, int line);
-
-#define MLN_HIP(ctx, call)                                                   \
-  do {                                                                       \
-    hipError_t e__ = (call);                                                 \
-    if (e__ != hipSuccess) return mln_hip_fail((ctx), e__, #call, __FILE__, __LINE__); \
-  } while (0)
-
-#define MLN_TRY(call)            \
-  do {                           \
-    int s__ = (call);            \
-    if (s__ != MLN_OK) return s__; \
-  } while (0)
-
-// alloc.hip: caching device allocator (every internal device buffer goes through it)
-hipError_t mln_dmalloc(void** out, size_t bytes);
-hipError_t mln_dfree(void* p);
-void mln_dcache_flush();
-
-// ---- device-side covariance program (by-value kernel argument) ------------------------------
-struct DevLeaf {
-  int kind;
-  int ndims;
-  int dims_off;  // offset into DevCov::dims
-  int pad;
-  double ls;
-  double alpha;
-  double alpha_inv_ls[2];  // [1] = 1 / ls
-};
-struct DevCov {
-  int n_leaves;
-  int n_toks;
-  DevLeaf leaves[MLN_MAX_LEAVES];
-  int tok_op[MLN_MAX_TOKS];
-  int tok_leaf[MLN_MAX_TOKS];
-  double tok_val[MLN_MAX_TOKS];
-  short dims[MLN_MAX_DIMS];
-};
-int mln_lower_cov(mln_ctx* ctx, const mln_kernel_desc* cov, int d, DevCov* out);
+// comm.hip: the collectives of the sharded path, over RCCL or the in-process loopback group
+int comm_allreduce(mln_ctx* ctx, double* dev, int64_t count);                       // sum, in place, same bits on every rank
+int comm_bcast0(mln_ctx* ctx, double* dev, int64_t count);                          // rank 0 -> all
+int comm_allgather(mln_ctx* ctx, const double* send, double* recv, int64_t count);  // count per rank, rank order
+void comm_release(mln_ctx* ctx);
 
 // ---- kernel launchers (all asynchronous on ctx->stream; device pointers only) ---------------
 // cov_kernels.hip
@@ -114,26 +62,3 @@ int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, in
 int dev_eigh(mln_ctx* ctx, const double* A, int64_t m, int64_t lda, double* w_host, double* Vrows, int64_t ldv,
              int* n_sweeps_out);
 
-// objective.hip
-struct ObjArgs {
-  const double* L; int64_t ldl; int64_t n; int64_t m;
-  const double* z; const double* V; const double* Vdr; double mu;
-  double* part_grad;   // n_wg x m_pad
-  double* part_hess;   // n_wg x m_pad or null
-  double* part_loss;   // n_wg
-  const double* weights;  // if non-null: "gemv-T" mode, grad_j = sum_i weights_i L_ij (V, Vdr, z unused)
-  double* f_out;          // if non-null: store f_i = L_i . z + mu
-  int n_wg; int64_t m_pad;
-  const float* L32;       // if non-null: stream this fp32 copy of L instead (same shape / leading dimension)
-};
-int objective_max_m();
-int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count);
-int launch_objective(mln_ctx* ctx, const ObjArgs& a);
-int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out_loss_grad /* 1 + m [+ m] */);
-int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x,
-                     double* y);   // y = M x, one wave per row
-int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, const double* x, double* y,
-                         int upper, int64_t blk, int64_t ncol, int64_t seg);   // triangular blocks: non-zero part only
-
-// helpers (api.hip)
-int mln_scratch(mln_ctx* ctx, size_t bytes, void** out);

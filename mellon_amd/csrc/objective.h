@@ -1,0 +1,39 @@
+// The streaming pass over the n x m factor and the small m x m products around it (objective.hip).
+#pragma once
+#include "mln_core.h"
+
+// objective.hip
+struct ObjArgs {
+  const double* L; int64_t ldl; int64_t n; int64_t m;
+  const double* z; const double* V; const double* Vdr; double mu;
+  double* part_grad;   // n_wg x m_pad
+  double* part_hess;   // n_wg x m_pad or null
+  double* part_loss;   // n_wg
+  const double* weights;  // if non-null: "gemv-T" mode, grad_j = sum_i weights_i L_ij (V, Vdr, z unused)
+  double* f_out;          // if non-null: store f_i = L_i . z + mu
+  int n_wg; int64_t m_pad;
+  const float* L32;       // if non-null: stream this fp32 copy of L instead (same shape / leading dimension)
+  const int* gate;        // if non-null: the launch is a no-op unless *gate == gate_want (device-resident solver:
+  int gate_want;          //   MLN_GATE_F64 / MLN_GATE_F32 select the streamed copy, MLN_GATE_DONE stops everything)
+};
+enum { MLN_GATE_F64 = 0, MLN_GATE_F32 = 1, MLN_GATE_DONE = 2 };
+int objective_max_m();
+int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count);
+int launch_objective(mln_ctx* ctx, const ObjArgs& a);
+int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out_loss_grad /* 1 + m [+ m] */);
+// the same reduction with the loss and the gradient going to separate places (no-op when *a.gate == MLN_GATE_DONE)
+int launch_reduce_obj2(mln_ctx* ctx, const ObjArgs& a, double* out_loss, double* out_grad);
+int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, int64_t cols, const double* x,
+                     double* y);   // y = M x, one wave per row
+int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, const double* x, double* y,
+                         int upper, int64_t blk, int64_t ncol, int64_t seg);   // triangular blocks: non-zero part only
+// General form: rows >= blk write to y2[r - blk] (when y2 != null); the second column segment starts at column
+// `mseg` of M and at element `xseg` of x; no-op when *gate == MLN_GATE_DONE.
+struct GemvTri {
+  const double* M; int64_t ld; int64_t rows;
+  const double* x; double* y; double* y2;
+  int upper; int64_t blk, ncol, mseg, xseg;
+  const int* gate;
+};
+int launch_gemv_tri(mln_ctx* ctx, const GemvTri& g);
+

@@ -16,6 +16,7 @@
 // Determinism: rows are split into contiguous per-workgroup ranges; per-workgroup partials are
 // summed in workgroup order by k_reduce_obj.
 #include "mln_internal.h"
+#include "objective.h"
 
 namespace {
 
@@ -111,6 +112,7 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
 
 template <int CPT, int R, int MODE>
 __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
+  if (a.gate && *a.gate != a.gate_want) return;   // uniform: the device-resident solver chose the other copy / is done
   __shared__ double red[2][8][R];
   const int tid = threadIdx.x;
   const int64_t ld2 = a.ldl / 2;
@@ -254,6 +256,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
 
 template <int CQ, int R, bool GEMVT = false>
 __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
+  if (a.gate && *a.gate != a.gate_want) return;
   __shared__ double red[2][8][R];
   const int tid = threadIdx.x;
   const int64_t ld4 = a.ldl / 4;
@@ -316,7 +319,9 @@ __global__ void k_to_f32(const double* __restrict__ src, float* __restrict__ dst
 // out[0] = sum_wg loss ; out[1 + j] = sum_wg grad[wg][j] ; out[1 + m + j] = sum_wg hess[wg][j]
 // 64 columns x 4 groups of workgroup-partials per block; each group sums its partials in ascending
 // workgroup order and the 4 group sums are added in fixed order -> bit-reproducible.
-__global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restrict__ out, int with_hess) {
+__global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restrict__ out_loss,
+                                                    double* __restrict__ out_grad, int with_hess) {
+  if (a.gate && *a.gate == MLN_GATE_DONE) return;
   __shared__ double red[2][4][64];
   const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 64 + c;
@@ -332,14 +337,14 @@ __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restric
   red[1][grp][c] = t;
   __syncthreads();
   if (grp == 0 && j < a.m) {
-    out[1 + j] = ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c];
-    if (with_hess) out[1 + a.m + j] = ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c];
+    out_grad[j] = ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c];
+    if (with_hess) out_grad[a.m + j] = ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double l = 0.0;
     if (a.part_loss)
       for (int w = 0; w < a.n_wg; ++w) l += a.part_loss[w];
-    out[0] = l;
+    out_loss[0] = l;
   }
 }
 
@@ -371,33 +376,37 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const double* __restrict__ M,
 
 // The same product for the stacked preconditioner operators, whose m x m blocks are triangular: only the non-zero
 // part of each row is read (half the bytes).  upper: row i of every block of `blk` rows holds columns [i, ncol);
-// lower: columns [0, i] -- in each of the (1 or 2) column segments, the second one starting at column `seg`.
-__global__ __launch_bounds__(256) void k_gemv_rows_tri(const double* __restrict__ M, int64_t ld, int64_t rows,
-                                                       const double* __restrict__ x, double* __restrict__ y,
-                                                       int upper, int64_t blk, int64_t ncol, int64_t seg) {
+// lower: columns [0, i] -- in each of the (1 or 2) column segments, the second one starting at column `mseg` of M
+// and element `xseg` of x.  Rows past the first block go to y2 when it is given.
+__global__ __launch_bounds__(256) void k_gemv_rows_tri(GemvTri g) {
+  if (g.gate && *g.gate == MLN_GATE_DONE) return;
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  const int64_t i = r % blk;
-  const int64_t c_lo = upper ? (i & ~(int64_t)1) : 0, c_hi = upper ? ncol : i + 1;
-  const double* __restrict__ rowp = M + r * ld;
+  if (r >= g.rows) return;
+  const int64_t i = r % g.blk;
+  const int64_t c_lo = g.upper ? (i & ~(int64_t)1) : 0, c_hi = g.upper ? g.ncol : i + 1;
+  const double* __restrict__ rowp = g.M + r * g.ld;
   double s0 = 0.0, s1 = 0.0;
-  const int nseg = seg ? 2 : 1;
+  const int nseg = g.mseg ? 2 : 1;
   for (int sg = 0; sg < nseg; ++sg) {
-    const int64_t base = sg * seg;
-    const d2* __restrict__ row = reinterpret_cast<const d2*>(rowp + base);
-    const d2* __restrict__ xv = reinterpret_cast<const d2*>(x + base);
+    const double* __restrict__ rb = rowp + sg * g.mseg;
+    const double* __restrict__ xb = g.x + sg * g.xseg;
+    const d2* __restrict__ row = reinterpret_cast<const d2*>(rb);
+    const d2* __restrict__ xv = reinterpret_cast<const d2*>(xb);
     for (int64_t p = c_lo / 2 + lane; 2 * p + 1 < c_hi; p += 64) {
       const d2 a = row[p], b = xv[p];
       s0 = fma(a.x, b.x, s0);
       s1 = fma(a.y, b.y, s1);
     }
-    if ((c_hi & 1) && lane == 0) s0 = fma(rowp[base + c_hi - 1], x[base + c_hi - 1], s0);
+    if ((c_hi & 1) && lane == 0) s0 = fma(rb[c_hi - 1], xb[c_hi - 1], s0);
   }
   double s = s0 + s1;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) y[r] = s;
+  if (lane == 0) {
+    if (g.y2 && r >= g.blk) g.y2[r - g.blk] = s;
+    else g.y[r] = s;
+  }
 }
 
 template <int CPT, int R>
@@ -467,19 +476,28 @@ int launch_gemv_rows(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, in
   return MLN_OK;
 }
 
-int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, const double* x, double* y,
-                         int upper, int64_t blk, int64_t ncol, int64_t seg) {
-  if (rows <= 0) return MLN_OK;
-  if ((ld & 1) || (seg & 1) || ((uintptr_t)M & 15) || ((uintptr_t)x & 15)) { mln_set_error(ctx, "gemv_rows_tri: unaligned operands"); return MLN_ERR_ARG; }
-  hipLaunchKernelGGL(k_gemv_rows_tri, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, M, ld, rows, x, y,
-                     upper, blk, ncol, seg);
+int launch_gemv_tri(mln_ctx* ctx, const GemvTri& g) {
+  if (g.rows <= 0) return MLN_OK;
+  if ((g.ld & 1) || (g.mseg & 1) || (g.xseg & 1) || ((uintptr_t)g.M & 15) || ((uintptr_t)g.x & 15)) {
+    mln_set_error(ctx, "gemv_rows_tri: unaligned operands");
+    return MLN_ERR_ARG;
+  }
+  hipLaunchKernelGGL(k_gemv_rows_tri, dim3((unsigned)((g.rows + 3) / 4)), dim3(256), 0, ctx->stream, g);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
 
-int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out) {
-  hipLaunchKernelGGL(k_reduce_obj, dim3((unsigned)((a.m + 63) / 64)), dim3(256), 0, ctx->stream, a, out,
+int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows, const double* x, double* y,
+                         int upper, int64_t blk, int64_t ncol, int64_t seg) {
+  GemvTri g{M, ld, rows, x, y, nullptr, upper, blk, ncol, seg, seg, nullptr};
+  return launch_gemv_tri(ctx, g);
+}
+
+int launch_reduce_obj2(mln_ctx* ctx, const ObjArgs& a, double* out_loss, double* out_grad) {
+  hipLaunchKernelGGL(k_reduce_obj, dim3((unsigned)((a.m + 63) / 64)), dim3(256), 0, ctx->stream, a, out_loss, out_grad,
                      a.part_hess ? 1 : 0);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
+
+int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out) { return launch_reduce_obj2(ctx, a, out, out + 1); }

@@ -1,0 +1,36 @@
+// Device-resident L-BFGS state of the MAP solve (solver.hip).  Reference: inference.minimize_lbfgsb
+// (inference.py:272-288) = SciPy L-BFGS-B without bounds; here the optimiser's state and every decision
+// live on the GPU, so that between two passes over the n x m buffer there is no host round trip.
+#pragma once
+#include "mln_core.h"
+
+enum { MLN_SOLVE_FIRST = 0, MLN_SOLVE_LS = 1, MLN_SOLVE_REEVAL = 2 };
+
+struct SolverState {
+  int gate;      // MLN_GATE_F64 / MLN_GATE_F32: which copy of the buffer the next evaluation streams; MLN_GATE_DONE
+  int mode;      // what the evaluation in flight is: first point, line-search trial, re-evaluation at u (phase switch)
+  int status;    // 0 converged, 1 maxiter, 2 line search failed
+  int it, n_eval, n_eval32, ls;
+  int k, head;   // curvature pairs stored / slot of the oldest
+  int maxiter, maxcor, maxls;
+  int m, pad_;
+  double ftol, gtol, ftol32;
+  double prior_const;       // (m / 2) log 2 pi
+  double fx, t, gd;         // accepted loss, current trial step, g . d at the accepted point
+};
+
+struct SolverBuffers {
+  SolverState* st;
+  double *u, *g, *un, *gn, *d;   // m each: accepted point / gradient, trial point / gradient, direction
+  double *S, *Y;                 // maxcor x ld
+  double *rho, *yy;              // maxcor each: 1 / s.y and y.y
+  const double* z;               // z = C^-T un of the evaluation in flight (m)
+  const double* lik;             // its (all-reduced) likelihood sum
+  int64_t ld;
+  double* trace;                 // optional: 4 doubles per evaluation (loss, step, mode, gate), 512 entries
+};
+
+// u0 (device, m) is copied into u and un; the first evaluation is then enqueued by the caller
+int launch_solver_init(mln_ctx* ctx, const SolverBuffers& b, const SolverState& init, const double* u0);
+// consumes the evaluation in flight (gn, z, lik) and prepares the next trial point in un -- or sets gate = DONE
+int launch_solver_step(mln_ctx* ctx, const SolverBuffers& b, int m);

@@ -1,0 +1,284 @@
+// The MAP solve's optimiser as ONE single-workgroup kernel per evaluation (reference: inference.minimize_lbfgsb,
+// inference.py:272-288: SciPy L-BFGS-B without bounds behind jaxopt.ScipyMinimize).
+//
+// Same method as before -- limited-memory BFGS two-loop recursion with H0 = s.y / y.y, sufficient-decrease
+// backtracking from step 1, SciPy's stopping tests (relative decrease <= ftol, max|g| <= gtol, maxiter) -- on the
+// preconditioned variable u (z = C^-T u).  What changed is where it runs: the m-vectors (u, g, the <= 30 curvature
+// pairs) and every decision (accept / backtrack / switch from the fp32 copy to the fp64 buffer / stop) stay on the
+// device.  One evaluation is then a fixed chain of launches
+//     k_solver_step -> [z ; w] = Q1 un -> k_objective32 | k_objective (gated) -> reduction -> (all-reduce) -> gn = Q2 [z ; r]
+// which the host enqueues in batches without ever waiting for a result; after the solver has set its gate to DONE
+// the remaining launches of a batch return immediately.  With cells sharded over ranks every rank runs this same
+// optimiser on the same all-reduced numbers, so no rank-0 round trip is needed either.
+//
+// 512 threads own m <= 8192 elements (EPT each).  Dot products: wave64 shuffle + 8 partials through LDS, summed
+// in fixed order by every thread -> the result is uniform across the workgroup and bit-reproducible.
+#include <cmath>
+
+#include "objective.h"
+#include "solver.h"
+
+namespace {
+
+constexpr int ST = 512;    // threads of the step kernel
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < ST / 64; ++w) s += red[w];
+  return s;
+}
+
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double (*red3)[ST / 64]) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red3[0][threadIdx.x >> 6] = a; red3[1][threadIdx.x >> 6] = b; red3[2][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < ST / 64; ++w) { s0 += red3[0][w]; s1 += red3[1][w]; s2 += red3[2][w]; }
+  a = s0; b = s1; c = s2;
+}
+
+__device__ __forceinline__ double block_max(double v, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < ST / 64; ++w) s = fmax(s, red[w]);
+  return s;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
+  SolverState* st = b.st;
+  if (st->gate == MLN_GATE_DONE) return;
+  __shared__ double red[ST / 64];
+  __shared__ double red3[3][ST / 64];
+  __shared__ double alpha_s[64];
+  const int tid = threadIdx.x;
+  const int m = st->m;
+  const int64_t ld = b.ld;
+  bool on[EPT];
+  int idx[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) { idx[e] = tid + ST * e; on[e] = idx[e] < m; }
+  double u[EPT], g[EPT], un[EPT], gn[EPT], d[EPT];
+  double zz = 0.0;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    u[e] = on[e] ? b.u[idx[e]] : 0.0;
+    g[e] = on[e] ? b.g[idx[e]] : 0.0;
+    un[e] = on[e] ? b.un[idx[e]] : 0.0;
+    gn[e] = on[e] ? b.gn[idx[e]] : 0.0;
+    d[e] = on[e] ? b.d[idx[e]] : 0.0;
+    const double zv = on[e] ? b.z[idx[e]] : 0.0;
+    zz = fma(zv, zv, zz);
+  }
+  // ---- the evaluation that just finished: loss = 1/2 |z|^2 + (m/2) log 2 pi + likelihood sum (inference.py:45-46,89-91)
+  zz = block_sum(zz, red);
+  const double fn = b.lik[0] + 0.5 * zz + st->prior_const;
+  const bool phase32 = st->gate == MLN_GATE_F32;
+  int mode = st->mode, it = st->it, n_eval = st->n_eval + 1, n_eval32 = st->n_eval32 + (phase32 ? 1 : 0);
+  int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
+  double fx = st->fx, t = st->t, gd = st->gd;
+  if (b.trace && tid == 0) {
+    double* tr = b.trace + 4 * ((n_eval - 1) & 511);
+    tr[0] = fn; tr[1] = (mode == MLN_SOLVE_LS) ? t : 0.0; tr[2] = (double)mode; tr[3] = (double)gate;
+  }
+  bool to_head = false, reeval = false, done = false;
+  if (mode != MLN_SOLVE_LS) {            // first point, or the same point again on the fp64 buffer
+    fx = fn;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) g[e] = gn[e];
+    to_head = true;
+  } else {
+    ++ls;
+    const bool ok = isfinite(fn) && fn <= fx + 1e-4 * t * gd;
+    if (ok) {
+      double sy = 0.0, ss = 0.0, yy = 0.0;
+      double sv[EPT], yv[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        sv[e] = un[e] - u[e];
+        yv[e] = gn[e] - g[e];
+        sy = fma(sv[e], yv[e], sy); ss = fma(sv[e], sv[e], ss); yy = fma(yv[e], yv[e], yy);
+      }
+      block_sum3(sy, ss, yy, red3);
+      const double f_old = fx;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) { u[e] = un[e]; g[e] = gn[e]; }
+      fx = fn;
+      if (sy > 1e-10 * sqrt(ss * yy)) {   // keep the pair (SPD update)
+        int slot;
+        if (k < st->maxcor) { slot = (head + k) % st->maxcor; ++k; }
+        else { slot = head; head = (head + 1) % st->maxcor; }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+          if (on[e]) { b.S[slot * ld + idx[e]] = sv[e]; b.Y[slot * ld + idx[e]] = yv[e]; }
+        if (tid == 0) { b.rho[slot] = 1.0 / sy; b.yy[slot] = yy; }
+        __threadfence_block();
+        __syncthreads();   // the two-loop recursion below re-reads the pair from memory
+      }
+      ++it;
+      const double fscale = fmax(fmax(fabs(f_old), fabs(fx)), 1.0);
+      if (phase32) {
+        // the fp32 objective is a smooth surrogate whose optimum sits ~5e-5 (relative loss) from the true one: once
+        // its progress per iteration falls below ftol32, continue on the fp64 buffer with the pairs collected so far
+        if ((f_old - fx) <= st->ftol32 * fscale) reeval = true; else to_head = true;
+      } else {
+        if ((f_old - fx) <= st->ftol * fscale) { status = 0; done = true; } else to_head = true;
+      }
+    } else if (ls >= st->maxls) {
+      if (phase32) reeval = true;          // the surrogate is exhausted: continue in fp64 from the accepted point
+      else { status = 2; done = true; }
+    } else {
+      if (isfinite(fn)) {
+        const double tq = -gd * t * t / (2.0 * (fn - fx - gd * t));   // minimiser of the quadratic model
+        t = fmin(fmax(tq, 0.1 * t), 0.5 * t);
+      } else {
+        t *= 0.1;
+      }
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) un[e] = fma(t, d[e], u[e]);
+    }
+  }
+  if (to_head) {
+    double gm = 0.0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) gm = fmax(gm, fabs(g[e]));
+    gm = block_max(gm, red);
+    if (!(gm > st->gtol)) {
+      if (phase32) reeval = true; else { status = 0; done = true; }
+    } else if (it >= st->maxiter) {
+      status = 1; done = true;
+    } else {
+      // two-loop recursion over the k stored pairs (chronological j -> slot (head + j) % maxcor)
+      double q[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) q[e] = g[e];
+      // (the pair of the NEXT step is requested before the reduction of the current one: the L2 latency of the row
+      //  loads -- ~1 us each -- would otherwise sit on the critical path 2 k times)
+      double sv[EPT], yv[EPT], sn[EPT], yn[EPT];
+      auto load_pair = [&](int j, double (&s_)[EPT], double (&y_)[EPT]) {
+        const int slot = (head + j) % st->maxcor;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          s_[e] = on[e] ? b.S[slot * ld + idx[e]] : 0.0;
+          y_[e] = on[e] ? b.Y[slot * ld + idx[e]] : 0.0;
+        }
+      };
+      if (k > 0) load_pair(k - 1, sv, yv);
+      for (int j = k - 1; j >= 0; --j) {
+        const int slot = (head + j) % st->maxcor;
+        if (j > 0) load_pair(j - 1, sn, yn); else load_pair(0, sn, yn);   // j == 0: first pair of the second loop
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc = fma(sv[e], q[e], acc);
+        const double a = b.rho[slot] * block_sum(acc, red);
+        if (tid == 0) alpha_s[j] = a;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { q[e] = fma(-a, yv[e], q[e]); sv[e] = sn[e]; yv[e] = yn[e]; }
+      }
+      if (k > 0) {
+        const int last = (head + k - 1) % st->maxcor;
+        const double gamma = 1.0 / (b.rho[last] * b.yy[last]);   // s.y / y.y of the newest pair
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) q[e] *= gamma;
+      }
+      __syncthreads();
+      for (int j = 0; j < k; ++j) {
+        const int slot = (head + j) % st->maxcor;
+        if (j + 1 < k) load_pair(j + 1, sn, yn);
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) acc = fma(yv[e], q[e], acc);
+        const double beta = b.rho[slot] * block_sum(acc, red);
+        const double c = alpha_s[j] - beta;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { q[e] = fma(sv[e], c, q[e]); sv[e] = sn[e]; yv[e] = yn[e]; }
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) { d[e] = -q[e]; acc = fma(g[e], d[e], acc); }
+      gd = block_sum(acc, red);
+      if (!(gd < 0.0)) {   // not a descent direction (cannot happen for SPD pairs; guard anyway)
+        k = 0; head = 0;
+        acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) { d[e] = -g[e]; acc = fma(g[e], g[e], acc); }
+        gd = -block_sum(acc, red);
+      }
+      t = 1.0;
+      if (k == 0) {
+        double g1 = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) g1 += fabs(g[e]);
+        g1 = block_sum(g1, red);
+        t = fmin(1.0, 1.0 / g1);
+      }
+      ls = 0;
+      mode = MLN_SOLVE_LS;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) un[e] = fma(t, d[e], u[e]);
+    }
+  }
+  if (reeval) {           // same point, fp64 buffer: refreshes fx and g, keeps the curvature pairs
+    gate = MLN_GATE_F64;
+    mode = MLN_SOLVE_REEVAL;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) un[e] = u[e];
+  }
+  if (done) gate = MLN_GATE_DONE;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e)
+    if (on[e]) { b.u[idx[e]] = u[e]; b.g[idx[e]] = g[e]; b.un[idx[e]] = un[e]; b.d[idx[e]] = d[e]; }
+  if (tid == 0) {
+    st->gate = gate; st->mode = mode; st->status = status; st->it = it; st->n_eval = n_eval; st->n_eval32 = n_eval32;
+    st->ls = ls; st->k = k; st->head = head; st->fx = fx; st->t = t; st->gd = gd;
+  }
+}
+
+__global__ void k_solver_init(SolverBuffers b, SolverState init, const double* __restrict__ u0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < init.m) {
+    const double v = u0[i];
+    b.u[i] = v; b.un[i] = v; b.g[i] = 0.0; b.gn[i] = 0.0; b.d[i] = 0.0;
+  }
+  if (i == 0) *b.st = init;
+}
+
+}  // namespace
+
+int launch_solver_init(mln_ctx* ctx, const SolverBuffers& b, const SolverState& init, const double* u0) {
+  hipLaunchKernelGGL(k_solver_init, dim3((unsigned)((init.m + 255) / 256)), dim3(256), 0, ctx->stream, b, init, u0);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_solver_step(mln_ctx* ctx, const SolverBuffers& b, int m) {
+  const int ept = (m + ST - 1) / ST;
+  const dim3 grid(1), block(ST);
+#define MLN_STEP(E) case E: hipLaunchKernelGGL(k_solver_step<E>, grid, block, 0, ctx->stream, b); break;
+  switch (ept) {
+    MLN_STEP(1) MLN_STEP(2) MLN_STEP(3) MLN_STEP(4) MLN_STEP(5) MLN_STEP(6) MLN_STEP(7) MLN_STEP(8)
+    MLN_STEP(9) MLN_STEP(10) MLN_STEP(11) MLN_STEP(12) MLN_STEP(13) MLN_STEP(14) MLN_STEP(15) MLN_STEP(16)
+    default: mln_set_error(ctx, "solver: m > 8192 is not supported by this build"); return MLN_ERR_UNSUPPORTED;
+  }
+#undef MLN_STEP
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}

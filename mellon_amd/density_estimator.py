@@ -20,12 +20,16 @@ class _Background:
 
     def __init__(self, fn):
         import threading
+        from . import distributed
         self._exc, self._fn = None, fn
+        self._state = distributed.thread_state()      # the worker acts for the same rank / device context
         self._t = threading.Thread(target=self._run, daemon=True)
         self._t.start()
 
     def _run(self):
         try:
+            from . import distributed
+            distributed.adopt_thread_state(self._state)
             self._fn()
         except BaseException as e:     # noqa: BLE001 -- re-raised in join()
             self._exc = e
@@ -134,16 +138,23 @@ class DensityEstimator(BaseEstimator):
                 # The device factorisation (Lp, K) only needs the covariance and the landmarks; the
                 # O(n) host heuristics behind mu / the likelihood constants do not depend on it.
                 # Run the former in a worker thread (ctypes drops the GIL) while the host does the latter.
+                # (With ranks the heuristics' reductions travel over the host communicator, never through the
+                #  device context the worker is using.)
                 for early in self._DEVICE_FIT_INPUTS:
                     self._prepare_attribute(early)
-                from .distributed import current
-                # (single process only: with ranks the host heuristics issue collectives on the same
-                #  context, which is not thread-safe, and the host work is already 1/N per rank)
-                worker = _Background(self._device_fit if current().world_size == 1 else (lambda: None))
-                self._prepare_attribute("mu")
-                self._host_constants()
+                worker = _Background(self._device_fit)
+                try:
+                    self._prepare_attribute("mu")
+                    self._host_constants()
+                except BaseException:
+                    try:
+                        worker.join()                  # never leave device work running on the shared context
+                    except BaseException:              # noqa: BLE001 -- the primary error wins
+                        pass
+                    raise
             elif attr == "Lp" and worker is not None:
                 worker.join()
+                worker = None
                 self._prepare_attribute(attr)
             else:
                 self._prepare_attribute(attr)

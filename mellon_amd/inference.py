@@ -86,7 +86,7 @@ class LossFunc:
         self.preconditioned = True     # optimise u with z = C^-T u, C C^T ~ L^T L + I (see minimize_lbfgsb)
         self.native_solver = True      # L-BFGS inside the library; False: SciPy L-BFGS-B drives the device objective
         from .parameters import ridge_row_stride
-        self.fit.precond_build(ridge_row_stride(self.fit.n, self.fit.m))   # no-op if the Ridge init built it
+        self.fit.precond_build(*ridge_row_stride(self.fit.n, self.fit.m, with_offset=True))   # no-op if the Ridge init built it
 
     def value_and_grad(self, z):
         self.n_eval += 1

@@ -1,6 +1,8 @@
 """Consistency checks between rank / gp_type / landmarks (mellon/parameter_validation.py)."""
 import logging
 
+import numpy as np
+
 from .base_cov import Covariance
 from .util import GaussianProcessType
 from .validation import validate_float_or_int, validate_positive_int
@@ -84,3 +86,14 @@ def validate_cov_func(cov_func, param_name, optional=False):
     if not isinstance(cov_func, Covariance):
         raise ValueError(f"'{param_name}' must be an instance of a subclass of mellon.Covariance")
     return cov_func
+
+
+def validate_normalize_parameter(normalize, unique_times):
+    """reference parameter_validation.py:266-280: a dict must name every time point, a list / array must have one
+    entry per time point (earliest to latest)."""
+    if isinstance(normalize, dict):
+        absent = [t for t in unique_times if t.item() not in normalize]
+        if absent:
+            raise ValueError(f"Missing time point(s) in normalization dictionary: {absent}")
+    elif isinstance(normalize, (list, np.ndarray)) and len(normalize) != len(unique_times):
+        raise ValueError("Length of the normalize list or array must match the number of unique time points.")

@@ -138,13 +138,34 @@ def compute_nn_distances(x, seed=DEFAULT_RANDOM_SEED):
     return _lib.default_context().nn_distances(np.ascontiguousarray(x, dtype=np.float64))
 
 
+def _target_cell_count(normalize, t, average, unique_times):
+    """reference parameters.py:436-441: True -> the average count per time point, dict -> by time value,
+    list / array -> by position among the sorted unique time points."""
+    if isinstance(normalize, bool):
+        return average
+    if isinstance(normalize, dict):
+        return normalize[t.item()]
+    return normalize[unique_times.tolist().index(t)]
+
+
 def compute_nn_distances_within_time_points(x, times=None, d=None, normalize=False):
     """reference parameters.py:444-531."""
+    from .parameter_validation import validate_normalize_parameter
+    from .validation import validate_float_or_iterable_numerical
     x = validate_time_x(x, times)
     unique_times = np.unique(x[:, -1])
     nn = np.empty(x.shape[0])
     n_cells = x.shape[0]
     av = n_cells / len(unique_times)
+    validate_normalize_parameter(normalize, unique_times)
+    normalizing = normalize is not False and normalize is not None
+    if normalizing:
+        d = validate_float_or_iterable_numerical(d, "d", optional=False, positive=True)
+        if np.ndim(d) > 0 and len(d) != n_cells:
+            raise ValueError(f"If `d` (length={len(d):,}) is a vector then it needs to have one value "
+                             f"per cell in x (x.shape[0]={n_cells:,}).")
+        logger.info("Normalizing nearest neighbor distances correcting sampling bias for "
+                    f"{len(unique_times):,} different time points.")
     for t in unique_times:
         mask = x[:, -1] == t
         n_t = int(mask.sum())
@@ -153,8 +174,8 @@ def compute_nn_distances_within_time_points(x, times=None, d=None, normalize=Fal
                 f"Insufficient data: Only {n_t} sample(s) found at time point {t}. "
                 "Nearest neighbors cannot be computed with less than two samples per time point.")
         nn_t = compute_nn_distances(x[mask, :-1])
-        if normalize is not False and normalize is not None:
-            target = av if isinstance(normalize, bool) else normalize[float(t)]
+        if normalizing:
+            target = _target_cell_count(normalize, t, av, unique_times)
             dd = np.asarray(d, dtype=np.float64)
             nn_t = (n_t / target) ** (1 / dd if dd.ndim == 0 else 1 / dd[mask]) * nn_t
         nn[mask] = nn_t
@@ -248,16 +269,18 @@ def _fit_of(L):
 RIDGE_ROWS_PER_LANDMARK = 12    # measured at C3 with the mixed-precision solve: 12 m cells minimise Gram time + extra passes
 
 
-def ridge_row_stride(n_local, m):
-    """Cells used for the Ridge / preconditioner Gram: every k-th cell such that ~12 m cells remain
-    (all cells when n <= 32 m).  The Gram only seeds and preconditions a strictly convex solve, so
+def ridge_row_stride(n_local, m, with_offset=False):
+    """Cells used for the Ridge / preconditioner Gram: every k-th cell (by GLOBAL index) such that ~12 m cells remain
+    (all cells when n <= 24 m).  The Gram only seeds and preconditions a strictly convex solve, so
     the subsample changes the iteration count (measured: not at all down to 2 m rows), never the
-    optimum; `row_stride=1` reproduces the reference's exact Ridge on all cells."""
+    optimum; `row_stride=1` reproduces the reference's exact Ridge on all cells.
+    with_offset: also return the global index of this rank's first cell."""
     import os
     from .distributed import current
     per_m = int(os.environ.get("MELLON_AMD_RIDGE_ROWS_PER_M", RIDGE_ROWS_PER_LANDMARK))
-    n_global = int(current().allreduce_sum(np.array([float(n_local)]))[0])
-    return max(1, n_global // (per_m * int(m))) if n_global > 2 * per_m * int(m) else 1
+    offset, n_global = current().global_offset(n_local)
+    stride = max(1, n_global // (per_m * int(m))) if n_global > 2 * per_m * int(m) else 1
+    return (stride, offset) if with_offset else stride
 
 
 def compute_initial_value(nn_distances, d, mu, L, row_stride=None, target=None):
@@ -267,7 +290,8 @@ def compute_initial_value(nn_distances, d, mu, L, row_stride=None, target=None):
     if target is None:
         target = mle(np.asarray(nn_distances, dtype=np.float64), d) - mu
     fit = _fit_of(L)
-    fit.precond_build(ridge_row_stride(fit.n, fit.m) if row_stride is None else row_stride)
+    auto, offset = ridge_row_stride(fit.n, fit.m, with_offset=True)
+    fit.precond_build(auto if row_stride is None else row_stride, offset)
     return fit.ridge_init(target)
 
 

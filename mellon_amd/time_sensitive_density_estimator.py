@@ -46,7 +46,9 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
     _PIPELINE = ("n_landmarks", "rank", "gp_type", None, "d", "nn_distances", "mu", "ls", "ls_time", "cov_func",
                  "landmarks", "Lp", "L", "initial_value", "transform", "loss_func")
 
-    _DEVICE_FIT_INPUTS = ("ls", "ls_time", "cov_func", "landmarks")
+    # mu before ls_time: the per-time-point fits behind the automatic ls_time receive the GLOBAL mu
+    # (time_sensitive_density_estimator.py:655-657 prepares mu before ls / ls_time)
+    _DEVICE_FIT_INPUTS = ("ls", "mu", "ls_time", "cov_func", "landmarks")
 
     def _compute_d(self):
         if self.d_method == "fractal":

@@ -1125,14 +1125,27 @@ def compute_ls_time(nn_distances, x_with_time, cov_func_curry=Matern52, density_
     return float(np.exp(res.x[0]))
 
 
-def per_time_nn_distances(x, times):
-    """parameters.py:444-531 -- nearest neighbour within each time point."""
+def per_time_nn_distances(x, times, d=None, normalize=False):
+    """parameters.py:444-531 -- nearest neighbour within each time point; with `normalize` the distances of a
+    time point holding n_t cells are scaled by (n_t / target)^(1/d) (parameters.py:520-528), target = the average
+    count per time point (True), normalize[t] (dict) or normalize[position of t] (list / array; :436-441)."""
     x = ensure_2d(x)
     times = np.asarray(times)
+    uniq = np.unique(times)
     out = np.empty(x.shape[0])
-    for t in np.unique(times):
+    for pos, t in enumerate(uniq):
         idx = np.flatnonzero(times == t)
-        out[idx] = exact_nn_distances(x[idx])
+        nn = exact_nn_distances(x[idx])
+        if normalize is not False and normalize is not None:
+            if isinstance(normalize, bool):
+                target = x.shape[0] / len(uniq)
+            elif isinstance(normalize, dict):
+                target = normalize[t.item()]
+            else:
+                target = normalize[pos]
+            dd = np.asarray(d, dtype=np.float64)
+            nn = (len(idx) / target) ** (1.0 / (dd if dd.ndim == 0 else dd[idx])) * nn
+        out[idx] = nn
     return out
 
 

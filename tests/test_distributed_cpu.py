@@ -17,6 +17,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _gloo_host_comm(dist):
+    """The product's host communicator interface on torch.distributed (gloo) -- tests only; the product itself
+    exchanges its few host-side kilobytes over a plain socket (distributed.SocketHostComm)."""
+    from mellon_amd import distributed
+
+    class GlooHostComm(distributed.HostComm):
+        rank, world_size = dist.get_rank(), dist.get_world_size()
+
+        def allgather(self, obj):
+            out = [None] * self.world_size
+            dist.all_gather_object(out, obj)
+            return out
+
+    return GlooHostComm()
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -28,7 +44,7 @@ def _worker(rank, world, port, out_dir):
     from mellon_amd import distributed, parameters
     from oracle import mellon_oracle as mo
 
-    comm = distributed.set_current(distributed.TorchCommunicator())
+    comm = distributed.set_current(distributed.ShardedCommunicator(None, _gloo_host_comm(dist)))
     assert (comm.rank, comm.world_size) == (rank, world)
     n, d, m = 4001, 6, 60                                   # odd n: uneven shards
     x = mo.gaussian_mixture(n, d, seed=21)                  # identical on every rank
@@ -40,7 +56,10 @@ def _worker(rank, world, port, out_dir):
     assert abs(parameters.compute_mu(nns, d) - mo.compute_mu(nn, d)) < 1e-12
     assert abs(parameters.compute_ls(nns) - mo.compute_ls(nn)) < 1e-12 * mo.compute_ls(nn)
     assert np.array_equal(comm.allgather_rows(nns), nn)
-    assert comm.broadcast_bytes(b"unique-id" if rank == 0 else b"") == b"unique-id"
+    assert comm.broadcast(b"unique-id" if rank == 0 else None) == b"unique-id"
+    assert comm.global_count(hi - lo) == n
+    for q in (0.01, 0.5, 0.97, 0.0, 1.0):                   # partial-gather quantile == quantile of all cells
+        assert comm.global_quantile(nns, q) == pytest.approx(np.quantile(nn, q), rel=1e-14, abs=0)
 
     ref = mo.density_fit(x, n_landmarks=m, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
     cov, mu, lm = ref.cov_func, ref.mu, ref.landmarks
@@ -116,6 +135,72 @@ def test_cell_sharded_contract_world_size_2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def _socket_worker(rank, world, name, q):
+    sys.path.insert(0, ROOT)
+    from mellon_amd import distributed
+    host = distributed.SocketHostComm(("unix", name), rank, world, timeout=60.0)
+    comm = distributed.ShardedCommunicator(None, host)
+    got = comm.allreduce_sum(np.arange(5.0) * (rank + 1))
+    rows = comm.allgather_rows(np.full(rank + 1, float(rank)))
+    uid = comm.broadcast(b"x" * 128 if rank == 0 else None)
+    comm.barrier()
+    quant = comm.global_quantile(np.arange(rank, 1000, world, dtype=np.float64), 0.01)
+    host.close()
+    q.put((rank, got.tolist(), rows.tolist(), uid, quant))
+
+
+def test_socket_host_communicator_three_ranks():
+    """The product's own host-side exchange (standard library sockets, no framework): three processes."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"mellon_amd.test.{os.getpid()}"
+    procs = [ctx.Process(target=_socket_worker, args=(r, 3, name, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, red, rows, uid, quant in got:
+        assert red == (np.arange(5.0) * 6).tolist()
+        assert rows == [0.0, 1.0, 1.0, 2.0, 2.0, 2.0]
+        assert uid == b"x" * 128
+        assert quant == pytest.approx(np.quantile(np.arange(1000.0), 0.01), rel=1e-14)
+
+
+def test_thread_host_communicator():
+    """Thread-ranks (the host side of the loopback communicator) see the same reductions."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from mellon_amd import distributed
+    group = distributed.ThreadGroup(4)
+    out = [None] * 4
+
+    def body(r):
+        comm = distributed.ShardedCommunicator(None, distributed.ThreadHostComm(group, r))
+        distributed.set_thread_current(comm)
+        assert distributed.current() is comm
+        out[r] = (comm.allreduce_sum(np.array([r + 1.0])), comm.global_quantile(np.arange(r, 400, 4.0), 0.25))
+        distributed.set_thread_current(None)
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(o[0][0] == 10.0 for o in out)
+    assert all(o[1] == pytest.approx(np.quantile(np.arange(400.0), 0.25)) for o in out)
+    assert distributed.current().world_size == 1
+
+
+def test_product_has_no_framework_dependency():
+    """north_star: "no PyTorch" -- nothing under mellon_amd/ imports torch (the gloo communicator lives in tests/)."""
+    import re
+    pkg = os.path.join(ROOT, "mellon_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert not re.search(r"^\s*(import|from)\s+torch\b", open(os.path.join(pkg, f)).read(), re.M), f
 
 
 def test_sharded_estimator_requires_shared_inputs():

@@ -908,3 +908,54 @@ def test_sigma_input_forms(mellon, n_landmarks):
                              y_is_mean=True)
         np.testing.assert_allclose(ym.predict(X), rm(X), rtol=1e-7, atol=1e-9)
         assert ym.get_obs_variance().shape == (160,)
+
+
+@pytest.mark.gpu
+def test_automatic_ls_time_uses_the_global_mu(mellon):
+    """time_sensitive_density_estimator.py:655-657 prepares mu BEFORE ls_time, so every per-time-point fit behind the
+    automatic ls_time receives the GLOBAL mu.  Time points with clearly different nearest-neighbour scales: a
+    per-time-point mu would move the densities (and ls_time) visibly."""
+    rng = np.random.default_rng(5)
+    d, T = 3, 4
+    sizes, spreads = [220, 90, 160, 60], [0.4, 1.6, 0.8, 2.4]
+    X = np.concatenate([rng.normal(size=(n_t, d)) * s + 0.3 * t for t, (n_t, s) in enumerate(zip(sizes, spreads))])
+    times = np.concatenate([np.full(n_t, float(t)) for t, n_t in enumerate(sizes)])
+    est = mellon.TimeSensitiveDensityEstimator(n_landmarks=40, _save_intermediate_ls_times=True)
+    est.fit(X, times)
+    xt = np.column_stack([X, times])
+    want = mo.compute_ls_time(np.asarray(est.nn_distances), xt,
+                              density_fit_kwargs=dict(d=est.d, mu=est.mu, ls=est.ls, lbfgsb_options=mo.LBFGSB_TIGHT))
+    assert abs(est.ls_time - want) < 1e-4 * want, (est.ls_time, want)
+    # the per-time-point mus differ from the global one by far more than the tolerance above would forgive
+    per_t = [mo.compute_mu(np.asarray(est.nn_distances)[times == t], est.d) for t in range(T)]
+    assert max(abs(m_ - est.mu) for m_ in per_t) > 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["true", "list", "array", "dict"])
+def test_normalize_per_time_point(mellon, kind):
+    """normalize_per_time_point = True / list / ndarray / dict (parameters.py:436-441,520-528): the nearest-neighbour
+    distances of a time point are rescaled by (n_t / target)^(1/d); the length scale still comes from the raw ones."""
+    rng = np.random.default_rng(9)
+    d = 2
+    sizes = [120, 60, 200]
+    tvals = [0.0, 1.0, 2.5]
+    X = np.concatenate([rng.normal(size=(n_t, d)) + 0.2 * i for i, n_t in enumerate(sizes)])
+    times = np.concatenate([np.full(n_t, t) for t, n_t in zip(tvals, sizes)])
+    counts = [1000, 4000, 2500]
+    norm = {"true": True, "list": counts, "array": np.array(counts), "dict": dict(zip(tvals, counts))}[kind]
+    est = mellon.TimeSensitiveDensityEstimator(n_landmarks=30, ls_time=1.0, normalize_per_time_point=norm)
+    dens = est.fit_predict(X, times)
+    want_nn = mo.per_time_nn_distances(X, times, d=d, normalize=norm)
+    raw_nn = mo.per_time_nn_distances(X, times)
+    np.testing.assert_allclose(est.nn_distances, want_nn, rtol=1e-12)
+    assert abs(est.ls - mo.compute_ls(raw_nn)) < 1e-12 * est.ls
+    assert np.all(np.isfinite(dens))
+    n_obs = (sum(sizes) / 3) if kind == "true" else sum(counts) / 3
+    assert est.predict.n_obs == pytest.approx(n_obs)
+    if kind != "true":
+        with pytest.raises(ValueError):
+            bad = counts[:2] if kind != "dict" else dict(zip(tvals[:2], counts[:2]))
+            mellon.TimeSensitiveDensityEstimator(n_landmarks=30, ls_time=1.0,
+                                                 normalize_per_time_point=np.array(bad) if kind == "array" else bad
+                                                 ).fit(X, times)

@@ -203,3 +203,25 @@ def test_bench_prints_exactly_one_stdout_line():
     assert out.returncode == 0, out.stderr
     assert out.stdout == '{"metric": 1}\n', out.stdout
     assert "buffered C noise" in out.stderr and "late C noise" in out.stderr
+
+
+def test_normalize_per_time_point_validation_and_target_counts():
+    """parameter_validation.py:266-280 and parameters.py:436-441 of the reference: dict -> by time value,
+    list / array -> by position among the sorted time points, True -> the average count."""
+    from mellon_amd.parameter_validation import validate_normalize_parameter
+    from mellon_amd.parameters import _target_cell_count
+    times = np.array([0.0, 1.5, 4.0])
+    validate_normalize_parameter(True, times)
+    validate_normalize_parameter([10, 20, 30], times)
+    validate_normalize_parameter(np.array([10, 20, 30]), times)
+    validate_normalize_parameter({0.0: 10, 1.5: 20, 4.0: 30}, times)
+    with pytest.raises(ValueError, match="Missing time point"):
+        validate_normalize_parameter({0.0: 10, 1.5: 20}, times)
+    with pytest.raises(ValueError, match="must match the number of unique time points"):
+        validate_normalize_parameter([10, 20], times)
+    with pytest.raises(ValueError, match="must match the number of unique time points"):
+        validate_normalize_parameter(np.array([1, 2, 3, 4]), times)
+    assert _target_cell_count(True, times[1], 7.0, times) == 7.0
+    assert _target_cell_count({0.0: 10, 1.5: 20, 4.0: 30}, times[1], 7.0, times) == 20
+    assert _target_cell_count([10, 20, 30], times[2], 7.0, times) == 30
+    assert _target_cell_count(np.array([10, 20, 30]), times[0], 7.0, times) == 10

@@ -4,6 +4,7 @@ import re, sqlite3, sys
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"^void ", "", name)
     return re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", name)
+thresh = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 2e5     # optional: minimum busy time in us
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
 # last fit starts at the last k_kernel_matrix pair (Lp matrix = small one)
@@ -21,6 +22,6 @@ for name, s, e in rows:
         groups.append([n, s, e, e - s, 1])
 print(f"{'kernel':40s} {'t_start_ms':>10s} {'span_ms':>9s} {'busy_ms':>9s} {'launches':>8s}")
 for n, s, e, busy, cnt in groups:
-    if busy > 2e5 or cnt > 20:
+    if busy > thresh or cnt > 20:
         print(f"{n[:40]:40s} {(s-t0)/1e6:10.2f} {(e-s)/1e6:9.2f} {busy/1e6:9.2f} {cnt:8d}")
 print("total span ms", (rows[-1][2] - t0) / 1e6)
