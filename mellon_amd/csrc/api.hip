@@ -474,6 +474,9 @@ struct mln_fit {
   SolverState* h_state = nullptr; // pinned mirror
   int sv_maxcor = 0;
   std::vector<hipEvent_t> evs;    // three per evaluation: before the fp32 pass, between, after the fp64 pass
+  // f = L z + mu of every row at the solver's accepted point, kept by the objective passes themselves
+  double* f_keep[2] = {nullptr, nullptr};
+  int f_final = -1;               // which buffer holds f at z_cached (-1: none; mln_transform then streams the buffer)
 };
 
 static void fit_free(mln_fit* f) {
@@ -486,7 +489,7 @@ static void fit_free(mln_fit* f) {
   triinv_free(&f->tri);
   void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
                   f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w, f->d_w_cached,
-                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block};
+                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block, f->f_keep[0], f->f_keep[1]};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (f->h_state) (void)hipHostFree(f->h_state);
   for (hipEvent_t e : f->evs) (void)hipEventDestroy(e);
@@ -895,6 +898,13 @@ extern "C" int mln_transform(mln_fit* f, const double* z, double mu, double* f_o
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   if (f->n == 0) return MLN_OK;
   MLN_HIP(ctx, hipMemcpyAsync(f->d_z, z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  if (f->f_final >= 0 && mu == f->mu && !is_device_ptr(z) && f->z_cached.size() == (size_t)f->m &&
+      std::memcmp(z, f->z_cached.data(), sizeof(double) * f->m) == 0) {
+    // the last accepted pass of the MAP solve stored exactly this vector (same kernel, same operands)
+    MLN_HIP(ctx, hipMemcpyAsync(f_out, f->f_keep[f->f_final], sizeof(double) * (size_t)f->n, hipMemcpyDefault, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MLN_OK;
+  }
   DevOut o;
   MLN_TRY(o.init(ctx, f_out, (size_t)f->n));
   ObjArgs a = obj_args(f);
@@ -1145,6 +1155,8 @@ static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, boo
   ObjArgs a = obj_args(f);
   a.z = f->kspace ? f->d_w : f->d_zr;
   a.gate = gate;
+  static const bool no_fkeep = std::getenv("MELLON_AMD_NO_FKEEP") != nullptr;
+  if (gate && !no_fkeep && f->f_keep[0] && objective_can_keep_f(f->n, f->n_wg)) { a.f_keep[0] = f->f_keep[0]; a.f_keep[1] = f->f_keep[1]; a.f_slot = &f->sv.st->f_slot; }
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   if (f->L32 && (gate || use32)) {
     ObjArgs a32 = a;
@@ -1239,6 +1251,9 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (o.maxls < 1) o.maxls = 1;
   const int64_t m = f->m;
   MLN_TRY(fit_solver_alloc(f, o.maxcor));
+  for (int b = 0; b < 2; ++b)
+    if (!f->f_keep[b]) MLN_HIP(ctx, mln_dmalloc((void**)&f->f_keep[b], sizeof(double) * (size_t)(f->n > 0 ? f->n : 1)));
+  f->f_final = -1;
   // u0 = C^T z0, identical on every rank
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, z0, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));
@@ -1318,6 +1333,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  if (st.f_valid && objective_can_keep_f(f->n, f->n_wg) && !std::getenv("MELLON_AMD_NO_FKEEP")) f->f_final = st.f_slot;   // f = L z + mu at this z is already there (mln_transform)
   if (trace_lvl)
     fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the fp32 copy), %d iterations, %d enqueued, status %d\n",
             st.n_eval, st.n_eval32, st.it, n_enq, st.status);

@@ -8,7 +8,8 @@
 //   * batched predict                     out = K W                           (NN)
 //
 // 128x128x16 tile per 256-thread workgroup; 4 waves in a 2x2 grid, each wave owns a 64x64 block
-// = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  Both operand tiles are staged k-major
+// = 4x4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs).  A 64x64x16 variant of the same kernel (2x2
+// accumulators per wave) serves launches with fewer tiles than CUs (see launch_dgemm).  Both operand tiles are staged k-major
 // in LDS ([k][row], row stride 128+16 doubles so the four k-groups of a wave hit disjoint banks),
 // with register prefetch of the next k-tile issued before the MFMA block of the current one.
 // fp64 MFMA on gfx950 runs at the fp64 vector rate (64 cycles per 16x16x4 instruction per SIMD),
@@ -19,22 +20,23 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, LPAD = 16;
+constexpr int LPAD = 16;
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
-// Each thread stages NL = BKT/2 doubles of a 128 x BKT operand tile.
-//   KCONTIG  (element (o, k) at P[o * ld + k]): row o = t / 2, k range (t % 2) * NL .. + NL
-//   !KCONTIG (element (o, k) at P[k * ld + o]): k = t / (256 / BKT), o range (t % (256/BKT)) * NL .. + NL
+// Each thread stages NL doubles of a BT x BKT operand tile (BT = 128 or 64 rows/columns of C).
+//   KCONTIG  (element (o, k) at P[o * ld + k]): row o = t / TPR, k range (t % TPR) * NL .. + NL      (TPR = 256 / BT)
+//   !KCONTIG (element (o, k) at P[k * ld + o]): k = t / TPK, o range (t % TPK) * NL .. + NL           (TPK = 256 / BKT)
 // VEC: 16-byte loads (requires 16-byte aligned base and even ld); element masks still apply.
-template <bool KCONTIG, int BKT, bool VEC>
+template <bool KCONTIG, int BT, int BKT, bool VEC>
 __device__ __forceinline__ void tile_load(const double* __restrict__ P, int64_t ld, int64_t o0, int64_t k0,
-                                          int64_t O, int64_t kend, double (&r)[BKT / 2]) {
-  constexpr int NL = BKT / 2;
+                                          int64_t O, int64_t kend, double (&r)[BT * BKT / 256]) {
+  constexpr int NL = BT * BKT / 256;
   const int t = threadIdx.x;
   if (KCONTIG) {
-    const int64_t o = o0 + (t >> 1);
-    const int64_t kb = k0 + (t & 1) * NL;
+    constexpr int TPR = 256 / BT;
+    const int64_t o = o0 + t / TPR;
+    const int64_t kb = k0 + (t % TPR) * NL;
     const double* p = P + o * ld + kb;
     const bool ok = o < O;
     if (VEC) {
@@ -76,12 +78,13 @@ __device__ __forceinline__ void tile_load(const double* __restrict__ P, int64_t 
   }
 }
 
-template <bool KCONTIG, int BKT>
-__device__ __forceinline__ void tile_store(double (*S)[BM + LPAD], const double (&r)[BKT / 2]) {
-  constexpr int NL = BKT / 2;
+template <bool KCONTIG, int BT, int BKT>
+__device__ __forceinline__ void tile_store(double (*S)[BT + LPAD], const double (&r)[BT * BKT / 256]) {
+  constexpr int NL = BT * BKT / 256;
   const int t = threadIdx.x;
   if (KCONTIG) {
-    const int o = t >> 1, kb = (t & 1) * NL;
+    constexpr int TPR = 256 / BT;
+    const int o = t / TPR, kb = (t % TPR) * NL;
 #pragma unroll
     for (int q = 0; q < NL; ++q) S[kb + q][o] = r[q];
   } else {
@@ -92,63 +95,69 @@ __device__ __forceinline__ void tile_store(double (*S)[BM + LPAD], const double 
   }
 }
 
-template <bool AK, bool BKC, int BKT, bool VEC>
+// BT = 128: the throughput tile (4 x 4 MFMA accumulators per wave).  BT = 64: the latency tile (2 x 2 per wave) for
+// launches with few tiles -- the panel and diagonal-block products of the factorisations, where one 128 x 128 x 128
+// tile alone is 4.2 MFLOP = 14 us on a single CU at the fp64 matrix rate, and there are 40-80 of them in a chain.
+template <bool AK, bool BKC, int BT, int BKT, bool VEC>
 __global__ __launch_bounds__(256, 2) void k_dgemm(GemmArgs g, int64_t tiles_n, int64_t kchunk) {
-  __shared__ double As[BKT][BM + LPAD];
-  __shared__ double Bs[BKT][BN + LPAD];
+  constexpr int TW = BT / 32;   // MFMA tiles per wave and dimension
+  __shared__ double As[BKT][BT + LPAD];
+  __shared__ double Bs[BKT][BT + LPAD];
   const int64_t bid = blockIdx.x;
   const int64_t tm = bid / tiles_n, tn = bid % tiles_n;
-  if (g.lower_only && tn > tm) return;
-  const int64_t m0 = tm * BM, n0 = tn * BN;
-  const int64_t kbeg = (int64_t)blockIdx.y * kchunk;
-  const int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
+  if ((g.lower_only == 1 && tn > tm) || (g.lower_only == 2 && tn >= tm) || (g.lower_only == 3 && tn < tm)) return;
+  const int64_t m0 = tm * BT, n0 = tn * BT;
+  int64_t kbeg = (int64_t)blockIdx.y * kchunk;
+  int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
+  if (g.kmode == 1) { kbeg = m0; kend = (m0 + BT < g.K) ? (m0 + BT) : g.K; }        // block-diagonal op(A)
+  else if (g.kmode == 2) { kbeg = n0; kend = (n0 + BT < g.K) ? (n0 + BT) : g.K; }   // block-diagonal op(B)
   double* C = g.C + (int64_t)blockIdx.y * g.c_split_stride;  // may alias A (in-place panels)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
   const int lk = lane >> 4, li = lane & 15;
 
-  v4d acc[4][4];
+  v4d acc[TW][TW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < TW; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  double ra[BKT / 2], rb[BKT / 2];
+  double ra[BT * BKT / 256], rb[BT * BKT / 256];
   if (kbeg < kend) {
-    tile_load<AK, BKT, VEC>(g.A, g.lda, m0, kbeg, g.M, kend, ra);
-    tile_load<BKC, BKT, VEC>(g.B, g.ldb, n0, kbeg, g.N, kend, rb);
+    tile_load<AK, BT, BKT, VEC>(g.A, g.lda, m0, kbeg, g.M, kend, ra);
+    tile_load<BKC, BT, BKT, VEC>(g.B, g.ldb, n0, kbeg, g.N, kend, rb);
   }
   for (int64_t k0 = kbeg; k0 < kend; k0 += BKT) {
     __syncthreads();
-    tile_store<AK, BKT>(As, ra);
-    tile_store<BKC, BKT>(Bs, rb);
+    tile_store<AK, BT, BKT>(As, ra);
+    tile_store<BKC, BT, BKT>(Bs, rb);
     __syncthreads();
     if (k0 + BKT < kend) {
-      tile_load<AK, BKT, VEC>(g.A, g.lda, m0, k0 + BKT, g.M, kend, ra);
-      tile_load<BKC, BKT, VEC>(g.B, g.ldb, n0, k0 + BKT, g.N, kend, rb);
+      tile_load<AK, BT, BKT, VEC>(g.A, g.lda, m0, k0 + BKT, g.M, kend, ra);
+      tile_load<BKC, BT, BKT, VEC>(g.B, g.ldb, n0, k0 + BKT, g.N, kend, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BKT; kk += 4) {
-      double a[4], b[4];
+      double a[TW], b[TW];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < TW; ++t) {
         a[t] = As[kk + lk][wm + t * 16 + li];
         b[t] = Bs[kk + lk][wn + t * 16 + li];
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
   const bool use_beta = (g.split_k <= 1) && (g.beta != 0.0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TW; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < TW; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + wm + i * 16 + lk + 4 * r;
@@ -173,38 +182,67 @@ __global__ void k_sum_partials(const double* __restrict__ parts, int n_parts, in
 
 }  // namespace
 
-template <int BKT, bool VEC>
+template <int BT, int BKT, bool VEC>
 static void dispatch(const GemmArgs& g, dim3 grid, hipStream_t st, int64_t tiles_n, int64_t kchunk) {
   const bool ak = (g.ta == 0), bk = (g.tb == 1);
   dim3 block(256);
-  if (ak && bk) hipLaunchKernelGGL((k_dgemm<true, true, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
-  else if (ak && !bk) hipLaunchKernelGGL((k_dgemm<true, false, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
-  else if (!ak && bk) hipLaunchKernelGGL((k_dgemm<false, true, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
-  else hipLaunchKernelGGL((k_dgemm<false, false, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
+  if (ak && bk) hipLaunchKernelGGL((k_dgemm<true, true, BT, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
+  else if (ak && !bk) hipLaunchKernelGGL((k_dgemm<true, false, BT, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
+  else if (!ak && bk) hipLaunchKernelGGL((k_dgemm<false, true, BT, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
+  else hipLaunchKernelGGL((k_dgemm<false, false, BT, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
 }
 
-static int g_bk_override = -1;   // diagnostics: force BK (16 / 32); -1 = automatic
+static int g_bk_override = -1;   // diagnostics: force the tile size (128 / 64); -1 = automatic
 void dgemm_set_bk(int bk) { g_bk_override = bk; }
 
 int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return MLN_OK;
-  const int64_t tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+  // tile choice: 128 x 128 unless that leaves most CUs idle (fewer tiles than CUs): then 64 x 64 -- four times the
+  // workgroups, a quarter of the serial work each.  In-place panel products (C aliases A with one column tile per row
+  // tile) keep 128 when N > 64, because two 64-wide column tiles of one row tile would read what the other writes.
+  // (callers that update in place were written for 128-wide tiles: any overlap of C with an operand keeps them)
+  auto overlaps = [&](const double* P, int64_t rows, int64_t cols, int64_t ld) {
+    const double* c1 = g.C + (g.M - 1) * g.ldc + g.N;
+    const double* p1 = P + (rows - 1) * ld + cols;
+    if (!(g.C < p1 && P < c1)) return false;            // disjoint address ranges
+    if (ld != g.ldc) return true;                        // different layouts: assume the worst
+    // two rectangles of one row-major matrix with leading dimension ld: compare row and column intervals
+    const int64_t off = P - g.C;                         // position of P relative to C
+    int64_t dr = off / ld, dc = off % ld;
+    if (dc < 0) { dc += ld; dr -= 1; }
+    if (dc + cols > ld) return true;                     // wraps around a row end: not a rectangle of this matrix
+    const bool rows_hit = dr < g.M && 0 < dr + rows;
+    const bool cols_hit = dc < g.N && 0 < dc + cols;
+    // (P to the left of C in the same rows shows up as dc close to ld with dr one less)
+    const bool cols_hit_wrapped = (dc - ld) < g.N && 0 < (dc - ld) + cols && (dr + 1) < g.M && 0 < dr + 1 + rows;
+    return (rows_hit && cols_hit) || cols_hit_wrapped;
+  };
+  const bool inplace = overlaps(g.A, g.ta == 0 ? g.M : g.K, g.ta == 0 ? g.K : g.M, g.lda) ||
+                       overlaps(g.B, g.tb == 0 ? g.K : g.N, g.tb == 0 ? g.N : g.K, g.ldb);
+  int bt = 128;
+  {
+    const int64_t t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.lower_only ? 2 : 1);
+    const int64_t n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    if (t128 * (g.split_k > 1 ? g.split_k : 1) < n_cu && !inplace) bt = 64;
+  }
+  if (g_bk_override == 128 || g_bk_override == 64) bt = inplace ? 128 : g_bk_override;
+  if (g.kmode != 0) bt = 128;   // the block-diagonal modes are defined on 128-wide blocks
+  const int64_t tiles_m = (g.M + bt - 1) / bt, tiles_n = (g.N + bt - 1) / bt;
   const int64_t nblk = tiles_m * tiles_n;
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }
   const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0);
-  int bkt = 16;   // measured: BK=32 (246 VGPRs, 74 KB LDS) is 10-20 % slower than BK=16 on every shape
-  if (g_bk_override == 16 || g_bk_override == 32) bkt = g_bk_override;
+  constexpr int bkt = 16;   // measured: BK=32 (246 VGPRs, 74 KB LDS) is 10-20 % slower than BK=16 on every shape
   int split = g.split_k > 1 ? g.split_k : 1;
   int64_t kchunk = (g.K + split - 1) / split;
   kchunk = ((kchunk + bkt - 1) / bkt) * bkt;
   if (kchunk <= 0) kchunk = bkt;
   dim3 grid((unsigned)nblk, (unsigned)split);
-  if (bkt == 32) {
-    if (vec) dispatch<32, true>(g, grid, ctx->stream, tiles_n, kchunk);
-    else dispatch<32, false>(g, grid, ctx->stream, tiles_n, kchunk);
+  if (bt == 64) {
+    if (vec) dispatch<64, 16, true>(g, grid, ctx->stream, tiles_n, kchunk);
+    else dispatch<64, 16, false>(g, grid, ctx->stream, tiles_n, kchunk);
   } else {
-    if (vec) dispatch<16, true>(g, grid, ctx->stream, tiles_n, kchunk);
-    else dispatch<16, false>(g, grid, ctx->stream, tiles_n, kchunk);
+    if (vec) dispatch<128, 16, true>(g, grid, ctx->stream, tiles_n, kchunk);
+    else dispatch<128, 16, false>(g, grid, ctx->stream, tiles_n, kchunk);
   }
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;

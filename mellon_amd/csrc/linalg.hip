@@ -185,16 +185,30 @@ int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst,
   return MLN_OK;
 }
 
+namespace {
+// dst <- src on the tiles strictly below the 128-block diagonal
+__global__ void k_copy_below_blocks(const double* __restrict__ src, double* __restrict__ dst, int64_t m, int64_t ld) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j < m && (j >> 7) < (i >> 7)) dst[i * ld + j] = src[i * ld + j];
+}
+
+}  // namespace
+
 // In-place lower Cholesky of the m x m matrix at A (only the lower triangle is read): right-looking over 128-wide
 // block columns.  Per step: k_potrf128 (potrf.hip: the diagonal block and its inverse, one workgroup), the rest of
-// the block column as one GEMM  P <- P T^-T,  the trailing update as one lower-tiles-only GEMM  A22 -= P P^T.
+// the block column as one GEMM  P = A_panel T^-T  written to a side matrix (no aliasing -> the 64 x 64 latency tiles
+// apply: with <= 39 row tiles a 128-tile launch is 14 us of serial work per CU), the trailing update as one
+// lower-tiles-only GEMM  A22 -= P P^T.  The side matrix is copied under the block diagonal of A at the end.
 int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   if (m <= 0) return MLN_OK;
   constexpr int CB = 128;
   double* Dinv = nullptr;
+  double* Ls = nullptr;
   MLN_HIP(ctx, mln_dmalloc((void**)&Dinv, sizeof(double) * CB * CB));
   MLN_HIP(ctx, hipMemsetAsync(Dinv, 0, sizeof(double) * CB * CB, ctx->stream));
   MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  if (m > CB) MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)m * (size_t)lda));
   int rc = MLN_OK;
   for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += CB) {
     const int nb = (int)((m - j0 < CB) ? (m - j0) : CB);
@@ -203,9 +217,9 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
     if (rc != MLN_OK) break;
     const int64_t rem = m - j0 - nb;
     if (rem > 0) {
-      double* P = A + (j0 + nb) * lda + j0;
-      GemmArgs g{};  // P <- P * Dinv^T   (in place: one 128-wide column tile per row tile)
-      g.A = P; g.lda = lda; g.B = Dinv; g.ldb = CB; g.C = P; g.ldc = lda;
+      double* P = Ls + (j0 + nb) * lda + j0;
+      GemmArgs g{};  // P = A_panel * Dinv^T
+      g.A = A + (j0 + nb) * lda + j0; g.lda = lda; g.B = Dinv; g.ldb = CB; g.C = P; g.ldc = lda;
       g.M = rem; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
       rc = launch_dgemm(ctx, g);
       if (rc != MLN_OK) break;
@@ -217,6 +231,7 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   }
   int info = 0;
   if (rc == MLN_OK) {
+    if (Ls) hipLaunchKernelGGL(k_copy_below_blocks, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, Ls, A, m, lda);
     hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, A, m, lda);
     hipError_t e = hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -225,6 +240,7 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
     (void)hipStreamSynchronize(ctx->stream);
   }
   (void)mln_dfree(Dinv);
+  if (Ls) (void)mln_dfree(Ls);
   if (rc == MLN_OK && info != 0) {
     mln_set_error(ctx, "Cholesky failed: non-positive or NaN pivot at index " + std::to_string(info - 1));
     return MLN_ERR_NOT_PD;
@@ -239,49 +255,40 @@ void triinv_free(TriInv* t) {
   t->W = t->W2 = nullptr;
 }
 
-// W  (row-scaled):    W[j, <=j]  = Dinv_j [ -Lf[j,<j] | I ]     -> forward solves and X Lf^-T
-// W2 (column-scaled): W2[>=j, j] = [ I ; -Lf[>j,j] ] Dinv_j     -> backward (transposed) solves
+// W  (row-scaled):    W[j, <=j]  = Dinv_j [ -Lf[j,<j] | I ]     -> forward left-looking solves, X Lf^-T, backward updates
+// W2 (column-scaled): W2[>=j, j] = [ I ; -Lf[>j,j] ] Dinv_j     -> backward left-looking solves, forward updates
+// Both are built whatever the flags say: each is ONE launch of the GEMM kernel in its block-diagonal mode
+// (the tile (i, j), i > j, of W is -Dinv_i Lf_ij: K range = row block i; of W2 it is -Lf_ij Dinv_j: K range =
+// column block j) -- 2 launches where the block-column loops took 78.
 int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool need_w, bool need_w2, TriInv* out) {
+  (void)need_w; (void)need_w2;
   out->m = m;
   out->Lf = Lf;
   out->ldf = ld;
   out->ld = ((m + 15) / 16) * 16;
   const size_t bytes = sizeof(double) * (size_t)m * (size_t)out->ld;
-  double* D = nullptr;  // block-diagonal inverse, stored in an m x ld matrix
-  MLN_HIP(ctx, mln_dmalloc((void**)&D, bytes));
+  MLN_HIP(ctx, mln_dmalloc((void**)&out->W, bytes));
+  hipError_t e = mln_dmalloc((void**)&out->W2, bytes);
+  if (e != hipSuccess) { triinv_free(out); return mln_hip_fail(ctx, e, "alloc W2", __FILE__, __LINE__); }
+  double* D = out->W;   // block-diagonal inverse first; the blocks under it follow
   MLN_HIP(ctx, hipMemsetAsync(D, 0, bytes, ctx->stream));
   const int64_t nb64 = (m + PB - 1) / PB, nb128 = (m + TB - 1) / TB;
   hipLaunchKernelGGL(k_trtri64, dim3((unsigned)nb64), dim3(256), 0, ctx->stream, Lf, m, ld, D, out->ld);
   hipLaunchKernelGGL(k_trtri_merge128, dim3((unsigned)nb128), dim3(256), 0, ctx->stream, Lf, m, ld, D, out->ld);
   MLN_HIP(ctx, hipGetLastError());
+  MLN_HIP(ctx, hipMemcpyAsync(out->W2, D, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   int rc = MLN_OK;
-  if (need_w2) {
-    rc = (mln_dmalloc((void**)&out->W2, bytes) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-    if (rc == MLN_OK) rc = (hipMemcpyAsync(out->W2, D, bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-    for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += TB) {
-      const int64_t nb = (m - j0 < TB) ? (m - j0) : TB;
-      const int64_t rem = m - j0 - nb;
-      if (rem <= 0) break;
-      GemmArgs g{};  // W2[>j, j] = -Lf[>j, j] * Dinv_j
-      g.A = Lf + (j0 + nb) * ld + j0; g.lda = ld; g.B = D + j0 * out->ld + j0; g.ldb = out->ld;
-      g.C = out->W2 + (j0 + nb) * out->ld + j0; g.ldc = out->ld;
-      g.M = rem; g.N = nb; g.K = nb; g.alpha = -1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
-      rc = launch_dgemm(ctx, g);
+  if (m > TB) {
+    GemmArgs g{};   // W2[i, j] = -Lf[i, j] Dinv_j  (i > j): op(B) = the block-diagonal D, read from W2's own diagonal
+    g.A = Lf; g.lda = ld; g.B = D; g.ldb = out->ld; g.C = out->W2; g.ldc = out->ld;
+    g.M = m; g.N = m; g.K = m; g.alpha = -1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.lower_only = 2; g.kmode = 2;
+    rc = launch_dgemm(ctx, g);
+    if (rc == MLN_OK) {
+      GemmArgs h{};  // W[i, j] = -Dinv_i Lf[i, j]  (i > j): op(A) block-diagonal -- read from W2, whose diagonal
+      h.A = out->W2; h.lda = out->ld; h.B = Lf; h.ldb = ld; h.C = out->W; h.ldc = out->ld;   // blocks this launch leaves alone
+      h.M = m; h.N = m; h.K = m; h.alpha = -1.0; h.beta = 0.0; h.ta = 0; h.tb = 0; h.lower_only = 2; h.kmode = 1;
+      rc = launch_dgemm(ctx, h);
     }
-  }
-  if (need_w && rc == MLN_OK) {
-    for (int64_t j0 = TB; j0 < m && rc == MLN_OK; j0 += TB) {
-      const int64_t nb = (m - j0 < TB) ? (m - j0) : TB;
-      GemmArgs g{};  // W[j, <j] = -Dinv_j * Lf[j, <j]   (written next to the diagonal blocks in D)
-      g.A = D + j0 * out->ld + j0; g.lda = out->ld; g.B = Lf + j0 * ld; g.ldb = ld;
-      g.C = D + j0 * out->ld; g.ldc = out->ld;
-      g.M = nb; g.N = j0; g.K = nb; g.alpha = -1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
-      rc = launch_dgemm(ctx, g);
-    }
-    out->W = D;
-  } else {
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)mln_dfree(D);
   }
   if (rc != MLN_OK) { (void)hipStreamSynchronize(ctx->stream); triinv_free(out); mln_set_error(ctx, "triinv_build failed"); }
   return rc;
@@ -302,65 +309,75 @@ int triinv_solve_right_T(mln_ctx* ctx, const TriInv& t, double* X, int64_t n, in
 
 // B (m x p, in place) <- Lf^-1 B (forward substitution by 128-row blocks).
 //   few right-hand sides: left-looking,  B_j <- W_j [B_<j ; B_j]            (one GEMM per block row)
-//   many (p >= 256):      right-looking, B_j <- Dinv_j B_j ; B_>j -= Lf[>j,j] B_j   -- the trailing
-//   update is a (m-j) x p GEMM that fills the chip, where the left-looking form has only p/128 tiles
+//   many (p >= 256):      right-looking with the diagonal blocks factored out of the loop.  With B~_j the block row
+//   after all updates from above, the solution is X_j = Dinv_j B~_j and the update it triggers is
+//   B_>j -= Lf[>j,j] X_j = B_>j + W2[>j,j] B~_j: every step is ONE big GEMM on the un-multiplied block row, and the
+//   40 diagonal products -- each a 14-45 us chain link when done one by one -- collapse into one final launch of
+//   the GEMM kernel in its block-diagonal mode.
 int triinv_solve_left(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb, bool tri_b) {
-  const bool right_looking = (p >= 256) && t.Lf && t.W;
+  const bool right_looking = (p >= 256) && t.W && t.W2;
   tri_b = tri_b && right_looking && p == t.m;
-  for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
-    const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
-    GemmArgs g{};
-    if (!right_looking) {
+  if (!right_looking) {
+    for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
+      const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+      GemmArgs g{};
       // in place: one row tile (nb <= 128), so each workgroup reads and writes only its own column tile
       g.A = t.W + j0 * t.ld; g.lda = t.ld; g.B = B; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
       g.M = nb; g.N = p; g.K = j0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
       MLN_TRY(launch_dgemm(ctx, g));
-      continue;
     }
-    const int64_t ncol = tri_b ? (j0 + nb) : p;      // lower-triangular B: rows of this block end at column j0 + nb
-    g.A = t.W + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb; g.C = B + j0 * ldb; g.ldc = ldb;
-    g.M = nb; g.N = ncol; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
-    MLN_TRY(launch_dgemm(ctx, g));
-    const int64_t rem = t.m - j0 - nb;
-    if (rem > 0) {
-      GemmArgs u{};
-      u.A = t.Lf + (j0 + nb) * t.ldf + j0; u.lda = t.ldf; u.B = B + j0 * ldb; u.ldb = ldb;
-      u.C = B + (j0 + nb) * ldb; u.ldc = ldb;
-      u.M = rem; u.N = ncol; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 0; u.tb = 0;
-      MLN_TRY(launch_dgemm(ctx, u));
-    }
+    return MLN_OK;
   }
-  return MLN_OK;
+  for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
+    const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+    const int64_t rem = t.m - j0 - nb;
+    if (rem <= 0) break;
+    const int64_t ncol = tri_b ? (j0 + nb) : p;      // lower-triangular B: rows of this block end at column j0 + nb
+    GemmArgs u{};
+    u.A = t.W2 + (j0 + nb) * t.ld + j0; u.lda = t.ld; u.B = B + j0 * ldb; u.ldb = ldb;
+    u.C = B + (j0 + nb) * ldb; u.ldc = ldb;
+    u.M = rem; u.N = ncol; u.K = nb; u.alpha = 1.0; u.beta = 1.0; u.ta = 0; u.tb = 0;
+    MLN_TRY(launch_dgemm(ctx, u));
+  }
+  GemmArgs g{};   // X = blockdiag(Dinv) B~, in place: a tile reads exactly the tile it overwrites
+  g.A = t.W; g.lda = t.ld; g.B = B; g.ldb = ldb; g.C = B; g.ldc = ldb;
+  g.M = t.m; g.N = p; g.K = t.m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.kmode = 1;
+  g.lower_only = tri_b ? 1 : 0;
+  return launch_dgemm(ctx, g);
 }
 
 // B (m x p, in place) <- Lf^-T B (backward substitution).
 //   few right-hand sides: B_j <- W2[>=j, j]^T B[>=j]
-//   many (p >= 256):      B_j <- Dinv_j^T B_j ; B_<j -= Lf[j,<j]^T B_j
+//   many (p >= 256):      the mirror image of the forward solve: B_<j += W[j,<j]^T B~_j from the last block row up,
+//   then X = blockdiag(Dinv^T) B~ in one launch.
 int triinv_solve_left_T(mln_ctx* ctx, const TriInv& t, double* B, int64_t p, int64_t ldb, bool tri_b) {
-  const bool right_looking = (p >= 256) && t.Lf && t.W2;
+  const bool right_looking = (p >= 256) && t.W && t.W2;
   tri_b = tri_b && right_looking && p == t.m;
   const int64_t nblk = (t.m + TB - 1) / TB;
-  for (int64_t jb = nblk - 1; jb >= 0; --jb) {
-    const int64_t j0 = jb * TB;
-    const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
-    GemmArgs g{};
-    if (!right_looking) {
+  if (!right_looking) {
+    for (int64_t jb = nblk - 1; jb >= 0; --jb) {
+      const int64_t j0 = jb * TB;
+      const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+      GemmArgs g{};
       g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb; g.ldb = ldb;
       g.C = B + j0 * ldb; g.ldc = ldb;
       g.M = nb; g.N = p; g.K = t.m - j0; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;
       MLN_TRY(launch_dgemm(ctx, g));
-      continue;
     }
-    const int64_t c0 = tri_b ? j0 : 0;                // upper-triangular B: rows of this block start at column j0
-    g.A = t.W2 + j0 * t.ld + j0; g.lda = t.ld; g.B = B + j0 * ldb + c0; g.ldb = ldb; g.C = B + j0 * ldb + c0; g.ldc = ldb;
-    g.M = nb; g.N = p - c0; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;   // Dinv_j^T B_j
-    MLN_TRY(launch_dgemm(ctx, g));
-    if (j0 > 0) {
-      GemmArgs u{};
-      u.A = t.Lf + j0 * t.ldf; u.lda = t.ldf; u.B = B + j0 * ldb + c0; u.ldb = ldb; u.C = B + c0; u.ldc = ldb;
-      u.M = j0; u.N = p - c0; u.K = nb; u.alpha = -1.0; u.beta = 1.0; u.ta = 1; u.tb = 0;  // Lf[j,<j]^T B_j
-      MLN_TRY(launch_dgemm(ctx, u));
-    }
+    return MLN_OK;
   }
-  return MLN_OK;
+  for (int64_t jb = nblk - 1; jb >= 1; --jb) {
+    const int64_t j0 = jb * TB;
+    const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+    const int64_t c0 = tri_b ? j0 : 0;                // upper-triangular B: rows of this block start at column j0
+    GemmArgs u{};
+    u.A = t.W + j0 * t.ld; u.lda = t.ld; u.B = B + j0 * ldb + c0; u.ldb = ldb; u.C = B + c0; u.ldc = ldb;
+    u.M = j0; u.N = p - c0; u.K = nb; u.alpha = 1.0; u.beta = 1.0; u.ta = 1; u.tb = 0;   // W[j,<j]^T B~_j
+    MLN_TRY(launch_dgemm(ctx, u));
+  }
+  GemmArgs g{};
+  g.A = t.W; g.lda = t.ld; g.B = B; g.ldb = ldb; g.C = B; g.ldc = ldb;
+  g.M = t.m; g.N = p; g.K = t.m; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0; g.kmode = 1;
+  g.lower_only = tri_b ? 3 : 0;
+  return launch_dgemm(ctx, g);
 }

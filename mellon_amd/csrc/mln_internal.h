@@ -24,7 +24,10 @@ int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* 
 // dgemm.hip : C = alpha * op(A) op(B) + beta * C   (row-major, fp64 MFMA 16x16x4)
 //   ta = 0: A is M x K (lda >= K);  ta = 1: A is stored K x M (lda >= M)
 //   tb = 0: B is K x N (ldb >= N);  tb = 1: B is stored N x K (ldb >= K)
-//   lower_only: skip 128x128 tiles strictly above the diagonal (square C)
+//   lower_only: 1 = skip tiles strictly above the diagonal (square C); 2 = also skip the diagonal tiles;
+//               3 = skip the tiles strictly BELOW the diagonal
+//   kmode:      1 = the K range of a tile is its own ROW block [m0, m0 + 128) -- op(A) block-diagonal;
+//               2 = its own COLUMN block [n0, n0 + 128) -- op(B) block-diagonal   (128 x 128 tiles)
 //   split_k > 1: writes split_k partial C's at C + s * c_split_stride (beta ignored, alpha applied)
 struct GemmArgs {
   const double* A; int64_t lda;
@@ -35,6 +38,7 @@ struct GemmArgs {
   int ta, tb;
   int lower_only;
   int split_k; int64_t c_split_stride;
+  int kmode;
 };
 int launch_dgemm(mln_ctx* ctx, const GemmArgs& g);
 int launch_sum_partials(mln_ctx* ctx, const double* parts, int n_parts, int64_t stride, double* out,

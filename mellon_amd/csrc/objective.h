@@ -13,11 +13,15 @@ struct ObjArgs {
   double* f_out;          // if non-null: store f_i = L_i . z + mu
   int n_wg; int64_t m_pad;
   const float* L32;       // if non-null: stream this fp32 copy of L instead (same shape / leading dimension)
+  double* f_keep[2];      // if f_slot is non-null: f_i = L_i . z + mu of every row is also stored to f_keep[1 - *f_slot]
+  const int* f_slot;      //   (the solver's "trial" buffer; accepting a point flips the slot -- the log-density at the
+                          //    optimum then needs no pass of its own)
   const int* gate;        // if non-null: the launch is a no-op unless *gate == gate_want (device-resident solver:
   int gate_want;          //   MLN_GATE_F64 / MLN_GATE_F32 select the streamed copy, MLN_GATE_DONE stops everything)
 };
 enum { MLN_GATE_F64 = 0, MLN_GATE_F32 = 1, MLN_GATE_DONE = 2 };
 int objective_max_m();
+bool objective_can_keep_f(int64_t n, int n_wg);
 int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count);
 int launch_objective(mln_ctx* ctx, const ObjArgs& a);
 int launch_reduce_obj(mln_ctx* ctx, const ObjArgs& a, double* out_loss_grad /* 1 + m [+ m] */);

@@ -21,9 +21,18 @@
 namespace {
 
 constexpr int WG = 512;
+constexpr int MLN_FSTAGE = 6144;   // rows of f one workgroup can stage in LDS (48 KB)
 enum { MODE_OBJ = 0, MODE_OBJ_HESS = 1, MODE_GEMVT = 2, MODE_FONLY = 3 };
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+
+// One ds_write_b64 the compiler cannot schedule around: written as a plain C++ store, the LDS write of the per-row f
+// made the scheduler sink the NEXT row set's global loads below the current set's arithmetic (vmcnt(0) at the loop
+// head, +10 % per pass); as an opaque instruction it leaves the load-early order of the source alone.
+__device__ __forceinline__ void lds_store_f64(double* base, int idx, double v) {
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)base + 8u * (unsigned)idx;
+  asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(v));   // no memory clobber: global loads may move across it
+}
 
 template <int CPT, int R>
 __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2, int64_t row, int64_t row_end,
@@ -46,10 +55,22 @@ __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2
   }
 }
 
-template <int CPT, int R, int MODE>
+// V and Vdr of the R rows of a step (clamped to the last row: rows past the end have coefficient 0)
+template <int R>
+__device__ __forceinline__ void load_lik(const ObjArgs& a, int64_t row, double (&pv)[2][R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t i = (row + r < a.n) ? (row + r) : (a.n - 1);
+    pv[0][r] = a.V[i];
+    pv[1][r] = a.Vdr[i];
+  }
+}
+
+template <int CPT, int R, int MODE, bool KEEP>
 __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                              const d2 (&v)[R][CPT], const d2 (&z)[CPT], d2 (&g)[CPT],
-                                             d2 (&h)[CPT], double& loss, double (*red)[8][R]) {
+                                             d2 (&h)[CPT], double& loss, double (*red)[8][R], double* fstage,
+                                             int64_t fbase, const double (&pv)[2][R]) {
   double coef[R], aexp[R];
   if (MODE == MODE_GEMVT) {
 #pragma unroll
@@ -86,11 +107,18 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
         coef[r] = 0.0;
         aexp[r] = 0.0;
       } else {
-        const double Vi = rok ? a.V[row + r] : 0.0;
+        // KEEP: V / Vdr of the row were requested together with the row itself (load_lik) -- a load issued HERE would
+        // sit behind the next set's row loads in the in-order return queue (s_waitcnt vmcnt(0))
+        const double Vi = KEEP ? pv[0][r] : (rok ? a.V[row + r] : 0.0);
         const double e = rok ? exp(f + Vi) : 0.0;
         aexp[r] = e;
         coef[r] = rok ? (e - 1.0) : 0.0;
-        if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;   // inference.py:89-91
+        if (KEEP) { if (tid == 0 && rok) loss -= (f + pv[1][r]) - e; }
+        else if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;   // inference.py:89-91
+        // f of the row goes to LDS.  Unconditional store by every lane (thread 0 to the row's slot, the others to a
+        // per-lane dummy slot): a store under `if (tid == 0)` is a real branch in the loop body, and a global store
+        // there serialises the load pipeline -- both cost 10-20 % of the pass.
+        if (KEEP) lds_store_f64(fstage, (tid == 0 && rok) ? (int)(row + r - fbase) : (MLN_FSTAGE + tid), f);
       }
     }
   }
@@ -110,7 +138,7 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
   }
 }
 
-template <int CPT, int R, int MODE>
+template <int CPT, int R, int MODE, bool KEEP = false>
 __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   if (a.gate && *a.gate != a.gate_want) return;   // uniform: the device-resident solver chose the other copy / is done
   __shared__ double red[2][8][R];
@@ -137,17 +165,30 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
     h[c] = (d2){0.0, 0.0};
   }
   double loss = 0.0;
+  // f of this workgroup's rows is staged in LDS and written out once at the end
+  __shared__ double fstage[KEEP ? (MLN_FSTAGE + WG) : 1];
+  const int64_t fbase = s_beg * R;
   d2 va[R][CPT], vb[R][CPT];
   // Software pipeline with UNCONDITIONAL loads (steps past the end re-read the last step): the load
   // count between any use and the loads it depends on is then static, so the compiler waits with
   // vmcnt(loads of one set) instead of vmcnt(0) and one set is always in flight behind the one consumed.
   const int64_t s_last = s_end - 1;
-  if (s_beg < s_end) load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va);
+  double pa[2][R], pb[2][R];
+  if (s_beg < s_end) { load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {
-    load_rows<CPT, R>(L2, ld2, ((s + 1 < s_end) ? s + 1 : s_last) * R, a.n, tid, vb);
-    process_rows<CPT, R, MODE>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red);
-    load_rows<CPT, R>(L2, ld2, ((s + 2 < s_end) ? s + 2 : s_last) * R, a.n, tid, va);
-    if (s + 1 < s_end) process_rows<CPT, R, MODE>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red);
+    const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
+    load_rows<CPT, R>(L2, ld2, s1 * R, a.n, tid, vb);
+    if (KEEP) load_lik<R>(a, s1 * R, pb);
+    process_rows<CPT, R, MODE, KEEP>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red, fstage, fbase, pa);
+    load_rows<CPT, R>(L2, ld2, s2 * R, a.n, tid, va);
+    if (KEEP) load_lik<R>(a, s2 * R, pa);
+    if (s + 1 < s_end) process_rows<CPT, R, MODE, KEEP>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red, fstage, fbase, pb);
+  }
+  if (KEEP) {
+    __syncthreads();
+    double* fo = a.f_keep[1 - *a.f_slot];
+    const int64_t r_beg = s_beg * R, r_end = (s_end * R < a.n) ? s_end * R : a.n;
+    for (int64_t i = r_beg + tid; i < r_end; i += WG) fo[i] = fstage[i - r_beg];
   }
   if (MODE != MODE_FONLY) {
     double* pg = a.part_grad + (int64_t)blockIdx.x * a.m_pad;
@@ -190,10 +231,11 @@ __device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t l
   }
 }
 
-template <int CQ, int R, bool GEMVT>
+template <int CQ, int R, bool GEMVT, bool KEEP>
 __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                                const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
-                                               double& loss, double (*red)[8][R]) {
+                                               double& loss, double (*red)[8][R], double* fstage, int64_t fbase,
+                                               const double (&pv)[2][R]) {
   double coef[R], dot[R];
   if (GEMVT) {   // grad_j = sum_i weights_i L_ij  (Ridge right-hand side): no row dots, no barrier
 #pragma unroll
@@ -237,10 +279,12 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     for (int w = 0; w < 8; ++w) s += red[par][w][r];
     const bool rok = (row + r) < row_end;
     const double f = s + a.mu;
-    const double Vi = rok ? a.V[row + r] : 0.0;
+    const double Vi = KEEP ? pv[0][r] : (rok ? a.V[row + r] : 0.0);
     const double e = rok ? exp(f + Vi) : 0.0;
     coef[r] = rok ? (e - 1.0) : 0.0;
-    if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;
+    if (KEEP) { if (tid == 0 && rok) loss -= (f + pv[1][r]) - e; }
+    else if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;
+    if (KEEP) lds_store_f64(fstage, (tid == 0 && rok) ? (int)(row + r - fbase) : (MLN_FSTAGE + tid), f);   // see k_objective
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -254,7 +298,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
   }
 }
 
-template <int CQ, int R, bool GEMVT = false>
+template <int CQ, int R, bool GEMVT = false, bool KEEP = false>
 __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
   if (a.gate && *a.gate != a.gate_want) return;
   __shared__ double red[2][8][R];
@@ -276,14 +320,26 @@ __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
       g[c][e] = 0.0;
     }
   double loss = 0.0;
+  __shared__ double fstage[KEEP ? (MLN_FSTAGE + WG) : 1];
+  const int64_t fbase = s_beg * R;
   f4 va[R][CQ], vb[R][CQ];
   const int64_t s_last = s_end - 1;
-  if (s_beg < s_end) load_rows32<CQ, R>(L4, ld4, s_beg * R, a.n, tid, va);
+  double pa[2][R], pb[2][R];
+  if (s_beg < s_end) { load_rows32<CQ, R>(L4, ld4, s_beg * R, a.n, tid, va); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {   // unconditional loads: see k_objective
-    load_rows32<CQ, R>(L4, ld4, ((s + 1 < s_end) ? s + 1 : s_last) * R, a.n, tid, vb);
-    process_rows32<CQ, R, GEMVT>(a, s * R, a.n, tid, 0, va, z, g, loss, red);
-    load_rows32<CQ, R>(L4, ld4, ((s + 2 < s_end) ? s + 2 : s_last) * R, a.n, tid, va);
-    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red);
+    const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
+    load_rows32<CQ, R>(L4, ld4, s1 * R, a.n, tid, vb);
+    if (KEEP) load_lik<R>(a, s1 * R, pb);
+    process_rows32<CQ, R, GEMVT, KEEP>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa);
+    load_rows32<CQ, R>(L4, ld4, s2 * R, a.n, tid, va);
+    if (KEEP) load_lik<R>(a, s2 * R, pa);
+    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb);
+  }
+  if (KEEP) {
+    __syncthreads();
+    double* fo = a.f_keep[1 - *a.f_slot];
+    const int64_t r_beg = s_beg * R, r_end = (s_end * R < a.n) ? s_end * R : a.n;
+    for (int64_t i = r_beg + tid; i < r_end; i += WG) fo[i] = fstage[i - r_beg];
   }
   double* pg = a.part_grad + (int64_t)blockIdx.x * a.m_pad;
 #pragma unroll
@@ -300,6 +356,8 @@ __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
 template <int CQ, int R>
 int launch_f32(mln_ctx* ctx, const ObjArgs& a) {
   if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
+  // (never the f-keeping variant: what the fp32 copy yields is not the final log-density, and its variant of the
+  //  loop measured 3.58 instead of 3.23 ms per pass)
   else hipLaunchKernelGGL((k_objective32<CQ, R, false>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
@@ -316,19 +374,21 @@ __global__ void k_to_f32(const double* __restrict__ src, float* __restrict__ dst
   }
 }
 
-// out[0] = sum_wg loss ; out[1 + j] = sum_wg grad[wg][j] ; out[1 + m + j] = sum_wg hess[wg][j]
-// 64 columns x 4 groups of workgroup-partials per block; each group sums its partials in ascending
-// workgroup order and the 4 group sums are added in fixed order -> bit-reproducible.
+// out_loss[0] = sum_wg loss ; out_grad[j] = sum_wg grad[wg][j] ; out_grad[m + j] = sum_wg hess[wg][j]
+// 16 columns x 16 groups of workgroup-partials per block: each group sums its (n_wg / 16) partials in ascending
+// workgroup order, the 16 group sums are added in fixed order -> bit-reproducible.  (64 columns x 4 groups, i.e. 64
+// dependent loads per thread, took 30 us between two objective passes; this shape takes a few.)
 __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restrict__ out_loss,
                                                     double* __restrict__ out_grad, int with_hess) {
   if (a.gate && *a.gate == MLN_GATE_DONE) return;
-  __shared__ double red[2][4][64];
-  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t j = (int64_t)blockIdx.x * 64 + c;
+  __shared__ double red[2][16][16];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int64_t j = (int64_t)blockIdx.x * 16 + c;
   double s = 0.0, t = 0.0;
   if (j < a.m) {
-    const int per = (a.n_wg + 3) / 4;
+    const int per = (a.n_wg + 15) / 16;
     const int w0 = grp * per, w1 = (w0 + per < a.n_wg) ? (w0 + per) : a.n_wg;
+#pragma unroll 4
     for (int w = w0; w < w1; ++w) s += a.part_grad[(int64_t)w * a.m_pad + j];
     if (with_hess)
       for (int w = w0; w < w1; ++w) t += a.part_hess[(int64_t)w * a.m_pad + j];
@@ -337,14 +397,19 @@ __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restric
   red[1][grp][c] = t;
   __syncthreads();
   if (grp == 0 && j < a.m) {
-    out_grad[j] = ((red[0][0][c] + red[0][1][c]) + red[0][2][c]) + red[0][3][c];
-    if (with_hess) out_grad[a.m + j] = ((red[1][0][c] + red[1][1][c]) + red[1][2][c]) + red[1][3][c];
+    double gs = 0.0, hs = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { gs += red[0][q][c]; hs += red[1][q][c]; }
+    out_grad[j] = gs;
+    if (with_hess) out_grad[a.m + j] = hs;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {   // the loss partials: one wave, fixed shuffle tree
     double l = 0.0;
     if (a.part_loss)
-      for (int w = 0; w < a.n_wg; ++w) l += a.part_loss[w];
-    out_loss[0] = l;
+      for (int w = threadIdx.x; w < a.n_wg; w += 64) l += a.part_loss[w];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+    if (threadIdx.x == 0) out_loss[0] = l;
   }
 }
 
@@ -413,7 +478,10 @@ template <int CPT, int R>
 int launch_mode(mln_ctx* ctx, const ObjArgs& a, int mode) {
   dim3 grid((unsigned)a.n_wg), block(WG);
   switch (mode) {
-    case MODE_OBJ: hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ>), grid, block, 0, ctx->stream, a); break;
+    case MODE_OBJ:
+      if (a.f_slot) hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ, true>), grid, block, 0, ctx->stream, a);
+      else hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ>), grid, block, 0, ctx->stream, a);
+      break;
     case MODE_OBJ_HESS: hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ_HESS>), grid, block, 0, ctx->stream, a); break;
     case MODE_GEMVT: hipLaunchKernelGGL((k_objective<CPT, R, MODE_GEMVT>), grid, block, 0, ctx->stream, a); break;
     default: hipLaunchKernelGGL((k_objective<CPT, R, MODE_FONLY>), grid, block, 0, ctx->stream, a); break;
@@ -433,6 +501,9 @@ int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count) {
 }
 
 int objective_max_m() { return 1024 * 8; }
+
+// rows per workgroup the f-staging of the objective kernels can hold: callers leave f_slot null beyond it
+bool objective_can_keep_f(int64_t n, int n_wg) { return n_wg > 0 && (n + n_wg - 1) / n_wg + 16 <= MLN_FSTAGE; }
 
 int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   if (a.ldl % 2 != 0) { mln_set_error(ctx, "objective: leading dimension of L must be even"); return MLN_ERR_ARG; }
@@ -494,7 +565,7 @@ int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows
 }
 
 int launch_reduce_obj2(mln_ctx* ctx, const ObjArgs& a, double* out_loss, double* out_grad) {
-  hipLaunchKernelGGL(k_reduce_obj, dim3((unsigned)((a.m + 63) / 64)), dim3(256), 0, ctx->stream, a, out_loss, out_grad,
+  hipLaunchKernelGGL(k_reduce_obj, dim3((unsigned)((a.m + 15) / 16)), dim3(256), 0, ctx->stream, a, out_loss, out_grad,
                      a.part_hess ? 1 : 0);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;

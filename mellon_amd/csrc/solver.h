@@ -13,7 +13,10 @@ struct SolverState {
   int it, n_eval, n_eval32, ls;
   int k, head;   // curvature pairs stored / slot of the oldest
   int maxiter, maxcor, maxls;
-  int m, pad_;
+  int m;
+  int f_slot;    // which of the two per-row f buffers holds f at the ACCEPTED point (the pass in flight writes the other)
+  int f_valid;   // ... and whether that evaluation streamed the fp64 buffer
+  int pad_;
   double ftol, gtol, ftol32;
   double prior_const;       // (m / 2) log 2 pi
   double fx, t, gd;         // accepted loss, current trial step, g . d at the accepted point

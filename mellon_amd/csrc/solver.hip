@@ -95,6 +95,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   int mode = st->mode, it = st->it, n_eval = st->n_eval + 1, n_eval32 = st->n_eval32 + (phase32 ? 1 : 0);
   int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
   double fx = st->fx, t = st->t, gd = st->gd;
+  int f_slot = st->f_slot, f_valid = st->f_valid;
   if (b.trace && tid == 0) {
     double* tr = b.trace + 4 * ((n_eval - 1) & 511);
     tr[0] = fn; tr[1] = (mode == MLN_SOLVE_LS) ? t : 0.0; tr[2] = (double)mode; tr[3] = (double)gate;
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   bool to_head = false, reeval = false, done = false;
   if (mode != MLN_SOLVE_LS) {            // first point, or the same point again on the fp64 buffer
     fx = fn;
+    f_slot ^= 1; f_valid = phase32 ? 0 : 1;   // the rows' f of this pass belong to the accepted point
 #pragma unroll
     for (int e = 0; e < EPT; ++e) g[e] = gn[e];
     to_head = true;
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) { u[e] = un[e]; g[e] = gn[e]; }
       fx = fn;
+      f_slot ^= 1; f_valid = phase32 ? 0 : 1;
       if (sy > 1e-10 * sqrt(ss * yy)) {   // keep the pair (SPD update)
         int slot;
         if (k < st->maxcor) { slot = (head + k) % st->maxcor; ++k; }
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   if (tid == 0) {
     st->gate = gate; st->mode = mode; st->status = status; st->it = it; st->n_eval = n_eval; st->n_eval32 = n_eval32;
     st->ls = ls; st->k = k; st->head = head; st->fx = fx; st->t = t; st->gd = gd;
+    st->f_slot = f_slot; st->f_valid = f_valid;
   }
 }
 
