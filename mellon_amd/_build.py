@@ -10,7 +10,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmellon_hip.so")
-SOURCES = ["api.hip", "alloc.hip", "comm.hip", "cov_grad.hip", "cov_kernels.hip", "cov_rows.hip", "predict_rows.hip",
+SOURCES = ["api.hip", "alloc.hip", "comm.hip", "cov_grad.hip", "cov_kernels.hip", "cov_rows.hip", "cov_rows_matern32.hip", "cov_rows_matern52.hip", "cov_rows_expquad.hip",
+           "cov_rows_exponential.hip", "predict_rows.hip",
            "dgemm.hip", "diag.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

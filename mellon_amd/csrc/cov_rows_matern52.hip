@@ -1,0 +1,4 @@
+// k_kernel_matrix_rows for MLN_K_MATERN52 (see cov_rows_impl.h)
+#include "cov_rows_impl.h"
+
+MLN_DEFINE_ROWS_KIND(launch_kernel_matrix_rows_matern52, MLN_K_MATERN52)

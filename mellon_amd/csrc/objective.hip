@@ -15,6 +15,8 @@
 // HBM-bound: algorithmic bytes per launch = n_local * ldl * 8 (+ O(n + n_wg * m)).
 // Determinism: rows are split into contiguous per-workgroup ranges; per-workgroup partials are
 // summed in workgroup order by k_reduce_obj.
+#include <cstdlib>
+
 #include "mln_internal.h"
 #include "objective.h"
 
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
 // where they are used; every sum is fp64.  Half the HBM bytes per pass.
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int CQ, int R>
+template <int CQ, int R, int NW>
 __device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t ld4, int64_t row, int64_t row_end,
                                             unsigned tid, f4 (&v)[R][CQ]) {
 #pragma unroll
@@ -224,17 +226,17 @@ __device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t l
     const f4* rowp = L4 + (rok ? (row + r) : row) * ld4;
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {   // unconditional, clamped: see load_rows
-      unsigned off = (unsigned)c * WG + tid;
+      unsigned off = (unsigned)c * (64 * NW) + tid;
       off = (off < (unsigned)ld4) ? off : (unsigned)ld4 - 1u;
       v[r][c] = __builtin_nontemporal_load(rowp + off);
     }
   }
 }
 
-template <int CQ, int R, bool GEMVT, bool KEEP>
+template <int CQ, int R, bool GEMVT, bool KEEP, int NW>
 __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                                const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
-                                               double& loss, double (*red)[8][R], double* fstage, int64_t fbase,
+                                               double& loss, double (*red)[NW][R], double* fstage, int64_t fbase,
                                                const double (&pv)[2][R]) {
   double coef[R], dot[R];
   if (GEMVT) {   // grad_j = sum_i weights_i L_ij  (Ridge right-hand side): no row dots, no barrier
@@ -276,7 +278,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) s += red[par][w][r];
+    for (int w = 0; w < NW; ++w) s += red[par][w][r];
     const bool rok = (row + r) < row_end;
     const double f = s + a.mu;
     const double Vi = KEEP ? pv[0][r] : (rok ? a.V[row + r] : 0.0);
@@ -298,10 +300,13 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
   }
 }
 
-template <int CQ, int R, bool GEMVT = false, bool KEEP = false>
-__global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
+// NW waves per workgroup: a row of ld4 column quads is spread over 64 NW CQ lane slots, and NW is chosen so that few
+// of them are idle (m = 5000: 1252 quads on 7 x 64 x 3 = 1344 slots, 93 %; 8 waves would use 81 % of 1536)
+template <int CQ, int R, bool GEMVT = false, bool KEEP = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   if (a.gate && *a.gate != a.gate_want) return;
-  __shared__ double red[2][8][R];
+  constexpr int WG = 64 * NW;
+  __shared__ double red[2][NW][R];
   const int tid = threadIdx.x;
   const int64_t ld4 = a.ldl / 4;
   const f4* __restrict__ L4 = reinterpret_cast<const f4*>(a.L32);
@@ -325,15 +330,15 @@ __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
   f4 va[R][CQ], vb[R][CQ];
   const int64_t s_last = s_end - 1;
   double pa[2][R], pb[2][R];
-  if (s_beg < s_end) { load_rows32<CQ, R>(L4, ld4, s_beg * R, a.n, tid, va); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
+  if (s_beg < s_end) { load_rows32<CQ, R, NW>(L4, ld4, s_beg * R, a.n, tid, va); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {   // unconditional loads: see k_objective
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
-    load_rows32<CQ, R>(L4, ld4, s1 * R, a.n, tid, vb);
+    load_rows32<CQ, R, NW>(L4, ld4, s1 * R, a.n, tid, vb);
     if (KEEP) load_lik<R>(a, s1 * R, pb);
-    process_rows32<CQ, R, GEMVT, KEEP>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa);
-    load_rows32<CQ, R>(L4, ld4, s2 * R, a.n, tid, va);
+    process_rows32<CQ, R, GEMVT, KEEP, NW>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa);
+    load_rows32<CQ, R, NW>(L4, ld4, s2 * R, a.n, tid, va);
     if (KEEP) load_lik<R>(a, s2 * R, pa);
-    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb);
+    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb);
   }
   if (KEEP) {
     __syncthreads();
@@ -353,14 +358,26 @@ __global__ __launch_bounds__(WG) void k_objective32(ObjArgs a) {
   if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss;
 }
 
-template <int CQ, int R>
-int launch_f32(mln_ctx* ctx, const ObjArgs& a) {
-  if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
+template <int CQ, int R, int NW>
+int launch_f32_nw(mln_ctx* ctx, const ObjArgs& a) {
+  const dim3 grid((unsigned)a.n_wg), block(64 * NW);
+  if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true, false, NW>), grid, block, 0, ctx->stream, a);
   // (never the f-keeping variant: what the fp32 copy yields is not the final log-density, and its variant of the
   //  loop measured 3.58 instead of 3.23 ms per pass)
-  else hipLaunchKernelGGL((k_objective32<CQ, R, false>), dim3((unsigned)a.n_wg), dim3(WG), 0, ctx->stream, a);
+  else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW>), grid, block, 0, ctx->stream, a);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
+}
+
+template <int CQ, int R>
+int launch_f32(mln_ctx* ctx, const ObjArgs& a) {
+  const int64_t ld4 = a.ldl / 4;
+  int nw = (int)((ld4 + 64 * CQ - 1) / (64 * CQ));
+  static const int force = std::getenv("MELLON_AMD_OBJ32_WAVES") ? std::atoi(std::getenv("MELLON_AMD_OBJ32_WAVES")) : 0;
+  if (force >= 6 && force <= 8 && (int64_t)force * 64 * CQ >= ld4) nw = force;
+  if (nw <= 6) return launch_f32_nw<CQ, R, 6>(ctx, a);
+  if (nw == 7) return launch_f32_nw<CQ, R, 7>(ctx, a);
+  return launch_f32_nw<CQ, R, 8>(ctx, a);
 }
 
 __global__ void k_to_f32(const double* __restrict__ src, float* __restrict__ dst, int64_t count) {

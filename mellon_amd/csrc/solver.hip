@@ -145,6 +145,12 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       } else {
         if ((f_old - fx) <= st->ftol * fscale) { status = 0; done = true; } else to_head = true;
       }
+    } else if (isfinite(fn) && fabs(fn - fx) <= st->ftol * fmax(fmax(fabs(fx), fabs(fn)), 1.0)) {
+      // The trial changed the loss by no more than the stopping tolerance but was not a sufficient decrease: the
+      // search has reached the rounding noise of the objective (sums of n terms), where shrinking the step further
+      // only samples that noise -- seen as 5-7 wasted passes with t = 0.2, 0.02, ... before one happened to pass.
+      // This is the relative-decrease test of the accepted branch applied to the rejected trial: converged.
+      if (phase32) reeval = true; else { status = 0; done = true; }
     } else if (ls >= st->maxls) {
       if (phase32) reeval = true;          // the surrogate is exhausted: continue in fp64 from the accepted point
       else { status = 2; done = true; }

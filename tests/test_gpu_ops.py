@@ -623,3 +623,33 @@ def test_util_helpers_distance_and_rank(ctx):
     with pytest.raises(Exception):
         ctx.predict_gradient(__import__("mellon_amd").base_cov.LoweredCov([(7, 1.0, 1.0, np.arange(5))], [(0, 0, 0.0)]),
                              x, y, np.ones(33))
+
+
+@pytest.mark.parametrize("name", ["Matern32", "Matern52", "ExpQuad", "Exponential", "RatQuad"])
+@pytest.mark.parametrize("d", [8, 50, 60])
+def test_kernel_matrix_persistent_rows(ctx, name, d):
+    """The persistent-row kernel of the fit (cov_rows_impl.h: n >= 4096, m >= 256, one stationary leaf over all
+    d <= 64 columns) with its straight-line sqrt / exp: ragged last row block and last centre tile, coincident
+    points, and distances from 0 to far beyond the length scale (exp underflow), all three k-step variants."""
+    from mellon_amd import cov
+    n, m = 4500, 300
+    rng = np.random.default_rng(d)
+    x = rng.normal(size=(n, d)) * 1.5
+    y = rng.normal(size=(m, d)) * 1.5
+    y[:100] = x[:100]                                   # coincident points: the +1e-12 branch
+    x[200:260] *= 400.0                                 # r >> 1: e^-r underflows
+    y[250:] = x[300:350] + 1e-3 * rng.normal(size=(50, d))   # r << 1
+    ls = 1.7 * np.sqrt(d / 8.0)                         # typical pair distances of a few length scales at every d
+    c = getattr(cov, name)(2.0, ls) if name == "RatQuad" else getattr(cov, name)(ls)
+    K = c(x, y)
+    ref = _pair(c)(x, y)
+    # (near-)coincident pairs: the cancellation in xx - 2xy + yy, not the sqrt / exp code, sets the error there
+    # (see test_kernel_matrix_leaves)
+    co = mo.distance(x, y) < 0.05
+    assert co.sum() >= 150
+    assert np.all(np.isfinite(K))
+    assert np.abs(K - ref)[~co].max() < 1e-12
+    assert np.abs(K - ref)[co].max() < 1e-6
+    big = (ref > 1e-3) & ~co
+    assert big.sum() > 10000
+    assert (np.abs(K - ref)[big] / ref[big]).max() < 1e-11       # (summation order of the d-term dot products differs)
