@@ -184,19 +184,23 @@ class BaseEstimator:
                 and fit.m > self.rank * RANK_FRACTION_THRESHOLD * n_landmarks:          # base_model.py:333-342
             logger.warning(f"Shallow rank reduction from {n_landmarks:,} to {fit.m:,} indicates underrepresentation "
                            "by landmarks. Consider increasing n_landmarks!")
-        if self.check_rank:                                                              # base_model.py:344-355
+        # base_model.py:344-355: on request, or automatically for a sparse-Cholesky fit with more than 10 cells per
+        # landmark.  Log-only in the reference too (an n x m SVD there; here the m x m Gram over all cells of all ranks
+        # and its eigenvalues on the device: ~3 s at 1e6 x 5000, so timed runs pass check_rank=False).
+        if self.check_rank or (self.check_rank is None and self.gp_type == GaussianProcessType.SPARSE_CHOLESKY
+                               and SAMPLE_LANDMARK_RATIO * n_landmarks < self._n_cells_global()):
             from .util import test_rank
             logger.info(f"Estimating approximation accuracy since {n_samples:,} samples are more than "
                         f"{SAMPLE_LANDMARK_RATIO} x {n_landmarks:,} landmarks.")
             test_rank(FactorL(fit), threshold=RANK_FRACTION_THRESHOLD)
-        elif (self.check_rank is None and self.gp_type == GaussianProcessType.SPARSE_CHOLESKY
-                and SAMPLE_LANDMARK_RATIO * n_landmarks < n_samples):
-            logger.info("Rank diagnostic (matrix_rank of L; log only in the reference, base_model.py:344-355) is run "
-                        "on request only (check_rank=True): an n m^2 Gram and an m x m eigensolve that change no "
-                        "result.")
         logger.info(f"Using rank {fit.m:,} covariance representation.")
         return FactorLp(fit) if self.gp_type == GaussianProcessType.FULL and fit.m == fit.n and \
             getattr(fit, "_has_lp", True) else FactorL(fit)
+
+    def _n_cells_global(self):
+        """Cells over all ranks (the rank diagnostic's trigger must be the same decision on every rank)."""
+        from .distributed import current
+        return current().global_count(self.x.shape[0])
 
     def validate_parameter(self):
         validate_params(self.rank, self.gp_type, self.x.shape[0], self.n_landmarks, self.landmarks)

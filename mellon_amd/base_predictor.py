@@ -208,7 +208,10 @@ class Predictor:
     def __setstate__(self, state):
         for name, value in state["data"].items():
             setattr(self, name, deserialize(value))
-        self._state_variables = set(self._state_variables)
+        # files written by mellon 1.3.1 carry neither `_state_variables` nor `n_obs` (tests/test_density_estimator.py:
+        # 139-151): every other entry of "data" is then a state variable, and n_obs stays None (normalize=True raises)
+        meta = {"n_input_features", "n_obs", "d", "d_method", "_state_variables"}
+        self._state_variables = set(getattr(self, "_state_variables", None) or (set(state["data"]) - meta))
         self.cov_func = Covariance.from_dict(state["cov_func"])
         for k in (self._center_name, "weights", "L", "W"):
             if getattr(self, k, None) is not None:

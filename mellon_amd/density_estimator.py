@@ -85,7 +85,9 @@ class DensityEstimator(BaseEstimator):
         return compute_mu(self.nn_distances, self.d)
 
     def _compute_initial_value(self):
-        return compute_initial_value(self.nn_distances, self.d, self.mu, self.L,
+        # lbfgsb_options = "reference": the reference's exact Ridge on all cells is part of "as run"
+        exact = isinstance(self.lbfgsb_options, str) and self.lbfgsb_options == "reference"
+        return compute_initial_value(self.nn_distances, self.d, self.mu, self.L, row_stride=1 if exact else None,
                                      target=getattr(self, "_ridge_target", None))
 
     def _compute_transform(self):

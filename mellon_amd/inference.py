@@ -119,14 +119,19 @@ def compute_loss_func(nn_distances, d, transform, k, constants=None):
 
 
 def minimize_lbfgsb(loss_func, initial_value, jit=DEFAULT_JIT, options=None):
-    """inference.py:272-288.  `options` overrides LBFGSB_OPTIONS (pass REFERENCE_LBFGSB_OPTIONS for
-    the reference's looser stopping rule)."""
+    """inference.py:272-288.  `options` overrides LBFGSB_OPTIONS.  options="reference" runs the reference AS RUN:
+    SciPy's L-BFGS-B (the routine behind jaxopt.ScipyMinimize) with its default stopping rule (ftol 2.2e-9, gtol 1e-5,
+    maxcor 10, maxiter 500) on the un-preconditioned variable z, every evaluation one device pass -- the early-stopped
+    answer of the reference (~5e-5 from the optimum) instead of the optimum."""
+    reference_mode = isinstance(options, str) and options == "reference"
     opts = dict(LBFGSB_OPTIONS)
-    if options:
+    if reference_mode:
+        opts = dict(REFERENCE_LBFGSB_OPTIONS)
+    elif options:
         opts.update(options)
     Results = namedtuple("Results", "pre_transformation opt_state loss")
     z0 = np.asarray(initial_value, dtype=np.float64)
-    if getattr(loss_func, "preconditioned", False):
+    if getattr(loss_func, "preconditioned", False) and not reference_mode:
         # Same method, same objective, better-conditioned variable: z = C^-T u with
         # C C^T ~ L^T L + I (the Ridge matrix = the MAP Hessian where e^{f+V} = 1).  The optimum is
         # unique (strict convexity), so this only changes how many passes over L it takes (~10x fewer).

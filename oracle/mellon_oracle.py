@@ -171,6 +171,43 @@ class Covariance:
         return obj
 
 
+def _serialize(v):
+    """util.py:69-92: arrays -> {"type": "jax.numpy", "data": nested lists}, slices, dicts and sets tagged, NumPy
+    scalars -> Python scalars, None -> the string "None"."""
+    if isinstance(v, np.ndarray):
+        return {"type": "jax.numpy", "data": v.tolist()}
+    if isinstance(v, np.integer):
+        return int(v)
+    if isinstance(v, np.floating):
+        return float(v)
+    if isinstance(v, slice):
+        return {"type": "slice", "data": ["None" if q is None else q for q in (v.start, v.stop, v.step)]}
+    if isinstance(v, dict):
+        return {"type": "dict", "data": {k: _serialize(q) for k, q in v.items()}}
+    if isinstance(v, set):
+        return {"type": "set", "data": [_serialize(q) for q in v]}
+    return "None" if v is None else v
+
+
+def _metadata(classname, module_name):
+    import datetime
+    import sys
+    return {"classname": classname, "module_name": module_name, "module_version": "1.7.1",
+            "serialization_date": datetime.datetime.now().isoformat(), "python_version": sys.version}
+
+
+def covariance_to_dict(c):
+    """base_cov.py:122-160 (leaves: every attribute under "data") and :244-272 (Add / Mul / Pow: left_data,
+    right_data -- a covariance state or a serialised scalar -- and active_dims)."""
+    if isinstance(c, _Pair):
+        right = covariance_to_dict(c.right) if callable(c.right) else _serialize(c.right)
+        return {"type": "mellon.Covariance", "left_data": covariance_to_dict(c.left), "right_data": right,
+                "active_dims": _serialize(getattr(c, "active_dims", None)),
+                "metadata": _metadata(type(c).__name__, "mellon")}
+    return {"type": "mellon.Covariance", "data": {k: _serialize(v) for k, v in c.__dict__.items()},
+            "metadata": _metadata(type(c).__name__, "mellon.cov")}
+
+
 def _deserialize(v):
     """util.py:95-132: tagged dicts for arrays / slices, the string "None" for None."""
     if isinstance(v, dict):
@@ -717,6 +754,30 @@ class Predictor:
         return out
 
     mean = __call__
+
+    # -- wire format of base_predictor.py:541-595 (only what the mean needs) -----------------------------------------
+    def to_dict(self, classname="LandmarksConditionalCholesky", center_name="landmarks", d=None, d_method=None):
+        """__getstate__: every name of `_state_variables` plus n_input_features, n_obs, d, d_method and the set itself
+        under "data", the covariance state, the metadata block.  center_name: "landmarks" (conditional.py:839-841) or
+        "x" (:276-278)."""
+        names = {center_name, "weights", "mu", "jitter", "sigma", "per_feature_sigma"}
+        vals = {center_name: self.centers, "weights": self.weights, "mu": self.mu, "jitter": DEFAULT_JITTER,
+                "sigma": None, "per_feature_sigma": False, "n_input_features": self.n_input_features,
+                "n_obs": self.n_obs, "d": d, "d_method": d_method, "_state_variables": names}
+        return {"data": {k: _serialize(v) for k, v in vals.items()}, "cov_func": covariance_to_dict(self.cov_func),
+                "metadata": _metadata(classname, "mellon.conditional")}
+
+    @staticmethod
+    def from_dict(state):
+        """__setstate__ (base_predictor.py:583-595): every entry of "data" becomes an attribute; the covariance comes
+        from "cov_func".  States written by mellon 1.3.1 carry neither n_obs nor _state_variables
+        (tests/test_density_estimator.py:139-151)."""
+        data = {k: _deserialize(v) for k, v in state["data"].items()}
+        centers = data["landmarks"] if "landmarks" in data else data["x"]
+        p = Predictor(Covariance.from_dict(state["cov_func"]), np.asarray(centers, dtype=np.float64),
+                      np.asarray(data["weights"], dtype=np.float64), data["mu"], data.get("n_obs"))
+        p.d, p.d_method = data.get("d"), data.get("d_method")
+        return p
 
     def gradient(self, Xnew, h=None):
         """base_predictor.py:490-505: d mean / d x per row.  The reference uses jax.jacrev of `_mean`;

@@ -959,3 +959,137 @@ def test_normalize_per_time_point(mellon, kind):
             mellon.TimeSensitiveDensityEstimator(n_landmarks=30, ls_time=1.0,
                                                  normalize_per_time_point=np.array(bad) if kind == "array" else bad
                                                  ).fit(X, times)
+
+
+@pytest.mark.gpu
+def test_c4_shaped_against_oracle(mellon):
+    """BASELINE config 4 shape at a size the oracle finishes in seconds: product kernel
+    Matern52(ls, :-1) * Matern52(ls_time, -1) (parameters.py:641-644), 4 time points, 1000 landmarks."""
+    rng = np.random.default_rng(44)
+    n_per, d, T, m = 1500, 6, 4, 1000
+    xs = np.concatenate([mo.gaussian_mixture(n_per, d, seed=40 + t) + 0.3 * t for t in range(T)])
+    times = np.repeat(np.arange(float(T)), n_per)
+    xt = np.ascontiguousarray(np.column_stack([xs, times]))
+    nn = mo.per_time_nn_distances(xs, times)
+    ls, ls_time = mo.compute_ls(nn), 1.5
+    sub = xt.copy()
+    sub[:, -1] *= ls / ls_time
+    lm = mo.compute_landmarks(sub, mo.SPARSE_CHOLESKY, m, 42)
+    lm[:, -1] /= ls / ls_time
+    ref = mo.density_fit(xt, landmarks=lm, nn_distances=nn, ls_time=ls_time, lbfgsb_options=mo.LBFGSB_TIGHT)
+    est = mellon.TimeSensitiveDensityEstimator(landmarks=lm, nn_distances=nn, ls_time=ls_time)
+    dens = est.fit_predict(xs, times)
+    assert abs(est.mu - ref.mu) < 1e-10 and abs(est.ls - ref.ls) < 1e-10 * ref.ls
+    assert rel_std(dens, ref.log_density_x) < 1e-5 and rel_max(dens, ref.log_density_x) < 1e-5
+    q = np.column_stack([xs[::7] + 0.05 * rng.normal(size=xs[::7].shape), times[::7]])
+    assert rel_max(est.predict(q), ref.predict(q)) < 1e-5
+    assert rel_max(est.predict(q[:, :-1], q[:, -1]), ref.predict(q)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_c5_shaped_against_oracle(mellon):
+    """BASELINE config 5 shape: FunctionEstimator with p = 250 outputs, scalar sigma, landmark conditional
+    (conditional.py:513-547 + _sparse_solve :57-66), batched predict on Xnew = X."""
+    rng = np.random.default_rng(55)
+    n, d, m, p = 6000, 12, 400, 250
+    x = mo.gaussian_mixture(n, d, seed=5)
+    W = rng.normal(size=(d, p)) / np.sqrt(d)
+    y = np.sin(x @ W) + 0.1 * rng.normal(size=(n, p))
+    nn = mo.exact_nn_distances(x)
+    lm = mo.compute_landmarks(x, mo.SPARSE_CHOLESKY, m, 42)
+    ref = mo.function_fit(x, y, 0.1, landmarks=lm, nn_distances=nn)
+    est = mellon.FunctionEstimator(sigma=0.1, landmarks=lm, nn_distances=nn)
+    pred = est.fit_predict(x, y, x)
+    want = ref(x) if callable(ref) else ref.predict(x)
+    assert pred.shape == (n, p)
+    assert rel_max(pred, want) < 1e-7
+
+
+@pytest.mark.gpu
+def test_reference_as_run_stopping_rule(mellon):
+    """The reference AS RUN (inference.py:272-288: SciPy L-BFGS-B at its default ftol 2.2e-9 / gtol 1e-5 / maxcor 10 /
+    maxiter 500 on z, from the exact Ridge start): `lbfgsb_options = "reference"` drives the same SciPy routine over
+    the device objective.  Measured here, C2-shaped: product-default (the optimum) vs oracle-default (early stopped) is
+    the ~5e-5 the design note quotes; reference-mode vs oracle-default is the reproducibility floor of an
+    early-stopped run (two roundings of the same objective), an order of magnitude closer."""
+    n, d, m = 20000, 20, 500
+    x = mo.gaussian_mixture(n, d, seed=2)
+    nn = mo.exact_nn_distances(x)
+    lm = mo.compute_landmarks(x[:5000], mo.SPARSE_CHOLESKY, m, 42)
+    loose = mo.density_fit(x, cov_func_curry=mo.ExpQuad, landmarks=lm, nn_distances=nn)              # reference defaults
+    tight = mo.density_fit(x, cov_func_curry=mo.ExpQuad, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    est = mellon.DensityEstimator(cov_func_curry=mellon.cov.ExpQuad, landmarks=lm, nn_distances=nn)
+    dens = est.fit_predict(x)
+    as_run = mellon.DensityEstimator(cov_func_curry=mellon.cov.ExpQuad, landmarks=lm, nn_distances=nn)
+    as_run.lbfgsb_options = "reference"
+    dens_run = as_run.fit_predict(x)
+    # the exact Ridge start of the reference (not the subsampled one of the default route)
+    assert rel_max(as_run.initial_value, loose.initial_value) < 1e-4     # (5e-6: the K-space Gram amplifies rounding by cond(Lp)^2)
+    d_opt_vs_ref = rel_max(dens, loose.log_density_x)            # optimum vs the reference's early-stopped answer
+    d_run_vs_ref = rel_max(dens_run, loose.log_density_x)        # reference mode vs the reference's answer
+    d_opt = rel_max(dens, tight.log_density_x)
+    print(f"product-default vs oracle-default {d_opt_vs_ref:.2e}; reference-mode vs oracle-default {d_run_vs_ref:.2e}; "
+          f"product-default vs optimum {d_opt:.2e}; evaluations: reference mode {as_run.loss_func.n_eval}, "
+          f"oracle default {loose.n_eval}")
+    # the reference's early-stopped run against ITSELF from a start perturbed at rounding level
+    pert = mo.density_fit(x, cov_func_curry=mo.ExpQuad, landmarks=lm, nn_distances=nn,
+                          initial_value=loose.initial_value * (1 + 1e-13 * np.random.default_rng(0).normal(size=m)))
+    d_self = rel_max(pert.log_density_x, loose.log_density_x)
+    # measured (tools/reference_mode_check.py, profiles/r02_reference_mode.json): optimum 1.3e-8; reference default 6.3e-5
+    # from the optimum and 9.9e-5 from its own perturbed rerun; reference mode 6.1e-5 from the reference default
+    assert d_opt < 1e-6                                          # the product's default is the optimum
+    assert 1e-6 < d_opt_vs_ref < 1e-3                            # the reference as run stops short of it
+    assert d_self > 1e-6                                         # ... and is not reproducible to 1e-5 against itself
+    assert d_run_vs_ref < 3e-4                                   # reference mode lands where reference runs land
+    assert d_run_vs_ref < 3 * max(d_self, d_opt_vs_ref)
+    assert abs(as_run.loss_func.n_eval - loose.n_eval) <= max(20, 0.25 * loose.n_eval)
+
+
+@pytest.mark.gpu
+def test_predictor_json_interop_with_reference_wire_format(mellon, small_x, tmp_path):
+    """base_predictor.py:541-734 / docs serialization: a predictor written by the product is read by the oracle's
+    restatement of the reference's __setstate__ and evaluates to the same numbers; a state written in the reference's
+    format (oracle) is read by the product, including the shape mellon 1.3.1 wrote -- no n_obs, no _state_variables
+    (tests/test_density_estimator.py:139-151)."""
+    import json
+    est = mellon.DensityEstimator(n_landmarks=25).fit(small_x)
+    pred = est.predict
+    want = pred(small_x)
+    state = json.loads(pred.to_json())
+    assert state["metadata"]["classname"] == "LandmarksConditionalCholesky"
+    assert state["metadata"]["module_name"] == "mellon.conditional"
+    assert state["data"]["landmarks"]["type"] == "jax.numpy" and state["cov_func"]["type"] == "mellon.Covariance"
+    assert set(state["data"]["_state_variables"]["data"]) >= {"landmarks", "weights", "mu"}
+    # product -> reference format reader
+    op = mo.Predictor.from_dict(state)
+    np.testing.assert_allclose(op(small_x), want, rtol=1e-10)
+    np.testing.assert_allclose(op(small_x, normalize=True), pred(small_x, normalize=True), rtol=1e-10)
+    # reference format writer -> product
+    ostate = json.loads(json.dumps(op.to_dict(d=est.d, d_method=est.d_method)))
+    back = mellon.Predictor.from_dict(ostate)
+    np.testing.assert_allclose(back(small_x), want, rtol=1e-10)
+    assert back.n_obs == small_x.shape[0]
+    # the 1.3.1 shape
+    old = json.loads(json.dumps(ostate))
+    old["metadata"]["module_version"] = "1.3.1"
+    old["data"].pop("n_obs")
+    old["data"].pop("_state_variables")
+    legacy = mellon.Predictor.from_dict(old)
+    np.testing.assert_allclose(legacy(small_x), want, rtol=1e-10)
+    with pytest.raises(ValueError):
+        legacy(small_x, normalize=True)                       # no n_obs in a 1.3.1 file (base_predictor.py:246-252)
+    # files, compressed and not
+    for comp, name in ((None, "p.json"), ("gzip", "p.json.gz"), ("bz2", "p.json.bz2")):
+        pred.to_json(str(tmp_path / "p.json"), compress=comp)
+        again = mellon.Predictor.from_json(str(tmp_path / name))
+        np.testing.assert_allclose(again(small_x), want, rtol=1e-12)
+        assert np.allclose(mo.Predictor.from_dict(again.to_dict())(small_x), want, rtol=1e-10)
+    # the time-sensitive product kernel through the same path
+    tt = np.repeat([0.0, 1.0], small_x.shape[0] // 2)
+    xs = small_x[: tt.size]
+    test = mellon.TimeSensitiveDensityEstimator(n_landmarks=20, ls_time=1.0).fit(xs, tt)
+    st = json.loads(test.predict.to_json())
+    assert st["metadata"]["classname"] == "LandmarksConditionalCholeskyTime"
+    ot = mo.Predictor.from_dict(st)
+    q = np.column_stack([xs, tt])
+    np.testing.assert_allclose(ot(q), test.predict(q), rtol=1e-10)
