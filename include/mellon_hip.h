@@ -250,7 +250,7 @@ int mln_objective(mln_fit* fit, const double* z, double* loss, double* grad /* m
  * status: 0 converged, 1 maxiter, 2 line search failed.                                         */
 typedef struct {
   int32_t maxiter; /* 5000  */
-  int32_t maxcor;  /* 30    L-BFGS memory            */
+  int32_t maxcor;  /* 10    L-BFGS memory (<= 64)    */
   int32_t maxls;   /* 30    line-search evaluations  */
   double ftol;     /* 1e-13 (SciPy default 2.2e-9 leaves the log-density ~5e-5 off the optimum) */
   double gtol;     /* 1e-7  on the preconditioned gradient */

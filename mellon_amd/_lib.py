@@ -653,7 +653,7 @@ class Fit:
                                                        z.ctypes.data), jitter="ridge")
         return loss.value, grad, z
 
-    def map_solve(self, z0, maxiter=5000, maxcor=30, maxls=30, ftol=1e-13, gtol=1e-7):
+    def map_solve(self, z0, maxiter=5000, maxcor=10, maxls=30, ftol=1e-13, gtol=1e-7):
         """In-library L-BFGS on the preconditioned variable; returns (z, loss, n_eval, n_iter, status)."""
         z0 = _f64(z0)
         opts = SolverOpts(int(maxiter), int(maxcor), int(maxls), float(ftol), float(gtol))

@@ -959,6 +959,23 @@ static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
   // |Lp^-1|^2, which would matter for a quantity that enters the result; as a preconditioner the
   // outcome is spectrally equivalent to the row-solved Gram within 1e-3 (measured), at none of the
   // n_s m^2 triangular-solve flops.
+  // With many ranks the sampled rows are few per rank (~12 m / N) while the two m x m block solves are replicated:
+  // from N = 7 on it is cheaper for every rank to whiten ITS rows first, L_s = K_s Lp^-T (rows x m^2 flops, < 2 m^3),
+  // and to all-reduce the Gram of those -- the explicit route's arithmetic, no replicated solve, same single
+  // collective.  (The choice depends on the rank count only, so every rank takes the same branch.)
+  static const int row_solve_from = std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS")) : 7;
+  if (ctx->n_ranks >= row_solve_from && row_solve_from > 0) {
+    double* R = nullptr;
+    const int64_t rr = rows > 0 ? rows : 1;
+    MLN_HIP(ctx, mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl));
+    int rc = MLN_OK;
+    if (rows > 0) rc = launch_copy_block(ctx, Ls, f->ldl * row_stride, R, f->ldl, rows, f->ldl);
+    if (rc == MLN_OK && rows > 0) rc = triinv_solve_right_T(ctx, f->tri, R, rows, f->ldl);
+    if (rc == MLN_OK) rc = gram_of(ctx, R, f->ldl, rows, f->m, (double)row_stride, G, ldg);   // all-reduced
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)mln_dfree(R);
+    return rc;
+  }
   int rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);   // all-reduced
   double* T = nullptr;
   if (rc == MLN_OK) {
@@ -1244,7 +1261,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   MLN_TRY(fit_build_precond(f, 1));
-  mln_solver_opts o = {5000, 30, 30, 1e-13, 1e-7};
+  mln_solver_opts o = {5000, 10, 30, 1e-13, 1e-7};
   if (opts_in) o = *opts_in;
   if (o.maxcor < 1) o.maxcor = 1;
   if (o.maxcor > 64) o.maxcor = 64;

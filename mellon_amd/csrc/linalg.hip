@@ -297,6 +297,25 @@ int triinv_build(mln_ctx* ctx, const double* Lf, int64_t m, int64_t ld, bool nee
 // X (n x m, in place) <- X Lf^-T, left-looking over 128-wide block columns:
 //   X_j <- [X_<j | X_j] W_j^T      (decomposition.py:209:  L = solve_triangular(Lp, C.T, lower=True).T)
 int triinv_solve_right_T(mln_ctx* ctx, const TriInv& t, double* X, int64_t n, int64_t ldx) {
+  if (n < 32768 && t.W && t.W2 && t.m > TB) {
+    // Few rows (the per-rank Gram sample of a many-rank run): the left-looking form would give each of the n / 128
+    // row tiles one workgroup with a K loop of up to m -- serial work of ~0.5 ms per launch, 40 launches.  Right-
+    // looking with the diagonal blocks factored out (see triinv_solve_left): B_i += B~_j W2[i,j]^T for i > j is an
+    // n x (m - j) x 128 product on many tiles, and X = B~ blockdiag(Dinv^T) is one launch at the end.
+    for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
+      const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
+      const int64_t rem = t.m - j0 - nb;
+      if (rem <= 0) break;
+      GemmArgs u{};
+      u.A = X + j0; u.lda = ldx; u.B = t.W2 + (j0 + nb) * t.ld + j0; u.ldb = t.ld; u.C = X + j0 + nb; u.ldc = ldx;
+      u.M = n; u.N = rem; u.K = nb; u.alpha = 1.0; u.beta = 1.0; u.ta = 0; u.tb = 1;
+      MLN_TRY(launch_dgemm(ctx, u));
+    }
+    GemmArgs g{};   // in place: tile (i, j) reads columns of block j of its own rows only
+    g.A = X; g.lda = ldx; g.B = t.W; g.ldb = t.ld; g.C = X; g.ldc = ldx;
+    g.M = n; g.N = t.m; g.K = t.m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1; g.kmode = 2;
+    return launch_dgemm(ctx, g);
+  }
   for (int64_t j0 = 0; j0 < t.m; j0 += TB) {
     const int64_t nb = (t.m - j0 < TB) ? (t.m - j0) : TB;
     GemmArgs g{};

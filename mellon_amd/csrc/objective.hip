@@ -475,11 +475,25 @@ __global__ __launch_bounds__(256) void k_gemv_rows_tri(GemvTri g) {
     const double* __restrict__ xb = g.x + sg * g.xseg;
     const d2* __restrict__ row = reinterpret_cast<const d2*>(rb);
     const d2* __restrict__ xv = reinterpret_cast<const d2*>(xb);
-    for (int64_t p = c_lo / 2 + lane; 2 * p + 1 < c_hi; p += 64) {
+    // four 16-byte loads per lane in flight (a single one per iteration left the row at ~2 TB/s: latency-bound)
+    int64_t p = c_lo / 2 + lane;
+    const int64_t p_end = c_hi / 2;            // pairs [p, p_end) are complete
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
+    for (; p + 192 < p_end; p += 256) {
+      const d2 a0 = row[p], a1 = row[p + 64], a2 = row[p + 128], a3 = row[p + 192];
+      const d2 b0 = xv[p], b1 = xv[p + 64], b2 = xv[p + 128], b3 = xv[p + 192];
+      s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
+      t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
+      t2 = fma(a2.x, b2.x, t2); t3 = fma(a2.y, b2.y, t3);
+      t4 = fma(a3.x, b3.x, t4); t5 = fma(a3.y, b3.y, t5);
+    }
+    for (; p < p_end; p += 64) {
       const d2 a = row[p], b = xv[p];
       s0 = fma(a.x, b.x, s0);
       s1 = fma(a.y, b.y, s1);
     }
+    s0 += (t0 + t2) + t4;
+    s1 += (t1 + t3) + t5;
     if ((c_hi & 1) && lane == 0) s0 = fma(rb[c_hi - 1], xb[c_hi - 1], s0);
   }
   double s = s0 + s1;

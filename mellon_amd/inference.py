@@ -31,9 +31,10 @@ DEFAULT_JIT = False
 # unique.  The reference stops L-BFGS-B at SciPy's defaults (ftol 2.2e-9, gtol 1e-5, maxcor 10,
 # maxiter 500), which leaves the log-density ~5e-5 (relative) short of that optimum and makes its
 # output irreproducible below ~1e-4 across BLAS roundings (tests/test_oracle.py).  To honour
-# "log-density within 1e-5" we converge to the optimum instead: a longer L-BFGS memory and
-# tighter stopping rule reach ~3e-7 in about as many evaluations as the reference's defaults use.
-LBFGSB_OPTIONS = dict(maxiter=5000, maxfun=50000, maxcor=30, ftol=1e-13, gtol=1e-7)
+# "log-density within 1e-5" we converge to the optimum instead: SciPy's memory of 10 pairs (on the
+# preconditioned variable 7 ... 30 pairs all need 46-49 passes at C3, tools/maxcor_sweep.py) and a tighter
+# stopping rule reach ~3e-7 in far fewer evaluations than the reference's defaults use.
+LBFGSB_OPTIONS = dict(maxiter=5000, maxfun=50000, maxcor=10, ftol=1e-13, gtol=1e-7)
 REFERENCE_LBFGSB_OPTIONS = dict(maxiter=500)     # jaxopt.ScipyMinimize defaults
 
 

@@ -1,0 +1,63 @@
+"""What ONE rank of an N-rank strong-scaling run of C3 computes, timed on one GPU: rank 0's shard (1e6 / N cells), the
+Gram sample stride of the GLOBAL problem, everything replicated (landmark factorisations, preconditioner, the
+optimiser) in full.  The collectives are absent (one process): their cost is modelled separately in DESIGN.md S5.
+
+    python tools/emulate_rank.py 1 2 4 8 > profiles/rNN_emulated_ranks.json   (N >= 7 whitens the sampled rows per rank, like the real run)
+"""
+import gc, json, os, sys, time
+if any(a.isdigit() and int(a) >= 7 for a in sys.argv[1:]) and len(sys.argv) == 2:
+    os.environ['MELLON_AMD_GRAM_ROWSOLVE_RANKS'] = '1'      # the library picks this route from the rank count (>= 7)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench, mellon_amd
+from mellon_amd import _lib, distributed
+
+
+class OneOfN(distributed.Communicator):
+    def __init__(self, n_ranks):
+        self.n_ranks = n_ranks
+
+    def global_count(self, n_local):
+        return int(n_local) * self.n_ranks
+
+    def global_offset(self, n_local):
+        return 0, int(n_local) * self.n_ranks
+
+
+ctx = _lib.default_context()
+n, d, m = 1_000_000, 50, 5000
+x = bench.gaussian_mixture(n, d, 3)
+lm, _ = bench.make_landmarks(x, m, "device", ctx)
+xd = ctx.to_device(x)
+nn = ctx.nn_distances(xd, xd)
+out = {}
+for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    distributed.set_current(OneOfN(N))
+    lo, hi = distributed.shard_bounds(n, N, 0)
+    xs = ctx.to_device(x[lo:hi])
+    best = None
+    for rep in range(4):
+        t0 = time.perf_counter()
+        est = mellon_amd.DensityEstimator(landmarks=lm, nn_distances=nn[lo:hi], check_rank=False)
+        dens = est.fit_predict(xs)
+        dt = time.perf_counter() - t0
+        st = est._fit.stage_times()
+        ev = est.loss_func.n_eval
+        est._fit.close()
+        del est
+        if rep > 0 and (best is None or dt < best[0]):
+            best = (dt, st, ev)
+    dt, st, ev = best
+    n32, n64 = st["objective32_launches"], st["objective_launches"]
+    out[str(N)] = {"cells_on_this_rank": hi - lo, "step_ms": 1e3 * dt, "evaluations": ev,
+                   "objective_kernels_ms": 1e3 * (st["objective_kernel_s"] + st["objective32_kernel_s"]),
+                   "fp32_pass_ms": 1e3 * st["objective32_kernel_s"] / max(n32, 1), "fp64_pass_ms": 1e3 * st["objective_kernel_s"] / max(n64, 1),
+                   "kernel_matrix_ms": 1e3 * st["kernel_matrix_s"], "chol_Lp_ms": 1e3 * st["cholesky_s"],
+                   "gram_and_solves_ms": 1e3 * st["ridge_gram_s"], "chol_C_inverses_ms": 1e3 * st["ridge_solve_s"]}
+    xs.free()
+    gc.collect()
+distributed.set_current(distributed.Communicator())
+one = out.get("1", {}).get("step_ms")
+for k, v in out.items():
+    v["speedup_without_communication"] = None if not one else one / v["step_ms"]
+print(json.dumps(out, indent=1))
