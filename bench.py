@@ -295,8 +295,9 @@ def main():
         "metric": "cells/sec fit_predict", "value": value, "unit": "cells/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None,
-        "dtype": (f"f64 results; {int(n32)} of {int(n_eval)} passes stream an fp32 copy of K (4 B/element), "
-                  f"{n64} the fp64 buffer -- pure-fp64 step: ms_per_step_fp64_only") if n32 > 0 else "f64",
+        "dtype": (f"f64 results; {int(n32)} of {int(n_eval)} passes stream a 32-bit copy of K (4 B/element: "
+                  + ("fixed point round(K 2^32)" if stats.get("copy32_format") == 2.0 else "fp32")
+                  + f"), {n64} the fp64 buffer -- pure-fp64 step: ms_per_step_fp64_only") if n32 > 0 else "f64",
         "data": "synthetic",
         **extra,
         "config": {"workload": f"C3 DensityEstimator.fit_predict: {n_total} cells x {d} dims Gaussian mixture "
@@ -317,7 +318,7 @@ def main():
                      "algorithmic_bytes_per_launch": stats["objective_bytes_per_launch"],
                      "avg_launch_ms": 1e3 * per_launch, "launches": n64,
                      "share_of_step": stats["objective_kernel_s"] / (elapsed / args.steps) if world == 1 else None},
-        "roofline_fp32_passes": {"bound": "hbm", "kernel": "k_objective32 (same pass over the fp32 copy of K: warm-up "
+        "roofline_fp32_passes": {"bound": "hbm", "kernel": "k_objective32 (same pass over the 32-bit copy of K: warm-up "
                                  "iterations of the MAP solve)", "achieved": ach32, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach32 / HBM_PEAK_GBS, "traffic": traffic32,
                                  "algorithmic_bytes_per_launch": bytes32, "avg_launch_ms": 1e3 * per_launch32,

@@ -159,8 +159,10 @@ int mln_trsm_lower(mln_ctx* ctx, const double* Lf, int64_t m, int32_t trans, dou
 #define MLN_FIT_IMPLICIT 1 /* flags: keep K = cov(x,xu) in the n x m buffer and fold Lp^-T into the
                              m-vectors (L z = K (Lp^-T z), L^T v = Lp^-1 (K^T v)): no n x m triangular
                              solve; mln_fit_get_L materialises rows on demand; no Hessian diagonal.
-                             For n_local * m >= 2^27 the kernel-matrix pass also keeps an fp32 copy of K
-                             (n_local x ld x 4 bytes) for the warm-up passes of mln_map_solve; environment
+                             For n_local * m >= 2^27 the kernel-matrix pass also keeps a 32-bit copy of K
+                             (n_local x ld x 4 bytes: fixed point round(v 2^32) when the covariance is a stationary
+                             kernel or a product of such, i.e. bounded by 1; fp32 otherwise) for the warm-up passes of
+                             mln_map_solve, which finishes on the fp64 buffer at the same tolerances; environment
                              MELLON_AMD_MIXED=0 disables, MELLON_AMD_MIXED_MIN_ELEMS moves the threshold. */
 int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n_local,
                     int32_t d, const double* xu, int64_t m, double jitter, const double* Lp_in,
@@ -343,9 +345,10 @@ int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const 
 /* wall-clock seconds of the stages of the last mln_fit_prepare / mln_ridge_init and counters
  * of mln_objective: [0] kernel matrix, [1] cholesky, [2] trsm, [3] ridge gram, [4] ridge solve,
  * [5] objective kernel time (sum, HIP events), [6] objective launches, [7] bytes of L streamed
- * per objective launch; [8] / [9] the same time / launch count for the fp32 warm-up passes of
- * mln_map_solve (mixed precision: they stream 4 bytes per element, half of [7]).                */
-#define MLN_N_STAGE_TIMES 10
+ * per objective launch; [8] / [9] the same time / launch count for the warm-up passes of mln_map_solve on the
+ * 32-bit copy (mixed precision: they stream 4 bytes per element, half of [7]); [10] the format of that copy:
+ * 0 none, 1 fp32 values, 2 32-bit fixed point round(v 2^32) (covariances bounded by 1); [11] reserved.            */
+#define MLN_N_STAGE_TIMES 12
 int mln_stage_times(mln_fit* fit, double* out /* MLN_N_STAGE_TIMES */);
 
 #ifdef __cplusplus

@@ -462,6 +462,7 @@ struct mln_fit {
   double* eigU = nullptr;
   // fp32 copy of the streamed n x m buffer for the warm-up passes of the MAP solve (mixed precision)
   float* L32 = nullptr;
+  int l32_fixed = 0;     // format of that copy: 0 = fp32, 1 = 32-bit fixed point (covariances bounded by 1)
   int evals32 = 0;
   double times32 = 0.0;
   // evaluation buffers of the preconditioned objective: d_zr = [z (ld2) | r (ld2)] with the likelihood sum at
@@ -588,7 +589,25 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
     if (const char* ev = std::getenv("MELLON_AMD_MIXED_MIN_ELEMS")) mixed_min = std::atoll(ev);
     if (mixed && n * m >= mixed_min && n > 0)
       MLN_HIP(ctx, mln_dmalloc((void**)&f->L32, sizeof(float) * (size_t)n * f->ldl));
-    MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0, f->L32));
+    // Format of the copy.  Covariance values of stationary kernels and of their products lie in [0, 1]: there the
+    // fixed-point number round(v 2^32) has an absolute error of 1.2e-10 for EVERY entry, where fp32 carries up to 3e-8
+    // on the entries near 1 -- which, with the nearest-neighbour length-scale heuristic, are most of them.  The
+    // surrogate objective then sits ~100x closer to the true one, and the solver can stay on the 4-byte stream for
+    // more of its iterations.  Sums, scalars, powers, the Linear kernel: fp32.  MELLON_AMD_SURROGATE=float|fixed overrides.
+    f->l32_fixed = 0;
+    if (f->L32) {
+      bool bounded = true;
+      for (int l = 0; l < f->cov.n_leaves; ++l)
+        bounded = bounded && f->cov.leaves[l].kind >= MLN_K_MATERN32 && f->cov.leaves[l].kind <= MLN_K_RATQUAD;
+      for (int t = 0; t < f->cov.n_toks; ++t)
+        bounded = bounded && (f->cov.tok_op[t] == MLN_OP_LEAF || f->cov.tok_op[t] == MLN_OP_MUL);
+      f->l32_fixed = bounded ? 1 : 0;
+      if (const char* ev = std::getenv("MELLON_AMD_SURROGATE")) {
+        if (std::strcmp(ev, "float") == 0) f->l32_fixed = 0;
+        else if (std::strcmp(ev, "fixed") == 0 && bounded) f->l32_fixed = 1;
+      }
+    }
+    MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0, f->L32, f->l32_fixed));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) fprintf(stderr, "[trace] L kernel matrix done at %.4f s\n", now_s() - t0);
     f->times[0] += now_s() - t0;
@@ -1122,7 +1141,8 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
     ObjArgs a = obj_args(f);
     a.weights = dt.dev;
     a.part_loss = nullptr;
-    a.L32 = f->L32;   // the Ridge solution only seeds the solve: its right-hand side may come from the fp32 copy
+    a.L32 = f->L32;   // the Ridge solution only seeds the solve: its right-hand side may come from the 32-bit copy
+    a.l32_fixed = f->l32_fixed;
     MLN_TRY(launch_objective(ctx, a));
     MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
     MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
@@ -1178,6 +1198,7 @@ static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, boo
   if (f->L32 && (gate || use32)) {
     ObjArgs a32 = a;
     a32.L32 = f->L32;
+    a32.l32_fixed = f->l32_fixed;
     a32.gate_want = MLN_GATE_F32;
     MLN_TRY(launch_objective(ctx, a32));
   }
@@ -1286,7 +1307,10 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.status = 1;
   init.maxiter = o.maxiter; init.maxcor = o.maxcor; init.maxls = o.maxls;
   init.m = (int)m;
-  init.ftol = o.ftol; init.gtol = o.gtol; init.ftol32 = 3e-6;
+  init.ftol = o.ftol; init.gtol = o.gtol;
+  // progress per iteration below which the 32-bit surrogate is left for the fp64 buffer (relative to the loss):
+  // the fp32 copy's optimum sits ~1e-5 (relative loss) from the true one, the fixed-point copy's ~1e-9
+  init.ftol32 = f->l32_fixed ? 1e-9 : 3e-6;
   if (const char* ev = std::getenv("MELLON_AMD_MIXED_FTOL")) init.ftol32 = std::atof(ev);
   init.prior_const = 0.5 * (double)m * std::log(2.0 * M_PI);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
@@ -1406,8 +1430,10 @@ extern "C" int mln_weights_full(mln_fit* f, const double* y, int64_t p, double m
 extern "C" int mln_stage_times(mln_fit* f, double* out) {
   if (!f || !out) return MLN_ERR_ARG;
   for (int i = 0; i < 8; ++i) out[i] = f->times[i];
-  out[8] = f->times32;                                  // fp32 warm-up passes: kernel seconds (HIP events)
-  out[9] = (double)f->evals32;                          //                      launches
+  out[8] = f->times32;                                  // 32-bit warm-up passes: kernel seconds (HIP events)
+  out[9] = (double)f->evals32;                          //                        launches
+  out[10] = f->L32 ? (f->l32_fixed ? 2.0 : 1.0) : 0.0;  //                        format of the copy
+  out[11] = 0.0;
   return MLN_OK;
 }
 

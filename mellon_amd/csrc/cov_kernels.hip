@@ -13,6 +13,7 @@
 #include "mln_internal.h"
 #include "cov_program.h"
 #include "cov_rows.h"
+#include "cov_rows_q.h"
 
 namespace {
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double*
                                                        const double* __restrict__ yy,
                                                        double* __restrict__ out, int64_t ldo,
                                                        double add_diag, int64_t tiles_n,
-                                                       float* __restrict__ out32) {
+                                                       float* __restrict__ out32, int q32) {
   __shared__ double xs[DK][TM + PADT];
   __shared__ double ys[DK][TN + PADT];
   const int64_t bid = blockIdx.x;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void k_kernel_matrix(DevCov cov, const double*
       const double v = (c < m) ? val[i][j] + ((r == c) ? add_diag : 0.0) : 0.0;
       if (c < ldo) {   // pad columns of the leading dimension stay zero
         out[r * ldo + c] = v;
-        if (out32) out32[r * ldo + c] = (float)v;   // fp32 copy for the warm-up passes of the MAP solve
+        if (out32) out32[r * ldo + c] = mln_surrogate_bits(v, q32);   // 32-bit copy for the warm-up passes of the MAP solve
       }
     }
   }
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void k_kernel_matrix_mfma(DevCov cov, const do
                                                             const double* __restrict__ xx,
                                                             const double* __restrict__ yy,
                                                             double* __restrict__ out, int64_t ldo, double add_diag,
-                                                            int64_t tiles_n, float* __restrict__ out32) {
+                                                            int64_t tiles_n, float* __restrict__ out32, int q32) {
   const DevLeaf lf = cov.leaves[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
   const int64_t bid = blockIdx.x;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void k_kernel_matrix_mfma(DevCov cov, const do
       if (row < n && c < ldo) {   // pad columns of the leading dimension stay zero
         const double v = (c < m) ? leaf_value(lf, xr[r], yc, acc[t][r]) + ((row == c) ? add_diag : 0.0) : 0.0;
         out[row * ldo + c] = v;
-        if (out32) out32[row * ldo + c] = (float)v;
+        if (out32) out32[row * ldo + c] = mln_surrogate_bits(v, q32);
       }
     }
   }
@@ -933,7 +934,7 @@ int sqnorms(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, 
 }  // namespace
 
 int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
-                         int64_t m, int d, double* out, int64_t ldo, double add_diag, float* out32) {
+                         int64_t m, int d, double* out, int64_t ldo, double add_diag, float* out32, int q32) {
   if (n == 0 || m == 0) return MLN_OK;
   double* norms = nullptr;
   MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)cov.n_leaves * (size_t)(n + m), (void**)&norms));
@@ -952,16 +953,16 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   static const bool no_rows = std::getenv("MELLON_AMD_KM_NO_ROWS") != nullptr;
   if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD) {
-    MLN_TRY(launch_kernel_matrix_rows(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32));
+    MLN_TRY(launch_kernel_matrix_rows_q(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32, q32));
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_kernel_matrix_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
-                       xx, yy, out, ldo, add_diag, tiles_n, out32);
+                       xx, yy, out, ldo, add_diag, tiles_n, out32, q32);
   else if (single)
     hipLaunchKernelGGL(k_kernel_matrix<true>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
-                       xx, yy, out, ldo, add_diag, tiles_n, out32);
+                       xx, yy, out, ldo, add_diag, tiles_n, out32, q32);
   else
     hipLaunchKernelGGL(k_kernel_matrix<false>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
-                       xx, yy, out, ldo, add_diag, tiles_n, out32);
+                       xx, yy, out, ldo, add_diag, tiles_n, out32, q32);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

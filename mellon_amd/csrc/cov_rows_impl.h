@@ -62,6 +62,12 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return __builtin_amdgcn_ldexp(p, (int)fmax(k, -1100.0));   // underflows to 0 like exp()
 }
 
+// the 32-bit copy: fp32 value, or (q32) the fixed-point number round(v 2^32) -- see mln_internal.h
+__device__ __forceinline__ float surrogate_bits(double v, int q32) {
+  const unsigned fx = (unsigned)fmin(fma(v, 4294967296.0, 0.5), 4294967295.0);
+  return q32 ? __uint_as_float(fx) : (float)v;
+}
+
 template <int KIND>
 __device__ __forceinline__ double leaf_value_k(const DevLeaf& lf, double xx, double yy, double xy) {
   const double inv_ls = lf.alpha_inv_ls[1];
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
                                                             const double* __restrict__ xx,
                                                             const double* __restrict__ yy,
                                                             double* __restrict__ out, int64_t ldo, double add_diag,
-                                                            float* __restrict__ out32) {
+                                                            float* __restrict__ out32, int q32) {
   __shared__ double ys[2][TN * NNS];   // tile t+1 is consumed while tile t+2 lands in the buffer tile t left
   __shared__ double yn[3][512];        // norms of the centres: [..][tid < TN] used, the rest absorbs the other threads' stores
   __shared__ double sink[512];         // where the staging stores of threads without an element go
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
           const int64_t row = row0 + lk + 4 * r;
           const double v = leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]);
           out[row * ldo + c] = v;
-          if (HAS32) out32[row * ldo + c] = (float)v;
+          if (HAS32) out32[row * ldo + c] = surrogate_bits(v, q32);
         }
       }
 #pragma unroll
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
           if (row < n && c < ldo) {
             const double v = (c < m) ? leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]) + ((row == c) ? add_diag : 0.0) : 0.0;
             out[row * ldo + c] = v;
-            if (HAS32) out32[row * ldo + c] = (float)v;
+            if (HAS32) out32[row * ldo + c] = surrogate_bits(v, q32);
           }
         }
       }
@@ -230,13 +236,14 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
 
 template <int KIND>
 static int launch_rows_kind(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y, int64_t m, int d,
-                            const double* xx, const double* yy, double* out, int64_t ldo, double add_diag, float* out32) {
+                            const double* xx, const double* yy, double* out, int64_t ldo, double add_diag, float* out32,
+                            int q32) {
   const dim3 grid((unsigned)((n + 127) / 128)), block(512);
 #define MLN_KM_ROWS2(KS)                                                                                              \
   if (out32) hipLaunchKernelGGL((k_kernel_matrix_rows<KIND, true, KS>), grid, block, 0, ctx->stream, cov, x, n, y, m, d, \
-                                xx, yy, out, ldo, add_diag, out32);                                                  \
+                                xx, yy, out, ldo, add_diag, out32, q32);                                             \
   else hipLaunchKernelGGL((k_kernel_matrix_rows<KIND, false, KS>), grid, block, 0, ctx->stream, cov, x, n, y, m, d, xx,  \
-                          yy, out, ldo, add_diag, out32);
+                          yy, out, ldo, add_diag, out32, q32);
   if (d <= 32) { MLN_KM_ROWS2(8) }
   else if (d <= 52) { MLN_KM_ROWS2(13) }
   else { MLN_KM_ROWS2(16) }
@@ -247,6 +254,6 @@ static int launch_rows_kind(mln_ctx* ctx, const DevCov& cov, const double* x, in
 
 #define MLN_DEFINE_ROWS_KIND(NAME, KIND)                                                                                 \
   int NAME(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y, int64_t m, int d,               \
-           const double* xx, const double* yy, double* out, int64_t ldo, double add_diag, float* out32) {                \
-    return launch_rows_kind<KIND>(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32);                           \
+           const double* xx, const double* yy, double* out, int64_t ldo, double add_diag, float* out32, int q32) {       \
+    return launch_rows_kind<KIND>(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32, q32);                      \
   }

@@ -10,8 +10,16 @@ void comm_release(mln_ctx* ctx);
 
 // ---- kernel launchers (all asynchronous on ctx->stream; device pointers only) ---------------
 // cov_kernels.hip
+// out32 (optional): a 32-bit copy of the result for the warm-up passes of the MAP solve -- fp32 values, or with
+// q32 != 0 the 32-bit fixed-point number round(v 2^32) (covariance values in [0, 1]: absolute error 1.2e-10
+// everywhere, where fp32 has 3e-8 near 1)
 int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
-                         int64_t m, int d, double* out, int64_t ldo, double add_diag, float* out32 = nullptr);
+                         int64_t m, int d, double* out, int64_t ldo, double add_diag, float* out32 = nullptr,
+                         int q32 = 0);
+__device__ __forceinline__ float mln_surrogate_bits(double v, int q32) {
+  const unsigned fx = (unsigned)fmin(fma(v, 4294967296.0, 0.5), 4294967295.0);
+  return q32 ? __uint_as_float(fx) : (float)v;
+}
 int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
                          int64_t m, int d, const double* w, double mu, double* out);
 

@@ -12,7 +12,8 @@ struct ObjArgs {
   const double* weights;  // if non-null: "gemv-T" mode, grad_j = sum_i weights_i L_ij (V, Vdr, z unused)
   double* f_out;          // if non-null: store f_i = L_i . z + mu
   int n_wg; int64_t m_pad;
-  const float* L32;       // if non-null: stream this fp32 copy of L instead (same shape / leading dimension)
+  const float* L32;       // if non-null: stream this 32-bit copy of L instead (same shape / leading dimension)
+  int l32_fixed;          //   its format: 0 = fp32 values, 1 = 32-bit fixed point (value = bits / 2^32)
   double* f_keep[2];      // if f_slot is non-null: f_i = L_i . z + mu of every row is also stored to f_keep[1 - *f_slot]
   const int* f_slot;      //   (the solver's "trial" buffer; accepting a point flips the slot -- the log-density at the
                           //    optimum then needs no pass of its own)

@@ -233,7 +233,14 @@ __device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t l
   }
 }
 
-template <int CQ, int R, bool GEMVT, bool KEEP, int NW>
+// element of the 32-bit copy as a double: an fp32 value, or (FIXED) the integer numerator of a 32-bit fixed-point
+// number -- its 2^-32 is folded into z on the way in and into the gradient partials on the way out, both exact
+template <bool FIXED>
+__device__ __forceinline__ double elem32(float v) {
+  return FIXED ? (double)__float_as_uint(v) : (double)v;
+}
+
+template <int CQ, int R, bool GEMVT, bool KEEP, int NW, bool FIXED>
 __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                                const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
                                                double& loss, double (*red)[NW][R], double* fstage, int64_t fbase,
@@ -246,10 +253,10 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     for (int r = 0; r < R; ++r) {
 #pragma unroll
       for (int c = 0; c < CQ; ++c) {
-        g[c][0] = fma(coef[r], (double)v[r][c].x, g[c][0]);
-        g[c][1] = fma(coef[r], (double)v[r][c].y, g[c][1]);
-        g[c][2] = fma(coef[r], (double)v[r][c].z, g[c][2]);
-        g[c][3] = fma(coef[r], (double)v[r][c].w, g[c][3]);
+        g[c][0] = fma(coef[r], elem32<FIXED>(v[r][c].x), g[c][0]);
+        g[c][1] = fma(coef[r], elem32<FIXED>(v[r][c].y), g[c][1]);
+        g[c][2] = fma(coef[r], elem32<FIXED>(v[r][c].z), g[c][2]);
+        g[c][3] = fma(coef[r], elem32<FIXED>(v[r][c].w), g[c][3]);
       }
     }
     return;
@@ -259,10 +266,10 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     double s = 0.0;
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {
-      s = fma((double)v[r][c].x, z[c][0], s);
-      s = fma((double)v[r][c].y, z[c][1], s);
-      s = fma((double)v[r][c].z, z[c][2], s);
-      s = fma((double)v[r][c].w, z[c][3], s);
+      s = fma(elem32<FIXED>(v[r][c].x), z[c][0], s);
+      s = fma(elem32<FIXED>(v[r][c].y), z[c][1], s);
+      s = fma(elem32<FIXED>(v[r][c].z), z[c][2], s);
+      s = fma(elem32<FIXED>(v[r][c].w), z[c][3], s);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -292,17 +299,17 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
   for (int r = 0; r < R; ++r) {
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {
-      g[c][0] = fma(coef[r], (double)v[r][c].x, g[c][0]);
-      g[c][1] = fma(coef[r], (double)v[r][c].y, g[c][1]);
-      g[c][2] = fma(coef[r], (double)v[r][c].z, g[c][2]);
-      g[c][3] = fma(coef[r], (double)v[r][c].w, g[c][3]);
+      g[c][0] = fma(coef[r], elem32<FIXED>(v[r][c].x), g[c][0]);
+      g[c][1] = fma(coef[r], elem32<FIXED>(v[r][c].y), g[c][1]);
+      g[c][2] = fma(coef[r], elem32<FIXED>(v[r][c].z), g[c][2]);
+      g[c][3] = fma(coef[r], elem32<FIXED>(v[r][c].w), g[c][3]);
     }
   }
 }
 
 // NW waves per workgroup: a row of ld4 column quads is spread over 64 NW CQ lane slots, and NW is chosen so that few
 // of them are idle (m = 5000: 1252 quads on 7 x 64 x 3 = 1344 slots, 93 %; 8 waves would use 81 % of 1536)
-template <int CQ, int R, bool GEMVT = false, bool KEEP = false, int NW = 8>
+template <int CQ, int R, bool GEMVT = false, bool KEEP = false, int NW = 8, bool FIXED = false>
 __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   if (a.gate && *a.gate != a.gate_want) return;
   constexpr int WG = 64 * NW;
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int64_t col = 4 * ((int64_t)c * WG + tid) + e;
-      z[c][e] = (!GEMVT && col < a.m) ? a.z[col] : 0.0;
+      z[c][e] = (!GEMVT && col < a.m) ? a.z[col] * (FIXED ? 0x1p-32 : 1.0) : 0.0;
       g[c][e] = 0.0;
     }
   double loss = 0.0;
@@ -335,10 +342,10 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
     load_rows32<CQ, R, NW>(L4, ld4, s1 * R, a.n, tid, vb);
     if (KEEP) load_lik<R>(a, s1 * R, pb);
-    process_rows32<CQ, R, GEMVT, KEEP, NW>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa);
+    process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa);
     load_rows32<CQ, R, NW>(L4, ld4, s2 * R, a.n, tid, va);
     if (KEEP) load_lik<R>(a, s2 * R, pa);
-    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb);
+    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb);
   }
   if (KEEP) {
     __syncthreads();
@@ -351,8 +358,9 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   for (int c = 0; c < CQ; ++c) {
     const int64_t col = 4 * ((int64_t)c * WG + tid);
     if (col < a.m_pad) {   // m_pad is a multiple of 16
-      *reinterpret_cast<d2*>(pg + col) = (d2){g[c][0], g[c][1]};
-      *reinterpret_cast<d2*>(pg + col + 2) = (d2){g[c][2], g[c][3]};
+      constexpr double sc = FIXED ? 0x1p-32 : 1.0;
+      *reinterpret_cast<d2*>(pg + col) = (d2){g[c][0] * sc, g[c][1] * sc};
+      *reinterpret_cast<d2*>(pg + col + 2) = (d2){g[c][2] * sc, g[c][3] * sc};
     }
   }
   if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss;
@@ -361,10 +369,15 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
 template <int CQ, int R, int NW>
 int launch_f32_nw(mln_ctx* ctx, const ObjArgs& a) {
   const dim3 grid((unsigned)a.n_wg), block(64 * NW);
-  if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true, false, NW>), grid, block, 0, ctx->stream, a);
-  // (never the f-keeping variant: what the fp32 copy yields is not the final log-density, and its variant of the
+  // (never the f-keeping variant: what the 32-bit copy yields is not the final log-density, and its variant of the
   //  loop measured 3.58 instead of 3.23 ms per pass)
-  else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW>), grid, block, 0, ctx->stream, a);
+  if (a.l32_fixed) {
+    if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true, false, NW, true>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW, true>), grid, block, 0, ctx->stream, a);
+  } else {
+    if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true, false, NW>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW>), grid, block, 0, ctx->stream, a);
+  }
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

@@ -1,0 +1,30 @@
+"""Pass counts and step time of the C3 fit against the format of the 32-bit copy and the switch tolerance."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench, mellon_amd
+from mellon_amd import _lib
+ctx = _lib.default_context()
+n, d, m = 1_000_000, 50, 5000
+x = bench.gaussian_mixture(n, d, int(os.environ.get("SEED", "3")))
+lm, _ = bench.make_landmarks(x, m, "device", ctx)
+xd = ctx.to_device(x)
+nn = ctx.nn_distances(xd, xd)
+ref = None
+for fmt, tol in [("float", "3e-6"), ("fixed", "1e-7"), ("fixed", "1e-8"), ("fixed", "1e-9"), ("fixed", "1e-10"), ("fixed", "1e-11"), ("fixed", "1e-12")]:
+    os.environ["MELLON_AMD_SURROGATE"] = fmt
+    os.environ["MELLON_AMD_MIXED_FTOL"] = tol
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        est = mellon_amd.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+        dens = est.fit_predict(xd)
+        dt = time.perf_counter() - t0
+        st = est._fit.stage_times()
+        est._fit.close()
+        if rep > 0 and (best is None or dt < best[0]):
+            best = (dt, st["objective32_launches"], st["objective_launches"], dens.copy())
+    if ref is None:
+        ref = best[3]
+    print(fmt, tol, {"step_ms": round(1e3 * best[0], 1), "n32": best[1], "n64": best[2],
+                     "rel_vs_float": float(np.abs(best[3] - ref).max() / np.abs(ref).max())}, flush=True)
