@@ -327,6 +327,11 @@ int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xne
 int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result);
 int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
                    int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out);
+/* The integer Gram of the preconditioner in isolation (csrc/gram_i8.hip): out (m x m) = Q^T Q / 8355711^2 with
+ * Q = round(A * 8355711), A rows x m with values in [0, 1] (host or device); terms below 2^-23 relative are dropped.
+ * ms_out (may be NULL): milliseconds per call over `reps` calls.  Not a reference operation: the reference forms the
+ * fp64 Gram of all cells (parameters.py:895-896); this one only ever feeds the preconditioner. */
+int mln_diag_gram_i8(mln_ctx* ctx, const double* A, int64_t rows, int64_t m, double* out, int32_t reps, double* ms_out);
 /* ms of: kernel-matrix pass alone, Gram GEMM alone, both on two streams, Cholesky alone, kernel matrix ||
  * Cholesky, kernel matrix || (Cholesky then Gram) -- the measurement behind the two-stream set-up phase. */
 int mln_diag_overlap(mln_ctx* ctx, int64_t n, int64_t m, int32_t d, int64_t gram_rows, double* out /* 6 */);

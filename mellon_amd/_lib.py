@@ -106,6 +106,7 @@ SYMBOLS = [
     ("mln_stage_times", C.c_int, [_vp, _dp]),
     ("mln_diag_peak", C.c_int, [_vp, _i32, _i64, C.POINTER(_dbl)]),
     ("mln_diag_overlap", C.c_int, [_vp, _i64, _i64, _i32, _i64, _dp]),
+    ("mln_diag_gram_i8", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, C.POINTER(_dbl)]),
     ("mln_diag_dgemm", C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, C.POINTER(_dbl)]),
 ]
 
@@ -484,6 +485,15 @@ class Context:
         out = np.zeros(6)
         self._check(self.lib.mln_diag_overlap(self.handle, int(n), int(m), int(d), int(gram_rows), out.ctypes.data))
         return dict(zip(["k_ms", "gram_ms", "k_par_gram_ms", "chol_ms", "k_par_chol_ms", "k_par_chol_gram_ms"], out))
+
+    def diag_gram_i8(self, a, reps=1):
+        """(Gram of round(a * 8355711) / 8355711**2, ms per call): the preconditioner's integer Gram in isolation."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.empty((a.shape[1], a.shape[1]))
+        ms = C.c_double()
+        self._check(self.lib.mln_diag_gram_i8(self.handle, a.ctypes.data, a.shape[0], a.shape[1], out.ctypes.data, int(reps),
+                                              C.byref(ms)))
+        return out, ms.value
 
     def diag_peak(self, what, nbytes=1 << 32):
         r = C.c_double()

@@ -333,7 +333,7 @@ extern "C" int mln_predict_hessian(mln_ctx* ctx, const mln_kernel_desc* cov, con
 }
 
 static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
-                   int64_t ldg);
+                   int64_t ldg, bool quantised = false);
 static int64_t pad16(int64_t m);
 
 // G (m x m) = cov(x, xu)^T cov(x, xu): the B^T B of the landmark leverage (conditional.py:660-685) without
@@ -462,6 +462,7 @@ struct mln_fit {
   double* eigU = nullptr;
   // fp32 copy of the streamed n x m buffer for the warm-up passes of the MAP solve (mixed precision)
   float* L32 = nullptr;
+  bool cov_bounded01 = false;   // every covariance value lies in [0, 1] (stationary kernels and their products)
   int l32_fixed = 0;     // format of that copy: 0 = fp32, 1 = 32-bit fixed point (covariances bounded by 1)
   int evals32 = 0;
   double times32 = 0.0;
@@ -595,12 +596,13 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
     // surrogate objective then sits ~100x closer to the true one, and the solver can stay on the 4-byte stream for
     // more of its iterations.  Sums, scalars, powers, the Linear kernel: fp32.  MELLON_AMD_SURROGATE=float|fixed overrides.
     f->l32_fixed = 0;
+    bool bounded = true;
+    for (int l = 0; l < f->cov.n_leaves; ++l)
+      bounded = bounded && f->cov.leaves[l].kind >= MLN_K_MATERN32 && f->cov.leaves[l].kind <= MLN_K_RATQUAD;
+    for (int t = 0; t < f->cov.n_toks; ++t)
+      bounded = bounded && (f->cov.tok_op[t] == MLN_OP_LEAF || f->cov.tok_op[t] == MLN_OP_MUL);
+    f->cov_bounded01 = bounded;
     if (f->L32) {
-      bool bounded = true;
-      for (int l = 0; l < f->cov.n_leaves; ++l)
-        bounded = bounded && f->cov.leaves[l].kind >= MLN_K_MATERN32 && f->cov.leaves[l].kind <= MLN_K_RATQUAD;
-      for (int t = 0; t < f->cov.n_toks; ++t)
-        bounded = bounded && (f->cov.tok_op[t] == MLN_OP_LEAF || f->cov.tok_op[t] == MLN_OP_MUL);
       f->l32_fixed = bounded ? 1 : 0;
       if (const char* ev = std::getenv("MELLON_AMD_SURROGATE")) {
         if (std::strcmp(ev, "float") == 0) f->l32_fixed = 0;
@@ -672,9 +674,6 @@ extern "C" int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, in
   *out = f;
   return MLN_OK;
 }
-
-static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
-                   int64_t ldg);
 
 extern "C" int mln_eigh(mln_ctx* ctx, const double* A, int64_t m, double* w, double* V, int32_t* n_sweeps) {
   if (!ctx || (m > 0 && (!A || !w || !V))) return MLN_ERR_ARG;
@@ -938,11 +937,13 @@ extern "C" int mln_transform(mln_fit* f, const double* z, double mu, double* f_o
 }
 
 // G (m x ldg, full symmetric) = alpha * A^T A for the row-major A (rows x m, leading dim lda), all-reduced.
+// `quantised`: A holds covariance values in [0, 1] and the result only feeds a preconditioner -- the Gram of A rounded
+// to 23 fractional bits, exact in integers on the int8 matrix cores (gram_i8.hip).
 static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
-                   int64_t ldg) {
-  int split = (int)(rows / 8192);
+                   int64_t ldg, bool quantised) {
+  int split = quantised ? gram_i8_splits(rows, m) : (int)(rows / 8192);
   if (split < 1) split = 1;
-  if (split > 16) split = 16;
+  if (split > 16 && !quantised) split = 16;
   const size_t stride = (size_t)m * ldg;
   double* parts = nullptr;
   if (split > 1) MLN_HIP(ctx, mln_dmalloc((void**)&parts, sizeof(double) * stride * split));
@@ -954,7 +955,8 @@ static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int
   int rc = MLN_OK;
   if (split > 1) rc = (hipMemsetAsync(parts, 0, sizeof(double) * stride * split, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
   else rc = (hipMemsetAsync(G, 0, sizeof(double) * stride, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-  if (rc == MLN_OK && rows > 0) rc = launch_dgemm(ctx, g);
+  if (rc == MLN_OK && rows > 0)
+    rc = quantised ? launch_gram_i8(ctx, A, lda, rows, m, alpha, g.C, ldg, (int64_t)stride, split) : launch_dgemm(ctx, g);
   if (rc == MLN_OK && split > 1) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, G, (int64_t)stride, 0.0);
   if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
   if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)stride);
@@ -963,7 +965,52 @@ static int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int
   return rc;
 }
 
+// Test / measurement hook for gram_i8.hip: out (m x m) = the Gram of round(A 8355711) / 8355711^2, A rows x m with values
+// in [0, 1]; ms_out (may be NULL) = milliseconds per call of digit extraction + integer GEMM + sum of the k-chunks.
+extern "C" int mln_diag_gram_i8(mln_ctx* ctx, const double* A, int64_t rows, int64_t m, double* out, int32_t reps,
+                                double* ms_out) {
+  if (!ctx || !A || !out || rows < 1 || m < 1) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevIn a;
+  DevOut o;
+  MLN_TRY(a.init(ctx, A, (size_t)rows * m));
+  MLN_TRY(o.init(ctx, out, (size_t)m * m));
+  const int split = gram_i8_splits(rows, m);
+  const size_t stride = (size_t)m * m;
+  double *parts = nullptr, *G = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&parts, sizeof(double) * stride * split));
+  MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * stride));
+  hipEvent_t e0, e1;
+  MLN_HIP(ctx, hipEventCreate(&e0));
+  MLN_HIP(ctx, hipEventCreate(&e1));
+  int rc = MLN_OK;
+  if (reps < 1) reps = 1;
+  for (int r = 0; r <= reps && rc == MLN_OK; ++r) {   // round 0 warms up
+    if (r == 1) (void)hipEventRecord(e0, ctx->stream);
+    rc = (hipMemsetAsync(parts, 0, sizeof(double) * stride * split, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+    if (rc == MLN_OK) rc = launch_gram_i8(ctx, a.dev, m, rows, m, 1.0, parts, m, (int64_t)stride, split);
+    if (rc == MLN_OK) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, G, (int64_t)stride, 0.0);
+  }
+  (void)hipEventRecord(e1, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_out) *ms_out = ms / reps;
+  if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, m);
+  if (rc == MLN_OK) rc = launch_copy_block(ctx, G, m, o.dev, m, m, m);
+  if (rc == MLN_OK) rc = o.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(parts); (void)mln_dfree(G);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
 // G ~ L^T L from every `row_stride`-th cell of this rank (scaled by row_stride), all-reduced.
+__global__ void k_round_bits(double* __restrict__ A, int64_t count, double scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    A[i] = rint(A[i] * scale) / scale;
+}
+
 static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
   mln_ctx* ctx = f->ctx;
   if (row_stride < 1) row_stride = 1;
@@ -995,7 +1042,24 @@ static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
     (void)mln_dfree(R);
     return rc;
   }
-  int rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);   // all-reduced
+  int rc = MLN_OK;
+  const int qbits = std::getenv("MELLON_AMD_GRAM_QBITS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_QBITS")) : 0;
+  if (qbits > 0) {   // experiment: the Gram of the sampled rows rounded to `qbits` fractional bits
+    double* R = nullptr;
+    const int64_t rr = rows > 0 ? rows : 1;
+    MLN_HIP(ctx, mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl));
+    if (rows > 0) rc = launch_copy_block(ctx, Ls, f->ldl * row_stride, R, f->ldl, rows, f->ldl);
+    if (rc == MLN_OK && rows > 0)
+      hipLaunchKernelGGL(k_round_bits, dim3(2048), dim3(256), 0, ctx->stream, R, rows * f->ldl, std::ldexp(1.0, qbits));
+    if (rc == MLN_OK) rc = gram_of(ctx, R, f->ldl, rows, f->m, (double)row_stride, G, ldg);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)mln_dfree(R);
+  } else {
+    // bounded covariances: 23-bit integer Gram on the int8 matrix cores (the preconditioner needs ~20 bits: gram_i8.hip)
+    bool quant = f->cov_bounded01 && f->m >= 256;
+    if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
+    rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
+  }
   double* T = nullptr;
   if (rc == MLN_OK) {
     hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)f->m * ldg);

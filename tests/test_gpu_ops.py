@@ -653,3 +653,41 @@ def test_kernel_matrix_persistent_rows(ctx, name, d):
     big = (ref > 1e-3) & ~co
     assert big.sum() > 10000
     assert (np.abs(K - ref)[big] / ref[big]).max() < 1e-11       # (summation order of the d-term dot products differs)
+
+
+def _digit_gram_exact(a):
+    """What csrc/gram_i8.hip computes, in exact int64 arithmetic: three balanced base-256 digits of
+    q = round(a * 8355711) and all nine digit-pair products -- i.e. q^T q."""
+    scale = 8355711
+    q = np.rint(np.clip(a, 0.0, 1.0) * scale).astype(np.int64)
+    d0 = ((q + 128) & 255) - 128
+    q1 = (q - d0) >> 8
+    d1 = ((q1 + 128) & 255) - 128
+    d2 = (q1 - d1) >> 8
+    assert d2.min() >= 0 and d2.max() <= 127 and np.array_equal(d0 + 256 * d1 + 65536 * d2, q)
+    D = [d.astype(np.float64) for d in (d0, d1, d2)]          # |sum| <= 2^14 rows < 2^53: the BLAS product is exact
+    acc = np.zeros((a.shape[1], a.shape[1]), dtype=np.int64)
+    for i in range(3):
+        for j in range(3):
+            acc += (D[i].T @ D[j]).astype(np.int64) << (8 * (i + j))
+    return acc, q, scale
+
+
+@pytest.mark.parametrize("rows,m", [(1000, 300), (4096, 512), (70_001, 257)])
+def test_integer_gram_of_the_preconditioner(ctx, rows, m):
+    """The int8-MFMA Gram (three signed digit planes, int32 accumulation per k-chunk): integer-exact against int64
+    NumPy -- the only floating-point operations are the final weighted sum of three exact integers and the sum of the
+    k-chunks -- including ragged shapes, more than one k-chunk, and the values 0 and 1 themselves."""
+    rng = np.random.default_rng(rows + m)
+    a = rng.random((rows, m)) ** 3
+    a[rng.integers(0, rows, 50), rng.integers(0, m, 50)] = 1.0
+    a[rng.integers(0, rows, 50), rng.integers(0, m, 50)] = 0.0
+    got, _ = ctx.diag_gram_i8(a)
+    acc, q, scale = _digit_gram_exact(a)
+    want = acc.astype(np.float64) / float(scale) ** 2
+    assert np.array_equal(got, got.T)
+    assert np.abs(got - want).max() <= 4e-16 * np.abs(want).max() * max(1, rows // 32768 + 1)
+    assert np.array_equal(acc, (q.T.astype(np.float64) @ q.astype(np.float64)).astype(np.int64)) or rows > 500   # 2^46 rows < 2^53
+    assert np.linalg.eigvalsh(got).min() >= -1e-12 * np.abs(got).max()                 # a Gram: positive semi-definite
+    exact = a.T @ a
+    assert np.abs(got - exact).max() <= 2.0 ** -20 * np.abs(exact).max()
