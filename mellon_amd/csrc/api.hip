@@ -1056,7 +1056,9 @@ static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
     (void)mln_dfree(R);
   } else {
     // bounded covariances: 23-bit integer Gram on the int8 matrix cores (the preconditioner needs ~20 bits: gram_i8.hip)
-    bool quant = f->cov_bounded01 && f->m >= 256;
+    // ... and only where the caller asked for a SAMPLED Gram (row_stride > 1: a preconditioner by construction);
+    // row_stride == 1 is the reference's exact Ridge matrix / the Gram whose eigenvalues are results
+    bool quant = f->cov_bounded01 && f->m >= 256 && row_stride > 1;
     if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
     rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
   }

@@ -58,6 +58,13 @@ __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2
 }
 
 // V and Vdr of the R rows of a step (clamped to the last row: rows past the end have coefficient 0)
+// lds_barrier_unused: the per-step barrier only publishes eight partial dot products through LDS, so
+// "s_waitcnt lgkmcnt(0); s_barrier" would do, and it would leave the prefetched rows of the next step in flight where
+// __syncthreads() (a full fence, vmcnt(0)) drains them.  Measured at C3: the fp64 kernel is unchanged (5.8 ms) and the
+// 32-bit kernel gets SLOWER, 3.10 -> 3.56 ms -- with the drain, the waves of a workgroup re-align at every step and issue
+// their next row segments back to back (whole 20 KB rows as one burst); without it they drift apart and the HBM pages
+// are revisited.  The full fence stays.
+
 template <int R>
 __device__ __forceinline__ void load_lik(const ObjArgs& a, int64_t row, double (&pv)[2][R]) {
 #pragma unroll
@@ -96,7 +103,7 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
 #pragma unroll
       for (int r = 0; r < R; ++r) red[par][wave][r] = dot[r];
     }
-    __syncthreads();
+    __syncthreads();   // full fence on purpose: see the note at lds_barrier_unused
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       double s = 0.0;
@@ -280,7 +287,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
 #pragma unroll
     for (int r = 0; r < R; ++r) red[par][wave][r] = dot[r];
   }
-  __syncthreads();
+  __syncthreads();   // full fence on purpose: see the note at lds_barrier_unused
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
