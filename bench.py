@@ -297,7 +297,9 @@ def main():
         "scaling": args.scaling, "vs_baseline": None,
         "dtype": (f"f64 results; {int(n32)} of {int(n_eval)} passes stream a 32-bit copy of K (4 B/element: "
                   + ("fixed point round(K 2^32)" if stats.get("copy32_format") == 2.0 else "fp32")
-                  + f"), {n64} the fp64 buffer -- pure-fp64 step: ms_per_step_fp64_only") if n32 > 0 else "f64",
+                  + f"), {n64} the fp64 buffer (they anchor the first-order correction of the 32-bit objective and verify "
+                    "the final point: loss, gradient and log-density of the returned optimum are fp64 evaluations) -- "
+                    "pure-fp64 step: ms_per_step_fp64_only") if n32 > 0 else "f64",
         "data": "synthetic",
         **extra,
         "config": {"workload": f"C3 DensityEstimator.fit_predict: {n_total} cells x {d} dims Gaussian mixture "

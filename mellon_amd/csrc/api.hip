@@ -1323,7 +1323,7 @@ static int fit_solver_alloc(mln_fit* f, int maxcor) {
   if (f->sv_block && f->sv_maxcor >= maxcor) return MLN_OK;
   if (f->sv_block) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, mln_dfree(f->sv_block)); f->sv_block = nullptr; }
   const size_t ld = (size_t)f->ldl;
-  const size_t n_dbl = 5 * ld + 2 * (size_t)maxcor * ld + 2 * 64 + 4 * 512 + 32;
+  const size_t n_dbl = 6 * ld + 2 * (size_t)maxcor * ld + 2 * 64 + 4 * 512 + 32;
   MLN_HIP(ctx, mln_dmalloc(&f->sv_block, sizeof(double) * n_dbl));
   MLN_HIP(ctx, hipMemsetAsync(f->sv_block, 0, sizeof(double) * n_dbl, ctx->stream));
   double* p = (double*)f->sv_block;
@@ -1331,6 +1331,7 @@ static int fit_solver_alloc(mln_fit* f, int maxcor) {
   b.u = p; p += ld; b.g = p; p += ld; b.un = p; p += ld; b.gn = p; p += ld; b.d = p; p += ld;
   b.S = p; p += (size_t)maxcor * ld; b.Y = p; p += (size_t)maxcor * ld;
   b.rho = p; p += 64; b.yy = p; p += 64;
+  b.c = p; p += ld;
   b.trace = p; p += 4 * 512;
   b.st = (SolverState*)p;
   b.ld = (int64_t)ld;
@@ -1378,6 +1379,10 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // the fp32 copy's optimum sits ~1e-5 (relative loss) from the true one, the fixed-point copy's ~1e-9
   init.ftol32 = f->l32_fixed ? 1e-9 : 3e-6;
   if (const char* ev = std::getenv("MELLON_AMD_MIXED_FTOL")) init.ftol32 = std::atof(ev);
+  // ... and after that first fp64 evaluation the solve continues on the 32-bit copy WITH its first-order correction
+  // (solver.hip), the fp64 objective verifying the final point (MELLON_AMD_CORRECTED=0: finish on the fp64 buffer)
+  init.use_corr = (phase32 && f->l32_fixed) ? 1 : 0;
+  if (const char* ev = std::getenv("MELLON_AMD_CORRECTED")) init.use_corr = init.use_corr && std::atoi(ev) != 0;
   init.prior_const = 0.5 * (double)m * std::log(2.0 * M_PI);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
   const int* gate = &f->sv.st->gate;
@@ -1420,7 +1425,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     tr.resize((size_t)4 * n_done);
     MLN_HIP(ctx, hipMemcpy(tr.data(), f->sv.trace, sizeof(double) * 4 * n_done, hipMemcpyDeviceToHost));
     for (int i = 0; i < n_done && timing && 3 * (i + 1) <= (int)f->evs.size(); ++i) {
-      const bool was32 = (int)tr[4 * i + 3] == MLN_GATE_F32;
+      const bool was32 = ((int)tr[4 * i + 3] & 3) == MLN_GATE_F32;
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, f->evs[3 * i + (was32 ? 0 : 1)], f->evs[3 * i + (was32 ? 1 : 2)]) != hipSuccess) continue;
       if (was32) { f->times32 += 1e-3 * ms; f->evals32 += 1; }
@@ -1428,7 +1433,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     }
     if (trace_lvl >= 2)
       for (int i = 0; i < n_done; ++i)
-        fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, (int)tr[4 * i + 3] == MLN_GATE_F32 ? "f32" : "f64",
+        fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, (int)tr[4 * i + 3] == MLN_GATE_F32 ? "f32" : ((int)tr[4 * i + 3] == MLN_GATE_F32C ? "f32c" : "f64"),
                 (int)tr[4 * i + 2], tr[4 * i + 1], tr[4 * i]);
   }
   // z = C^-T u and w = P u at the accepted point (one stacked product), remembered for transform / predictor weights

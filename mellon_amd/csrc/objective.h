@@ -20,7 +20,8 @@ struct ObjArgs {
   const int* gate;        // if non-null: the launch is a no-op unless *gate == gate_want (device-resident solver:
   int gate_want;          //   MLN_GATE_F64 / MLN_GATE_F32 select the streamed copy, MLN_GATE_DONE stops everything)
 };
-enum { MLN_GATE_F64 = 0, MLN_GATE_F32 = 1, MLN_GATE_DONE = 2 };
+// (the objective kernels compare gate & 3 with gate_want: MLN_GATE_F32C streams the same copy as MLN_GATE_F32)
+enum { MLN_GATE_F64 = 0, MLN_GATE_F32 = 1, MLN_GATE_DONE = 2, MLN_GATE_F32C = 5 };
 int objective_max_m();
 bool objective_can_keep_f(int64_t n, int n_wg);
 int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count);

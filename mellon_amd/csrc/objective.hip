@@ -149,7 +149,7 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
 
 template <int CPT, int R, int MODE, bool KEEP = false>
 __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
-  if (a.gate && *a.gate != a.gate_want) return;   // uniform: the device-resident solver chose the other copy / is done
+  if (a.gate && (*a.gate & 3) != a.gate_want) return;   // uniform: the device-resident solver chose the other copy / is done
   __shared__ double red[2][8][R];
   const int tid = threadIdx.x;
   const int64_t ld2 = a.ldl / 2;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
 // of them are idle (m = 5000: 1252 quads on 7 x 64 x 3 = 1344 slots, 93 %; 8 waves would use 81 % of 1536)
 template <int CQ, int R, bool GEMVT = false, bool KEEP = false, int NW = 8, bool FIXED = false>
 __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
-  if (a.gate && *a.gate != a.gate_want) return;
+  if (a.gate && (*a.gate & 3) != a.gate_want) return;
   constexpr int WG = 64 * NW;
   __shared__ double red[2][NW][R];
   const int tid = threadIdx.x;

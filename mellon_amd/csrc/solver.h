@@ -7,7 +7,8 @@
 enum { MLN_SOLVE_FIRST = 0, MLN_SOLVE_LS = 1, MLN_SOLVE_REEVAL = 2 };
 
 struct SolverState {
-  int gate;      // MLN_GATE_F64 / MLN_GATE_F32: which copy of the buffer the next evaluation streams; MLN_GATE_DONE
+  int gate;      // which copy of the buffer the next evaluation streams: MLN_GATE_F64, MLN_GATE_F32 (the plain 32-bit
+                 // surrogate), MLN_GATE_F32C (the 32-bit surrogate with its first-order correction); MLN_GATE_DONE
   int mode;      // what the evaluation in flight is: first point, line-search trial, re-evaluation at u (phase switch)
   int status;    // 0 converged, 1 maxiter, 2 line search failed
   int it, n_eval, n_eval32, ls;
@@ -16,10 +17,13 @@ struct SolverState {
   int m;
   int f_slot;    // which of the two per-row f buffers holds f at the ACCEPTED point (the pass in flight writes the other)
   int f_valid;   // ... and whether that evaluation streamed the fp64 buffer
-  int pad_;
+  int corr;      // a first-order correction (c, corr_k) of the 32-bit surrogate is in force
+  int n_anchor;  // fp64 evaluations that (re)anchored it
+  int use_corr;  // set by the host: continue on the corrected surrogate after the first fp64 evaluation
   double ftol, gtol, ftol32;
   double prior_const;       // (m / 2) log 2 pi
   double fx, t, gd;         // accepted loss, current trial step, g . d at the accepted point
+  double corr_k;            // corrected surrogate: F^(u) = F32(u) + c . u + corr_k,  grad F^ = grad F32 + c
 };
 
 struct SolverBuffers {
@@ -27,6 +31,7 @@ struct SolverBuffers {
   double *u, *g, *un, *gn, *d;   // m each: accepted point / gradient, trial point / gradient, direction
   double *S, *Y;                 // maxcor x ld
   double *rho, *yy;              // maxcor each: 1 / s.y and y.y
+  double* c;                     // m: gradient of (fp64 objective - 32-bit surrogate) at the last anchor
   const double* z;               // z = C^-T un of the evaluation in flight (m)
   const double* lik;             // its (all-reduced) likelihood sum
   int64_t ld;

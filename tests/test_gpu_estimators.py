@@ -432,18 +432,23 @@ def test_mixed_precision_warmup_reaches_the_same_optimum(mellon, monkeypatch):
     lm = x[rng.choice(6000, 300, replace=False)]
     nn = mo.exact_nn_distances(x)
     ref = mo.density_fit(x, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
-    out = {}
-    for mixed in ("1", "0"):
-        monkeypatch.setenv("MELLON_AMD_MIXED", mixed)
+    out, n64 = {}, {}
+    # "1": 32-bit copy, then the corrected 32-bit surrogate, the fp64 objective anchoring and verifying (the default);
+    # "plain": 32-bit copy, then the fp64 buffer (MELLON_AMD_CORRECTED=0); "0": fp64 only
+    for mixed in ("1", "plain", "0"):
+        monkeypatch.setenv("MELLON_AMD_MIXED", "0" if mixed == "0" else "1")
+        monkeypatch.setenv("MELLON_AMD_CORRECTED", "0" if mixed == "plain" else "1")
         monkeypatch.setenv("MELLON_AMD_MIXED_MIN_ELEMS", "0")
         est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn)
         out[mixed] = est.fit_predict(x)
         st = est._fit.stage_times()
-        assert (st["objective32_launches"] > 0) == (mixed == "1")
-        assert st["objective_launches"] > 0                       # the solve always finishes on the fp64 buffer
+        n64[mixed] = st["objective_launches"]
+        assert (st["objective32_launches"] > 0) == (mixed != "0")
+        assert st["objective_launches"] > 0                       # the fp64 objective always has the last word
         assert rel_std(out[mixed], ref.log_density_x) < 1e-5 and rel_max(out[mixed], ref.log_density_x) < 1e-5
         assert rel_max(est.predict(x[:500]), out[mixed][:500]) < 1e-9
-    assert rel_max(out["1"], out["0"]) < 2e-6
+    assert rel_max(out["1"], out["0"]) < 2e-6 and rel_max(out["plain"], out["0"]) < 2e-6
+    assert n64["1"] <= 4 and n64["1"] < n64["plain"] < n64["0"], n64   # anchor + verification (+ at most two re-anchors)
 
 
 def test_c3_subsample_golden(mellon):
