@@ -1384,6 +1384,11 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.use_corr = (phase32 && f->l32_fixed) ? 1 : 0;
   if (const char* ev = std::getenv("MELLON_AMD_CORRECTED")) init.use_corr = init.use_corr && std::atoi(ev) != 0;
   init.prior_const = 0.5 * (double)m * std::log(2.0 * M_PI);
+  init.t0 = 1.0;
+  init.boost = 0.15;    // solver.hip "step-length memory"; MELLON_AMD_LS_BOOST=0 keeps every first trial at 1
+  if (const char* ev = std::getenv("MELLON_AMD_LS_BOOST")) init.boost = std::atof(ev);
+  init.boost_fall = 0.15;
+  if (const char* ev = std::getenv("MELLON_AMD_LS_BOOST_FALL")) init.boost_fall = std::atof(ev);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
   const int* gate = &f->sv.st->gate;
   static const bool timing = !(std::getenv("MELLON_AMD_TIMING") && std::atoi(std::getenv("MELLON_AMD_TIMING")) == 0);

@@ -952,7 +952,7 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
   static const bool no_rows = std::getenv("MELLON_AMD_KM_NO_ROWS") != nullptr;
   if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
-      cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD) {
+      cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD && (!out32 || q32)) {
     MLN_TRY(launch_kernel_matrix_rows_q(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32, q32));
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_kernel_matrix_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,

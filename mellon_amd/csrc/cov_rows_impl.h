@@ -62,10 +62,13 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return __builtin_amdgcn_ldexp(p, (int)fmax(k, -1100.0));   // underflows to 0 like exp()
 }
 
-// the 32-bit copy: fp32 value, or (q32) the fixed-point number round(v 2^32) -- see mln_internal.h
-__device__ __forceinline__ float surrogate_bits(double v, int q32) {
-  const unsigned fx = (unsigned)fmin(fma(v, 4294967296.0, 0.5), 4294967295.0);
-  return q32 ? __uint_as_float(fx) : (float)v;
+// the 32-bit copy: the fixed-point number round(v 2^32), 1 stored as 2^32 - 1 -- see mln_internal.h.  (The rows kernels
+// only ever write this format -- every kind they handle is bounded by 1; an fp32 copy, MELLON_AMD_SURROGATE=float,
+// takes the tiled kernel.  A run-time choice between the two cost 5 instead of 3 instructions per element here.)
+// No conversion instruction: v + 2^20 has an ulp of 2^-32, so the low word of that double IS round(v 2^32) (to nearest
+// even); v is clamped to 1 - 2^-32 first, where the sum would carry into bit 32.
+__device__ __forceinline__ float surrogate_bits(double v, int) {
+  return __uint_as_float((unsigned)__double2loint(fmin(v, 0x1.fffffffep-1) + 0x1p20));
 }
 
 template <int KIND>

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   }
   int mode = st->mode, it = st->it, n_eval = st->n_eval + 1, n_eval32 = st->n_eval32 + (phase32 ? 1 : 0);
   int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
-  double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k;
+  double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k, t0 = st->t0;
+  if (mode != MLN_SOLVE_LS) t0 = 1.0;
   int f_slot = st->f_slot, f_valid = st->f_valid, corr = st->corr, n_anchor = st->n_anchor;
   if (b.trace && tid == 0) {
     double* tr = b.trace + 4 * ((n_eval - 1) & 511);
@@ -161,6 +162,21 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
         sy = fma(sv[e], yv[e], sy); ss = fma(sv[e], sv[e], ss); yy = fma(yv[e], yv[e], yy);
       }
       block_sum3(sy, ss, yy, red3);
+      // Step-length memory.  Where some cells' e^{f+V} is still huge (the Ridge start overshoots by up to e^14 in
+      // sparse regions) a quasi-Newton step walks down the exponential one unit at a time: the loss falls by ~2x per
+      // pass for a dozen passes and the slope along d after the unit step is still ~e^-1 of what it was (a quadratic
+      // model promises 0).  So: a first trial that was accepted with more than `boost` of the initial slope left
+      // doubles the first trial of the NEXT search (Armijo still decides; a failed trial backtracks as always).
+      if (st->boost > 0.0) {
+        double sl = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) sl = fma(gn[e], d[e], sl);
+        sl = block_sum(sl, red);
+        // (only while the loss itself still falls by more than `boost_fall` per pass: later, a doubled trial is a wasted
+        //  pass more often than a saved one.  tools/boost_sweep.py, six data seeds at C3: 50.5 -> 41.8 passes on average
+        //  with boost = boost_fall = 0.15)
+        t0 = (ls == 1 && t >= 1.0 && gd < 0.0 && sl / gd > st->boost && (fx - fn) > st->boost_fall * fabs(fx)) ? fmin(2.0 * t, 16.0) : 1.0;
+      }
       const double f_old = fx;
 #pragma unroll
       for (int e = 0; e < EPT; ++e) { u[e] = un[e]; g[e] = gn[e]; }
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       // If that is within the stopping tolerance, F itself has converged by the same measure the ftol test applies a
       // posteriori -- done, on fp64 evidence (the loss, the gradient and the rows' f of this very pass).
       if (verify && -0.5 * gd <= st->ftol * fmax(fabs(fx), 1.0)) { status = 0; done = true; }
-      t = 1.0;
+      t = t0;
       if (k == 0) {
         double g1 = 0.0;
 #pragma unroll
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     st->gate = gate; st->mode = mode; st->status = status; st->it = it; st->n_eval = n_eval; st->n_eval32 = n_eval32;
     st->ls = ls; st->k = k; st->head = head; st->fx = fx; st->t = t; st->gd = gd;
     st->f_slot = f_slot; st->f_valid = f_valid;
-    st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k;
+    st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k; st->t0 = t0;
   }
 }
 

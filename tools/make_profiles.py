@@ -13,6 +13,7 @@ import sqlite3
 import sys
 
 FP64_PEAK_TF = 78.6
+INT8_PEAK_TOPS = 3944.0
 
 
 def short(name):
@@ -73,9 +74,12 @@ def main(a):
            "fp32_passes": t32}
     json.dump(out, open("profiles/objective_traffic.json", "w"), indent=1)
     # MFMA utilisation
-    mf = {"peak_tflops_fp64": FP64_PEAK_TF, "definition": "SQ_INSTS_MFMA x 2048 flop (every matrix instruction of these kernels is "
-          "v_mfma_f64_16x16x4_f64) / launch duration; frac = that / 78.6 TFLOP/s.  On gfx950 the fp64 matrix pipe runs at the fp64 "
-          "vector rate, so frac is also the share of the CU's fp64 issue slots spent in MFMAs.", "kernels": {}}
+    mf = {"peak_tflops_fp64": FP64_PEAK_TF, "peak_tops_int8": INT8_PEAK_TOPS,
+          "definition": "SQ_INSTS_MFMA x flop per instruction / launch duration.  fp64 kernels: every matrix instruction is "
+          "v_mfma_f64_16x16x4_f64 (2048 flop), frac = that / 78.6 TFLOP/s; on gfx950 the fp64 matrix pipe runs at the fp64 "
+          "vector rate, so frac is also the share of the CU's fp64 issue slots spent in MFMAs.  k_gram_i8: every matrix "
+          "instruction is v_mfma_i32_32x32x32_i8 (65536 integer operations), frac = that / 3944 TOP/s (the measured "
+          "int8 ceiling of guides/MI355X_MICROARCH.md).", "kernels": {}}
     for k, cs in sq.items():
         if "SQ_INSTS_MFMA" not in cs:
             continue
@@ -84,10 +88,13 @@ def main(a):
             continue
         v, d = max(vals, key=lambda q: q[1])            # the largest launch of this kernel
         tot_v, tot_d = sum(q[0] for q in vals), sum(q[1] for q in vals)
-        mf["kernels"][k] = {"launches": len(vals), "largest_launch_us": d / 1e3, "largest_launch_tflops": v * 2048 / d / 1e3,
-                            "largest_launch_frac_of_peak": v * 2048 / d / 1e3 / FP64_PEAK_TF,
-                            "all_launches_tflops": tot_v * 2048 / tot_d / 1e3,
-                            "all_launches_frac_of_peak": tot_v * 2048 / tot_d / 1e3 / FP64_PEAK_TF}
+        i8 = k.startswith("k_gram_i8")
+        per, peak = (65536, INT8_PEAK_TOPS) if i8 else (2048, FP64_PEAK_TF)
+        mf["kernels"][k] = {"launches": len(vals), "largest_launch_us": d / 1e3, "largest_launch_tflops": v * per / d / 1e3,
+                            "largest_launch_frac_of_peak": v * per / d / 1e3 / peak,
+                            "all_launches_tflops": tot_v * per / tot_d / 1e3,
+                            "all_launches_frac_of_peak": tot_v * per / tot_d / 1e3 / peak,
+                            "unit": "TOP/s (int8)" if i8 else "TFLOP/s (fp64)"}
     mf["source"] = f"rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace, bench.py --steps 1 --warmup 0 ({tag})"
     json.dump(mf, open("profiles/mfma_util.json", "w"), indent=1)
     print(json.dumps({"traffic64": t64["hbm_bytes_per_launch"] / t64["algorithmic_bytes_per_launch"],
