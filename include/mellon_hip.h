@@ -352,7 +352,9 @@ int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const 
  * [5] objective kernel time (sum, HIP events), [6] objective launches, [7] bytes of L streamed
  * per objective launch; [8] / [9] the same time / launch count for the warm-up passes of mln_map_solve on the
  * 32-bit copy (mixed precision: they stream 4 bytes per element, half of [7]); [10] the format of that copy:
- * 0 none, 1 fp32 values, 2 32-bit fixed point round(v 2^32) (covariances bounded by 1); [11] reserved.            */
+ * 0 none, 1 fp32 values, 2 32-bit fixed point round(v 2^32) (covariances bounded by 1); [11] seconds spent on
+ * other ranks' column blocks under MELLON_AMD_EMULATE_RANKS (tools/emulate_rank.py; 0 otherwise), already excluded
+ * from [3] and [4].                                                                                                  */
 #define MLN_N_STAGE_TIMES 12
 int mln_stage_times(mln_fit* fit, double* out /* MLN_N_STAGE_TIMES */);
 

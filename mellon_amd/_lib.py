@@ -698,7 +698,7 @@ class Fit:
         self.ctx._check(self.lib.mln_stage_times(self.handle, out.ctypes.data))
         keys = ["kernel_matrix_s", "cholesky_s", "trsm_s", "ridge_gram_s", "ridge_solve_s",
                 "objective_kernel_s", "objective_launches", "objective_bytes_per_launch",
-                "objective32_kernel_s", "objective32_launches", "copy32_format", "reserved"]
+                "objective32_kernel_s", "objective32_launches", "copy32_format", "emulation_excluded_s"]
         return dict(zip(keys, out.tolist()))
 
 

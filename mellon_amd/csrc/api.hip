@@ -462,6 +462,7 @@ struct mln_fit {
   double* eigU = nullptr;
   // fp32 copy of the streamed n x m buffer for the warm-up passes of the MAP solve (mixed precision)
   float* L32 = nullptr;
+  double emu_excluded = 0.0;    // MELLON_AMD_EMULATE_RANKS: wall seconds spent on the OTHER ranks' column blocks (tools/emulate_rank.py)
   bool cov_bounded01 = false;   // every covariance value lies in [0, 1] (stationary kernels and their products)
   int l32_fixed = 0;     // format of that copy: 0 = fp32, 1 = 32-bit fixed point (covariances bounded by 1)
   int evals32 = 0;
@@ -1006,6 +1007,95 @@ extern "C" int mln_diag_gram_i8(mln_ctx* ctx, const double* A, int64_t rows, int
 }
 
 // G ~ L^T L from every `row_stride`-th cell of this rank (scaled by row_stride), all-reduced.
+// ---- column-split m x m work (strong scaling) -----------------------------------------------------------
+// The whitening of the Gram and the inverses behind the per-evaluation products are "m right-hand sides through a
+// triangular solve": replicated, they cost every rank ~3.7 m^3 flops.  From 3 ranks on, rank r solves only its block of
+// columns [r b, (r + 1) b), writes it into a zeroed full matrix, and ONE all-reduce (a sum with zeros: exact, the same
+// bits on every rank) assembles the result -- 4 m^3 / N flops per rank for the whitening, 2 m^3 / N for the inverses.
+// MELLON_AMD_EMULATE_RANKS=N (tools/emulate_rank.py, one process): rank 0's block is timed, the other blocks are
+// computed too (the fit must go on) with their wall time recorded in emu_excluded.
+static int split_ranks(const mln_ctx* ctx, int* my_rank, bool* emulate) {
+  *my_rank = ctx->rank; *emulate = false;
+  int n = ctx->n_ranks;
+  if (n <= 1)
+    if (const char* ev = std::getenv("MELLON_AMD_EMULATE_RANKS")) { n = std::atoi(ev); *my_rank = 0; *emulate = n > 1; }
+  static const int from = std::getenv("MELLON_AMD_COLSPLIT_RANKS") ? std::atoi(std::getenv("MELLON_AMD_COLSPLIT_RANKS")) : 3;
+  return (from > 0 && n >= from) ? n : 1;
+}
+
+template <typename Body>
+static int for_my_column_blocks(mln_fit* f, int n_split, int my_rank, bool emulate, int64_t b, Body body) {
+  mln_ctx* ctx = f->ctx;
+  for (int r = 0; r < n_split; ++r) {
+    if (!emulate && r != my_rank) continue;
+    const int64_t c0 = (int64_t)r * b, nb = std::min<int64_t>(b, f->m - c0);
+    if (nb <= 0) continue;
+    const bool excluded = emulate && r != my_rank;
+    double t0 = 0.0;
+    if (excluded) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); t0 = now_s(); }
+    MLN_TRY(body(c0, nb));
+    if (excluded) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); f->emu_excluded += now_s() - t0; }
+  }
+  return MLN_OK;
+}
+
+// G (S = K_s^T K_s, all-reduced, symmetric) <- Lp^-1 S Lp^-T, columns split over the ranks
+static int fit_whiten_split(mln_fit* f, double* G, int64_t ldg, int n_split, int my_rank, bool emulate) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
+  double *Z = nullptr, *T = nullptr, *Out = nullptr;
+  const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ldg;
+  MLN_HIP(ctx, mln_dmalloc((void**)&Z, blk));
+  MLN_HIP(ctx, mln_dmalloc((void**)&T, blk));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Out, full));
+  int rc = (hipMemsetAsync(Out, 0, full, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  if (rc == MLN_OK)
+    rc = for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
+      MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
+      MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));             // unit columns c0 .. c0 + nb
+      MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // (Lp^-T)[:, block]
+      GemmArgs g{};                                                       // T = S (Lp^-T)[:, block]
+      g.A = G; g.lda = ldg; g.B = Z; g.ldb = b; g.C = T; g.ldc = b;
+      g.M = m; g.N = nb; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+      MLN_TRY(launch_dgemm(ctx, g));
+      MLN_TRY(triinv_solve_left(ctx, f->tri, T, nb, b));                  // Lp^-1 S Lp^-T [:, block]
+      return launch_copy_block(ctx, T, b, Out + c0, ldg, m, nb);
+    });
+  if (rc == MLN_OK) rc = (hipMemcpyAsync(G, Out, full, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)m * ldg);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(Z); (void)mln_dfree(T); (void)mln_dfree(Out);
+  return rc;
+}
+
+// inv (m x ld) <- C^-1 and P (m x ld) <- Lp^-T C^-T, column blocks of [C^-T ; P] split over the ranks (both zeroed
+// by the caller); tc: the block-scaled copies of C
+static int fit_inverses_split(mln_fit* f, const TriInv& tc, double* inv, double* P, int64_t ld, int n_split, int my_rank,
+                              bool emulate) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
+  double *Z = nullptr, *Q = nullptr;
+  const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ld;
+  MLN_HIP(ctx, mln_dmalloc((void**)&Z, blk));
+  MLN_HIP(ctx, mln_dmalloc((void**)&Q, 2 * full));                       // [C^-T ; P], this rank's columns only
+  int rc = (hipMemsetAsync(Q, 0, 2 * full, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  if (rc == MLN_OK)
+    rc = for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
+      MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
+      MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));
+      MLN_TRY(triinv_solve_left_T(ctx, tc, Z, nb, b));                    // (C^-T)[:, block]
+      MLN_TRY(launch_copy_block(ctx, Z, b, Q + c0, ld, m, nb));
+      MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // P[:, block] = Lp^-T (C^-T)[:, block]
+      return launch_copy_block(ctx, Z, b, Q + (size_t)m * ld + c0, ld, m, nb);
+    });
+  if (rc == MLN_OK) rc = dev_allreduce(ctx, Q, 2 * (int64_t)m * ld);
+  if (rc == MLN_OK) rc = launch_transpose(ctx, Q, ld, inv, ld, m);                                  // C^-1
+  if (rc == MLN_OK) rc = launch_copy_block(ctx, Q + (size_t)m * ld, ld, P, ld, m, ld);              // P
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(Z); (void)mln_dfree(Q);
+  return rc;
+}
+
 __global__ void k_round_bits(double* __restrict__ A, int64_t count, double scale) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
     A[i] = rint(A[i] * scale) / scale;
@@ -1029,7 +1119,7 @@ static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
   // from N = 7 on it is cheaper for every rank to whiten ITS rows first, L_s = K_s Lp^-T (rows x m^2 flops, < 2 m^3),
   // and to all-reduce the Gram of those -- the explicit route's arithmetic, no replicated solve, same single
   // collective.  (The choice depends on the rank count only, so every rank takes the same branch.)
-  static const int row_solve_from = std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS")) : 7;
+  static const int row_solve_from = std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS")) : 0;   // superseded by the column split (fit_whiten_split)
   if (ctx->n_ranks >= row_solve_from && row_solve_from > 0) {
     double* R = nullptr;
     const int64_t rr = rows > 0 ? rows : 1;
@@ -1061,6 +1151,11 @@ static int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
     bool quant = f->cov_bounded01 && f->m >= 256 && row_stride > 1;
     if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
     rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
+  }
+  {
+    int my_rank = 0; bool emulate = false;
+    const int n_split = split_ranks(ctx, &my_rank, &emulate);
+    if (rc == MLN_OK && n_split > 1) return fit_whiten_split(f, G, ldg, n_split, my_rank, emulate);
   }
   double* T = nullptr;
   if (rc == MLN_OK) {
@@ -1103,11 +1198,13 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
   const size_t bytes = sizeof(double) * (size_t)m * ldg;
-  double t0 = now_s();
+  double t0 = now_s(), ex0 = f->emu_excluded;
   MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
   int rc = fit_gram(f, f->C, ldg, row_stride);
-  f->times[3] += now_s() - t0;
-  t0 = now_s();
+  f->times[3] += now_s() - t0 - (f->emu_excluded - ex0);
+  t0 = now_s(); ex0 = f->emu_excluded;
+  int my_rank = 0; bool emulate = false;
+  const int n_split = f->kspace ? split_ranks(ctx, &my_rank, &emulate) : 1;
   if (rc == MLN_OK) rc = launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1
   if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, f->C, m, ldg);
   TriInv t;
@@ -1118,6 +1215,12 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
     if (e == hipSuccess) e = hipMemsetAsync(inv, 0, bytes, ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc C^-1", __FILE__, __LINE__);
   }
+  if (rc == MLN_OK && n_split > 1) {                                // column blocks over the ranks, one all-reduce
+    hipError_t e = mln_dmalloc((void**)&f->P, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(f->P, 0, bytes, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
+    if (rc == MLN_OK) rc = fit_inverses_split(f, t, inv, f->P, ldg, n_split, my_rank, emulate);
+  } else {
   if (rc == MLN_OK) rc = launch_add_diag(ctx, inv, m, ldg, 1.0);
   if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg, true);   // C^-1 = C^-1 I (lower triangular B)
   if (rc == MLN_OK && f->kspace) {                                  // P = Lp^-T C^-T
@@ -1126,6 +1229,7 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
     if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);
     if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, f->P, m, ldg, true);   // C^-T is upper triangular
+  }
   }
   if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs
     const int64_t ld = ldg;
@@ -1155,7 +1259,7 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&t);
   if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
-  f->times[4] += now_s() - t0;
+  f->times[4] += now_s() - t0 - (f->emu_excluded - ex0);
   return rc;
 }
 
@@ -1509,7 +1613,7 @@ extern "C" int mln_stage_times(mln_fit* f, double* out) {
   out[8] = f->times32;                                  // 32-bit warm-up passes: kernel seconds (HIP events)
   out[9] = (double)f->evals32;                          //                        launches
   out[10] = f->L32 ? (f->l32_fixed ? 2.0 : 1.0) : 0.0;  //                        format of the copy
-  out[11] = 0.0;
+  out[11] = f->emu_excluded;                            // MELLON_AMD_EMULATE_RANKS: seconds spent on other ranks' blocks
   return MLN_OK;
 }
 
