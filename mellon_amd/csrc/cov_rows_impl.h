@@ -113,6 +113,15 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
     const int64_t row = row0 + lk + 4 * r;
     xr[r] = (row < n) ? xx[row] : 0.0;
   }
+  // Store addresses of the branch-free epilogue: a wave-uniform base per workgroup (SGPR pair) + a 32-bit element index
+  // per lane, shared by the fp64 buffer and its 32-bit copy.  Two sets of four 64-bit lane addresses pushed the variant
+  // with the copy over its register budget: the compiler then re-issued the staging loads late, each followed by
+  // s_waitcnt vmcnt(0) -- a drain of all 64 stores in flight, seven times per tile (25.3 ms against 21.0 without the copy).
+  double* const out_wg = out + (int64_t)blockIdx.x * 128 * ldo;
+  float* const out32_wg = HAS32 ? out32 + (int64_t)blockIdx.x * 128 * ldo : nullptr;
+  unsigned lrow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lrow[r] = (unsigned)(wave * 16 + lk + 4 * r) * (unsigned)ldo + (unsigned)li;
   for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;
   __syncthreads();
   const int cnt = TN * d;
@@ -187,10 +196,10 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
         const double yc = yn[cur][16 * tt + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = row0 + lk + 4 * r;
           const double v = leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]);
-          out[row * ldo + c] = v;
-          if (HAS32) out32[row * ldo + c] = surrogate_bits(v, q32);
+          const unsigned e = lrow[r] + (unsigned)col0 + 16u * tt;
+          out_wg[e] = v;
+          if (HAS32) out32_wg[e] = surrogate_bits(v, q32);
         }
       }
 #pragma unroll

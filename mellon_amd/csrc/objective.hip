@@ -242,6 +242,8 @@ __device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t l
 
 // element of the 32-bit copy as a double: an fp32 value, or (FIXED) the integer numerator of a 32-bit fixed-point
 // number -- its 2^-32 is folded into z on the way in and into the gradient partials on the way out, both exact
+// (tried: the integer as the mantissa of 2^52 + u, minus 2^52 -- one full-rate v_add_f64 in place of v_cvt_f64_u32:
+//  3.20 instead of 3.10 ms per pass; the conversion is not what bounds this kernel)
 template <bool FIXED>
 __device__ __forceinline__ double elem32(float v) {
   return FIXED ? (double)__float_as_uint(v) : (double)v;
@@ -567,7 +569,14 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
     switch (cq) {
       case 1: return launch_f32<1, 8>(ctx, a);
       case 2: return launch_f32<2, 4>(ctx, a);
-      case 3: return launch_f32<3, 3>(ctx, a);
+      case 3: {
+        static const int r3 = std::getenv("MELLON_AMD_OBJ32_ROWS") ? std::atoi(std::getenv("MELLON_AMD_OBJ32_ROWS")) : 3;
+        if (r3 == 4) return launch_f32<3, 4>(ctx, a);
+        if (r3 == 5) return launch_f32<3, 5>(ctx, a);
+        if (r3 == 2) return launch_f32<3, 2>(ctx, a);
+        if (r3 == 1) return launch_f32<3, 1>(ctx, a);
+        return launch_f32<3, 3>(ctx, a);
+      }
       default: return launch_f32<4, 2>(ctx, a);
     }
   }

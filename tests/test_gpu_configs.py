@@ -63,8 +63,9 @@ def test_c3_full_size_properties(ctx, c3):
 
 
 def test_c3_full_size_fp64_only_and_sharded(ctx, c3, monkeypatch):
-    """The same fit (i) without the fp32 warm-up passes and (ii) cell-sharded over two thread-ranks with real
-    collectives: same log-density."""
+    """The same fit (i) without the 32-bit copy (every pass fp64) and (ii) cell-sharded over four thread-ranks with real
+    collectives -- from three ranks on the whitening of the Gram and the inverses of the preconditioner are split by
+    columns over the ranks: same log-density."""
     import mellon_amd
     from mellon_amd import distributed
     x, lm, nn = c3
@@ -86,7 +87,7 @@ def test_c3_full_size_fp64_only_and_sharded(ctx, c3, monkeypatch):
         e._fit.close()
         return out
 
-    sharded = np.concatenate(distributed.run_loopback(2, body))
+    sharded = np.concatenate(distributed.run_loopback(4, body))
     assert relmax(sharded, dens) < 1e-6
 
 
