@@ -199,7 +199,8 @@ __global__ void k_copy_below_blocks(const double* __restrict__ src, double* __re
 // block columns.  Per step: k_potrf128 (potrf.hip: the diagonal block and its inverse, one workgroup), the rest of
 // the block column as one GEMM  P = A_panel T^-T  written to a side matrix (no aliasing -> the 64 x 64 latency tiles
 // apply: with <= 39 row tiles a 128-tile launch is 14 us of serial work per CU), the trailing update as one
-// lower-tiles-only GEMM  A22 -= P P^T.  The side matrix is copied under the block diagonal of A at the end.
+// lower-tiles-only GEMM  A22 -= P P^T per PAIR of block columns.  The side matrix is copied under the block diagonal of
+// A at the end.
 int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   if (m <= 0) return MLN_OK;
   constexpr int CB = 128;
@@ -210,24 +211,42 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (m > CB) MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)m * (size_t)lda));
   int rc = MLN_OK;
-  for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += CB) {
-    const int nb = (int)((m - j0 < CB) ? (m - j0) : CB);
-    double* Ajj = A + j0 * lda + j0;
-    rc = launch_potrf128(ctx, Ajj, lda, nb, Dinv, ctx->d_info, j0);
+  // Two block columns per round: the second one is brought up to date by a narrow GEMM (K = 128, 128 columns), and the
+  // big trailing update then runs ONCE with K = 256 on the two panels side by side in the side matrix -- the same flops
+  // as two K = 128 updates over nearly the same area, at half the per-tile prologue/epilogue cost.
+  auto panel = [&](int64_t j, int nb, int64_t rem) -> int {          // P = A[j+nb.., j..j+nb] Dinv^T -> side matrix
+    GemmArgs g{};
+    g.A = A + (j + nb) * lda + j; g.lda = lda; g.B = Dinv; g.ldb = CB; g.C = Ls + (j + nb) * lda + j; g.ldc = lda;
+    g.M = rem; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
+    return launch_dgemm(ctx, g);
+  };
+  for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += 2 * CB) {
+    const int nb1 = (int)((m - j0 < CB) ? (m - j0) : CB);
+    rc = launch_potrf128(ctx, A + j0 * lda + j0, lda, nb1, Dinv, ctx->d_info, j0);
+    const int64_t rem1 = m - j0 - nb1;
+    if (rc != MLN_OK || rem1 <= 0) break;
+    rc = panel(j0, nb1, rem1);
     if (rc != MLN_OK) break;
-    const int64_t rem = m - j0 - nb;
-    if (rem > 0) {
-      double* P = Ls + (j0 + nb) * lda + j0;
-      GemmArgs g{};  // P = A_panel * Dinv^T
-      g.A = A + (j0 + nb) * lda + j0; g.lda = lda; g.B = Dinv; g.ldb = CB; g.C = P; g.ldc = lda;
-      g.M = rem; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
-      rc = launch_dgemm(ctx, g);
+    const int64_t j1 = j0 + nb1;
+    const int nb2 = (int)((rem1 < CB) ? rem1 : CB);
+    const double* P1 = Ls + j1 * lda + j0;
+    {
+      GemmArgs u{};   // block column j1 only: A[j1.., j1..j1+nb2] -= P1 P1[0:nb2]^T
+      u.A = P1; u.lda = lda; u.B = P1; u.ldb = lda; u.C = A + j1 * lda + j1; u.ldc = lda;
+      u.M = rem1; u.N = nb2; u.K = nb1; u.alpha = -1.0; u.beta = 1.0; u.ta = 0; u.tb = 1;
+      rc = launch_dgemm(ctx, u);
       if (rc != MLN_OK) break;
-      GemmArgs s{};  // A22 -= P P^T on lower tiles
-      s.A = P; s.lda = lda; s.B = P; s.ldb = lda; s.C = A + (j0 + nb) * lda + (j0 + nb); s.ldc = lda;
-      s.M = rem; s.N = rem; s.K = nb; s.alpha = -1.0; s.beta = 1.0; s.ta = 0; s.tb = 1; s.lower_only = 1;
-      rc = launch_dgemm(ctx, s);
     }
+    rc = launch_potrf128(ctx, A + j1 * lda + j1, lda, nb2, Dinv, ctx->d_info, j1);
+    const int64_t rem2 = rem1 - nb2;
+    if (rc != MLN_OK || rem2 <= 0) break;
+    rc = panel(j1, nb2, rem2);
+    if (rc != MLN_OK) break;
+    GemmArgs t{};     // A22 -= [P1' P2] [P1' P2]^T on lower tiles, K = nb1 + nb2
+    const double* Pw = Ls + (j1 + nb2) * lda + j0;
+    t.A = Pw; t.lda = lda; t.B = Pw; t.ldb = lda; t.C = A + (j1 + nb2) * lda + (j1 + nb2); t.ldc = lda;
+    t.M = rem2; t.N = rem2; t.K = nb1 + nb2; t.alpha = -1.0; t.beta = 1.0; t.ta = 0; t.tb = 1; t.lower_only = 1;
+    rc = launch_dgemm(ctx, t);
   }
   int info = 0;
   if (rc == MLN_OK) {

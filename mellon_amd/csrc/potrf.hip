@@ -8,7 +8,8 @@
 //   T (128 x 130 doubles, row stride = 2 mod 32 so that "16 rows x 2 k" MFMA operand reads touch every bank once)
 //   eight micro-steps over 16-column panels:
 //     (a) wave 0: Cholesky of the 16 x 16 diagonal tile in registers (lane i = row i, v_readlane broadcasts, no
-//         barrier) and its inverse X_pp
+//         barrier) and its inverse X_pp -- for panel p + 1 this runs UNDER step (c) of panel p (look-ahead: wave 0
+//         updates the next diagonal tile first, then factors it while waves 1-3 update the other tiles)
 //     (b) all waves: L_ip = A_ip X_pp^T for the tiles below                     (4 x v_mfma_f64_16x16x4 per tile)
 //     (c) all waves: A_ij -= L_ip L_jp^T for the lower tiles right of the panel (4 MFMAs per tile)
 //   then X = T^-1 by block columns: wave w owns block columns w and 7 - w and keeps X_kj in registers -- the D layout
@@ -51,56 +52,75 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
   }
   __syncthreads();
 
-  for (int p = 0; p < NMB; ++p) {
+  // (a) diagonal tile p: Cholesky in registers + inverse, by wave 0 alone (every 16-lane group computes the same thing)
+  auto diag_tile = [&](int p) {
     const int c0 = p * MB;
-    // ---- (a) diagonal tile: factor + inverse, wave 0 (every 16-lane group computes the same thing) ----------
-    if (wave == 0) {
-      const int li = lane & 15;
-      double a[MB];
+    const int li = lane & 15;
+    double a[MB];
 #pragma unroll
-      for (int j = 0; j < MB; ++j) a[j] = (j <= li) ? T[(c0 + li) * LDT + c0 + j] : 0.0;
-      double dinv[MB];
-      bool bad = false;
+    for (int j = 0; j < MB; ++j) a[j] = (j <= li) ? T[(c0 + li) * LDT + c0 + j] : 0.0;
+    double dinv[MB];
+    bool bad = false;
 #pragma unroll
-      for (int k = 0; k < MB; ++k) {
-        const double dk = bcast_lane(a[k], k);
-        if (!(dk > 0.0)) {   // wave-uniform
-          if (!bad && lane == 0) { atomicCAS(info, 0, (int)(j0 + c0 + k + 1)); bad_s = 1; }
-          bad = true;
-        }
-        double inv = __builtin_amdgcn_rsq(dk);
-        inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
-        inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
-        double sq = dk * inv;
-        sq = fma(0.5 * inv, fma(-sq, sq, dk), sq);
-        dinv[k] = inv;
-        const double lik = (li == k) ? sq : ((li > k) ? a[k] * inv : 0.0);
-        a[k] = lik;
-#pragma unroll
-        for (int j = k + 1; j < MB; ++j) {
-          const double ljk = bcast_lane(lik, j);
-          a[j] = fma(-lik, ljk, a[j]);
-        }
+    for (int k = 0; k < MB; ++k) {
+      const double dk = bcast_lane(a[k], k);
+      if (!(dk > 0.0)) {   // wave-uniform
+        if (!bad && lane == 0) { atomicCAS(info, 0, (int)(j0 + c0 + k + 1)); bad_s = 1; }
+        bad = true;
       }
-      // X = L^-1, lane c owns column c:  x_i = (delta_ic - sum_{k<i} L_ik x_k) / L_ii   (L_ik = a[k] of lane i)
-      double x[MB];
+      double inv = __builtin_amdgcn_rsq(dk);
+      inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
+      inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
+      double sq = dk * inv;
+      sq = fma(0.5 * inv, fma(-sq, sq, dk), sq);
+      dinv[k] = inv;
+      const double lik = (li == k) ? sq : ((li > k) ? a[k] * inv : 0.0);
+      a[k] = lik;
 #pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        double s = (i == li) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) s = fma(-bcast_lane(a[k], i), x[k], s);
-        x[i] = s * dinv[i];
-      }
-      if (lane < MB) {
-#pragma unroll
-        for (int j = 0; j < MB; ++j) {
-          T[(c0 + li) * LDT + c0 + j] = (j <= li) ? a[j] : 0.0;
-          Xd[(p * MB + j) * LDX + li] = x[j];    // X[j][li]
-        }
+      for (int j = k + 1; j < MB; ++j) {
+        const double ljk = bcast_lane(lik, j);
+        a[j] = fma(-lik, ljk, a[j]);
       }
     }
-    __syncthreads();
-    if (bad_s) return;   // uniform: leave the block unfactorised, *info says where
+    // X = L^-1, lane c owns column c:  x_i = (delta_ic - sum_{k<i} L_ik x_k) / L_ii   (L_ik = a[k] of lane i)
+    double x[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      double s = (i == li) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s = fma(-bcast_lane(a[k], i), x[k], s);
+      x[i] = s * dinv[i];
+    }
+    if (lane < MB) {
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        T[(c0 + li) * LDT + c0 + j] = (j <= li) ? a[j] : 0.0;
+        Xd[(p * MB + j) * LDX + li] = x[j];    // X[j][li]
+      }
+    }
+  };
+  // (c) one trailing tile: A_ij -= L_ip L_jp^T
+  auto trailing_tile = [&](int p, int t) {
+    const int c0 = p * MB;
+    int ii = 0, rem = t;           // t -> (ii, jj) with 0 <= jj <= ii, row-major over the lower triangle
+    while (rem > ii) { rem -= ii + 1; ++ii; }
+    const int jj = rem;
+    const int r0 = (p + 1 + ii) * MB, q0 = (p + 1 + jj) * MB;
+    v4d acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = T[(r0 + (lane >> 4) + 4 * r) * LDT + q0 + (lane & 15)];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag(T, LDT, r0, c0, s, lane), frag(T, LDT, q0, c0, s, lane), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T[(r0 + (lane >> 4) + 4 * r) * LDT + q0 + (lane & 15)] = acc[r];
+  };
+
+  if (wave == 0) diag_tile(0);
+  __syncthreads();
+  if (bad_s) return;   // uniform: leave the block unfactorised, *info says where
+  for (int p = 0; p < NMB; ++p) {
+    const int c0 = p * MB;
     // ---- (b) panel tiles below the diagonal: L_ip = A_ip X_pp^T ---------------------------------------------
     for (int i = p + 1 + wave; i < NMB; i += 4) {
       const int r0 = i * MB;
@@ -114,27 +134,21 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
       for (int r = 0; r < 4; ++r) T[(r0 + (lane >> 4) + 4 * r) * LDT + c0 + (lane & 15)] = acc[r];
     }
     __syncthreads();
-    // ---- (c) trailing tiles: A_ij -= L_ip L_jp^T, p < j <= i ---------------------------------------------------
+    if (p + 1 == NMB) break;
+    // ---- (c) trailing tiles, with look-ahead: wave 0 updates the NEXT diagonal tile first and factors it right away
+    //      (the serial 16-step recurrence of (a): ~3 us) while waves 1-3 update the other tiles ----------------------
     {
       const int nt = NMB - 1 - p;               // tiles per side
       const int ntri = nt * (nt + 1) / 2;
-      for (int t = wave; t < ntri; t += 4) {
-        // t -> (ii, jj) with 0 <= jj <= ii < nt, row-major over the lower triangle
-        int ii = 0, rem = t;
-        while (rem > ii) { rem -= ii + 1; ++ii; }
-        const int jj = rem;
-        const int r0 = (p + 1 + ii) * MB, q0 = (p + 1 + jj) * MB;
-        v4d acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = T[(r0 + (lane >> 4) + 4 * r) * LDT + q0 + (lane & 15)];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag(T, LDT, r0, c0, s, lane), frag(T, LDT, q0, c0, s, lane), acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[(r0 + (lane >> 4) + 4 * r) * LDT + q0 + (lane & 15)] = acc[r];
+      if (wave == 0) {
+        trailing_tile(p, 0);                    // tile (p + 1, p + 1); LDS operations of one wave complete in order
+        diag_tile(p + 1);
+      } else {
+        for (int t = wave; t < ntri; t += 3) trailing_tile(p, t);
       }
     }
     __syncthreads();
+    if (bad_s) return;
   }
 
   // ---- factor back to global memory (strict upper part of the block zeroed) ------------------------------------
