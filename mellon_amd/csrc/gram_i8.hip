@@ -14,7 +14,7 @@
 // Lp^-1 S Lp^-T + I then stops being positive definite (seen at C3 with the low products dropped).
 // At ~4 Pop/s against 78 Tflop/s of fp64 MFMA the 1.5 Tflop fp64 GEMM of C3 (35.7 ms) becomes 13.5 Top (a few ms).
 //
-// Layout: the digit planes are stored TRANSPOSED, plane a = [landmark i][sampled cell k] with k contiguous, so that
+// Layout: the digit planes are stored TRANSPOSED (and tiled, see k_gram_digits), plane a = [landmark i][sampled cell k] with k contiguous, so that
 // both operands of the Gram are "k-contiguous rows": a lane's MFMA operand (16 consecutive k of one landmark) is one
 // 16-byte LDS read, and A and B use the same lane -> k map, so the k order inside the instruction does not matter.
 #include "mln_internal.h"
@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void k_gram_digits(const double* __restrict__ 
     v4i_t o;
     o.x = (int)tile[a][oi][seg * 4 + 0]; o.y = (int)tile[a][oi][seg * 4 + 1];
     o.z = (int)tile[a][oi][seg * 4 + 2]; o.w = (int)tile[a][oi][seg * 4 + 3];
-    *reinterpret_cast<v4i_t*>(planes + ((int64_t)a * Mp + i0 + oi) * Kp + k0 + seg * 16) = o;
+    // tiled layout: [plane][128-landmark tile][64-cell chunk][landmark in tile][64 bytes] -- what one stage of k_gram_i8
+    // loads per operand and plane is ONE contiguous 8 KB block (full cache lines; 64-byte pieces of Kp-strided rows
+    // made every line travel twice)
+    const int64_t gi2 = i0 + oi;
+    *reinterpret_cast<v4i_t*>(planes + (int64_t)a * Mp * Kp + (((gi2 >> 7) * (Kp >> 6) + (k0 >> 6)) * 128 + (gi2 & 127)) * 64 +
+                              seg * 16) = o;
   }
 }
 
@@ -80,55 +85,66 @@ struct GramTile { int ti, tj; };
 // One sweep over the k-chunk for one 128 x 128 tile.  PASS 0: the six digit products of weight >= 2 (three int32
 // accumulators per element); PASS 1: the three of weight <= 1 (two accumulators, planes 0 and 1 only).  Five
 // accumulators at once would be 320 registers per lane for them alone -- the two sweeps cost the same MFMAs and keep
-// every accumulator in place.  res (fp64, 16 x 4 per lane) += sum_w 256^w acc_w.
-template <int PASS>
+// every accumulator in place.  res (fp64) += sum_w 256^w acc_w.
+// NW waves per workgroup: 4 (wave tile 64 x 64, one wave per SIMD, 2 MFMAs per operand read) or 8 (wave tile 64 x 32,
+// two waves per SIMD hide each other's LDS latency and barrier waits, 1.3 MFMAs per operand read).
+template <int PASS, int NW>
 __device__ __forceinline__ void gram_sweep(unsigned char* lds, const int8_t* gA, const int8_t* gB, int64_t plane_sz, int64_t half,
-                                           int n_steps, int ldst0, int fa, int fb, double (&res)[2][2][16]) {
+                                           int n_steps, int ldst0, int fa, int fb, double (&res)[2][8 / NW][16]) {
   constexpr int NP = PASS == 0 ? 3 : 2;       // planes staged
   constexpr int NA = PASS == 0 ? 3 : 2;       // accumulators (weights 4, 3, 2 | 1, 0)
-  v4i_t stage[2 * NP];
-  auto g_load = [&](int st, int o) {
+  constexpr int NBJ = 8 / NW;                 // 32-column blocks per wave
+  constexpr int NRH = 512 / (64 * NW);        // row halves a thread stages per plane (64 NW / 4 rows per sweep of the threads)
+  // global -> registers -> LDS, both operands of a stage at once, ONE FULL STAGE ahead: the loads of stage st + 2 are
+  // issued at the top of stage st, right after the registers holding stage st + 1 went to LDS, and have the whole stage
+  // (24-48 MFMAs per SIMD) to land.  (Half a stage ahead, the matrix pipe was busy 34 % of the time.)
+  v4i_t stage[2][NRH * NP];
+  auto g_load = [&](int st) {
 #pragma unroll
-    for (int j = 0; j < 2 * NP; ++j) {
-      const int8_t* src = (o == 0 ? gA : gB) + (j >> 1) * plane_sz + (j & 1) * half + (int64_t)st * GBK;
-      stage[j] = *reinterpret_cast<const v4i_t*>(src);
-    }
-  };
-  auto l_store = [&](int buf, int o) {
+    for (int o = 0; o < 2; ++o)
 #pragma unroll
-    for (int j = 0; j < 2 * NP; ++j)
-      *reinterpret_cast<v4i_t*>(lds + buf * GSTAGE + ldst0 + ((o * 3 + (j >> 1)) * GT + 64 * (j & 1)) * GROW) = stage[j];
+      for (int j = 0; j < NRH * NP; ++j) {
+        const int8_t* src = (o == 0 ? gA : gB) + (j / NRH) * plane_sz + (j % NRH) * half + (int64_t)st * (GT * GBK);
+        stage[o][j] = *reinterpret_cast<const v4i_t*>(src);
+      }
   };
-  v16i_t acc[NA][2][2];
+  auto l_store = [&](int buf) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int j = 0; j < NRH * NP; ++j)
+        *reinterpret_cast<v4i_t*>(lds + buf * GSTAGE + ldst0 + ((o * 3 + (j / NRH)) * GT + 64 * (j % NRH)) * GROW) = stage[o][j];
+  };
+  v16i_t acc[NA][2][NBJ];
 #pragma unroll
   for (int w = 0; w < NA; ++w)
 #pragma unroll
     for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj) acc[w][bi][bj] = v16i_t{};
+      for (int bj = 0; bj < NBJ; ++bj) acc[w][bi][bj] = v16i_t{};
 
-  g_load(0, 0); l_store(0, 0);
-  g_load(0, 1); l_store(0, 1);
+  g_load(0); l_store(0);
+  if (n_steps > 1) g_load(1);
   lds_barrier();
   for (int st = 0; st < n_steps; ++st) {
     const int buf = st & 1;
-    const bool more = st + 1 < n_steps;
+    if (st + 1 < n_steps) l_store(buf ^ 1);       // stage st + 1: requested one stage ago; its LDS buffer was released
+    if (st + 2 < n_steps) g_load(st + 2);         // by the barrier that ended stage st - 1
     const unsigned char* base = lds + buf * GSTAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (more) g_load(st + 1, ks);
-      v4i_t A[NP][2], B[NP][2];
+      v4i_t A[NP][2], B[NP][NBJ];
 #pragma unroll
-      for (int a = 0; a < NP; ++a)
+      for (int a = 0; a < NP; ++a) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          A[a][b] = *reinterpret_cast<const v4i_t*>(base + fa + (a * GT + b * 32) * GROW + ks * 32);
-          B[a][b] = *reinterpret_cast<const v4i_t*>(base + fb + (a * GT + b * 32) * GROW + ks * 32);
-        }
+        for (int b = 0; b < 2; ++b) A[a][b] = *reinterpret_cast<const v4i_t*>(base + fa + (a * GT + b * 32) * GROW + ks * 32);
+#pragma unroll
+        for (int b = 0; b < NBJ; ++b) B[a][b] = *reinterpret_cast<const v4i_t*>(base + fb + (a * GT + b * 32) * GROW + ks * 32);
+      }
 #pragma unroll
       for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj) {
+        for (int bj = 0; bj < NBJ; ++bj) {
           if constexpr (PASS == 0) {
             acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2][bi], B[2][bj], acc[0][bi][bj], 0, 0, 0);
             acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][bi], B[2][bj], acc[1][bi][bj], 0, 0, 0);
@@ -142,14 +158,13 @@ __device__ __forceinline__ void gram_sweep(unsigned char* lds, const int8_t* gA,
             acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][bi], B[0][bj], acc[1][bi][bj], 0, 0, 0);
           }
         }
-      if (more) l_store(buf ^ 1, ks);
     }
     lds_barrier();
   }
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
+    for (int bj = 0; bj < NBJ; ++bj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if constexpr (PASS == 0)
@@ -161,9 +176,10 @@ __device__ __forceinline__ void gram_sweep(unsigned char* lds, const int8_t* gA,
 }
 
 // One 128 x 128 tile (ti >= tj) of one k-chunk: parts[split][i][j] = scale sum_w 256^w acc_w
-__global__ __launch_bounds__(256, 1) void k_gram_i8(const int8_t* __restrict__ planes, int64_t Mp, int64_t Kp, int64_t kchunk,
-                                                    const GramTile* __restrict__ tiles, int n_tiles, int n_wg, double scale,
-                                                    double* __restrict__ parts, int64_t ldg, int64_t part_stride, int64_t m) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_gram_i8(const int8_t* __restrict__ planes, int64_t Mp, int64_t Kp, int64_t kchunk,
+                                                        const GramTile* __restrict__ tiles, int n_tiles, int n_wg, double scale,
+                                                        double* __restrict__ parts, int64_t ldg, int64_t part_stride, int64_t m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so XCD x gets the contiguous range
   // [x n_wg / 8, (x + 1) n_wg / 8) of the logical order -- neighbouring tiles (shared landmark blocks), same k-chunk
@@ -173,29 +189,32 @@ __global__ __launch_bounds__(256, 1) void k_gram_i8(const int8_t* __restrict__ p
   if (logical >= n_wg) return;
   const int split = logical / n_tiles;
   const GramTile tl = tiles[logical - split * n_tiles];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, wi = w >> 1, wj = w & 1;
+  constexpr int NBJ = 8 / NW, WJ = 64 / (32 * NBJ) * 1;   // column blocks per wave; waves per 64 columns
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wi = (NW == 4) ? (w >> 1) : (w >> 2), wj = (NW == 4) ? (w & 1) : (w & 3);
   const int64_t kbeg = (int64_t)split * kchunk;
   const int n_steps = (int)(kchunk / GBK);
   const int64_t plane_sz = Mp * Kp;
   // global -> register -> LDS staging: 16-byte chunks, one 64-bit address per operand, the rest wave-uniform
   const int seg = t & 3, r0 = t >> 2;
-  const int8_t* gA = planes + ((int64_t)tl.ti * GT + r0) * Kp + kbeg + seg * 16;
-  const int8_t* gB = planes + ((int64_t)tl.tj * GT + r0) * Kp + kbeg + seg * 16;
-  const int64_t half = 64 * Kp;
+  const int8_t* gA = planes + (((int64_t)tl.ti * (Kp >> 6) + (kbeg >> 6)) * GT + r0) * GBK + seg * 16;   // tiled layout, see k_gram_digits
+  const int8_t* gB = planes + (((int64_t)tl.tj * (Kp >> 6) + (kbeg >> 6)) * GT + r0) * GBK + seg * 16;
+  const int64_t half = 64 * GBK;
   const int ldst0 = r0 * GROW + seg * 16;
-  const int fa = ((wi * 64 + (lane & 31)) * GROW) + (lane >> 5) * 16;                    // operand A: rows of tile ti
-  const int fb = (3 * GT * GROW) + ((wj * 64 + (lane & 31)) * GROW) + (lane >> 5) * 16;  // operand B: rows of tile tj
+  const int fa = ((wi * 64 + (lane & 31)) * GROW) + (lane >> 5) * 16;                             // operand A: rows of tile ti
+  const int fb = (3 * GT * GROW) + ((wj * 32 * NBJ + (lane & 31)) * GROW) + (lane >> 5) * 16;     // operand B: rows of tile tj
+  (void)WJ;
 
-  double res[2][2][16];
-  gram_sweep<0>(lds, gA, gB, plane_sz, half, n_steps, ldst0, fa, fb, res);
-  gram_sweep<1>(lds, gA, gB, plane_sz, half, n_steps, ldst0, fa, fb, res);
+  double res[2][NBJ][16];
+  gram_sweep<0, NW>(lds, gA, gB, plane_sz, half, n_steps, ldst0, fa, fb, res);
+  gram_sweep<1, NW>(lds, gA, gB, plane_sz, half, n_steps, ldst0, fa, fb, res);
 
   double* out = parts + (int64_t)split * part_stride;
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const int64_t gj = (int64_t)tl.tj * GT + wj * 64 + bj * 32 + (lane & 31);
+    for (int bj = 0; bj < NBJ; ++bj) {
+      const int64_t gj = (int64_t)tl.tj * GT + wj * 32 * NBJ + bj * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t gi = (int64_t)tl.ti * GT + wi * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -249,18 +268,26 @@ int launch_gram_i8(mln_ctx* ctx, const double* K, int64_t ldk, int64_t rows, int
   if (rc == MLN_OK) {
     hipLaunchKernelGGL(k_gram_digits, dim3((unsigned)(Kp / 64), (unsigned)(Mp / 64)), dim3(256), 0, ctx->stream, K, ldk, rows, m,
                        planes, Mp, Kp);
+    static const int n_waves = std::getenv("MELLON_AMD_GRAM_I8_WAVES") ? std::atoi(std::getenv("MELLON_AMD_GRAM_I8_WAVES")) : 8;
     static bool attr_set = false;
     const int lds_bytes = 2 * GSTAGE;
     if (!attr_set) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_i8), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_i8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_i8<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
       if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "gram_i8 LDS size", __FILE__, __LINE__);
       attr_set = true;
     }
     if (rc == MLN_OK) {
       const int n_wg = n_tiles * n_splits;
       const int grid = (n_wg + 7) / 8 * 8;
-      hipLaunchKernelGGL(k_gram_i8, dim3((unsigned)grid), dim3(256), lds_bytes, ctx->stream, planes, Mp, Kp, kchunk, d_tiles,
-                         n_tiles, n_wg, alpha / ((double)GQ_SCALE * (double)GQ_SCALE), parts, ldg, part_stride, m);
+      const double scale = alpha / ((double)GQ_SCALE * (double)GQ_SCALE);
+      if (n_waves == 4)
+        hipLaunchKernelGGL(k_gram_i8<4>, dim3((unsigned)grid), dim3(256), lds_bytes, ctx->stream, planes, Mp, Kp, kchunk, d_tiles,
+                           n_tiles, n_wg, scale, parts, ldg, part_stride, m);
+      else
+        hipLaunchKernelGGL(k_gram_i8<8>, dim3((unsigned)grid), dim3(512), lds_bytes, ctx->stream, planes, Mp, Kp, kchunk, d_tiles,
+                           n_tiles, n_wg, scale, parts, ldg, part_stride, m);
       e = hipGetLastError();
       if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "k_gram_i8", __FILE__, __LINE__);
     }
