@@ -28,11 +28,7 @@ def test_header_and_binding_agree(lib):
 
 def test_no_cpu_fallback(lib):
     import ctypes as C
-    try:
-        import torch
-        has_gpu = torch.cuda.is_available()
-    except Exception:
-        has_gpu = os.path.exists("/dev/kfd")
+    has_gpu = os.path.exists("/dev/kfd")
     if has_gpu:
         pytest.skip("GPU present")
     from mellon_amd import _lib
