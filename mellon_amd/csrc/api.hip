@@ -1023,6 +1023,19 @@ extern "C" int mln_diag_gram_i8(mln_ctx* ctx, const double* A, int64_t rows, int
 }
 
 // G ~ L^T L from every `row_stride`-th cell of this rank (scaled by row_stride), all-reduced.
+// device scratch that frees itself (after draining the stream) on every exit path
+struct DevScratch {
+  mln_ctx* ctx;
+  double* p = nullptr;
+  explicit DevScratch(mln_ctx* c) : ctx(c) {}
+  hipError_t alloc(size_t bytes) { return mln_dmalloc((void**)&p, bytes); }
+  ~DevScratch() {
+    if (p) { (void)hipStreamSynchronize(ctx->stream); (void)mln_dfree(p); }
+  }
+  DevScratch(const DevScratch&) = delete;
+  DevScratch& operator=(const DevScratch&) = delete;
+};
+
 // ---- column-split m x m work (strong scaling) -----------------------------------------------------------
 // The whitening of the Gram and the inverses behind the per-evaluation products are "m right-hand sides through a
 // triangular solve": replicated, they cost every rank ~3.7 m^3 flops.  From 3 ranks on, rank r solves only its block of
@@ -1059,29 +1072,28 @@ static int for_my_column_blocks(mln_fit* f, int n_split, int my_rank, bool emula
 static int fit_whiten_split(mln_fit* f, double* G, int64_t ldg, int n_split, int my_rank, bool emulate) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
-  double *Z = nullptr, *T = nullptr, *Out = nullptr;
+  DevScratch zb(ctx), tb(ctx), ob(ctx);
   const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ldg;
-  MLN_HIP(ctx, mln_dmalloc((void**)&Z, blk));
-  MLN_HIP(ctx, mln_dmalloc((void**)&T, blk));
-  MLN_HIP(ctx, mln_dmalloc((void**)&Out, full));
-  int rc = (hipMemsetAsync(Out, 0, full, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-  if (rc == MLN_OK)
-    rc = for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
-      MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
-      MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));             // unit columns c0 .. c0 + nb
-      MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // (Lp^-T)[:, block]
-      GemmArgs g{};                                                       // T = S (Lp^-T)[:, block]
-      g.A = G; g.lda = ldg; g.B = Z; g.ldb = b; g.C = T; g.ldc = b;
-      g.M = m; g.N = nb; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
-      MLN_TRY(launch_dgemm(ctx, g));
-      MLN_TRY(triinv_solve_left(ctx, f->tri, T, nb, b));                  // Lp^-1 S Lp^-T [:, block]
-      return launch_copy_block(ctx, T, b, Out + c0, ldg, m, nb);
-    });
-  if (rc == MLN_OK) rc = (hipMemcpyAsync(G, Out, full, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-  if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)m * ldg);
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)mln_dfree(Z); (void)mln_dfree(T); (void)mln_dfree(Out);
-  return rc;
+  MLN_HIP(ctx, zb.alloc(blk));
+  MLN_HIP(ctx, tb.alloc(blk));
+  MLN_HIP(ctx, ob.alloc(full));
+  double *Z = zb.p, *T = tb.p, *Out = ob.p;
+  MLN_HIP(ctx, hipMemsetAsync(Out, 0, full, ctx->stream));
+  MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
+    MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
+    MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));             // unit columns c0 .. c0 + nb
+    MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // (Lp^-T)[:, block]
+    GemmArgs g{};                                                       // T = S (Lp^-T)[:, block]
+    g.A = G; g.lda = ldg; g.B = Z; g.ldb = b; g.C = T; g.ldc = b;
+    g.M = m; g.N = nb; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+    MLN_TRY(launch_dgemm(ctx, g));
+    MLN_TRY(triinv_solve_left(ctx, f->tri, T, nb, b));                  // Lp^-1 S Lp^-T [:, block]
+    return launch_copy_block(ctx, T, b, Out + c0, ldg, m, nb);
+  }));
+  MLN_HIP(ctx, hipMemcpyAsync(G, Out, full, hipMemcpyDeviceToDevice, ctx->stream));
+  MLN_TRY(dev_allreduce(ctx, G, (int64_t)m * ldg));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
 }
 
 // inv (m x ld) <- C^-1 and P (m x ld) <- Lp^-T C^-T, column blocks of [C^-T ; P] split over the ranks (both zeroed
@@ -1090,26 +1102,25 @@ static int fit_inverses_split(mln_fit* f, const TriInv& tc, double* inv, double*
                               bool emulate) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
-  double *Z = nullptr, *Q = nullptr;
+  DevScratch zb(ctx), qb(ctx);
   const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ld;
-  MLN_HIP(ctx, mln_dmalloc((void**)&Z, blk));
-  MLN_HIP(ctx, mln_dmalloc((void**)&Q, 2 * full));                       // [C^-T ; P], this rank's columns only
-  int rc = (hipMemsetAsync(Q, 0, 2 * full, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-  if (rc == MLN_OK)
-    rc = for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
-      MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
-      MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));
-      MLN_TRY(triinv_solve_left_T(ctx, tc, Z, nb, b));                    // (C^-T)[:, block]
-      MLN_TRY(launch_copy_block(ctx, Z, b, Q + c0, ld, m, nb));
-      MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // P[:, block] = Lp^-T (C^-T)[:, block]
-      return launch_copy_block(ctx, Z, b, Q + (size_t)m * ld + c0, ld, m, nb);
-    });
-  if (rc == MLN_OK) rc = dev_allreduce(ctx, Q, 2 * (int64_t)m * ld);
-  if (rc == MLN_OK) rc = launch_transpose(ctx, Q, ld, inv, ld, m);                                  // C^-1
-  if (rc == MLN_OK) rc = launch_copy_block(ctx, Q + (size_t)m * ld, ld, P, ld, m, ld);              // P
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)mln_dfree(Z); (void)mln_dfree(Q);
-  return rc;
+  MLN_HIP(ctx, zb.alloc(blk));
+  MLN_HIP(ctx, qb.alloc(2 * full));                                     // [C^-T ; P], this rank's columns only
+  double *Z = zb.p, *Q = qb.p;
+  MLN_HIP(ctx, hipMemsetAsync(Q, 0, 2 * full, ctx->stream));
+  MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
+    MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
+    MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));
+    MLN_TRY(triinv_solve_left_T(ctx, tc, Z, nb, b));                    // (C^-T)[:, block]
+    MLN_TRY(launch_copy_block(ctx, Z, b, Q + c0, ld, m, nb));
+    MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // P[:, block] = Lp^-T (C^-T)[:, block]
+    return launch_copy_block(ctx, Z, b, Q + (size_t)m * ld + c0, ld, m, nb);
+  }));
+  MLN_TRY(dev_allreduce(ctx, Q, 2 * (int64_t)m * ld));
+  MLN_TRY(launch_transpose(ctx, Q, ld, inv, ld, m));                                  // C^-1
+  MLN_TRY(launch_copy_block(ctx, Q + (size_t)m * ld, ld, P, ld, m, ld));              // P
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
 }
 
 __global__ void k_round_bits(double* __restrict__ A, int64_t count, double scale) {
