@@ -1397,6 +1397,7 @@ static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, boo
     a32.L32 = f->L32;
     a32.l32_fixed = f->l32_fixed;
     a32.gate_want = MLN_GATE_F32;
+    if (gate) a32.cap = &f->sv.st->cap;
     MLN_TRY(launch_objective(ctx, a32));
   }
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
@@ -1518,6 +1519,13 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.t0 = 1.0;
   init.boost = 0.15;    // solver.hip "step-length memory"; MELLON_AMD_LS_BOOST=0 keeps every first trial at 1
   if (const char* ev = std::getenv("MELLON_AMD_LS_BOOST")) init.boost = std::atof(ev);
+  // capped start (solver.hip): on the 32-bit copy the likelihood's e^t is continued linearly beyond t = 7 while the loss
+  // still falls steeply; MELLON_AMD_EXP_CAP=<t> moves the cap, MELLON_AMD_EXP_CAP=off removes it
+  init.cap = phase32 ? 7.0 : __builtin_inf();
+  if (const char* ev = std::getenv("MELLON_AMD_EXP_CAP"))
+    if (phase32) init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
+  init.cap_fall = 0.15;
+  if (const char* ev = std::getenv("MELLON_AMD_EXP_CAP_FALL")) init.cap_fall = std::atof(ev);
   init.boost_fall = 0.15;
   if (const char* ev = std::getenv("MELLON_AMD_LS_BOOST_FALL")) init.boost_fall = std::atof(ev);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));

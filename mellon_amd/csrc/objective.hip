@@ -253,7 +253,7 @@ template <int CQ, int R, bool GEMVT, bool KEEP, int NW, bool FIXED>
 __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                                const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
                                                double& loss, double (*red)[NW][R], double* fstage, int64_t fbase,
-                                               const double (&pv)[2][R]) {
+                                               const double (&pv)[2][R], double capv, double ecap) {
   double coef[R], dot[R];
   if (GEMVT) {   // grad_j = sum_i weights_i L_ij  (Ridge right-hand side): no row dots, no barrier
 #pragma unroll
@@ -298,8 +298,11 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     const bool rok = (row + r) < row_end;
     const double f = s + a.mu;
     const double Vi = KEEP ? pv[0][r] : (rok ? a.V[row + r] : 0.0);
-    const double e = rok ? exp(f + Vi) : 0.0;
-    coef[r] = rok ? (e - 1.0) : 0.0;
+    const double tt = f + Vi;
+    const bool over = tt > capv;                                    // capv = +inf unless the solver's cap is on
+    const double ex = exp(over ? capv : tt);
+    const double e = rok ? (over ? ecap * (1.0 + (tt - capv)) : ex) : 0.0;
+    coef[r] = rok ? (ex - 1.0) : 0.0;                               // d/dt: e^t below the cap, e^cap above it
     if (KEEP) { if (tid == 0 && rok) loss -= (f + pv[1][r]) - e; }
     else if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;
     if (KEEP) lds_store_f64(fstage, (tid == 0 && rok) ? (int)(row + r - fbase) : (MLN_FSTAGE + tid), f);   // see k_objective
@@ -341,6 +344,8 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
       g[c][e] = 0.0;
     }
   double loss = 0.0;
+  const double capv = a.cap ? *a.cap : __builtin_inf();
+  const double ecap = exp(capv);
   __shared__ double fstage[KEEP ? (MLN_FSTAGE + WG) : 1];
   const int64_t fbase = s_beg * R;
   f4 va[R][CQ], vb[R][CQ];
@@ -351,10 +356,10 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
     load_rows32<CQ, R, NW>(L4, ld4, s1 * R, a.n, tid, vb);
     if (KEEP) load_lik<R>(a, s1 * R, pb);
-    process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa);
+    process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa, capv, ecap);
     load_rows32<CQ, R, NW>(L4, ld4, s2 * R, a.n, tid, va);
     if (KEEP) load_lik<R>(a, s2 * R, pa);
-    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb);
+    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb, capv, ecap);
   }
   if (KEEP) {
     __syncthreads();

@@ -23,6 +23,8 @@ struct SolverState {
   double ftol, gtol, ftol32;
   double prior_const;       // (m / 2) log 2 pi
   double fx, t, gd;         // accepted loss, current trial step, g . d at the accepted point
+  double cap_fall;          // relative decrease of the loss per pass below which the cap is dropped
+  double cap;               // the likelihood's e^t is continued linearly beyond t = cap while the loss falls steeply (inf: off)
   double boost_fall;        // ... and the relative decrease of the loss per pass above which that rule applies
   double t0, boost;         // first trial step of the next line search; slope ratio above which it doubles (0: always 1)
   double corr_k;            // corrected surrogate: F^(u) = F32(u) + c . u + corr_k,  grad F^ = grad F32 + c

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   }
   int mode = st->mode, it = st->it, n_eval = st->n_eval + 1, n_eval32 = st->n_eval32 + (phase32 ? 1 : 0);
   int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
-  double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k, t0 = st->t0;
+  double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k, t0 = st->t0, cap = st->cap;
+  bool recap = false;
   if (mode != MLN_SOLVE_LS) t0 = 1.0;
   int f_slot = st->f_slot, f_valid = st->f_valid, corr = st->corr, n_anchor = st->n_anchor;
   if (b.trace && tid == 0) {
@@ -195,6 +196,14 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       }
       ++it;
       const double fscale = fmax(fmax(fabs(f_old), fabs(fx)), 1.0);
+      // Capped start.  The Ridge start overshoots log-density x volume by up to e^14 in a few sparse cells, and while
+      // those terms dominate, every quasi-Newton step is sized by them (Newton on e^t moves t by one unit per step).
+      // Until the loss stops falling steeply the 32-bit kernel therefore continues e^t LINEARLY beyond t = cap -- still
+      // convex and C^1, the same function wherever no cell is above the cap, but with bounded curvature: the capped
+      // problem gets within a few per cent of the optimum's loss in ~5 passes instead of ~10.  Then the cap is dropped
+      // for good and the same point is evaluated once more on the true objective (the curvature pairs stay: they are
+      // the true ones for every cell below the cap).  tools/cap_sweep.py, six data seeds at C3: 41.8 -> 39.2 passes.
+      if (cap < 1e300 && it >= 3 && (f_old - fx) <= st->cap_fall * fabs(f_old)) { cap = __builtin_inf(); recap = true; }
       if (phaseA) {
         // the plain 32-bit objective is a smooth surrogate whose optimum sits ~1e-9 (fixed point; fp32: ~5e-5) in
         // relative loss from the true one: once its progress per iteration falls below ftol32, evaluate in fp64 at
@@ -318,6 +327,11 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) un[e] = u[e];
   }
+  if (recap && !reeval && !done) {   // the same point once more, on the uncapped objective (same copy)
+    mode = MLN_SOLVE_REEVAL;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) un[e] = u[e];
+  }
   if (done) gate = MLN_GATE_DONE;
 #pragma unroll
   for (int e = 0; e < EPT; ++e)
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     st->gate = gate; st->mode = mode; st->status = status; st->it = it; st->n_eval = n_eval; st->n_eval32 = n_eval32;
     st->ls = ls; st->k = k; st->head = head; st->fx = fx; st->t = t; st->gd = gd;
     st->f_slot = f_slot; st->f_valid = f_valid;
-    st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k; st->t0 = t0;
+    st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k; st->t0 = t0; st->cap = cap;
   }
 }
 
