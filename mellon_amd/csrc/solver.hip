@@ -322,6 +322,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     }
   }
   if (reeval) {           // same point, fp64 buffer: refreshes fx and g, keeps the curvature pairs
+    cap = __builtin_inf();   // (a surrogate left while still capped: everything from here on is the true objective)
     gate = MLN_GATE_F64;
     mode = MLN_SOLVE_REEVAL;
 #pragma unroll
