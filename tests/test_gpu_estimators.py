@@ -451,6 +451,28 @@ def test_mixed_precision_warmup_reaches_the_same_optimum(mellon, monkeypatch):
     assert n64["1"] <= 4 and n64["1"] < n64["plain"] < n64["0"], n64   # anchor + verification (+ at most two re-anchors)
 
 
+def test_capped_start_and_step_memory_leave_the_optimum_alone(mellon, monkeypatch):
+    """The solver's shortcuts through the steep first part -- e^t continued linearly beyond a cap on the 32-bit copy
+    (here a cap low enough to bind at the optimum itself, so that dropping it matters), first trial steps that double
+    -- change the path, not the destination: same log-density as with both switched off, and the oracle's optimum."""
+    x = mo.gaussian_mixture(6000, 10, 19)
+    rng = np.random.default_rng(4)
+    lm = x[rng.choice(6000, 300, replace=False)]
+    nn = mo.exact_nn_distances(x)
+    ref = mo.density_fit(x, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    monkeypatch.setenv("MELLON_AMD_MIXED_MIN_ELEMS", "0")
+    out = {}
+    for cap, boost in (("off", "0"), ("7", "0.15"), ("1", "0.15"), ("0.5", "0")):
+        monkeypatch.setenv("MELLON_AMD_EXP_CAP", cap)
+        monkeypatch.setenv("MELLON_AMD_LS_BOOST", boost)
+        est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn)
+        out[cap] = est.fit_predict(x)
+        assert est._fit.stage_times()["objective32_launches"] > 0
+        assert rel_max(out[cap], ref.log_density_x) < 1e-5 and rel_std(out[cap], ref.log_density_x) < 1e-5
+    for cap in ("7", "1", "0.5"):
+        assert rel_max(out[cap], out["off"]) < 2e-6
+
+
 def test_c3_subsample_golden(mellon):
     """SURVEY.md S8d parity gate "C3 subsample (n = 1e5)": 1e5 x 50 cells, 5000 landmarks, Matern52 against the
     oracle's optimum (tests/golden/make_c3_subsample.py).  n m = 5e8 >= 2^27: the mixed-precision solve runs."""
