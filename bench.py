@@ -327,7 +327,9 @@ def main():
                    "parallelism": f"cells/{world}",
                    "objective_evaluations": int(n_eval), "objective_evaluations_32bit": int(n32),
                    "objective_evaluations_fp32": int(n32),   # (same number under its round-1 name)
-                   "optimizer": "device-resident L-BFGS maxcor=10 ftol=1e-13 gtol=1e-7 (converged to the unique MAP optimum)",
+                   "optimizer": "device-resident L-BFGS maxcor=10 ftol=1e-13 gtol=1e-7 on a preconditioned variable; path "
+                                "shortcuts that leave the optimum alone (DESIGN.md S4): capped start, step-length memory, "
+                                "first-order-corrected 32-bit surrogate verified by an fp64 evaluation of the final point",
                    "landmarks": lm_note,
                    "nn_distances": f"exact 1-NN on device, untimed ({t_nn:.2f} s)",
                    "timed_region": "x, landmarks, nn_distances resident (x in HBM) -> log-density in host memory; "
