@@ -115,7 +115,7 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
     MLN_HIP(ctx, hipMemcpyAsync((char*)B + off, pat.data(), std::min(pat.size() * 8, b_bytes - off), hipMemcpyHostToDevice, ctx->stream));
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = Cm; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-  g.alpha = 1.0; g.beta = 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
+  g.alpha = 1.0; g.beta = std::getenv("MELLON_AMD_DIAG_BETA") ? std::atof(std::getenv("MELLON_AMD_DIAG_BETA")) : 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
   g.c_split_stride = (int64_t)M * ldc;
   hipEvent_t e0, e1;
   MLN_HIP(ctx, hipEventCreate(&e0));
