@@ -13,10 +13,10 @@ def relmax(a, b): return float(np.abs(a - b).max() / np.abs(b).max())
 which = sys.argv[1:] or ["c2", "c4", "c5"]
 if "c2" in which:
     n, d, m = 100_000, 20, 1000
-    x = bench.gaussian_mixture(n, d, 2); lm = bench.make_landmarks(x, m); xd = ctx.to_device(x); nn = ctx.nn_distances(xd)
+    x = bench.gaussian_mixture(n, d, 2); lm = bench.make_landmarks(x, m, "device", ctx)[0]; xd = ctx.to_device(x); nn = ctx.nn_distances(xd)
     for rep in range(2):
         t0 = time.perf_counter()
-        est = mellon_amd.DensityEstimator(cov_func_curry=mellon_amd.cov.ExpQuad, landmarks=lm, nn_distances=nn)
+        est = mellon_amd.DensityEstimator(cov_func_curry=mellon_amd.cov.ExpQuad, landmarks=lm, nn_distances=nn, check_rank=False)
         dens = est.fit_predict(xd); t1 = time.perf_counter()
     t2 = time.perf_counter(); pred = est.predict(x); t3 = time.perf_counter()
     out["c2"] = dict(n=n, d=d, m=m, kernel="ExpQuad", fit_predict_s=t1 - t0, cells_per_s=n / (t1 - t0),
@@ -40,7 +40,7 @@ if "c4" in which:
     lm = k_means(km, m, n_init=1, random_state=42, max_iter=10, init="random")[0]; lm[:, -1] /= ls / 1.5
     for rep in range(2):
         t0 = time.perf_counter()
-        est = mellon_amd.TimeSensitiveDensityEstimator(landmarks=lm, nn_distances=nn, ls_time=1.5, d=d)
+        est = mellon_amd.TimeSensitiveDensityEstimator(landmarks=lm, nn_distances=nn, ls_time=1.5, d=d, check_rank=False)
         dens = est.fit_predict(xt); t1 = time.perf_counter()
     k = 50000
     t2 = time.perf_counter(); pred = est.predict(xt[:k]); t3 = time.perf_counter()
@@ -53,7 +53,7 @@ if "c5" in which:
     rng = np.random.default_rng(5)
     x = bench.gaussian_mixture(n, d, 5); W = rng.normal(size=(d, p)) / np.sqrt(d)
     y = np.sin(x @ W) + 0.1 * rng.normal(size=(n, p))
-    lm = bench.make_landmarks(x, m); nn = ctx.nn_distances(x)
+    lm = bench.make_landmarks(x, m, "device", ctx)[0]; nn = ctx.nn_distances(x)
     t0 = time.perf_counter()
     est = mellon_amd.FunctionEstimator(sigma=0.1, landmarks=lm, nn_distances=nn)
     est.fit(x, y); t1 = time.perf_counter()
