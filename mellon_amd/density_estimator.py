@@ -86,7 +86,11 @@ class DensityEstimator(BaseEstimator):
 
     def _compute_initial_value(self):
         # lbfgsb_options = "reference": the reference's exact Ridge on all cells is part of "as run"
-        exact = isinstance(self.lbfgsb_options, str) and self.lbfgsb_options == "reference"
+        # ... and so is it for the optimisers that do not run to convergence (adam: a fixed number of steps), whose result
+        # depends on where they start; the converged L-BFGS route may start anywhere (unique optimum) and takes the
+        # sampled Gram of the preconditioner
+        exact = (isinstance(self.lbfgsb_options, str) and self.lbfgsb_options == "reference") or \
+            str(getattr(self, "optimizer", "L-BFGS-B")).lower() not in ("l-bfgs-b", "lbfgsb")
         return compute_initial_value(self.nn_distances, self.d, self.mu, self.L, row_stride=1 if exact else None,
                                      target=getattr(self, "_ridge_target", None))
 
