@@ -211,6 +211,10 @@ int mln_predict_hessian(mln_ctx* ctx, const mln_kernel_desc* cov, const double* 
  * The rank rule of _eigendecomposition (:51-76) is host logic on S (mellon_amd/decomposition.py).   */
 int mln_eigh(mln_ctx* ctx, const double* A, int64_t m, double* w, double* V, int32_t* n_sweeps);
 int mln_fit_gram_eigh(mln_fit* fit, double* w /* m */, int32_t* n_sweeps);
+/* util.test_rank (util.py:429-483) = numpy.linalg.matrix_rank(L, rtol=tol): the number of singular values of L above
+ * tol * the largest, i.e. of eigenvalues of L^T L (all cells, all ranks) above tol^2 * lambda_max -- counted by Sturm
+ * sequences on the Householder-tridiagonalised Gram, no eigendecomposition.  sigma_max_out may be NULL. */
+int mln_fit_gram_rank(mln_fit* fit, double tol, int64_t* rank_out, double* sigma_max_out);
 int mln_fit_project(mln_fit* fit, int64_t p, mln_fit** out);
 
 /* a-9: Ridge initial value  z0 = (L^T L + I)^-1 L^T target   (parameters.py:877-896;

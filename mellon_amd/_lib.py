@@ -81,6 +81,7 @@ SYMBOLS = [
     ("mln_fit_rank", C.c_int, [_vp, C.POINTER(_i64)]),
     ("mln_eigh", C.c_int, [_vp, _dp, _i64, _dp, _dp, C.POINTER(_i32)]),
     ("mln_fit_gram_eigh", C.c_int, [_vp, _dp, C.POINTER(_i32)]),
+    ("mln_fit_gram_rank", C.c_int, [_vp, _dbl, C.POINTER(_i64), C.POINTER(_dbl)]),
     ("mln_fit_project", C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     ("mln_ridge_init", C.c_int, [_vp, _dp, _dp]),
     ("mln_precond_build", C.c_int, [_vp, _i64]),
@@ -567,6 +568,13 @@ class Fit:
         self.ctx._check(self.lib.mln_fit_gram_eigh(self.handle, w.ctypes.data, C.byref(sw)))
         self.last_eigh_sweeps = int(sw.value)
         return w
+
+    def gram_rank(self, tol):
+        """(number of singular values of L above tol * the largest, the largest): Sturm counts on the tridiagonalised
+        Gram of all cells of all ranks -- no eigendecomposition."""
+        r, smax = _i64(0), C.c_double()
+        self.ctx._check(self.lib.mln_fit_gram_rank(self.handle, float(tol), C.byref(r), C.byref(smax)))
+        return int(r.value), smax.value
 
     def project(self, p):
         """New handle with L <- L U[:, -p:] (top-p eigenvectors of L^T L, after gram_eigh)."""

@@ -745,6 +745,24 @@ extern "C" int mln_fit_gram_eigh(mln_fit* f, double* w, int32_t* n_sweeps) {
   return MLN_OK;
 }
 
+// util.test_rank without an eigendecomposition: the number of singular values of L above tol * the largest = the number of
+// eigenvalues of L^T L (all cells, all ranks) above tol^2 * lambda_max, counted on the tridiagonalised Gram (tridiag.hip)
+extern "C" int mln_fit_gram_rank(mln_fit* f, double tol, int64_t* rank_out, double* sigma_max_out) {
+  if (!f || !rank_out || !(tol >= 0.0)) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t m = f->m, ld = f->ldl;
+  double* G = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * (size_t)m * ld));
+  int rc = f->kspace ? fit_gram(f, G, ld, 1) : gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld);
+  double lmax = 0.0;
+  if (rc == MLN_OK) rc = dev_sym_rank_above(ctx, G, m, ld, tol * tol, rank_out, &lmax);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(G);
+  if (rc == MLN_OK && sigma_max_out) *sigma_max_out = std::sqrt(std::max(lmax, 0.0));
+  return rc;
+}
+
 extern "C" int mln_fit_project(mln_fit* f, int64_t p, mln_fit** out) {
   if (!f || !out) return MLN_ERR_ARG;
   *out = nullptr;

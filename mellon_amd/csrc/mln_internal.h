@@ -58,6 +58,8 @@ int launch_add_diag(mln_ctx* ctx, double* A, int64_t m, int64_t lda, double v);
 int launch_symmetrize_from_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda);
 // gram_i8.hip: lower 128-tiles of alpha * Q^T Q, Q = round(K 8355711) in three int8 digit planes, per k-chunk (`n_splits`
 // partial results `part_stride` doubles apart, to be summed by the caller); K holds values in [0, 1], row pitch ldk
+// tridiag.hip: A (m x m symmetric, full storage, destroyed) -> number of eigenvalues above tol2 * lambda_max
+int dev_sym_rank_above(mln_ctx* ctx, double* A, int64_t m, int64_t ld, double tol2, int64_t* rank, double* lambda_max);
 int gram_i8_splits(int64_t rows, int64_t m);
 int launch_gram_i8(mln_ctx* ctx, const double* K, int64_t ldk, int64_t rows, int64_t m, double alpha, double* parts,
                    int64_t ldg, int64_t part_stride, int n_splits);

@@ -167,19 +167,19 @@ def test_rank(input, tol=DEFAULT_RANK_TOL, threshold=None):
         raise TypeError("Input must be either a matrix or a mellon enstimator with a transformation L.")
     if len(L.shape) != 2:
         raise ValueError("Matrix L must be 2D.")
+    # a COUNT of singular values above a threshold needs neither eigenvectors nor eigenvalues: Sturm sequences on the
+    # tridiagonalised Gram (csrc/tridiag.hip) -- 0.4 s at 5000 landmarks, where the eigensolver takes seconds
     if isinstance(L, (FactorL, FactorLp)) and L.fit.handle is not None and not isinstance(L, FactorLp):
-        ev = L.fit.gram_eigh()
+        approx_rank, _ = L.fit.gram_rank(tol)
     else:
         Lh = np.asarray(L, dtype=np.float64)
         if Lh.shape[0] < Lh.shape[1]:
             Lh = Lh.T                       # same singular values, smaller Gram
         fit = _lib.Fit.from_L(_lib.default_context(), np.ascontiguousarray(Lh))
         try:
-            ev = fit.gram_eigh()
+            approx_rank, _ = fit.gram_rank(tol)
         finally:
             fit.close()
-    sv = np.sqrt(np.maximum(ev, 0.0))
-    approx_rank = int(np.count_nonzero(sv > tol * sv.max()))
     max_rank = int(min(L.shape))
     rank_fraction = approx_rank / max_rank
     if threshold is not None:

@@ -691,3 +691,32 @@ def test_integer_gram_of_the_preconditioner(ctx, rows, m):
     assert np.linalg.eigvalsh(got).min() >= -1e-12 * np.abs(got).max()                 # a Gram: positive semi-definite
     exact = a.T @ a
     assert np.abs(got - exact).max() <= 2.0 ** -20 * np.abs(exact).max()
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 65, 700])
+def test_rank_count_by_sturm_sequences(ctx, m):
+    """mln_fit_gram_rank (Householder tridiagonalisation of L^T L + Sturm counts, csrc/tridiag.hip) == the count from the
+    eigenvalues (mln_fit_gram_eigh) == numpy.linalg.matrix_rank(L, rtol) -- for a spectrum with clusters, repeated and
+    tiny singular values, thresholds on both sides of every gap."""
+    from mellon_amd import _lib
+    rng = np.random.default_rng(100 + m)
+    n = max(3 * m, 8)
+    q1, _ = np.linalg.qr(rng.normal(size=(n, m)))
+    q2, _ = np.linalg.qr(rng.normal(size=(m, m)))
+    s = np.sort(np.concatenate([[1.0], 10.0 ** rng.uniform(-6, 0, size=max(m - 1, 0))]))[::-1][:m]
+    if m >= 65:
+        s[5:9] = s[5]                    # a repeated singular value
+        s[-3:] = 1e-12                   # numerically rank deficient
+    L = (q1 * s) @ q2.T
+    fit = _lib.Fit.from_L(ctx, np.ascontiguousarray(L))
+    try:
+        ev = np.sqrt(np.maximum(fit.gram_eigh(), 0.0))
+        for tol in (0.5, 0.3, 0.05, 1e-3, 1e-5):
+            # thresholds at least 1 % away from a singular value (the Gram squares the conditioning: ties are undefined)
+            if np.any(np.abs(s / s.max() - tol) < 0.01 * tol):
+                continue
+            rank, smax = fit.gram_rank(tol)
+            assert rank == int(np.count_nonzero(ev > tol * ev.max())) == np.linalg.matrix_rank(L, rtol=tol), (m, tol)
+            assert abs(smax - s.max()) < 1e-9 * s.max()
+    finally:
+        fit.close()
