@@ -15,9 +15,14 @@ one process per GPU, RCCL all-reduce of (loss, grad) per evaluation and of the R
 `--scaling weak` fits one model on N x 1e6 cells instead (1e6 per GPU).  Only the launcher's environment variables
 (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) are used; the ranks' host sides talk over a Unix socket.
 
-Prints ONE JSON line on rank 0 (fields documented in DESIGN.md S6).  Besides the K timed steps the run measures,
-untimed by the contract but in the same process, the pure-fp64 step (`ms_per_step_fp64_only`) and the
-host-to-host step (`ms_per_step_host_to_host`, x uploaded inside the step).
+Prints ONE JSON line on rank 0 (fields documented in DESIGN.md S6).  The K timed steps are PURE FLOAT64: every pass
+of the MAP solve streams the fp64 n x m buffer (MELLON_AMD_MIXED=0), so `value`, `ms_per_step`, `roofline` and
+`dtype` describe the reference's own precision.  Beside it, untimed by the contract but in the same process: the
+product default with its 32-bit fixed-point surrogate passes (`ms_per_step_mixed`, `roofline_mixed_passes`) and the
+host-to-host fp64 step (`ms_per_step_host_to_host`, x uploaded inside the step).
+
+    --config c2 | c4 | c5      the other BASELINE configs as bench lines (same contract, their own workloads)
+    --dry-run-comm             only set up the communicator, run its self-test and one all-reduce, print a JSON line
 """
 import argparse
 import ctypes
@@ -130,22 +135,199 @@ def _print_result_line(real_stdout, line):
 
 
 
-def roofline_objects(stats, step_s, ach, per_launch, n64, traffic, traffic_src, ach32, per_launch32, n32, bytes32, traffic32):
-    """`roofline` describes the DOMINANT kernel of the step -- since the MAP solve runs all but two of its passes on the
-    32-bit copy that is k_objective32; the fp64 kernel (same structure, 8 B/element) is reported beside it."""
-    r64 = {"bound": "hbm", "kernel": "k_objective (fused loss+grad, one pass over the fp64 buffer: the anchor and the "
-           "verification of the MAP solve)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-           "algorithmic_bytes_per_launch": stats["objective_bytes_per_launch"], "avg_launch_ms": 1e3 * per_launch,
-           "launches": n64, "share_of_step": stats["objective_kernel_s"] / step_s if step_s else None}
-    r32 = {"bound": "hbm", "kernel": "k_objective32 (fused loss+grad, one pass over the 32-bit fixed-point copy of K: "
-           "every other pass of the MAP solve)", "achieved": ach32, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": ach32 / HBM_PEAK_GBS, "traffic": traffic32, "traffic_source": traffic_src,
-           "algorithmic_bytes_per_launch": bytes32, "avg_launch_ms": 1e3 * per_launch32, "launches": n32,
-           "share_of_step": stats.get("objective32_kernel_s", 0.0) / step_s if step_s else None}
-    if stats.get("objective32_kernel_s", 0.0) > stats["objective_kernel_s"]:
-        return {"roofline": r32, "roofline_fp64_passes": r64}
-    return {"roofline": r64, "roofline_fp32_passes": r32}
+def roofline_object(kernel, bytes_per_launch, kernel_s, launches, step_s, traffic, traffic_src):
+    per_launch = kernel_s / max(launches, 1.0)
+    ach = bytes_per_launch / per_launch / 1e9 if per_launch > 0 and launches > 0 else 0.0
+    return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": 1e3 * per_launch,
+            "launches": int(launches), "share_of_step": (kernel_s / step_s) if step_s else None}
+
+
+def committed_traffic(n_local, m):
+    """HBM bytes per launch of the two objective kernels from the committed rocprofv3 PMC passes (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs with --kernel-trace only; gfx950 correction x2 on FETCH_SIZE), with the commit the
+    library was at when they were taken."""
+    tfile = os.path.join(ROOT, "profiles", "objective_traffic.json")
+    try:
+        t = json.load(open(tfile))
+    except Exception:
+        return None, None, None
+    if t.get("n_local") != n_local or t.get("m") != m:
+        return None, None, None
+    src = ("profiles/objective_traffic.json (rocprofv3 PMC passes of this command, committed; measured at commit "
+           + str(t.get("measured_at_commit", "unrecorded")) + ", kernel source hash "
+           + str(t.get("objective_hip_sha16", "unrecorded")) + "; not re-measured in this run)")
+    return t.get("hbm_bytes_per_launch"), t.get("fp32_passes", {}).get("hbm_bytes_per_launch"), src
+
+
+def c4_workload(n, d, T, seed):
+    """BASELINE C4: Gaussian-mixture cells at T equally sized time points whose component means drift
+    linearly in time; the time column is appended.  Rows are ordered by time."""
+    xs = gaussian_mixture(n, d, seed)
+    times = np.repeat(np.arange(float(T)), n // T)
+    times = np.concatenate([times, np.full(n - times.size, float(T - 1))])
+    xs = xs + 0.2 * times[:, None]
+    return np.ascontiguousarray(np.concatenate([xs, times[:, None]], axis=1))
+
+
+def bench_other(args, comm, ctx, info, world, rank):
+    """C4 (TimeSensitiveDensityEstimator.fit_predict) and C5 (FunctionEstimator fit + batched predict) under the same
+    contract as the headline: resident inputs, W untimed + K timed steps between fences, MAX over ranks, cells sharded
+    over the ranks in contiguous blocks (replicated landmarks; one model)."""
+    import mellon_amd
+    from mellon_amd import distributed
+    n, d, m = args.n, args.d, args.m
+    kern = getattr(mellon_amd.cov, args.kernel)
+    os.environ["MELLON_AMD_MIXED"] = "0"          # float64 throughout, like the headline
+    lo, hi = distributed.shard_bounds(n, world, rank)
+
+    def fence():
+        comm.barrier()
+        ctx.synchronize()
+
+    if args.config == "c4":
+        T, ls_time = 8, 1.5
+        xt = c4_workload(n, d, T, args.seed)
+        x_loc = np.ascontiguousarray(xt[lo:hi])
+        t0 = time.perf_counter()
+        # exact 1-NN within each time point, this rank's cells against the time point's cells of all ranks (untimed)
+        from mellon_amd.parameters import compute_nn_distances_within_time_points
+        nn_loc = compute_nn_distances_within_time_points(xt, local=(lo, hi - lo))
+        t_nn = time.perf_counter() - t0
+        ls = float(np.exp(comm.global_mean(np.log(nn_loc)) + 3.0))
+        if rank == 0:                               # k-means of a 20 000-cell subsample with the time column rescaled (parameters.py:294-349)
+            rng = np.random.default_rng(args.seed)
+            km = xt[rng.choice(n, min(n, 20000), replace=False)].copy()
+            km[:, -1] *= ls / ls_time
+            lm = ctx.kmeans(km, m, seed=42) if m < km.shape[0] else km[:m]
+            lm[:, -1] /= ls / ls_time
+            lm = np.ascontiguousarray(lm.astype(np.float32).astype(np.float64))
+        else:
+            lm = None
+        lm = comm.broadcast(lm, src=0)
+
+        def one_step():
+            est = mellon_amd.TimeSensitiveDensityEstimator(cov_func_curry=kern, landmarks=lm, nn_distances=nn_loc,
+                                                           ls_time=ls_time, d=d, check_rank=False)
+            dens = est.fit_predict(x_loc)
+            return est, dens
+
+        what = (f"C4 TimeSensitiveDensityEstimator.fit_predict: {n} cells x {d} dims (+ time column) at {T} time points, "
+                f"{m} landmarks, {args.kernel}(ls) * {args.kernel}(ls_time=1.5), one model, cells sharded over {world} GPU(s)")
+        unit_cells = n
+    else:
+        p, sigma = 2000, 0.1
+        x = gaussian_mixture(n, d, args.seed)
+        rng = np.random.default_rng(args.seed)
+        Wm = rng.normal(size=(d, p)) / np.sqrt(d)
+        x_loc = np.ascontiguousarray(x[lo:hi])
+        y_loc = np.sin(x_loc @ Wm) + 0.1 * np.random.default_rng([args.seed, rank]).normal(size=(hi - lo, p))
+        t0 = time.perf_counter()
+        x_all_dev = ctx.to_device(x)
+        nn_loc = ctx.nn_distances(ctx.to_device(x_loc) if world > 1 else x_all_dev, x_all_dev, self_offset=lo)
+        t_nn = time.perf_counter() - t0
+        x_all_dev.free()
+        lm_pack = make_landmarks(x, m, "device", ctx) if rank == 0 else None
+        lm = comm.broadcast(lm_pack, src=0)[0]
+
+        def one_step():
+            est = mellon_amd.FunctionEstimator(cov_func_curry=kern, sigma=sigma, landmarks=lm, nn_distances=nn_loc)
+            est.fit(x_loc, y_loc)
+            pred = est.predict(x_loc)                 # batched predict of this rank's cells, all p outputs
+            return est, pred
+
+        what = (f"C5 FunctionEstimator.fit + batched predict: {n} cells x {d} dims, {p} outputs (sin(X W) + noise), sigma 0.1, "
+                f"{m} landmarks, {args.kernel}, Xnew = X, cells sharded over {world} GPU(s)")
+        unit_cells = n
+
+    for _ in range(args.warmup):
+        est, _ = one_step()
+        del est
+    gc.collect()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        est, res = one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    elapsed = float(comm.allreduce_sum(np.eye(world)[rank] * elapsed).max())
+    out = {"metric": "cells/sec fit_predict", "value": unit_cells * args.steps / elapsed, "unit": "cells/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": what, "n": n, "n_per_gpu": hi - lo, "d": d, "m": m, "kernel": args.kernel,
+                      "parallelism": f"cells/{world}", "nn_distances": f"exact 1-NN on device, untimed ({t_nn:.2f} s)",
+                      "device": info["arch"]}}
+    if args.config == "c4":
+        st = est._fit.stage_times()
+        out["config"]["objective_evaluations"] = int(est.loss_func.n_eval)
+        out["config"]["objective_full_pass_equivalents"] = st.get("objective_pass_equivalents")
+        out["roofline"] = roofline_object("k_objective (fp64, one pass over the n x m buffer per evaluation)",
+                                          st["objective_bytes_per_launch"], st["objective_kernel_s"], st["objective_launches"],
+                                          elapsed / args.steps if world == 1 else None, None, None)
+        out["stages_s"] = {k: round(v, 4) for k, v in st.items() if k.endswith("_s")}
+    else:
+        # the two GEMM-shaped parts: A A^T (n m^2) + A r (n m p) in the fit, K W (n m p) in the predict
+        flops = (hi - lo) * (2.0 * m * m + 4.0 * m * 2000)
+        out["roofline"] = {"bound": "mfma", "kernel": "fp64 MFMA GEMMs of the landmark conditional (A A^T, A r) and of the "
+                           "batched predict (K W), whole step", "achieved": flops / (elapsed / args.steps) / 1e12,
+                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops / (elapsed / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "note": "step-level figure (host<->device traffic of the n x p arrays included)"}
+    return out
+
+
+def pick_cpu_samples(args, n, host_gb):
+    """the CPU baseline belongs at 2.5e5 (and 5e5) cells.  The default run takes the 2.5e5-cell point when
+    the host has the memory for it (L + its transposed copy + the Ridge Gram: ~25 GB at m = 5000) AND a quick probe
+    predicts that it fits the time budget; otherwise the largest sample that does, saying so."""
+    if args.cpu_sample_full:
+        return [250_000, 500_000], "SURVEY S8(d) sizes (--cpu-sample-full)"
+    if args.cpu_sample > 0:
+        big = min(args.cpu_sample, n)
+        return [max(big // 2, 1), big], f"--cpu-sample {args.cpu_sample}"
+    return None, None
+
+
+def cpu_baseline_budgeted(x, landmarks, nn, kern_name, n_target, budget_s, host_gb):
+    """Probe at 12 000 cells, then the largest of (2.5e5, 1.25e5, 6e4, 3e4) cells whose predicted time (linear in n:
+    every stage is O(n) at fixed m, and the evaluation count is n-independent within ~10 %) fits `budget_s` and whose
+    memory fits the host."""
+    probe = cpu_baseline(x, landmarks, nn, kern_name, [12_000], n_target)
+    per_cell = probe["points"][0]["seconds"] / 12_000.0
+    m = landmarks.shape[0]
+    note = []
+    for cand in (250_000, 125_000, 60_000, 30_000):
+        if cand > x.shape[0]:
+            continue
+        need_gb = 3.2 * cand * m * 8 / 1e9          # L, the transposed copy of decomposition.py:209, solver temporaries
+        pred = per_cell * cand
+        if need_gb > 0.8 * host_gb:
+            note.append(f"{cand} cells need ~{need_gb:.0f} GB of host RAM ({host_gb:.0f} GB here)")
+            continue
+        if pred > budget_s:
+            note.append(f"{cand} cells predicted {pred:.0f} s > budget {budget_s:.0f} s")
+            continue
+        out = cpu_baseline(x, landmarks, nn, kern_name, [cand], n_target)
+        out["points"] = probe["points"] + out["points"]
+        (n0, t0_), (n1, t1_) = [(q["cells"], q["seconds"]) for q in out["points"][-2:]]
+        b = (t1_ - t0_) / (n1 - n0)
+        extrap = (t1_ - b * n1) + b * n_target
+        out["extrapolated_seconds_at_full_size"] = round(extrap, 1)
+        out["extrapolated_cells_per_s_at_full_size"] = n_target / extrap if extrap > 0 else None
+        out["sample"] += "; probe at 12000 cells first" + ("; skipped: " + "; ".join(note) if note else "")
+        out["time_budget_s"] = budget_s
+        return out
+    probe["sample"] += "; no larger sample fits the budget: " + "; ".join(note)
+    return probe
+
+
+def host_memory_gb():
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 1e9
+    except (ValueError, OSError):
+        return 0.0
+
 
 def main():
     real_stdout = _stdout_to_stderr()
@@ -153,18 +335,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cells", dest="n", type=int, default=1_000_000, help="cells in total (strong) / per GPU (weak)")
+    ap.add_argument("--config", choices=["c3", "c2", "c4", "c5"], default="c3",
+                    help="BASELINE.json config: c3 = the headline (1e6 x 50, 5000 landmarks, Matern52); c2 / c4 / c5 time "
+                         "the other configs under the same contract")
+    ap.add_argument("--cells", dest="n", type=int, default=None, help="cells in total (strong) / per GPU (weak)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--dims", dest="d", type=int, default=50)
-    ap.add_argument("--landmarks", dest="m", type=int, default=5000)
+    ap.add_argument("--dims", dest="d", type=int, default=None)
+    ap.add_argument("--landmarks", dest="m", type=int, default=None)
     ap.add_argument("--landmark-method", choices=["sklearn", "device"], default="sklearn")
-    ap.add_argument("--kernel", default="Matern52")
-    ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=30000,
-                    help="largest CPU-baseline sample in cells (a second point at half of it gives the slope); 0 = skip")
+    ap.add_argument("--kernel", default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="largest CPU-baseline sample in cells (a second point at half of it gives the slope); 0 = skip; "
+                         "default: 2.5e5 cells when the host's memory and --cpu-budget-s allow, else the largest that fits")
+    ap.add_argument("--cpu-budget-s", type=float, default=330.0, help="wall-clock budget of the default CPU baseline")
     ap.add_argument("--cpu-sample-full", action="store_true",
                     help="SURVEY S8(d) sizes: 2.5e5 and 5e5 cells (needs ~60 GB of host RAM and ~15 min)")
-    ap.add_argument("--extra-steps", type=int, default=2, help="steps of the fp64-only and host-to-host measurements")
+    ap.add_argument("--extra-steps", type=int, default=2, help="steps of the mixed-precision and host-to-host measurements")
+    ap.add_argument("--dry-run-comm", action="store_true",
+                    help="communicator set-up + self-test + one all-reduce of the per-evaluation size, nothing else")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,15 +365,49 @@ def main():
 
     import mellon_amd
     from mellon_amd import _lib, distributed
+    t_comm = time.perf_counter()
     comm = distributed.init_from_env()
+    t_comm = time.perf_counter() - t_comm
     ctx = _lib.default_context()
     info = ctx.device_info()
+
+    if args.dry_run_comm:
+        rep = getattr(comm, "self_test_report", {"world_size": world, "ok": True})
+        buf = np.full(5001, float(rank + 1))
+        t0 = time.perf_counter()
+        for _ in range(20):
+            out_v = ctx.allreduce_sum(buf)
+        dt = (time.perf_counter() - t0) / 20
+        ok = bool(np.all(out_v == world * (world + 1) / 2.0))
+        comm.barrier()
+        if rank == 0:
+            _print_result_line(real_stdout, json.dumps({
+                "metric": "communicator dry run", "value": 1.0 if ok and rep.get("ok") else 0.0, "unit": "ok", "n_gpus": world,
+                "steps": 0, "warmup": 0, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": args.scaling,
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "communicator set-up, self-test (distributed.self_test) and 20 all-reduces of m + 1 = "
+                                       "5001 fp64 from host buffers", "device": info["arch"]},
+                "init_s": t_comm, "self_test": rep}))
+        return
+
+    defaults = {"c3": (1_000_000, 50, 5000, "Matern52", 3), "c2": (100_000, 20, 1000, "ExpQuad", 2),
+                "c4": (500_000, 30, 2000, "Matern52", 4), "c5": (200_000, 50, 2000, "Matern52", 5)}[args.config]
+    args.n = args.n or defaults[0]
+    args.d = args.d or defaults[1]
+    args.m = args.m or defaults[2]
+    args.kernel = args.kernel or defaults[3]
+    args.seed = defaults[4] if args.seed is None else args.seed
+    if args.config in ("c4", "c5"):
+        out = bench_other(args, comm, ctx, info, world, rank)
+        if rank == 0:
+            _print_result_line(real_stdout, json.dumps(out))
+        return
 
     # ---- synthetic workload -----------------------------------------------------------------------------
     n, d, m = args.n, args.d, args.m
     weak = args.scaling == "weak"
     t_gen = time.perf_counter()
-    x0 = gaussian_mixture(n, d, args.seed)                # shard 0 == the BASELINE C3 data set
+    x0 = gaussian_mixture(n, d, args.seed)                # shard 0 == the BASELINE data set
     # replicated inputs must be BIT-identical on every rank (they steer the shared optimiser): rank 0 computes them
     lm_pack = make_landmarks(x0, m, args.landmark_method, ctx) if rank == 0 else None
     landmarks, lm_note = comm.broadcast(lm_pack, src=0)
@@ -259,6 +482,8 @@ def main():
         elapsed = float(comm.allreduce_sum(np.eye(world)[rank] * elapsed).max())   # MAX over ranks
         return elapsed, last, t_fit, t_free
 
+    # ---- the headline: PURE FLOAT64 (no 32-bit copy exists, every pass streams the fp64 buffer) ---------------
+    os.environ["MELLON_AMD_MIXED"] = "0"
     for _ in range(args.warmup):
         est, dens = one_step(x_loc_dev)
         release(est)
@@ -274,86 +499,83 @@ def main():
 
     # ---- beside the headline, same process, same inputs (untimed by the contract) -------------------------
     extra = {}
+    stats_mixed = None
     if args.extra_steps > 0:
-        e_h2h, (_, dens_h, _, n_eval_h), _, _ = timed(args.extra_steps, x_loc)          # host x -> host density
+        e_h2h, (_, dens_h, _, n_eval_h), _, _ = timed(args.extra_steps, x_loc)          # host x -> host density, fp64
         extra["ms_per_step_host_to_host"] = 1e3 * e_h2h / args.extra_steps
-        os.environ["MELLON_AMD_MIXED"] = "0"
+        del os.environ["MELLON_AMD_MIXED"]                                               # the product default
         one_step(x_loc_dev)[0]._fit.close()                                             # allocator warm-up of the other buffer set
-        e_f64, (_, dens64, stats64, n_eval64), _, _ = timed(args.extra_steps, x_loc_dev)
-        del os.environ["MELLON_AMD_MIXED"]
-        extra["ms_per_step_fp64_only"] = 1e3 * e_f64 / args.extra_steps
-        extra["objective_evaluations_fp64_only"] = int(n_eval64)
-        extra["fp64_only_vs_mixed_rel_max"] = float(np.abs(dens64 - dens).max() / np.abs(dens).max())
+        e_mx, (_, dens_mx, stats_mixed, n_eval_mx), _, _ = timed(args.extra_steps, x_loc_dev)
+        extra["ms_per_step_mixed"] = 1e3 * e_mx / args.extra_steps
+        extra["cells_per_s_mixed"] = n_total * args.extra_steps / e_mx
+        extra["objective_evaluations_mixed"] = int(n_eval_mx)
+        extra["objective_evaluations_mixed_32bit"] = int(stats_mixed.get("objective32_launches", 0.0))
+        extra["mixed_vs_fp64_rel_max"] = float(np.abs(dens_mx - dens).max() / np.abs(dens).max())
+        os.environ["MELLON_AMD_MIXED"] = "0"
 
     if rank != 0:
         return
     ms_per_step = 1e3 * elapsed / args.steps
+    step_s = elapsed / args.steps
     value = n_total * args.steps / elapsed
-    per_launch = stats["objective_kernel_s"] / max(stats["objective_launches"], 1.0)
-    ach = stats["objective_bytes_per_launch"] / per_launch / 1e9 if per_launch > 0 else 0.0
-    # fp32 warm-up passes of the MAP solve (mixed precision): same rows, 4 bytes per element
-    n32 = stats.get("objective32_launches", 0.0)
-    per_launch32 = stats.get("objective32_kernel_s", 0.0) / max(n32, 1.0)
-    bytes32 = stats["objective_bytes_per_launch"] / 2.0
-    ach32 = bytes32 / per_launch32 / 1e9 if n32 > 0 and per_launch32 > 0 else 0.0
-    n64 = int(stats["objective_launches"])
-    traffic = traffic32 = None
-    traffic_src = None
-    tfile = os.path.join(ROOT, "profiles", "objective_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            t = json.load(open(tfile))
-            if t.get("n_local") == hi - lo and t.get("m") == m:
-                traffic = t.get("hbm_bytes_per_launch")
-                traffic32 = t.get("fp32_passes", {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/objective_traffic.json (rocprofv3 PMC passes of this command, committed; not re-measured in this run)"
-        except Exception:
-            traffic = traffic32 = None
+    n64 = stats["objective_launches"]
+    bytes64 = stats["objective_bytes_per_launch"]
+    traffic, traffic32, traffic_src = committed_traffic(hi - lo, m)
+    roof = roofline_object("k_objective (fused loss + gradient, ONE pass over the fp64 n x m buffer per evaluation of the MAP "
+                           "solve; also the Ridge right-hand side)", bytes64, stats["objective_kernel_s"], n64,
+                           step_s if world == 1 else None, traffic, traffic_src)
+    # step level, by SURVEY S8(d)'s byte formula with I = the evaluations actually performed (full-pass equivalents)
+    passes = stats.get("objective_pass_equivalents", float(n_eval))
+    step_bytes = 8.0 * (d + m * (passes + 3.0) + 1.0) * (hi - lo)
+    roof["step_level"] = {"formula": "8 (d + m (I + 3) + 1) bytes per cell, I = objective passes in full-pass equivalents",
+                          "I": passes, "bytes": step_bytes, "GBps": step_bytes / step_s / 1e9,
+                          "frac_of_peak": step_bytes / step_s / 1e9 / HBM_PEAK_GBS}
     out = {
         "metric": "cells/sec fit_predict", "value": value, "unit": "cells/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None,
-        "dtype": (f"f64 results; {int(n32)} of {int(n_eval)} passes stream a 32-bit copy of K (4 B/element: "
-                  + ("fixed point round(K 2^32)" if stats.get("copy32_format") == 2.0 else "fp32")
-                  + f"), {n64} the fp64 buffer (they anchor the first-order correction of the 32-bit objective and verify "
-                    "the final point: loss, gradient and log-density of the returned optimum are fp64 evaluations) -- "
-                    "pure-fp64 step: ms_per_step_fp64_only") if n32 > 0 else "f64",
+        "dtype": "f64",
         "data": "synthetic",
         **extra,
-        "config": {"workload": f"C3 DensityEstimator.fit_predict: {n_total} cells x {d} dims Gaussian mixture "
+        "config": {"workload": f"{args.config.upper()} DensityEstimator.fit_predict: {n_total} cells x {d} dims Gaussian mixture "
                                f"(seed {args.seed}), {m} landmarks, {args.kernel}, one model, cells sharded over "
                                f"{world} GPU(s) ({hi - lo} cells per GPU)",
                    "n": n_total, "n_per_gpu": hi - lo, "d": d, "m": m, "kernel": args.kernel,
                    "parallelism": f"cells/{world}",
-                   "objective_evaluations": int(n_eval), "objective_evaluations_32bit": int(n32),
-                   "objective_evaluations_fp32": int(n32),   # (same number under its round-1 name)
+                   "precision": "every kernel of the timed step computes in and streams float64 (MELLON_AMD_MIXED=0: the "
+                                "32-bit fixed-point copy of the product default does not exist in this step)",
+                   "objective_evaluations": int(n_eval), "objective_full_pass_equivalents": passes,
                    "optimizer": "device-resident L-BFGS maxcor=10 ftol=1e-13 gtol=1e-7 on a preconditioned variable; path "
-                                "shortcuts that leave the optimum alone (DESIGN.md S4): capped start, step-length memory, "
-                                "first-order-corrected 32-bit surrogate verified by an fp64 evaluation of the final point",
+                                "shortcuts that leave the optimum alone (DESIGN.md S4)",
                    "landmarks": lm_note,
                    "nn_distances": f"exact 1-NN on device, untimed ({t_nn:.2f} s)",
                    "timed_region": "x, landmarks, nn_distances resident (x in HBM) -> log-density in host memory; "
                                    "ms_per_step_host_to_host starts from x in host memory (BASELINE.md S2)",
                    "predict_equals_fit_predict_rel_max": prop, "device": info["arch"]},
-        **roofline_objects(stats, elapsed / args.steps if world == 1 else None, ach, per_launch, n64, traffic, traffic_src,
-                           ach32, per_launch32, int(n32), bytes32, traffic32),
+        "roofline": roof,
         "stages_s": {k: round(v, 4) for k, v in stats.items() if k.endswith("_s")},
         "host_s": {"fit_predict_per_step": round(t_fit / args.steps, 4), "release_per_step": round(t_free / args.steps, 4)},
     }
+    if stats_mixed is not None and stats_mixed.get("objective32_launches", 0.0) > 0:
+        out["roofline_mixed_passes"] = roofline_object(
+            "k_objective32 (the same pass over the 32-bit fixed-point copy of K: the warm-up passes of the product default; "
+            "NOT part of the timed fp64 step)", bytes64 / 2.0, stats_mixed["objective32_kernel_s"],
+            stats_mixed["objective32_launches"], None, traffic32, traffic_src)
     mfile = os.path.join(ROOT, "profiles", "mfma_util.json")
     if os.path.exists(mfile):
         try:
             out["mfma"] = json.load(open(mfile))
         except Exception:
             pass
-    if world == 1 and (args.cpu_sample > 0 or args.cpu_sample_full):
+    if world == 1 and args.cpu_sample != 0:
         gc.collect()
-        if args.cpu_sample_full:
-            samples = [250_000, 500_000]
+        samples, why = pick_cpu_samples(args, n, host_memory_gb())
+        if samples is not None:
+            out["cpu_baseline"] = cpu_baseline(x0, landmarks, nn_loc, args.kernel, samples, n_total)
+            out["cpu_baseline"]["sample"] += "; " + why
         else:
-            big = min(args.cpu_sample, n)
-            samples = [max(big // 2, 1), big]
-        out["cpu_baseline"] = cpu_baseline(x0, landmarks, nn_loc, args.kernel, samples, n_total)
+            out["cpu_baseline"] = cpu_baseline_budgeted(x0, landmarks, nn_loc, args.kernel, n_total, args.cpu_budget_s,
+                                                        host_memory_gb())
     _print_result_line(real_stdout, json.dumps(out))
 
 

@@ -88,6 +88,7 @@ int mln_ctx_create(int device, mln_ctx** out);
 void mln_ctx_destroy(mln_ctx* ctx);
 const char* mln_last_error(mln_ctx* ctx); /* ctx may be NULL: last error of the calling thread */
 int mln_device_info(mln_ctx* ctx, char* name, int name_cap, int* n_cu, int64_t* mem_bytes);
+int mln_device_count(int* count_out); /* GPUs visible to this process (0 and MLN_OK when there are none) */
 int mln_synchronize(mln_ctx* ctx);
 
 int mln_malloc(mln_ctx* ctx, int64_t bytes, void** dev_ptr);
@@ -172,6 +173,32 @@ int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, i
  * predictor-weight entries are unavailable on this handle.                                      */
 int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, int64_t m, const double* Lp,
                    mln_fit** out);
+/* ---- kernel-plugin surface, user-defined kernels: a Covariance subclass whose k(x, y) is Python code
+ * (base_cov.py:17-69: the ABC's only contract is `k`) cannot be lowered to an mln_kernel_desc.  The binding then
+ * evaluates the USER'S function itself -- cov(xu, xu) once, cov(x_block, xu) in row blocks -- and hands the values
+ * over; everything after the kernel matrix (Cholesky, triangular solves, Ridge, MAP solve, weights) is the same
+ * device path as for the built-in kernels.  The same entries serve covariance trees too large for one device
+ * program (MLN_MAX_LEAVES / MLN_MAX_TOKS), whose blocks the binding assembles on the device with mln_ewise.
+ *   mln_fit_prepare_from_K  Kuu = cov(xu, xu) (m x m; jitter is added here; ignored when Lp_in is given);
+ *                           flags: MLN_FIT_IMPLICIT as above; MLN_FIT_FULL: the full GP (n_local == m, L = Lp,
+ *                           no n x m buffer, nothing to upload)
+ *   mln_fit_set_K_rows      rows [row0, row0 + n_rows) of cov(x, xu), n_rows x m, host or device
+ *   mln_fit_finish_K        after the last block: L = K Lp^-T unless implicit; the handle is then a normal fit     */
+#define MLN_FIT_FULL 2
+int mln_fit_prepare_from_K(mln_ctx* ctx, const double* Kuu, int64_t n_local, int64_t m, double jitter,
+                           const double* Lp_in, int32_t flags, mln_fit** out);
+int mln_fit_set_K_rows(mln_fit* fit, int64_t row0, int64_t n_rows, const double* K_rows);
+int mln_fit_finish_K(mln_fit* fit);
+/* C (M x N) = alpha op(A) op(B) + beta C on the fp64 matrix cores; row-major, host or device pointers.
+ * ta = 0: A is M x K (lda >= K); ta = 1: A is stored K x M.  tb likewise.  The mean of a predictor with a
+ * user-defined kernel is mu + cov(Xnew, centers) W with the kernel block evaluated by the user's k
+ * (conditional.py:366-373,651-658,899-906).                                                                       */
+int mln_gemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+/* out[i] = a[i] op (b ? b[i] : scalar), op in {MLN_OP_ADD, MLN_OP_MUL, MLN_OP_POW} (base_cov.py:309-315,375-381,
+ * 449-453 on whole blocks); out may alias a.  Device or host pointers.                                            */
+int mln_ewise(mln_ctx* ctx, int32_t op, const double* a, const double* b, double scalar, double* out, int64_t count);
+
 void mln_fit_destroy(mln_fit* fit);
 int mln_fit_get_Lp(mln_fit* fit, double* out /* m x m */);
 int mln_fit_get_L(mln_fit* fit, int64_t row0, int64_t n_rows, double* out /* n_rows x m */);
@@ -358,8 +385,11 @@ int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const 
  * 32-bit copy (mixed precision: they stream 4 bytes per element, half of [7]); [10] the format of that copy:
  * 0 none, 1 fp32 values, 2 32-bit fixed point round(v 2^32) (covariances bounded by 1); [11] seconds spent on
  * other ranks' column blocks under MELLON_AMD_EMULATE_RANKS (tools/emulate_rank.py; 0 otherwise), already excluded
- * from [3] and [4].                                                                                                  */
-#define MLN_N_STAGE_TIMES 12
+ * from [3] and [4].
+ * [12] / [13] kernel seconds / launches of the solver's subsample passes (every [14]-th row: the cells of the preconditioner's
+ * Gram); [15] wall seconds and [16] count of preconditioner rebuilds inside mln_map_solve; [17] passes over the n x m buffer in
+ * full-fp64-pass equivalents ([6] + [9] / 2 + [13] / [14]).                                                            */
+#define MLN_N_STAGE_TIMES 18
 int mln_stage_times(mln_fit* fit, double* out /* MLN_N_STAGE_TIMES */);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmellon_hip.so")
 
 MLN_OK, MLN_ERR_NOT_PD, MLN_ERR_SHAPE, MLN_ERR_HIP, MLN_ERR_RCCL, MLN_ERR_ARG, MLN_ERR_UNSUPPORTED = range(7)
 MLN_UNIQUE_ID_BYTES = 128
-MLN_N_STAGE_TIMES = 12
+MLN_N_STAGE_TIMES = 18
 
 K_MATERN32, K_MATERN52, K_EXPQUAD, K_EXPONENTIAL, K_RATQUAD, K_LINEAR, K_DISTANCE = 1, 2, 3, 4, 5, 6, 7
 OP_LEAF, OP_CONST, OP_ADD, OP_MUL, OP_POW = 0, 1, 2, 3, 4
@@ -52,6 +52,7 @@ SYMBOLS = [
     ("mln_ctx_destroy", None, [_vp]),
     ("mln_last_error", C.c_char_p, [_vp]),
     ("mln_device_info", C.c_int, [_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
+    ("mln_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("mln_synchronize", C.c_int, [_vp]),
     ("mln_malloc", C.c_int, [_vp, _i64, C.POINTER(_vp)]),
     ("mln_free", C.c_int, [_vp, _vp]),
@@ -75,6 +76,11 @@ SYMBOLS = [
     ("mln_trsm_lower", C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64]),
     ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, _i32, C.POINTER(_vp)]),
     ("mln_fit_from_L", C.c_int, [_vp, _dp, _i64, _i64, _dp, C.POINTER(_vp)]),
+    ("mln_fit_prepare_from_K", C.c_int, [_vp, _dp, _i64, _i64, _dbl, _dp, _i32, C.POINTER(_vp)]),
+    ("mln_fit_set_K_rows", C.c_int, [_vp, _i64, _i64, _dp]),
+    ("mln_fit_finish_K", C.c_int, [_vp]),
+    ("mln_gemm", C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _dbl, _dp, _i64, _dp, _i64, _dbl, _dp, _i64]),
+    ("mln_ewise", C.c_int, [_vp, _i32, _dp, _dp, _dbl, _dp, _i64]),
     ("mln_fit_destroy", None, [_vp]),
     ("mln_fit_get_Lp", C.c_int, [_vp, _dp]),
     ("mln_fit_get_L", C.c_int, [_vp, _i64, _i64, _dp]),
@@ -132,6 +138,31 @@ def load_library():
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def device_count():
+    """GPUs visible to this process."""
+    n = C.c_int(0)
+    load_library().mln_device_count(C.byref(n))
+    return int(n.value)
+
+
+class BlockEvaluatedCov:
+    """Marker base of covariances that do not lower to ONE device program (a user-defined Python `k`, or a tree beyond
+    MLN_MAX_LEAVES / MLN_MAX_TOKS): `block(x, y)` returns the kernel values of one row block -- a DeviceArray when they
+    were assembled on the device, else a host array -- and the Context methods below take the values-in route
+    (mln_fit_prepare_from_K, mln_gemm).  base_cov.BlockCov implements it."""
+    rows_per_block = 8192
+
+    def block(self, x, y):
+        raise NotImplementedError
+
+
+def _needs_program(desc, what):
+    if isinstance(desc, BlockEvaluatedCov):
+        raise NotImplementedError(
+            f"{what} needs a covariance that lowers to one device program (built-in kernels combined with + * ** within "
+            "the program limits); user-defined Python kernels and larger trees support k(), fit and the predictive mean.")
 
 
 class DeviceArray:
@@ -272,6 +303,12 @@ class Context:
         x, y = _as2d(x), _as2d(y)
         if x.shape[1] != y.shape[1]:
             raise ValueError("x and y must have the same number of features")
+        if isinstance(desc, BlockEvaluatedCov):
+            out = np.empty((x.shape[0], y.shape[0]), dtype=np.float64)
+            for i0 in range(0, x.shape[0], desc.rows_per_block):
+                blk = desc.block(x[i0:i0 + desc.rows_per_block], y)
+                out[i0:i0 + desc.rows_per_block] = blk.to_host() if isinstance(blk, DeviceArray) else blk
+            return out
         out = np.empty((x.shape[0], y.shape[0]), dtype=np.float64)
         self._check(self.lib.mln_kernel_matrix(self.handle, desc.ref, _ptr(x), x.shape[0], _ptr(y), y.shape[0],
                                                x.shape[1], out.ctypes.data))
@@ -279,6 +316,15 @@ class Context:
 
     def kernel_gram(self, desc, x, xu):
         """cov(x, xu)^T cov(x, xu) as an (m, m) array."""
+        if isinstance(desc, BlockEvaluatedCov):
+            xh = x.to_host() if isinstance(x, DeviceArray) else _as2d(x)
+            xu = _as2d(xu)
+            G = self.to_device(np.zeros((xu.shape[0], xu.shape[0])))
+            for i0 in range(0, xh.shape[0], desc.rows_per_block):
+                blk = desc.block(xh[i0:i0 + desc.rows_per_block], xu)
+                self.gemm(blk, blk, ta=True, out=G, beta=1.0)
+            G = self.allreduce_sum(G)
+            return G.to_host()
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
         out = np.empty((xu.shape[0], xu.shape[0]), dtype=np.float64)
@@ -288,6 +334,7 @@ class Context:
 
     def kernel_grad(self, desc, x, y):
         """d cov(x_i, y_j) / d y_j as an (n, m, d) array (Covariance.k_grad)."""
+        _needs_program(desc, "kernel_grad")
         x, y = _as2d(x), _as2d(y)
         if x.shape[1] != y.shape[1]:
             raise ValueError("x and y must have the same number of features")
@@ -298,6 +345,7 @@ class Context:
 
     def predict_gradient(self, desc, xnew, centers, W):
         """Gradient of the predictive mean with respect to each query point: (n_new, d)."""
+        _needs_program(desc, "predict_gradient")
         xnew = xnew if isinstance(xnew, DeviceArray) else _as2d(xnew)
         centers = centers if isinstance(centers, DeviceArray) else _as2d(centers)
         Wd = _f64(W)
@@ -312,6 +360,7 @@ class Context:
 
     def predict_hessian(self, desc, xnew, centers, W):
         """Hessian of the predictive mean at each query point: (n_new, d, d)."""
+        _needs_program(desc, "predict_hessian")
         xnew = xnew if isinstance(xnew, DeviceArray) else _as2d(xnew)
         centers = centers if isinstance(centers, DeviceArray) else _as2d(centers)
         Wd = _f64(W)
@@ -378,11 +427,22 @@ class Context:
         m = centers.shape[0]
         p = 1 if len(Wd.shape) == 1 else Wd.shape[1]
         out = np.empty((n_new,) if len(Wd.shape) == 1 else (n_new, p), dtype=np.float64)
+        if isinstance(desc, BlockEvaluatedCov):
+            # mean = mu + cov(Xnew, centers) W with the kernel block from the user's k: conditional.py:366-373,651-658,899-906
+            xh = xnew.to_host() if isinstance(xnew, DeviceArray) else xnew
+            ch = centers.to_host() if isinstance(centers, DeviceArray) else centers
+            W2 = Wd if isinstance(Wd, DeviceArray) else self.to_device(np.ascontiguousarray(Wd.reshape(m, p)))
+            for i0 in range(0, n_new, desc.rows_per_block):
+                blk = desc.block(xh[i0:i0 + desc.rows_per_block], ch)
+                res = self.gemm(blk, W2).to_host() + float(mu)
+                out[i0:i0 + desc.rows_per_block] = res[:, 0] if out.ndim == 1 else res
+            return out
         self._check(self.lib.mln_predict_mean(self.handle, desc.ref, _ptr(xnew), n_new, d, _ptr(centers), m,
                                               _ptr(Wd), p, float(mu), out.ctypes.data))
         return out
 
     def predict_covariance(self, desc, xnew, centers, Lf, diag=True):
+        _needs_program(desc, "predict_covariance")
         xnew, centers, Lf = _as2d(xnew), _as2d(centers), _f64(Lf)
         n = xnew.shape[0]
         out = np.empty((n,) if diag else (n, n), dtype=np.float64)
@@ -392,6 +452,7 @@ class Context:
         return out
 
     def predict_mean_covariance(self, desc, xnew, centers, W, diag=True):
+        _needs_program(desc, "predict_mean_covariance")
         xnew, centers, W = _as2d(xnew), _as2d(centers), _as2d(W)
         n = xnew.shape[0]
         out = np.empty((n,) if diag else (n, n), dtype=np.float64)
@@ -402,6 +463,7 @@ class Context:
 
     def sparse_solve(self, desc, x, xu, y, mu, sigma, jitter, return_factors=False):
         """Weights of the noisy landmark conditional; with return_factors also (Lp, Cs = Lp L_B)."""
+        _needs_program(desc, "sparse_solve")
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
         y2 = _f64(y)
@@ -424,6 +486,7 @@ class Context:
 
     def sparse_solve_noise(self, desc, x, xu, y, mu, sigma, kind, jitter):
         """Landmark-conditional weights under per-output (sigma[p]) or per-cell (sigma[n]) noise."""
+        _needs_program(desc, "sparse_solve_noise")
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
         y2 = _f64(y)
@@ -442,6 +505,7 @@ class Context:
     def full_conditional_noise(self, desc, x, y, mu, sigma, jitter, leverage=False, obs_variance=False):
         """Full-GP weights for outputs with one noise level each, from one eigendecomposition of K(x, x).
         Returns W, or (W, leverage), or (W, leverage, corrected_r2, variance_W)."""
+        _needs_program(desc, "full_conditional_noise")
         x = _as2d(x)
         y2 = np.ascontiguousarray(_f64(y))
         sig = _f64(np.atleast_1d(sigma))
@@ -469,6 +533,7 @@ class Context:
 
     def landmark_leverage(self, desc, x, xu, Lk, sigma, jitter):
         """(n, p) leverage of the landmark conditional for the p noise levels `sigma`, K_uu = Lk Lk^T."""
+        _needs_program(desc, "landmark_leverage")
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
         Lk = _f64(Lk)
@@ -507,7 +572,43 @@ class Context:
         return r.value
 
     def fit_prepare(self, desc, x, landmarks, jitter, Lp=None, implicit=False):
+        if isinstance(desc, BlockEvaluatedCov):
+            return Fit.from_blocks(self, desc, x, landmarks, jitter, Lp, implicit)
         return Fit(self, desc, x, landmarks, jitter, Lp, implicit)
+
+    def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None):
+        """out = alpha op(A) op(B) + beta out on the fp64 matrix cores (mln_gemm); A, B, out host arrays or
+        DeviceArrays (2-D, row-major).  Returns a DeviceArray unless `out` is a host array."""
+        A = A if isinstance(A, DeviceArray) else _as2d(A)
+        B = B if isinstance(B, DeviceArray) else _as2d(B)
+        M, K = (A.shape[1], A.shape[0]) if ta else A.shape
+        Kb, N = (B.shape[1], B.shape[0]) if tb else B.shape
+        if K != Kb:
+            raise ValueError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+        if out is None:
+            out = self.empty((M, N))
+            beta = 0.0
+        if tuple(out.shape) != (M, N):
+            raise ValueError(f"gemm: out has shape {tuple(out.shape)}, expected {(M, N)}")
+        self._check(self.lib.mln_gemm(self.handle, 1 if ta else 0, 1 if tb else 0, M, N, K, float(alpha), _ptr(A),
+                                      A.shape[1], _ptr(B), B.shape[1], float(beta), _ptr(out), N))
+        return out
+
+    def ewise(self, op, a, b, out=None):
+        """a op b element-wise on the device (op: OP_ADD / OP_MUL / OP_POW; b an array like a, or a scalar)."""
+        a = a if isinstance(a, DeviceArray) else self.to_device(a)
+        out = a if out is None else out
+        scalar = 0.0
+        bp = None
+        if isinstance(b, (int, float, np.floating, np.integer)):
+            scalar = float(b)
+        else:
+            b = b if isinstance(b, DeviceArray) else self.to_device(b)
+            if tuple(b.shape) != tuple(a.shape):
+                raise ValueError("ewise: shapes differ")
+            bp = b.ptr
+        self._check(self.lib.mln_ewise(self.handle, int(op), a.ptr, bp, scalar, out.ptr, a.size))
+        return out
 
 
 class LoopbackGroup:
@@ -560,6 +661,44 @@ class Fit:
         self.n, self.d, self.m, self.jitter = n, None, m, None
         self.implicit = False
         self._has_lp = Lp_ is not None
+        return self
+
+    @classmethod
+    def from_blocks(cls, ctx, cov, x, landmarks, jitter, Lp=None, implicit=False):
+        """The fit of a covariance that is evaluated block-wise by the binding (BlockEvaluatedCov: a user-defined Python
+        `k`, or a tree too large for one device program): cov(xu, xu) and the row blocks of cov(x, xu) are handed to the
+        library as VALUES (mln_fit_prepare_from_K / mln_fit_set_K_rows / mln_fit_finish_K); the factorisations, the Ridge
+        start, the MAP solve and the weights are the unchanged device path."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self.handle = ctx, ctx.lib, None
+        xh = x.to_host() if isinstance(x, DeviceArray) else _as2d(x)
+        n, d = xh.shape
+        full = landmarks is None
+        xu = xh if full else (landmarks.to_host() if isinstance(landmarks, DeviceArray) else _as2d(landmarks))
+        m = xu.shape[0]
+        self.implicit = bool(implicit) and not full
+        Lp_ = None if Lp is None else _f64(Lp)
+        if Lp_ is not None and Lp_.shape != (m, m):
+            raise ValueError(f"Lp has shape {Lp_.shape}, expected {(m, m)}")
+        Kuu = None
+        if Lp_ is None:
+            Kuu = cov.block(xu, xu)
+        flags = (1 if self.implicit else 0) | (2 if full else 0)
+        h = C.c_void_p()
+        ctx._check(self.lib.mln_fit_prepare_from_K(ctx.handle, _ptr(Kuu), n, m, float(jitter), _ptr(Lp_), flags,
+                                                   C.byref(h)), jitter=jitter)
+        self.handle = h.value
+        self.n, self.d, self.m, self.jitter = n, d, m, jitter
+        self._has_lp = True
+        if not full:
+            for i0 in range(0, n, cov.rows_per_block):
+                blk = cov.block(xh[i0:i0 + cov.rows_per_block], xu)
+                rows = min(cov.rows_per_block, n - i0)
+                if tuple(blk.shape) != (rows, m):
+                    raise ValueError(f"covariance returned a block of shape {tuple(blk.shape)}, expected {(rows, m)}")
+                blk = blk if isinstance(blk, DeviceArray) else _f64(blk)
+                ctx._check(self.lib.mln_fit_set_K_rows(self.handle, i0, rows, _ptr(blk)))
+        ctx._check(self.lib.mln_fit_finish_K(self.handle))
         return self
 
     def gram_eigh(self):
@@ -647,11 +786,16 @@ class Fit:
                                                _ptr(hess)))
         return (loss.value, grad, hess) if with_hess else (loss.value, grad)
 
-    def precond_build(self, row_stride=1, row_offset=0):
+    def precond_build(self, row_stride=1, row_offset=0, force=False):
         """Factor the Ridge / preconditioner matrix from the cells whose global index (row_offset + local index) is a
-        multiple of row_stride; a no-op once built."""
+        multiple of row_stride.  A no-op once a factor exists, unless `force` asks for this very sample (the library
+        then re-factors when the stride differs from the one it has)."""
+        built = getattr(self, "_precond_stride", None)
+        if built is not None and (not force or built == int(row_stride)):
+            return
         self.ctx._check(self.lib.mln_fit_set_row_offset(self.handle, int(row_offset)))
         self.ctx._check(self.lib.mln_precond_build(self.handle, int(row_stride)), jitter="ridge")
+        self._precond_stride = max(1, int(row_stride))
 
     def precond_apply(self, mode, v):
         """mode 0: u = C^T z; 1: z = C^-T u; 2: g_u = C^-1 g_z  (C C^T = L^T L + I)."""
@@ -706,7 +850,9 @@ class Fit:
         self.ctx._check(self.lib.mln_stage_times(self.handle, out.ctypes.data))
         keys = ["kernel_matrix_s", "cholesky_s", "trsm_s", "ridge_gram_s", "ridge_solve_s",
                 "objective_kernel_s", "objective_launches", "objective_bytes_per_launch",
-                "objective32_kernel_s", "objective32_launches", "copy32_format", "emulation_excluded_s"]
+                "objective32_kernel_s", "objective32_launches", "copy32_format", "emulation_excluded_s",
+                "objective_sub_kernel_s", "objective_sub_launches", "objective_sub_stride", "precond_rebuild_s",
+                "precond_rebuilds", "objective_pass_equivalents"]
         return dict(zip(keys, out.tolist()))
 
 

@@ -1,7 +1,11 @@
 """Kernel-plugin surface: Covariance ABC with `+ * **`, active_dims and the reference's JSON
 wire format (mellon/base_cov.py:17-497).  `k()` is evaluated by the HIP tile kernel through the
 C-ABI: a covariance tree is lowered to a postfix program over leaves (include/mellon_hip.h).
-Custom Python `k` implementations cannot be lowered and are refused -- there is no CPU fallback.
+A subclass that defines its own Python `k(x, y)` (the ABC's only contract, reference base_cov.py:17-69) cannot be
+lowered: `lower()` then returns a `BlockCov`, through which the binding evaluates the USER'S function in row blocks and
+hands the values to the library (mln_fit_prepare_from_K, mln_gemm) -- everything after the kernel matrix stays on the
+device.  Trees larger than one device program (MLN_MAX_LEAVES / MLN_MAX_TOKS / stack depth) take the same route, their
+sub-trees evaluated by device programs and combined on the device (mln_ewise).
 """
 import ctypes as C
 import json
@@ -38,6 +42,37 @@ class LoweredCov:
         self.leaves, self.toks = leaves, toks
 
 
+# limits of ONE device program (include/mellon_hip.h, csrc/api.hip mln_lower_cov)
+MAX_LEAVES, MAX_TOKS, MAX_DEPTH, MAX_DIMS = 4, 16, 3, 256
+
+
+def _program_fits(leaves, toks):
+    if not (1 <= len(leaves) <= MAX_LEAVES and 1 <= len(toks) <= MAX_TOKS):
+        return False
+    if sum(len(l[3]) for l in leaves) > MAX_DIMS:
+        return False
+    depth = 0
+    for op, _, _ in toks:
+        depth += 1 if op in (_lib.OP_LEAF, _lib.OP_CONST) else -1
+        if depth > MAX_DEPTH:
+            return False
+    return True
+
+
+class BlockCov(_lib.BlockEvaluatedCov):
+    """A covariance evaluated block by block: what `Covariance.lower()` returns for trees that are not one device
+    program.  `block(x, y)` walks the tree: every sub-tree that IS a device program becomes one kernel-matrix launch,
+    user-defined leaves call the user's `k` on the host, and Add / Mul / Pow nodes combine the blocks on the device."""
+
+    def __init__(self, cov, d):
+        self.cov, self.d = cov, int(d)
+
+    def block(self, x, y):
+        x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
+        y = np.ascontiguousarray(ensure_2d(y), dtype=np.float64)
+        return self.cov._block(np.arange(self.d), x, y)
+
+
 class Covariance(ABC):
     """Base covariance function (reference base_cov.py:17-224)."""
 
@@ -54,21 +89,55 @@ class Covariance(ABC):
         return self.__class__.__name__ + "(" + ", ".join(args) + ")"
 
     # -- lowering ---------------------------------------------------------------------------------
+    def _user_defined(self):
+        """A leaf whose arithmetic is the subclass's own Python `k` (no device kind, or `k` overridden)."""
+        return self._kind is None or type(self).k is not Covariance.k
+
     def _emit(self, cols, leaves, toks):
-        """Append this node's leaves / tokens; `cols` are the original column indices visible here."""
-        if self._kind is None:
+        """Append this node's leaves / tokens; `cols` are the original column indices visible here.
+        Raises NotImplementedError for user-defined leaves (the caller falls back to block evaluation)."""
+        if self._user_defined():
             raise NotImplementedError(
-                f"Covariance {self.__class__.__name__} defines a Python-level k(); only compositions of the "
-                "built-in kernels can be lowered to the HIP kernel program (no CPU fallback).")
+                f"Covariance {self.__class__.__name__} defines a Python-level k(): it is evaluated by the binding in "
+                "row blocks (BlockCov), not by the device kernel program.")
         dims = compose_active_dims(cols, self.active_dims)
         leaves.append((self._kind, getattr(self, "ls", 1.0), getattr(self, "alpha", 1.0), dims))
         toks.append((_lib.OP_LEAF, len(leaves) - 1, 0.0))
 
-    def lower(self, d):
-        """mln_kernel_desc for inputs with d feature columns."""
+    def _try_program(self, cols):
+        """(leaves, toks) when this sub-tree is one device program over the columns `cols`, else None."""
         leaves, toks = [], []
-        self._emit(np.arange(d), leaves, toks)
-        return LoweredCov(leaves, toks)
+        try:
+            self._emit(cols, leaves, toks)
+        except NotImplementedError:
+            return None
+        return (leaves, toks) if _program_fits(leaves, toks) else None
+
+    def lower(self, d):
+        """What the C ABI takes for inputs with d feature columns: an mln_kernel_desc (LoweredCov) when the tree is one
+        device program, else a BlockCov (values computed block-wise by the binding)."""
+        prog = self._try_program(np.arange(d))
+        if prog is not None:
+            return LoweredCov(*prog)
+        return BlockCov(self, d)
+
+    def _block(self, cols, x, y):
+        """Kernel values of one block; x, y carry ALL original columns, `cols` the ones visible at this node."""
+        prog = self._try_program(cols)
+        if prog is not None:
+            ctx = _lib.default_context()
+            out = ctx.empty((x.shape[0], y.shape[0]))
+            ctx._check(ctx.lib.mln_kernel_matrix(ctx.handle, LoweredCov(*prog).ref, x.ctypes.data, x.shape[0],
+                                                 y.ctypes.data, y.shape[0], x.shape[1], out.ptr))
+            return out
+        # user-defined leaf: the subclass's k sees the columns visible here (enclosing active_dims applied, its own
+        # selection is its own business, as in the reference where k() calls select_active_dims itself)
+        full = len(cols) == x.shape[1] and np.array_equal(cols, np.arange(x.shape[1]))
+        xs, ys = (x, y) if full else (np.ascontiguousarray(x[:, cols]), np.ascontiguousarray(y[:, cols]))
+        vals = np.asarray(type(self).k(self, xs, ys), dtype=np.float64)
+        if vals.shape != (x.shape[0], y.shape[0]):
+            raise ValueError(f"{self.__class__.__name__}.k returned shape {vals.shape}, expected {(x.shape[0], y.shape[0])}")
+        return np.ascontiguousarray(vals)
 
     # -- evaluation ---------------------------------------------------------------------------------
     def k(self, x, y):
@@ -198,6 +267,26 @@ class CovariancePair(Covariance):
         else:
             toks.append((_lib.OP_CONST, 0, float(self.right)))
         toks.append((self._op, 0, 0.0))
+
+    def _user_defined(self):
+        return False
+
+    def _block(self, cols, x, y):
+        prog = self._try_program(cols)
+        if prog is not None:
+            return Covariance._block(self, cols, x, y)
+        ctx = _lib.default_context()
+        cols = compose_active_dims(cols, self.active_dims)
+        left = self.left._block(cols, x, y)
+        left = left if isinstance(left, _lib.DeviceArray) else ctx.to_device(left)
+        if callable(self.right):
+            if self._op == _lib.OP_POW:
+                raise NotImplementedError("covariance ** covariance is not defined")
+            right = self.right._block(cols, x, y)
+            right = right if isinstance(right, _lib.DeviceArray) else ctx.to_device(right)
+        else:
+            right = float(self.right)
+        return ctx.ewise(self._op, left, right)          # in place on the left block
 
     def __getstate__(self):
         right = self.right.__getstate__() if callable(self.right) else make_serializable(self.right)

@@ -117,18 +117,47 @@ class BaseEstimator:
                 f"{what} need all cells; when cells are sharded across ranks pass `{what}=` explicitly "
                 "(replicated landmarks / this rank's nn_distances).")
 
+    def _all_cells(self):
+        """Cell-sharded fit: the cells of ALL ranks in rank order (host array, gathered once over the host
+        communicator) and the global index of this rank's first cell.  Single rank: (x, 0).  Only the two inputs that
+        need every cell -- nearest-neighbour distances and k-means landmarks (parameters.py:243-291,352-433) -- use it."""
+        from .distributed import current
+        comm = current()
+        x_loc = self.x.to_host() if isinstance(self.x, _lib.DeviceArray) else np.ascontiguousarray(self.x, dtype=np.float64)
+        if comm.world_size == 1:
+            return x_loc, 0
+        cached = getattr(self, "_x_all", None)
+        if cached is None:
+            parts = comm.host.allgather(x_loc)
+            lo = int(sum(p.shape[0] for p in parts[:comm.rank]))
+            cached = self._x_all = (np.ascontiguousarray(np.concatenate(parts, axis=0)), lo)
+        return cached
+
     def _compute_landmarks(self):
-        self._require_single_process("landmarks")
-        n = self.x.shape[0]
+        from .distributed import current
+        comm = current()
+        x_all, _ = self._all_cells()
+        n = x_all.shape[0]
         if n > 100 * self.n_landmarks and n > 1e6:
             logger.info(f"Large number of {n:,} cells and small number of {self.n_landmarks:,} landmarks. Consider "
                         "computing k-means on a subset of cells and passing the results as 'landmarks'.")
-        return compute_landmarks(self.x, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed())
+        if comm.world_size == 1:
+            return compute_landmarks(self.x, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed())
+        # replicated input: rank 0 clusters the gathered cells, every rank receives the same bits
+        lm = compute_landmarks(x_all, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed()) \
+            if comm.rank == 0 else None
+        return comm.broadcast(None if lm is None else np.ascontiguousarray(lm, dtype=np.float64), src=0)
 
     def _compute_nn_distances(self):
-        self._require_single_process("nn_distances")
         logger.info("Computing nearest neighbor distances.")
-        return validate_nn_distances(compute_nn_distances(self.x, seed=self._seed()))
+        from .distributed import current
+        if current().world_size == 1:
+            return validate_nn_distances(compute_nn_distances(self.x, seed=self._seed()))
+        x_all, lo = self._all_cells()
+        n_loc = self.x.shape[0]
+        # this rank's cells against the cells of all ranks, the pair (i, lo + i) excluded
+        nn = _lib.default_context().nn_distances(np.ascontiguousarray(x_all[lo:lo + n_loc]), x_all, self_offset=lo)
+        return validate_nn_distances(nn)
 
     def _compute_ls(self):
         return compute_ls(self.nn_distances) * self.ls_factor

@@ -10,6 +10,7 @@
 #include "linalg.h"
 #include "mln_internal.h"
 #include "objective.h"
+#include "precond_rebuild.h"
 #include "solver.h"
 
 // ---- errors -------------------------------------------------------------------------------------
@@ -196,6 +197,14 @@ extern "C" int mln_device_info(mln_ctx* ctx, char* name, int name_cap, int* n_cu
   if (name && name_cap > 0) { std::strncpy(name, prop.gcnArchName, name_cap - 1); name[name_cap - 1] = 0; }
   if (n_cu) *n_cu = prop.multiProcessorCount;
   if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
+  return MLN_OK;
+}
+
+extern "C" int mln_device_count(int* count_out) {
+  if (!count_out) return MLN_ERR_ARG;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+  *count_out = count;
   return MLN_OK;
 }
 
@@ -480,7 +489,23 @@ struct mln_fit {
   // f = L z + mu of every row at the solver's accepted point, kept by the objective passes themselves
   double* f_keep[2] = {nullptr, nullptr};
   int f_final = -1;               // which buffer holds f at z_cached (-1: none; mln_transform then streams the buffer)
+  // row subsample shared by the preconditioner's Gram and the solver's first phase: cells whose GLOBAL index is a
+  // multiple of precond_stride (0: no preconditioner yet; 1: all cells)
+  int64_t precond_stride = 0;
+  // handle whose kernel values come from the binding (mln_fit_prepare_from_K): rows received, finished
+  bool from_K = false, k_finished = false;
+  int64_t k_rows_done = 0;
+  double build_seconds = 0.0;     // wall time of the first preconditioner build (Gram + factorisation): the rebuild's price
+  double times_sub = 0.0, times_rebuild = 0.0;
+  int evals_sub = 0, n_rebuild = 0;
 };
+
+// rows of this shard in the subsample of stride s: first local index and count
+static void fit_sample_rows(const mln_fit* f, int64_t s, int64_t* first, int64_t* rows) {
+  if (s < 1) s = 1;
+  *first = (s - f->row0 % s) % s;
+  *rows = (f->n > *first) ? (f->n - *first + s - 1) / s : 0;
+}
 
 static void fit_free(mln_fit* f) {
   if (!f) return;
@@ -598,7 +623,7 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
     bool mixed = (flags & MLN_FIT_IMPLICIT) != 0;
     if (const char* ev = std::getenv("MELLON_AMD_MIXED")) mixed = mixed && std::atoi(ev) != 0;
     if (const char* ev = std::getenv("MELLON_AMD_MIXED_MIN_ELEMS")) mixed_min = std::atoll(ev);
-    if (mixed && n * m >= mixed_min && n > 0)
+    if (mixed && n * m >= mixed_min && n > 0 && m <= 8192)     // (beyond 8192 landmarks the pass is segmented: objective.hip)
       MLN_HIP(ctx, mln_dmalloc((void**)&f->L32, sizeof(float) * (size_t)n * f->ldl));
     // Format of the copy.  Covariance values of stationary kernels and of their products lie in [0, 1]: there the
     // fixed-point number round(v 2^32) has an absolute error of 1.2e-10 for EVERY entry, where fp32 carries up to 3e-8
@@ -690,6 +715,162 @@ extern "C" int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, in
   if (rc != MLN_OK) { fit_free(f); return rc; }
   *out = f;
   return MLN_OK;
+}
+
+// ---- user-defined kernels / oversized covariance trees: the kernel values arrive from the binding -----------------
+extern "C" int mln_fit_prepare_from_K(mln_ctx* ctx, const double* Kuu, int64_t n_local, int64_t m, double jitter,
+                                      const double* Lp_in, int32_t flags, mln_fit** out) {
+  if (!ctx || !out) return MLN_ERR_ARG;
+  *out = nullptr;
+  const bool full = (flags & MLN_FIT_FULL) != 0;
+  if (n_local < 0 || m < 1 || m > 65535 || (full && n_local != m)) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
+  if (!Kuu && !Lp_in) { mln_set_error(ctx, "mln_fit_prepare_from_K needs cov(xu, xu) or its factor"); return MLN_ERR_ARG; }
+  if (full && ctx->n_ranks > 1) { mln_set_error(ctx, "the full (non-sparse) GP cannot be cell-sharded"); return MLN_ERR_UNSUPPORTED; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  mln_fit* f = new mln_fit();
+  f->ctx = ctx; f->n = n_local; f->m = m; f->d = 0; f->full = full;
+  f->ldl = pad16(m); f->ldp = pad16(m);
+  f->cov.n_leaves = 0; f->cov.n_toks = 0;          // no device program: values only
+  f->from_K = true;
+  f->kspace = !full && (flags & MLN_FIT_IMPLICIT) != 0;
+  auto body = [&]() -> int {
+    double t0 = now_s();
+    const size_t lp_bytes = sizeof(double) * (size_t)m * f->ldp;
+    MLN_HIP(ctx, mln_dmalloc((void**)&f->Lp, lp_bytes));
+    MLN_HIP(ctx, hipMemsetAsync(f->Lp, 0, lp_bytes, ctx->stream));
+    DevIn dk;
+    MLN_TRY(dk.init(ctx, Lp_in ? Lp_in : Kuu, (size_t)m * m));
+    MLN_TRY(launch_copy_block(ctx, dk.dev, m, f->Lp, f->ldp, m, m));
+    if (!Lp_in) {
+      MLN_TRY(launch_add_diag(ctx, f->Lp, m, f->ldp, jitter));          // decomposition.py:111-114
+      MLN_TRY(dev_cholesky_lower(ctx, f->Lp, m, f->ldp));
+    }
+    MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f->times[1] += now_s() - t0;
+    if (full) {
+      f->L = f->Lp;
+      f->k_rows_done = n_local;
+      return fit_alloc_workspace(f);
+    }
+    const size_t l_bytes = sizeof(double) * (size_t)(n_local > 0 ? n_local : 1) * f->ldl;
+    MLN_HIP(ctx, mln_dmalloc((void**)&f->L, l_bytes));
+    if (f->ldl != m) MLN_HIP(ctx, hipMemsetAsync(f->L, 0, l_bytes, ctx->stream));      // the pad columns must be zero
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MLN_OK;
+  };
+  int rc = body();
+  if (rc != MLN_OK) { fit_free(f); return rc; }
+  *out = f;
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_set_K_rows(mln_fit* f, int64_t row0, int64_t n_rows, const double* K_rows) {
+  if (!f || (n_rows > 0 && !K_rows)) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (!f->from_K || f->full || f->k_finished) { mln_set_error(ctx, "mln_fit_set_K_rows: not a handle awaiting kernel rows"); return MLN_ERR_ARG; }
+  if (row0 < 0 || n_rows < 0 || row0 + n_rows > f->n) { mln_set_error(ctx, "mln_fit_set_K_rows: rows out of range"); return MLN_ERR_SHAPE; }
+  if (n_rows == 0) return MLN_OK;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  double t0 = now_s();
+  MLN_HIP(ctx, hipMemcpy2DAsync(f->L + row0 * f->ldl, sizeof(double) * (size_t)f->ldl, K_rows, sizeof(double) * (size_t)f->m,
+                                sizeof(double) * (size_t)f->m, (size_t)n_rows, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  f->k_rows_done += n_rows;
+  f->times[0] += now_s() - t0;
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_finish_K(mln_fit* f) {
+  if (!f) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  if (!f->from_K) { mln_set_error(ctx, "mln_fit_finish_K: not a handle built from kernel values"); return MLN_ERR_ARG; }
+  if (f->k_finished || f->full) { f->k_finished = true; return MLN_OK; }
+  if (f->k_rows_done < f->n) { mln_set_error(ctx, "mln_fit_finish_K: kernel rows are missing"); return MLN_ERR_SHAPE; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  if (!f->kspace) {                       // L = K Lp^-T                                   decomposition.py:205-210
+    double t0 = now_s();
+    MLN_TRY(triinv_solve_right_T(ctx, f->tri, f->L, f->n, f->ldl));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f->times[2] += now_s() - t0;
+  }
+  f->k_finished = true;
+  return fit_alloc_workspace(f);
+}
+
+__global__ void k_ewise(int op, const double* __restrict__ a, const double* __restrict__ b, double scalar,
+                        double* __restrict__ out, int64_t count) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const double l = a[i], r = b ? b[i] : scalar;
+    out[i] = op == MLN_OP_ADD ? l + r : (op == MLN_OP_MUL ? l * r : pow(l, r));
+  }
+}
+
+extern "C" int mln_ewise(mln_ctx* ctx, int32_t op, const double* a, const double* b, double scalar, double* out,
+                         int64_t count) {
+  if (!ctx || count < 0 || (count > 0 && (!a || !out))) return MLN_ERR_ARG;
+  if (op != MLN_OP_ADD && op != MLN_OP_MUL && op != MLN_OP_POW) { mln_set_error(ctx, "mln_ewise: unknown operation"); return MLN_ERR_ARG; }
+  if (count == 0) return MLN_OK;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevIn da, db;
+  DevOut o;
+  const bool alias = (out == a);
+  MLN_TRY(o.init(ctx, out, (size_t)count, alias));
+  if (alias && is_device_ptr(a)) da.dev = a; else if (alias) da.dev = o.dev; else MLN_TRY(da.init(ctx, a, (size_t)count));
+  if (b) MLN_TRY(db.init(ctx, b, (size_t)count));
+  const int64_t blocks = std::min<int64_t>((count + 255) / 256, 65535);
+  hipLaunchKernelGGL(k_ewise, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, op, da.dev, b ? db.dev : nullptr, scalar, o.dev, count);
+  MLN_HIP(ctx, hipGetLastError());
+  return o.commit();
+}
+
+extern "C" int mln_gemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* Cm, int64_t ldc) {
+  if (!ctx || M < 0 || N < 0 || K < 0) return MLN_ERR_ARG;
+  if (M == 0 || N == 0) return MLN_OK;
+  if (!A || !B || !Cm) return MLN_ERR_ARG;
+  const int64_t ar = ta ? K : M, ac = ta ? M : K, br = tb ? N : K, bc = tb ? K : N;
+  if (lda < ac || ldb < bc || ldc < N) { mln_set_error(ctx, "mln_gemm: leading dimension too small"); return MLN_ERR_SHAPE; }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  // host operands are staged compactly (their leading dimension becomes the column count)
+  DevIn da, db;
+  DevOut oc;
+  const bool a_dev = is_device_ptr(A), b_dev = is_device_ptr(B), c_dev = is_device_ptr(Cm);
+  std::vector<double> ha, hb, hc;
+  const double* Ah = A; const double* Bh = B;
+  int64_t lda_d = lda, ldb_d = ldb, ldc_d = ldc;
+  if (!a_dev && lda != ac) { ha.resize((size_t)ar * ac); for (int64_t r = 0; r < ar; ++r) std::memcpy(&ha[(size_t)r * ac], A + r * lda, sizeof(double) * ac); Ah = ha.data(); }
+  if (!b_dev && ldb != bc) { hb.resize((size_t)br * bc); for (int64_t r = 0; r < br; ++r) std::memcpy(&hb[(size_t)r * bc], B + r * ldb, sizeof(double) * bc); Bh = hb.data(); }
+  if (!a_dev) lda_d = ac;
+  if (!b_dev) ldb_d = bc;
+  MLN_TRY(da.init(ctx, Ah, a_dev ? 1 : (size_t)ar * ac));
+  MLN_TRY(db.init(ctx, Bh, b_dev ? 1 : (size_t)br * bc));
+  if (a_dev) da.dev = A;
+  if (b_dev) db.dev = B;
+  double* Cd = Cm;
+  double* c_owned = nullptr;
+  if (!c_dev) {
+    ldc_d = (N + 1) & ~(int64_t)1;
+    MLN_HIP(ctx, mln_dmalloc((void**)&c_owned, sizeof(double) * (size_t)M * ldc_d));
+    Cd = c_owned;
+    if (beta != 0.0)
+      MLN_HIP(ctx, hipMemcpy2DAsync(Cd, sizeof(double) * ldc_d, Cm, sizeof(double) * ldc, sizeof(double) * N, (size_t)M, hipMemcpyHostToDevice, ctx->stream));
+  }
+  GemmArgs g{};
+  g.A = da.dev; g.lda = lda_d; g.B = db.dev; g.ldb = ldb_d; g.C = Cd; g.ldc = ldc_d;
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.ta = ta ? 1 : 0; g.tb = tb ? 1 : 0;
+  int rc = (K > 0) ? launch_dgemm(ctx, g) : MLN_OK;
+  if (rc == MLN_OK && K == 0) {
+    mln_set_error(ctx, "mln_gemm: K = 0");
+    rc = MLN_ERR_SHAPE;
+  }
+  if (rc == MLN_OK && !c_dev) {
+    hipError_t e = hipMemcpy2DAsync(Cm, sizeof(double) * ldc, Cd, sizeof(double) * ldc_d, sizeof(double) * N, (size_t)M, hipMemcpyDeviceToHost, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "mln_gemm download", __FILE__, __LINE__);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  if (c_owned) (void)mln_dfree(c_owned);
+  return rc;
 }
 
 extern "C" int mln_eigh(mln_ctx* ctx, const double* A, int64_t m, double* w, double* V, int32_t* n_sweeps) {
@@ -1238,19 +1419,22 @@ static int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev) {
 // With row_stride > 1 the Gram is estimated from every row_stride-th cell: any SPD matrix is a valid
 // preconditioner / initial guess for a strictly convex problem, and ~8 m rows already give the same
 // iteration count as all n (measured), at 1/row_stride of the n m^2 flops.
-static int fit_build_precond(mln_fit* f, int64_t row_stride) {
-  if (f->Cinv) return MLN_OK;
+static void fit_drop_precond_operators(mln_fit* f) {
+  (void)hipStreamSynchronize(f->ctx->stream);
+  void* ptrs[] = {f->Cinv, f->P, f->Q1, f->Q2};
+  for (void* p : ptrs) if (p) (void)mln_dfree(p);
+  f->Cinv = nullptr; f->P = nullptr; f->Q1 = nullptr; f->Q2 = nullptr;
+}
+
+// f->C holds the (whitened) Gram: add the prior's identity, factor C C^T, and build C^-1, P = Lp^-T C^-T and the stacked
+// per-evaluation operators Q1, Q2
+static int fit_factor_precond(mln_fit* f) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
   const size_t bytes = sizeof(double) * (size_t)m * ldg;
-  double t0 = now_s(), ex0 = f->emu_excluded;
-  MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
-  int rc = fit_gram(f, f->C, ldg, row_stride);
-  f->times[3] += now_s() - t0 - (f->emu_excluded - ex0);
-  t0 = now_s(); ex0 = f->emu_excluded;
   int my_rank = 0; bool emulate = false;
   const int n_split = f->kspace ? split_ranks(ctx, &my_rank, &emulate) : 1;
-  if (rc == MLN_OK) rc = launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1
+  int rc = launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1 / the prior's Hessian
   if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, f->C, m, ldg);
   TriInv t;
   if (rc == MLN_OK) rc = triinv_build(ctx, f->C, m, ldg, true, false, &t);
@@ -1304,7 +1488,66 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&t);
   if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
-  f->times[4] += now_s() - t0 - (f->emu_excluded - ex0);
+  return rc;
+}
+
+static int fit_build_precond(mln_fit* f, int64_t row_stride) {
+  if (f->Cinv) return MLN_OK;
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, ldg = f->ldl;
+  const size_t bytes = sizeof(double) * (size_t)m * ldg;
+  double t0 = now_s(), ex0 = f->emu_excluded;
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
+  int rc = fit_gram(f, f->C, ldg, row_stride);
+  f->times[3] += now_s() - t0 - (f->emu_excluded - ex0);
+  double t1 = now_s(); ex0 = f->emu_excluded;
+  if (rc == MLN_OK) rc = fit_factor_precond(f);
+  f->times[4] += now_s() - t1 - (f->emu_excluded - ex0);
+  if (rc == MLN_OK) { f->precond_stride = row_stride < 1 ? 1 : row_stride; f->build_seconds = now_s() - t0; }
+  return rc;
+}
+
+// The solver's SECOND preconditioner (precond_rebuild.hip): C C^T = I + sum_i a_i L_i L_i^T estimated from an importance
+// sample of ~rows_per_m * m cells at the point whose rows' f = L z + mu is `f_dev`; replaces C, C^-1, P, Q1, Q2.
+static int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, ldg = f->ldl;
+  RebuildSelection sel{};
+  const double target = rows_per_m * (double)m;
+  MLN_TRY(rebuild_select_rows(ctx, f_dev, f->V, f->n, f->row0, target, 0x6d656c6c6f6eull, &sel));
+  double* R = nullptr;
+  int rc = MLN_OK;
+  const int64_t rr = sel.rows > 0 ? sel.rows : 1;
+  if (mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl) != hipSuccess) rc = MLN_ERR_HIP;
+  if (rc == MLN_OK) rc = launch_gather_scale_rows(ctx, f->L, f->ldl, sel.idx, sel.scale, sel.rows, R);
+  fit_drop_precond_operators(f);
+  if (rc == MLN_OK) {
+    // scaled covariances stay in [0, 1]: the integer Gram applies where it did for the first preconditioner
+    bool quant = f->kspace && f->cov_bounded01 && m >= 256;
+    if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
+    rc = gram_of(ctx, R, f->ldl, sel.rows, m, sel.w_max, f->C, ldg, quant);                   // all-reduced
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  if (R) (void)mln_dfree(R);
+  rebuild_selection_free(ctx, &sel);
+  if (rc == MLN_OK && f->kspace) {                                                              // Lp^-1 G Lp^-T
+    int my_rank = 0; bool emulate = false;
+    const int n_split = split_ranks(ctx, &my_rank, &emulate);
+    if (n_split > 1) rc = fit_whiten_split(f, f->C, ldg, n_split, my_rank, emulate);
+    else {
+      double* T = nullptr;
+      hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)m * ldg);
+      if (e == hipSuccess) e = hipMemsetAsync(T, 0, sizeof(double) * (size_t)m * ldg, ctx->stream);
+      if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc Gram temp", __FILE__, __LINE__);
+      if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, f->C, m, ldg);
+      if (rc == MLN_OK) rc = launch_transpose(ctx, f->C, ldg, T, ldg, m);
+      if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, T, m, ldg);
+      if (rc == MLN_OK) rc = (hipMemcpyAsync(f->C, T, sizeof(double) * (size_t)m * ldg, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+      (void)hipStreamSynchronize(ctx->stream);
+      if (T) (void)mln_dfree(T);
+    }
+  }
+  if (rc == MLN_OK) rc = fit_factor_precond(f);
   return rc;
 }
 
@@ -1340,6 +1583,14 @@ extern "C" int mln_fit_set_row_offset(mln_fit* f, int64_t global_row0) {
 extern "C" int mln_precond_build(mln_fit* f, int64_t row_stride) {
   if (!f) return MLN_ERR_ARG;
   MLN_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  if (row_stride < 1) row_stride = 1;
+  if (f->Cinv && f->precond_stride != row_stride) {
+    // an explicit request for a DIFFERENT sample (e.g. the reference's exact Ridge, stride 1, after a sampled
+    // preconditioner had been built): drop the factor and build the one asked for
+    fit_drop_precond_operators(f);
+    if (f->C) { (void)mln_dfree(f->C); f->C = nullptr; }
+    f->precond_stride = 0;
+  }
   return fit_build_precond(f, row_stride);
 }
 
@@ -1352,10 +1603,19 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
   DevIn dt;
   MLN_TRY(dt.init(ctx, target, (size_t)f->n));
   // z0 = (L^T L + I)^-1 L^T t = C^-T C^-1 (L^T t);  implicit mode: C^-1 L^T t = P^T (K^T t)
+  // With a sampled Gram (stride s >= 4) the right-hand side is taken over the SAME cells, s L_s^T t_s: z0 is then the
+  // exact Ridge solution of the subsample -- the problem the solver's first phase works on -- and costs 1/s of a pass.
+  int64_t rs = (f->precond_stride >= 4) ? f->precond_stride : 1;
+  if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) rs = 1; }
+  ObjArgs a = obj_args(f);
+  a.weights = dt.dev;
+  a.part_loss = nullptr;
+  if (rs > 1) {
+    int64_t first = 0, rows = 0;
+    fit_sample_rows(f, rs, &first, &rows);
+    a.n = rows; a.row_first = first; a.row_stride = rs; a.out_scale = (double)rs;
+  }
   if (f->kspace) {
-    ObjArgs a = obj_args(f);
-    a.weights = dt.dev;
-    a.part_loss = nullptr;
     a.L32 = f->L32;   // the Ridge solution only seeds the solve: its right-hand side may come from the 32-bit copy
     a.l32_fixed = f->l32_fixed;
     MLN_TRY(launch_objective(ctx, a));
@@ -1363,8 +1623,10 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
     MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
     MLN_TRY(fit_small_gemv(f, f->P, 1, f->d_out + 1, f->d_gu));
   } else {
-    MLN_TRY(fit_gemvT(f, dt.dev, f->d_u));
-    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_u, f->d_gu));
+    MLN_TRY(launch_objective(ctx, a));
+    MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+    MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
+    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));
   }
   MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_gu, f->d_z));       // z0 = C^-T (.)   [d_gu plays the role of u0]
   MLN_TRY(fit_cache_pair_from_u(f, f->d_gu));
@@ -1399,7 +1661,7 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
 // are launched and the one the solver's state does not select returns at once; everything is a no-op after DONE.
 // ev (optional): three events -- before the fp32 pass, between the two, after the fp64 pass.
 static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32, const int* gate,
-                            hipEvent_t* ev) {
+                            hipEvent_t* ev, int64_t sub_stride = 0) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ld = f->ldl, ld2 = f->ld2;
   GemvTri g1{f->Q1, ld, f->kspace ? 2 * m : m, u_dev, f->d_zr, f->kspace ? f->d_w : nullptr, 1, m, m, 0, 0, gate};
@@ -1422,6 +1684,18 @@ static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, boo
   if (gate || !use32 || !f->L32) {
     a.gate_want = MLN_GATE_F64;
     MLN_TRY(launch_objective(ctx, a));
+  }
+  if (gate && sub_stride > 1) {
+    // the subsample objective of the solver's first phase: the same fp64 kernel over every sub_stride-th row (same grid:
+    // workgroups past the shorter row range write zero partials), sums scaled by sub_stride in the reduction
+    ObjArgs as = a;
+    int64_t first = 0, rows = 0;
+    fit_sample_rows(f, sub_stride, &first, &rows);
+    as.n = rows; as.row_first = first; as.row_stride = sub_stride;
+    as.f_keep[0] = as.f_keep[1] = nullptr; as.f_slot = nullptr;
+    as.gate_want = MLN_GATE_SUB;
+    MLN_TRY(launch_objective(ctx, as));
+    a.out_scale = (double)sub_stride;      // (applied by the reduction only when the solver's gate says SUB)
   }
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
   MLN_TRY(launch_reduce_obj2(ctx, a, f->d_zr + ld2 + m, f->d_zr + ld2));
@@ -1498,6 +1772,11 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   mln_ctx* ctx = f->ctx;
   if (!f->V) { mln_set_error(ctx, "mln_fit_set_likelihood has not been called"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
+  if (f->m > 8192) {
+    mln_set_error(ctx, "mln_map_solve: the device-resident solver holds at most 8192 landmarks; drive mln_objective_precond "
+                       "from the host instead (the Python binding does: inference.minimize_lbfgsb)");
+    return MLN_ERR_UNSUPPORTED;
+  }
   MLN_TRY(fit_build_precond(f, 1));
   mln_solver_opts o = {5000, 10, 30, 1e-13, 1e-7};
   if (opts_in) o = *opts_in;
@@ -1546,6 +1825,34 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (const char* ev = std::getenv("MELLON_AMD_EXP_CAP_FALL")) init.cap_fall = std::atof(ev);
   init.boost_fall = 0.15;
   if (const char* ev = std::getenv("MELLON_AMD_LS_BOOST_FALL")) init.boost_fall = std::atof(ev);
+  // Subsample start (solver.h): when the preconditioner's Gram came from every s-th cell (s >= 4), the solve starts
+  // on the MAP problem of exactly those cells -- the Ridge matrix is ITS Hessian at a = 1 -- at 1/s of the bytes per
+  // pass, and moves to all cells once that problem's progress per iteration is below sub_tol.  The walk down from the
+  // Ridge start (a dozen passes) then costs about two.  MELLON_AMD_SUBSAMPLE=0 disables, MELLON_AMD_SUB_TOL moves it.
+  int64_t sub_stride = (f->precond_stride >= 4) ? f->precond_stride : 0;
+  if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) sub_stride = 0; }
+  init.gate_full = init.gate;
+  init.sub_tol = 1e-3;
+  if (const char* ev = std::getenv("MELLON_AMD_SUB_TOL")) init.sub_tol = std::atof(ev);
+  if (sub_stride > 1) { init.gate = MLN_GATE_SUB; init.cap = __builtin_inf(); }
+  // Preconditioner rebuild (solver.h, precond_rebuild.hip): pays when the ~12 full passes it saves cost more than the
+  // m^3 work of a second factorisation -- decided from rank 0's measurement of the first build, the same on every rank.
+  // MELLON_AMD_REBUILD=0 / 1 forces the decision.
+  const double pass_s = (double)f->n * (double)f->ldl * 8.0 / 6.5e12;
+  double want_rebuild = (f->build_seconds > 0.0 && 12.0 * pass_s > 1.1 * f->build_seconds) ? 1.0 : 0.0;
+  if (const char* ev = std::getenv("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
+  if (phase32) want_rebuild = 0.0;          // (the 32-bit phases keep no f per row: fp64-only solves for now)
+  {
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_tmp, &want_rebuild, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MLN_TRY(dev_bcast0(ctx, f->d_tmp, 1));
+    MLN_HIP(ctx, hipMemcpyAsync(&want_rebuild, f->d_tmp, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  init.rebuild_armed = want_rebuild != 0.0 ? 1 : 0;
+  init.rebuild_tol = 1e-2;
+  if (const char* ev = std::getenv("MELLON_AMD_REBUILD_TOL")) init.rebuild_tol = std::atof(ev);
+  double rebuild_rows_per_m = 12.0;
+  if (const char* ev = std::getenv("MELLON_AMD_REBUILD_ROWS_PER_M")) rebuild_rows_per_m = std::atof(ev);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
   const int* gate = &f->sv.st->gate;
   static const bool timing = !(std::getenv("MELLON_AMD_TIMING") && std::atoi(std::getenv("MELLON_AMD_TIMING")) == 0);
@@ -1559,7 +1866,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     }
     return &f->evs[3 * i];
   };
-  MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq)));
+  MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), sub_stride));
   ++n_enq;
   int batch = 8;
   if (const char* ev = std::getenv("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
@@ -1567,7 +1874,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   for (;;) {
     for (int b = 0; b < batch; ++b) {
       MLN_TRY(launch_solver_step(ctx, f->sv, (int)m));
-      MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq)));
+      MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), sub_stride));
       ++n_enq;
     }
     // rank 0's state decides for everyone (it is the same state on every rank by construction: identical inputs,
@@ -1576,6 +1883,35 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     MLN_HIP(ctx, hipMemcpyAsync(f->h_state, f->sv.st, sizeof(SolverState), hipMemcpyDeviceToHost, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (f->h_state->gate == MLN_GATE_DONE) break;
+    if (f->h_state->gate == MLN_GATE_PAUSE) {
+      // ---- second preconditioner at the accepted point (whose rows' f the last accepted fp64 pass left in f_keep) ----
+      const double tr0 = now_s();
+      const SolverState ps = *f->h_state;
+      if (!ps.f_valid || !objective_can_keep_f(f->n, f->n_wg)) {
+        // no per-row f to weight the cells with: resume with the preconditioner we have
+        MLN_TRY(launch_solver_resume(ctx, f->sv, init.gate_full, 0));
+      } else {
+        double *zt = nullptr, *gz = nullptr;
+        MLN_HIP(ctx, mln_dmalloc((void**)&zt, sizeof(double) * 2 * (size_t)f->ldl));
+        gz = zt + f->ldl;
+        MLN_HIP(ctx, hipMemsetAsync(zt, 0, sizeof(double) * 2 * (size_t)f->ldl, ctx->stream));
+        // old variable -> z-space:  z = C^-T u,  g_z = C g_u
+        int rc = fit_small_gemv(f, f->Cinv, 1, f->sv.u, zt);
+        if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 0, f->sv.g, gz);
+        if (rc == MLN_OK) rc = fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m);
+        // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z
+        if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 1, zt, f->sv.u);
+        if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, gz, f->sv.g);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)mln_dfree(zt);
+        MLN_TRY(rc);
+        MLN_TRY(launch_solver_resume(ctx, f->sv, init.gate_full, 1));
+        f->n_rebuild += 1;
+      }
+      MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      f->times_rebuild += now_s() - tr0;
+      continue;
+    }
     if (n_enq > hard_cap) { mln_set_error(ctx, "map_solve: the device solver did not terminate"); return MLN_ERR_NOCONV; }
     if (batch < 16 && f->h_state->gate == MLN_GATE_F64) batch = std::min(batch, 6);
   }
@@ -1587,15 +1923,16 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     tr.resize((size_t)4 * n_done);
     MLN_HIP(ctx, hipMemcpy(tr.data(), f->sv.trace, sizeof(double) * 4 * n_done, hipMemcpyDeviceToHost));
     for (int i = 0; i < n_done && timing && 3 * (i + 1) <= (int)f->evs.size(); ++i) {
-      const bool was32 = ((int)tr[4 * i + 3] & 3) == MLN_GATE_F32;
+      const bool was32 = ((int)tr[4 * i + 3] & 3) == MLN_GATE_F32, was_sub = (int)tr[4 * i + 3] == MLN_GATE_SUB;
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, f->evs[3 * i + (was32 ? 0 : 1)], f->evs[3 * i + (was32 ? 1 : 2)]) != hipSuccess) continue;
-      if (was32) { f->times32 += 1e-3 * ms; f->evals32 += 1; }
+      if (was_sub) { f->times_sub += 1e-3 * ms; f->evals_sub += 1; }
+      else if (was32) { f->times32 += 1e-3 * ms; f->evals32 += 1; }
       else { f->times[5] += 1e-3 * ms; f->times[6] += 1.0; f->times[7] = (double)f->n * (double)f->ldl * 8.0; }
     }
     if (trace_lvl >= 2)
       for (int i = 0; i < n_done; ++i)
-        fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, (int)tr[4 * i + 3] == MLN_GATE_F32 ? "f32" : ((int)tr[4 * i + 3] == MLN_GATE_F32C ? "f32c" : "f64"),
+        fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, (int)tr[4 * i + 3] == MLN_GATE_F32 ? "f32" : ((int)tr[4 * i + 3] == MLN_GATE_F32C ? "f32c" : ((int)tr[4 * i + 3] == MLN_GATE_SUB ? "sub" : "f64")),
                 (int)tr[4 * i + 2], tr[4 * i + 1], tr[4 * i]);
   }
   // z = C^-T u and w = P u at the accepted point (one stacked product), remembered for transform / predictor weights
@@ -1609,8 +1946,9 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   }
   if (st.f_valid && objective_can_keep_f(f->n, f->n_wg) && !std::getenv("MELLON_AMD_NO_FKEEP")) f->f_final = st.f_slot;   // f = L z + mu at this z is already there (mln_transform)
   if (trace_lvl)
-    fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the fp32 copy), %d iterations, %d enqueued, status %d\n",
-            st.n_eval, st.n_eval32, st.it, n_enq, st.status);
+    fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the 32-bit copy, %d on the row subsample of stride %lld), %d iterations, "
+            "%d rebuild(s), %d enqueued, status %d\n", st.n_eval, st.n_eval32, st.n_eval_sub, (long long)sub_stride, st.it,
+            f->n_rebuild, n_enq, st.status);
   if (loss_out) *loss_out = st.fx;
   if (n_eval_out) *n_eval_out = st.n_eval;
   if (n_iter_out) *n_iter_out = st.it;
@@ -1667,6 +2005,13 @@ extern "C" int mln_stage_times(mln_fit* f, double* out) {
   out[9] = (double)f->evals32;                          //                        launches
   out[10] = f->L32 ? (f->l32_fixed ? 2.0 : 1.0) : 0.0;  //                        format of the copy
   out[11] = f->emu_excluded;                            // MELLON_AMD_EMULATE_RANKS: seconds spent on other ranks' blocks
+  out[12] = f->times_sub;                               // subsample passes of the solver's first phase: kernel seconds
+  out[13] = (double)f->evals_sub;                       //                                                launches
+  out[14] = (double)(f->precond_stride > 0 ? f->precond_stride : 1);   // their row stride (= the Gram sample's)
+  out[15] = f->times_rebuild;                           // second preconditioner: wall seconds (selection, Gram, factorisation)
+  out[16] = (double)f->n_rebuild;
+  // passes over the n x m buffer in full-fp64-pass equivalents (bytes streamed / bytes of one fp64 pass)
+  out[17] = f->times[6] + 0.5 * (double)f->evals32 + (double)f->evals_sub / out[14];
   return MLN_OK;
 }
 

@@ -20,9 +20,17 @@ struct ObjArgs {
   const double* cap;      // if non-null (device): e^t is continued linearly beyond t = *cap (32-bit kernel; solver.hip "cap")
   const int* gate;        // if non-null: the launch is a no-op unless *gate == gate_want (device-resident solver:
   int gate_want;          //   MLN_GATE_F64 / MLN_GATE_F32 select the streamed copy, MLN_GATE_DONE stops everything)
+  int64_t row_stride;     // > 1: the pass covers the rows row_first + i * row_stride, i < n (n = their number), of the
+  int64_t row_first;      //   buffer and of V / Vdr / weights -- the subsample objective of the solver's first phase
+  double out_scale;       // != 0: factor applied to the reduced loss / gradient sums (row_stride for that objective)
+  int64_t seg_cols;       // > 0: L points at a segment of seg_cols columns of a wider matrix (row pitch ldl): m > 8192
+  int64_t seg_left;       //      ... and this many (padded) columns remain in the row from that pointer
+  int f_accum;            // f_out mode: add this segment's dot products to what f_out already holds
 };
-// (the objective kernels compare gate & 3 with gate_want: MLN_GATE_F32C streams the same copy as MLN_GATE_F32)
-enum { MLN_GATE_F64 = 0, MLN_GATE_F32 = 1, MLN_GATE_DONE = 2, MLN_GATE_F32C = 5 };
+// (the objective kernels compare gate & 3 with gate_want: MLN_GATE_F32C streams the same copy as MLN_GATE_F32;
+//  MLN_GATE_SUB selects the launch over the row subsample; MLN_GATE_PAUSE, like DONE, stops every launch of the chain
+//  until the host has rebuilt the preconditioner and resumed the solver)
+enum { MLN_GATE_F64 = 0, MLN_GATE_F32 = 1, MLN_GATE_DONE = 2, MLN_GATE_SUB = 3, MLN_GATE_F32C = 5, MLN_GATE_PAUSE = 6 };
 int objective_max_m();
 bool objective_can_keep_f(int64_t n, int n_wg);
 int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count);

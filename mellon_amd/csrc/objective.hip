@@ -36,9 +36,14 @@ __device__ __forceinline__ void lds_store_f64(double* base, int idx, double v) {
   asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(v));   // no memory clobber: global loads may move across it
 }
 
+// Row subsample (the solver's first phase: the MAP problem of every row_stride-th cell, solver.hip): logical row i of
+// the pass is row  r0 + i * rs  of the buffer (and of V, Vdr, weights); rs = 1, r0 = 0 is the whole shard.
+struct RowMap { int64_t r0, rs; __device__ __forceinline__ int64_t operator()(int64_t i) const { return r0 + i * rs; } };
+__device__ __forceinline__ RowMap row_map(const ObjArgs& a) { return RowMap{a.row_first, a.row_stride > 0 ? a.row_stride : 1}; }
+
 template <int CPT, int R>
 __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2, int64_t row, int64_t row_end,
-                                          unsigned tid, d2 (&v)[R][CPT]) {
+                                          unsigned tid, d2 (&v)[R][CPT], const RowMap rm, unsigned lim) {
   // Loads are unconditional (no exec-masked branches, so the compiler keeps exact vmcnt counts and the
   // next register set really is in flight while the current one is consumed): rows past the end re-read
   // the first row of the step (their coefficient is 0), lanes past the row end re-read its last pair
@@ -47,11 +52,11 @@ __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2
   for (int r = 0; r < R; ++r) {
     const bool rok = (row + r) < row_end;
     // wave-uniform row base (scalar registers) + 32-bit per-lane offset -> saddr addressing
-    const d2* rowp = L2 + (rok ? (row + r) : row) * ld2;
+    const d2* rowp = L2 + rm(rok ? (row + r) : row) * ld2;
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       unsigned off = (unsigned)c * WG + tid;
-      off = (off < (unsigned)ld2) ? off : (unsigned)ld2 - 1u;
+      off = (off < lim) ? off : lim - 1u;        // lim: pairs left in the row from the pointer (ld2, or less for a column segment)
       v[r][c] = __builtin_nontemporal_load(rowp + off);
     }
   }
@@ -67,9 +72,10 @@ __device__ __forceinline__ void load_rows(const d2* __restrict__ L2, int64_t ld2
 
 template <int R>
 __device__ __forceinline__ void load_lik(const ObjArgs& a, int64_t row, double (&pv)[2][R]) {
+  const RowMap rm = row_map(a);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int64_t i = (row + r < a.n) ? (row + r) : (a.n - 1);
+    const int64_t i = rm((row + r < a.n) ? (row + r) : (a.n - 1));
     pv[0][r] = a.V[i];
     pv[1][r] = a.Vdr[i];
   }
@@ -81,9 +87,10 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
                                              d2 (&h)[CPT], double& loss, double (*red)[8][R], double* fstage,
                                              int64_t fbase, const double (&pv)[2][R]) {
   double coef[R], aexp[R];
+  const RowMap rm = row_map(a);
   if (MODE == MODE_GEMVT) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) coef[r] = (row + r < row_end) ? a.weights[row + r] : 0.0;
+    for (int r = 0; r < R; ++r) coef[r] = (row + r < row_end) ? a.weights[rm(row + r)] : 0.0;
   } else {
     double dot[R];
 #pragma unroll
@@ -112,18 +119,19 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
       const bool rok = (row + r) < row_end;
       const double f = s + a.mu;
       if (MODE == MODE_FONLY) {
-        if (rok && tid == 0) a.f_out[row + r] = f;
+        // (f_accum: this launch covers one column segment of a wide matrix and adds to what the previous ones left)
+        if (rok && tid == 0) a.f_out[row + r] = a.f_accum ? (s + a.f_out[row + r]) : f;
         coef[r] = 0.0;
         aexp[r] = 0.0;
       } else {
         // KEEP: V / Vdr of the row were requested together with the row itself (load_lik) -- a load issued HERE would
         // sit behind the next set's row loads in the in-order return queue (s_waitcnt vmcnt(0))
-        const double Vi = KEEP ? pv[0][r] : (rok ? a.V[row + r] : 0.0);
+        const double Vi = KEEP ? pv[0][r] : (rok ? a.V[rm(row + r)] : 0.0);
         const double e = rok ? exp(f + Vi) : 0.0;
         aexp[r] = e;
         coef[r] = rok ? (e - 1.0) : 0.0;
         if (KEEP) { if (tid == 0 && rok) loss -= (f + pv[1][r]) - e; }
-        else if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;   // inference.py:89-91
+        else if (tid == 0 && rok) loss -= (f + a.Vdr[rm(row + r)]) - e;   // inference.py:89-91
         // f of the row goes to LDS.  Unconditional store by every lane (thread 0 to the row's slot, the others to a
         // per-lane dummy slot): a store under `if (tid == 0)` is a real branch in the loop body, and a global store
         // there serialises the load pipeline -- both cost 10-20 % of the pass.
@@ -183,13 +191,15 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   // vmcnt(loads of one set) instead of vmcnt(0) and one set is always in flight behind the one consumed.
   const int64_t s_last = s_end - 1;
   double pa[2][R], pb[2][R];
-  if (s_beg < s_end) { load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
+  const RowMap rm = row_map(a);
+  const unsigned lim = a.seg_cols > 0 ? (unsigned)(a.seg_left / 2) : (unsigned)ld2;
+  if (s_beg < s_end) { load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va, rm, lim); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
-    load_rows<CPT, R>(L2, ld2, s1 * R, a.n, tid, vb);
+    load_rows<CPT, R>(L2, ld2, s1 * R, a.n, tid, vb, rm, lim);
     if (KEEP) load_lik<R>(a, s1 * R, pb);
     process_rows<CPT, R, MODE, KEEP>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red, fstage, fbase, pa);
-    load_rows<CPT, R>(L2, ld2, s2 * R, a.n, tid, va);
+    load_rows<CPT, R>(L2, ld2, s2 * R, a.n, tid, va, rm, lim);
     if (KEEP) load_lik<R>(a, s2 * R, pa);
     if (s + 1 < s_end) process_rows<CPT, R, MODE, KEEP>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red, fstage, fbase, pb);
   }
@@ -201,10 +211,11 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   }
   if (MODE != MODE_FONLY) {
     double* pg = a.part_grad + (int64_t)blockIdx.x * a.m_pad;
+    const int64_t store_lim = a.seg_cols > 0 ? ((a.seg_cols + 1) & ~(int64_t)1) : a.m_pad;   // a segment only writes its own columns
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int64_t col = 2 * ((int64_t)c * WG + tid);
-      if (col < a.m_pad) *reinterpret_cast<d2*>(pg + col) = g[c];
+      if (col < store_lim) *reinterpret_cast<d2*>(pg + col) = g[c];
     }
     if (MODE == MODE_OBJ_HESS) {
       double* ph = a.part_hess + (int64_t)blockIdx.x * a.m_pad;
@@ -226,11 +237,11 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <int CQ, int R, int NW>
 __device__ __forceinline__ void load_rows32(const f4* __restrict__ L4, int64_t ld4, int64_t row, int64_t row_end,
-                                            unsigned tid, f4 (&v)[R][CQ]) {
+                                            unsigned tid, f4 (&v)[R][CQ], const RowMap rm) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const bool rok = (row + r) < row_end;
-    const f4* rowp = L4 + (rok ? (row + r) : row) * ld4;
+    const f4* rowp = L4 + rm(rok ? (row + r) : row) * ld4;
 #pragma unroll
     for (int c = 0; c < CQ; ++c) {   // unconditional, clamped: see load_rows
       unsigned off = (unsigned)c * (64 * NW) + tid;
@@ -255,9 +266,10 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
                                                double& loss, double (*red)[NW][R], double* fstage, int64_t fbase,
                                                const double (&pv)[2][R], double capv, double ecap) {
   double coef[R], dot[R];
+  const RowMap rm = row_map(a);
   if (GEMVT) {   // grad_j = sum_i weights_i L_ij  (Ridge right-hand side): no row dots, no barrier
 #pragma unroll
-    for (int r = 0; r < R; ++r) coef[r] = (row + r < row_end) ? a.weights[row + r] : 0.0;
+    for (int r = 0; r < R; ++r) coef[r] = (row + r < row_end) ? a.weights[rm(row + r)] : 0.0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -297,14 +309,14 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     for (int w = 0; w < NW; ++w) s += red[par][w][r];
     const bool rok = (row + r) < row_end;
     const double f = s + a.mu;
-    const double Vi = KEEP ? pv[0][r] : (rok ? a.V[row + r] : 0.0);
+    const double Vi = KEEP ? pv[0][r] : (rok ? a.V[rm(row + r)] : 0.0);
     const double tt = f + Vi;
     const bool over = tt > capv;                                    // capv = +inf unless the solver's cap is on
     const double ex = exp(over ? capv : tt);
     const double e = rok ? (over ? ecap * (1.0 + (tt - capv)) : ex) : 0.0;
     coef[r] = rok ? (ex - 1.0) : 0.0;                               // d/dt: e^t below the cap, e^cap above it
     if (KEEP) { if (tid == 0 && rok) loss -= (f + pv[1][r]) - e; }
-    else if (tid == 0 && rok) loss -= (f + a.Vdr[row + r]) - e;
+    else if (tid == 0 && rok) loss -= (f + a.Vdr[rm(row + r)]) - e;
     if (KEEP) lds_store_f64(fstage, (tid == 0 && rok) ? (int)(row + r - fbase) : (MLN_FSTAGE + tid), f);   // see k_objective
   }
 #pragma unroll
@@ -351,13 +363,14 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   f4 va[R][CQ], vb[R][CQ];
   const int64_t s_last = s_end - 1;
   double pa[2][R], pb[2][R];
-  if (s_beg < s_end) { load_rows32<CQ, R, NW>(L4, ld4, s_beg * R, a.n, tid, va); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
+  const RowMap rm = row_map(a);
+  if (s_beg < s_end) { load_rows32<CQ, R, NW>(L4, ld4, s_beg * R, a.n, tid, va, rm); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {   // unconditional loads: see k_objective
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
-    load_rows32<CQ, R, NW>(L4, ld4, s1 * R, a.n, tid, vb);
+    load_rows32<CQ, R, NW>(L4, ld4, s1 * R, a.n, tid, vb, rm);
     if (KEEP) load_lik<R>(a, s1 * R, pb);
     process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa, capv, ecap);
-    load_rows32<CQ, R, NW>(L4, ld4, s2 * R, a.n, tid, va);
+    load_rows32<CQ, R, NW>(L4, ld4, s2 * R, a.n, tid, va, rm);
     if (KEEP) load_lik<R>(a, s2 * R, pa);
     if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb, capv, ecap);
   }
@@ -424,7 +437,7 @@ __global__ void k_to_f32(const double* __restrict__ src, float* __restrict__ dst
 // dependent loads per thread, took 30 us between two objective passes; this shape takes a few.)
 __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restrict__ out_loss,
                                                     double* __restrict__ out_grad, int with_hess) {
-  if (a.gate && *a.gate == MLN_GATE_DONE) return;
+  if (a.gate && (*a.gate & 3) == MLN_GATE_DONE) return;   // DONE, or PAUSE (the host rebuilds the preconditioner)
   __shared__ double red[2][16][16];
   const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int64_t j = (int64_t)blockIdx.x * 16 + c;
@@ -444,8 +457,9 @@ __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restric
     double gs = 0.0, hs = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { gs += red[0][q][c]; hs += red[1][q][c]; }
-    out_grad[j] = gs;
-    if (with_hess) out_grad[a.m + j] = hs;
+    const double sc = (a.out_scale != 0.0 && (!a.gate || *a.gate == MLN_GATE_SUB)) ? a.out_scale : 1.0;   // subsample passes: the sums stand for row_stride x as many cells
+    out_grad[j] = gs * sc;
+    if (with_hess) out_grad[a.m + j] = hs * sc;
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {   // the loss partials: one wave, fixed shuffle tree
     double l = 0.0;
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restric
       for (int w = threadIdx.x; w < a.n_wg; w += 64) l += a.part_loss[w];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-    if (threadIdx.x == 0) out_loss[0] = l;
+    if (threadIdx.x == 0) out_loss[0] = l * ((a.out_scale != 0.0 && (!a.gate || *a.gate == MLN_GATE_SUB)) ? a.out_scale : 1.0);
   }
 }
 
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const double* __restrict__ M,
 // lower: columns [0, i] -- in each of the (1 or 2) column segments, the second one starting at column `mseg` of M
 // and element `xseg` of x.  Rows past the first block go to y2 when it is given.
 __global__ __launch_bounds__(256) void k_gemv_rows_tri(GemvTri g) {
-  if (g.gate && *g.gate == MLN_GATE_DONE) return;
+  if (g.gate && (*g.gate & 3) == MLN_GATE_DONE) return;
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= g.rows) return;
@@ -558,13 +572,90 @@ int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count) {
   return MLN_OK;
 }
 
-int objective_max_m() { return 1024 * 8; }
+int objective_max_m() { return 65535; }          // beyond 8192 columns: the segmented two-pass route below
+static constexpr int64_t MLN_SEG = 8192;        // columns one workgroup can own in registers (CPT <= 8)
+
+namespace {
+
+// per row: a = exp(f + V), coefficient a - 1 of the gradient, and the row's likelihood term; per-block loss partials
+__global__ __launch_bounds__(256) void k_lik_rows(const double* __restrict__ f, const double* __restrict__ V,
+                                                  const double* __restrict__ Vdr, int64_t n, double* __restrict__ coef,
+                                                  double* __restrict__ part_loss, int n_part) {
+  __shared__ double red[4];
+  const int64_t per = (n + n_part - 1) / n_part;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < n) ? r0 + per : n;
+  double l = 0.0;
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) {
+    const double e = exp(f[i] + V[i]);
+    coef[i] = e - 1.0;
+    l -= (f[i] + Vdr[i]) - e;                   // inference.py:89-91
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) part_loss[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+}  // namespace
+
+int launch_objective(mln_ctx* ctx, const ObjArgs& a);
+
+// m > 8192 columns: no workgroup can hold a whole row's coefficients in registers, so the pass is split the way the
+// reference evaluates it -- f = L z over column segments, the row-wise likelihood, then L^T (a - 1) over the same
+// segments: two reads of the buffer instead of one.  Host-driven evaluations only (no device-resident solver, no
+// 32-bit copy, no Hessian diagonal).
+static int launch_objective_wide(mln_ctx* ctx, const ObjArgs& a) {
+  if (a.gate || a.part_hess || a.L32 || (a.row_stride > 1)) {
+    mln_set_error(ctx, "objective: this mode is not available beyond 8192 landmarks");
+    return MLN_ERR_UNSUPPORTED;
+  }
+  const bool gemvt = a.weights != nullptr, fonly = !gemvt && a.f_out != nullptr;
+  double *ftmp = nullptr, *coef = nullptr;
+  const int64_t n1 = a.n > 0 ? a.n : 1;
+  if (!gemvt && !fonly) {
+    MLN_HIP(ctx, mln_dmalloc((void**)&ftmp, sizeof(double) * (size_t)n1 * 2));
+    coef = ftmp + n1;
+  }
+  int rc = MLN_OK;
+  if (!gemvt) {                                    // f = L z + mu, segment by segment
+    for (int64_t c0 = 0; c0 < a.m && rc == MLN_OK; c0 += MLN_SEG) {
+      ObjArgs s = a;
+      s.L = a.L + c0; s.m = std::min<int64_t>(MLN_SEG, a.m - c0); s.z = a.z + c0;
+      s.ldl = a.ldl; s.m_pad = a.m_pad;
+      s.weights = nullptr; s.part_hess = nullptr; s.part_loss = nullptr;
+      s.f_out = fonly ? a.f_out : ftmp;
+      s.f_accum = c0 > 0 ? 1 : 0;
+      s.f_slot = nullptr;
+      s.seg_cols = s.m; s.seg_left = a.ldl - c0;
+      rc = launch_objective(ctx, s);
+    }
+  }
+  if (rc == MLN_OK && !gemvt && !fonly) {
+    hipLaunchKernelGGL(k_lik_rows, dim3((unsigned)a.n_wg), dim3(256), 0, ctx->stream, ftmp, a.V, a.Vdr, a.n, coef,
+                       a.part_loss, a.n_wg);
+    if (hipGetLastError() != hipSuccess) rc = MLN_ERR_HIP;
+  }
+  if (rc == MLN_OK && !fonly) {                     // grad = L^T coef, segment by segment
+    for (int64_t c0 = 0; c0 < a.m && rc == MLN_OK; c0 += MLN_SEG) {
+      ObjArgs s = a;
+      s.L = a.L + c0; s.m = std::min<int64_t>(MLN_SEG, a.m - c0);
+      s.weights = gemvt ? a.weights : coef;
+      s.part_grad = a.part_grad + c0; s.part_hess = nullptr; s.part_loss = nullptr; s.f_out = nullptr; s.f_slot = nullptr;
+      s.seg_cols = s.m; s.seg_left = a.ldl - c0;
+      rc = launch_objective(ctx, s);
+    }
+  }
+  if (ftmp) { (void)hipStreamSynchronize(ctx->stream); (void)mln_dfree(ftmp); }
+  return rc;
+}
 
 // rows per workgroup the f-staging of the objective kernels can hold: callers leave f_slot null beyond it
 bool objective_can_keep_f(int64_t n, int n_wg) { return n_wg > 0 && (n + n_wg - 1) / n_wg + 16 <= MLN_FSTAGE; }
 
 int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   if (a.ldl % 2 != 0) { mln_set_error(ctx, "objective: leading dimension of L must be even"); return MLN_ERR_ARG; }
+  if (a.seg_cols == 0 && a.m > MLN_SEG) return launch_objective_wide(ctx, a);
   int mode = MODE_OBJ;
   if (a.weights) mode = MODE_GEMVT;
   else if (a.f_out) mode = MODE_FONLY;
@@ -585,7 +676,8 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
       default: return launch_f32<4, 2>(ctx, a);
     }
   }
-  const int64_t pairs = a.ldl / 2;
+  // (a column segment of a wide matrix: the workgroup owns seg_cols columns, the row pitch stays ldl)
+  const int64_t pairs = a.seg_cols > 0 ? (a.seg_cols + 1) / 2 : a.ldl / 2;
   const int cpt = (int)((pairs + WG - 1) / WG);
   // rows per step chosen so that one register set holds <= 12 double2 per thread
   switch (cpt) {

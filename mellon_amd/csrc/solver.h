@@ -4,7 +4,7 @@
 #pragma once
 #include "mln_core.h"
 
-enum { MLN_SOLVE_FIRST = 0, MLN_SOLVE_LS = 1, MLN_SOLVE_REEVAL = 2 };
+enum { MLN_SOLVE_FIRST = 0, MLN_SOLVE_LS = 1, MLN_SOLVE_REEVAL = 2, MLN_SOLVE_RESUME = 3 };
 
 struct SolverState {
   int gate;      // which copy of the buffer the next evaluation streams: MLN_GATE_F64, MLN_GATE_F32 (the plain 32-bit
@@ -28,6 +28,20 @@ struct SolverState {
   double boost_fall;        // ... and the relative decrease of the loss per pass above which that rule applies
   double t0, boost;         // first trial step of the next line search; slope ratio above which it doubles (0: always 1)
   double corr_k;            // corrected surrogate: F^(u) = F32(u) + c . u + corr_k,  grad F^ = grad F32 + c
+  // Row-subsample start (gate == MLN_GATE_SUB): the solve begins on the MAP problem of every row_stride-th cell (the
+  // cells of the preconditioner's Gram) -- passes at 1 / row_stride of the bytes -- and moves to the full objective
+  // (gate_full) at the same point once its progress per iteration falls below sub_tol.
+  double sub_tol;
+  int gate_full;            // MLN_GATE_F64, or MLN_GATE_F32 when a 32-bit copy exists
+  int n_eval_sub;           // evaluations on the subsample so far
+  // Preconditioner rebuild: with rebuild_armed set by the host, the solver PAUSES (gate = MLN_GATE_PAUSE) after an
+  // accepted fp64 iteration whose progress has fallen below rebuild_tol; the host then re-factors the preconditioner
+  // from the a-weighted importance sample at that point (api.hip fit_rebuild_precond), re-expresses u and g in the new
+  // variable and resumes (mode = MLN_SOLVE_RESUME, no pairs).
+  int rebuild_armed;
+  int it_full;              // accepted iterations on the full objective
+  int resume_keep_pairs;    // MLN_SOLVE_RESUME: the curvature pairs are still valid (no new variable)
+  double rebuild_tol;
 };
 
 struct SolverBuffers {
@@ -46,3 +60,6 @@ struct SolverBuffers {
 int launch_solver_init(mln_ctx* ctx, const SolverBuffers& b, const SolverState& init, const double* u0);
 // consumes the evaluation in flight (gn, z, lik) and prepares the next trial point in un -- or sets gate = DONE
 int launch_solver_step(mln_ctx* ctx, const SolverBuffers& b, int m);
+// after a pause: the host has written the accepted point and its gradient in the (new) preconditioned variable into
+// b.u / b.g; the next step starts a line search from there on `gate` (pairs_dropped: the history starts over)
+int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped);

@@ -65,7 +65,7 @@ __device__ __forceinline__ double block_max(double v, double* red) {
 template <int EPT>
 __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   SolverState* st = b.st;
-  if (st->gate == MLN_GATE_DONE) return;
+  if ((st->gate & 3) == MLN_GATE_DONE) return;    // DONE or PAUSE
   __shared__ double red[ST / 64];
   __shared__ double red3[3][ST / 64];
   __shared__ double alpha_s[64];
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   // fp64 evaluation, converges on F^ by the FINAL tolerances, and then asks the fp64 objective at that point whether
   // F^ told the truth (|F - F^| within the stopping tolerance, or gradient below gtol); if not, that evaluation is
   // the next anchor.  Every fp64 pass saved reads 40 GB less.
-  const bool phaseA = st->gate == MLN_GATE_F32, phaseC = st->gate == MLN_GATE_F32C;
+  const bool resume = st->mode == MLN_SOLVE_RESUME;   // the host re-expressed u, g in a new preconditioned variable: no evaluation to consume
+  const bool phaseA = st->gate == MLN_GATE_F32, phaseC = st->gate == MLN_GATE_F32C, phaseS = st->gate == MLN_GATE_SUB;
   const bool phase32 = phaseA || phaseC;
+  const bool approx = phase32 || phaseS;               // the evaluation in flight was of a surrogate (32-bit copy / row subsample)
   if (phaseC) {
     double cu = 0.0;
 #pragma unroll
@@ -111,18 +113,22 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     }
     fn += block_sum(cu, red) + st->corr_k;
   }
-  int mode = st->mode, it = st->it, n_eval = st->n_eval + 1, n_eval32 = st->n_eval32 + (phase32 ? 1 : 0);
+  int mode = st->mode, it = st->it, n_eval = st->n_eval + (resume ? 0 : 1), n_eval32 = st->n_eval32 + ((phase32 && !resume) ? 1 : 0);
+  int n_eval_sub = st->n_eval_sub + ((phaseS && !resume) ? 1 : 0), it_full = st->it_full;
   int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
   double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k, t0 = st->t0, cap = st->cap;
   bool recap = false;
   if (mode != MLN_SOLVE_LS) t0 = 1.0;
   int f_slot = st->f_slot, f_valid = st->f_valid, corr = st->corr, n_anchor = st->n_anchor;
-  if (b.trace && tid == 0) {
+  if (b.trace && tid == 0 && !resume) {
     double* tr = b.trace + 4 * ((n_eval - 1) & 511);
     tr[0] = fn; tr[1] = (mode == MLN_SOLVE_LS) ? t : 0.0; tr[2] = (double)mode; tr[3] = (double)gate;
   }
-  bool to_head = false, reeval = false, done = false, verify = false;
-  if (mode != MLN_SOLVE_LS) {            // first point, or the same point again on the fp64 buffer
+  bool to_head = false, reeval = false, done = false, verify = false, pause = false;
+  if (resume) {
+    to_head = true;                      // u, g, fx are the accepted point (in the NEW variable when the history was dropped)
+    if (!st->resume_keep_pairs) { k = 0; head = 0; }
+  } else if (mode != MLN_SOLVE_LS) {            // first point, or the same point again on the fp64 buffer
     if (mode == MLN_SOLVE_REEVAL && !phase32 && st->use_corr) {
       // fp64 evaluation at the accepted point u, where fx / g hold the surrogate's loss / gradient (F32 after phase A,
       // F^ after phase C): (re)anchor the correction here -- and, after phase C, let the fp64 gradient decide below
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       }
     }
     fx = fn;
-    f_slot ^= 1; f_valid = phase32 ? 0 : 1;   // the rows' f of this pass belong to the accepted point
+    f_slot ^= 1; f_valid = approx ? 0 : 1;   // the rows' f of this pass belong to the accepted point
 #pragma unroll
     for (int e = 0; e < EPT; ++e) g[e] = gn[e];
     to_head = true;
@@ -182,7 +188,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) { u[e] = un[e]; g[e] = gn[e]; }
       fx = fn;
-      f_slot ^= 1; f_valid = phase32 ? 0 : 1;
+      f_slot ^= 1; f_valid = approx ? 0 : 1;
+      if (!approx) ++it_full;
       if (sy > 1e-10 * sqrt(ss * yy)) {   // keep the pair (SPD update)
         int slot;
         if (k < st->maxcor) { slot = (head + k) % st->maxcor; ++k; }
@@ -204,7 +211,13 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       // for good and the same point is evaluated once more on the true objective (the curvature pairs stay: they are
       // the true ones for every cell below the cap).  tools/cap_sweep.py, six data seeds at C3: 41.8 -> 39.2 passes.
       if (cap < 1e300 && it >= 3 && (f_old - fx) <= st->cap_fall * fabs(f_old)) { cap = __builtin_inf(); recap = true; }
-      if (phaseA) {
+      if (phaseS) {
+        // the subsample objective has done its job once its own progress per iteration is small: same point, full objective
+        if ((f_old - fx) <= st->sub_tol * fscale) reeval = true; else to_head = true;
+      } else if (st->rebuild_armed && !phase32 && it_full >= 2 && (f_old - fx) <= st->rebuild_tol * fscale &&
+                 (f_old - fx) > st->ftol * fscale) {
+        pause = true;                    // the host rebuilds the preconditioner from the weights a = e^{f+V} at THIS point
+      } else if (phaseA) {
         // the plain 32-bit objective is a smooth surrogate whose optimum sits ~1e-9 (fixed point; fp32: ~5e-5) in
         // relative loss from the true one: once its progress per iteration falls below ftol32, evaluate in fp64 at
         // the same point and continue (corrected surrogate, or the fp64 buffer) with the pairs collected so far
@@ -221,9 +234,9 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       // This is the relative-decrease test of the accepted branch applied to the rejected trial: converged.
       // (phase C with f_valid: the accepted point IS the last fp64 evaluation -- nothing has been accepted since -- so
       //  its loss, gradient and rows' f are already fp64: no second verification of the same point)
-      if (phase32 && !(phaseC && f_valid)) reeval = true; else { status = 0; done = true; }
+      if (approx && !(phaseC && f_valid)) reeval = true; else { status = 0; done = true; }
     } else if (ls >= st->maxls) {
-      if (phase32 && !(phaseC && f_valid)) reeval = true;   // the surrogate is exhausted: continue in fp64 from the accepted point
+      if (approx && !(phaseC && f_valid)) reeval = true;   // the surrogate is exhausted: continue in fp64 from the accepted point
       else { status = phaseC ? 0 : 2; done = true; }
     } else {
       if (isfinite(fn)) {
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     for (int e = 0; e < EPT; ++e) gm = fmax(gm, fabs(g[e]));
     gm = block_max(gm, red);
     if (!(gm > st->gtol)) {
-      if (phase32) reeval = true; else { status = 0; done = true; }
+      if (approx) reeval = true; else { status = 0; done = true; }
     } else if (it >= st->maxiter) {
       status = 1; done = true;
     } else {
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       // posteriori -- done, on fp64 evidence (the loss, the gradient and the rows' f of this very pass).
       if (verify && -0.5 * gd <= st->ftol * fmax(fabs(fx), 1.0)) { status = 0; done = true; }
       t = t0;
-      if (k == 0) {
+      if (k == 0 && !resume) {
         double g1 = 0.0;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) g1 += fabs(g[e]);
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   }
   if (reeval) {           // same point, fp64 buffer: refreshes fx and g, keeps the curvature pairs
     cap = __builtin_inf();   // (a surrogate left while still capped: everything from here on is the true objective)
-    gate = MLN_GATE_F64;
+    gate = phaseS ? st->gate_full : MLN_GATE_F64;     // (after the subsample: the full objective, on its 32-bit copy if there is one)
     mode = MLN_SOLVE_REEVAL;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) un[e] = u[e];
@@ -333,6 +346,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) un[e] = u[e];
   }
+  if (pause) gate = MLN_GATE_PAUSE;
   if (done) gate = MLN_GATE_DONE;
 #pragma unroll
   for (int e = 0; e < EPT; ++e)
@@ -342,6 +356,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     st->ls = ls; st->k = k; st->head = head; st->fx = fx; st->t = t; st->gd = gd;
     st->f_slot = f_slot; st->f_valid = f_valid;
     st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k; st->t0 = t0; st->cap = cap;
+    st->n_eval_sub = n_eval_sub; st->it_full = it_full;
+    if (pause) st->rebuild_armed = 0;    // once per solve
   }
 }
 
@@ -354,7 +370,23 @@ __global__ void k_solver_init(SolverBuffers b, SolverState init, const double* _
   if (i == 0) *b.st = init;
 }
 
+__global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    SolverState* st = b.st;
+    st->gate = gate;
+    st->mode = MLN_SOLVE_RESUME;
+    if (pairs_dropped) { st->k = 0; st->head = 0; }
+    st->resume_keep_pairs = pairs_dropped ? 0 : 1;
+  }
+}
+
 }  // namespace
+
+int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped) {
+  hipLaunchKernelGGL(k_solver_resume, dim3(1), dim3(64), 0, ctx->stream, b, gate, pairs_dropped);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
 
 int launch_solver_init(mln_ctx* ctx, const SolverBuffers& b, const SolverState& init, const double* u0) {
   hipLaunchKernelGGL(k_solver_init, dim3((unsigned)((init.m + 255) / 256)), dim3(256), 0, ctx->stream, b, init, u0);

@@ -39,13 +39,27 @@ __global__ __launch_bounds__(HT) void k_house(const double* __restrict__ A, int6
   __shared__ double red[HT / 64];
   const int64_t s = n - k - 1;
   const double* x = A + k * ld + k + 1;
+  // dlarfg's safeguard: the sum of squares is taken of x / max|x|, so that a Gram with entries near the ends of the
+  // double range neither overflows nor underflows into a NaN (or a zero) beta
+  double mx = 0.0;
+  for (int64_t i = threadIdx.x; i < s; i += HT) mx = fmax(mx, fabs(x[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = 0.0;
+#pragma unroll
+  for (int w = 0; w < HT / 64; ++w) mx = fmax(mx, red[w]);
+  const double inv = (mx > 0.0 && isfinite(mx)) ? 1.0 / mx : 0.0;
   double sig = 0.0;
-  for (int64_t i = 1 + threadIdx.x; i < s; i += HT) sig = fma(x[i], x[i], sig);
+  for (int64_t i = 1 + threadIdx.x; i < s; i += HT) { const double xi = x[i] * inv; sig = fma(xi, xi, sig); }
   sig = block_sum_d(sig, red);
   const double alpha = x[0];
   double beta = alpha, t = 0.0, scale = 0.0;
   if (sig > 0.0) {
-    beta = -copysign(sqrt(fma(alpha, alpha, sig)), alpha);
+    const double as = alpha * inv;
+    beta = -copysign(mx * sqrt(fma(as, as, sig)), alpha);
     t = (beta - alpha) / beta;
     scale = 1.0 / (alpha - beta);
   }
@@ -117,7 +131,7 @@ int dev_sym_rank_above(mln_ctx* ctx, double* A, int64_t m, int64_t ld, double to
     hipLaunchKernelGGL(k_rank2_rows, dim3((unsigned)s), dim3(256), 0, ctx->stream, A, ld, m, k, v, w);
   }
   hipError_t err = hipGetLastError();
-  std::vector<double> full((size_t)m * 2, 0.0);   // the last 2 x 2 block (or the 1 x 1 matrix) comes straight from A
+  // (the last 2 x 2 block -- or the 1 x 1 matrix -- comes straight from A)
   std::vector<double> d((size_t)m), e((size_t)(m > 1 ? m - 1 : 0));
   if (err == hipSuccess) err = hipMemcpyAsync(d.data(), dd, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream);
   if (err == hipSuccess && m > 1) err = hipMemcpyAsync(e.data(), de, sizeof(double) * (m - 1), hipMemcpyDeviceToHost, ctx->stream);
@@ -133,6 +147,11 @@ int dev_sym_rank_above(mln_ctx* ctx, double* A, int64_t m, int64_t ld, double to
   if (err != hipSuccess) return mln_hip_fail(ctx, err, "tridiagonalisation", __FILE__, __LINE__);
   if (m >= 2) { d[m - 2] = tail[0]; e[m - 2] = tail[1]; }
   d[m - 1] = tail[2];
+  for (int64_t i = 0; i < m; ++i)
+    if (!std::isfinite(d[i]) || (i + 1 < m && !std::isfinite(e[i]))) {
+      mln_set_error(ctx, "rank diagnostic: the tridiagonalised Gram is not finite (NaN / inf in L, or a Gram beyond the double range)");
+      return MLN_ERR_NOCONV;
+    }
   // Gershgorin bounds, then bisection on the Sturm count for lambda_max
   double lo = d[0], hi = d[0], nrm = 0.0;
   for (int64_t i = 0; i < m; ++i) {
@@ -140,7 +159,7 @@ int dev_sym_rank_above(mln_ctx* ctx, double* A, int64_t m, int64_t ld, double to
     lo = std::min(lo, d[i] - r); hi = std::max(hi, d[i] + r);
     nrm = std::max(nrm, std::fabs(d[i]) + r);
   }
-  const double tiny = std::max(nrm, 1e-300) * 1e-300 + 1e-300 * 0 + nrm * 2.3e-16 * 1e-3;
+  const double tiny = std::max(nrm, 1e-300) * 1e-300 + nrm * 2.3e-16 * 1e-3;
   double a = lo, b = hi;
   for (int it = 0; it < 200 && (b - a) > 4e-16 * std::max(std::fabs(a), std::fabs(b)) + 1e-300; ++it) {
     const double mid = 0.5 * (a + b);

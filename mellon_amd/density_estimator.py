@@ -185,7 +185,15 @@ class DensityEstimator(BaseEstimator):
         if initial_value is not None:
             self.initial_value = initial_value
         if optimizer is not None:
+            switched = str(optimizer).lower() != str(self.optimizer).lower()
             self.optimizer = optimizer
+            # An optimiser that does not run to convergence (adam: a fixed number of steps) ends where its start puts
+            # it: it gets the reference's exact Ridge start (all cells), also when prepare_inference() ran under another
+            # optimiser and built the start from the sampled Gram.
+            if switched and initial_value is None and str(optimizer).lower() not in ("l-bfgs-b", "lbfgsb") \
+                    and self.L is not None and self.nn_distances is not None:
+                self.initial_value = None
+                self._prepare_attribute("initial_value")
         self._run_inference()
         return self.pre_transformation
 

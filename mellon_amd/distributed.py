@@ -20,7 +20,6 @@ Two layers:
     LOCAL_RANK / MASTER_ADDR / MASTER_PORT are read.
 """
 import os
-import pickle
 import socket
 import struct
 import threading
@@ -55,6 +54,116 @@ class HostComm:
         pass
 
 
+# Wire format of the host communicator.  Only plain data ever travels (rank ids, counts, float64 vectors of the
+# heuristics, the 128-byte RCCL id, landmark matrices, short notes), so the codec knows exactly these types and
+# nothing else: a peer can make a rank allocate memory, never run code (no pickle on a socket any local process
+# can connect to).  One value = 1 tag byte + payload; containers nest.
+_T_NONE, _T_FALSE, _T_TRUE, _T_INT, _T_FLOAT, _T_STR, _T_BYTES, _T_ARRAY, _T_LIST, _T_TUPLE = range(10)
+_DTYPES = ("float64", "float32", "int64", "int32", "uint8", "bool")
+_MAX_MSG = 1 << 34        # 16 GiB: nothing legitimate is larger than a landmark matrix
+_MAX_DEPTH = 8
+
+
+def _encode(obj, out, depth=0):
+    if depth > _MAX_DEPTH:
+        raise TypeError("host communicator: value nests too deeply")
+    if obj is None:
+        out.append(bytes([_T_NONE]))
+    elif obj is True or obj is False or isinstance(obj, np.bool_):
+        out.append(bytes([_T_TRUE if obj else _T_FALSE]))
+    elif isinstance(obj, (int, np.integer)):
+        out.append(bytes([_T_INT]) + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(bytes([_T_FLOAT]) + struct.pack("<d", float(obj)))
+    elif isinstance(obj, str):
+        b = obj.encode("utf-8")
+        out.append(bytes([_T_STR]) + struct.pack("<Q", len(b)) + b)
+    elif isinstance(obj, (bytes, bytearray, memoryview)):
+        b = bytes(obj)
+        out.append(bytes([_T_BYTES]) + struct.pack("<Q", len(b)) + b)
+    elif isinstance(obj, np.ndarray):
+        name = obj.dtype.name
+        if name not in _DTYPES:
+            raise TypeError(f"host communicator: arrays of dtype {name} do not travel")
+        a = np.ascontiguousarray(obj)
+        head = bytes([_T_ARRAY, _DTYPES.index(name), a.ndim]) + struct.pack(f"<{a.ndim}q", *a.shape)
+        out.append(head)
+        out.append(a.tobytes())
+    elif isinstance(obj, (list, tuple)):
+        out.append(bytes([_T_LIST if isinstance(obj, list) else _T_TUPLE]) + struct.pack("<Q", len(obj)))
+        for item in obj:
+            _encode(item, out, depth + 1)
+    else:
+        raise TypeError(f"host communicator: values of type {type(obj).__name__} do not travel")
+
+
+def encode(obj):
+    out = []
+    _encode(obj, out)
+    return b"".join(out)
+
+
+def _decode(buf, pos, depth=0):
+    if depth > _MAX_DEPTH or pos >= len(buf):
+        raise ValueError("host communicator: malformed message")
+    tag = buf[pos]
+    pos += 1
+
+    def take(k):
+        nonlocal pos
+        if k < 0 or pos + k > len(buf):
+            raise ValueError("host communicator: truncated message")
+        piece = buf[pos:pos + k]
+        pos += k
+        return piece
+
+    if tag == _T_NONE:
+        return None, pos
+    if tag in (_T_FALSE, _T_TRUE):
+        return tag == _T_TRUE, pos
+    if tag == _T_INT:
+        return struct.unpack("<q", take(8))[0], pos
+    if tag == _T_FLOAT:
+        return struct.unpack("<d", take(8))[0], pos
+    if tag in (_T_STR, _T_BYTES):
+        (k,) = struct.unpack("<Q", take(8))
+        b = bytes(take(k))
+        return (b.decode("utf-8") if tag == _T_STR else b), pos
+    if tag == _T_ARRAY:
+        code, ndim = take(2)
+        if code >= len(_DTYPES) or ndim > 8:
+            raise ValueError("host communicator: malformed array header")
+        shape = struct.unpack(f"<{ndim}q", take(8 * ndim))
+        if any(k < 0 for k in shape):
+            raise ValueError("host communicator: negative array extent")
+        dt = np.dtype(_DTYPES[code])
+        count = 1
+        for k in shape:
+            count *= k
+        raw = take(count * dt.itemsize)
+        return np.frombuffer(raw, dtype=dt).reshape(shape).copy(), pos
+    if tag in (_T_LIST, _T_TUPLE):
+        (k,) = struct.unpack("<Q", take(8))
+        if k > len(buf):
+            raise ValueError("host communicator: malformed container")
+        items = []
+        for _ in range(k):
+            item, pos = _decode(buf, pos, depth + 1)
+            items.append(item)
+        return (items if tag == _T_LIST else tuple(items)), pos
+    raise ValueError(f"host communicator: unknown type tag {tag}")
+
+
+def decode(buf):
+    obj, pos = _decode(memoryview(buf), 0)
+    if pos != len(buf):
+        raise ValueError("host communicator: trailing bytes in message")
+    return obj
+
+
+_MAGIC = b"MLNHC1"
+
+
 def _send_msg(sock, payload):
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
@@ -69,69 +178,128 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv_msg(sock):
+def _recv_msg(sock, limit=_MAX_MSG):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
+    if n > limit:
+        raise ValueError(f"host communicator: message of {n} bytes refused")
     return _recv_exact(sock, n)
+
+
+def _describe_env():
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MELLON_AMD_PORT")
+    return ", ".join(f"{k}={os.environ.get(k, '<unset>')}" for k in keys)
 
 
 class SocketHostComm(HostComm):
     """Star all-gather over stream sockets: rank 0 listens, collects one message per rank and sends
     the list back.  `address` is ("unix", name) -- an abstract-namespace Unix socket, the default on
-    one node: no port to collide with, gone when the processes exit -- or ("tcp", host, port)."""
+    one node: no port to collide with, gone when the processes exit -- or ("tcp", host, port).
+    A list of addresses is tried in order (rank 0 listens on all of them): the Unix socket first, TCP on
+    MASTER_ADDR as the fallback when the ranks do not share a network namespace.
 
-    def __init__(self, address, rank, world_size, timeout=300.0):
+    Messages use the typed binary codec above (no pickle).  The handshake is `magic | job token | rank`; a
+    connection with the wrong token, a rank outside [1, world_size) or a rank already seated is dropped."""
+
+    def __init__(self, address, rank, world_size, timeout=300.0, token=b""):
         self.rank, self.world_size = int(rank), int(world_size)
         self._peers = []
         self._sock = None
-        kind = address[0]
-        fam = socket.AF_UNIX if kind == "unix" else socket.AF_INET
-        target = ("\0" + address[1]) if kind == "unix" else (address[1], int(address[2]))
+        addresses = [address] if isinstance(address[0], str) else list(address)
+        token = bytes(token)[:64]
+        hello = _MAGIC + struct.pack("<B", len(token)) + token
+
+        def open_socket(addr):
+            kind = addr[0]
+            fam = socket.AF_UNIX if kind == "unix" else socket.AF_INET
+            target = ("\0" + addr[1]) if kind == "unix" else (addr[1], int(addr[2]))
+            return kind, socket.socket(fam, socket.SOCK_STREAM), target
+
         if self.rank == 0:
-            srv = socket.socket(fam, socket.SOCK_STREAM)
-            if kind == "tcp":
-                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind(target)
-            srv.listen(self.world_size)
-            srv.settimeout(timeout)
+            servers = []
+            for addr in addresses:
+                kind, srv, target = open_socket(addr)
+                try:
+                    if kind == "tcp":
+                        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind(target)
+                    srv.listen(self.world_size)
+                    srv.setblocking(False)
+                    servers.append((kind, srv))
+                except OSError:
+                    srv.close()
+            if not servers:
+                raise OSError(f"rank 0: cannot listen on any of {addresses} ({_describe_env()})")
+            import select
             peers = {}
+            deadline = time.time() + timeout
             while len(peers) < self.world_size - 1:
-                conn, _ = srv.accept()
-                conn.settimeout(timeout)
-                if kind == "tcp":
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                r = pickle.loads(_recv_msg(conn))
-                peers[int(r)] = conn
-            srv.close()
+                left = deadline - time.time()
+                if left <= 0:
+                    missing = sorted(set(range(1, self.world_size)) - set(peers))
+                    for _, srv in servers:
+                        srv.close()
+                    raise TimeoutError(f"rank 0: ranks {missing} never reached the host communicator at {addresses} "
+                                       f"within {timeout:.0f} s ({_describe_env()})")
+                ready, _, _ = select.select([srv for _, srv in servers], [], [], min(left, 1.0))
+                for srv in ready:
+                    try:
+                        conn, _ = srv.accept()
+                    except OSError:
+                        continue
+                    conn.settimeout(10.0)
+                    try:
+                        head = _recv_exact(conn, len(hello) + 8)
+                        (r,) = struct.unpack("<q", head[len(hello):])
+                        if head[:len(hello)] != hello or not (1 <= r < self.world_size) or r in peers:
+                            raise ValueError("handshake refused")
+                    except (ValueError, OSError, ConnectionError):
+                        conn.close()         # not one of ours (or a duplicate): the seat stays free
+                        continue
+                    conn.settimeout(timeout)
+                    if conn.family == socket.AF_INET:
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.sendall(b"ok")
+                    peers[int(r)] = conn
+            for _, srv in servers:
+                srv.close()
             self._peers = [peers[r] for r in range(1, self.world_size)]
         else:
             deadline = time.time() + timeout
-            while True:
-                s = socket.socket(fam, socket.SOCK_STREAM)
-                try:
-                    s.connect(target)
-                    break
-                except (ConnectionRefusedError, FileNotFoundError, OSError):
-                    s.close()
+            s = None
+            while s is None:
+                for addr in addresses:
+                    kind, cand, target = open_socket(addr)
+                    try:
+                        cand.settimeout(5.0)
+                        cand.connect(target)
+                        if kind == "tcp":
+                            cand.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        cand.sendall(hello + struct.pack("<q", self.rank))
+                        if _recv_exact(cand, 2) != b"ok":
+                            raise ConnectionError("handshake refused")
+                        s = cand
+                        break
+                    except (OSError, ConnectionError):
+                        cand.close()
+                if s is None:
                     if time.time() > deadline:
-                        raise TimeoutError(f"rank {self.rank}: cannot reach the host communicator of rank 0 at {address}")
-                    time.sleep(0.02)
+                        raise TimeoutError(f"rank {self.rank}: cannot reach the host communicator of rank 0 at {addresses} "
+                                           f"within {timeout:.0f} s ({_describe_env()})")
+                    time.sleep(0.05)
             s.settimeout(timeout)
-            if kind == "tcp":
-                s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send_msg(s, pickle.dumps(self.rank))
             self._sock = s
 
     def allgather(self, obj):
         if self.world_size == 1:
             return [obj]
         if self.rank == 0:
-            items = [obj] + [pickle.loads(_recv_msg(c)) for c in self._peers]
-            blob = pickle.dumps(items, protocol=pickle.HIGHEST_PROTOCOL)
+            items = [obj] + [decode(_recv_msg(c)) for c in self._peers]
+            blob = encode(items)
             for c in self._peers:
                 _send_msg(c, blob)
             return items
-        _send_msg(self._sock, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
-        return pickle.loads(_recv_msg(self._sock))
+        _send_msg(self._sock, encode(obj))
+        return decode(_recv_msg(self._sock))
 
     def close(self):
         for c in self._peers:
@@ -286,27 +454,120 @@ def adopt_thread_state(state):
 
 
 def _host_address():
+    """Where the ranks' host sides meet: MELLON_AMD_PORT set -> TCP only; else the abstract Unix socket named after
+    the launcher's rendezvous, with TCP on MASTER_ADDR : MASTER_PORT + 1 as the fallback (tried by every rank in
+    the same order; rank 0 listens on both)."""
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = os.environ.get("MELLON_AMD_PORT")
     if port:
-        return ("tcp", os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port))
+        return [("tcp", addr, int(port))]
     run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    return ("unix", f"mellon_amd.{os.environ.get('MASTER_ADDR', '127.0.0.1')}.{os.environ.get('MASTER_PORT', '0')}.{run}")
+    out = [("unix", f"mellon_amd.{addr}.{os.environ.get('MASTER_PORT', '0')}.{run}")]
+    try:
+        mp = int(os.environ.get("MASTER_PORT", "0"))
+    except ValueError:
+        mp = 0
+    if 0 < mp < 65535:
+        out.append(("tcp", addr, mp + 1))
+    return out
 
 
-def init_from_env():
+def _job_token():
+    """Shared by the ranks of one launch and by nobody who cannot read their environment."""
+    tok = os.environ.get("MELLON_AMD_TOKEN") or os.environ.get("TORCHELASTIC_RUN_ID", "")
+    return tok.encode("utf-8")[:64]
+
+
+def _with_deadline(what, fn, timeout):
+    """Run `fn()` (a call into the C library: ctypes releases the GIL) and give up with a readable error when it
+    does not return -- a communicator whose peers never arrive blocks inside RCCL, where no exception can reach."""
+    box = {}
+
+    def body():
+        try:
+            box["value"] = fn()
+        except BaseException as e:      # noqa: BLE001 -- re-raised on the caller's thread
+            box["error"] = e
+
+    state = thread_state()
+    t = threading.Thread(target=lambda: (adopt_thread_state(state), body()), daemon=True)
+    t.start()
+    t.join(timeout)
+    if t.is_alive():
+        raise TimeoutError(f"{what} did not complete within {timeout:.0f} s ({_describe_env()}; visible GPUs: "
+                           f"{_visible_devices()}).  Every rank must reach this point: check that WORLD_SIZE processes "
+                           "were started, that LOCAL_RANK indexes a visible GPU, and that HSA_ENABLE_IPC_MODE_LEGACY=0 "
+                           "is exported (RCCL's intra-node transport needs dmabuf IPC on this driver).")
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
+def _visible_devices():
+    try:
+        from . import _lib
+        return _lib.device_count()
+    except Exception:      # noqa: BLE001 -- diagnostic text only
+        return "unknown"
+
+
+def self_test(comm, timeout=120.0):
+    """First collectives of a fresh communicator, checked: all-reduce of (rank + 1) and of a rank-dependent vector,
+    and the host-side exchange.  Returns a small report; raises with the environment spelled out on any mismatch."""
+    w, r = comm.world_size, comm.rank
+    if w == 1 and comm.ctx is None:
+        return {"world_size": 1, "ok": True}
+    t0 = time.perf_counter()
+    probe = np.concatenate([[r + 1.0], np.arange(1024, dtype=np.float64) * (r + 1)])
+    got = _with_deadline("the first device all-reduce (RCCL)", lambda: comm.ctx.allreduce_sum(probe), timeout)
+    tri = w * (w + 1) / 2.0
+    want = np.concatenate([[tri], np.arange(1024, dtype=np.float64) * tri])
+    if got.shape != want.shape or not np.array_equal(got, want):
+        raise RuntimeError(f"rank {r}: device all-reduce self-test failed (sum of rank ids {got[0]} instead of {tri}; "
+                           f"{_describe_env()})")
+    dt_dev = time.perf_counter() - t0
+    ranks = comm.host.allgather(r) if hasattr(comm, "host") else [r]
+    if list(ranks) != list(range(w)):
+        raise RuntimeError(f"rank {r}: host communicator seats are {ranks}, expected 0..{w - 1} ({_describe_env()})")
+    sizes = [1 << 10, 1 << 20]
+    lat = []
+    for count in sizes:      # two sizes: latency of the per-evaluation all-reduce, bandwidth of the Gram's
+        buf = np.ones(count // 8)
+        comm.ctx.allreduce_sum(buf)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            comm.ctx.allreduce_sum(buf)
+        lat.append((time.perf_counter() - t1) / 5)
+    return {"world_size": w, "ok": True, "first_allreduce_s": dt_dev,
+            "allreduce_host_buffers_s": {str(b): t for b, t in zip(sizes, lat)}}
+
+
+def init_from_env(self_check=True):
     """One process per GPU (launched e.g. by `python -m torch.distributed.run`): read RANK / WORLD_SIZE /
-    LOCAL_RANK / MASTER_*, connect the host communicator, create the RCCL communicator on GPU LOCAL_RANK."""
+    LOCAL_RANK / MASTER_*, connect the host communicator, create the RCCL communicator on GPU LOCAL_RANK and run
+    its self-test (`self_test`: the first collectives, checked, under a deadline)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     force = os.environ.get("MELLON_AMD_FORCE_COMM") == "1" and "RANK" in os.environ   # 1-rank RCCL (testing)
     if world <= 1 and not force:
         return set_current(Communicator())
     from . import _lib
     rank = int(os.environ.get("RANK", "0"))
-    host = SocketHostComm(_host_address(), rank, world)
+    if not 0 <= rank < world:
+        raise ValueError(f"RANK={rank} outside [0, WORLD_SIZE={world}) ({_describe_env()})")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = _lib.device_count()
+    if local >= n_dev:
+        raise RuntimeError(f"LOCAL_RANK={local} but only {n_dev} GPU(s) are visible to this process ({_describe_env()}; "
+                           "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES restrict the set)")
+    timeout = float(os.environ.get("MELLON_AMD_COMM_TIMEOUT", "300"))
+    host = SocketHostComm(_host_address(), rank, world, timeout=timeout, token=_job_token())
     ctx = _lib.default_context()                       # device = LOCAL_RANK
     uid = host.broadcast(ctx.comm_unique_id() if rank == 0 else None, src=0)
-    ctx.comm_init(uid, world, rank)
-    return set_current(ShardedCommunicator(ctx, host))
+    _with_deadline("RCCL communicator set-up (ncclCommInitRank)", lambda: ctx.comm_init(uid, world, rank), timeout)
+    comm = set_current(ShardedCommunicator(ctx, host))
+    if self_check:
+        comm.self_test_report = self_test(comm, timeout=min(timeout, 120.0))
+    return comm
 
 
 def run_loopback(n_ranks, fn, device=None):

@@ -85,7 +85,9 @@ class LossFunc:
         self.fit.set_likelihood(V, Vdr, transform.mu)
         self.n_eval = 0
         self.preconditioned = True     # optimise u with z = C^-T u, C C^T ~ L^T L + I (see minimize_lbfgsb)
-        self.native_solver = True      # L-BFGS inside the library; False: SciPy L-BFGS-B drives the device objective
+        # L-BFGS inside the library; False (or more than 8192 landmarks, beyond the device-resident solver's register
+        # budget): SciPy L-BFGS-B drives the device objective, one evaluation per call
+        self.native_solver = self.fit.m <= 8192
         from .parameters import ridge_row_stride
         self.fit.precond_build(*ridge_row_stride(self.fit.n, self.fit.m, with_offset=True))   # no-op if the Ridge init built it
 

@@ -148,24 +148,29 @@ def _target_cell_count(normalize, t, average, unique_times):
     return normalize[unique_times.tolist().index(t)]
 
 
-def compute_nn_distances_within_time_points(x, times=None, d=None, normalize=False):
-    """reference parameters.py:444-531."""
+def compute_nn_distances_within_time_points(x, times=None, d=None, normalize=False, local=None):
+    """reference parameters.py:444-531.  `local=(lo, n_local)`: x holds the cells of ALL ranks and only the rows
+    [lo, lo + n_local) -- this rank's shard -- are searched for (against every cell of their time point) and returned;
+    counts per time point and their average are then the global ones by construction."""
     from .parameter_validation import validate_normalize_parameter
     from .validation import validate_float_or_iterable_numerical
     x = validate_time_x(x, times)
     unique_times = np.unique(x[:, -1])
-    nn = np.empty(x.shape[0])
     n_cells = x.shape[0]
+    lo, n_loc = (0, n_cells) if local is None else (int(local[0]), int(local[1]))
+    nn = np.empty(n_loc)
     av = n_cells / len(unique_times)
     validate_normalize_parameter(normalize, unique_times)
     normalizing = normalize is not False and normalize is not None
     if normalizing:
         d = validate_float_or_iterable_numerical(d, "d", optional=False, positive=True)
-        if np.ndim(d) > 0 and len(d) != n_cells:
+        if np.ndim(d) > 0 and len(d) != n_loc:
             raise ValueError(f"If `d` (length={len(d):,}) is a vector then it needs to have one value "
-                             f"per cell in x (x.shape[0]={n_cells:,}).")
+                             f"per cell in x (x.shape[0]={n_loc:,}).")
         logger.info("Normalizing nearest neighbor distances correcting sampling bias for "
                     f"{len(unique_times):,} different time points.")
+    own = np.zeros(n_cells, dtype=bool)
+    own[lo:lo + n_loc] = True
     for t in unique_times:
         mask = x[:, -1] == t
         n_t = int(mask.sum())
@@ -173,12 +178,24 @@ def compute_nn_distances_within_time_points(x, times=None, d=None, normalize=Fal
             raise ValueError(
                 f"Insufficient data: Only {n_t} sample(s) found at time point {t}. "
                 "Nearest neighbors cannot be computed with less than two samples per time point.")
-        nn_t = compute_nn_distances(x[mask, :-1])
+        mine = mask & own
+        if not mine.any():
+            continue
+        if local is None:
+            nn_t = compute_nn_distances(x[mask, :-1])
+        else:
+            # this rank's cells of the time point are a contiguous run of the time point's cells (order preserved)
+            before = int((mask[:lo]).sum())
+            x_t = np.ascontiguousarray(x[mask, :-1], dtype=np.float64)
+            k_t = int(mine.sum())
+            nn_t = _lib.default_context().nn_distances(np.ascontiguousarray(x_t[before:before + k_t]), x_t,
+                                                       self_offset=before)
+        sel = mine[lo:lo + n_loc]
         if normalizing:
             target = _target_cell_count(normalize, t, av, unique_times)
             dd = np.asarray(d, dtype=np.float64)
-            nn_t = (n_t / target) ** (1 / dd if dd.ndim == 0 else 1 / dd[mask]) * nn_t
-        nn[mask] = nn_t
+            nn_t = (n_t / target) ** (1 / dd if dd.ndim == 0 else 1 / dd[sel]) * nn_t
+        nn[sel] = nn_t
     return nn
 
 
@@ -209,10 +226,17 @@ def compute_cov_func(cov_func_curry, ls, ls_time=None):
 
 
 def compute_average_cell_count(x, normalize):
-    """reference parameters.py:927-969."""
-    n_times = np.unique(x[:, -1]).shape[0]
+    """reference parameters.py:927-969 (cells and time points of ALL ranks when sharded)."""
+    from .distributed import current
+    comm = current()
+    local_times = np.unique(x[:, -1])
+    if comm.world_size > 1:
+        n_times = np.unique(np.concatenate(comm.host.allgather(local_times))).shape[0]
+        n_cells = comm.global_count(x.shape[0])
+    else:
+        n_times, n_cells = local_times.shape[0], x.shape[0]
     if normalize is None or isinstance(normalize, bool):
-        return x.shape[0] / n_times
+        return n_cells / n_times
     if isinstance(normalize, dict):
         return sum(normalize.values()) / n_times
     if isinstance(normalize, (list, np.ndarray)):
@@ -291,7 +315,7 @@ def compute_initial_value(nn_distances, d, mu, L, row_stride=None, target=None):
         target = mle(np.asarray(nn_distances, dtype=np.float64), d) - mu
     fit = _fit_of(L)
     auto, offset = ridge_row_stride(fit.n, fit.m, with_offset=True)
-    fit.precond_build(auto if row_stride is None else row_stride, offset)
+    fit.precond_build(auto if row_stride is None else row_stride, offset, force=row_stride is not None)
     return fit.ridge_init(target)
 
 

@@ -59,15 +59,22 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
                              f"numerical instability issues; explicitly pass d={self.d} if intended.")
         return d
 
+    def _nn_within_time_points(self, normalize):
+        from .distributed import current
+        if current().world_size == 1:
+            return compute_nn_distances_within_time_points(self.x, d=self.d, normalize=normalize)
+        x_all, lo = self._all_cells()                 # every time point needs its cells from all ranks
+        return compute_nn_distances_within_time_points(x_all, d=self.d, normalize=normalize,
+                                                       local=(lo, self.x.shape[0]))
+
     def _compute_nn_distances(self):
         logger.info("Computing nearest neighbor distances within time points.")
-        return validate_nn_distances(compute_nn_distances_within_time_points(
-            self.x, d=self.d, normalize=self.normalize_per_time_point))
+        return validate_nn_distances(self._nn_within_time_points(self.normalize_per_time_point))
 
     def _compute_ls(self):
         nn = self.nn_distances
         if self.normalize_per_time_point is not False and self.normalize_per_time_point is not None:
-            nn = compute_nn_distances_within_time_points(self.x, normalize=False)
+            nn = self._nn_within_time_points(False)
         return compute_ls(nn) * self.ls_factor
 
     def _compute_ls_time(self):
@@ -88,8 +95,15 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
         return ls * self.ls_time_factor
 
     def _compute_landmarks(self):
-        return compute_landmarks_rescale_time(self.x, self.ls, self.ls_time, n_landmarks=self.n_landmarks,
-                                              random_state=self._seed())
+        from .distributed import current
+        comm = current()
+        if comm.world_size == 1:
+            return compute_landmarks_rescale_time(self.x, self.ls, self.ls_time, n_landmarks=self.n_landmarks,
+                                                  random_state=self._seed())
+        x_all, _ = self._all_cells()
+        lm = compute_landmarks_rescale_time(x_all, self.ls, self.ls_time, n_landmarks=self.n_landmarks,
+                                            random_state=self._seed()) if comm.rank == 0 else None
+        return comm.broadcast(None if lm is None else np.ascontiguousarray(lm, dtype=np.float64), src=0)
 
     def _compute_cov_func(self):
         cov_func = compute_cov_func(self.cov_func_curry, self.ls, self.ls_time)

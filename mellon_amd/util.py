@@ -169,18 +169,29 @@ def test_rank(input, tol=DEFAULT_RANK_TOL, threshold=None):
         raise ValueError("Matrix L must be 2D.")
     # a COUNT of singular values above a threshold needs neither eigenvectors nor eigenvalues: Sturm sequences on the
     # tridiagonalised Gram (csrc/tridiag.hip) -- 0.4 s at 5000 landmarks, where the eigensolver takes seconds
+    n_rows = int(L.shape[0])
     if isinstance(L, (FactorL, FactorLp)) and L.fit.handle is not None and not isinstance(L, FactorLp):
+        # a cell-sharded factor: the Gram is all-reduced, so this is a COLLECTIVE call (every rank must make it, as the
+        # estimator's own check does) and the rank is that of the whole n x m factor
+        from .distributed import current
         approx_rank, _ = L.fit.gram_rank(tol)
+        n_rows = current().global_count(n_rows)
     else:
+        # a plain array is this caller's own matrix: a local diagnostic, as in the reference.  It runs on a context
+        # WITHOUT the rank's communicator, so that one rank calling it alone never waits inside a collective.
         Lh = np.asarray(L, dtype=np.float64)
         if Lh.shape[0] < Lh.shape[1]:
             Lh = Lh.T                       # same singular values, smaller Gram
-        fit = _lib.Fit.from_L(_lib.default_context(), np.ascontiguousarray(Lh))
+        base = _lib.default_context()
+        ctx = base if base.n_ranks == 1 else _lib.Context(base.device)
+        fit = _lib.Fit.from_L(ctx, np.ascontiguousarray(Lh))
         try:
             approx_rank, _ = fit.gram_rank(tol)
         finally:
             fit.close()
-    max_rank = int(min(L.shape))
+            if ctx is not base:
+                ctx.close()
+    max_rank = int(min(n_rows, L.shape[1]))
     rank_fraction = approx_rank / max_rank
     if threshold is not None:
         if rank_fraction > threshold:

@@ -203,22 +203,157 @@ def test_product_has_no_framework_dependency():
             assert not re.search(r"^\s*(import|from)\s+torch\b", open(os.path.join(pkg, f)).read(), re.M), f
 
 
-def test_sharded_estimator_requires_shared_inputs():
-    """Landmarks and nn_distances need all cells: in sharded mode they must be passed in."""
+def test_sharded_estimator_gathers_shared_inputs(monkeypatch):
+    """Landmarks and nn_distances need all cells (parameters.py:243-291,352-433): a sharded fit gathers the cells over the
+    host communicator -- rank 0 clusters and broadcasts, every rank searches its own cells among all of them.  Two
+    thread-ranks over the product's ThreadHostComm; the device search is replaced by a NumPy one (no GPU here)."""
     sys.path.insert(0, ROOT)
+    import threading
     import mellon_amd
-    from mellon_amd import distributed
+    from mellon_amd import _lib, distributed, parameters
+    from oracle import mellon_oracle as mo
 
-    class Two(distributed.Communicator):
-        rank, world_size = 0, 2
+    class FakeCtx:
+        n_ranks = 2
 
-    distributed.set_current(Two())
+        def nn_distances(self, x, y=None, self_offset=0):
+            y = x if y is None else y
+            d2 = ((x[:, None, :] - y[None, :, :]) ** 2).sum(-1)
+            d2[np.arange(x.shape[0]), np.arange(x.shape[0]) + self_offset] = np.inf
+            return np.sqrt(d2.min(axis=1))
+
+    monkeypatch.setattr(_lib, "default_context", lambda: FakeCtx())
+    n, d, m = 301, 3, 12
+    x = mo.gaussian_mixture(n, d, seed=4)
+    times = np.repeat(np.arange(3.0), [100, 100, 101])
+    xt = np.column_stack([x, times])
+    nn_all = mo.exact_nn_distances(x)
+    nn_t = mo.per_time_nn_distances(x, times)
+    group = distributed.ThreadGroup(2)
+    out, errs = [None, None], []
+
+    def body(rank):
+        try:
+            comm = distributed.ShardedCommunicator(None, distributed.ThreadHostComm(group, rank))
+            distributed.set_thread_current(comm)
+            lo, hi = distributed.shard_bounds(n, 2, rank)
+            est = mellon_amd.DensityEstimator(n_landmarks=m)
+            est.set_x(np.ascontiguousarray(x[lo:hi]))
+            est.gp_type = mellon_amd.GaussianProcessType.SPARSE_CHOLESKY
+            nn = est._compute_nn_distances()
+            lm = est._compute_landmarks()
+            tse = mellon_amd.TimeSensitiveDensityEstimator(n_landmarks=m, ls_time=1.0)
+            tse.set_x(np.ascontiguousarray(xt[lo:hi]))
+            tse.d = d
+            nn_time = tse._nn_within_time_points(False)
+            avg = parameters.compute_average_cell_count(tse.x, False)
+            out[rank] = (nn, lm, nn_time, avg)
+        except BaseException as e:     # noqa: BLE001
+            errs.append(e)
+            group.barrier.abort()
+        finally:
+            distributed.set_thread_current(None)
+
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert np.allclose(np.concatenate([out[0][0], out[1][0]]), nn_all, rtol=1e-10)
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][1].shape == (m, d)       # the same landmarks, bit for bit
+    assert np.allclose(np.concatenate([out[0][2], out[1][2]]), nn_t, rtol=1e-10)     # within time points, across ranks
+    assert out[0][3] == out[1][3] == n / 3
+
+
+# ---- the host communicator's wire format and handshake (no GPU, no framework) ---------------------------------------
+def test_host_codec_round_trip_and_refusals():
+    from mellon_amd import distributed as D
+    rng = np.random.default_rng(0)
+    samples = [None, True, False, 0, -7, 2 ** 40, 1.5, float("inf"), "landmarks: k-means, untimed", b"\x00\x01" * 64,
+               rng.normal(size=(5, 3)), rng.normal(size=0), np.arange(6, dtype=np.int64).reshape(2, 3),
+               np.array([True, False]), rng.normal(size=(2, 3, 4)).astype(np.float32),
+               [1, "a", None, (2.0, np.ones(3))], (np.zeros((2, 2)), "note")]
+    for obj in samples:
+        back = D.decode(D.encode(obj))
+        if isinstance(obj, np.ndarray):
+            assert back.dtype == obj.dtype and back.shape == obj.shape and np.array_equal(back, obj)
+        elif isinstance(obj, (list, tuple)):
+            assert type(back) is type(obj) and len(back) == len(obj)
+        else:
+            assert back == obj and type(back) is type(obj)
+    nested = D.decode(D.encode([1, "a", None, (2.0, np.ones(3))]))
+    assert nested[3][0] == 2.0 and np.array_equal(nested[3][1], np.ones(3))
+    # only plain data travels: objects, callables, exotic dtypes are refused at the sender ...
+    for bad in (object(), lambda: 0, {"a": 1}, np.array(["x"]), np.ones(2, dtype=np.complex128)):
+        with pytest.raises(TypeError):
+            D.encode(bad)
+    # ... and a hostile or damaged message is a ValueError at the receiver, never code execution
+    import pickle
+    for blob in (pickle.dumps(os.system), b"", b"\x63", D.encode(np.ones(4))[:-3], D.encode("abc") + b"x",
+                 bytes([7, 9, 1]) + b"\x00" * 8, bytes([8]) + (2 ** 60).to_bytes(8, "little")):
+        with pytest.raises(ValueError):
+            D.decode(blob)
+
+
+def _socket_rank(rank, world, addresses, token, q):
+    sys.path.insert(0, ROOT)
+    from mellon_amd import distributed as D
     try:
-        est = mellon_amd.DensityEstimator(n_landmarks=10)
-        est.set_x(np.zeros((40, 2)))
-        with pytest.raises(NotImplementedError):
-            est._compute_nn_distances()
-        with pytest.raises(NotImplementedError):
-            est._compute_landmarks()
-    finally:
-        distributed.set_current(distributed.Communicator())
+        comm = D.SocketHostComm(addresses, rank, world, timeout=30.0, token=token)
+        got = comm.allgather((rank, np.full(3, float(rank))))
+        b = comm.broadcast(b"id-" + bytes([65 + rank]) if rank == 0 else None, src=0)
+        comm.barrier()
+        comm.close()
+        q.put((rank, [g[0] for g in got], float(sum(g[1].sum() for g in got)), b))
+    except BaseException as e:      # noqa: BLE001
+        q.put((rank, "error", repr(e), None))
+
+
+@pytest.mark.parametrize("transport", ["unix", "tcp-fallback"])
+def test_socket_host_comm_handshake(transport):
+    """Three processes over the host communicator: all-gather / broadcast / barrier; with `tcp-fallback` the Unix
+    socket name is unusable for the non-zero ranks (they are given a different one), so they meet rank 0 on TCP.
+    Meanwhile strangers knock: a wrong token, an out-of-range rank, garbage -- none of them takes a seat."""
+    import multiprocessing as mp
+    import socket as sk
+    import struct
+    import time
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    name = f"mellon_amd.test.{os.getpid()}.{port}"
+    addr0 = [("unix", name), ("tcp", "127.0.0.1", port)]
+    addr_others = addr0 if transport == "unix" else [("unix", name + ".nobody-listens"), ("tcp", "127.0.0.1", port)]
+    q = ctx.Queue()
+    token = b"job-42"
+    procs = [ctx.Process(target=_socket_rank, args=(0, 3, addr0, token, q))]
+    procs[0].start()
+    # strangers, before the real ranks arrive
+    deadline = time.time() + 20
+    knocked = 0
+    while knocked < 3 and time.time() < deadline:
+        try:
+            s = sk.socket(sk.AF_INET, sk.SOCK_STREAM)
+            s.settimeout(2.0)
+            s.connect(("127.0.0.1", port))
+            hello = b"MLNHC1" + bytes([len(token)]) + token
+            payload = [b"MLNHC1" + bytes([5]) + b"wrong" + struct.pack("<q", 1),     # wrong token
+                       hello + struct.pack("<q", 7),                                   # rank out of range
+                       b"\x80\x04garbage-that-is-not-a-handshake-at-all........"][knocked]
+            s.sendall(payload)
+            try:
+                assert s.recv(2) != b"ok"
+            except (sk.timeout, ConnectionError):
+                pass
+            s.close()
+            knocked += 1
+        except (ConnectionRefusedError, OSError):
+            time.sleep(0.05)
+    assert knocked == 3
+    for r in (1, 2):
+        procs.append(ctx.Process(target=_socket_rank, args=(r, 3, addr_others, token, q)))
+        procs[-1].start()
+    results = sorted(q.get(timeout=60) for _ in range(3))
+    for p in procs:
+        p.join(timeout=30)
+    for rank, seats, total, b in results:
+        assert seats == [0, 1, 2], (rank, seats, total)
+        assert total == 9.0 and b == b"id-A"

@@ -1,0 +1,335 @@
+"""Round-3 additions on a real MI355X (-m gpu), each against the oracle:
+
+* the kernel-plugin boundary: a Covariance subclass with a Python `k` (reference base_cov.py:17-69), alone and inside
+  Add / Mul; covariance trees beyond one device program (6 leaves); more than 8192 landmarks;
+* the solver's iteration path: subsample start and importance-weighted preconditioner rebuild reach the same optimum;
+* the cell-sharded path of TimeSensitiveDensityEstimator (C4) and FunctionEstimator (C5) on thread-ranks, and the
+  shared inputs (nearest-neighbour distances, k-means landmarks) computed inside a sharded fit;
+* the new C-ABI entries (mln_gemm, mln_ewise, mln_fit_prepare_from_K / _set_K_rows / _finish_K).
+"""
+import numpy as np
+import pytest
+
+from oracle import mellon_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_max(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def rel_std(a, b):
+    return np.std(a - b) / np.std(b)
+
+
+@pytest.fixture(scope="module")
+def mellon():
+    import mellon_amd
+    return mellon_amd
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mellon_amd import _lib
+    return _lib.default_context()
+
+
+# ---- C ABI: gemm / ewise ----------------------------------------------------------------------------------------
+def test_gemm_and_ewise_entries(ctx):
+    from mellon_amd import _lib
+    rng = np.random.default_rng(0)
+    for (M, N, K, ta, tb) in [(7, 5, 3, False, False), (130, 257, 64, True, False), (33, 1, 900, False, True), (300, 300, 300, True, True)]:
+        A = rng.normal(size=(K, M) if ta else (M, K))
+        B = rng.normal(size=(N, K) if tb else (K, N))
+        want = (A.T if ta else A) @ (B.T if tb else B)
+        got = ctx.gemm(A, B, ta=ta, tb=tb).to_host()
+        assert rel_max(got, want) < 1e-13
+        acc = ctx.to_device(np.ones((M, N)))
+        ctx.gemm(ctx.to_device(A), B, ta=ta, tb=tb, alpha=0.5, beta=2.0, out=acc)
+        assert rel_max(acc.to_host(), 0.5 * want + 2.0) < 1e-13
+    a, b = rng.uniform(0.1, 2.0, size=(50, 7)), rng.uniform(0.1, 2.0, size=(50, 7))
+    assert np.allclose(ctx.ewise(_lib.OP_ADD, a, b).to_host(), a + b, rtol=0, atol=0)
+    assert np.allclose(ctx.ewise(_lib.OP_MUL, a, b).to_host(), a * b, rtol=0, atol=0)
+    assert rel_max(ctx.ewise(_lib.OP_POW, a, 2.5).to_host(), a ** 2.5) < 1e-14
+    assert np.allclose(ctx.ewise(_lib.OP_MUL, a, 3.0).to_host(), 3.0 * a, rtol=0, atol=0)
+    assert _lib.device_count() >= 1
+
+
+# ---- user-defined kernels ---------------------------------------------------------------------------------------
+def _user_matern52(mellon):
+    class UserMatern52(mellon.base_cov.Covariance):
+        """A user's own kernel: Matern-5/2 written in NumPy (the ABC's contract is just k(x, y))."""
+
+        def __init__(self, ls=1.0, active_dims=None):
+            super().__init__()
+            self.ls = ls
+            self.active_dims = active_dims
+            self.calls = 0
+
+        def k(self, x, y):
+            self.calls += 1
+            if self.active_dims is not None:
+                x, y = x[:, self.active_dims], y[:, self.active_dims]
+            sq = (x * x).sum(1)[:, None] - 2.0 * x @ y.T + (y * y).sum(1)[None, :] + 1e-12
+            r = np.sqrt(5.0) * np.sqrt(np.maximum(sq, 0.0)) / self.ls
+            return (r + r * r / 3.0 + 1.0) * np.exp(-r)
+
+    return UserMatern52
+
+
+def test_user_defined_kernel_density_estimator(mellon):
+    """DensityEstimator with a Python-level kernel: the binding evaluates the user's k in row blocks, the library does
+    everything after the kernel matrix; result == the oracle with the equivalent built-in kernel, predict included."""
+    User = _user_matern52(mellon)
+    n, d, m = 6000, 6, 200
+    x = mo.gaussian_mixture(n, d, seed=31)
+    nn = mo.exact_nn_distances(x)
+    ref = mo.density_fit(x, n_landmarks=m, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    for implicit in (True, False):
+        est = mellon.DensityEstimator(cov_func_curry=User, landmarks=ref.landmarks, nn_distances=nn)
+        est.implicit_factor = implicit
+        dens = est.fit_predict(x)
+        assert isinstance(est.cov_func, User) and est.cov_func.calls > 1
+        assert rel_max(dens, ref.log_density_x) < 1e-5 and rel_std(dens, ref.log_density_x) < 1e-5
+        q = x[::11] + 0.01
+        assert rel_max(est.predict(q), ref.predict(q)) < 1e-5
+        assert rel_max(est.predict(x[:500]), dens[:500]) < 1e-9
+    # full GP (no landmarks) with the user's kernel
+    xs, nns = x[:700], mo.exact_nn_distances(x[:700])
+    reff = mo.density_fit(xs, nn_distances=nns, lbfgsb_options=mo.LBFGSB_TIGHT)
+    estf = mellon.DensityEstimator(cov_func_curry=User, nn_distances=nns)
+    assert rel_max(estf.fit_predict(xs), reff.log_density_x) < 1e-5
+    assert rel_max(estf.predict(xs[::5] + 0.02), reff.predict(xs[::5] + 0.02)) < 1e-5
+    # what cannot work without a device program says so
+    with pytest.raises(NotImplementedError):
+        est.predict.gradient(q)
+
+
+def test_user_defined_kernel_inside_algebra(mellon, ctx):
+    """A Python kernel as one operand of + and *: built-in sub-trees run as device programs, the user's leaf on the host,
+    the node combines the blocks on the device; composite active_dims reach the user's k as column selections."""
+    User = _user_matern52(mellon)
+    cov = mellon.cov
+    rng = np.random.default_rng(3)
+    x, y = rng.normal(size=(700, 5)), rng.normal(size=(90, 5))
+    tree = (User(1.3, active_dims=[0, 1]) * cov.ExpQuad(2.0, active_dims=[2, 3, 4]) + 0.25 * cov.Matern32(0.9)) ** 2
+    otree = (mo.Matern52(1.3, active_dims=[0, 1]) * mo.ExpQuad(2.0, active_dims=[2, 3, 4]) + 0.25 * mo.Matern32(0.9)) ** 2
+    assert type(tree.lower(5)).__name__ == "BlockCov"
+    assert rel_max(tree(x, y), otree(x, y)) < 1e-12
+    # an enclosing node's active_dims select the columns the user's k sees
+    outer = mellon.base_cov.Mul(User(0.8), cov.Matern52(1.1), active_dims=slice(1, 4))
+    oouter = mo.Mul(mo.Matern52(0.8), mo.Matern52(1.1), active_dims=slice(1, 4))
+    assert rel_max(outer(x, y), oouter(x, y)) < 1e-12
+
+
+def test_six_leaf_sum_of_products(mellon):
+    """Beyond MLN_MAX_LEAVES = 4 leaves / stack depth 3: k(), fit_predict and predict of a 6-leaf sum of products."""
+    cov = mellon.cov
+
+    def build(c):
+        return (c.Matern52(1.5, active_dims=[0, 1]) * c.ExpQuad(2.5, active_dims=[2, 3])
+                + c.Matern32(1.1, active_dims=[0, 2]) * c.Exponential(3.0, active_dims=[1, 3])
+                + 0.5 * (c.RatQuad(2.0, 1.7, active_dims=[1, 2]) * c.ExpQuad(1.9, active_dims=[0, 3])))
+
+    tree, otree = build(cov), build(mo)
+    assert type(tree.lower(4)).__name__ == "BlockCov"
+    rng = np.random.default_rng(5)
+    x, y = rng.normal(size=(900, 4)), rng.normal(size=(120, 4))
+    assert rel_max(tree(x, y), otree(x, y)) < 1e-12
+    n, m = 5000, 150
+    xs = mo.gaussian_mixture(n, 4, seed=17)
+    nn = mo.exact_nn_distances(xs)
+    lm = mo.compute_landmarks(xs, mo.SPARSE_CHOLESKY, m, 42)
+    ref = mo.density_fit(xs, cov_func=otree, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    est = mellon.DensityEstimator(cov_func=tree, landmarks=lm, nn_distances=nn)
+    dens = est.fit_predict(xs)
+    assert rel_max(dens, ref.log_density_x) < 1e-5 and rel_std(dens, ref.log_density_x) < 1e-5
+    assert rel_max(est.predict(xs[::9] + 0.01), ref.predict(xs[::9] + 0.01)) < 1e-5
+
+
+def test_more_than_8192_landmarks(mellon, ctx):
+    """m = 12 000 landmarks: the fused pass is segmented (two reads of the buffer), the solve is driven from the host.
+    Objective / gradient == the oracle's loss_and_grad at arbitrary z; the fit reaches the oracle's optimum."""
+    n, d, m = 12_600, 4, 12_000
+    x = mo.gaussian_mixture(n, d, seed=23)
+    nn = mo.exact_nn_distances(x)
+    lm = np.ascontiguousarray(x[:m] + 1e-3)                 # (k-means with 12 000 centres is not what is tested here)
+    ls, mu = mo.compute_ls(nn), mo.compute_mu(nn, d)
+    ocov = mo.Matern52(ls)
+    Lp = mo.full_rank(lm, ocov)
+    L = mo.standard_low_rank(x, ocov, lm, Lp=Lp)
+    V, Vdr = mo.nn_likelihood_constants(nn, d)
+    rng = np.random.default_rng(1)
+    for implicit in (False, True):
+        fit = ctx.fit_prepare(mellon.cov.Matern52(ls).lower(d), x, lm, 1e-6, implicit=implicit)
+        fit.set_likelihood(V, Vdr, mu)
+        for scale in (0.0, 0.3):
+            z = scale * rng.normal(size=m)
+            want_l, want_g = mo.loss_and_grad(z, L, mu, V, Vdr)
+            got_l, got_g = fit.objective(z)
+            assert abs(got_l - want_l) < 1e-9 * abs(want_l)
+            assert np.abs(got_g - want_g).max() < 1e-8 * np.abs(want_g).max()
+            assert rel_max(fit.transform(z, mu), L @ z + mu) < 1e-9
+        fit.close()
+    ref_z = mo.minimize_lbfgsb(lambda z: mo.loss_and_grad(z, L, mu, V, Vdr), mo.compute_initial_value(nn, d, mu, L),
+                               mo.LBFGSB_TIGHT).pre_transformation
+    ref_dens = L @ ref_z + mu
+    est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+    dens = est.fit_predict(x)
+    assert not est.loss_func.native_solver
+    assert rel_max(dens, ref_dens) < 1e-5 and rel_std(dens, ref_dens) < 1e-5
+    assert rel_max(est.predict(x[:300]), dens[:300]) < 1e-8
+
+
+# ---- iteration path: subsample start, preconditioner rebuild ------------------------------------------------------
+@pytest.fixture(scope="module")
+def path_workload():
+    from sklearn.cluster import k_means
+    n, d, m = 40_000, 10, 300
+    x = mo.gaussian_mixture(n, d, seed=13)
+    nn = mo.exact_nn_distances(x)
+    lm = np.ascontiguousarray(k_means(x[:8000], m, n_init=1, random_state=42)[0])
+    ref = mo.density_fit(x, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    return x, nn, lm, ref
+
+
+@pytest.mark.parametrize("sub,rebuild,mixed", [("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("1", "1", "0"), ("1", "0", "1")])
+def test_iteration_path_switches_leave_the_optimum_alone(mellon, path_workload, monkeypatch, sub, rebuild, mixed):
+    """Subsample start (solver.hip phase S) and the importance-weighted second preconditioner (precond_rebuild.hip) are
+    shortcuts of the PATH: with each of them on or off the fit lands on the oracle's optimum."""
+    x, nn, lm, ref = path_workload
+    monkeypatch.setenv("MELLON_AMD_SUBSAMPLE", sub)
+    monkeypatch.setenv("MELLON_AMD_REBUILD", rebuild)
+    monkeypatch.setenv("MELLON_AMD_MIXED", mixed)
+    monkeypatch.setenv("MELLON_AMD_MIXED_MIN_ELEMS", "1")
+    est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+    dens = est.fit_predict(x)
+    st = est._fit.stage_times()
+    assert (st["objective_sub_launches"] > 0) == (sub == "1"), st
+    if mixed == "0":
+        assert st["objective32_launches"] == 0
+        assert st["precond_rebuilds"] == (1.0 if rebuild == "1" else 0.0), st
+    assert rel_max(dens, ref.log_density_x) < 1e-5 and rel_std(dens, ref.log_density_x) < 1e-5, (sub, rebuild, mixed)
+    assert rel_max(est.predict(x[:400]), dens[:400]) < 1e-9
+
+
+def test_iteration_path_sharded(mellon, path_workload, monkeypatch):
+    """The same switches on 3 uneven thread-rank shards: the subsample is by GLOBAL cell index, the rebuild's importance
+    sample is a hash of it -- the sharded fit equals the unsharded one."""
+    from mellon_amd import distributed
+    x, nn, lm, ref = path_workload
+    x, nn = x[:-7], nn[:-7]
+    monkeypatch.setenv("MELLON_AMD_SUBSAMPLE", "1")
+    monkeypatch.setenv("MELLON_AMD_REBUILD", "1")
+    monkeypatch.setenv("MELLON_AMD_MIXED", "0")
+    est1 = mellon.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+    dens1 = est1.fit_predict(x)
+
+    def body(comm):
+        lo, hi = distributed.shard_bounds(x.shape[0], comm.world_size, comm.rank)
+        est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn[lo:hi], check_rank=False)
+        dens = est.fit_predict(np.ascontiguousarray(x[lo:hi]))
+        st = est._fit.stage_times()
+        return dens, st["precond_rebuilds"], st["objective_sub_launches"]
+
+    res = distributed.run_loopback(3, body)
+    dens = np.concatenate([r[0] for r in res])
+    assert all(r[1] == 1.0 and r[2] > 0 for r in res)
+    assert rel_max(dens, dens1) < 1e-6
+
+
+# ---- sharded C4 / C5 ------------------------------------------------------------------------------------------------
+def test_time_sensitive_estimator_sharded(mellon):
+    """C4 shape on 4 thread-ranks: per-time-point nearest neighbours across ranks, global ls / mu / average cell count,
+    product kernel; == the unsharded fit and the oracle; predictors agree (normalize=True uses the GLOBAL n_obs)."""
+    from mellon_amd import distributed
+    n_per, d, T, m = 1200, 5, 4, 300
+    xs = np.concatenate([mo.gaussian_mixture(n_per, d, seed=60 + t) + 0.3 * t for t in range(T)])
+    times = np.repeat(np.arange(float(T)), n_per)
+    xt = np.ascontiguousarray(np.column_stack([xs, times]))
+    nn = mo.per_time_nn_distances(xs, times)
+    ls, ls_time = mo.compute_ls(nn), 1.5
+    sub = xt.copy()
+    sub[:, -1] *= ls / ls_time
+    lm = mo.compute_landmarks(sub, mo.SPARSE_CHOLESKY, m, 42)
+    lm[:, -1] /= ls / ls_time
+    ref = mo.density_fit(xt, landmarks=lm, nn_distances=nn, ls_time=ls_time, lbfgsb_options=mo.LBFGSB_TIGHT)
+    est1 = mellon.TimeSensitiveDensityEstimator(landmarks=lm, nn_distances=nn, ls_time=ls_time)
+    dens1 = est1.fit_predict(xt)
+    q = np.column_stack([xs[::13] + 0.02, times[::13]])
+
+    def body(comm):
+        lo, hi = distributed.shard_bounds(xt.shape[0], comm.world_size, comm.rank)
+        # nn_distances NOT given: computed inside the sharded fit, within time points, across ranks
+        est = mellon.TimeSensitiveDensityEstimator(landmarks=lm, ls_time=ls_time)
+        dens = est.fit_predict(np.ascontiguousarray(xt[lo:hi]))
+        return dict(dens=dens, nn=np.asarray(est.nn_distances), mu=est.mu, ls=est.ls, pred=est.predict(q),
+                    predn=est.predict(q, normalize=True), n_obs=est.predict.n_obs)
+
+    res = distributed.run_loopback(4, body)
+    assert rel_max(np.concatenate([r["nn"] for r in res]), nn) < 1e-12
+    assert all(abs(r["mu"] - ref.mu) < 1e-10 and abs(r["ls"] - ref.ls) < 1e-10 * ref.ls for r in res)
+    assert all(r["n_obs"] == xt.shape[0] / T for r in res)
+    dens = np.concatenate([r["dens"] for r in res])
+    assert rel_max(dens, dens1) < 1e-6
+    assert rel_max(dens, ref.log_density_x) < 1e-5 and rel_std(dens, ref.log_density_x) < 1e-5
+    assert all(np.array_equal(r["pred"], res[0]["pred"]) for r in res)
+    assert rel_max(res[0]["pred"], ref.predict(q)) < 1e-5
+    assert rel_max(res[0]["predn"], est1.predict(q, normalize=True)) < 1e-6
+
+
+def test_function_estimator_sharded(mellon):
+    """C5 shape (p = 64 outputs) on 8 thread-ranks: A A^T and A r all-reduced inside mln_sparse_solve, replicated weights,
+    per-rank batched predict; == unsharded == oracle.  Landmarks and nearest-neighbour distances are computed INSIDE
+    the sharded fit (gathered cells; rank 0's k-means broadcast)."""
+    from mellon_amd import distributed
+    rng = np.random.default_rng(65)
+    n, d, m, p = 4003, 8, 250, 64
+    x = mo.gaussian_mixture(n, d, seed=6)
+    W = rng.normal(size=(d, p)) / np.sqrt(d)
+    y = np.sin(x @ W) + 0.1 * rng.normal(size=(n, p))
+    nn = mo.exact_nn_distances(x)
+    lm = mo.compute_landmarks(x, mo.SPARSE_CHOLESKY, m, 42)
+    ref = mo.function_fit(x, y, 0.1, landmarks=lm, nn_distances=nn)
+    want = ref(x) if callable(ref) else ref.predict(x)
+    pred1 = mellon.FunctionEstimator(sigma=0.1, landmarks=lm, nn_distances=nn).fit_predict(x, y, x)
+
+    def body(comm, given):
+        lo, hi = distributed.shard_bounds(n, comm.world_size, comm.rank)
+        kw = dict(landmarks=lm, nn_distances=nn[lo:hi]) if given else dict(n_landmarks=m)
+        est = mellon.FunctionEstimator(sigma=0.1, **kw)
+        pred = est.fit_predict(np.ascontiguousarray(x[lo:hi]), np.ascontiguousarray(y[lo:hi]), np.ascontiguousarray(x[lo:hi]))
+        return pred, np.asarray(est.landmarks), est.ls
+
+    res = distributed.run_loopback(8, lambda comm: body(comm, True))
+    pred = np.concatenate([r[0] for r in res])
+    assert pred.shape == (n, p)
+    assert rel_max(pred, pred1) < 1e-9 and rel_max(pred, want) < 1e-7
+    # shared inputs computed inside the sharded fit: same landmarks on every rank, the global length scale
+    res2 = distributed.run_loopback(4, lambda comm: body(comm, False))
+    assert all(np.array_equal(r[1], res2[0][1]) for r in res2)
+    assert all(abs(r[2] - mo.compute_ls(nn)) < 1e-10 * r[2] for r in res2)
+    ref2 = mo.function_fit(x, y, 0.1, landmarks=res2[0][1], nn_distances=nn)
+    want2 = ref2(x) if callable(ref2) else ref2.predict(x)
+    assert rel_max(np.concatenate([r[0] for r in res2]), want2) < 1e-7
+
+
+def test_density_estimator_sharded_with_default_inputs(mellon):
+    """The drop-in call on shards: no landmarks=, no nn_distances= -- both are computed from the gathered cells
+    (parameters.py:243-291,352-433) and the fit equals the single-rank drop-in call."""
+    from mellon_amd import distributed
+    n, d, m = 9001, 6, 120
+    x = mo.gaussian_mixture(n, d, seed=19)
+    est1 = mellon.DensityEstimator(n_landmarks=m)
+    dens1 = est1.fit_predict(x)
+
+    def body(comm):
+        lo, hi = distributed.shard_bounds(n, comm.world_size, comm.rank)
+        est = mellon.DensityEstimator(n_landmarks=m)
+        return est.fit_predict(np.ascontiguousarray(x[lo:hi])), np.asarray(est.landmarks), np.asarray(est.nn_distances)
+
+    res = distributed.run_loopback(3, body)
+    assert all(np.array_equal(r[1], np.asarray(est1.landmarks)) for r in res)
+    assert np.array_equal(np.concatenate([r[2] for r in res]), np.asarray(est1.nn_distances))
+    assert rel_max(np.concatenate([r[0] for r in res]), dens1) < 1e-6
