@@ -118,7 +118,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
   double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k, t0 = st->t0, cap = st->cap;
   bool recap = false;
-  if (mode != MLN_SOLVE_LS) t0 = 1.0;
+  if (mode != MLN_SOLVE_LS && !resume) t0 = 1.0;
   int f_slot = st->f_slot, f_valid = st->f_valid, corr = st->corr, n_anchor = st->n_anchor;
   if (b.trace && tid == 0 && !resume) {
     double* tr = b.trace + 4 * ((n_eval - 1) & 511);
@@ -213,7 +213,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       if (cap < 1e300 && it >= 3 && (f_old - fx) <= st->cap_fall * fabs(f_old)) { cap = __builtin_inf(); recap = true; }
       if (phaseS) {
         // the subsample objective has done its job once its own progress per iteration is small: same point, full objective
-        if ((f_old - fx) <= st->sub_tol * fscale) reeval = true; else to_head = true;
+        // (not before a few iterations: the very first step from the Ridge start is a cautious t = 1 / |g|_1)
+        if (it >= 4 && (f_old - fx) <= st->sub_tol * fscale) reeval = true; else to_head = true;
       } else if (st->rebuild_armed && !phase32 && it_full >= 2 && (f_old - fx) <= st->rebuild_tol * fscale &&
                  (f_old - fx) > st->ftol * fscale) {
         pause = true;                    // the host rebuilds the preconditioner from the weights a = e^{f+V} at THIS point

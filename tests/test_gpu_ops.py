@@ -69,15 +69,21 @@ def test_kernel_matrix_algebra_and_active_dims(ctx):
         assert relmax(c(x, y), _pair(c)(x, y)) < 1e-12, repr(c)
 
 
-def test_custom_python_kernel_refused(ctx):
-    from mellon_amd.base_cov import Covariance
+def test_custom_python_kernel_is_evaluated_block_wise(ctx):
+    """A subclass with its own Python k (reference base_cov.py:17-69) does not lower to a device program: lower() hands
+    back the block evaluator, k() returns the user's values, scalar algebra on top runs on the device."""
+    from mellon_amd.base_cov import BlockCov, Covariance
 
     class Mine(Covariance):
         def k(self, x, y):
             return x @ y.T
 
+    rng = np.random.default_rng(2)
+    x, y = rng.normal(size=(40, 3)), rng.normal(size=(7, 3))
+    assert isinstance((Mine() * 2.0).lower(3), BlockCov)
+    assert relmax((Mine() * 2.0 + 1.0)(x, y), 2.0 * (x @ y.T) + 1.0) < 1e-14
     with pytest.raises(NotImplementedError):
-        (Mine() * 2.0).lower(3)
+        Mine().k_grad(x)(y)
 
 
 @pytest.mark.parametrize("m", [1, 5, 64, 65, 200, 777])
