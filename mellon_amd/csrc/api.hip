@@ -497,7 +497,7 @@ struct mln_fit {
   bool from_K = false, k_finished = false;
   int64_t k_rows_done = 0;
   double build_seconds = 0.0;     // wall time of the first preconditioner build (Gram + factorisation): the rebuild's price
-  double times_sub = 0.0, times_rebuild = 0.0;
+  double times_sub = 0.0, times_rebuild = 0.0, sub_pass_equiv = 0.0;
   int evals_sub = 0, n_rebuild = 0;
 };
 
@@ -1527,22 +1527,9 @@ static int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_
     bool quant = f->kspace && f->cov_bounded01 && m >= 256;
     if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
     rc = gram_of(ctx, R, f->ldl, sel.rows, m, sel.w_max, f->C, ldg, quant);                   // all-reduced
-    if (rc == MLN_OK && quant) {
-      // The integer Gram is that of the rows ROUNDED to 1 / 8355711: Q = R + E with independent rounding errors of
-      // variance 1 / (12 * 8355711^2) per entry, so E[Q^T Q] = R^T R + rows * var * I.  For the first preconditioner that
-      // bias is nothing; here it is multiplied by w_max (~1e3) and then by |Lp^-1|^2 (~1e6) in the whitening -- an O(1)
-      // spurious multiple of K_uu^-1 that grows with the number of rows (measured: 24 m rows needed MORE passes than
-      // 12 m).  Its expectation is known, so it is taken out; what remains is zero-mean and ~sqrt(rows) smaller.
-      double cnt = (double)sel.rows;
-      hipError_t e = hipMemcpyAsync(f->d_tmp, &cnt, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-      if (e != hipSuccess) rc = MLN_ERR_HIP;
-      if (rc == MLN_OK) rc = dev_allreduce(ctx, f->d_tmp, 1);
-      if (rc == MLN_OK && (hipMemcpyAsync(&cnt, f->d_tmp, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                           hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = MLN_ERR_HIP;
-      const double var = 1.0 / (12.0 * 8355711.0 * 8355711.0);
-      static const bool debias = !(std::getenv("MELLON_AMD_GRAM_DEBIAS") && std::atoi(std::getenv("MELLON_AMD_GRAM_DEBIAS")) == 0);
-      if (rc == MLN_OK && debias) rc = launch_add_diag(ctx, f->C, m, ldg, -sel.w_max * cnt * var);
-    }
+    // (The integer Gram is that of the rows ROUNDED to 1 / 8355711; the rounding's own Gram, rows * var * I times w_max
+    //  and the whitening's |Lp^-1|^2, is an O(0.1) multiple of K_uu^-1.  Subtracting its expectation was tried: no change
+    //  in the pass count at w_max ~ 5e3, and at w_max ~ 1e5 the subtraction itself made the matrix indefinite.)
     if (std::getenv("MELLON_AMD_TRACE"))
       fprintf(stderr, "[trace] rebuild: %lld of %lld local rows kept (target %.0f global), c = %.4g, 1/c = %.4g, w_max = %.4g, sum a = %.6g\n",
               (long long)sel.rows, (long long)f->n, target, sel.c, 1.0 / sel.c, sel.w_max, sel.sum_a);
@@ -1681,7 +1668,7 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
 // are launched and the one the solver's state does not select returns at once; everything is a no-op after DONE.
 // ev (optional): three events -- before the fp32 pass, between the two, after the fp64 pass.
 static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32, const int* gate,
-                            hipEvent_t* ev, int64_t sub_stride = 0) {
+                            hipEvent_t* ev, const std::vector<int64_t>* sub_strides = nullptr) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ld = f->ldl, ld2 = f->ld2;
   GemvTri g1{f->Q1, ld, f->kspace ? 2 * m : m, u_dev, f->d_zr, f->kspace ? f->d_w : nullptr, 1, m, m, 0, 0, gate};
@@ -1705,17 +1692,21 @@ static int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, boo
     a.gate_want = MLN_GATE_F64;
     MLN_TRY(launch_objective(ctx, a));
   }
-  if (gate && sub_stride > 1) {
-    // the subsample objective of the solver's first phase: the same fp64 kernel over every sub_stride-th row (same grid:
-    // workgroups past the shorter row range write zero partials), sums scaled by sub_stride in the reduction
-    ObjArgs as = a;
-    int64_t first = 0, rows = 0;
-    fit_sample_rows(f, sub_stride, &first, &rows);
-    as.n = rows; as.row_first = first; as.row_stride = sub_stride;
-    as.f_keep[0] = as.f_keep[1] = nullptr; as.f_slot = nullptr;
-    as.gate_want = MLN_GATE_SUB;
-    MLN_TRY(launch_objective(ctx, as));
-    a.out_scale = (double)sub_stride;      // (applied by the reduction only when the solver's gate says SUB)
+  if (gate && sub_strides) {
+    // the subsample objectives of the solver's first phase: the same fp64 kernel over every s-th row, one launch per
+    // level (the solver's state says which one works; same grid: workgroups past the shorter row range write zero
+    // partials), partial sums scaled by s
+    for (size_t lv = 0; lv < sub_strides->size(); ++lv) {
+      const int64_t sub_stride = (*sub_strides)[lv];
+      ObjArgs as = a;
+      int64_t first = 0, rows = 0;
+      fit_sample_rows(f, sub_stride, &first, &rows);
+      as.n = rows; as.row_first = first; as.row_stride = sub_stride; as.out_scale = (double)sub_stride;
+      as.f_keep[0] = as.f_keep[1] = nullptr; as.f_slot = nullptr;
+      as.gate_want = MLN_GATE_SUB;
+      as.gate2 = &f->sv.st->sub_level; as.gate2_want = (int)lv;
+      MLN_TRY(launch_objective(ctx, as));
+    }
   }
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
   MLN_TRY(launch_reduce_obj2(ctx, a, f->d_zr + ld2 + m, f->d_zr + ld2));
@@ -1849,19 +1840,40 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // on the MAP problem of exactly those cells -- the Ridge matrix is ITS Hessian at a = 1 -- at 1/s of the bytes per
   // pass, and moves to all cells once that problem's progress per iteration is below sub_tol.  The walk down from the
   // Ridge start (a dozen passes) then costs about two.  MELLON_AMD_SUBSAMPLE=0 disables, MELLON_AMD_SUB_TOL moves it.
-  int64_t sub_stride = (f->precond_stride >= 4) ? f->precond_stride : 0;
-  if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) sub_stride = 0; }
+  // Which cells: ~32 m of them (every (3 s / 8)-th cell for a Gram stride s = n / 12 m; nested levels are possible,
+  // MELLON_AMD_SUB_LEVELS="16:8", but did not pay).  tools/solver_sweep.py, five data seeds at C3, mean step in ms:
+  // no subsample 302 | stride 16: 241 | 12: 204 | 8: 203 | 6: 193 | 4: 203 | 16 then 8: 213 | 16 then 4: 215.
+  // The smaller the sample, the cheaper its passes but the more its optimum overfits (at stride 16 the first full
+  // evaluation finds the loss 60 % above the optimum's and e^{f+V} of unseen cells up to 1e5).
+  std::vector<int64_t> sub_strides;
+  if (f->precond_stride >= 4) sub_strides.push_back(std::max<int64_t>(2, 3 * f->precond_stride / 8));
+  if (const char* ev = std::getenv("MELLON_AMD_SUB_LEVELS")) {
+    if (!sub_strides.empty()) {
+      sub_strides.clear();
+      for (const char* p = ev; *p;) {
+        char* end = nullptr;
+        const long long v = std::strtoll(p, &end, 10);
+        if (end == p) break;
+        if (v >= 2) sub_strides.push_back((int64_t)v);
+        p = (*end != 0) ? end + 1 : end;        // any one separator character ("16,4", "16:4")
+      }
+    }
+  }
+  if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) sub_strides.clear(); }
+  const std::vector<int64_t>* subs = sub_strides.empty() ? nullptr : &sub_strides;
   init.gate_full = init.gate;
   init.sub_tol = 1e-3;
   if (const char* ev = std::getenv("MELLON_AMD_SUB_TOL")) init.sub_tol = std::atof(ev);
-  if (sub_stride > 1) { init.gate = MLN_GATE_SUB; init.cap = __builtin_inf(); }
+  init.n_sub_levels = (int)sub_strides.size();
+  init.sub_level = 0;
+  if (subs) { init.gate = MLN_GATE_SUB; init.cap = __builtin_inf(); }
   // Preconditioner rebuild (solver.h, precond_rebuild.hip): pays when the ~12 full passes it saves cost more than the
   // m^3 work of a second factorisation -- decided from rank 0's measurement of the first build, the same on every rank.
   // MELLON_AMD_REBUILD=0 / 1 forces the decision.
   const double pass_s = (double)f->n * (double)f->ldl * 8.0 / 6.5e12;
   double want_rebuild = (f->build_seconds > 0.0 && 12.0 * pass_s > 1.1 * f->build_seconds) ? 1.0 : 0.0;
   if (const char* ev = std::getenv("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
-  if (phase32) want_rebuild = 0.0;          // (the 32-bit phases keep no f per row: fp64-only solves for now)
+  if (phase32 && !(f->l32_fixed)) want_rebuild = 0.0;   // (mixed solves pause at their fp64 anchor, which only the corrected fixed-point surrogate has)
   {
     MLN_HIP(ctx, hipMemcpyAsync(f->d_tmp, &want_rebuild, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MLN_TRY(dev_bcast0(ctx, f->d_tmp, 1));
@@ -1869,6 +1881,8 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   init.rebuild_armed = want_rebuild != 0.0 ? 1 : 0;
+  init.rebuild_at_switch = 0;     // (measured: at the switch the unseen cells' weights are still too wild -- 37-96 full passes)
+  if (const char* ev = std::getenv("MELLON_AMD_REBUILD_AT_SWITCH")) init.rebuild_at_switch = std::atoi(ev) != 0 ? 1 : 0;
   init.rebuild_tol = 1e-3;       // (tools/solver_sweep.py at C3, two seeds: 1e-2 -> 23-28 full passes, 1e-3 -> 20-22, 2e-4 -> 22-26)
   if (const char* ev = std::getenv("MELLON_AMD_REBUILD_TOL")) init.rebuild_tol = std::atof(ev);
   double rebuild_rows_per_m = 6.0;   // (6 m, 12 m, 24 m importance-sampled rows: the same pass counts; 6 m is the cheapest Gram)
@@ -1886,7 +1900,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     }
     return &f->evs[3 * i];
   };
-  MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), sub_stride));
+  MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), subs));
   ++n_enq;
   int batch = 8;
   if (const char* ev = std::getenv("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
@@ -1894,7 +1908,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   for (;;) {
     for (int b = 0; b < batch; ++b) {
       MLN_TRY(launch_solver_step(ctx, f->sv, (int)m));
-      MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), sub_stride));
+      MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), subs));
       ++n_enq;
     }
     // rank 0's state decides for everyone (it is the same state on every rank by construction: identical inputs,
@@ -1909,23 +1923,25 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
       const SolverState ps = *f->h_state;
       if (!ps.f_valid || !objective_can_keep_f(f->n, f->n_wg)) {
         // no per-row f to weight the cells with: resume with the preconditioner we have
-        MLN_TRY(launch_solver_resume(ctx, f->sv, init.gate_full, 0));
+        MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0));
       } else {
-        double *zt = nullptr, *gz = nullptr;
-        MLN_HIP(ctx, mln_dmalloc((void**)&zt, sizeof(double) * 2 * (size_t)f->ldl));
-        gz = zt + f->ldl;
-        MLN_HIP(ctx, hipMemsetAsync(zt, 0, sizeof(double) * 2 * (size_t)f->ldl, ctx->stream));
-        // old variable -> z-space:  z = C^-T u,  g_z = C g_u
+        double *zt = nullptr, *gz = nullptr, *cz = nullptr;
+        MLN_HIP(ctx, mln_dmalloc((void**)&zt, sizeof(double) * 3 * (size_t)f->ldl));
+        gz = zt + f->ldl; cz = gz + f->ldl;
+        MLN_HIP(ctx, hipMemsetAsync(zt, 0, sizeof(double) * 3 * (size_t)f->ldl, ctx->stream));
+        // old variable -> z-space:  z = C^-T u,  g_z = C g_u  (and the surrogate's correction c, a gradient in u, likewise)
         int rc = fit_small_gemv(f, f->Cinv, 1, f->sv.u, zt);
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 0, f->sv.g, gz);
+        if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->C, 0, f->sv.c, cz);
         if (rc == MLN_OK) rc = fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m);
         // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 1, zt, f->sv.u);
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, gz, f->sv.g);
+        if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->Cinv, 0, cz, f->sv.c);
         (void)hipStreamSynchronize(ctx->stream);
         (void)mln_dfree(zt);
         MLN_TRY(rc);
-        MLN_TRY(launch_solver_resume(ctx, f->sv, init.gate_full, 1));
+        MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1));
         if (const char* ev = std::getenv("MELLON_AMD_RESUME_T0")) {     // experiment: first trial step under the new preconditioner
           const double t0v = std::atof(ev);
           MLN_HIP(ctx, hipMemcpyAsync(&f->sv.st->t0, &t0v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1947,16 +1963,20 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     tr.resize((size_t)4 * n_done);
     MLN_HIP(ctx, hipMemcpy(tr.data(), f->sv.trace, sizeof(double) * 4 * n_done, hipMemcpyDeviceToHost));
     for (int i = 0; i < n_done && timing && 3 * (i + 1) <= (int)f->evs.size(); ++i) {
-      const bool was32 = ((int)tr[4 * i + 3] & 3) == MLN_GATE_F32, was_sub = (int)tr[4 * i + 3] == MLN_GATE_SUB;
+      const int gcode = (int)tr[4 * i + 3] & 15, lvl = (int)tr[4 * i + 3] >> 4;
+      const bool was32 = (gcode & 3) == MLN_GATE_F32, was_sub = gcode == MLN_GATE_SUB;
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, f->evs[3 * i + (was32 ? 0 : 1)], f->evs[3 * i + (was32 ? 1 : 2)]) != hipSuccess) continue;
-      if (was_sub) { f->times_sub += 1e-3 * ms; f->evals_sub += 1; }
+      if (was_sub) {
+        f->times_sub += 1e-3 * ms; f->evals_sub += 1;
+        f->sub_pass_equiv += 1.0 / (double)((lvl >= 0 && lvl < (int)sub_strides.size()) ? sub_strides[lvl] : 1);
+      }
       else if (was32) { f->times32 += 1e-3 * ms; f->evals32 += 1; }
       else { f->times[5] += 1e-3 * ms; f->times[6] += 1.0; f->times[7] = (double)f->n * (double)f->ldl * 8.0; }
     }
     if (trace_lvl >= 2)
       for (int i = 0; i < n_done; ++i)
-        fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, (int)tr[4 * i + 3] == MLN_GATE_F32 ? "f32" : ((int)tr[4 * i + 3] == MLN_GATE_F32C ? "f32c" : ((int)tr[4 * i + 3] == MLN_GATE_SUB ? "sub" : "f64")),
+        fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, ((int)tr[4 * i + 3] & 15) == MLN_GATE_F32 ? "f32" : (((int)tr[4 * i + 3] & 15) == MLN_GATE_F32C ? "f32c" : (((int)tr[4 * i + 3] & 15) == MLN_GATE_SUB ? (((int)tr[4 * i + 3] >> 4) ? "sub1" : "sub0") : "f64")),
                 (int)tr[4 * i + 2], tr[4 * i + 1], tr[4 * i]);
   }
   // z = C^-T u and w = P u at the accepted point (one stacked product), remembered for transform / predictor weights
@@ -1971,7 +1991,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (st.f_valid && objective_can_keep_f(f->n, f->n_wg) && !std::getenv("MELLON_AMD_NO_FKEEP")) f->f_final = st.f_slot;   // f = L z + mu at this z is already there (mln_transform)
   if (trace_lvl)
     fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the 32-bit copy, %d on the row subsample of stride %lld), %d iterations, "
-            "%d rebuild(s), %d enqueued, status %d\n", st.n_eval, st.n_eval32, st.n_eval_sub, (long long)sub_stride, st.it,
+            "%d rebuild(s), %d enqueued, status %d\n", st.n_eval, st.n_eval32, st.n_eval_sub, (long long)(subs ? sub_strides[0] : 0), st.it,
             f->n_rebuild, n_enq, st.status);
   if (loss_out) *loss_out = st.fx;
   if (n_eval_out) *n_eval_out = st.n_eval;
@@ -2035,7 +2055,7 @@ extern "C" int mln_stage_times(mln_fit* f, double* out) {
   out[15] = f->times_rebuild;                           // second preconditioner: wall seconds (selection, Gram, factorisation)
   out[16] = (double)f->n_rebuild;
   // passes over the n x m buffer in full-fp64-pass equivalents (bytes streamed / bytes of one fp64 pass)
-  out[17] = f->times[6] + 0.5 * (double)f->evals32 + (double)f->evals_sub / out[14];
+  out[17] = f->times[6] + 0.5 * (double)f->evals32 + f->sub_pass_equiv;
   return MLN_OK;
 }
 

@@ -22,7 +22,9 @@ struct ObjArgs {
   int gate_want;          //   MLN_GATE_F64 / MLN_GATE_F32 select the streamed copy, MLN_GATE_DONE stops everything)
   int64_t row_stride;     // > 1: the pass covers the rows row_first + i * row_stride, i < n (n = their number), of the
   int64_t row_first;      //   buffer and of V / Vdr / weights -- the subsample objective of the solver's first phase
-  double out_scale;       // != 0: factor applied to the reduced loss / gradient sums (row_stride for that objective)
+  double out_scale;       // != 0: factor applied to this launch's loss / gradient partials (row_stride for that objective)
+  const int* gate2;       // second condition of a gated launch: no-op unless *gate2 == gate2_want (the solver's subsample
+  int gate2_want;         //   LEVEL: one strided launch per level is enqueued, the state picks which one works)
   int64_t seg_cols;       // > 0: L points at a segment of seg_cols columns of a wider matrix (row pitch ldl): m > 8192
   int64_t seg_left;       //      ... and this many (padded) columns remain in the row from that pointer
   int f_accum;            // f_out mode: add this segment's dot products to what f_out already holds

@@ -158,6 +158,7 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
 template <int CPT, int R, int MODE, bool KEEP = false>
 __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   if (a.gate && (*a.gate & 3) != a.gate_want) return;   // uniform: the device-resident solver chose the other copy / is done
+  if (a.gate2 && *a.gate2 != a.gate2_want) return;      //          ... or another subsample level
   __shared__ double red[2][8][R];
   const int tid = threadIdx.x;
   const int64_t ld2 = a.ldl / 2;
@@ -212,10 +213,11 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   if (MODE != MODE_FONLY) {
     double* pg = a.part_grad + (int64_t)blockIdx.x * a.m_pad;
     const int64_t store_lim = a.seg_cols > 0 ? ((a.seg_cols + 1) & ~(int64_t)1) : a.m_pad;   // a segment only writes its own columns
+    const double osc = a.out_scale != 0.0 ? a.out_scale : 1.0;   // subsample passes: the sums stand for row_stride x as many cells
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int64_t col = 2 * ((int64_t)c * WG + tid);
-      if (col < store_lim) *reinterpret_cast<d2*>(pg + col) = g[c];
+      if (col < store_lim) *reinterpret_cast<d2*>(pg + col) = (d2){g[c].x * osc, g[c].y * osc};
     }
     if (MODE == MODE_OBJ_HESS) {
       double* ph = a.part_hess + (int64_t)blockIdx.x * a.m_pad;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
         if (col < a.m_pad) *reinterpret_cast<d2*>(ph + col) = h[c];
       }
     }
-    if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss;
+    if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss * osc;
   }
 }
 
@@ -336,6 +338,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
 template <int CQ, int R, bool GEMVT = false, bool KEEP = false, int NW = 8, bool FIXED = false>
 __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   if (a.gate && (*a.gate & 3) != a.gate_want) return;
+  if (a.gate2 && *a.gate2 != a.gate2_want) return;
   constexpr int WG = 64 * NW;
   __shared__ double red[2][NW][R];
   const int tid = threadIdx.x;
@@ -385,12 +388,12 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   for (int c = 0; c < CQ; ++c) {
     const int64_t col = 4 * ((int64_t)c * WG + tid);
     if (col < a.m_pad) {   // m_pad is a multiple of 16
-      constexpr double sc = FIXED ? 0x1p-32 : 1.0;
+      const double sc = (FIXED ? 0x1p-32 : 1.0) * (a.out_scale != 0.0 ? a.out_scale : 1.0);
       *reinterpret_cast<d2*>(pg + col) = (d2){g[c][0] * sc, g[c][1] * sc};
       *reinterpret_cast<d2*>(pg + col + 2) = (d2){g[c][2] * sc, g[c][3] * sc};
     }
   }
-  if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss;
+  if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss * (a.out_scale != 0.0 ? a.out_scale : 1.0);
 }
 
 template <int CQ, int R, int NW>
@@ -457,9 +460,8 @@ __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restric
     double gs = 0.0, hs = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { gs += red[0][q][c]; hs += red[1][q][c]; }
-    const double sc = (a.out_scale != 0.0 && (!a.gate || *a.gate == MLN_GATE_SUB)) ? a.out_scale : 1.0;   // subsample passes: the sums stand for row_stride x as many cells
-    out_grad[j] = gs * sc;
-    if (with_hess) out_grad[a.m + j] = hs * sc;
+    out_grad[j] = gs;
+    if (with_hess) out_grad[a.m + j] = hs;
   }
   if (blockIdx.x == 0 && threadIdx.x < 64) {   // the loss partials: one wave, fixed shuffle tree
     double l = 0.0;
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restric
       for (int w = threadIdx.x; w < a.n_wg; w += 64) l += a.part_loss[w];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-    if (threadIdx.x == 0) out_loss[0] = l * ((a.out_scale != 0.0 && (!a.gate || *a.gate == MLN_GATE_SUB)) ? a.out_scale : 1.0);
+    if (threadIdx.x == 0) out_loss[0] = l;
   }
 }
 

@@ -33,7 +33,9 @@ struct SolverState {
   // (gate_full) at the same point once its progress per iteration falls below sub_tol.
   double sub_tol;
   int gate_full;            // MLN_GATE_F64, or MLN_GATE_F32 when a 32-bit copy exists
-  int n_eval_sub;           // evaluations on the subsample so far
+  int n_eval_sub;           // evaluations on the subsamples so far
+  int sub_level, n_sub_levels;   // ... which of the (nested, ever larger) subsamples the SUB gate currently means
+  int rebuild_at_switch;    // pause for the preconditioner rebuild right after the first full evaluation that follows the subsamples
   // Preconditioner rebuild: with rebuild_armed set by the host, the solver PAUSES (gate = MLN_GATE_PAUSE) after an
   // accepted fp64 iteration whose progress has fallen below rebuild_tol; the host then re-factors the preconditioner
   // from the a-weighted importance sample at that point (api.hip fit_rebuild_precond), re-expresses u and g in the new
@@ -41,6 +43,7 @@ struct SolverState {
   int rebuild_armed;
   int it_full;              // accepted iterations on the full objective
   int resume_keep_pairs;    // MLN_SOLVE_RESUME: the curvature pairs are still valid (no new variable)
+  int gate_after_pause;     // the copy the solve continues on once the host resumes it
   double rebuild_tol;
 };
 

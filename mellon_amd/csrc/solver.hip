@@ -114,7 +114,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     fn += block_sum(cu, red) + st->corr_k;
   }
   int mode = st->mode, it = st->it, n_eval = st->n_eval + (resume ? 0 : 1), n_eval32 = st->n_eval32 + ((phase32 && !resume) ? 1 : 0);
-  int n_eval_sub = st->n_eval_sub + ((phaseS && !resume) ? 1 : 0), it_full = st->it_full;
+  int n_eval_sub = st->n_eval_sub + ((phaseS && !resume) ? 1 : 0), it_full = st->it_full, sub_level = st->sub_level;
+  bool next_level = false;
   int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
   double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k, t0 = st->t0, cap = st->cap;
   bool recap = false;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   int f_slot = st->f_slot, f_valid = st->f_valid, corr = st->corr, n_anchor = st->n_anchor;
   if (b.trace && tid == 0 && !resume) {
     double* tr = b.trace + 4 * ((n_eval - 1) & 511);
-    tr[0] = fn; tr[1] = (mode == MLN_SOLVE_LS) ? t : 0.0; tr[2] = (double)mode; tr[3] = (double)gate;
+    tr[0] = fn; tr[1] = (mode == MLN_SOLVE_LS) ? t : 0.0; tr[2] = (double)mode; tr[3] = (double)(gate + 16 * st->sub_level);
   }
   bool to_head = false, reeval = false, done = false, verify = false, pause = false;
   if (resume) {
@@ -155,7 +156,11 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     f_slot ^= 1; f_valid = approx ? 0 : 1;   // the rows' f of this pass belong to the accepted point
 #pragma unroll
     for (int e = 0; e < EPT; ++e) g[e] = gn[e];
-    to_head = true;
+    // first full fp64 evaluation after the subsample levels: the weights a = e^{f+V} of EVERY cell are on the table and the
+    // point is close to the optimum -- the moment for the second preconditioner
+    if (mode == MLN_SOLVE_REEVAL && !approx && st->rebuild_armed && st->rebuild_at_switch && st->n_eval_sub > 0 && it_full == 0) pause = true;
+    else if (mode == MLN_SOLVE_REEVAL && !approx && st->rebuild_armed && corr && n_anchor == 1 && st->use_corr) pause = true;   // the early anchor of the mixed solve
+    else to_head = true;
   } else {
     ++ls;
     const bool ok = isfinite(fn) && fn <= fx + 1e-4 * t * gd;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       for (int e = 0; e < EPT; ++e) { u[e] = un[e]; g[e] = gn[e]; }
       fx = fn;
       f_slot ^= 1; f_valid = approx ? 0 : 1;
-      if (!approx) ++it_full;
+      if (!phaseS) ++it_full;
       if (sy > 1e-10 * sqrt(ss * yy)) {   // keep the pair (SPD update)
         int slot;
         if (k < st->maxcor) { slot = (head + k) % st->maxcor; ++k; }
@@ -214,10 +219,12 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       if (phaseS) {
         // the subsample objective has done its job once its own progress per iteration is small: same point, full objective
         // (not before a few iterations: the very first step from the Ridge start is a cautious t = 1 / |g|_1)
-        if (it >= 4 && (f_old - fx) <= st->sub_tol * fscale) reeval = true; else to_head = true;
+        if (it >= 4 && (f_old - fx) <= st->sub_tol * fscale) { reeval = true; next_level = true; } else to_head = true;
       } else if (st->rebuild_armed && !phase32 && it_full >= 2 && (f_old - fx) <= st->rebuild_tol * fscale &&
                  (f_old - fx) > st->ftol * fscale) {
         pause = true;                    // the host rebuilds the preconditioner from the weights a = e^{f+V} at THIS point
+      } else if (phaseA && st->rebuild_armed && it_full >= 2 && (f_old - fx) <= st->rebuild_tol * fscale) {
+        reeval = true;                   // mixed precision: the rebuild needs the rows' f -- anchor in fp64 HERE, then pause (below)
       } else if (phaseA) {
         // the plain 32-bit objective is a smooth surrogate whose optimum sits ~1e-9 (fixed point; fp32: ~5e-5) in
         // relative loss from the true one: once its progress per iteration falls below ftol32, evaluate in fp64 at
@@ -235,9 +242,9 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       // This is the relative-decrease test of the accepted branch applied to the rejected trial: converged.
       // (phase C with f_valid: the accepted point IS the last fp64 evaluation -- nothing has been accepted since -- so
       //  its loss, gradient and rows' f are already fp64: no second verification of the same point)
-      if (approx && !(phaseC && f_valid)) reeval = true; else { status = 0; done = true; }
+      if (approx && !(phaseC && f_valid)) { reeval = true; next_level = phaseS; } else { status = 0; done = true; }
     } else if (ls >= st->maxls) {
-      if (approx && !(phaseC && f_valid)) reeval = true;   // the surrogate is exhausted: continue in fp64 from the accepted point
+      if (approx && !(phaseC && f_valid)) { reeval = true; next_level = phaseS; }   // the surrogate is exhausted: continue in fp64 from the accepted point
       else { status = phaseC ? 0 : 2; done = true; }
     } else {
       if (isfinite(fn)) {
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     for (int e = 0; e < EPT; ++e) gm = fmax(gm, fabs(g[e]));
     gm = block_max(gm, red);
     if (!(gm > st->gtol)) {
-      if (approx) reeval = true; else { status = 0; done = true; }
+      if (approx) { reeval = true; next_level = phaseS; } else { status = 0; done = true; }
     } else if (it >= st->maxiter) {
       status = 1; done = true;
     } else {
@@ -337,7 +344,9 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   }
   if (reeval) {           // same point, fp64 buffer: refreshes fx and g, keeps the curvature pairs
     cap = __builtin_inf();   // (a surrogate left while still capped: everything from here on is the true objective)
-    gate = phaseS ? st->gate_full : MLN_GATE_F64;     // (after the subsample: the full objective, on its 32-bit copy if there is one)
+    // after a subsample: the next, larger one -- or, after the last, the full objective (on its 32-bit copy if there is one)
+    if (phaseS && next_level && sub_level + 1 < st->n_sub_levels) { ++sub_level; gate = MLN_GATE_SUB; }
+    else gate = phaseS ? st->gate_full : MLN_GATE_F64;
     mode = MLN_SOLVE_REEVAL;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) un[e] = u[e];
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) un[e] = u[e];
   }
-  if (pause) gate = MLN_GATE_PAUSE;
+  if (pause) { if (tid == 0) st->gate_after_pause = gate; gate = MLN_GATE_PAUSE; }
   if (done) gate = MLN_GATE_DONE;
 #pragma unroll
   for (int e = 0; e < EPT; ++e)
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     st->ls = ls; st->k = k; st->head = head; st->fx = fx; st->t = t; st->gd = gd;
     st->f_slot = f_slot; st->f_valid = f_valid;
     st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k; st->t0 = t0; st->cap = cap;
-    st->n_eval_sub = n_eval_sub; st->it_full = it_full;
+    st->n_eval_sub = n_eval_sub; st->it_full = it_full; st->sub_level = sub_level;
     if (pause) st->rebuild_armed = 0;    // once per solve
   }
 }
