@@ -936,7 +936,15 @@ extern "C" int mln_fit_gram_rank(mln_fit* f, double tol, int64_t* rank_out, doub
   const int64_t m = f->m, ld = f->ldl;
   double* G = nullptr;
   MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * (size_t)m * ld));
-  int rc = f->kspace ? fit_gram(f, G, ld, 1) : gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld);
+  // With more than 24 cells per landmark the count is taken from the Gram of ~12 m evenly spaced cells (by global index,
+  // scaled by the stride; the integer Gram of the preconditioner where the covariance is bounded): the diagnostic only
+  // compares the count with 80 % of m (base_model.py:344-355), and the full fp64 Gram is n m^2 flops -- 0.5 s at C3.
+  const int n_ranks = ctx->n_ranks > 1 ? ctx->n_ranks : 1;
+  const int64_t n_est = f->n * n_ranks;
+  int64_t stride = 1;
+  static const bool sampled_ok = !(std::getenv("MELLON_AMD_RANK_SAMPLED") && std::atoi(std::getenv("MELLON_AMD_RANK_SAMPLED")) == 0);
+  if (sampled_ok && f->kspace && n_est >= 24 * m) stride = std::max<int64_t>(1, n_est / (12 * m));
+  int rc = f->kspace ? fit_gram(f, G, ld, stride) : gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld);
   double lmax = 0.0;
   if (rc == MLN_OK) rc = dev_sym_rank_above(ctx, G, m, ld, tol * tol, rank_out, &lmax);
   (void)hipStreamSynchronize(ctx->stream);
@@ -1902,6 +1910,9 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   };
   MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), subs));
   ++n_enq;
+  // evaluation t of the solver's trace ran in enqueue slot t + shift: the chains left in a batch after a pause are
+  // no-ops that use up slots (their events time nothing)
+  std::vector<std::pair<int, int>> slot_shift;      // (first trace index, shift)
   int batch = 8;
   if (const char* ev = std::getenv("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
   const int64_t hard_cap = (int64_t)o.maxiter * o.maxls + 16;
@@ -1950,6 +1961,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
       }
       MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
       f->times_rebuild += now_s() - tr0;
+      slot_shift.push_back({ps.n_eval, n_enq - ps.n_eval});
       continue;
     }
     if (n_enq > hard_cap) { mln_set_error(ctx, "map_solve: the device solver did not terminate"); return MLN_ERR_NOCONV; }
@@ -1962,11 +1974,14 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (n_done > 0) {
     tr.resize((size_t)4 * n_done);
     MLN_HIP(ctx, hipMemcpy(tr.data(), f->sv.trace, sizeof(double) * 4 * n_done, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n_done && timing && 3 * (i + 1) <= (int)f->evs.size(); ++i) {
+    for (int i = 0; i < n_done && timing; ++i) {
       const int gcode = (int)tr[4 * i + 3] & 15, lvl = (int)tr[4 * i + 3] >> 4;
       const bool was32 = (gcode & 3) == MLN_GATE_F32, was_sub = gcode == MLN_GATE_SUB;
+      int slot = i;
+      for (const auto& sh : slot_shift) if (i >= sh.first) slot = i + sh.second;
+      if (3 * (slot + 1) > (int)f->evs.size()) continue;
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, f->evs[3 * i + (was32 ? 0 : 1)], f->evs[3 * i + (was32 ? 1 : 2)]) != hipSuccess) continue;
+      if (hipEventElapsedTime(&ms, f->evs[3 * slot + (was32 ? 0 : 1)], f->evs[3 * slot + (was32 ? 1 : 2)]) != hipSuccess) continue;
       if (was_sub) {
         f->times_sub += 1e-3 * ms; f->evals_sub += 1;
         f->sub_pass_equiv += 1.0 / (double)((lvl >= 0 && lvl < (int)sub_strides.size()) ? sub_strides[lvl] : 1);

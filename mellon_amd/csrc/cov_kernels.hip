@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "mln_internal.h"
+#include "rowmin_f16.h"
 #include "cov_program.h"
 #include "cov_rows.h"
 #include "cov_rows_q.h"
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256) void k_nn_distances(const double* __restrict__
                                                       const double* __restrict__ y, int64_t m, int d,
                                                       const double* __restrict__ xx,
                                                       const double* __restrict__ yy, int64_t self_offset,
-                                                      double* __restrict__ out) {
+                                                      const int64_t* __restrict__ excl, double* __restrict__ out) {
   __shared__ double xs[DK][TM + PADT];
   __shared__ double ys[DK][TN + PADT];
   __shared__ double red[TM][17];
@@ -762,7 +763,8 @@ __global__ __launch_bounds__(256) void k_nn_distances(const double* __restrict__
       for (int i = 0; i < 4; ++i) {
         const int64_t r = row0 + ty * 4 + i;
         const double sq = fmax(xr[i] - 2.0 * acc[i][j] + yj, 0.0);
-        if (c < m && c != r + self_offset) best[i] = fmin(best[i], sq);
+        const int64_t skip = (excl && r < n) ? excl[r] : r + self_offset;
+        if (c < m && c != skip) best[i] = fmin(best[i], sq);
       }
     }
   }
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
                                                            const double* __restrict__ y, int64_t m, int d,
                                                            const double* __restrict__ xx,
                                                            const double* __restrict__ yy, int64_t self_offset,
-                                                           double* __restrict__ out) {
+                                                           const int64_t* __restrict__ excl, double* __restrict__ out) {
   __shared__ double ys[2][TN * NNS];
   __shared__ double yn[2][TN];
   const int tid = threadIdx.x;
@@ -806,10 +808,12 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
     }
   }
   double xr[4], best[4];
+  int64_t ex[4];        // the candidate that does not count for each of this lane's rows
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + lk + 4 * r;
     xr[r] = (row < n) ? xx[row] : 0.0;
+    ex[r] = (excl && row < n) ? excl[row] : row + self_offset;
     best[r] = INFINITY;
   }
   for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;   // zero incl. the k padding
@@ -845,9 +849,8 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
       const double yc = yn[buf][16 * t + li];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = row0 + lk + 4 * r;
         const double sq = fmax(xr[r] - 2.0 * acc[t][r] + yc, 0.0);
-        if (c < m && c != row + self_offset) best[r] = fmin(best[r], sq);
+        if (c < m && c != ex[r]) best[r] = fmin(best[r], sq);
       }
     }
     __syncthreads();
@@ -998,11 +1001,11 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   return MLN_OK;
 }
 
-int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
-                        int64_t self_offset, double* out) {
+int launch_nn_distances_exact(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                              int64_t self_offset, const int64_t* excl, double* out) {
   if (n == 0) return MLN_OK;
   double* norms = nullptr;
-  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)(n + m), (void**)&norms));
+  MLN_HIP(ctx, mln_dmalloc((void**)&norms, sizeof(double) * (size_t)(n + m)));
   double* xx = norms;
   double* yy = norms + n;
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, d, xx);
@@ -1010,12 +1013,27 @@ int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* 
   static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
   if (d <= 64 && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_nn_distances_mfma, dim3((unsigned)((n + 127) / 128)), dim3(512), 0, ctx->stream, x, n, y, m, d,
-                       xx, yy, self_offset, out);
+                       xx, yy, self_offset, excl, out);
   else
     hipLaunchKernelGGL(k_nn_distances, dim3((unsigned)((n + TM - 1) / TM)), dim3(256), 0, ctx->stream, x, n, y, m, d,
-                       xx, yy, self_offset, out);
-  MLN_HIP(ctx, hipGetLastError());
+                       xx, yy, self_offset, excl, out);
+  hipError_t e = hipGetLastError();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(norms);
+  if (e != hipSuccess) return mln_hip_fail(ctx, e, "nn_distances", __FILE__, __LINE__);
   return MLN_OK;
+}
+
+// Exact nearest-neighbour distances.  Large searches (d <= 64) go through the fp16 pre-filter with fp64 certification
+// (rowmin_f16.hip): same result, a fraction of the time.  MELLON_AMD_NN_PREFILTER=0 forces the plain fp64 search.
+int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                        int64_t self_offset, double* out) {
+  if (n == 0) return MLN_OK;
+  static const bool prefilter = !(std::getenv("MELLON_AMD_NN_PREFILTER") && std::atoi(std::getenv("MELLON_AMD_NN_PREFILTER")) == 0);
+  static const int64_t min_pairs = std::getenv("MELLON_AMD_NN_PREFILTER_MIN") ? std::atoll(std::getenv("MELLON_AMD_NN_PREFILTER_MIN")) : ((int64_t)1 << 26);
+  if (prefilter && d <= 64 && m >= 2 && n * m >= min_pairs && m < 2147483647LL)
+    return nn_distances_prefiltered(ctx, x, n, y, m, d, self_offset, out, nullptr);
+  return launch_nn_distances_exact(ctx, x, n, y, m, d, self_offset, nullptr, out);
 }
 
 int launch_cov_diag(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, double* out) {

@@ -1,0 +1,17 @@
+// fp16-split row minimum (rowmin_f16.hip): pre-filter of the exact 1-NN search, assignment step of k-means.
+#pragma once
+#include "mln_core.h"
+
+size_t rowmin_split_bytes(int64_t rows);   // device bytes of the split (hi | lo halves) copy of `rows` rows
+// x (n x d doubles, d <= 64) -> split rows, squared norms in fp64 (xx, may be null) and rounded to fp32 (xxf, may be null)
+int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf);
+// per row i of xs: m1 = min_j (yyf_j - 2 x_i.y_j), arg = its j, m2 = the second smallest (null: not tracked);
+// exclude_self: the pair (i, i + self_offset) does not count
+int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
+                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg);
+// exact nearest-neighbour distances via the pre-filter + fp64 certification (+ exact re-search of uncertified rows)
+int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                             int64_t self_offset, double* out, double* stats);
+// the exact fp64 search (cov_kernels.hip); excl (optional, device): the excluded candidate of each row
+int launch_nn_distances_exact(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                              int64_t self_offset, const int64_t* excl, double* out);

@@ -1,0 +1,314 @@
+// Row-wise nearest candidate on the fp16 matrix cores, with a rigorous error bound: the pre-filter of the exact 1-NN
+// search (parameters.py:352-433: the reference's nearest-neighbour distances) and the assignment step of k-means
+// (parameters.py:243-291).
+//
+// The exact search is 2 n m d fp64 flops on the fp64 matrix pipe (78 TFLOP/s: 2.3 s at 1e6 x 1e6 x 50).  The fp16
+// pipe is 30x faster, and a double split into two halves, x = hi + lo (hi = half(x), lo = half(x - hi)), carries 21-22
+// bits: the three products hi.hi + hi.lo + lo.hi, accumulated in fp32, give  s_ij = |y_j|^2 - 2 x_i.y_j  with an
+// error that can be BOUNDED, per row, by a small multiple of 2^-18 |x_i| max_j |y_j|.  One sweep keeps, per query row,
+// the smallest and the second-smallest approximate value and the arg of the smallest.  The caller then evaluates the
+// winner exactly in fp64; if the runner-up's approximate value minus the bound still exceeds it, no other candidate
+// can be closer -- the row is CERTIFIED and its distance is the exact fp64 one.  The few rows that are not (2nd
+// neighbour within the bound: ~1 % at C3) are re-searched by the exact fp64 kernel.  The result is the exact
+// nearest-neighbour distance for every row; only the time changes.
+//
+// Kernel shape: 8 waves x 32 query rows per workgroup; every wave keeps the MFMA A operands of its rows (4 k-steps x
+// {hi, lo}) in registers for the whole sweep; candidate tiles (128 rows x 64 k x {hi, lo} halves = 32 KB) go through LDS
+// once per workgroup, double buffered, row pitch 272 B (conflict-free 16-byte reads).  v_mfma_f32_32x32x16_f16: both
+// operands are "k-contiguous rows" read with the same lane -> k map, so the k order inside the instruction is irrelevant.
+#include <cmath>
+#include <vector>
+
+#include "mln_internal.h"
+#include "rowmin_f16.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int KP = 64;               // padded feature count (d <= 64)
+constexpr int ROWH = 2 * KP;         // halves per split row: hi[0..63] | lo[0..63]
+constexpr int RT = 128;              // candidates per stage
+constexpr int PITCH = 272;           // LDS bytes per candidate row (256 + 16)
+
+// x (n x d doubles) -> split rows (n x 128 halves, zero padded), squared norms (fp64) and their fp32 roundings
+__global__ __launch_bounds__(256) void k_split_f16(const double* __restrict__ x, int64_t n, int d, _Float16* __restrict__ out,
+                                                   double* __restrict__ xx, float* __restrict__ xxf) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int k = threadIdx.x & 63;
+  if (row >= n) return;
+  double v = (k < d) ? x[row * d + k] : 0.0;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)(v - (double)hi);
+  out[row * ROWH + k] = hi;
+  out[row * ROWH + KP + k] = lo;
+  double s = v * v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (k == 0) { if (xx) xx[row] = s; if (xxf) xxf[row] = (float)s; }
+}
+
+__global__ void k_max_norm(const double* __restrict__ xx, int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double m = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmax(m, xx[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// TOP2: also the second-smallest value per row (1-NN certification); else only the arg of the smallest (k-means labels)
+template <bool TOP2>
+__global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict__ Xs, int64_t n,
+                                                      const _Float16* __restrict__ Ys, int64_t m,
+                                                      const float* __restrict__ yyf, int64_t self_offset, int exclude_self,
+                                                      float* __restrict__ out_m1, float* __restrict__ out_m2,
+                                                      int* __restrict__ out_arg) {
+  extern __shared__ unsigned char lds[];                      // 2 x (RT x PITCH) candidate rows + 2 x RT norms
+  float* ynl = reinterpret_cast<float*>(lds + 2 * RT * PITCH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lg = lane >> 5;
+  const int64_t row0w = (int64_t)blockIdx.x * 256 + wave * 32;
+  // A operands: this wave's 32 rows, k = 16 ks + 8 lg + e
+  h8 ahi[4], alo[4];
+  {
+    const int64_t ar = (row0w + lr < n) ? row0w + lr : n - 1;
+    const _Float16* src = Xs + ar * ROWH + 8 * lg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ahi[ks] = *reinterpret_cast<const h8*>(src + 16 * ks);
+      alo[ks] = *reinterpret_cast<const h8*>(src + KP + 16 * ks);
+    }
+  }
+  float m1[16], m2[16];
+  int a1[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { m1[r] = INFINITY; m2[r] = INFINITY; a1[r] = 0; }
+
+  // staging: 128 rows x 256 B = 2048 16-byte pieces per stage, 4 per thread
+  v4i st[4];
+  float stn = 0.f;
+  auto g_load = [&](int64_t col0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = tid + 512 * q, r = piece >> 4, seg = piece & 15;
+      const int64_t c = col0 + r;
+      st[q] = (c < m) ? *reinterpret_cast<const v4i*>(Ys + c * ROWH + seg * 8) : v4i{0, 0, 0, 0};
+    }
+    if (tid < RT) stn = (col0 + tid < m) ? yyf[col0 + tid] : INFINITY;
+  };
+  auto l_store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = tid + 512 * q, r = piece >> 4, seg = piece & 15;
+      *reinterpret_cast<v4i*>(lds + buf * (RT * PITCH) + r * PITCH + seg * 16) = st[q];
+    }
+    if (tid < RT) ynl[buf * RT + tid] = stn;
+  };
+  g_load(0);
+  l_store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t col0 = 0; col0 < m; col0 += RT, buf ^= 1) {
+    const bool more = col0 + RT < m;
+    if (more) g_load(col0 + RT);
+    const unsigned char* base = lds + buf * (RT * PITCH);
+#pragma unroll
+    for (int sub = 0; sub < RT / 32; ++sub) {
+      f16v hh, cx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hh[r] = 0.f; cx[r] = 0.f; }
+      const unsigned char* brow = base + (sub * 32 + lr) * PITCH + 16 * lg;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const h8 bhi = *reinterpret_cast<const h8*>(brow + 32 * ks);
+        const h8 blo = *reinterpret_cast<const h8*>(brow + 2 * KP + 32 * ks);
+        hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi, hh, 0, 0, 0);
+        cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo, cx, 0, 0, 0);
+        cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi, cx, 0, 0, 0);
+      }
+      const float yc = ynl[buf * RT + sub * 32 + lr];
+      const int col = (int)(col0 + sub * 32 + lr);
+      // the excluded pair (i, i + self_offset) can only sit in a tile that meets this wave's diagonal band
+      const int64_t lo_c = col0 + sub * 32, d0 = row0w + self_offset;
+      const bool diag = exclude_self && lo_c < d0 + 32 && lo_c + 32 > d0;
+      if (!diag) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float s = fmaf(-2.f, hh[r] + cx[r], yc);
+          if (TOP2) m2[r] = fminf(m2[r], fmaxf(m1[r], s));
+          a1[r] = (s < m1[r]) ? col : a1[r];
+          m1[r] = fminf(m1[r], s);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0w + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          float s = fmaf(-2.f, hh[r] + cx[r], yc);
+          if ((int64_t)col == row + self_offset) s = INFINITY;
+          if (TOP2) m2[r] = fminf(m2[r], fmaxf(m1[r], s));
+          a1[r] = (s < m1[r]) ? col : a1[r];
+          m1[r] = fminf(m1[r], s);
+        }
+      }
+    }
+    if (more) l_store(buf ^ 1);
+    __syncthreads();
+  }
+  // merge the 32 column-lanes of each row (lanes with the same lg hold the same rows)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const float o1 = __shfl_xor(m1[r], off, 64), o2 = __shfl_xor(m2[r], off, 64);
+      const int oa = __shfl_xor(a1[r], off, 64);
+      if (TOP2) m2[r] = fminf(fmaxf(m1[r], o1), fminf(m2[r], o2));
+      // ties go to the smaller candidate index: the result does not depend on the lane order of the merge
+      const bool take = (o1 < m1[r]) || (o1 == m1[r] && oa < a1[r]);
+      a1[r] = take ? oa : a1[r];
+      m1[r] = fminf(m1[r], o1);
+    }
+    const int64_t row = row0w + (r & 3) + 8 * (r >> 2) + 4 * lg;
+    if (lr == 0 && row < n) {
+      out_m1[row] = m1[r];
+      if (TOP2) out_m2[row] = m2[r];
+      out_arg[row] = a1[r];
+    }
+  }
+}
+
+// Exact fp64 value of the winner, certification against the runner-up, list of the rows that need the exact search.
+//   s_j = |y_j|^2 - 2 x.y_j (exact);  |s~_j - s_j| <= E_i for every j  =>  j* != arg implies s_{j*} >= m2~ - E_i.
+__global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x, int64_t n, const double* __restrict__ y, int d,
+                                                    const double* __restrict__ xx, const double* __restrict__ yy,
+                                                    const float* __restrict__ m2, const int* __restrict__ arg,
+                                                    const double* __restrict__ yy_max, double* __restrict__ out,
+                                                    int* __restrict__ n_flag, int* __restrict__ flagged) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t j = arg[i];
+  double dot = 0.0;
+  for (int k = 0; k < d; ++k) dot = fma(x[i * d + k], y[j * d + k], dot);
+  const double s = yy[j] - 2.0 * dot;
+  const double xn = sqrt(xx[i]), yn = sqrt(yy_max[0]);
+  // dropped split terms 2^-19, fp32 accumulation of the 64 hi.hi terms (80 u) and of the 128 cross terms (2^-10 of
+  // them), the fp32 epilogue (|y|^2 rounded to fp32, one fma), half-precision subnormals of tiny coordinates; x 1.5
+  const double u = 5.9604644775390625e-08;   // 2^-24
+  const double rel = 1.9073486328125e-06 + 80.0 * u + 160.0 * u * 9.765625e-04;
+  const double E = 1.5 * (2.0 * rel * xn * yn + 4.0 * u * (yn * yn + 2.0 * xn * yn) + 4.8e-07 * (xn + yn) + 1e-300);
+  const bool certified = ((double)m2[i] - E) > s;
+  out[i] = sqrt(fmax(xx[i] + s, 0.0));
+  if (!certified) {
+    const int slot = atomicAdd(n_flag, 1);
+    flagged[slot] = (int)i;
+  }
+}
+
+__global__ void k_gather_rows_excl(const double* __restrict__ x, int d, const int* __restrict__ idx, int cnt,
+                                   int64_t self_offset, double* __restrict__ xg, int64_t* __restrict__ excl) {
+  const int r = blockIdx.x;
+  if (r >= cnt) return;
+  const int64_t i = idx[r];
+  for (int k = threadIdx.x; k < d; k += blockDim.x) xg[(int64_t)r * d + k] = x[i * d + k];
+  if (threadIdx.x == 0) excl[r] = i + self_offset;
+}
+
+__global__ void k_scatter_rows(const double* __restrict__ vals, const int* __restrict__ idx, int cnt, double* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < cnt) out[idx[r]] = vals[r];
+}
+
+}  // namespace
+
+size_t rowmin_split_bytes(int64_t rows) { return sizeof(_Float16) * (size_t)rows * ROWH; }
+
+int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf) {
+  if (n <= 0) return MLN_OK;
+  if (d > KP) { mln_set_error(ctx, "split_f16: more than 64 features"); return MLN_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL(k_split_f16, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, x, n, d,
+                     reinterpret_cast<_Float16*>(split), xx, xxf);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
+                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg) {
+  if (n <= 0 || m <= 0) return MLN_OK;
+  if (m > 2147483647LL) { mln_set_error(ctx, "rowmin: too many candidates"); return MLN_ERR_UNSUPPORTED; }
+  const size_t lds_bytes = (size_t)2 * RT * PITCH + 2 * RT * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_f16x3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_f16x3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr = true;
+  }
+  const dim3 grid((unsigned)((n + 255) / 256)), block(512);
+  if (m2)
+    hipLaunchKernelGGL(k_rowmin_f16x3<true>, grid, block, lds_bytes, ctx->stream, reinterpret_cast<const _Float16*>(xs), n,
+                       reinterpret_cast<const _Float16*>(ys), m, yyf, self_offset, exclude_self, m1, m2, arg);
+  else
+    hipLaunchKernelGGL(k_rowmin_f16x3<false>, grid, block, lds_bytes, ctx->stream, reinterpret_cast<const _Float16*>(xs), n,
+                       reinterpret_cast<const _Float16*>(ys), m, yyf, self_offset, exclude_self, m1, nullptr, arg);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+// Exact 1-NN distances through the fp16 pre-filter (see the head of this file).  x: n x d, y: m x d (device), d <= 64.
+// stats (optional, host): [0] rows re-searched exactly.
+int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                             int64_t self_offset, double* out, double* stats) {
+  const bool same = (x == y && n == m);
+  void *xs = nullptr, *ys = nullptr;
+  double *xx = nullptr, *yy = nullptr, *ymax = nullptr;
+  float *yyf = nullptr, *m1 = nullptr, *m2 = nullptr;
+  int *arg = nullptr, *nflag = nullptr, *flagged = nullptr;
+  std::vector<void*> owned;
+  auto alloc = [&](void** p, size_t bytes) -> bool {
+    if (mln_dmalloc(p, bytes > 0 ? bytes : 8) != hipSuccess) return false;
+    owned.push_back(*p);
+    return true;
+  };
+  auto cleanup = [&](int rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : owned) (void)mln_dfree(p);
+    return rc;
+  };
+  bool ok = alloc(&xs, rowmin_split_bytes(n)) && alloc((void**)&xx, sizeof(double) * n) &&
+            alloc((void**)&m1, sizeof(float) * n) && alloc((void**)&m2, sizeof(float) * n) &&
+            alloc((void**)&arg, sizeof(int) * n) && alloc((void**)&nflag, sizeof(int)) &&
+            alloc((void**)&flagged, sizeof(int) * n) && alloc((void**)&ymax, sizeof(double)) &&
+            alloc((void**)&yyf, sizeof(float) * m);
+  if (ok && !same) ok = alloc(&ys, rowmin_split_bytes(m)) && alloc((void**)&yy, sizeof(double) * m);
+  if (!ok) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+  int rc = launch_split_f16(ctx, x, n, d, xs, xx, same ? yyf : nullptr);
+  if (rc == MLN_OK && !same) rc = launch_split_f16(ctx, y, m, d, ys, yy, yyf);
+  if (same) { ys = xs; yy = xx; }
+  if (rc != MLN_OK) return cleanup(rc);
+  hipLaunchKernelGGL(k_max_norm, dim3(1), dim3(256), 0, ctx->stream, yy, m, ymax);
+  if (hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+  rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg);
+  if (rc != MLN_OK) return cleanup(rc);
+  hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, d, xx, yy, m2, arg,
+                     ymax, out, nflag, flagged);
+  int cnt = 0;
+  if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
+  if (stats) stats[0] = (double)cnt;
+  if (cnt > 0) {
+    // the uncertified rows: exact fp64 search, each with its own excluded candidate
+    double *xg = nullptr, *og = nullptr;
+    int64_t* excl = nullptr;
+    if (!alloc((void**)&xg, sizeof(double) * (size_t)cnt * d) || !alloc((void**)&og, sizeof(double) * cnt) ||
+        !alloc((void**)&excl, sizeof(int64_t) * cnt)) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+    hipLaunchKernelGGL(k_gather_rows_excl, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, x, d, flagged, cnt, self_offset, xg, excl);
+    rc = launch_nn_distances_exact(ctx, xg, cnt, y, m, d, 0, excl, og);
+    if (rc != MLN_OK) return cleanup(rc);
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, og, flagged, cnt, out);
+  }
+  if (hipGetLastError() != hipSuccess) return cleanup(MLN_ERR_HIP);
+  return cleanup(MLN_OK);
+}

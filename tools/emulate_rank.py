@@ -26,6 +26,8 @@ class OneOfN(distributed.Communicator):
         return 0, int(n_local) * self.n_ranks
 
 
+if os.environ.get("MIXED", "0") == "0":
+    os.environ["MELLON_AMD_MIXED"] = "0"          # the headline mode: float64 throughout
 ctx = _lib.default_context()
 n, d, m = 1_000_000, 50, 5000
 x = bench.gaussian_mixture(n, d, 3)
@@ -57,7 +59,10 @@ for N in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
                    "objective_kernels_ms": 1e3 * (st["objective_kernel_s"] + st["objective32_kernel_s"]),
                    "fp32_pass_ms": 1e3 * st["objective32_kernel_s"] / max(n32, 1), "fp64_pass_ms": 1e3 * st["objective_kernel_s"] / max(n64, 1),
                    "kernel_matrix_ms": 1e3 * st["kernel_matrix_s"], "chol_Lp_ms": 1e3 * st["cholesky_s"],
-                   "gram_and_solves_ms": 1e3 * st["ridge_gram_s"], "chol_C_inverses_ms": 1e3 * st["ridge_solve_s"]}
+                   "gram_and_solves_ms": 1e3 * st["ridge_gram_s"], "chol_C_inverses_ms": 1e3 * st["ridge_solve_s"],
+                   "sub_passes_ms": 1e3 * st["objective_sub_kernel_s"], "sub_evaluations": st["objective_sub_launches"],
+                   "rebuild_ms": 1e3 * st["precond_rebuild_s"], "rebuilds": st["precond_rebuilds"],
+                   "full_pass_equivalents": st["objective_pass_equivalents"], "fp64_launches": n64, "launches_32bit": n32}
     xs.free()
     gc.collect()
 distributed.set_current(distributed.Communicator())
