@@ -70,6 +70,115 @@ __global__ void k_seed_pick(const double* __restrict__ mind, int64_t n, int64_t 
   *out = pick;
 }
 
+// The same update from the half-precision copy of the cells (rowmin_f16.hip split rows, hi halves: one 128-byte line per
+// cell instead of 400 bytes): D^2 only weights the k-means++ draw, three significant digits are plenty, and the 5000
+// sequential updates of a 1e6-cell seeding are pure memory traffic.  scale: the copy holds scale * x.
+__global__ __launch_bounds__(256) void k_seed_update_h(const _Float16* __restrict__ xh, int64_t n, int d, float inv_scale,
+                                                       const double* __restrict__ c, double* __restrict__ mind,
+                                                       double* __restrict__ bsum, int first) {
+  __shared__ float cs[64];
+  __shared__ double red[256];
+  for (int k = threadIdx.x; k < 64; k += 256) cs[k] = (k < d) ? (float)c[k] : 0.f;
+  __syncthreads();
+  typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+  const int64_t base = (int64_t)blockIdx.x * SBLK;
+  double acc = 0.0;
+  const int dk = (d + 7) / 8;
+  for (int q = 0; q < SBLK / 256; ++q) {
+    const int64_t i = base + q * 256 + threadIdx.x;
+    if (i < n) {
+      const h8_t* row = reinterpret_cast<const h8_t*>(xh + i * 128);
+      float s = 0.f;
+      for (int g = 0; g < dk; ++g) {
+        const h8_t v = row[g];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 8 * g + e;
+          const float t = (k < d) ? (float)v[e] * inv_scale - cs[k] : 0.f;
+          s = fmaf(t, t, s);
+        }
+      }
+      double sd = (double)s;
+      if (!first) sd = fmin(sd, mind[i]);
+      mind[i] = sd;
+      acc += sd;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
+}
+
+// One k-means++ draw on the device (no host round trip per centre): total of the block sums, the block and then the cell
+// where the running sum of D^2 passes u * total -- the same sequential sums the host used to form -- and the cell's
+// coordinates copied into the next centre's slot.  u: this step's uniform draw (the whole sequence is uploaded once).
+__global__ __launch_bounds__(256) void k_seed_select(const double* __restrict__ bsum, int64_t nblk, const double* __restrict__ mind,
+                                                     int64_t n, double u, const double* __restrict__ x, int d,
+                                                     double* __restrict__ c_next) {
+  __shared__ double part[256];
+  __shared__ int64_t chosen, blk;
+  __shared__ double tgt;
+  const int t = threadIdx.x;
+  // level 1: which block of SBLK cells.  Thread t sums its run of block sums, thread 0 walks the 256 partial sums, the
+  // owner of the run walks its few entries: fixed order, no atomics -- the same draw in every run.
+  const int64_t per = (nblk + 255) / 256;
+  const int64_t b0 = t * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+  double ps = 0.0;
+  for (int64_t b = b0; b < b1; ++b) ps += bsum[b];
+  part[t] = ps;
+  __syncthreads();
+  if (t == 0) {
+    double total = 0.0;
+    for (int q = 0; q < 256; ++q) total += part[q];
+    blk = -1; chosen = 0;
+    if (!(total > 0.0)) {                      // all cells coincide with centres: any cell will do
+      const int64_t cur = (int64_t)(u * (double)n);
+      chosen = cur >= n ? n - 1 : cur;
+    } else {
+      double target = u * total;
+      int q = 0;
+      for (; q < 255; ++q) { if (target < part[q]) break; target -= part[q]; }
+      int64_t b = (int64_t)q * per;
+      const int64_t bend = (b + per < nblk) ? b + per : nblk;
+      if (b >= nblk) b = nblk - 1;
+      for (; b + 1 < bend; ++b) { if (target < bsum[b]) break; target -= bsum[b]; }
+      blk = b; tgt = target;
+    }
+  }
+  __syncthreads();
+  if (blk >= 0) {
+    // level 2: which cell of the block, the same way (4 cells per thread)
+    const int64_t lo = blk * SBLK, hi = (lo + SBLK < n) ? lo + SBLK : n;
+    constexpr int CPT = SBLK / 256;
+    double v[CPT], ls = 0.0;
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) { const int64_t i = lo + t * CPT + e; v[e] = (i < hi) ? mind[i] : 0.0; ls += v[e]; }
+    __syncthreads();
+    part[t] = ls;
+    __syncthreads();
+    if (t == 0) {
+      double target = tgt;
+      int q = 0;
+      for (; q < 255; ++q) { if (!(target >= part[q])) break; target -= part[q]; }
+      blk = q; tgt = target;                    // (reused: the owning thread and what is left of the target)
+    }
+    __syncthreads();
+    if (t == (int)blk) {
+      double run = 0.0;
+      int64_t pick = lo + t * CPT + CPT - 1;
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) { run += v[e]; if (run > tgt) { pick = lo + t * CPT + e; break; } }
+      chosen = pick < hi ? pick : hi - 1;
+    }
+    __syncthreads();
+  }
+  for (int k = t; k < d; k += 256) c_next[k] = x[chosen * d + k];
+}
+
 // label[i] = argmin_j |x_i - c_j|^2 (ties: smallest j)
 __global__ __launch_bounds__(256) void k_assign(const double* __restrict__ x, int64_t n,
                                                 const double* __restrict__ c, int64_t m, int d,
@@ -302,26 +411,29 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "kmeans", __FILE__, __LINE__); };
 
   // ---- k-means++ seeding ------------------------------------------------------------------------
+  // m - 1 sequential draws, each after one update of every cell's distance to its nearest centre so far.  Everything stays
+  // on the device (the uniform draws are uploaded once); large problems read the half-precision copy of the cells.
   XorShift rng((unsigned long long)seed);
-  std::vector<double> hb((size_t)nblk);
   int64_t cur = (int64_t)(rng.uniform() * (double)n);
   if (cur >= n) cur = n - 1;
-  for (int64_t j = 0; j < m && rc == MLN_OK; ++j) {
-    chk(hipMemcpyAsync(dc + j * d, dx + cur * d, sizeof(double) * d, hipMemcpyDeviceToDevice, st));
-    if (j + 1 == m) break;
-    hipLaunchKernelGGL(k_seed_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
-    chk(hipMemcpyAsync(hb.data(), bsum, sizeof(double) * (size_t)nblk, hipMemcpyDeviceToHost, st));
-    chk(hipStreamSynchronize(st));
-    double total = 0.0;
-    for (double v : hb) total += v;
-    if (!(total > 0.0)) { cur = (int64_t)(rng.uniform() * (double)n) % n; continue; }   // all cells coincide with centres
-    double target = rng.uniform() * total;
-    int64_t b = 0;
-    for (; b + 1 < nblk; ++b) { if (target < hb[(size_t)b]) break; target -= hb[(size_t)b]; }
-    hipLaunchKernelGGL(k_seed_pick, dim3(1), dim3(64), 0, st, mind, n, b, target, pick);
-    chk(hipMemcpyAsync(&cur, pick, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    chk(hipStreamSynchronize(st));
+  static const bool km_fp16_seed = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
+  const bool seed_h = km_fp16_seed && d <= 61 && n * m >= ((int64_t)1 << 24) && m >= 2;
+  void* xsplit = nullptr;
+  if (seed_h && rc == MLN_OK) {
+    chk(mln_dmalloc(&xsplit, rowmin_split_bytes(n)));
+    if (rc == MLN_OK) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, 1);   // role 1: -2 x (also the Lloyd sweeps' operand)
   }
+  if (rc == MLN_OK) chk(hipMemcpyAsync(dc, dx + cur * d, sizeof(double) * d, hipMemcpyDeviceToDevice, st));
+  for (int64_t j = 0; j + 1 < m && rc == MLN_OK; ++j) {
+    if (seed_h)
+      hipLaunchKernelGGL(k_seed_update_h, dim3((unsigned)nblk), dim3(256), 0, st, reinterpret_cast<const _Float16*>(xsplit), n, d,
+                         -0.5f, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
+    else
+      hipLaunchKernelGGL(k_seed_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_seed_select, dim3(1), dim3(256), 0, st, bsum, nblk, mind, n, rng.uniform(), dx, d, dc + (j + 1) * d);
+    if ((j & 1023) == 1023) chk(hipStreamSynchronize(st));     // (bounds the launch queue)
+  }
+  chk(hipGetLastError());
 
   // ---- Lloyd ------------------------------------------------------------------------------------------
   // tolerance scaled like sklearn: tol * mean over features of the feature variance
@@ -352,20 +464,22 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   // 5e11 fp64 flops per sweep at 1e6 cells x 5000 centres (15 ms) become ~1 ms.  MELLON_AMD_KM_FP16=0 disables.
   static const bool km_fp16 = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
   const bool fast_assign = km_fp16 && d <= 64 && n * m >= ((int64_t)1 << 24) && m >= 2;
-  void *xsplit = nullptr, *csplit = nullptr;
+  const bool km_fold = d <= 61;
+  void* csplit = nullptr;
   float *ccf = nullptr, *m1f = nullptr;
   if (fast_assign && rc == MLN_OK) {
-    chk(mln_dmalloc(&xsplit, rowmin_split_bytes(n)));
+    const bool have = xsplit != nullptr;       // (the seeding's copy has role 1: right for the folded product)
+    if (!have) chk(mln_dmalloc(&xsplit, rowmin_split_bytes(n)));
     chk(mln_dmalloc(&csplit, rowmin_split_bytes(m)));
     chk(mln_dmalloc((void**)&ccf, sizeof(float) * (size_t)m));
     chk(mln_dmalloc((void**)&m1f, sizeof(float) * (size_t)n));
-    if (rc == MLN_OK) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr);
+    if (rc == MLN_OK && !have) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, km_fold ? 1 : 0);
   }
   for (; it < max_iter && rc == MLN_OK; ++it) {
     hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);
     if (fast_assign) {
-      rc = launch_split_f16(ctx, dc, m, d, csplit, nullptr, ccf);
-      if (rc == MLN_OK) rc = launch_rowmin_f16x3(ctx, xsplit, n, csplit, m, ccf, 0, 0, m1f, nullptr, label);
+      rc = launch_split_f16(ctx, dc, m, d, csplit, nullptr, ccf, km_fold ? 2 : 0);
+      if (rc == MLN_OK) rc = launch_rowmin_f16x3(ctx, xsplit, n, csplit, m, ccf, 0, 0, m1f, nullptr, label, km_fold ? 1 : 0);
       if (rc != MLN_OK) break;
     } else if (d <= 64 && n * m >= 4096)
       hipLaunchKernelGGL(k_assign_mfma, dim3((unsigned)((n + 127) / 128)), dim3(512), 0, st, dx, n, dc, m, d, xx, cc, label, mind);

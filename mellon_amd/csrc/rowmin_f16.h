@@ -4,11 +4,16 @@
 
 size_t rowmin_split_bytes(int64_t rows);   // device bytes of the split (hi | lo halves) copy of `rows` rows
 // x (n x d doubles, d <= 64) -> split rows, squared norms in fp64 (xx, may be null) and rounded to fp32 (xxf, may be null)
-int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf);
+// role 0: plain rows; 1: query rows of the folded product (coordinates x -2, ones in three spare slots); 2: candidate rows of
+// it (|y|^2 as three halves in those slots) -- roles 1 / 2 need d <= 61
+int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf, int role);
 // per row i of xs: m1 = min_j (yyf_j - 2 x_i.y_j), arg = its j, m2 = the second smallest (null: not tracked);
 // exclude_self: the pair (i, i + self_offset) does not count
+// fold: operands split with roles 1 / 2; arg is then the first of four candidates arg + {0, 32, 64, 96} (launch_resolve_labels
+// picks the closest in fp64)
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
-                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg);
+                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold);
+int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg);
 // exact nearest-neighbour distances via the pre-filter + fp64 certification (+ exact re-search of uncertified rows)
 int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
                              int64_t self_offset, double* out, double* stats);

@@ -33,20 +33,32 @@ constexpr int ROWH = 2 * KP;         // halves per split row: hi[0..63] | lo[0..
 constexpr int RT = 128;              // candidates per stage
 constexpr int PITCH = 272;           // LDS bytes per candidate row (256 + 16)
 
-// x (n x d doubles) -> split rows (n x 128 halves, zero padded), squared norms (fp64) and their fp32 roundings
+// x (n x d doubles) -> split rows (n x 128 halves, zero padded), squared norms (fp64) and their fp32 roundings.
+// role 1 (query rows): the coordinates are stored times -2 (exact in binary) and the three spare k slots d, d+1, d+2 of
+// the hi half hold 1;  role 2 (candidate rows): those slots hold |y|^2 as three halves (hi + mid + lo, 33 bits) -- the
+// matrix product of a query and a candidate row is then  |y|^2 - 2 x.y  itself, no epilogue arithmetic.  Needs d <= 61.
 __global__ __launch_bounds__(256) void k_split_f16(const double* __restrict__ x, int64_t n, int d, _Float16* __restrict__ out,
-                                                   double* __restrict__ xx, float* __restrict__ xxf) {
+                                                   double* __restrict__ xx, float* __restrict__ xxf, int role) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int k = threadIdx.x & 63;
   if (row >= n) return;
-  double v = (k < d) ? x[row * d + k] : 0.0;
-  const _Float16 hi = (_Float16)v;
-  const _Float16 lo = (_Float16)(v - (double)hi);
-  out[row * ROWH + k] = hi;
-  out[row * ROWH + KP + k] = lo;
-  double s = v * v;
+  const double v0 = (k < d) ? x[row * d + k] : 0.0;
+  double s = v0 * v0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  double v = (role == 1) ? -2.0 * v0 : v0;
+  _Float16 hi = (_Float16)v;
+  _Float16 lo = (_Float16)(v - (double)hi);
+  if (role == 1 && k >= d && k < d + 3) { hi = (_Float16)1.0f; lo = (_Float16)0.0f; }
+  if (role == 2 && k >= d && k < d + 3) {
+    const _Float16 n0 = (_Float16)s;
+    const _Float16 n1 = (_Float16)(s - (double)n0);
+    const _Float16 n2 = (_Float16)(s - (double)n0 - (double)n1);
+    hi = (k == d) ? n0 : (k == d + 1 ? n1 : n2);
+    lo = (_Float16)0.0f;
+  }
+  out[row * ROWH + k] = hi;
+  out[row * ROWH + KP + k] = lo;
   if (k == 0) { if (xx) xx[row] = s; if (xxf) xxf[row] = (float)s; }
 }
 
@@ -61,8 +73,12 @@ __global__ void k_max_norm(const double* __restrict__ xx, int64_t n, double* __r
   if (threadIdx.x == 0) out[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-// TOP2: also the second-smallest value per row (1-NN certification); else only the arg of the smallest (k-means labels)
-template <bool TOP2>
+// TOP2: also the second-smallest value per row (1-NN certification); else only the arg of the smallest (k-means labels).
+// FOLD: the operands carry -2 and |y|^2 (k_split_f16 roles 1 / 2): the accumulator IS the value, and the epilogue is two
+// VALU instructions per element (v_med3_f32 keeps the runner-up, v_min_f32 the winner).  With TOP2 the winner's column is
+// then only known per STAGE of 128 candidates and lane: out_arg = the stage's first candidate of that lane, the winner is
+// one of out_arg + {0, 32, 64, 96}; without TOP2 (labels) the exact column is tracked (three instructions per element).  (With the full 7-instruction epilogue the sweep took 510 ms at 1e6 x 1e6: VALU-bound.)
+template <bool TOP2, bool FOLD>
 __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict__ Xs, int64_t n,
                                                       const _Float16* __restrict__ Ys, int64_t m,
                                                       const float* __restrict__ yyf, int64_t self_offset, int exclude_self,
@@ -117,6 +133,72 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
     const bool more = col0 + RT < m;
     if (more) g_load(col0 + RT);
     const unsigned char* base = lds + buf * (RT * PITCH);
+    if (FOLD) {
+      float m1_in[16];
+      if (TOP2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m1_in[r] = m1[r];
+      }
+      // two sub-tiles at a time, their MFMA chains interleaved: an accumulator is only touched every other instruction
+      // (a chain of dependent 32x32 MFMAs runs at their 64-cycle latency, not at the 32-cycle issue rate)
+#pragma unroll
+      for (int sp = 0; sp < RT / 64; ++sp) {
+        f16v acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        const unsigned char* brow0 = base + (sp * 64 + lr) * PITCH + 16 * lg;
+        const unsigned char* brow1 = brow0 + 32 * PITCH;
+        h8 bhi0[4], bhi1[4];
+        // the small cross terms first, the hi.hi terms on top: the fp32 roundings that matter are those of the last four
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          bhi0[ks] = *reinterpret_cast<const h8*>(brow0 + 32 * ks);
+          bhi1[ks] = *reinterpret_cast<const h8*>(brow1 + 32 * ks);
+          const h8 blo0 = *reinterpret_cast<const h8*>(brow0 + 2 * KP + 32 * ks);
+          const h8 blo1 = *reinterpret_cast<const h8*>(brow1 + 2 * KP + 32 * ks);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo1, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi0[ks], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi1[ks], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi0[ks], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi1[ks], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int sub = 2 * sp + h;
+          // fast path: every candidate of the stage exists and none is the excluded one -- two instructions per element
+          const int64_t lo_c = col0 + sub * 32, d0 = row0w + self_offset;
+          const bool diag = exclude_self && lo_c < d0 + 32 && lo_c + 32 > d0;
+          const int col = (int)(col0 + sub * 32 + lr);
+          if (!diag && col0 + RT <= m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              if (TOP2) m2[r] = __builtin_amdgcn_fmed3f(m1[r], m2[r], acc[h][r]);
+              else a1[r] = (acc[h][r] < m1[r]) ? col : a1[r];          // (labels: the exact column, three instructions)
+              m1[r] = fminf(m1[r], acc[h][r]);
+            }
+          } else {
+            const bool valid = col < m;                            // (a padded candidate row is all zero: value 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int64_t row = row0w + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              const float sv = (valid && !(exclude_self && (int64_t)col == row + self_offset)) ? acc[h][r] : INFINITY;
+              if (TOP2) m2[r] = __builtin_amdgcn_fmed3f(m1[r], m2[r], sv);
+              else a1[r] = (sv < m1[r]) ? col : a1[r];
+              m1[r] = fminf(m1[r], sv);
+            }
+          }
+        }
+      }
+      if (TOP2) {
+        const int stage_col = (int)(col0 + lr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a1[r] = (m1[r] < m1_in[r]) ? stage_col : a1[r];
+      }
+    } else
 #pragma unroll
     for (int sub = 0; sub < RT / 32; ++sub) {
       f16v hh, cx;
@@ -183,29 +265,55 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
 
 // Exact fp64 value of the winner, certification against the runner-up, list of the rows that need the exact search.
 //   s_j = |y_j|^2 - 2 x.y_j (exact);  |s~_j - s_j| <= E_i for every j  =>  j* != arg implies s_{j*} >= m2~ - E_i.
-__global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x, int64_t n, const double* __restrict__ y, int d,
+// fold: the winner is one of arg + {0, 32, 64, 96} (k_rowmin_f16x3 FOLD): all four are evaluated exactly.
+__global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x, int64_t n, const double* __restrict__ y, int64_t m, int d,
                                                     const double* __restrict__ xx, const double* __restrict__ yy,
                                                     const float* __restrict__ m2, const int* __restrict__ arg,
-                                                    const double* __restrict__ yy_max, double* __restrict__ out,
-                                                    int* __restrict__ n_flag, int* __restrict__ flagged) {
+                                                    const double* __restrict__ yy_max, int fold, int64_t self_offset,
+                                                    double* __restrict__ out, int* __restrict__ n_flag, int* __restrict__ flagged) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int64_t j = arg[i];
-  double dot = 0.0;
-  for (int k = 0; k < d; ++k) dot = fma(x[i * d + k], y[j * d + k], dot);
-  const double s = yy[j] - 2.0 * dot;
+  double s = INFINITY;
+  for (int q = 0; q < (fold ? 4 : 1); ++q) {
+    const int64_t j = (int64_t)arg[i] + 32 * q;
+    if (j >= m || j == i + self_offset) continue;
+    double dot = 0.0;
+    for (int k = 0; k < d; ++k) dot = fma(x[i * d + k], y[j * d + k], dot);
+    s = fmin(s, yy[j] - 2.0 * dot);
+  }
   const double xn = sqrt(xx[i]), yn = sqrt(yy_max[0]);
-  // dropped split terms 2^-19, fp32 accumulation of the 64 hi.hi terms (80 u) and of the 128 cross terms (2^-10 of
-  // them), the fp32 epilogue (|y|^2 rounded to fp32, one fma), half-precision subnormals of tiny coordinates; x 1.5
+  // The value the sweep compares is |y|^2 - 2 x.y from three half-precision products (hi.hi + hi.lo + lo.hi) accumulated in
+  // fp32.  Dropped terms of the split: 2^-19 of 2 |x| |y|; fp32 accumulation: <= 17 roundings per MFMA x 4 MFMAs + slack
+  // = 80 u on the magnitudes of the hi.hi terms (2 |x| |y| + |y|^2), 160 u on the 2^-10 smaller cross terms; |y|^2 in
+  // fp32 (plain) or as three halves (fold); half-precision subnormals of tiny coordinates (2^-24 each, 64 of them).
   const double u = 5.9604644775390625e-08;   // 2^-24
-  const double rel = 1.9073486328125e-06 + 80.0 * u + 160.0 * u * 9.765625e-04;
-  const double E = 1.5 * (2.0 * rel * xn * yn + 4.0 * u * (yn * yn + 2.0 * xn * yn) + 4.8e-07 * (xn + yn) + 1e-300);
+  const double mag = 2.0 * xn * yn + yn * yn;
+  const double E = 1.25 * (1.9073486328125e-06 * 2.0 * xn * yn + 80.0 * u * mag + 160.0 * u * 9.765625e-04 * mag +
+                           4.0 * u * mag + 64.0 * u * 2.0 * (2.0 * xn + yn) + 1e-300);
   const bool certified = ((double)m2[i] - E) > s;
   out[i] = sqrt(fmax(xx[i] + s, 0.0));
   if (!certified) {
     const int slot = atomicAdd(n_flag, 1);
     flagged[slot] = (int)i;
   }
+}
+
+// labels from the fold variant's stage-level args: the closest of the four candidates, in fp64
+__global__ __launch_bounds__(256) void k_resolve_labels(const double* __restrict__ x, int64_t n, const double* __restrict__ y, int64_t m,
+                                                        int d, const double* __restrict__ yy, int* __restrict__ arg) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double best = INFINITY;
+  int bj = arg[i];
+  for (int q = 0; q < 4; ++q) {
+    const int64_t j = (int64_t)arg[i] + 32 * q;
+    if (j >= m) continue;
+    double dot = 0.0;
+    for (int k = 0; k < d; ++k) dot = fma(x[i * d + k], y[j * d + k], dot);
+    const double sv = yy[j] - 2.0 * dot;
+    if (sv < best) { best = sv; bj = (int)j; }
+  }
+  arg[i] = bj;
 }
 
 __global__ void k_gather_rows_excl(const double* __restrict__ x, int d, const int* __restrict__ idx, int cnt,
@@ -226,33 +334,41 @@ __global__ void k_scatter_rows(const double* __restrict__ vals, const int* __res
 
 size_t rowmin_split_bytes(int64_t rows) { return sizeof(_Float16) * (size_t)rows * ROWH; }
 
-int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf) {
+int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf, int role) {
   if (n <= 0) return MLN_OK;
-  if (d > KP) { mln_set_error(ctx, "split_f16: more than 64 features"); return MLN_ERR_UNSUPPORTED; }
+  if (d > KP || (role != 0 && d > KP - 3)) { mln_set_error(ctx, "split_f16: too many features"); return MLN_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL(k_split_f16, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, x, n, d,
-                     reinterpret_cast<_Float16*>(split), xx, xxf);
+                     reinterpret_cast<_Float16*>(split), xx, xxf, role);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
 
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
-                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg) {
+                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold) {
   if (n <= 0 || m <= 0) return MLN_OK;
   if (m > 2147483647LL) { mln_set_error(ctx, "rowmin: too many candidates"); return MLN_ERR_UNSUPPORTED; }
   const size_t lds_bytes = (size_t)2 * RT * PITCH + 2 * RT * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_f16x3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_f16x3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const void* fns[] = {reinterpret_cast<const void*>(k_rowmin_f16x3<true, false>), reinterpret_cast<const void*>(k_rowmin_f16x3<false, false>),
+                         reinterpret_cast<const void*>(k_rowmin_f16x3<true, true>), reinterpret_cast<const void*>(k_rowmin_f16x3<false, true>)};
+    for (const void* fn : fns) MLN_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr = true;
   }
   const dim3 grid((unsigned)((n + 255) / 256)), block(512);
-  if (m2)
-    hipLaunchKernelGGL(k_rowmin_f16x3<true>, grid, block, lds_bytes, ctx->stream, reinterpret_cast<const _Float16*>(xs), n,
-                       reinterpret_cast<const _Float16*>(ys), m, yyf, self_offset, exclude_self, m1, m2, arg);
-  else
-    hipLaunchKernelGGL(k_rowmin_f16x3<false>, grid, block, lds_bytes, ctx->stream, reinterpret_cast<const _Float16*>(xs), n,
-                       reinterpret_cast<const _Float16*>(ys), m, yyf, self_offset, exclude_self, m1, nullptr, arg);
+  const _Float16* X = reinterpret_cast<const _Float16*>(xs);
+  const _Float16* Y = reinterpret_cast<const _Float16*>(ys);
+  if (m2 && fold) hipLaunchKernelGGL((k_rowmin_f16x3<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg);
+  else if (m2) hipLaunchKernelGGL((k_rowmin_f16x3<true, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg);
+  else if (fold) hipLaunchKernelGGL((k_rowmin_f16x3<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg);
+  else hipLaunchKernelGGL((k_rowmin_f16x3<false, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg) {
+  if (n <= 0) return MLN_OK;
+  hipLaunchKernelGGL(k_resolve_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, yy, arg);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -277,23 +393,27 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
     for (void* p : owned) (void)mln_dfree(p);
     return rc;
   };
+  const int fold = (d <= KP - 3) ? 1 : 0;       // (three spare k slots carry |y|^2)
+  const bool share = same && !fold;             // without folding, queries and candidates are the same split copy
   bool ok = alloc(&xs, rowmin_split_bytes(n)) && alloc((void**)&xx, sizeof(double) * n) &&
             alloc((void**)&m1, sizeof(float) * n) && alloc((void**)&m2, sizeof(float) * n) &&
             alloc((void**)&arg, sizeof(int) * n) && alloc((void**)&nflag, sizeof(int)) &&
             alloc((void**)&flagged, sizeof(int) * n) && alloc((void**)&ymax, sizeof(double)) &&
             alloc((void**)&yyf, sizeof(float) * m);
-  if (ok && !same) ok = alloc(&ys, rowmin_split_bytes(m)) && alloc((void**)&yy, sizeof(double) * m);
+  if (ok && !share) ok = alloc(&ys, rowmin_split_bytes(m));
+  if (ok && !same) ok = alloc((void**)&yy, sizeof(double) * m);
   if (!ok) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
-  int rc = launch_split_f16(ctx, x, n, d, xs, xx, same ? yyf : nullptr);
-  if (rc == MLN_OK && !same) rc = launch_split_f16(ctx, y, m, d, ys, yy, yyf);
-  if (same) { ys = xs; yy = xx; }
+  int rc = launch_split_f16(ctx, x, n, d, xs, xx, share ? yyf : nullptr, fold ? 1 : 0);
+  if (rc == MLN_OK && !share) rc = launch_split_f16(ctx, y, m, d, ys, same ? nullptr : yy, yyf, fold ? 2 : 0);
+  if (share) ys = xs;
+  if (same) yy = xx;
   if (rc != MLN_OK) return cleanup(rc);
   hipLaunchKernelGGL(k_max_norm, dim3(1), dim3(256), 0, ctx->stream, yy, m, ymax);
   if (hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
-  rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg);
+  rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold);
   if (rc != MLN_OK) return cleanup(rc);
-  hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, d, xx, yy, m2, arg,
-                     ymax, out, nflag, flagged);
+  hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
+                     ymax, fold, self_offset, out, nflag, flagged);
   int cnt = 0;
   if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
