@@ -180,6 +180,10 @@ class DeviceArray:
     def nbytes(self):
         return self.size * 8
 
+    @property
+    def ndim(self):
+        return len(self.shape)
+
     def to_host(self):
         out = np.empty(self.shape, dtype=np.float64)
         self.ctx._check(self.ctx.lib.mln_memcpy(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
@@ -419,14 +423,24 @@ class Context:
                                             B2.ctypes.data, B2.shape[1]))
         return B2.reshape(shape)
 
-    def predict_mean(self, desc, xnew, centers, W, mu):
+    def predict_mean(self, desc, xnew, centers, W, mu, out=None):
+        """mu + cov(xnew, centers) W.  out: a DeviceArray of the result's shape keeps the predictions in HBM (returned
+        as is); default: a new host array."""
         xnew = xnew if isinstance(xnew, DeviceArray) else _as2d(xnew)
         centers = centers if isinstance(centers, DeviceArray) else _as2d(centers)
         Wd = W if isinstance(W, DeviceArray) else _f64(W)
         n_new, d = xnew.shape
         m = centers.shape[0]
         p = 1 if len(Wd.shape) == 1 else Wd.shape[1]
-        out = np.empty((n_new,) if len(Wd.shape) == 1 else (n_new, p), dtype=np.float64)
+        shape = (n_new,) if len(Wd.shape) == 1 else (n_new, p)
+        if out is not None:
+            if not isinstance(out, DeviceArray) or tuple(out.shape) != shape:
+                raise ValueError(f"out must be a DeviceArray of shape {shape}")
+            _needs_program(desc, "predict_mean(out=DeviceArray)")
+            self._check(self.lib.mln_predict_mean(self.handle, desc.ref, _ptr(xnew), n_new, d, _ptr(centers), m,
+                                                  _ptr(Wd), p, float(mu), out.ptr))
+            return out
+        out = np.empty(shape, dtype=np.float64)
         if isinstance(desc, BlockEvaluatedCov):
             # mean = mu + cov(Xnew, centers) W with the kernel block from the user's k: conditional.py:366-373,651-658,899-906
             xh = xnew.to_host() if isinstance(xnew, DeviceArray) else xnew
@@ -466,18 +480,19 @@ class Context:
         _needs_program(desc, "sparse_solve")
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
-        y2 = _f64(y)
+        y2 = y if isinstance(y, DeviceArray) else _f64(y)          # (HBM-resident targets are used in place)
+        y_ndim = len(y2.shape)
         m = xu.shape[0]
-        p = 1 if y2.ndim == 1 else y2.shape[1]
-        W = np.empty((m,) if y2.ndim == 1 else (m, p), dtype=np.float64)
+        p = 1 if y_ndim == 1 else y2.shape[1]
+        W = np.empty((m,) if y_ndim == 1 else (m, p), dtype=np.float64)
         if not return_factors:
             self._check(self.lib.mln_sparse_solve(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1], _ptr(xu),
-                                                  m, y2.ctypes.data, p, float(mu), float(sigma),
+                                                  m, _ptr(y2), p, float(mu), float(sigma),
                                                   float(jitter), W.ctypes.data), jitter=jitter)
             return W
         Lp, Cs = np.empty((m, m)), np.empty((m, m))
         self._check(self.lib.mln_sparse_solve_factors(self.handle, desc.ref, _ptr(x), x.shape[0], x.shape[1],
-                                                      _ptr(xu), m, y2.ctypes.data, p, float(mu), float(sigma),
+                                                      _ptr(xu), m, _ptr(y2), p, float(mu), float(sigma),
                                                       float(jitter), W.ctypes.data, Lp.ctypes.data,
                                                       Cs.ctypes.data), jitter=jitter)
         return W, Lp, Cs

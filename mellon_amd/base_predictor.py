@@ -52,12 +52,14 @@ class Predictor:
                 "\n".join(f"    {k}: {np.shape(getattr(self, k))}" for k in sorted(self._state_variables)))
 
     # -- evaluation (conditional.py:366-373,651-658,899-906 through base_predictor.py:180-257) ------
-    def _mean(self, Xnew):
+    def _mean(self, Xnew, out=None):
         ctx = _lib.default_context()
         return ctx.predict_mean(self.cov_func.lower(self.n_input_features), Xnew, self.centers,
-                                self.weights, self.mu)
+                                self.weights, self.mu, out=out)
 
-    def mean(self, x, normalize=False):
+    def mean(self, x, normalize=False, out=None):
+        """reference base_predictor.py:180-257.  `out` (beyond the reference's signature): a _lib.DeviceArray that
+        receives the predictions in HBM -- with HBM-resident queries a batched predict then moves nothing over PCIe."""
         x = validate_array(x, "x")
         if not isinstance(x, _lib.DeviceArray):
             x = np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
@@ -71,8 +73,10 @@ class Predictor:
             if self.n_obs is None or self.n_obs == 0:
                 raise ValueError("Cannot normalize without n_obs. Please set self.n_obs to the number "
                                  "of samples/cells trained on to enable normalization.")
+            if out is not None:
+                raise ValueError("normalize=True is not combined with a device-resident output")
             return self._mean(x) - log(self.n_obs)
-        return self._mean(x)
+        return self._mean(x, out=out)
 
     __call__ = mean
 
@@ -298,6 +302,8 @@ class PredictorTime(Predictor):
     @make_multi_time_argument
     def mean(self, Xnew, time=None, normalize=False):
         Xnew = validate_array(Xnew, "Xnew")
+        if isinstance(Xnew, _lib.DeviceArray) and time is None:
+            return Predictor.mean(self, Xnew, normalize=normalize)      # HBM-resident queries [state | time]: used in place
         Xnew = np.ascontiguousarray(ensure_2d(Xnew), dtype=np.float64)
         x = validate_time_x(Xnew, time, n_features=self.n_input_features, cast_scalar=True)
         return Predictor.mean(self, np.ascontiguousarray(x), normalize=normalize)

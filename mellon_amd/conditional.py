@@ -319,10 +319,13 @@ class _LandmarksConditional:
         ctx = _lib.default_context()
         xh = x if isinstance(x, _lib.DeviceArray) else np.ascontiguousarray(ensure_2d(x), dtype=np.float64)
         xu = np.ascontiguousarray(ensure_2d(xu), dtype=np.float64)
-        yh = np.asarray(y, dtype=np.float64)
+        y_resident = isinstance(y, _lib.DeviceArray)              # targets already in HBM: scalar-sigma solve only
+        yh = y if y_resident else np.asarray(y, dtype=np.float64)
         desc = cov_func.lower(xu.shape[1])
-        per_feature = _is_per_feature_sigma(sigma, yh)
+        per_feature = False if y_resident else _is_per_feature_sigma(sigma, yh)
         vector = (not per_feature) and (not y_is_mean) and sigma is not None and np.ndim(sigma) >= 1
+        if y_resident and (vector or obs_variance or np.ndim(sigma) > 0):
+            raise NotImplementedError("device-resident targets take a scalar sigma and no observation variance")
         Lp_h = Cs_h = None
 
         def solve(target, mean, want_factors=False):

@@ -12,6 +12,7 @@
 
 #include "mln_internal.h"
 #include "rowmin_f16.h"
+#include "predict_rows_prod.h"
 #include "cov_program.h"
 #include "cov_rows.h"
 #include "cov_rows_q.h"
@@ -988,6 +989,8 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   if (contiguous && !no_mfma && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE) {
     MLN_TRY(launch_predict_mean_rows(ctx, cov, x, n, y, m, d, xx, yy, w, mu, out));
+  } else if (!no_mfma && n >= 4096 && m >= 256 && predict_rows_prod_eligible(cov, d)) {
+    MLN_TRY(launch_predict_mean_rows_prod(ctx, cov, x, n, y, m, d, xx, yy, w, mu, out));      // leaf 0's norms come first
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_predict_mean_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, w, mu, out);

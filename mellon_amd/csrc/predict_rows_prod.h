@@ -1,0 +1,7 @@
+// predict_rows_prod.hip: the persistent-row fused predictive mean for the time-sensitive product kernel (state leaf x time
+// leaf).  (Its own header: cov_rows.h is included by the slow-to-compile persistent-row translation units.)
+#pragma once
+#include "mln_core.h"
+bool predict_rows_prod_eligible(const DevCov& cov, int d);
+int launch_predict_mean_rows_prod(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y, int64_t m,
+                                  int d, const double* xx0, const double* yy0, const double* w, double mu, double* out);

@@ -334,3 +334,43 @@ def test_density_estimator_sharded_with_default_inputs(mellon):
     assert all(np.allclose(r[1], np.asarray(est1.landmarks), rtol=1e-8, atol=1e-10) for r in res)  # == the single-rank call's (threaded BLAS: not bitwise)
     assert np.allclose(np.concatenate([r[2] for r in res]), np.asarray(est1.nn_distances), rtol=1e-12, atol=0)
     assert rel_max(np.concatenate([r[0] for r in res]), dens1) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["Matern52", "Matern32", "ExpQuad", "Exponential"])
+@pytest.mark.parametrize("d_state", [5, 30, 40, 63])
+def test_product_kernel_predict_rows(mellon, ctx, kind, d_state):
+    """The fused predictive mean of the time-sensitive product kernel k(ls, :-1) * k(ls_time, -1) (parameters.py:641-644,
+    conditional.py:899-906) on its persistent-row kernel == the materialised kernel matrix times the weights, and ==
+    the oracle's kernel algebra."""
+    rng = np.random.default_rng(d_state)
+    n, m = 5000, 300
+    x = np.column_stack([rng.normal(size=(n, d_state)), rng.integers(0, 6, size=n).astype(float)])
+    c = np.column_stack([rng.normal(size=(m, d_state)), rng.integers(0, 6, size=m).astype(float)])
+    w = rng.normal(size=m)
+    ls, ls_time = 1.3 * np.sqrt(d_state), 1.7
+    K = getattr(mellon.cov, kind)
+    cov = K(ls, active_dims=slice(None, -1)) * K(ls_time, active_dims=-1)
+    ocov = getattr(mo, kind)(ls, active_dims=slice(None, -1)) * getattr(mo, kind)(ls_time, active_dims=-1)
+    got = ctx.predict_mean(cov.lower(d_state + 1), x, c, w, 0.25)
+    want = ocov(x, c) @ w + 0.25
+    assert rel_max(got, want) < 1e-11
+    assert rel_max(got, cov(x, c) @ w + 0.25) < 1e-11
+
+
+def test_function_estimator_with_resident_targets_and_predictions(mellon, ctx):
+    """C5's resident form: x, y (n x p) and the predictions as device arrays -- same numbers as the host-array call."""
+    rng = np.random.default_rng(8)
+    n, d, m, p = 3000, 6, 200, 17
+    x = mo.gaussian_mixture(n, d, seed=9)
+    y = np.sin(x @ rng.normal(size=(d, p))) + 0.1 * rng.normal(size=(n, p))
+    nn = mo.exact_nn_distances(x)
+    lm = mo.compute_landmarks(x, mo.SPARSE_CHOLESKY, m, 42)
+    host = mellon.FunctionEstimator(sigma=0.2, landmarks=lm, nn_distances=nn).fit_predict(x, y, x)
+    est = mellon.FunctionEstimator(sigma=0.2, landmarks=lm, nn_distances=nn)
+    xd, yd, out = ctx.to_device(x), ctx.to_device(y), ctx.empty((n, p))
+    est.fit(xd, yd)
+    res = est.predict(xd, out=out)
+    assert res is out
+    assert rel_max(out.to_host(), host) < 1e-12
+    with pytest.raises(ValueError):
+        est.predict(xd, out=ctx.empty((n, p + 1)))
