@@ -1944,15 +1944,49 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         int rc = fit_small_gemv(f, f->Cinv, 1, f->sv.u, zt);
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 0, f->sv.g, gz);
         if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->C, 0, f->sv.c, cz);
+        // The curvature pairs survive the change of variable u' = T u, T = C'^T C^-T:  s' = T s,  y' = T^-T y  (s'.y' = s.y).
+        // First half here (into z-space, in place), second half once the new factor exists.  Measured (five data seeds at C3):
+        // carrying them over costs 1-3 full passes MORE than starting the history afresh -- the new factor already holds
+        // the curvature the old pairs describe, relative to a metric that is gone -- so they are dropped by default
+        // (MELLON_AMD_REBUILD_KEEP_PAIRS=1 keeps them).
+        const bool keep_pairs = std::getenv("MELLON_AMD_REBUILD_KEEP_PAIRS") && std::atoi(std::getenv("MELLON_AMD_REBUILD_KEEP_PAIRS")) != 0;
+        const int n_pairs = keep_pairs ? ps.k : 0;
+        double* ptmp = zt;     // (reuses zt after z has been consumed below: see order)
+        std::vector<int> slots;
+        for (int j = 0; j < n_pairs; ++j) slots.push_back((ps.head + j) % ps.maxcor);
+        double* pbuf = nullptr;
+        if (n_pairs > 0 && rc == MLN_OK) {
+          if (mln_dmalloc((void**)&pbuf, sizeof(double) * (size_t)f->ldl) != hipSuccess) rc = MLN_ERR_HIP;
+          if (rc == MLN_OK && hipMemsetAsync(pbuf, 0, sizeof(double) * (size_t)f->ldl, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
+          for (int sl : slots) {
+            double* S = f->sv.S + (size_t)sl * f->sv.ld;
+            double* Y = f->sv.Y + (size_t)sl * f->sv.ld;
+            if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 1, S, pbuf);          // s_z = C^-T s
+            if (rc == MLN_OK && hipMemcpyAsync(S, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
+            if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 0, Y, pbuf);             // y_z = C y
+            if (rc == MLN_OK && hipMemcpyAsync(Y, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
+          }
+        }
+        (void)ptmp;
         if (rc == MLN_OK) rc = fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m);
         // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 1, zt, f->sv.u);
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, gz, f->sv.g);
         if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->Cinv, 0, cz, f->sv.c);
+        for (int sl : slots) {
+          double* S = f->sv.S + (size_t)sl * f->sv.ld;
+          double* Y = f->sv.Y + (size_t)sl * f->sv.ld;
+          if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 1, S, pbuf);               // s' = C'^T s_z
+          if (rc == MLN_OK && hipMemcpyAsync(S, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
+          if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, Y, pbuf);            // y' = C'^-1 y_z
+          if (rc == MLN_OK && hipMemcpyAsync(Y, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
+        }
+        if (rc == MLN_OK && n_pairs > 0) rc = launch_solver_refresh_pairs(ctx, f->sv, ps.maxcor);
         (void)hipStreamSynchronize(ctx->stream);
         (void)mln_dfree(zt);
+        if (pbuf) (void)mln_dfree(pbuf);
         MLN_TRY(rc);
-        MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1));
+        MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, n_pairs > 0 ? 0 : 1));
         if (const char* ev = std::getenv("MELLON_AMD_RESUME_T0")) {     // experiment: first trial step under the new preconditioner
           const double t0v = std::atof(ev);
           MLN_HIP(ctx, hipMemcpyAsync(&f->sv.st->t0, &t0v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));

@@ -66,3 +66,5 @@ int launch_solver_step(mln_ctx* ctx, const SolverBuffers& b, int m);
 // after a pause: the host has written the accepted point and its gradient in the (new) preconditioned variable into
 // b.u / b.g; the next step starts a line search from there on `gate` (pairs_dropped: the history starts over)
 int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped);
+// the stored pairs were re-expressed in a new variable by the host (S <- T S, Y <- T^-T Y): recompute y.y per slot
+int launch_solver_refresh_pairs(mln_ctx* ctx, const SolverBuffers& b, int maxcor);

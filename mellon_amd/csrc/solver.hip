@@ -380,6 +380,18 @@ __global__ void k_solver_init(SolverBuffers b, SolverState init, const double* _
   if (i == 0) *b.st = init;
 }
 
+// after the host re-expressed the stored pairs in a new variable: s.y is invariant, y.y is not
+__global__ __launch_bounds__(512) void k_solver_refresh_pairs(SolverBuffers b) {
+  __shared__ double red[ST / 64];
+  const SolverState* st = b.st;
+  const int slot = blockIdx.x;
+  if (slot >= st->maxcor) return;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < st->m; i += ST) { const double v = b.Y[slot * b.ld + i]; acc = fma(v, v, acc); }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) b.yy[slot] = acc;
+}
+
 __global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     SolverState* st = b.st;
@@ -391,6 +403,12 @@ __global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped) {
 }
 
 }  // namespace
+
+int launch_solver_refresh_pairs(mln_ctx* ctx, const SolverBuffers& b, int maxcor) {
+  hipLaunchKernelGGL(k_solver_refresh_pairs, dim3((unsigned)maxcor), dim3(ST), 0, ctx->stream, b);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
 
 int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped) {
   hipLaunchKernelGGL(k_solver_resume, dim3(1), dim3(64), 0, ctx->stream, b, gate, pairs_dropped);
