@@ -1620,7 +1620,7 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
   // z0 = (L^T L + I)^-1 L^T t = C^-T C^-1 (L^T t);  implicit mode: C^-1 L^T t = P^T (K^T t)
   // With a sampled Gram (stride s >= 4) the right-hand side is taken over the SAME cells, s L_s^T t_s: z0 is then the
   // exact Ridge solution of the subsample -- the problem the solver's first phase works on -- and costs 1/s of a pass.
-  int64_t rs = (f->precond_stride >= 4) ? f->precond_stride : 1;
+  int64_t rs = (f->precond_stride >= 11) ? f->precond_stride : 1;
   if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) rs = 1; }
   ObjArgs a = obj_args(f);
   a.weights = dt.dev;
@@ -1848,13 +1848,13 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // on the MAP problem of exactly those cells -- the Ridge matrix is ITS Hessian at a = 1 -- at 1/s of the bytes per
   // pass, and moves to all cells once that problem's progress per iteration is below sub_tol.  The walk down from the
   // Ridge start (a dozen passes) then costs about two.  MELLON_AMD_SUBSAMPLE=0 disables, MELLON_AMD_SUB_TOL moves it.
-  // Which cells: ~32 m of them (every (3 s / 8)-th cell for a Gram stride s = n / 12 m; nested levels are possible,
+  // Which cells: ~32 m of them (every (3 s / 16)-th cell for a Gram stride s = n / 6 m; nested levels are possible,
   // MELLON_AMD_SUB_LEVELS="16:8", but did not pay).  tools/solver_sweep.py, five data seeds at C3, mean step in ms:
   // no subsample 302 | stride 16: 241 | 12: 204 | 8: 203 | 6: 193 | 4: 203 | 16 then 8: 213 | 16 then 4: 215.
   // The smaller the sample, the cheaper its passes but the more its optimum overfits (at stride 16 the first full
   // evaluation finds the loss 60 % above the optimum's and e^{f+V} of unseen cells up to 1e5).
   std::vector<int64_t> sub_strides;
-  if (f->precond_stride >= 4) sub_strides.push_back(std::max<int64_t>(2, 3 * f->precond_stride / 8));
+  if (f->precond_stride >= 11) sub_strides.push_back(std::max<int64_t>(2, 3 * f->precond_stride / 16));
   if (const char* ev = std::getenv("MELLON_AMD_SUB_LEVELS")) {
     if (!sub_strides.empty()) {
       sub_strides.clear();

@@ -290,7 +290,9 @@ def _fit_of(L):
     return _lib.Fit.from_L(_lib.default_context(), np.asarray(L, dtype=np.float64))
 
 
-RIDGE_ROWS_PER_LANDMARK = 12    # measured at C3 with the mixed-precision solve: 12 m cells minimise Gram time + extra passes
+RIDGE_ROWS_PER_LANDMARK = 6     # cells of the first preconditioner's Gram per landmark (round 3, tools/solver_sweep.py, five seeds at C3:
+                                # 6 m: 192 ms, 8 m: 193, 12 m: 198, 24 m: 207 -- the subsample phase and the rebuild made the first factor's
+                                # accuracy matter less than its Gram time)
 
 
 def ridge_row_stride(n_local, m, with_offset=False):

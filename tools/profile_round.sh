@@ -1,19 +1,54 @@
-# One profiling session of the bench command on the GPU box: kernel statistics + timeline, HBM traffic counters,
-# matrix-pipe counters.  Usage (from the repo root on the box): bash tools/profile_round.sh r02
-TAG=${1:-rXX}
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B="python bench.py --cpu-sample 0 --extra-steps 0 --landmark-method device"
-O=gpurun_out/prof_$TAG
-rm -rf $O; mkdir -p $O profiles
-rocprofv3 --kernel-trace --stats -d $O/stats -o bench -- $B --steps 3 --warmup 1 > $O/stats.out 2> $O/stats.log
-grep '^{' $O/stats.out > profiles/${TAG}_bench_c3_1gpu_under_rocprof.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o bench -- $B --steps 1 --warmup 0 > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o bench -- $B --steps 1 --warmup 0 > $O/write.log 2>&1
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $O/sq -o bench -- $B --steps 1 --warmup 0 > $O/sq.log 2>&1
-S=$(find $O/stats -name "*.db" | head -1); F=$(find $O/fetch -name "*.db" | head -1); W=$(find $O/write -name "*.db" | head -1); Q=$(find $O/sq -name "*.db" | head -1)
-python tools/rocpd_summary.py $S $F $W > profiles/${TAG}_bench_c3_summary.txt 2>&1
-python tools/rocpd_timeline.py $S 20 > profiles/${TAG}_bench_c3_timeline.txt 2>&1
-python tools/pmc_summary.py $Q > profiles/${TAG}_pmc_sq.txt 2>&1
-python tools/make_profiles.py $S $F $W $Q 1000000 5000 5008 $TAG
-cp profiles/${TAG}_* profiles/objective_traffic.json profiles/mfma_util.json gpurun_out/ 2>/dev/null
-find gpurun_out -name "*.db" -size +30M -delete
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun): rocprofv3 kernel trace + stats of the default bench command, then the
+# PMC passes for HBM traffic (FETCH_SIZE, WRITE_SIZE in SEPARATE runs, --kernel-trace only) and MFMA utilisation.
+# Results land in gpurun_out/prof_$TAG/; tools/make_profiles.py turns the databases into profiles/*.json, and the text
+# summaries are copied to profiles/ by hand.   usage: bash tools/profile_round.sh r03 [bench args...]
+set -u
+TAG=${1:-r03}; shift || true
+ARGS=${@:---steps 2 --warmup 1 --cpu-sample 0 --landmark-method device}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+run() {  # name, rocprof flags...
+  local name=$1; shift
+  timeout 900 rocprofv3 "$@" -d "$OUT/$name" -o "$name" -- python "$ROOT/bench.py" $ARGS > "$OUT/$name.bench.json" 2> "$OUT/$name.err"
+  echo "$name rc=$?"
+}
+run stats --kernel-trace --stats
+run fetch --kernel-trace --pmc FETCH_SIZE
+run write --kernel-trace --pmc WRITE_SIZE
+run sq --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+# the databases are too large to travel back: reduce them here, keep the summaries
+COMMIT=${COMMIT:-unrecorded}
+SHA=$(sha256sum "$ROOT/mellon_amd/csrc/objective.hip" | cut -c1-16)
+cd "$OUT" && mkdir -p profiles
+python - "$OUT" "$TAG" <<'PY' > "$OUT/${TAG}_bench_c3_summary.txt" 2> "$OUT/summary.err"
+import sqlite3, sys, re, json
+out, tag = sys.argv[1], sys.argv[2]
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    return re.sub(r"^void ", "", name)[:120]
+con = sqlite3.connect(f"{out}/stats/stats_results.db")
+rows = con.execute("select name, count(*), avg(duration), sum(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+tot = sum(r[3] for r in rows)
+print(f"# rocprofv3 --kernel-trace --stats -- python bench.py (see {tag}_bench_c3_1gpu_under_rocprof.json for the line this run printed)")
+print(f"# {len(rows)} kernels, {tot / 1e6:.1f} ms of kernel time in total")
+print(f"{'kernel':122s} {'calls':>7s} {'avg us':>12s} {'total ms':>10s} {'%':>6s} {'min us':>10s} {'max us':>10s}")
+for n, c, a, s, mn, mx in rows:
+    print(f"{short(n):122s} {c:7d} {a / 1e3:12.2f} {s / 1e6:10.2f} {100 * s / tot:6.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f}")
+PY
+python "$ROOT/tools/make_profiles.py" "$OUT/stats/stats_results.db" "$OUT/fetch/fetch_results.db" "$OUT/write/write_results.db" "$OUT/sq/sq_results.db" 1000000 5000 5008 "$TAG" > "$OUT/make_profiles.out" 2> "$OUT/make_profiles.err"
+python - "$OUT/profiles/objective_traffic.json" "$COMMIT" "$SHA" <<'PY'
+import json, sys
+p, commit, sha = sys.argv[1:4]
+try:
+    d = json.load(open(p)); d["measured_at_commit"] = commit; d["objective_hip_sha16"] = sha
+    json.dump(d, open(p, "w"), indent=1)
+except Exception as e:
+    print("stamp failed:", e)
+PY
+python "$ROOT/tools/pmc_summary.py" "$OUT/sq/sq_results.db" > "$OUT/${TAG}_pmc_sq.txt" 2>> "$OUT/summary.err"
+cp "$OUT/stats.bench.json" "$OUT/${TAG}_bench_c3_1gpu_under_rocprof.json"
+rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write" "$OUT/sq"
+ls -la "$OUT" "$OUT/profiles"
