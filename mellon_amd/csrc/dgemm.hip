@@ -111,6 +111,12 @@ __global__ __launch_bounds__(256, 2) void k_dgemm(GemmArgs g, int64_t tiles_n, i
   int64_t kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
   if (g.kmode == 1) { kbeg = m0; kend = (m0 + BT < g.K) ? (m0 + BT) : g.K; }        // block-diagonal op(A)
   else if (g.kmode == 2) { kbeg = n0; kend = (n0 + BT < g.K) ? (n0 + BT) : g.K; }   // block-diagonal op(B)
+  else if (g.kmode == 3) { kend = (m0 + BT < kend) ? (m0 + BT) : kend; }            // op(A) lower triangular: k <= row
+  else if (g.kmode == 4) { kend = (n0 + BT < kend) ? (n0 + BT) : kend; }            // op(B) upper triangular: k <= column
+  else if (g.kmode == 7) {                                                          // lower x lower: column <= k <= row
+    kbeg = (n0 > kbeg) ? n0 : kbeg;
+    kend = (m0 + BT < kend) ? (m0 + BT) : kend;
+  }
   double* C = g.C + (int64_t)blockIdx.y * g.c_split_stride;  // may alias A (in-place panels)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -243,7 +249,7 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
     if (t128 * (g.split_k > 1 ? g.split_k : 1) < n_cu && !inplace) bt = 64;
   }
   if (g_bk_override == 128 || g_bk_override == 64) bt = inplace ? 128 : g_bk_override;
-  if (g.kmode != 0) bt = 128;   // the block-diagonal modes are defined on 128-wide blocks
+  if (g.kmode == 1 || g.kmode == 2) bt = 128;   // the block-diagonal modes are defined on 128-wide blocks
   const int64_t tiles_m = (g.M + bt - 1) / bt, tiles_n = (g.N + bt - 1) / bt;
   const int64_t nblk = tiles_m * tiles_n;
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }

@@ -36,6 +36,8 @@ int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* 
 //               3 = skip the tiles strictly BELOW the diagonal
 //   kmode:      1 = the K range of a tile is its own ROW block [m0, m0 + 128) -- op(A) block-diagonal;
 //               2 = its own COLUMN block [n0, n0 + 128) -- op(B) block-diagonal   (128 x 128 tiles)
+//               3 = [0, m0 + tile): op(A) lower triangular;  4 = [0, n0 + tile): op(B) upper triangular;
+//               7 = [n0, m0 + tile): the product of two lower triangular matrices (its lower tiles)
 //   split_k > 1: writes split_k partial C's at C + s * c_split_stride (beta ignored, alpha applied)
 struct GemmArgs {
   const double* A; int64_t lda;
