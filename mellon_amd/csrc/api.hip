@@ -1567,13 +1567,14 @@ static int fit_build_precond(mln_fit* f, int64_t row_stride) {
   const int64_t m = f->m, ldg = f->ldl;
   const size_t bytes = sizeof(double) * (size_t)m * ldg;
   double t0 = now_s(), ex0 = f->emu_excluded;
+  const double ex_start = f->emu_excluded;
   MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
   int rc = fit_gram(f, f->C, ldg, row_stride);
   f->times[3] += now_s() - t0 - (f->emu_excluded - ex0);
   double t1 = now_s(); ex0 = f->emu_excluded;
   if (rc == MLN_OK) rc = fit_factor_precond(f);
   f->times[4] += now_s() - t1 - (f->emu_excluded - ex0);
-  if (rc == MLN_OK) { f->precond_stride = row_stride < 1 ? 1 : row_stride; f->build_seconds = now_s() - t0; }
+  if (rc == MLN_OK) { f->precond_stride = row_stride < 1 ? 1 : row_stride; f->build_seconds = now_s() - t0 - (f->emu_excluded - ex_start); }
   return rc;
 }
 
@@ -1937,11 +1938,14 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.n_sub_levels = (int)sub_strides.size();
   init.sub_level = 0;
   if (subs) { init.gate = MLN_GATE_SUB; init.cap = __builtin_inf(); }
-  // Preconditioner rebuild (solver.h, precond_rebuild.hip): pays when the ~12 full passes it saves cost more than the
-  // m^3 work of a second factorisation -- decided from rank 0's measurement of the first build, the same on every rank.
-  // MELLON_AMD_REBUILD=0 / 1 forces the decision.
-  const double pass_s = (double)f->n * (double)f->ldl * 8.0 / 6.5e12;
-  double want_rebuild = (f->build_seconds > 0.0 && 12.0 * pass_s > 1.1 * f->build_seconds) ? 1.0 : 0.0;
+  // Preconditioner rebuild (solver.h, precond_rebuild.hip): pays when the evaluations it saves (measured: 33-40 full
+  // passes without it, 15-26 with it) cost more than the m^3 work of a second factorisation -- decided from rank 0's
+  // measurement of the first build, the same on every rank.  An evaluation = one pass of this rank's rows + ~0.14 ms of
+  // small launches.  MELLON_AMD_REBUILD=0 / 1 forces the decision.
+  const double pass_s = (double)f->n * (double)f->ldl * 8.0 / 6.5e12 + 1.4e-4;
+  // (emulated ranks of C3, tools/emulate_rank.py: the rebuild gains 9 ms per step at 4 ranks -- first build = 8.9 evaluations
+  //  -- and loses 2.5 ms at 8 -- 12.7 evaluations: the threshold sits between)
+  double want_rebuild = (f->build_seconds > 0.0 && 11.0 * pass_s > f->build_seconds) ? 1.0 : 0.0;
   if (const char* ev = std::getenv("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
   if (phase32 && !(f->l32_fixed)) want_rebuild = 0.0;   // (mixed solves pause at their fp64 anchor, which only the corrected fixed-point surrogate has)
   {
@@ -1992,7 +1996,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     if (f->h_state->gate == MLN_GATE_DONE) break;
     if (f->h_state->gate == MLN_GATE_PAUSE) {
       // ---- second preconditioner at the accepted point (whose rows' f the last accepted fp64 pass left in f_keep) ----
-      const double tr0 = now_s();
+      const double tr0 = now_s(), ex_r0 = f->emu_excluded;
       const SolverState ps = *f->h_state;
       if (!ps.f_valid || !objective_can_keep_f(f->n, f->n_wg)) {
         // no per-row f to weight the cells with: resume with the preconditioner we have
@@ -2056,7 +2060,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         f->n_rebuild += 1;
       }
       MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      f->times_rebuild += now_s() - tr0;
+      f->times_rebuild += now_s() - tr0 - (f->emu_excluded - ex_r0);
       slot_shift.push_back({ps.n_eval, n_enq - ps.n_eval});
       continue;
     }
