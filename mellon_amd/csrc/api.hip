@@ -1585,13 +1585,19 @@ static int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_
   const int64_t m = f->m, ldg = f->ldl;
   RebuildSelection sel{};
   const double target = rows_per_m * (double)m;
+  const bool tr_on = std::getenv("MELLON_AMD_TRACE") != nullptr;
+  double tt[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i, double& t0) { if (tr_on) { (void)hipStreamSynchronize(ctx->stream); const double t1 = now_s(); tt[i] += t1 - t0; t0 = t1; } };
+  double tl = now_s();
   MLN_TRY(rebuild_select_rows(ctx, f_dev, f->V, f->n, f->row0, target, 0x6d656c6c6f6eull, &sel));
+  lap(0, tl);
   double* R = nullptr;
   int rc = MLN_OK;
   const int64_t rr = sel.rows > 0 ? sel.rows : 1;
   if (mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl) != hipSuccess) rc = MLN_ERR_HIP;
   if (rc == MLN_OK) rc = launch_gather_scale_rows(ctx, f->L, f->ldl, sel.idx, sel.scale, sel.rows, R);
   fit_drop_precond_operators(f);
+  lap(1, tl);
   if (rc == MLN_OK) {
     // scaled covariances stay in [0, 1]: the integer Gram applies where it did for the first preconditioner
     bool quant = f->kspace && f->cov_bounded01 && m >= 256;
@@ -1607,6 +1613,7 @@ static int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_
   (void)hipStreamSynchronize(ctx->stream);
   if (R) (void)mln_dfree(R);
   rebuild_selection_free(ctx, &sel);
+  lap(2, tl);
   if (rc == MLN_OK && f->kspace) {                                                              // Lp^-1 G Lp^-T
     int my_rank = 0; bool emulate = false;
     const int n_split = split_ranks(ctx, &my_rank, &emulate);
@@ -1625,7 +1632,11 @@ static int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_
       if (T) (void)mln_dfree(T);
     }
   }
+  lap(3, tl);
   if (rc == MLN_OK) rc = fit_factor_precond(f);
+  lap(4, tl);
+  if (tr_on) fprintf(stderr, "[trace] rebuild ms: select %.2f, gather+drop %.2f, gram %.2f, whiten %.2f, factor+inverses+stacks %.2f\n",
+                     1e3 * tt[0], 1e3 * tt[1], 1e3 * tt[2], 1e3 * tt[3], 1e3 * tt[4]);
   return rc;
 }
 
