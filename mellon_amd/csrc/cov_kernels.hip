@@ -1032,8 +1032,10 @@ int launch_nn_distances_exact(mln_ctx* ctx, const double* x, int64_t n, const do
 int launch_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
                         int64_t self_offset, double* out) {
   if (n == 0) return MLN_OK;
-  static const bool prefilter = !(std::getenv("MELLON_AMD_NN_PREFILTER") && std::atoi(std::getenv("MELLON_AMD_NN_PREFILTER")) == 0);
-  static const int64_t min_pairs = std::getenv("MELLON_AMD_NN_PREFILTER_MIN") ? std::atoll(std::getenv("MELLON_AMD_NN_PREFILTER_MIN")) : ((int64_t)1 << 26);
+  const char* e_on = std::getenv("MELLON_AMD_NN_PREFILTER");          // read per call: the tests flip it
+  const char* e_min = std::getenv("MELLON_AMD_NN_PREFILTER_MIN");
+  const bool prefilter = !(e_on && std::atoi(e_on) == 0);
+  const int64_t min_pairs = e_min ? std::atoll(e_min) : ((int64_t)1 << 26);
   if (prefilter && d <= 64 && m >= 2 && n * m >= min_pairs && m < 2147483647LL)
     return nn_distances_prefiltered(ctx, x, n, y, m, d, self_offset, out, nullptr);
   return launch_nn_distances_exact(ctx, x, n, y, m, d, self_offset, nullptr, out);

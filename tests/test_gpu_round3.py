@@ -374,3 +374,38 @@ def test_function_estimator_with_resident_targets_and_predictions(mellon, ctx):
     assert rel_max(out.to_host(), host) < 1e-12
     with pytest.raises(ValueError):
         est.predict(xd, out=ctx.empty((n, p + 1)))
+
+
+# ---- the fp16-split pre-filter of the 1-NN search (csrc/rowmin_f16.hip) ---------------------------------------------
+@pytest.mark.parametrize("d", [3, 20, 50, 64])
+def test_nn_prefilter_exact(ctx, monkeypatch, d):
+    """The pre-filtered search (fp16-split row minima + fp64 certification + exact re-search of uncertified rows) returns
+    the distances of the plain fp64 search and of the oracle's tree search -- on data built to stress the certificate:
+    tight clusters far from the origin (large |x|, small gaps), exact duplicates (distance 0) and near-ties."""
+    rng = np.random.default_rng(100 + d)
+    n = 12000
+    x = mo.gaussian_mixture(n, d, seed=d)
+    x[:3000] = 40.0 + 1e-3 * rng.normal(size=(3000, d))          # a tight cluster far out: gaps ~1e-3 at |x| ~ 40 sqrt(d)
+    x[3000:3010] = x[3010:3020]                                   # exact duplicates
+    x[3020:3030] = x[3030:3040] + 1e-9                            # near-duplicates
+    want = mo.exact_nn_distances(x)
+    monkeypatch.setenv("MELLON_AMD_NN_PREFILTER_MIN", "1")
+    monkeypatch.setenv("MELLON_AMD_NN_PREFILTER", "1")
+    fast = ctx.nn_distances(x)
+    monkeypatch.setenv("MELLON_AMD_NN_PREFILTER", "0")
+    plain = ctx.nn_distances(x)
+    scale = np.linalg.norm(x, axis=1).max()
+    # squared distances come out of |x|^2 + |y|^2 - 2 x.y in both searches: absolute error ~ eps |x|^2 on d^2
+    tol2 = 64 * np.finfo(float).eps * scale**2
+    assert np.abs(fast**2 - want**2).max() < tol2 and np.abs(plain**2 - want**2).max() < tol2
+    assert np.array_equal(fast[3000:3010] == 0, want[3000:3010] == 0)
+    # a shard of the rows against all cells (the sharded fit's call), and a rectangular search (cells vs landmarks)
+    monkeypatch.setenv("MELLON_AMD_NN_PREFILTER", "1")
+    lo, hi = 5000, 9000
+    part = ctx.nn_distances(np.ascontiguousarray(x[lo:hi]), x, self_offset=lo)
+    assert np.array_equal(part, fast[lo:hi])
+    lm = x[::37]
+    from sklearn.neighbors import BallTree
+    near = BallTree(lm).query(x[1::2], k=1)[0][:, 0]
+    got = ctx.nn_distances(np.ascontiguousarray(x[1::2]), lm, self_offset=-n)        # i - n < 0: no pair excluded
+    assert np.abs(got**2 - near**2).max() < tol2
