@@ -700,6 +700,21 @@ __global__ void k_row_sqnorms(DevCov cov, const double* __restrict__ x, int64_t 
 }
 
 
+// The search compares |x|^2 - 2 x.y + |y|^2, whose absolute error is ~eps |x|^2: enough to pick the winner (up to ties
+// inside that noise), not to report a tiny distance -- a duplicated cell would come out as ~1e-7 |x| instead of 0, and the
+// reference replaces exactly the non-positive distances (validation.py:528-592).  The reported value is therefore
+// recomputed from the winner's coordinates: sum (x_k - y_k)^2, relative error ~eps.
+__device__ __forceinline__ double nn_direct_distance(const double* __restrict__ x, int64_t i, const double* __restrict__ y,
+                                                     int64_t j, int d) {
+  if (j < 0) return INFINITY;
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double t = x[i * d + k] - y[j * d + k];
+    s = fma(t, t, s);
+  }
+  return sqrt(s);
+}
+
 // Exact Euclidean nearest-neighbour distance of every row of x among the rows of y, skipping the
 // pair (i, i + self_offset).  Replaces the approximate pynndescent search of the reference
 // (mellon/parameters.py:352-433) -- same tile structure as the covariance kernel; the running
@@ -712,10 +727,12 @@ __global__ __launch_bounds__(256) void k_nn_distances(const double* __restrict__
   __shared__ double xs[DK][TM + PADT];
   __shared__ double ys[DK][TN + PADT];
   __shared__ double red[TM][17];
+  __shared__ int64_t redj[TM][17];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * TM;
   double best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+  int64_t bj[4] = {-1, -1, -1, -1};
   double xr[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -763,21 +780,23 @@ __global__ __launch_bounds__(256) void k_nn_distances(const double* __restrict__
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int64_t r = row0 + ty * 4 + i;
-        const double sq = fmax(xr[i] - 2.0 * acc[i][j] + yj, 0.0);
+        const double sq = xr[i] - 2.0 * acc[i][j] + yj;
         const int64_t skip = (excl && r < n) ? excl[r] : r + self_offset;
-        if (c < m && c != skip) best[i] = fmin(best[i], sq);
+        if (c < m && c != skip && sq < best[i]) { best[i] = sq; bj[i] = c; }
       }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) red[ty * 4 + i][tx] = best[i];
+  for (int i = 0; i < 4; ++i) { red[ty * 4 + i][tx] = best[i]; redj[ty * 4 + i][tx] = bj[i]; }
   __syncthreads();
   if (tid < TM) {
     double s = INFINITY;
+    int64_t j = -1;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) s = fmin(s, red[tid][t]);
+    for (int t = 0; t < 16; ++t)
+      if (red[tid][t] < s) { s = red[tid][t]; j = redj[tid][t]; }
     int64_t r = row0 + tid;
-    if (r < n) out[r] = sqrt(s);
+    if (r < n) out[r] = nn_direct_distance(x, r, y, j, d);
   }
 }
 
@@ -809,6 +828,7 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
     }
   }
   double xr[4], best[4];
+  int bt[4];            // the winner so far as a 16-column group: column = 16 bt + li (bt < 2^31: m < 2^35)
   int64_t ex[4];        // the candidate that does not count for each of this lane's rows
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -816,6 +836,7 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
     xr[r] = (row < n) ? xx[row] : 0.0;
     ex[r] = (excl && row < n) ? excl[row] : row + self_offset;
     best[r] = INFINITY;
+    bt[r] = -1;
   }
   for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;   // zero incl. the k padding
   __syncthreads();
@@ -848,10 +869,11 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
     for (int t = 0; t < 4; ++t) {
       const int64_t c = col0 + 16 * t + li;
       const double yc = yn[buf][16 * t + li];
+      const int grp = (int)(col0 >> 4) + t;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double sq = fmax(xr[r] - 2.0 * acc[t][r] + yc, 0.0);
-        if (c < m && c != ex[r]) best[r] = fmin(best[r], sq);
+        const double sq = xr[r] - 2.0 * acc[t][r] + yc;
+        if (c < m && c != ex[r] && sq < best[r]) { best[r] = sq; bt[r] = grp; }
       }
     }
     __syncthreads();
@@ -859,10 +881,15 @@ __global__ __launch_bounds__(512) void k_nn_distances_mfma(const double* __restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     double s_ = best[r];
+    int64_t j_ = bt[r] < 0 ? -1 : 16 * (int64_t)bt[r] + li;
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) s_ = fmin(s_, __shfl_xor(s_, off, 64));
+    for (int off = 8; off > 0; off >>= 1) {
+      const double so = __shfl_xor(s_, off, 64);
+      const int64_t jo = __shfl_xor(j_, off, 64);
+      if (so < s_ || (so == s_ && jo >= 0 && (j_ < 0 || jo < j_))) { s_ = so; j_ = jo; }
+    }
     const int64_t row = row0 + lk + 4 * r;
-    if (li == 0 && row < n) out[row] = sqrt(s_);
+    if (li == 0 && row < n) out[row] = nn_direct_distance(x, row, y, j_, d);
   }
 }
 

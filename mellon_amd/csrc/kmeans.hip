@@ -74,11 +74,14 @@ __global__ void k_seed_pick(const double* __restrict__ mind, int64_t n, int64_t 
 // cell instead of 400 bytes): D^2 only weights the k-means++ draw, three significant digits are plenty, and the 5000
 // sequential updates of a 1e6-cell seeding are pure memory traffic.  scale: the copy holds scale * x.
 __global__ __launch_bounds__(256) void k_seed_update_h(const _Float16* __restrict__ xh, int64_t n, int d, float inv_scale,
-                                                       const double* __restrict__ c, double* __restrict__ mind,
-                                                       double* __restrict__ bsum, int first) {
+                                                       const double* __restrict__ c, const double* __restrict__ prep,
+                                                       double* __restrict__ mind, double* __restrict__ bsum, int first) {
   __shared__ float cs[64];
   __shared__ double red[256];
-  for (int k = threadIdx.x; k < 64; k += 256) cs[k] = (k < d) ? (float)c[k] : 0.f;
+  // the copy holds -2 (x - centre) * scale (rowmin_prepare): the centre goes through the same map, D^2 comes back in the
+  // data's units
+  for (int k = threadIdx.x; k < 64; k += 256) cs[k] = (k < d) ? (float)((c[k] - prep[k]) * prep[64]) : 0.f;
+  const double unscale = 1.0 / (prep[64] * prep[64]);
   __syncthreads();
   typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
   const int64_t base = (int64_t)blockIdx.x * SBLK;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void k_seed_update_h(const _Float16* __restric
           s = fmaf(t, t, s);
         }
       }
-      double sd = (double)s;
+      double sd = (double)s * unscale;
       if (!first) sd = fmin(sd, mind[i]);
       mind[i] = sd;
       acc += sd;
@@ -416,18 +419,23 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   XorShift rng((unsigned long long)seed);
   int64_t cur = (int64_t)(rng.uniform() * (double)n);
   if (cur >= n) cur = n - 1;
-  static const bool km_fp16_seed = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
+  const bool km_fp16_seed = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
   const bool seed_h = km_fp16_seed && d <= 61 && n * m >= ((int64_t)1 << 24) && m >= 2;
   void* xsplit = nullptr;
+  double* prep = nullptr;          // centre and scale of the half-precision copies (rowmin_prepare)
+  if (d <= 64 && n * m >= ((int64_t)1 << 24) && m >= 2 && rc == MLN_OK) {
+    chk(mln_dmalloc((void**)&prep, sizeof(double) * ROWMIN_PREP_DOUBLES));
+    if (rc == MLN_OK) rc = rowmin_prepare(ctx, dx, n, nullptr, 0, d, prep);
+  }
   if (seed_h && rc == MLN_OK) {
     chk(mln_dmalloc(&xsplit, rowmin_split_bytes(n)));
-    if (rc == MLN_OK) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, 1);   // role 1: -2 x (also the Lloyd sweeps' operand)
+    if (rc == MLN_OK) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, 1, prep);   // role 1: -2 x (also the Lloyd sweeps' operand)
   }
   if (rc == MLN_OK) chk(hipMemcpyAsync(dc, dx + cur * d, sizeof(double) * d, hipMemcpyDeviceToDevice, st));
   for (int64_t j = 0; j + 1 < m && rc == MLN_OK; ++j) {
     if (seed_h)
       hipLaunchKernelGGL(k_seed_update_h, dim3((unsigned)nblk), dim3(256), 0, st, reinterpret_cast<const _Float16*>(xsplit), n, d,
-                         -0.5f, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
+                         -0.5f, dc + j * d, prep, mind, bsum, j == 0 ? 1 : 0);
     else
       hipLaunchKernelGGL(k_seed_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
     hipLaunchKernelGGL(k_seed_select, dim3(1), dim3(256), 0, st, bsum, nblk, mind, n, rng.uniform(), dx, d, dc + (j + 1) * d);
@@ -462,7 +470,7 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   // fp32 accumulation: distances to ~1e-5 relative).  A cell whose two nearest centres tie within that may land on
   // either -- k-means is indifferent -- and the centre update, the stopping test and the final inertia stay fp64.
   // 5e11 fp64 flops per sweep at 1e6 cells x 5000 centres (15 ms) become ~1 ms.  MELLON_AMD_KM_FP16=0 disables.
-  static const bool km_fp16 = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
+  const bool km_fp16 = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
   const bool fast_assign = km_fp16 && d <= 64 && n * m >= ((int64_t)1 << 24) && m >= 2;
   const bool km_fold = d <= 61;
   void* csplit = nullptr;
@@ -473,12 +481,12 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
     chk(mln_dmalloc(&csplit, rowmin_split_bytes(m)));
     chk(mln_dmalloc((void**)&ccf, sizeof(float) * (size_t)m));
     chk(mln_dmalloc((void**)&m1f, sizeof(float) * (size_t)n));
-    if (rc == MLN_OK && !have) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, km_fold ? 1 : 0);
+    if (rc == MLN_OK && !have) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, km_fold ? 1 : 0, prep);
   }
   for (; it < max_iter && rc == MLN_OK; ++it) {
     hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);
     if (fast_assign) {
-      rc = launch_split_f16(ctx, dc, m, d, csplit, nullptr, ccf, km_fold ? 2 : 0);
+      rc = launch_split_f16(ctx, dc, m, d, csplit, nullptr, ccf, km_fold ? 2 : 0, prep);
       if (rc == MLN_OK) rc = launch_rowmin_f16x3(ctx, xsplit, n, csplit, m, ccf, 0, 0, m1f, nullptr, label, km_fold ? 1 : 0);
       if (rc != MLN_OK) break;
     } else if (d <= 64 && n * m >= 4096)
@@ -515,7 +523,7 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   }
   if (n_iter_out) *n_iter_out = it;
   (void)hipStreamSynchronize(st);
-  void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f};
+  void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f, prep};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (own_x) (void)mln_dfree(dx);
   return rc;

@@ -6,7 +6,12 @@ size_t rowmin_split_bytes(int64_t rows);   // device bytes of the split (hi | lo
 // x (n x d doubles, d <= 64) -> split rows, squared norms in fp64 (xx, may be null) and rounded to fp32 (xxf, may be null)
 // role 0: plain rows; 1: query rows of the folded product (coordinates x -2, ones in three spare slots); 2: candidate rows of
 // it (|y|^2 as three halves in those slots) -- roles 1 / 2 need d <= 61
-int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf, int role);
+// prep (device, ROWMIN_PREP_DOUBLES doubles, from rowmin_prepare): the split holds (x - centre) * scale and xx / xxf are the
+// squared norms of THAT
+#define ROWMIN_PREP_DOUBLES 66
+int rowmin_prepare(mln_ctx* ctx, const double* y, int64_t m, const double* x, int64_t n, int d, double* prep);
+int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf, int role,
+                     const double* prep);
 // per row i of xs: m1 = min_j (yyf_j - 2 x_i.y_j), arg = its j, m2 = the second smallest (null: not tracked);
 // exclude_self: the pair (i, i + self_offset) does not count
 // fold: operands split with roles 1 / 2; arg is then the first of four candidates arg + {0, 32, 64, 96} (launch_resolve_labels

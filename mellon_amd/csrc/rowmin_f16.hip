@@ -38,11 +38,14 @@ constexpr int PITCH = 272;           // LDS bytes per candidate row (256 + 16)
 // the hi half hold 1;  role 2 (candidate rows): those slots hold |y|^2 as three halves (hi + mid + lo, 33 bits) -- the
 // matrix product of a query and a candidate row is then  |y|^2 - 2 x.y  itself, no epilogue arithmetic.  Needs d <= 61.
 __global__ __launch_bounds__(256) void k_split_f16(const double* __restrict__ x, int64_t n, int d, _Float16* __restrict__ out,
-                                                   double* __restrict__ xx, float* __restrict__ xxf, int role) {
+                                                   double* __restrict__ xx, float* __restrict__ xxf, int role,
+                                                   const double* __restrict__ prep) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int k = threadIdx.x & 63;
   if (row >= n) return;
-  const double v0 = (k < d) ? x[row * d + k] : 0.0;
+  // prep (rowmin_prepare): [0..63] the centre, [64] the power-of-two scale -- the split holds (x - centre) * scale, whose
+  // squared norms stay below 2^14: nothing overflows half precision whatever the units or the offset of the data
+  const double v0 = (k < d) ? (x[row * d + k] - prep[k]) * prep[64] : 0.0;
   double s = v0 * v0;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -60,6 +63,41 @@ __global__ __launch_bounds__(256) void k_split_f16(const double* __restrict__ x,
   out[row * ROWH + k] = hi;
   out[row * ROWH + KP + k] = lo;
   if (k == 0) { if (xx) xx[row] = s; if (xxf) xxf[row] = (float)s; }
+}
+
+// Centre of the data: the mean of up to 4096 evenly spaced rows, summed in a fixed order (deterministic).  One workgroup.
+__global__ __launch_bounds__(256) void k_sample_centre(const double* __restrict__ y, int64_t m, int d, double* __restrict__ prep) {
+  __shared__ double part[4][64];
+  const int k = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t cnt = m < 4096 ? m : 4096;
+  const int64_t stride = m / cnt;
+  double s = 0.0;
+  if (k < d)
+    for (int64_t r = g; r < cnt; r += 4) s += y[(r * stride) * d + k];
+  part[g][k] = s;
+  __syncthreads();
+  if (g == 0) prep[k] = (k < d) ? (part[0][k] + part[1][k] + part[2][k] + part[3][k]) / (double)cnt : 0.0;
+  if (threadIdx.x == 0) { prep[64] = 1.0; prep[65] = 0.0; }
+}
+
+// prep[65] = max over rows of |x - centre|^2 (a maximum: order-independent, so the atomic is deterministic;
+// non-negative doubles order like their bit patterns)
+__global__ __launch_bounds__(256) void k_max_centred_norm(const double* __restrict__ x, int64_t n, int d, double* __restrict__ prep) {
+  __shared__ double red[4];
+  double mx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) { const double t = x[i * d + k] - prep[k]; s = fma(t, t, s); }
+    mx = fmax(mx, s);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double v = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    atomicMax(reinterpret_cast<unsigned long long*>(prep + 65), (unsigned long long)__double_as_longlong(v));
+  }
 }
 
 __global__ void k_max_norm(const double* __restrict__ xx, int64_t n, double* __restrict__ out) {
@@ -270,16 +308,22 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
                                                     const double* __restrict__ xx, const double* __restrict__ yy,
                                                     const float* __restrict__ m2, const int* __restrict__ arg,
                                                     const double* __restrict__ yy_max, int fold, int64_t self_offset,
+                                                    const double* __restrict__ prep,
                                                     double* __restrict__ out, int* __restrict__ n_flag, int* __restrict__ flagged) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  // everything the sweep saw is (x - centre) * scale: xx, yy, m2 and the bound E live in those units; the winner's value
+  // s is formed from the same centred and scaled coordinates in fp64
+  const double sc = prep[64];
   double s = INFINITY;
+  int64_t js = -1;
   for (int q = 0; q < (fold ? 4 : 1); ++q) {
     const int64_t j = (int64_t)arg[i] + 32 * q;
     if (j >= m || j == i + self_offset) continue;
     double dot = 0.0;
-    for (int k = 0; k < d; ++k) dot = fma(x[i * d + k], y[j * d + k], dot);
-    s = fmin(s, yy[j] - 2.0 * dot);
+    for (int k = 0; k < d; ++k) dot = fma((x[i * d + k] - prep[k]) * sc, (y[j * d + k] - prep[k]) * sc, dot);
+    const double sv = yy[j] - 2.0 * dot;
+    if (sv < s) { s = sv; js = j; }
   }
   const double xn = sqrt(xx[i]), yn = sqrt(yy_max[0]);
   // The value the sweep compares is |y|^2 - 2 x.y from three half-precision products (hi.hi + hi.lo + lo.hi) accumulated in
@@ -291,7 +335,17 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
   const double E = 1.25 * (1.9073486328125e-06 * 2.0 * xn * yn + 80.0 * u * mag + 160.0 * u * 9.765625e-04 * mag +
                            4.0 * u * mag + 64.0 * u * 2.0 * (2.0 * xn + yn) + 1e-300);
   const bool certified = ((double)m2[i] - E) > s;
-  out[i] = sqrt(fmax(xx[i] + s, 0.0));
+  // reported: the winner's distance from its coordinates (sum (x_k - y_k)^2), not from the cancelling |x|^2 - 2 x.y + |y|^2:
+  // exact 0 for a duplicated cell, relative error ~eps otherwise (see nn_direct_distance in cov_kernels.hip)
+  double dd = INFINITY;
+  if (js >= 0) {
+    dd = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const double t = x[i * d + k] - y[js * d + k];
+      dd = fma(t, t, dd);
+    }
+  }
+  out[i] = sqrt(dd);
   if (!certified) {
     const int slot = atomicAdd(n_flag, 1);
     flagged[slot] = (int)i;
@@ -334,11 +388,37 @@ __global__ void k_scatter_rows(const double* __restrict__ vals, const int* __res
 
 size_t rowmin_split_bytes(int64_t rows) { return sizeof(_Float16) * (size_t)rows * ROWH; }
 
-int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf, int role) {
+// Centre and scale for the half-precision copies of y (m x d) and, if given, x (n x d): prep[0..63] = the mean of an
+// evenly spaced sample of y, prep[64] = the power of two that brings the largest centred squared norm of either set into
+// [2^12, 2^14) (1 for all-equal data).  Distances do not depend on the centre, and a power-of-two scale is exact: only the
+// RANGE of what half precision has to hold changes -- raw counts in the thousands or coordinates of 1e-6 neither
+// overflow nor flush to zero.  prep: ROWMIN_PREP_DOUBLES doubles on the device.
+int rowmin_prepare(mln_ctx* ctx, const double* y, int64_t m, const double* x, int64_t n, int d, double* prep) {
+  if (m <= 0) return MLN_OK;
+  hipLaunchKernelGGL(k_sample_centre, dim3(1), dim3(256), 0, ctx->stream, y, m, d, prep);
+  hipLaunchKernelGGL(k_max_centred_norm, dim3(1024), dim3(256), 0, ctx->stream, y, m, d, prep);
+  if (x && n > 0 && x != y) hipLaunchKernelGGL(k_max_centred_norm, dim3(1024), dim3(256), 0, ctx->stream, x, n, d, prep);
+  double mx = 0.0;
+  MLN_HIP(ctx, hipMemcpyAsync(&mx, prep + 65, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double scale = 1.0;
+  if (std::isfinite(mx) && mx > 0.0) {
+    int e = 0;
+    (void)std::frexp(mx, &e);                                   // mx = f * 2^e, f in [0.5, 1)
+    const int q = 14 - e;
+    scale = std::ldexp(1.0, q >= 0 ? q / 2 : -((1 - q) / 2));    // floor(q / 2): mx * scale^2 in [2^12, 2^14)
+  }
+  MLN_HIP(ctx, hipMemcpyAsync(prep + 64, &scale, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));      // (scale lives on this stack frame)
+  return MLN_OK;
+}
+
+int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* split, double* xx, float* xxf, int role,
+                     const double* prep) {
   if (n <= 0) return MLN_OK;
   if (d > KP || (role != 0 && d > KP - 3)) { mln_set_error(ctx, "split_f16: too many features"); return MLN_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL(k_split_f16, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, x, n, d,
-                     reinterpret_cast<_Float16*>(split), xx, xxf, role);
+                     reinterpret_cast<_Float16*>(split), xx, xxf, role, prep);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -379,7 +459,7 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
                              int64_t self_offset, double* out, double* stats) {
   const bool same = (x == y && n == m);
   void *xs = nullptr, *ys = nullptr;
-  double *xx = nullptr, *yy = nullptr, *ymax = nullptr;
+  double *xx = nullptr, *yy = nullptr, *ymax = nullptr, *prep = nullptr;
   float *yyf = nullptr, *m1 = nullptr, *m2 = nullptr;
   int *arg = nullptr, *nflag = nullptr, *flagged = nullptr;
   std::vector<void*> owned;
@@ -399,12 +479,13 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
             alloc((void**)&m1, sizeof(float) * n) && alloc((void**)&m2, sizeof(float) * n) &&
             alloc((void**)&arg, sizeof(int) * n) && alloc((void**)&nflag, sizeof(int)) &&
             alloc((void**)&flagged, sizeof(int) * n) && alloc((void**)&ymax, sizeof(double)) &&
-            alloc((void**)&yyf, sizeof(float) * m);
+            alloc((void**)&yyf, sizeof(float) * m) && alloc((void**)&prep, sizeof(double) * ROWMIN_PREP_DOUBLES);
   if (ok && !share) ok = alloc(&ys, rowmin_split_bytes(m));
   if (ok && !same) ok = alloc((void**)&yy, sizeof(double) * m);
   if (!ok) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
-  int rc = launch_split_f16(ctx, x, n, d, xs, xx, share ? yyf : nullptr, fold ? 1 : 0);
-  if (rc == MLN_OK && !share) rc = launch_split_f16(ctx, y, m, d, ys, same ? nullptr : yy, yyf, fold ? 2 : 0);
+  int rc = rowmin_prepare(ctx, y, m, same ? nullptr : x, n, d, prep);
+  if (rc == MLN_OK) rc = launch_split_f16(ctx, x, n, d, xs, xx, share ? yyf : nullptr, fold ? 1 : 0, prep);
+  if (rc == MLN_OK && !share) rc = launch_split_f16(ctx, y, m, d, ys, same ? nullptr : yy, yyf, fold ? 2 : 0, prep);
   if (share) ys = xs;
   if (same) yy = xx;
   if (rc != MLN_OK) return cleanup(rc);
@@ -413,7 +494,7 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
   rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold);
   if (rc != MLN_OK) return cleanup(rc);
   hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
-                     ymax, fold, self_offset, out, nflag, flagged);
+                     ymax, fold, self_offset, prep, out, nflag, flagged);
   int cnt = 0;
   if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
