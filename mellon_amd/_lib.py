@@ -455,8 +455,32 @@ class Context:
                                               _ptr(Wd), p, float(mu), out.ctypes.data))
         return out
 
+    def _rows_sq_blocks(self, desc, xnew, centers, Mt, diag):
+        """|cov(x_i, centers) Mt|^2 per row (diag) or the Gram of those rows: blocks of the user's kernel times a device
+        matrix on the matrix cores."""
+        xnew, centers = _as2d(xnew), _as2d(centers)
+        Md = self.to_device(np.ascontiguousarray(Mt))
+        n = xnew.shape[0]
+        if not diag:
+            blk = desc.block(xnew, centers)
+            T = self.gemm(blk if isinstance(blk, DeviceArray) else self.to_device(blk), Md)
+            return self.gemm(T, T, tb=True).to_host()
+        out = np.empty(n)
+        ones = self.to_device(np.ones((Md.shape[1], 1)))
+        for i0 in range(0, n, desc.rows_per_block):
+            blk = desc.block(xnew[i0:i0 + desc.rows_per_block], centers)
+            T = self.gemm(blk if isinstance(blk, DeviceArray) else self.to_device(blk), Md)
+            out[i0:i0 + desc.rows_per_block] = self.gemm(self.ewise(OP_MUL, T, T), ones).to_host()[:, 0]
+        return out
+
     def predict_covariance(self, desc, xnew, centers, Lf, diag=True):
-        _needs_program(desc, "predict_covariance")
+        if isinstance(desc, BlockEvaluatedCov):
+            # k(x, x) - |cov(x, centers) L^-T|^2 (conditional.py:375-381,660-685,707-716)
+            Lf = _f64(Lf)
+            LinvT = np.ascontiguousarray(self.trsm_lower(Lf, np.eye(Lf.shape[0])).T)
+            kss = desc.diag(_as2d(xnew)) if diag else desc.block(_as2d(xnew), _as2d(xnew))
+            kss = kss.to_host() if isinstance(kss, DeviceArray) else kss
+            return kss - self._rows_sq_blocks(desc, xnew, centers, LinvT, diag)
         xnew, centers, Lf = _as2d(xnew), _as2d(centers), _f64(Lf)
         n = xnew.shape[0]
         out = np.empty((n,) if diag else (n, n), dtype=np.float64)
@@ -466,7 +490,8 @@ class Context:
         return out
 
     def predict_mean_covariance(self, desc, xnew, centers, W, diag=True):
-        _needs_program(desc, "predict_mean_covariance")
+        if isinstance(desc, BlockEvaluatedCov):
+            return self._rows_sq_blocks(desc, xnew, centers, _as2d(W), diag)
         xnew, centers, W = _as2d(xnew), _as2d(centers), _as2d(W)
         n = xnew.shape[0]
         out = np.empty((n,) if diag else (n, n), dtype=np.float64)
@@ -477,7 +502,9 @@ class Context:
 
     def sparse_solve(self, desc, x, xu, y, mu, sigma, jitter, return_factors=False):
         """Weights of the noisy landmark conditional; with return_factors also (Lp, Cs = Lp L_B)."""
-        _needs_program(desc, "sparse_solve")
+        if isinstance(desc, BlockEvaluatedCov):
+            W, Lp, Cs = self._sparse_solve_blocks(desc, x, xu, y, mu, np.array([float(sigma)]), jitter, return_factors)
+            return (W, Lp, Cs) if return_factors else W
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
         y2 = y if isinstance(y, DeviceArray) else _f64(y)          # (HBM-resident targets are used in place)
@@ -499,9 +526,54 @@ class Context:
 
     SIGMA_SCALAR, SIGMA_PER_OUTPUT, SIGMA_PER_CELL = 0, 1, 2
 
+    def _sparse_solve_blocks(self, desc, x, xu, y, mu, sigma, jitter, return_factors):
+        """The landmark conditional (conditional.py:57-66,526-545) of a block-evaluated covariance, assembled from the
+        library's device primitives: G = K^T K and R = K^T (y - mu) accumulate over row blocks on the matrix cores
+        (mln_gemm) and are summed over the ranks; the m x m part -- Lp = chol(K_uu + jitter I), A A^T = Lp^-1 G Lp^-T,
+        L_B = chol(A A^T / sigma^2 + I), the two pairs of triangular solves -- goes through mln_chol_lower /
+        mln_trsm_lower.  sigma: one value, or one per output column (columns that share a value share the factor)."""
+        xh = x.to_host() if isinstance(x, DeviceArray) else _as2d(x)
+        xu = _as2d(xu)
+        yh = y.to_host() if isinstance(y, DeviceArray) else _f64(y)
+        y_ndim = yh.ndim
+        r = (yh - float(mu)).reshape(xh.shape[0], -1)
+        m, p = xu.shape[0], r.shape[1]
+        if sigma.shape[0] not in (1, p):
+            raise ValueError(f"sigma has shape {sigma.shape}, expected (1,) or ({p},)")
+        G, R = self.to_device(np.zeros((m, m))), self.to_device(np.zeros((m, p)))
+        for i0 in range(0, xh.shape[0], desc.rows_per_block):
+            blk = desc.block(xh[i0:i0 + desc.rows_per_block], xu)
+            blk = blk if isinstance(blk, DeviceArray) else self.to_device(blk)
+            self.gemm(blk, blk, ta=True, out=G, beta=1.0)
+            self.gemm(blk, np.ascontiguousarray(r[i0:i0 + desc.rows_per_block]), ta=True, out=R, beta=1.0)
+        G, R = self.allreduce_sum(G).to_host(), self.allreduce_sum(R).to_host()
+        Kuu = desc.block(xu, xu)
+        Kuu = Kuu.to_host() if isinstance(Kuu, DeviceArray) else Kuu
+        Lp = self.chol_lower(Kuu, add_diag=float(jitter))
+        T = self.trsm_lower(Lp, G)                                             # Lp^-1 G
+        AAt = self.trsm_lower(Lp, np.ascontiguousarray(T.T))                   # Lp^-1 G^T Lp^-T (symmetric)
+        AAt = 0.5 * (AAt + AAt.T)
+        Ar = self.trsm_lower(Lp, R)                                            # A (y - mu)
+        W = np.empty((m, p))
+        Cs = None
+        sig_cols = np.broadcast_to(sigma, (p,))
+        for sg in np.unique(sig_cols):
+            cols = np.nonzero(sig_cols == sg)[0]
+            s2 = float(sg) ** 2
+            L_B = self.chol_lower(AAt / s2, add_diag=1.0)
+            c = self.trsm_lower(L_B, np.ascontiguousarray(Ar[:, cols]) / s2)
+            W[:, cols] = self.trsm_lower(Lp, self.trsm_lower(L_B, c, trans=True), trans=True)
+            if return_factors:
+                Cs = self.gemm(Lp, L_B).to_host()
+        W = W[:, 0] if y_ndim == 1 else W
+        return W, Lp, Cs
+
     def sparse_solve_noise(self, desc, x, xu, y, mu, sigma, kind, jitter):
         """Landmark-conditional weights under per-output (sigma[p]) or per-cell (sigma[n]) noise."""
-        _needs_program(desc, "sparse_solve_noise")
+        if isinstance(desc, BlockEvaluatedCov):
+            if kind == self.SIGMA_PER_CELL:
+                _needs_program(desc, "sparse_solve_noise with one sigma per cell")
+            return self._sparse_solve_blocks(desc, x, xu, y, mu, _f64(np.atleast_1d(sigma)), jitter, False)[0]
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         xu = _as2d(xu)
         y2 = _f64(y)

@@ -72,6 +72,10 @@ class BlockCov(_lib.BlockEvaluatedCov):
         y = np.ascontiguousarray(ensure_2d(y), dtype=np.float64)
         return self.cov._block(np.arange(self.d), x, y)
 
+    def diag(self, x):
+        """k(x_i, x_i) of every row (reference base_cov.py:71-93)."""
+        return self.cov.diag(x)
+
 
 class Covariance(ABC):
     """Base covariance function (reference base_cov.py:17-224)."""

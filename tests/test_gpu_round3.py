@@ -440,3 +440,63 @@ def test_half_precision_copies_are_range_safe(ctx, monkeypatch, scale, shift):
     from sklearn.metrics import pairwise_distances_argmin
     lab = pairwise_distances_argmin(x, c1)
     assert len(np.unique(lab)) > 0.98 * m
+
+
+# ---- block-evaluated kernels beyond the density fit: FunctionEstimator and predictive uncertainty ------------------
+def test_user_defined_kernel_function_estimator_and_uncertainty(mellon):
+    """The noisy landmark conditional (scalar and per-output sigma) and the predictive covariance / mean covariance with
+    a Python-level kernel: assembled by the binding from mln_gemm / mln_chol_lower / mln_trsm_lower over blocks of the
+    user's k; == the oracle with the equivalent built-in kernel."""
+    User = _user_matern52(mellon)
+    rng = np.random.default_rng(8)
+    n, d, m, p = 5000, 4, 150, 3
+    x = mo.gaussian_mixture(n, d, seed=9)
+    y = np.sin(x[:, :p]) + 0.1 * rng.normal(size=(n, p))
+    nn = mo.exact_nn_distances(x)
+    lm = mo.compute_landmarks(x, mo.SPARSE_CHOLESKY, m, 42)
+    xq = x[::97] * 1.05 + 0.02
+    for sigma in (0.1, np.array([0.1, 0.3, 0.1])):
+        est = mellon.FunctionEstimator(cov_func_curry=User, sigma=sigma, landmarks=lm, nn_distances=nn,
+                                       predictor_with_uncertainty=np.ndim(sigma) == 0)
+        est.fit(x, y)
+        assert isinstance(est.cov_func, User)
+        ref = mo.function_fit(x, y, sigma, landmarks=lm, nn_distances=nn, with_uncertainty=np.ndim(sigma) == 0)
+        # (the user's NumPy kernel differs from the built-in one in the last bits; cond(K_uu + jitter I) ~ 1e6 amplifies it)
+        assert rel_max(est.predict(xq), ref(xq)) < 1e-5
+        if np.ndim(sigma) == 0:
+            for diag in (True, False):
+                c, cr = est.predict.covariance(xq, diag=diag), ref.covariance(xq, diag=diag)
+                assert c.shape == cr.shape and np.abs(c - cr).max() < 1e-5 * np.abs(cr).max()
+    # one output, 1-D targets
+    est1 = mellon.FunctionEstimator(cov_func_curry=User, sigma=0.2, landmarks=lm, nn_distances=nn).fit(x, y[:, 0])
+    ref1 = mo.function_fit(x, y[:, 0], 0.2, landmarks=lm, nn_distances=nn)
+    assert est1.predict(xq).shape == (xq.shape[0],) and rel_max(est1.predict(xq), ref1(xq)) < 1e-5
+    # DensityEstimator: Laplace uncertainty of the log-density through the user's kernel
+    estd = mellon.DensityEstimator(cov_func_curry=User, landmarks=lm, nn_distances=nn, predictor_with_uncertainty=True)
+    estd.fit(x)
+    refd = mo.density_fit(x, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    V, _ = mo.nn_likelihood_constants(refd.nn_distances, refd.d)
+    op = refd.predict.attach_uncertainty(refd.Lp, mo.laplace_std(refd.pre_transformation, refd.L, refd.mu, V))
+    assert np.abs(estd.predict.covariance(xq) - op.covariance(xq)).max() < 1e-6
+    assert rel_max(estd.predict.mean_covariance(xq), op.mean_covariance(xq)) < 1e-3
+    assert rel_max(estd.predict.uncertainty(xq, diag=False), op.uncertainty(xq, diag=False)) < 1e-3
+
+
+def test_user_defined_kernel_time_sensitive(mellon):
+    """TimeSensitiveDensityEstimator with a user's kernel over the state columns times a built-in kernel over time."""
+    User = _user_matern52(mellon)
+    n_per, d, m = 1500, 3, 120
+    x = np.concatenate([mo.gaussian_mixture(n_per, d, seed=20 + t) + 0.3 * t for t in range(3)])
+    t = np.repeat(np.arange(3.0), n_per)
+    X = np.ascontiguousarray(np.column_stack([x, t]))
+    nn = mo.per_time_nn_distances(x, t)
+    ls = mo.compute_ls(nn)
+    lm = X[:: X.shape[0] // m][:m].copy()
+    cov = User(ls, active_dims=slice(0, d)) * mellon.cov.Matern52(1.5, active_dims=d)
+    ocov = mo.Matern52(ls, active_dims=slice(0, d)) * mo.Matern52(1.5, active_dims=d)
+    est = mellon.TimeSensitiveDensityEstimator(cov_func=cov, landmarks=lm, nn_distances=nn)
+    dens = est.fit_predict(X)
+    ref = mo.density_fit(X, cov_func=ocov, landmarks=lm, nn_distances=nn, d=d, lbfgsb_options=mo.LBFGSB_TIGHT)
+    assert rel_max(dens, ref.log_density_x) < 1e-5
+    q = np.column_stack([x[::17] + 0.02, t[::17]])
+    assert rel_max(est.predict(q), ref.predict(q)) < 1e-5
