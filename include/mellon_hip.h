@@ -114,6 +114,13 @@ typedef struct mln_loopback mln_loopback;
 int mln_loopback_create(int n_ranks /* <= 16 */, mln_loopback** out);
 void mln_loopback_destroy(mln_loopback* group);
 int mln_comm_init_loopback(mln_ctx* ctx, mln_loopback* group, int rank);
+/* Host-staged collectives: the fall-back for a box where RCCL cannot be initialised, and the way to run the real
+ * multi-PROCESS path on fewer GPUs than ranks (RCCL refuses two ranks on one device).  The library copies the buffer to
+ * pinned host memory, calls `fn`, copies the result back, all in stream order.  op 0: all-reduce (sum over ranks, in rank
+ * order) of buf[count] in place; op 1: buf[count] <- rank 0's; op 2: all-gather, buf[count] of every rank in rank order
+ * into buf2[n_ranks * count].  fn returns 0 on success. */
+typedef int (*mln_host_collective_fn)(void* user, int op, double* buf, double* buf2, int64_t count);
+int mln_comm_init_host(mln_ctx* ctx, int n_ranks, int rank, mln_host_collective_fn fn, void* user);
 void mln_loopback_abort(mln_loopback* group); /* a rank failed outside a collective: wake the others with MLN_ERR_RCCL */
 
 /* ---- a-1..a-3: K = cov(x, y)   (util.py:351-366 distance, cov.py k(), base_cov.py Add/Mul/Pow)

@@ -21,6 +21,9 @@ K_MATERN32, K_MATERN52, K_EXPQUAD, K_EXPONENTIAL, K_RATQUAD, K_LINEAR, K_DISTANC
 OP_LEAF, OP_CONST, OP_ADD, OP_MUL, OP_POW = 0, 1, 2, 3, 4
 
 
+HOST_COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+
 class MellonHipError(RuntimeError):
     """HIP / RCCL / argument failure inside libmellon_hip.so."""
 
@@ -64,6 +67,7 @@ SYMBOLS = [
     ("mln_loopback_create", C.c_int, [C.c_int, C.POINTER(_vp)]),
     ("mln_loopback_destroy", None, [_vp]),
     ("mln_comm_init_loopback", C.c_int, [_vp, _vp, C.c_int]),
+    ("mln_comm_init_host", C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     ("mln_loopback_abort", None, [_vp]),
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_kernel_grad", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
@@ -286,6 +290,14 @@ class Context:
     def comm_init(self, unique_id, n_ranks, rank):
         buf = C.create_string_buffer(bytes(unique_id), MLN_UNIQUE_ID_BYTES)
         self._check(self.lib.mln_comm_init(self.handle, buf, int(n_ranks), int(rank)))
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def comm_init_host(self, n_ranks, rank, collective):
+        """Device collectives staged through host memory: `collective(user, op, buf, buf2, count) -> 0 / 1` is called by
+        the library with pinned host pointers (distributed.HostStagedCollectives)."""
+        fn = HOST_COLLECTIVE_FN(collective)
+        self._check(self.lib.mln_comm_init_host(self.handle, int(n_ranks), int(rank), C.cast(fn, C.c_void_p), None))
+        self._host_collective = (fn, collective)          # keep the trampoline alive as long as the context
         self.n_ranks, self.rank = int(n_ranks), int(rank)
 
     def comm_init_loopback(self, group, rank):

@@ -246,7 +246,7 @@ static int dev_bcast0(mln_ctx* ctx, double* dev, int64_t count) { return comm_bc
 
 extern "C" int mln_comm_allreduce_sum(mln_ctx* ctx, double* buf, int64_t count) {
   if (!ctx || (count > 0 && !buf)) return MLN_ERR_ARG;
-  if (!ctx->comm && !ctx->loop) return MLN_OK;
+  if (!ctx->comm && !ctx->loop && ctx->n_ranks <= 1) return MLN_OK;     // (n_ranks > 1 without either: host-staged)
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   DevOut o;
   MLN_TRY(o.init(ctx, buf, (size_t)count, true));

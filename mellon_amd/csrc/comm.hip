@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "mln_internal.h"
@@ -184,11 +185,54 @@ int loop_allgather(mln_ctx* ctx, const double* send, double* recv, int64_t count
 
 }  // namespace
 
+// ---- host-staged --------------------------------------------------------------------------------------
+// (side table instead of a field of mln_ctx: only contexts that asked for it pay the lookup)
+struct HostStaged {
+  mln_host_collective_fn fn = nullptr;
+  void* user = nullptr;
+  double* pinned = nullptr;
+  size_t cap = 0;              // doubles
+};
+static std::mutex host_mu;
+static std::unordered_map<mln_ctx*, HostStaged> host_tab;
+
+static HostStaged* host_of(mln_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(host_mu);
+  auto it = host_tab.find(ctx);
+  return it == host_tab.end() ? nullptr : &it->second;     // (node-based map: the address is stable)
+}
+
+static int host_stage(mln_ctx* ctx, HostStaged* h, size_t doubles) {
+  if (h->cap >= doubles) return MLN_OK;
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  h->pinned = nullptr; h->cap = 0;
+  MLN_HIP(ctx, hipHostMalloc((void**)&h->pinned, sizeof(double) * doubles, hipHostMallocDefault));
+  h->cap = doubles;
+  return MLN_OK;
+}
+
+static int host_collective(mln_ctx* ctx, HostStaged* h, int op, const double* send, double* recv, int64_t count) {
+  const size_t total = (op == 2) ? (size_t)count * (size_t)(ctx->n_ranks + 1) : (size_t)count;
+  MLN_TRY(host_stage(ctx, h, total));
+  MLN_HIP(ctx, hipMemcpyAsync(h->pinned, send, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double* out = (op == 2) ? h->pinned + count : h->pinned;
+  const int rc = h->fn(h->user, op, h->pinned, op == 2 ? out : nullptr, count);
+  if (rc != 0) { mln_set_error(ctx, "host-staged collective failed (the host communicator reported an error)"); return MLN_ERR_RCCL; }
+  const size_t back = (op == 2) ? (size_t)count * (size_t)ctx->n_ranks : (size_t)count;
+  MLN_HIP(ctx, hipMemcpyAsync(recv, out, sizeof(double) * back, hipMemcpyHostToDevice, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));        // (the staging buffer is reused by the next collective)
+  return MLN_OK;
+}
+
 // ---- the three collectives the path uses --------------------------------------------------------------
 int comm_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
   if (count <= 0) return MLN_OK;
   if (ctx->loop) return loop_allreduce(ctx, dev, count);
-  if (!ctx->comm) return MLN_OK;   // a 1-rank RCCL communicator still goes through RCCL
+  if (!ctx->comm) {
+    if (ctx->n_ranks > 1) if (HostStaged* h = host_of(ctx)) return host_collective(ctx, h, 0, dev, dev, count);
+    return MLN_OK;   // a 1-rank RCCL communicator still goes through RCCL
+  }
   int rc = rccl::AllReduce(dev, dev, (size_t)count, rccl::kDouble, rccl::kSum, ctx->comm, ctx->stream);
   if (rc != 0) return rccl_fail(ctx, rc, "ncclAllReduce");
   return MLN_OK;
@@ -199,7 +243,10 @@ int comm_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
 int comm_bcast0(mln_ctx* ctx, double* dev, int64_t count) {
   if (count <= 0 || ctx->n_ranks <= 1) return MLN_OK;
   if (ctx->loop) return loop_bcast0(ctx, dev, count);
-  if (!ctx->comm) return MLN_OK;
+  if (!ctx->comm) {
+    if (HostStaged* h = host_of(ctx)) return host_collective(ctx, h, 1, dev, dev, count);
+    return MLN_OK;
+  }
   int rc = rccl::Broadcast(dev, dev, (size_t)count, rccl::kDouble, 0, ctx->comm, ctx->stream);
   if (rc != 0) return rccl_fail(ctx, rc, "ncclBroadcast");
   return MLN_OK;
@@ -209,6 +256,7 @@ int comm_allgather(mln_ctx* ctx, const double* send, double* recv, int64_t count
   if (count <= 0) return MLN_OK;
   if (ctx->loop) return loop_allgather(ctx, send, recv, count);
   if (!ctx->comm) {
+    if (ctx->n_ranks > 1) if (HostStaged* h = host_of(ctx)) return host_collective(ctx, h, 2, send, recv, count);
     if (recv != send) MLN_HIP(ctx, hipMemcpyAsync(recv, send, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, ctx->stream));
     return MLN_OK;
   }
@@ -221,6 +269,12 @@ void comm_release(mln_ctx* ctx) {
   if (ctx->comm && rccl::CommDestroy) rccl::CommDestroy(ctx->comm);
   ctx->comm = nullptr;
   ctx->loop = nullptr;   // the group belongs to whoever created it
+  std::lock_guard<std::mutex> lk(host_mu);
+  auto it = host_tab.find(ctx);
+  if (it != host_tab.end()) {
+    if (it->second.pinned) (void)hipHostFree(it->second.pinned);
+    host_tab.erase(it);
+  }
 }
 
 // ---- C ABI ----------------------------------------------------------------------------------------------
@@ -245,6 +299,20 @@ extern "C" int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank
   std::memcpy(&uid, id, MLN_UNIQUE_ID_BYTES);
   int rc = rccl::CommInitRank(&ctx->comm, n_ranks, uid, rank);
   if (rc != 0) return rccl_fail(ctx, rc, "ncclCommInitRank");
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return MLN_OK;
+}
+
+extern "C" int mln_comm_init_host(mln_ctx* ctx, int n_ranks, int rank, mln_host_collective_fn fn, void* user) {
+  if (!ctx || !fn || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MLN_ERR_ARG;
+  if (ctx->comm || ctx->loop || host_of(ctx)) { mln_set_error(ctx, "this context already has a communicator"); return MLN_ERR_ARG; }
+  {
+    std::lock_guard<std::mutex> lk(host_mu);
+    HostStaged& h = host_tab[ctx];
+    h.fn = fn;
+    h.user = user;
+  }
   ctx->n_ranks = n_ranks;
   ctx->rank = rank;
   return MLN_OK;

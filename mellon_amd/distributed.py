@@ -20,6 +20,7 @@ Two layers:
     LOCAL_RANK / MASTER_ADDR / MASTER_PORT are read.
 """
 import os
+import sys
 import socket
 import struct
 import threading
@@ -49,6 +50,14 @@ class HostComm:
 
     def broadcast(self, obj, src=0):
         return self.allgather(obj if self.rank == src else None)[src]
+
+    def reduce_sum(self, a):
+        """Sum of the ranks' float64 arrays, added in rank order (the same bits on every rank)."""
+        parts = self.allgather(np.ascontiguousarray(a, dtype=np.float64))
+        out = np.array(parts[0], dtype=np.float64)
+        for p in parts[1:]:
+            out = out + p
+        return out
 
     def close(self):
         pass
@@ -301,6 +310,26 @@ class SocketHostComm(HostComm):
         _send_msg(self._sock, encode(obj))
         return decode(_recv_msg(self._sock))
 
+    def reduce_sum(self, a):
+        """Star reduction: rank 0 adds the peers' arrays in rank order and returns the sum to everyone -- O(world) array
+        transfers where the all-gather form needs O(world^2) (the host-staged device collectives move 100 MB sums)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if self.world_size == 1:
+            return a.copy()
+        if self.rank == 0:
+            out = a.copy()
+            for c in self._peers:
+                part = decode(_recv_msg(c))
+                if part.shape != out.shape:
+                    raise ValueError(f"reduce_sum: a peer sent shape {part.shape}, expected {out.shape}")
+                out += part
+            blob = encode(out)
+            for c in self._peers:
+                _send_msg(c, blob)
+            return out
+        _send_msg(self._sock, encode(a))
+        return decode(_recv_msg(self._sock))
+
     def close(self):
         for c in self._peers:
             c.close()
@@ -453,22 +482,23 @@ def adopt_thread_state(state):
     _tls.comm = state
 
 
-def _host_address():
+def _host_address(channel=0):
     """Where the ranks' host sides meet: MELLON_AMD_PORT set -> TCP only; else the abstract Unix socket named after
     the launcher's rendezvous, with TCP on MASTER_ADDR : MASTER_PORT + 1 as the fallback (tried by every rank in
-    the same order; rank 0 listens on both)."""
+    the same order; rank 0 listens on both).  channel 1: the second connection that carries host-staged DEVICE
+    collectives (own sockets: a worker thread may be talking on channel 0 at the same time)."""
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = os.environ.get("MELLON_AMD_PORT")
     if port:
-        return [("tcp", addr, int(port))]
+        return [("tcp", addr, int(port) + 2 * channel)]
     run = os.environ.get("TORCHELASTIC_RUN_ID", "none")
-    out = [("unix", f"mellon_amd.{addr}.{os.environ.get('MASTER_PORT', '0')}.{run}")]
+    out = [("unix", f"mellon_amd.{addr}.{os.environ.get('MASTER_PORT', '0')}.{run}" + (f".ch{channel}" if channel else ""))]
     try:
         mp = int(os.environ.get("MASTER_PORT", "0"))
     except ValueError:
         mp = 0
-    if 0 < mp < 65535:
-        out.append(("tcp", addr, mp + 1))
+    if 0 < mp < 65533:
+        out.append(("tcp", addr, mp + 1 + 2 * channel))
     return out
 
 
@@ -556,18 +586,84 @@ def init_from_env(self_check=True):
         raise ValueError(f"RANK={rank} outside [0, WORLD_SIZE={world}) ({_describe_env()})")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     n_dev = _lib.device_count()
-    if local >= n_dev:
+    backend = os.environ.get("MELLON_AMD_COMM", "rccl").lower()
+    if backend not in ("rccl", "host"):
+        raise ValueError(f"MELLON_AMD_COMM={backend!r}: expected 'rccl' or 'host'")
+    if os.environ.get("MELLON_AMD_SHARE_GPU") == "1" and n_dev > 0:
+        # several ranks per GPU (testing the multi-process path on a small box): RCCL refuses that, host-staged works
+        os.environ["MELLON_AMD_DEVICE"] = str(local % n_dev)
+        backend = "host"
+    elif local >= n_dev:
         raise RuntimeError(f"LOCAL_RANK={local} but only {n_dev} GPU(s) are visible to this process ({_describe_env()}; "
-                           "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES restrict the set)")
+                           "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES restrict the set; MELLON_AMD_SHARE_GPU=1 lets "
+                           "ranks share a GPU over host-staged collectives)")
     timeout = float(os.environ.get("MELLON_AMD_COMM_TIMEOUT", "300"))
     host = SocketHostComm(_host_address(), rank, world, timeout=timeout, token=_job_token())
     ctx = _lib.default_context()                       # device = LOCAL_RANK
-    uid = host.broadcast(ctx.comm_unique_id() if rank == 0 else None, src=0)
-    _with_deadline("RCCL communicator set-up (ncclCommInitRank)", lambda: ctx.comm_init(uid, world, rank), timeout)
+    note = None
+    if backend == "rccl":
+        # An ERROR from the library (librccl missing, ncclCommInitRank refusing the topology) is survivable: if every rank
+        # saw one, all of them move to host-staged collectives.  A HANG is not -- it runs into the deadline and raises.
+        err, uid = None, None
+        if rank == 0:
+            try:
+                uid = ctx.comm_unique_id()
+            except _lib.MellonHipError as e:
+                err = e
+        uid = host.broadcast(uid, src=0)              # None: rank 0 could not even load RCCL
+        if uid is None:
+            err = err or RuntimeError("rank 0 could not create the RCCL id")
+        else:
+            try:
+                _with_deadline("RCCL communicator set-up (ncclCommInitRank)", lambda: ctx.comm_init(uid, world, rank), timeout)
+            except _lib.MellonHipError as e:
+                err = e
+        errs = host.allgather(None if err is None else str(err))
+        if any(e is not None for e in errs):
+            if not all(e is not None for e in errs):
+                raise RuntimeError(f"rank {rank}: RCCL set-up failed on ranks {[i for i, e in enumerate(errs) if e is not None]} "
+                                   f"only ({next(e for e in errs if e is not None)}); {_describe_env()}")
+            note = f"RCCL unavailable ({errs[0]}): host-staged collectives"
+            if rank == 0:
+                print(f"[mellon_amd] {note}", file=sys.stderr)
+            backend = "host"
+    if backend == "host":
+        staged = HostStagedCollectives(SocketHostComm(_host_address(channel=1), rank, world, timeout=timeout, token=_job_token()))
+        ctx.comm_init_host(world, rank, staged)
     comm = set_current(ShardedCommunicator(ctx, host))
+    comm.backend, comm.backend_note = backend, note
     if self_check:
         comm.self_test_report = self_test(comm, timeout=min(timeout, 120.0))
+        comm.self_test_report["backend"] = backend
     return comm
+
+
+class HostStagedCollectives:
+    """The callback behind mln_comm_init_host: device collectives staged through host memory and carried by a host
+    communicator of their own (include/mellon_hip.h: op 0 all-reduce, 1 broadcast from rank 0, 2 all-gather)."""
+
+    def __init__(self, host):
+        self.host = host
+        self.failure = None
+
+    def __call__(self, user, op, buf, buf2, count):
+        import ctypes
+        try:
+            a = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_double)), shape=(int(count),))
+            if op == 0:
+                a[:] = self.host.reduce_sum(a)
+            elif op == 1:
+                a[:] = self.host.broadcast(a.copy() if self.host.rank == 0 else None, src=0)
+            elif op == 2:
+                out = np.ctypeslib.as_array(ctypes.cast(buf2, ctypes.POINTER(ctypes.c_double)),
+                                            shape=(int(count) * self.host.world_size,))
+                out[:] = np.concatenate(self.host.allgather(a.copy()))
+            else:
+                raise ValueError(f"unknown collective {op}")
+            return 0
+        except BaseException as e:          # noqa: BLE001 -- must not unwind through the C frame
+            self.failure = e
+            return 1
 
 
 def run_loopback(n_ranks, fn, device=None):

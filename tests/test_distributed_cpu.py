@@ -147,8 +147,21 @@ def _socket_worker(rank, world, name, q):
     uid = comm.broadcast(b"x" * 128 if rank == 0 else None)
     comm.barrier()
     quant = comm.global_quantile(np.arange(rank, 1000, world, dtype=np.float64), 0.01)
+    # the star reduction that carries host-staged device collectives, through the library's callback signature
+    import ctypes
+    staged = distributed.HostStagedCollectives(host)
+    buf = (np.arange(7.0) + 100.0 * rank)
+    gathered = np.zeros(7 * world)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p).value
+    assert staged(None, 0, ptr(buf), None, 7) == 0            # all-reduce in place
+    red = buf.copy()
+    buf2 = np.full(3, float(rank))
+    assert staged(None, 1, ptr(buf2), None, 3) == 0           # broadcast from rank 0
+    buf3 = np.full(7, float(rank))
+    assert staged(None, 2, ptr(buf3), ptr(gathered), 7) == 0  # all-gather
+    assert staged(None, 9, ptr(buf3), None, 7) == 1 and isinstance(staged.failure, ValueError)
     host.close()
-    q.put((rank, got.tolist(), rows.tolist(), uid, quant))
+    q.put((rank, got.tolist(), rows.tolist(), uid, quant, red.tolist(), buf2.tolist(), gathered.tolist()))
 
 
 def test_socket_host_communicator_three_ranks():
@@ -164,11 +177,14 @@ def test_socket_host_communicator_three_ranks():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, red, rows, uid, quant in got:
+    for rank, red, rows, uid, quant, staged_sum, staged_bc, staged_ag in got:
         assert red == (np.arange(5.0) * 6).tolist()
         assert rows == [0.0, 1.0, 1.0, 2.0, 2.0, 2.0]
         assert uid == b"x" * 128
         assert quant == pytest.approx(np.quantile(np.arange(1000.0), 0.01), rel=1e-14)
+        assert staged_sum == (3 * np.arange(7.0) + 300.0).tolist()
+        assert staged_bc == [0.0, 0.0, 0.0]
+        assert staged_ag == np.repeat(np.arange(3.0), 7).tolist()
 
 
 def test_thread_host_communicator():

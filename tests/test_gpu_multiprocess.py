@@ -1,0 +1,79 @@
+"""The multi-PROCESS path on a 1-GPU box (-m gpu): two real processes under the launcher's environment variables, the
+socket rendezvous, the self-test, `bench.py --gpus 2` -- with the ranks sharing GPU 0 (MELLON_AMD_SHARE_GPU=1) and the
+device collectives staged through host memory (mln_comm_init_host), because RCCL refuses two ranks on one device.
+Everything except the transport of the device collectives is what an 8-GPU launch runs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import mellon_oracle as mo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(rank, world, port):
+    env = dict(os.environ)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MELLON_AMD_SHARE_GPU="1", MELLON_AMD_COMM_TIMEOUT="120",
+               TORCHELASTIC_RUN_ID=f"mp{port}", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fit_in_separate_processes(tmp_path, world):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_mp_rank_worker.py"), str(tmp_path)],
+                              env=_env(r, world, port), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert all(str(r["backend"]) == "host" and bool(r["self_test_ok"]) for r in res)
+    assert int(res[0]["lo"]) == 0 and int(res[-1]["hi"]) == 24000
+    assert all(int(a["hi"]) == int(b["lo"]) for a, b in zip(res[:-1], res[1:]))
+    # same landmarks / heuristics on every rank; the concatenated log-density == the unsharded fit == the oracle
+    assert all(np.array_equal(r["landmarks"], res[0]["landmarks"]) for r in res)
+    assert all(r["ls"] == res[0]["ls"] and r["mu"] == res[0]["mu"] for r in res)
+    assert all(np.array_equal(r["pred"], res[0]["pred"]) for r in res)
+    import mellon_amd
+    n, d = 24000, 8
+    x = mo.gaussian_mixture(n, d, seed=5)
+    dens = np.concatenate([r["dens"] for r in res])
+    nn = mo.exact_nn_distances(x)
+    est = mellon_amd.DensityEstimator(landmarks=res[0]["landmarks"], nn_distances=nn, check_rank=False)
+    one = est.fit_predict(x)
+    assert abs(float(res[0]["ls"]) / est.ls - 1) < 1e-9 and abs(float(res[0]["mu"]) - est.mu) < 1e-8
+    assert np.abs(dens - one).max() < 1e-6 * np.abs(one).max()
+    ref = mo.density_fit(x, landmarks=res[0]["landmarks"], nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    assert np.abs(dens - ref.log_density_x).max() < 1e-5 * np.abs(ref.log_density_x).max()
+
+
+def test_bench_two_ranks_under_the_launcher(tmp_path):
+    """The driver's launch line for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), small sizes."""
+    port = _free_port()
+    env = dict(os.environ)
+    env.update(MELLON_AMD_SHARE_GPU="1", MELLON_AMD_COMM_TIMEOUT="120", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--cells", "60000", "--dims", "10", "--landmarks", "400", "--landmark-method", "device", "--cpu-sample", "0",
+           "--extra-steps", "1"]
+    run = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-4000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["dtype"] == "f64" and out["value"] > 0
+    assert out["config"]["n_per_gpu"] == 30000 and out["scaling"] == "strong"
+    assert out["roofline"]["frac"] > 0 and out["config"]["predict_equals_fit_predict_rel_max"] < 1e-8
