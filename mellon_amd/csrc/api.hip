@@ -1840,7 +1840,7 @@ static int fit_solver_alloc(mln_fit* f, int maxcor) {
   if (f->sv_block && f->sv_maxcor >= maxcor) return MLN_OK;
   if (f->sv_block) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); MLN_HIP(ctx, mln_dfree(f->sv_block)); f->sv_block = nullptr; }
   const size_t ld = (size_t)f->ldl;
-  const size_t n_dbl = 6 * ld + 2 * (size_t)maxcor * ld + 2 * 64 + 4 * 512 + 32;
+  const size_t n_dbl = 6 * ld + 2 * (size_t)maxcor * ld + 2 * 64 + 4 * 512 + (sizeof(SolverState) + 63) / 64 * 8;
   MLN_HIP(ctx, mln_dmalloc(&f->sv_block, sizeof(double) * n_dbl));
   MLN_HIP(ctx, hipMemsetAsync(f->sv_block, 0, sizeof(double) * n_dbl, ctx->stream));
   double* p = (double*)f->sv_block;
@@ -1968,6 +1968,12 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.rebuild_armed = want_rebuild != 0.0 ? 1 : 0;
   init.rebuild_at_switch = 0;     // (measured: at the switch the unseen cells' weights are still too wild -- 37-96 full passes)
   if (const char* ev = std::getenv("MELLON_AMD_REBUILD_AT_SWITCH")) init.rebuild_at_switch = std::atoi(ev) != 0 ? 1 : 0;
+  init.switch_t0 = 0.35;
+  if (const char* ev = std::getenv("MELLON_AMD_SWITCH_T0")) init.switch_t0 = std::atof(ev);
+  init.gap_tol = 0.2 * o.ftol;     // (tools/solver_sweep.py, seven data seeds at C3: 15.9 -> 14.7 full passes with both rules, log-density
+                                   //  within 4e-8 of the old stop -- the spread between two runs of the old rule; 0.5 ftol: 14.3 passes, 1.8e-7)
+  if (const char* ev = std::getenv("MELLON_AMD_GAP_TOL")) init.gap_tol = std::atof(ev);
+  init.dec_prev = 0.0; init.dec_prev2 = 0.0;
   init.rebuild_tol = 1e-3;       // (tools/solver_sweep.py at C3, two seeds: 1e-2 -> 23-28 full passes, 1e-3 -> 20-22, 2e-4 -> 22-26)
   if (const char* ev = std::getenv("MELLON_AMD_REBUILD_TOL")) init.rebuild_tol = std::atof(ev);
   double rebuild_rows_per_m = 6.0;   // (6 m, 12 m, 24 m importance-sampled rows: the same pass counts; 6 m is the cheapest Gram)

@@ -45,6 +45,16 @@ struct SolverState {
   int resume_keep_pairs;    // MLN_SOLVE_RESUME: the curvature pairs are still valid (no new variable)
   int gate_after_pause;     // the copy the solve continues on once the host resumes it
   double rebuild_tol;
+  // First trial step of the first line search on the full objective after the subsample phase.  The quasi-Newton step
+  // built on the subsample's curvature is too long there -- the cells the subsample never saw still carry large weights
+  // e^{f+V} -- and t = 1 was rejected on most data sets tried (a wasted pass); the accepted lengths were 0.30-0.39.
+  double switch_t0;
+  // Estimated remaining gap.  Once the decrease per iteration contracts by more than 4x twice in a row (r = dec_k /
+  // dec_{k-1} < 1/4: the regime after the preconditioner rebuild, where it contracts 50-100x per pass) the loss still to
+  // gain is ~ dec_k r / (1 - r); the solve stops when that is below gap_tol * max(|f|, 1) instead of spending one or two
+  // more passes to watch the decrease itself fall below ftol.  0: off (SciPy's ftol test alone).
+  double gap_tol;
+  double dec_prev, dec_prev2;   // decrease of the loss in the last two accepted iterations on the full objective (0: none yet)
 };
 
 struct SolverBuffers {

@@ -118,6 +118,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   bool next_level = false;
   int ls = st->ls, k = st->k, head = st->head, status = st->status, gate = st->gate;
   double fx = st->fx, t = st->t, gd = st->gd, corr_k = st->corr_k, t0 = st->t0, cap = st->cap;
+  double dec_prev = st->dec_prev, dec_prev2 = st->dec_prev2;
+  const bool after_switch = mode == MLN_SOLVE_REEVAL && !phaseS && !phaseC && st->n_eval_sub > 0 && st->it_full == 0;   // (full objective, first direction)
   bool recap = false;
   if (mode != MLN_SOLVE_LS && !resume) t0 = 1.0;
   int f_slot = st->f_slot, f_valid = st->f_valid, corr = st->corr, n_anchor = st->n_anchor;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   if (resume) {
     to_head = true;                      // u, g, fx are the accepted point (in the NEW variable when the history was dropped)
     if (!st->resume_keep_pairs) { k = 0; head = 0; }
+    dec_prev = 0.0; dec_prev2 = 0.0;
   } else if (mode != MLN_SOLVE_LS) {            // first point, or the same point again on the fp64 buffer
     if (mode == MLN_SOLVE_REEVAL && !phase32 && st->use_corr) {
       // fp64 evaluation at the accepted point u, where fx / g hold the surrogate's loss / gradient (F32 after phase A,
@@ -233,8 +236,16 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       } else if ((f_old - fx) <= st->ftol * fscale) {
         if (phaseC) reeval = true; else { status = 0; done = true; }   // phase C: the fp64 objective has the last word
       } else {
-        to_head = true;
+        const double dec = f_old - fx;
+        bool small_gap = false;
+        if (st->gap_tol > 0.0 && !phaseS && dec_prev > 0.0 && dec_prev2 > 0.0 && dec < 0.25 * dec_prev && dec_prev < 0.25 * dec_prev2) {
+          const double r = dec / dec_prev;
+          small_gap = dec * r / (1.0 - r) <= st->gap_tol * fscale;
+        }
+        if (small_gap) { if (phaseC) reeval = true; else { status = 0; done = true; } }
+        else to_head = true;
       }
+      if (!phaseS) { dec_prev2 = dec_prev; dec_prev = f_old - fx; }
     } else if (isfinite(fn) && fabs(fn - fx) <= st->ftol * fmax(fmax(fabs(fx), fabs(fn)), 1.0)) {
       // The trial changed the loss by no more than the stopping tolerance but was not a sufficient decrease: the
       // search has reached the rounding noise of the objective (sums of n terms), where shrinking the step further
@@ -329,6 +340,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       // posteriori -- done, on fp64 evidence (the loss, the gradient and the rows' f of this very pass).
       if (verify && -0.5 * gd <= st->ftol * fmax(fabs(fx), 1.0)) { status = 0; done = true; }
       t = t0;
+      if (after_switch && st->switch_t0 > 0.0) t = st->switch_t0;
       if (k == 0 && !resume) {
         double g1 = 0.0;
 #pragma unroll
@@ -367,6 +379,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     st->f_slot = f_slot; st->f_valid = f_valid;
     st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k; st->t0 = t0; st->cap = cap;
     st->n_eval_sub = n_eval_sub; st->it_full = it_full; st->sub_level = sub_level;
+    st->dec_prev = dec_prev; st->dec_prev2 = dec_prev2;
     if (pause) st->rebuild_armed = 0;    // once per solve
   }
 }
