@@ -985,6 +985,9 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD && (!out32 || q32)) {
     MLN_TRY(launch_kernel_matrix_rows_q(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32, q32));
+  } else if (!no_mfma && !no_rows && n >= 4096 && m >= 256 && (!out32 || q32) && predict_rows_prod_eligible(cov, d)) {
+    // the time-sensitive product kernel: state leaf x time leaf, both in the persistent-row kernel (leaf 0's norms come first)
+    MLN_TRY(launch_kernel_matrix_rows_prod(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32, q32));
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_kernel_matrix_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, out, ldo, add_diag, tiles_n, out32, q32);

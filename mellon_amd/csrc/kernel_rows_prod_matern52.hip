@@ -1,0 +1,4 @@
+// k_kernel_matrix_rows_prod for MLN_K_MATERN52 (see kernel_rows_prod_impl.h)
+#include "kernel_rows_prod_impl.h"
+
+MLN_DEFINE_ROWS_PROD_KIND(launch_kernel_matrix_rows_prod_matern52, MLN_K_MATERN52)

@@ -153,3 +153,17 @@ int launch_predict_mean_rows_prod(mln_ctx* ctx, const DevCov& cov, const double*
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
+
+int launch_kernel_matrix_rows_prod(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y, int64_t m,
+                                   int d, const double* xx0, const double* yy0, double* out, int64_t ldo, double add_diag,
+                                   float* out32, int q32) {
+  switch (cov.leaves[0].kind) {
+    case MLN_K_MATERN32: return launch_kernel_matrix_rows_prod_matern32(ctx, cov, x, n, y, m, d, xx0, yy0, out, ldo, add_diag, out32, q32);
+    case MLN_K_MATERN52: return launch_kernel_matrix_rows_prod_matern52(ctx, cov, x, n, y, m, d, xx0, yy0, out, ldo, add_diag, out32, q32);
+    case MLN_K_EXPQUAD: return launch_kernel_matrix_rows_prod_expquad(ctx, cov, x, n, y, m, d, xx0, yy0, out, ldo, add_diag, out32, q32);
+    case MLN_K_EXPONENTIAL: return launch_kernel_matrix_rows_prod_exponential(ctx, cov, x, n, y, m, d, xx0, yy0, out, ldo, add_diag, out32, q32);
+    default: break;
+  }
+  mln_set_error(ctx, "kernel_matrix_rows_prod: unsupported kind");
+  return MLN_ERR_UNSUPPORTED;
+}

@@ -500,3 +500,40 @@ def test_user_defined_kernel_time_sensitive(mellon):
     assert rel_max(dens, ref.log_density_x) < 1e-5
     q = np.column_stack([x[::17] + 0.02, t[::17]])
     assert rel_max(est.predict(q), ref.predict(q)) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["Matern52", "Matern32", "ExpQuad", "Exponential"])
+@pytest.mark.parametrize("d_state,n,m", [(2, 4100, 257), (30, 5000, 300), (52, 4225, 321), (64, 4096, 256)])
+def test_product_kernel_matrix_rows(mellon, kind, d_state, n, m):
+    """cov(x, landmarks) of the time-sensitive product kernel on its persistent-row kernel (csrc/kernel_rows_prod_impl.h):
+    ragged row / column counts, every k-step variant, == the oracle's kernel algebra."""
+    rng = np.random.default_rng(100 * d_state + m)
+    x = np.column_stack([rng.normal(size=(n, d_state)), rng.integers(0, 8, size=n).astype(float)])
+    c = np.column_stack([rng.normal(size=(m, d_state)), rng.integers(0, 8, size=m).astype(float)])
+    c[:5] = x[:5]                                               # coincident points: covariance 1 (up to the reference's 1e-12 offset)
+    ls, ls_time = 1.1 * np.sqrt(d_state), 2.3
+    cov = getattr(mellon.cov, kind)(ls, active_dims=slice(None, -1)) * getattr(mellon.cov, kind)(ls_time, active_dims=-1)
+    ocov = getattr(mo, kind)(ls, active_dims=slice(None, -1)) * getattr(mo, kind)(ls_time, active_dims=-1)
+    got, want = cov(x, c), ocov(x, c)
+    # (Exponential is sqrt-like at coincident points: the 1e-16 |x|^2 rounding of |x|^2 - 2 x.y + |y|^2 next to the
+    #  reference's 1e-12 offset moves exp(-r / 2) by ~1e-10 there -- in any arithmetic)
+    assert got.shape == (n, m) and np.abs(got - want).max() < (1e-9 if kind == "Exponential" else 1e-12)
+    small = cov(x[:700], c)                                      # below the row-kernel's size threshold: the generic program kernel
+    assert np.abs(small - got[:700]).max() < (1e-9 if kind == "Exponential" else 1e-13)
+
+
+def test_time_sensitive_fit_uses_the_product_rows_kernel(mellon, monkeypatch):
+    """A time-sensitive fit large enough for the row kernels, with and without the 32-bit copy, against the same fit with
+    the row kernels switched off (MELLON_AMD_KM_NO_ROWS is read once per process: compare with the oracle instead)."""
+    n_per, d, T, m = 1500, 6, 4, 320
+    xs = np.concatenate([mo.gaussian_mixture(n_per, d, seed=80 + t) + 0.25 * t for t in range(T)])
+    times = np.repeat(np.arange(float(T)), n_per)
+    xt = np.ascontiguousarray(np.column_stack([xs, times]))
+    nn = mo.per_time_nn_distances(xs, times)
+    lm = xt[:: xt.shape[0] // m][:m].copy()
+    ref = mo.density_fit(xt, landmarks=lm, nn_distances=nn, ls_time=1.5, lbfgsb_options=mo.LBFGSB_TIGHT)
+    for mixed in ("1", "0"):
+        monkeypatch.setenv("MELLON_AMD_MIXED", mixed)
+        est = mellon.TimeSensitiveDensityEstimator(landmarks=lm, nn_distances=nn, ls_time=1.5)
+        dens = est.fit_predict(xt)
+        assert rel_max(dens, ref.log_density_x) < 1e-5 and rel_std(dens, ref.log_density_x) < 1e-5
