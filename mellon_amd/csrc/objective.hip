@@ -81,16 +81,96 @@ __device__ __forceinline__ void load_lik(const ObjArgs& a, int64_t row, double (
   }
 }
 
-template <int CPT, int R, int MODE, bool KEEP>
+// VEC variants (few column pairs per thread: m <= 3072): lane l < R owns row l of the step -- its V / Vdr arrive as ONE
+// vector load per lane instead of R wave-uniform ones
+template <int R>
+__device__ __forceinline__ void load_lik_vec(const ObjArgs& a, int64_t row, int tid, double (&pv)[2][R]) {
+  const RowMap rm = row_map(a);
+  const int lane = tid & 63;
+  const int64_t want = row + (lane < R ? lane : R - 1);
+  const int64_t i = rm((want < a.n) ? want : (a.n - 1));
+  pv[0][0] = a.V[i];
+  pv[1][0] = a.Vdr[i];
+}
+
+__device__ __forceinline__ double read_lane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum R = 2^K per-lane values over the 64 lanes of a wave with R - 1 + (6 - K) exchanges instead of 6 R: at each of the
+// first K steps a lane keeps one half of its values and hands the other half to its partner, so that afterwards lane l
+// holds ONE partial sum, of row l >> (6 - K); the remaining 6 - K steps are plain butterflies.  Returns that row's total.
+template <int R>
+__device__ __forceinline__ double transposed_wave_sum(double (&v)[R], int lane) {
+  constexpr int K = (R == 16) ? 4 : (R == 8) ? 3 : (R == 4) ? 2 : (R == 2) ? 1 : 0;
+  static_assert((1 << K) == R, "R must be a power of two <= 16");
+#pragma unroll
+  for (int st = 0; st < K; ++st) {
+    const int half = R >> (st + 1), mask = 32 >> st;
+    const bool upper = (lane & mask) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const double send = upper ? v[i] : v[i + half];
+      const double keep = upper ? v[i + half] : v[i];
+      v[i] = keep + __shfl_xor(send, mask, 64);
+    }
+  }
+  double s = v[0];
+#pragma unroll
+  for (int mask = 32 >> K; mask > 0; mask >>= 1) s += __shfl_xor(s, mask, 64);
+  return s;
+}
+
+template <int CPT, int R, int MODE, bool KEEP, bool VEC = false>
 __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                              const d2 (&v)[R][CPT], const d2 (&z)[CPT], d2 (&g)[CPT],
                                              d2 (&h)[CPT], double& loss, double (*red)[8][R], double* fstage,
                                              int64_t fbase, const double (&pv)[2][R]) {
   double coef[R], aexp[R];
   const RowMap rm = row_map(a);
-  if (MODE == MODE_GEMVT) {
+  if constexpr (MODE == MODE_GEMVT) {
 #pragma unroll
     for (int r = 0; r < R; ++r) coef[r] = (row + r < row_end) ? a.weights[rm(row + r)] : 0.0;
+  } else if constexpr (VEC && (MODE == MODE_OBJ || MODE == MODE_OBJ_HESS)) {
+    // With one to three column pairs per thread the per-row work that does not shrink with m -- six exchanges per row for
+    // the wave's dot product, an exp evaluated by EVERY thread for EVERY row -- outweighs the FMAs (C4, m = 2000: 5.0 TB/s;
+    // C2, m = 1000: less).  Here the R dot products are reduced together (transposed_wave_sum), and after the barrier
+    // lane l < R alone finishes row l: cross-wave sum, f, exp, likelihood term; the coefficients go back to all lanes
+    // through scalar registers (v_readlane).  One exp sequence per step instead of R.
+    double dot[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        s = fma(v[r][c].x, z[c].x, s);
+        s = fma(v[r][c].y, z[c].y, s);
+      }
+      dot[r] = s;
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int GRP = 64 / R;                       // lanes that end up with the same row's total
+    const double tot = transposed_wave_sum<R>(dot, lane);
+    if ((lane & (GRP - 1)) == 0) red[par][wave][lane / GRP] = tot;
+    __syncthreads();   // full fence on purpose: see the note at lds_barrier_unused
+    const int rl = lane < R ? lane : R - 1;
+    double sr = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sr += red[par][w][rl];
+    const bool rok = lane < R && (row + rl) < row_end;
+    const double f = sr + a.mu;
+    const double Vi = KEEP ? pv[0][0] : (rok ? a.V[rm(row + rl)] : 0.0);
+    const double e = rok ? exp(f + Vi) : 0.0;
+    const double cf = rok ? (e - 1.0) : 0.0;
+    if (wave == 0 && rok) loss -= (f + (KEEP ? pv[1][0] : a.Vdr[rm(row + rl)])) - e;   // inference.py:89-91 (summed over lanes at the end)
+    if (KEEP) lds_store_f64(fstage, (wave == 0 && rok) ? (int)(row + rl - fbase) : (MLN_FSTAGE + tid), f);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      coef[r] = read_lane_f64(cf, r);
+      aexp[r] = (MODE == MODE_OBJ_HESS) ? read_lane_f64(e, r) : 0.0;
+    }
   } else {
     double dot[R];
 #pragma unroll
@@ -155,7 +235,7 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
   }
 }
 
-template <int CPT, int R, int MODE, bool KEEP = false>
+template <int CPT, int R, int MODE, bool KEEP = false, bool VEC = false>
 __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   if (a.gate && (*a.gate & 3) != a.gate_want) return;   // uniform: the device-resident solver chose the other copy / is done
   if (a.gate2 && *a.gate2 != a.gate2_want) return;      //          ... or another subsample level
@@ -194,15 +274,16 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   double pa[2][R], pb[2][R];
   const RowMap rm = row_map(a);
   const unsigned lim = a.seg_cols > 0 ? (unsigned)(a.seg_left / 2) : (unsigned)ld2;
-  if (s_beg < s_end) { load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va, rm, lim); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
+  auto lik = [&](int64_t r0, double (&pv)[2][R]) { if (VEC) load_lik_vec<R>(a, r0, tid, pv); else load_lik<R>(a, r0, pv); };
+  if (s_beg < s_end) { load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va, rm, lim); if (KEEP) lik(s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
     load_rows<CPT, R>(L2, ld2, s1 * R, a.n, tid, vb, rm, lim);
-    if (KEEP) load_lik<R>(a, s1 * R, pb);
-    process_rows<CPT, R, MODE, KEEP>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red, fstage, fbase, pa);
+    if (KEEP) lik(s1 * R, pb);
+    process_rows<CPT, R, MODE, KEEP, VEC>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red, fstage, fbase, pa);
     load_rows<CPT, R>(L2, ld2, s2 * R, a.n, tid, va, rm, lim);
-    if (KEEP) load_lik<R>(a, s2 * R, pa);
-    if (s + 1 < s_end) process_rows<CPT, R, MODE, KEEP>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red, fstage, fbase, pb);
+    if (KEEP) lik(s2 * R, pa);
+    if (s + 1 < s_end) process_rows<CPT, R, MODE, KEEP, VEC>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red, fstage, fbase, pb);
   }
   if (KEEP) {
     __syncthreads();
@@ -226,6 +307,10 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
         const int64_t col = 2 * ((int64_t)c * WG + tid);
         if (col < a.m_pad) *reinterpret_cast<d2*>(ph + col) = h[c];
       }
+    }
+    if (VEC) {      // the likelihood terms sit in lanes 0 .. R-1 of wave 0
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
     }
     if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss * osc;
   }
@@ -548,15 +633,15 @@ __global__ __launch_bounds__(256) void k_gemv_rows_tri(GemvTri g) {
   }
 }
 
-template <int CPT, int R>
+template <int CPT, int R, bool VEC = false>
 int launch_mode(mln_ctx* ctx, const ObjArgs& a, int mode) {
   dim3 grid((unsigned)a.n_wg), block(WG);
   switch (mode) {
     case MODE_OBJ:
-      if (a.f_slot) hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ, true>), grid, block, 0, ctx->stream, a);
-      else hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ>), grid, block, 0, ctx->stream, a);
+      if (a.f_slot) hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ, true, VEC>), grid, block, 0, ctx->stream, a);
+      else hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ, false, VEC>), grid, block, 0, ctx->stream, a);
       break;
-    case MODE_OBJ_HESS: hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ_HESS>), grid, block, 0, ctx->stream, a); break;
+    case MODE_OBJ_HESS: hipLaunchKernelGGL((k_objective<CPT, R, MODE_OBJ_HESS, false, VEC>), grid, block, 0, ctx->stream, a); break;
     case MODE_GEMVT: hipLaunchKernelGGL((k_objective<CPT, R, MODE_GEMVT>), grid, block, 0, ctx->stream, a); break;
     default: hipLaunchKernelGGL((k_objective<CPT, R, MODE_FONLY>), grid, block, 0, ctx->stream, a); break;
   }
@@ -682,10 +767,14 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   const int64_t pairs = a.seg_cols > 0 ? (a.seg_cols + 1) / 2 : a.ldl / 2;
   const int cpt = (int)((pairs + WG - 1) / WG);
   // rows per step chosen so that one register set holds <= 12 double2 per thread
+  // (few column pairs per thread: the row-per-lane likelihood with more rows per barrier, see process_rows;
+  //  MELLON_AMD_OBJ_VEC=0 selects the plain variants)
+  const char* ev = std::getenv("MELLON_AMD_OBJ_VEC");
+  const bool vec = !(ev && std::atoi(ev) == 0) && (mode == MODE_OBJ || mode == MODE_OBJ_HESS);
   switch (cpt) {
-    case 1: return launch_mode<1, 8>(ctx, a, mode);
-    case 2: return launch_mode<2, 5>(ctx, a, mode);
-    case 3: return launch_mode<3, 3>(ctx, a, mode);
+    case 1: return vec ? launch_mode<1, 16, true>(ctx, a, mode) : launch_mode<1, 8>(ctx, a, mode);
+    case 2: return vec ? launch_mode<2, 8, true>(ctx, a, mode) : launch_mode<2, 5>(ctx, a, mode);
+    case 3: return vec ? launch_mode<3, 4, true>(ctx, a, mode) : launch_mode<3, 3>(ctx, a, mode);
     case 4: return launch_mode<4, 2>(ctx, a, mode);
     case 5: return launch_mode<5, 2>(ctx, a, mode);
     case 6: return launch_mode<6, 2>(ctx, a, mode);
