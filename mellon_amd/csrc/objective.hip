@@ -161,10 +161,10 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
     for (int w = 0; w < 8; ++w) sr += red[par][w][rl];
     const bool rok = lane < R && (row + rl) < row_end;
     const double f = sr + a.mu;
-    const double Vi = KEEP ? pv[0][0] : (rok ? a.V[rm(row + rl)] : 0.0);
+    const double Vi = pv[0][0];                       // (this lane's row: load_lik_vec)
     const double e = rok ? exp(f + Vi) : 0.0;
     const double cf = rok ? (e - 1.0) : 0.0;
-    if (wave == 0 && rok) loss -= (f + (KEEP ? pv[1][0] : a.Vdr[rm(row + rl)])) - e;   // inference.py:89-91 (summed over lanes at the end)
+    if (wave == 0 && rok) loss -= (f + pv[1][0]) - e;   // inference.py:89-91 (summed over lanes at the end)
     if (KEEP) lds_store_f64(fstage, (wave == 0 && rok) ? (int)(row + rl - fbase) : (MLN_FSTAGE + tid), f);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -275,14 +275,15 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
   const RowMap rm = row_map(a);
   const unsigned lim = a.seg_cols > 0 ? (unsigned)(a.seg_left / 2) : (unsigned)ld2;
   auto lik = [&](int64_t r0, double (&pv)[2][R]) { if (VEC) load_lik_vec<R>(a, r0, tid, pv); else load_lik<R>(a, r0, pv); };
-  if (s_beg < s_end) { load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va, rm, lim); if (KEEP) lik(s_beg * R, pa); }
+  constexpr bool PRE = KEEP || (VEC && (MODE == MODE_OBJ || MODE == MODE_OBJ_HESS));   // V / Vdr travel with the rows (a per-lane load after the barrier would drain the prefetch)
+  if (s_beg < s_end) { load_rows<CPT, R>(L2, ld2, s_beg * R, a.n, tid, va, rm, lim); if (PRE) lik(s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
     load_rows<CPT, R>(L2, ld2, s1 * R, a.n, tid, vb, rm, lim);
-    if (KEEP) lik(s1 * R, pb);
+    if (PRE) lik(s1 * R, pb);
     process_rows<CPT, R, MODE, KEEP, VEC>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red, fstage, fbase, pa);
     load_rows<CPT, R>(L2, ld2, s2 * R, a.n, tid, va, rm, lim);
-    if (KEEP) lik(s2 * R, pa);
+    if (PRE) lik(s2 * R, pa);
     if (s + 1 < s_end) process_rows<CPT, R, MODE, KEEP, VEC>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red, fstage, fbase, pb);
   }
   if (KEEP) {
@@ -347,7 +348,7 @@ __device__ __forceinline__ double elem32(float v) {
   return FIXED ? (double)__float_as_uint(v) : (double)v;
 }
 
-template <int CQ, int R, bool GEMVT, bool KEEP, int NW, bool FIXED>
+template <int CQ, int R, bool GEMVT, bool KEEP, int NW, bool FIXED, bool VEC = false>
 __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                                const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
                                                double& loss, double (*red)[NW][R], double* fstage, int64_t fbase,
@@ -369,6 +370,41 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     }
     return;
   }
+  if constexpr (VEC) {   // one or two column quads per thread: rows reduced together, one lane per row (see process_rows)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        s = fma(elem32<FIXED>(v[r][c].x), z[c][0], s);
+        s = fma(elem32<FIXED>(v[r][c].y), z[c][1], s);
+        s = fma(elem32<FIXED>(v[r][c].z), z[c][2], s);
+        s = fma(elem32<FIXED>(v[r][c].w), z[c][3], s);
+      }
+      dot[r] = s;
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    constexpr int GRP = 64 / R;
+    const double tot = transposed_wave_sum<R>(dot, lane);
+    if ((lane & (GRP - 1)) == 0) red[par][wave][lane / GRP] = tot;
+    __syncthreads();   // full fence on purpose: see the note at lds_barrier_unused
+    const int rl = lane < R ? lane : R - 1;
+    double sr = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sr += red[par][w][rl];
+    const bool rok = lane < R && (row + rl) < row_end;
+    const double f = sr + a.mu;
+    const double Vi = pv[0][0];
+    const double tt = f + Vi;
+    const bool over = tt > capv;
+    const double ex = exp(over ? capv : tt);
+    const double e = rok ? (over ? ecap * (1.0 + (tt - capv)) : ex) : 0.0;
+    const double cf = rok ? (ex - 1.0) : 0.0;
+    if (wave == 0 && rok) loss -= (f + pv[1][0]) - e;
+    if (KEEP) lds_store_f64(fstage, (wave == 0 && rok) ? (int)(row + rl - fbase) : (MLN_FSTAGE + tid), f);
+#pragma unroll
+    for (int r = 0; r < R; ++r) coef[r] = read_lane_f64(cf, r);
+  } else {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     double s = 0.0;
@@ -406,6 +442,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     else if (tid == 0 && rok) loss -= (f + a.Vdr[rm(row + r)]) - e;
     if (KEEP) lds_store_f64(fstage, (tid == 0 && rok) ? (int)(row + r - fbase) : (MLN_FSTAGE + tid), f);   // see k_objective
   }
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -420,7 +457,7 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
 
 // NW waves per workgroup: a row of ld4 column quads is spread over 64 NW CQ lane slots, and NW is chosen so that few
 // of them are idle (m = 5000: 1252 quads on 7 x 64 x 3 = 1344 slots, 93 %; 8 waves would use 81 % of 1536)
-template <int CQ, int R, bool GEMVT = false, bool KEEP = false, int NW = 8, bool FIXED = false>
+template <int CQ, int R, bool GEMVT = false, bool KEEP = false, int NW = 8, bool FIXED = false, bool VEC = false>
 __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   if (a.gate && (*a.gate & 3) != a.gate_want) return;
   if (a.gate2 && *a.gate2 != a.gate2_want) return;
@@ -452,15 +489,17 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
   const int64_t s_last = s_end - 1;
   double pa[2][R], pb[2][R];
   const RowMap rm = row_map(a);
-  if (s_beg < s_end) { load_rows32<CQ, R, NW>(L4, ld4, s_beg * R, a.n, tid, va, rm); if (KEEP) load_lik<R>(a, s_beg * R, pa); }
+  constexpr bool PRE = KEEP || (VEC && !GEMVT);
+  auto lik = [&](int64_t r0, double (&pv)[2][R]) { if (VEC) load_lik_vec<R>(a, r0, tid, pv); else load_lik<R>(a, r0, pv); };
+  if (s_beg < s_end) { load_rows32<CQ, R, NW>(L4, ld4, s_beg * R, a.n, tid, va, rm); if (PRE) lik(s_beg * R, pa); }
   for (int64_t s = s_beg; s < s_end; s += 2) {   // unconditional loads: see k_objective
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
     load_rows32<CQ, R, NW>(L4, ld4, s1 * R, a.n, tid, vb, rm);
-    if (KEEP) load_lik<R>(a, s1 * R, pb);
-    process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa, capv, ecap);
+    if (PRE) lik(s1 * R, pb);
+    process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED, VEC>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa, capv, ecap);
     load_rows32<CQ, R, NW>(L4, ld4, s2 * R, a.n, tid, va, rm);
-    if (KEEP) load_lik<R>(a, s2 * R, pa);
-    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb, capv, ecap);
+    if (PRE) lik(s2 * R, pa);
+    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED, VEC>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb, capv, ecap);
   }
   if (KEEP) {
     __syncthreads();
@@ -478,34 +517,38 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
       *reinterpret_cast<d2*>(pg + col + 2) = (d2){g[c][2] * sc, g[c][3] * sc};
     }
   }
+  if (VEC) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
+  }
   if (tid == 0 && a.part_loss) a.part_loss[blockIdx.x] = loss * (a.out_scale != 0.0 ? a.out_scale : 1.0);
 }
 
-template <int CQ, int R, int NW>
+template <int CQ, int R, int NW, bool VEC = false>
 int launch_f32_nw(mln_ctx* ctx, const ObjArgs& a) {
   const dim3 grid((unsigned)a.n_wg), block(64 * NW);
   // (never the f-keeping variant: what the 32-bit copy yields is not the final log-density, and its variant of the
   //  loop measured 3.58 instead of 3.23 ms per pass)
   if (a.l32_fixed) {
     if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true, false, NW, true>), grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW, true>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW, true, VEC>), grid, block, 0, ctx->stream, a);
   } else {
     if (a.weights) hipLaunchKernelGGL((k_objective32<CQ, R, true, false, NW>), grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_objective32<CQ, R, false, false, NW, false, VEC>), grid, block, 0, ctx->stream, a);
   }
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
 
-template <int CQ, int R>
+template <int CQ, int R, bool VEC = false>
 int launch_f32(mln_ctx* ctx, const ObjArgs& a) {
   const int64_t ld4 = a.ldl / 4;
   int nw = (int)((ld4 + 64 * CQ - 1) / (64 * CQ));
   static const int force = std::getenv("MELLON_AMD_OBJ32_WAVES") ? std::atoi(std::getenv("MELLON_AMD_OBJ32_WAVES")) : 0;
   if (force >= 6 && force <= 8 && (int64_t)force * 64 * CQ >= ld4) nw = force;
-  if (nw <= 6) return launch_f32_nw<CQ, R, 6>(ctx, a);
-  if (nw == 7) return launch_f32_nw<CQ, R, 7>(ctx, a);
-  return launch_f32_nw<CQ, R, 8>(ctx, a);
+  if (nw <= 6) return launch_f32_nw<CQ, R, 6, VEC>(ctx, a);
+  if (nw == 7) return launch_f32_nw<CQ, R, 7, VEC>(ctx, a);
+  return launch_f32_nw<CQ, R, 8, VEC>(ctx, a);
 }
 
 __global__ void k_to_f32(const double* __restrict__ src, float* __restrict__ dst, int64_t count) {
@@ -749,9 +792,11 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   else if (a.part_hess) mode = MODE_OBJ_HESS;
   if (a.L32 && (mode == MODE_OBJ || mode == MODE_GEMVT) && a.ldl % 4 == 0) {   // fp32 copy: 4 columns per 16-byte lane load
     const int cq = (int)((a.ldl / 4 + WG - 1) / WG);
+    const char* ev32 = std::getenv("MELLON_AMD_OBJ_VEC");
+    const bool vec32 = !(ev32 && std::atoi(ev32) == 0) && mode == MODE_OBJ;
     switch (cq) {
-      case 1: return launch_f32<1, 8>(ctx, a);
-      case 2: return launch_f32<2, 4>(ctx, a);
+      case 1: return vec32 ? launch_f32<1, 8, true>(ctx, a) : launch_f32<1, 8>(ctx, a);     // (R = 16 / 8 spill: the widening to
+      case 2: return vec32 ? launch_f32<2, 4, true>(ctx, a) : launch_f32<2, 4>(ctx, a);     //  fp64 doubles the registers per element)
       case 3: {
         static const int r3 = std::getenv("MELLON_AMD_OBJ32_ROWS") ? std::atoi(std::getenv("MELLON_AMD_OBJ32_ROWS")) : 3;
         if (r3 == 4) return launch_f32<3, 4>(ctx, a);
@@ -772,7 +817,7 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   const char* ev = std::getenv("MELLON_AMD_OBJ_VEC");
   const bool vec = !(ev && std::atoi(ev) == 0) && (mode == MODE_OBJ || mode == MODE_OBJ_HESS);
   switch (cpt) {
-    case 1: return vec ? launch_mode<1, 16, true>(ctx, a, mode) : launch_mode<1, 8>(ctx, a, mode);
+    case 1: return vec ? launch_mode<1, 8, true>(ctx, a, mode) : launch_mode<1, 8>(ctx, a, mode);     // (R = 16 spills)
     case 2: return vec ? launch_mode<2, 8, true>(ctx, a, mode) : launch_mode<2, 5>(ctx, a, mode);
     case 3: return vec ? launch_mode<3, 4, true>(ctx, a, mode) : launch_mode<3, 3>(ctx, a, mode);
     case 4: return launch_mode<4, 2>(ctx, a, mode);
