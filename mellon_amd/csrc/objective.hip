@@ -799,6 +799,9 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
       case 2: return vec32 ? launch_f32<2, 4, true>(ctx, a) : launch_f32<2, 4>(ctx, a);     //  fp64 doubles the registers per element)
       case 3: {
         static const int r3 = std::getenv("MELLON_AMD_OBJ32_ROWS") ? std::atoi(std::getenv("MELLON_AMD_OBJ32_ROWS")) : 3;
+        // row-per-lane likelihood (see process_rows): m = 5000, 7 waves: <3, 2, VEC> 2.93 ms per pass = 0.855 of the HBM
+        // spec against 3.19 ms = 0.786 for the plain <3, 3>; <3, 4, VEC> 3.16 ms
+        if (vec32 && !std::getenv("MELLON_AMD_OBJ32_ROWS")) return launch_f32<3, 2, true>(ctx, a);
         if (r3 == 4) return launch_f32<3, 4>(ctx, a);
         if (r3 == 5) return launch_f32<3, 5>(ctx, a);
         if (r3 == 2) return launch_f32<3, 2>(ctx, a);
