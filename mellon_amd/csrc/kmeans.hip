@@ -84,23 +84,29 @@ __global__ __launch_bounds__(256) void k_seed_update_h(const _Float16* __restric
   const double unscale = 1.0 / (prep[64] * prep[64]);
   __syncthreads();
   typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+  // Eight lanes per cell, one 16-byte piece of its 128-byte line each: a wave reads 8 consecutive lines = 1 KB in one
+  // instruction.  (One lane per cell -- 64 lanes, 64 different lines per load instruction -- ran at 2.1 TB/s: 61 us per
+  // update at 1e6 cells, 0.3 s of a 5000-centre seeding.)
   const int64_t base = (int64_t)blockIdx.x * SBLK;
-  double acc = 0.0;
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;      // piece of the line, cell within the pass of 32
   const int dk = (d + 7) / 8;
-  for (int q = 0; q < SBLK / 256; ++q) {
-    const int64_t i = base + q * 256 + threadIdx.x;
-    if (i < n) {
-      const h8_t* row = reinterpret_cast<const h8_t*>(xh + i * 128);
-      float s = 0.f;
-      for (int g = 0; g < dk; ++g) {
-        const h8_t v = row[g];
+  double acc = 0.0;
+  for (int q = 0; q < SBLK / 32; ++q) {
+    const int64_t i = base + q * 32 + grp;
+    float s = 0.f;
+    if (i < n && sub < dk) {
+      const h8_t v = *reinterpret_cast<const h8_t*>(xh + i * 128 + 8 * sub);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int k = 8 * g + e;
-          const float t = (k < d) ? (float)v[e] * inv_scale - cs[k] : 0.f;
-          s = fmaf(t, t, s);
-        }
+      for (int e = 0; e < 8; ++e) {
+        const int k = 8 * sub + e;
+        const float t = (k < d) ? (float)v[e] * inv_scale - cs[k] : 0.f;
+        s = fmaf(t, t, s);
       }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (i < n && sub == 0) {
       double sd = (double)s * unscale;
       if (!first) sd = fmin(sd, mind[i]);
       mind[i] = sd;
