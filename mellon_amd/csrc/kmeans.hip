@@ -73,14 +73,14 @@ __global__ void k_seed_pick(const double* __restrict__ mind, int64_t n, int64_t 
 // The same update from the half-precision copy of the cells (rowmin_f16.hip split rows, hi halves: one 128-byte line per
 // cell instead of 400 bytes): D^2 only weights the k-means++ draw, three significant digits are plenty, and the 5000
 // sequential updates of a 1e6-cell seeding are pure memory traffic.  scale: the copy holds scale * x.
-__global__ __launch_bounds__(256) void k_seed_update_h(const _Float16* __restrict__ xh, int64_t n, int d, float inv_scale,
+__global__ __launch_bounds__(1024) void k_seed_update_h(const _Float16* __restrict__ xh, int64_t n, int d, float inv_scale,
                                                        const double* __restrict__ c, const double* __restrict__ prep,
                                                        double* __restrict__ mind, double* __restrict__ bsum, int first) {
   __shared__ float cs[64];
-  __shared__ double red[256];
+  __shared__ double red[1024];
   // the copy holds -2 (x - centre) * scale (rowmin_prepare): the centre goes through the same map, D^2 comes back in the
   // data's units
-  for (int k = threadIdx.x; k < 64; k += 256) cs[k] = (k < d) ? (float)((c[k] - prep[k]) * prep[64]) : 0.f;
+  for (int k = threadIdx.x; k < 64; k += 1024) cs[k] = (k < d) ? (float)((c[k] - prep[k]) * prep[64]) : 0.f;
   const double unscale = 1.0 / (prep[64] * prep[64]);
   __syncthreads();
   typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
@@ -88,11 +88,11 @@ __global__ __launch_bounds__(256) void k_seed_update_h(const _Float16* __restric
   // instruction.  (One lane per cell -- 64 lanes, 64 different lines per load instruction -- ran at 2.1 TB/s: 61 us per
   // update at 1e6 cells, 0.3 s of a 5000-centre seeding.)
   const int64_t base = (int64_t)blockIdx.x * SBLK;
-  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;      // piece of the line, cell within the pass of 32
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;      // piece of the line, cell within the pass of 128
   const int dk = (d + 7) / 8;
   double acc = 0.0;
-  for (int q = 0; q < SBLK / 32; ++q) {
-    const int64_t i = base + q * 32 + grp;
+  for (int q = 0; q < SBLK / 128; ++q) {
+    const int64_t i = base + q * 128 + grp;
     float s = 0.f;
     if (i < n && sub < dk) {
       const h8_t v = *reinterpret_cast<const h8_t*>(xh + i * 128 + 8 * sub);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_seed_update_h(const _Float16* __restric
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 512; off > 0; off >>= 1) {
     if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
@@ -440,7 +440,7 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   if (rc == MLN_OK) chk(hipMemcpyAsync(dc, dx + cur * d, sizeof(double) * d, hipMemcpyDeviceToDevice, st));
   for (int64_t j = 0; j + 1 < m && rc == MLN_OK; ++j) {
     if (seed_h)
-      hipLaunchKernelGGL(k_seed_update_h, dim3((unsigned)nblk), dim3(256), 0, st, reinterpret_cast<const _Float16*>(xsplit), n, d,
+      hipLaunchKernelGGL(k_seed_update_h, dim3((unsigned)nblk), dim3(1024), 0, st, reinterpret_cast<const _Float16*>(xsplit), n, d,
                          -0.5f, dc + j * d, prep, mind, bsum, j == 0 ? 1 : 0);
     else
       hipLaunchKernelGGL(k_seed_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
