@@ -260,7 +260,11 @@ class Context:
             raise ValueError(f"libmellon_hip: {msg}")
         if rc == MLN_ERR_UNSUPPORTED:
             raise NotImplementedError(f"libmellon_hip: {msg}")
-        raise MellonHipError(f"libmellon_hip error {rc}: {msg}")
+        cause = None
+        staged = getattr(self, "_host_collective", None)
+        if staged is not None and getattr(staged[1], "failure", None) is not None:
+            cause, staged[1].failure = staged[1].failure, None     # what the host-staged collective's callback ran into
+        raise MellonHipError(f"libmellon_hip error {rc}: {msg}" + (f" ({type(cause).__name__}: {cause})" if cause else "")) from cause
 
     # -- info / memory ---------------------------------------------------------------------------
     def device_info(self):
