@@ -79,7 +79,8 @@ def main(a):
           "v_mfma_f64_16x16x4_f64 (2048 flop), frac = that / 78.6 TFLOP/s; on gfx950 the fp64 matrix pipe runs at the fp64 "
           "vector rate, so frac is also the share of the CU's fp64 issue slots spent in MFMAs.  k_gram_i8: every matrix "
           "instruction is v_mfma_i32_32x32x32_i8 (65536 integer operations), frac = that / 3944 TOP/s (the measured "
-          "int8 ceiling of guides/MI355X_MICROARCH.md).", "kernels": {}}
+          "int8 ceiling of guides/MI355X_MICROARCH.md).  k_rowmin_f16x3 (1-NN pre-filter, k-means assignment): "
+          "v_mfma_f32_32x32x16_f16 (32768 flop) against the 2500 TFLOP/s dense fp16 peak.", "kernels": {}}
     for k, cs in sq.items():
         if "SQ_INSTS_MFMA" not in cs:
             continue
@@ -89,12 +90,13 @@ def main(a):
         v, d = max(vals, key=lambda q: q[1])            # the largest launch of this kernel
         tot_v, tot_d = sum(q[0] for q in vals), sum(q[1] for q in vals)
         i8 = k.startswith("k_gram_i8")
-        per, peak = (65536, INT8_PEAK_TOPS) if i8 else (2048, FP64_PEAK_TF)
+        f16 = "k_rowmin_f16x3" in k                      # v_mfma_f32_32x32x16_f16: 32768 flop, dense fp16 peak 2500 TFLOP/s
+        per, peak = (65536, INT8_PEAK_TOPS) if i8 else ((32768, 2500.0) if f16 else (2048, FP64_PEAK_TF))
         mf["kernels"][k] = {"launches": len(vals), "largest_launch_us": d / 1e3, "largest_launch_tflops": v * per / d / 1e3,
                             "largest_launch_frac_of_peak": v * per / d / 1e3 / peak,
                             "all_launches_tflops": tot_v * per / tot_d / 1e3,
                             "all_launches_frac_of_peak": tot_v * per / tot_d / 1e3 / peak,
-                            "unit": "TOP/s (int8)" if i8 else "TFLOP/s (fp64)"}
+                            "unit": "TOP/s (int8)" if i8 else ("TFLOP/s (fp16, fp32 accumulate)" if f16 else "TFLOP/s (fp64)")}
     mf["source"] = f"rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace, bench.py --steps 1 --warmup 0 ({tag})"
     json.dump(mf, open("profiles/mfma_util.json", "w"), indent=1)
     print(json.dumps({"traffic64": t64["hbm_bytes_per_launch"] / t64["algorithmic_bytes_per_launch"],
