@@ -19,11 +19,19 @@
 #include "mln_internal.h"
 #include "linalg.h"
 
+// Phase stamps for tools/potrf_probe.py: build with -DMLN_POTRF_TIMING (100 MHz wall clock in [0, 32), shader clock in [32, 64))
+#ifdef MLN_POTRF_TIMING
+__device__ long long g_potrf_ts[64];
+#define TS(i) do { if (threadIdx.x == 0) { g_potrf_ts[i] = wall_clock64(); g_potrf_ts[32 + i] = clock64(); } } while (0)
+#else
+#define TS(i) do { } while (0)
+#endif
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int NB = 128, LDT = 130, MB = 16, NMB = NB / MB, LDX = 18;
+constexpr bool NEWTON2 = true;     // (one step: no faster -- the chain is hidden behind the LDS round trip -- and 3e-15 instead of 5e-16 backward error)
 
 __device__ __forceinline__ double bcast_lane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -45,56 +53,99 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
   double* Xd = smem + NB * LDT;            // NMB x MB x LDX: inverses of the 16 x 16 diagonal tiles
   __shared__ int bad_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  TS(0);
   if (tid == 0) bad_s = 0;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 7, j = e & 127;
-    T[i * LDT + j] = (i < nb && j <= i) ? A[(int64_t)i * lda + j] : ((i == j) ? 1.0 : 0.0);
+  // 128 x 128 doubles as 8192 pairs, 32 per thread in two batches of sixteen UNCONDITIONAL loads (clamped row, value
+  // selected afterwards): the branchy one-element-at-a-time form waited for every load on its own -- 11.7 us of a 66 us
+  // kernel (s_memtime stamps, tools/potrf_probe.py).  lda is even and A 16-byte aligned wherever this is called from.
+  {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const bool pairs_ok = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      d2_t v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * (16 * b + q), i = e >> 6, j = (e & 63) * 2;
+        const int ic = (i < nb) ? i : (nb - 1), jc = (j + 1 < nb) ? j : 0;
+        if (pairs_ok) v[q] = *reinterpret_cast<const d2_t*>(A + (int64_t)ic * lda + jc);
+        else { v[q].x = A[(int64_t)ic * lda + jc]; v[q].y = A[(int64_t)ic * lda + jc + 1]; }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int e = tid + 256 * (16 * b + q), i = e >> 6, j = (e & 63) * 2;
+        const bool in0 = i < nb && j <= i && j + 1 < nb, in1 = i < nb && j + 1 <= i && j + 1 < nb;
+        double x0 = in0 ? v[q].x : ((i == j) ? 1.0 : 0.0);
+        double x1 = in1 ? v[q].y : ((i == j + 1) ? 1.0 : 0.0);
+        if (i < nb && j <= i && j + 1 >= nb) x0 = A[(int64_t)i * lda + j];      // (odd nb: the last column, alone)
+        T[i * LDT + j] = x0;
+        T[i * LDT + j + 1] = x1;
+      }
+    }
   }
   __syncthreads();
+  TS(1);
 
   // (a) diagonal tile p: Cholesky in registers + inverse, by wave 0 alone (every 16-lane group computes the same thing)
   auto diag_tile = [&](int p) {
+    // Broadcasts go through LDS, not through v_readlane: with ~250 lane broadcasts per tile the scalar registers they
+    // land in ran out (the compiler spilled 253 of them into VGPR lanes, 822 readlanes in all) and the tile took 11 000
+    // cycles.  Here lane i writes L_ik into the tile the moment it is final, and everybody reads column k / row k back
+    // with wave-uniform addresses (an LDS broadcast).  One wave: its LDS operations complete in order, no barrier.
     const int c0 = p * MB;
     const int li = lane & 15;
+    double* Tt = T + c0 * LDT + c0;                    // Tt[i * LDT + j]
     double a[MB];
 #pragma unroll
-    for (int j = 0; j < MB; ++j) a[j] = (j <= li) ? T[(c0 + li) * LDT + c0 + j] : 0.0;
-    double dinv[MB];
-    bool bad = false;
+    for (int j = 0; j < MB; ++j) a[j] = (j <= li) ? Tt[li * LDT + j] : 0.0;
+    double x[MB];      // column li of X = L^-1: x_k = (delta_{k,li} - sum_{j<k} L_kj x_j) / L_kk
+    int badk = -1;
+    // Software pipeline over the pivots: the next pivot's diagonal is a[k+1] - L_{k+1,k}^2 on lane k + 1 -- its OWN
+    // values, no broadcast -- so its reciprocal square root (the longest dependent chain of a pivot) is computed while
+    // column k travels through LDS to the other lanes.
+    // (tried: X by row operations on [L | I] -- k + 1 independent FMAs per pivot instead of the substitution's dependent
+    //  chain, but divergent over lanes and 270 more LDS operations: 14 500 instead of 9 100 cycles per tile)
+    double dk = bcast_lane(a[0], 0);
+    double inv = __builtin_amdgcn_rsq(dk);
+    inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
+    if (NEWTON2) inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
 #pragma unroll
     for (int k = 0; k < MB; ++k) {
-      const double dk = bcast_lane(a[k], k);
-      if (!(dk > 0.0)) {   // wave-uniform
-        if (!bad && lane == 0) { atomicCAS(info, 0, (int)(j0 + c0 + k + 1)); bad_s = 1; }
-        bad = true;
-      }
-      double inv = __builtin_amdgcn_rsq(dk);
-      inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
-      inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
-      double sq = dk * inv;
-      sq = fma(0.5 * inv, fma(-sq, sq, dk), sq);
-      dinv[k] = inv;
+      badk = (!(dk > 0.0) && badk < 0) ? k : badk;        // (reported after the loop: no branch inside the recurrence)
+      const double sq = dk * inv;                        // sqrt(dk) to ~1 ulp
       const double lik = (li == k) ? sq : ((li > k) ? a[k] * inv : 0.0);
       a[k] = lik;
+      if (lane < MB && li >= k) Tt[li * LDT + k] = lik;  // column k of L, final (same wave: later reads see it)
+      double lcol[MB];
 #pragma unroll
-      for (int j = k + 1; j < MB; ++j) {
-        const double ljk = bcast_lane(lik, j);
-        a[j] = fma(-lik, ljk, a[j]);
+      for (int j = k + 1; j < MB; ++j) lcol[j] = Tt[j * LDT + k];
+      // row k of L (final) for x_k; four partial sums keep the dependent chain short
+      double s0 = (k == li) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int j = 0; j < k; ++j) {
+        const double lkj = Tt[k * LDT + j];
+        if ((j & 3) == 0) s0 = fma(-lkj, x[j], s0);
+        else if ((j & 3) == 1) s1 = fma(-lkj, x[j], s1);
+        else if ((j & 3) == 2) s2 = fma(-lkj, x[j], s2);
+        else s3 = fma(-lkj, x[j], s3);
       }
-    }
-    // X = L^-1, lane c owns column c:  x_i = (delta_ic - sum_{k<i} L_ik x_k) / L_ii   (L_ik = a[k] of lane i)
-    double x[MB];
+      x[k] = ((s0 + s1) + (s2 + s3)) * inv;
+      double dk1 = 1.0, inv1 = 1.0;
+      if (k + 1 < MB) {
+        dk1 = bcast_lane(fma(-lik, lik, a[k + 1]), k + 1);
+        inv1 = __builtin_amdgcn_rsq(dk1);
+        inv1 = inv1 * fma(-0.5 * dk1, inv1 * inv1, 1.5);
+        if (NEWTON2) inv1 = inv1 * fma(-0.5 * dk1, inv1 * inv1, 1.5);
+      }
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
-      double s = (i == li) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < i; ++k) s = fma(-bcast_lane(a[k], i), x[k], s);
-      x[i] = s * dinv[i];
+      for (int j = k + 1; j < MB; ++j) a[j] = fma(-lik, lcol[j], a[j]);
+      dk = dk1; inv = inv1;
     }
+    if (badk >= 0 && lane == 0) { atomicCAS(info, 0, (int)(j0 + c0 + badk + 1)); bad_s = 1; }   // first non-positive / NaN pivot
     if (lane < MB) {
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
-        T[(c0 + li) * LDT + c0 + j] = (j <= li) ? a[j] : 0.0;
+        if (j > li) Tt[li * LDT + j] = 0.0;
         Xd[(p * MB + j) * LDX + li] = x[j];    // X[j][li]
       }
     }
@@ -118,6 +169,7 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
 
   if (wave == 0) diag_tile(0);
   __syncthreads();
+  TS(2);
   if (bad_s) return;   // uniform: leave the block unfactorised, *info says where
   for (int p = 0; p < NMB; ++p) {
     const int c0 = p * MB;
@@ -134,6 +186,7 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
       for (int r = 0; r < 4; ++r) T[(r0 + (lane >> 4) + 4 * r) * LDT + c0 + (lane & 15)] = acc[r];
     }
     __syncthreads();
+    TS(3 + 2 * p);
     if (p + 1 == NMB) break;
     // ---- (c) trailing tiles, with look-ahead: wave 0 updates the NEXT diagonal tile first and factors it right away
     //      (the serial 16-step recurrence of (a): ~3 us) while waves 1-3 update the other tiles ----------------------
@@ -141,21 +194,26 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
       const int nt = NMB - 1 - p;               // tiles per side
       const int ntri = nt * (nt + 1) / 2;
       if (wave == 0) {
+        if (p == 3) TS(23);
         trailing_tile(p, 0);                    // tile (p + 1, p + 1); LDS operations of one wave complete in order
         diag_tile(p + 1);
+        if (p == 3) TS(26);
       } else {
         for (int t = wave; t < ntri; t += 3) trailing_tile(p, t);
       }
     }
     __syncthreads();
+    TS(4 + 2 * p);
     if (bad_s) return;
   }
+  TS(20);
 
   // ---- factor back to global memory (strict upper part of the block zeroed) ------------------------------------
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e >> 7, j = e & 127;
     if (i < nb && j < nb) A[(int64_t)i * lda + j] = (j <= i) ? T[i * LDT + j] : 0.0;
   }
+  __syncthreads(); TS(21);
   // ---- X = T^-1 by block columns ----------------------------------------------------------------------------------
   for (int pass = 0; pass < 2; ++pass) {
     const int j = pass == 0 ? wave : (NMB - 1 - wave);
@@ -196,6 +254,7 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
       }
     }
   }
+  __syncthreads(); TS(22);
 }
 
 }  // namespace
@@ -213,3 +272,7 @@ int launch_potrf128(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, 
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
+
+#ifdef MLN_POTRF_TIMING
+extern "C" int mln_diag_potrf_times(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_potrf_ts), sizeof(long long) * 64) == hipSuccess ? 0 : 1; }
+#endif
