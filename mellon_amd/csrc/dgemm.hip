@@ -103,8 +103,13 @@ __global__ __launch_bounds__(256, 2) void k_dgemm(GemmArgs g, int64_t tiles_n, i
   constexpr int TW = BT / 32;   // MFMA tiles per wave and dimension
   __shared__ double As[BKT][BT + LPAD];
   __shared__ double Bs[BKT][BT + LPAD];
-  const int64_t bid = blockIdx.x;
-  const int64_t tm = bid / tiles_n, tn = bid % tiles_n;
+  // K-range modes 3 / 7: a tile's work grows with its row block (k <= row), so the row-major launch order ran the heaviest
+  // tiles LAST, alone on the chip; reversed, the long ones start first and the short ones fill the tail.
+  const bool heavy_last = g.kmode == 3 || g.kmode == 7 || g.kmode == 4;
+  const int64_t bid = heavy_last ? ((int64_t)gridDim.x - 1 - blockIdx.x) : (int64_t)blockIdx.x;
+  const int64_t tiles_m = ((int64_t)gridDim.x + tiles_n - 1) / tiles_n;
+  // (mode 4: k <= column -- the work grows with the COLUMN block: column-major order, reversed)
+  const int64_t tm = (g.kmode == 4) ? bid % tiles_m : bid / tiles_n, tn = (g.kmode == 4) ? bid / tiles_m : bid % tiles_n;
   if ((g.lower_only == 1 && tn > tm) || (g.lower_only == 2 && tn >= tm) || (g.lower_only == 3 && tn < tm)) return;
   const int64_t m0 = tm * BT, n0 = tn * BT;
   int64_t kbeg = (int64_t)blockIdx.y * kchunk;
