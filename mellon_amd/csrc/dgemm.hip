@@ -14,6 +14,7 @@
 // with register prefetch of the next k-tile issued before the MFMA block of the current one.
 // fp64 MFMA on gfx950 runs at the fp64 vector rate (64 cycles per 16x16x4 instruction per SIMD),
 // so a single LDS buffer + two barriers per k-tile leaves the matrix pipe as the limiter.
+#include <cstdlib>
 #include "mln_internal.h"
 
 namespace {
@@ -251,7 +252,10 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   {
     const int64_t t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.lower_only ? 2 : 1);
     const int64_t n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    if (t128 * (g.split_k > 1 ? g.split_k : 1) < n_cu && !inplace) bt = 64;
+    static const int64_t below = std::getenv("MELLON_AMD_GEMM64_BELOW") ? std::atoll(std::getenv("MELLON_AMD_GEMM64_BELOW")) : 0;
+    // (below 4 tiles per CU the 128-wide tiling leaves its last round of workgroups mostly empty -- 722 tiles on 512 slots
+    //  -- and four times as many 64-wide tiles pack better: factor + inverses 9.1 -> 8.5 ms, rebuild 17.7 -> 17.1 ms at m = 5000)
+    if (t128 * (g.split_k > 1 ? g.split_k : 1) < (below > 0 ? below : 4 * n_cu) && !inplace) bt = 64;
   }
   if (g_bk_override == 128 || g_bk_override == 64) bt = inplace ? 128 : g_bk_override;
   if (g.kmode == 1 || g.kmode == 2) bt = 128;   // the block-diagonal modes are defined on 128-wide blocks
