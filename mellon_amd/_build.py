@@ -14,7 +14,7 @@ SOURCES = ["api.hip", "alloc.hip", "comm.hip", "cov_grad.hip", "cov_kernels.hip"
            "cov_rows_exponential.hip", "predict_rows.hip", "predict_rows_prod.hip", "kernel_rows_prod_matern32.hip", "kernel_rows_prod_matern52.hip",
            "kernel_rows_prod_expquad.hip", "kernel_rows_prod_exponential.hip",
            "dgemm.hip", "diag.hip", "precond_rebuild.hip", "rowmin_f16.hip", "gram_i8.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip", "tridiag.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DMLN_POTRF_TIMING"] if __import__("os").environ.get("MLN_POTRF_TIMING") else [])
 
 
 def _deps(depfile, src):
