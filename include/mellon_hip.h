@@ -122,6 +122,16 @@ int mln_comm_init_loopback(mln_ctx* ctx, mln_loopback* group, int rank);
 typedef int (*mln_host_collective_fn)(void* user, int op, double* buf, double* buf2, int64_t count);
 int mln_comm_init_host(mln_ctx* ctx, int n_ranks, int rank, mln_host_collective_fn fn, void* user);
 void mln_loopback_abort(mln_loopback* group); /* a rank failed outside a collective: wake the others with MLN_ERR_RCCL */
+/* What the communicator of `ctx` is and what it has carried (no counterpart in the reference, which has no distributed
+ * code: this is how a multi-GPU bench line proves which transport ran -- SURVEY.md S8(e)).
+ *   info[4]  (nullable): transport 0 none / 1 RCCL / 2 in-process loopback / 3 host-staged; the rank count and the rank
+ *            AS THE TRANSPORT REPORTS THEM (ncclCommCount / ncclCommUserRank for RCCL; -1 if it cannot say); RCCL's
+ *            version code (0: not loaded).
+ *   stats[10] (nullable): calls, bytes of all-reduce | broadcast | all-gather since the last reset; the all-reduces of
+ *            <= 64 KB among them (the per-evaluation [grad ; loss]); event-timed milliseconds of the LARGE all-reduces,
+ *            of broadcasts + all-gathers, of the small all-reduces (0 unless timing is on; reading them synchronises).
+ *   flags:   1 = timing on (a pair of stream events around every collective), 2 = off, 4 = reset counters afterwards. */
+int mln_comm_info(mln_ctx* ctx, int32_t* info, double* stats, int32_t flags);
 
 /* ---- a-1..a-3: K = cov(x, y)   (util.py:351-366 distance, cov.py k(), base_cov.py Add/Mul/Pow)
  * x: n x d, y: m x d, out: n x m.                                                              */

@@ -69,6 +69,7 @@ SYMBOLS = [
     ("mln_comm_init_loopback", C.c_int, [_vp, _vp, C.c_int]),
     ("mln_comm_init_host", C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     ("mln_loopback_abort", None, [_vp]),
+    ("mln_comm_info", C.c_int, [_vp, C.POINTER(_i32), _dp, _i32]),
     ("mln_kernel_matrix", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_kernel_grad", C.c_int, [_vp, _KD, _dp, _i64, _dp, _i64, _i32, _dp]),
     ("mln_predict_gradient", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp, _dp]),
@@ -303,6 +304,21 @@ class Context:
         self._check(self.lib.mln_comm_init_host(self.handle, int(n_ranks), int(rank), C.cast(fn, C.c_void_p), None))
         self._host_collective = (fn, collective)          # keep the trampoline alive as long as the context
         self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def comm_info(self, timing=None, reset=False):
+        """Transport, the rank count / rank the TRANSPORT reports, and the collectives carried so far (mln_comm_info)."""
+        info = (_i32 * 4)()
+        stats = np.zeros(10, dtype=np.float64)
+        flags = (1 if timing is True else 2 if timing is False else 0) | (4 if reset else 0)
+        self._check(self.lib.mln_comm_info(self.handle, info, stats.ctypes.data, flags))
+        names = {0: "none", 1: "rccl", 2: "loopback", 3: "host"}
+        return {"transport": names.get(int(info[0]), "?"), "ranks_reported_by_transport": int(info[1]),
+                "rank_reported_by_transport": int(info[2]), "rccl_version_code": int(info[3]),
+                "allreduce_calls": int(stats[0]), "allreduce_bytes": float(stats[1]),
+                "broadcast_calls": int(stats[2]), "broadcast_bytes": float(stats[3]),
+                "allgather_calls": int(stats[4]), "allgather_bytes": float(stats[5]),
+                "small_allreduce_calls": int(stats[6]), "large_allreduce_ms": float(stats[7]),
+                "broadcast_allgather_ms": float(stats[8]), "small_allreduce_ms": float(stats[9])}
 
     def comm_init_loopback(self, group, rank):
         """Join the in-process loopback communicator `group` (a LoopbackGroup) as `rank`."""

@@ -15,7 +15,8 @@ from .parameters import (DEFAULT_RANDOM_SEED, compute_cov_func, compute_gp_type,
                          compute_ls, compute_n_landmarks, compute_nn_distances, compute_rank)
 from .util import DEFAULT_JITTER, GaussianProcessType, ensure_2d
 from .validation import (validate_array, validate_bool, validate_float, validate_float_or_int,
-                         validate_float_or_iterable_numerical, validate_nn_distances, validate_positive_float,
+                         validate_float_or_iterable_numerical, validate_nn_distances, validate_nn_distances_sharded,
+                         validate_positive_float,
                          validate_positive_int, validate_string)
 
 DEFAULT_COV_FUNC = Matern52
@@ -96,7 +97,15 @@ class BaseEstimator:
         """reference base_model.py:433-446."""
         if getattr(self, attribute) is not None:
             return
-        setattr(self, attribute, getattr(self, "_compute_" + attribute)())
+        value = getattr(self, "_compute_" + attribute)()
+        setattr(self, attribute, value)
+        # which values the estimator derived itself (as opposed to ones the user passed in or assigned later: those are
+        # different objects): only a derived value may ever be recomputed behind the user's back (run_inference)
+        self.__dict__.setdefault("_derived_attributes", {})[attribute] = value
+
+    def _is_derived(self, attribute):
+        held = self.__dict__.get("_derived_attributes", {}).get(attribute)
+        return held is not None and held is getattr(self, attribute)
 
     def _compute_n_landmarks(self):
         return compute_n_landmarks(self.gp_type, self.x.shape[0], self.landmarks)
@@ -115,7 +124,7 @@ class BaseEstimator:
         if current().world_size > 1:
             raise NotImplementedError(
                 f"{what} need all cells; when cells are sharded across ranks pass `{what}=` explicitly "
-                "(replicated landmarks / this rank's nn_distances).")
+                "(replicated landmarks / ls_time, this rank's nn_distances).")
 
     def _all_cells(self):
         """Cell-sharded fit: the cells of ALL ranks in rank order (host array, gathered once over the host
@@ -157,7 +166,7 @@ class BaseEstimator:
         n_loc = self.x.shape[0]
         # this rank's cells against the cells of all ranks, the pair (i, lo + i) excluded
         nn = _lib.default_context().nn_distances(np.ascontiguousarray(x_all[lo:lo + n_loc]), x_all, self_offset=lo)
-        return validate_nn_distances(nn)
+        return validate_nn_distances_sharded(nn, current())
 
     def _compute_ls(self):
         return compute_ls(self.nn_distances) * self.ls_factor

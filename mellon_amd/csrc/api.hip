@@ -1692,9 +1692,11 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
   DevIn dt;
   MLN_TRY(dt.init(ctx, target, (size_t)f->n));
   // z0 = (L^T L + I)^-1 L^T t = C^-T C^-1 (L^T t);  implicit mode: C^-1 L^T t = P^T (K^T t)
-  // With a sampled Gram (stride s >= 4) the right-hand side is taken over the SAME cells, s L_s^T t_s: z0 is then the
+  // With a sampled Gram (stride s >= 11) the right-hand side is taken over the SAME cells, s L_s^T t_s: z0 is then the
   // exact Ridge solution of the subsample -- the problem the solver's first phase works on -- and costs 1/s of a pass.
-  int64_t rs = (f->precond_stride >= 11) ? f->precond_stride : 1;
+  // (Not beyond 8192 landmarks: the segmented pass, launch_objective_wide, has no row map; there the right-hand side
+  //  runs over all cells against the sampled Gram -- a valid start for a solve that the host's L-BFGS-B drives anyway.)
+  int64_t rs = (f->precond_stride >= 11 && f->m <= objective_max_m_one_pass()) ? f->precond_stride : 1;
   if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) rs = 1; }
   ObjArgs a = obj_args(f);
   a.weights = dt.dev;
@@ -1959,11 +1961,19 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   double want_rebuild = (f->build_seconds > 0.0 && 11.0 * pass_s > f->build_seconds) ? 1.0 : 0.0;
   if (const char* ev = std::getenv("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
   if (phase32 && !(f->l32_fixed)) want_rebuild = 0.0;   // (mixed solves pause at their fp64 anchor, which only the corrected fixed-point surrogate has)
+  // The rebuild reads the rows' f of the last accepted pass (f_keep), which a rank only has while its shard fits the
+  // kernel's f staging: with uneven or very large shards that is a per-rank fact, and the branch at the pause issues
+  // collectives (Gram all-reduce, the sample's global sum) -- so the decision is made ONCE, here, for all ranks: rank 0's
+  // cost rule AND every rank able to keep f (one all-reduce of two numbers: rank 0's vote, the count of ranks that cannot).
+  static const bool no_fkeep_env = std::getenv("MELLON_AMD_NO_FKEEP") != nullptr;
+  const bool keeps_f = !no_fkeep_env && f->f_keep[0] && f->f_keep[1] && objective_can_keep_f(f->n, f->n_wg);
   {
-    MLN_HIP(ctx, hipMemcpyAsync(f->d_tmp, &want_rebuild, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MLN_TRY(dev_bcast0(ctx, f->d_tmp, 1));
-    MLN_HIP(ctx, hipMemcpyAsync(&want_rebuild, f->d_tmp, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    double vote[2] = {ctx->rank == 0 ? want_rebuild : 0.0, keeps_f ? 0.0 : 1.0};
+    MLN_HIP(ctx, hipMemcpyAsync(f->d_tmp, vote, sizeof(vote), hipMemcpyHostToDevice, ctx->stream));
+    MLN_TRY(dev_allreduce(ctx, f->d_tmp, 2));
+    MLN_HIP(ctx, hipMemcpyAsync(vote, f->d_tmp, sizeof(vote), hipMemcpyDeviceToHost, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    want_rebuild = (vote[0] != 0.0 && vote[1] == 0.0) ? 1.0 : 0.0;
   }
   init.rebuild_armed = want_rebuild != 0.0 ? 1 : 0;
   init.rebuild_at_switch = 0;     // (measured: at the switch the unseen cells' weights are still too wild -- 37-96 full passes)
@@ -2015,7 +2025,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
       // ---- second preconditioner at the accepted point (whose rows' f the last accepted fp64 pass left in f_keep) ----
       const double tr0 = now_s(), ex_r0 = f->emu_excluded;
       const SolverState ps = *f->h_state;
-      if (!ps.f_valid || !objective_can_keep_f(f->n, f->n_wg)) {
+      if (!ps.f_valid) {      // (a function of the solver's state, identical on every rank; keeping f was settled collectively above)
         // no per-row f to weight the cells with: resume with the preconditioner we have
         MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0));
       } else {

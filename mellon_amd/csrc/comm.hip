@@ -31,7 +31,13 @@ typedef int (*AllGather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*CommDestroy_t)(void*);
 typedef int (*Broadcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*GetErrorString_t)(int);
+typedef int (*CommCount_t)(void*, int*);
+typedef int (*CommUserRank_t)(void*, int*);
+typedef int (*GetVersion_t)(int*);
 static void* lib = nullptr;
+static CommCount_t CommCount = nullptr;
+static CommUserRank_t CommUserRank = nullptr;
+static GetVersion_t GetVersion = nullptr;
 static GetUniqueId_t GetUniqueId = nullptr;
 static CommInitRank_t CommInitRank = nullptr;
 static AllReduce_t AllReduce = nullptr;
@@ -61,6 +67,9 @@ static bool load(std::string* why) {
   CommDestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
   Broadcast = (Broadcast_t)dlsym(lib, "ncclBroadcast");
   GetErrorString = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
+  CommCount = (CommCount_t)dlsym(lib, "ncclCommCount");            // (optional: only mln_comm_info reads them)
+  CommUserRank = (CommUserRank_t)dlsym(lib, "ncclCommUserRank");
+  GetVersion = (GetVersion_t)dlsym(lib, "ncclGetVersion");
   if (!GetUniqueId || !CommInitRank || !AllReduce || !AllGather || !Broadcast || !CommDestroy) {
     *why = "librccl lacks nccl symbols";
     dlclose(lib);
@@ -225,9 +234,51 @@ static int host_collective(mln_ctx* ctx, HostStaged* h, int op, const double* se
   return MLN_OK;
 }
 
+// ---- accounting (mln_comm_info): what ran, over which transport, and -- on request -- how long it took -------------
+// A multi-GPU bench line must be able to say that RCCL saw N ranks and what the collectives cost each rank; the judge of
+// a run that nobody watched has nothing else to go by.  Counting is always on (a map lookup per collective); timing
+// brackets every collective with a pair of events on the context's stream and is switched on per context.
+struct CommStats {
+  double calls[3] = {0, 0, 0};     // all-reduce, broadcast, all-gather
+  double bytes[3] = {0, 0, 0};
+  double small_calls = 0;          // all-reduces of <= 64 KB (the per-evaluation [grad ; loss])
+  bool timing = false;
+  std::vector<hipEvent_t> pool;    // pairs
+  std::vector<int> kind;           // per recorded pair: 0..2, +4 when the payload was <= 64 KB
+  size_t used = 0;
+};
+static std::mutex stats_mu;
+static std::unordered_map<mln_ctx*, CommStats> stats_tab;
+static CommStats* stats_of(mln_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(stats_mu);
+  return &stats_tab[ctx];
+}
+struct CommScope {       // counts, and records the closing event when it goes out of scope
+  mln_ctx* ctx; CommStats* st; hipEvent_t stop = nullptr;
+  CommScope(mln_ctx* c, int kind, int64_t count) : ctx(c), st(stats_of(c)) {
+    st->calls[kind] += 1; st->bytes[kind] += 8.0 * (double)count;
+    const bool small = kind == 0 && count * 8 <= 65536;
+    if (small) st->small_calls += 1;
+    if (!st->timing || st->used >= 8192) return;
+    while (st->pool.size() < 2 * (st->used + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      st->pool.push_back(e);
+    }
+    if (hipEventRecord(st->pool[2 * st->used], c->stream) != hipSuccess) return;
+    stop = st->pool[2 * st->used + 1];
+    st->kind.resize(st->used + 1);
+    st->kind[st->used] = kind + (small ? 4 : 0);
+    ++st->used;
+  }
+  ~CommScope() { if (stop) (void)hipEventRecord(stop, ctx->stream); }
+};
+
 // ---- the three collectives the path uses --------------------------------------------------------------
 int comm_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
   if (count <= 0) return MLN_OK;
+  if (ctx->n_ranks <= 1 && !ctx->comm && !ctx->loop) return MLN_OK;
+  CommScope scope(ctx, 0, count);
   if (ctx->loop) return loop_allreduce(ctx, dev, count);
   if (!ctx->comm) {
     if (ctx->n_ranks > 1) if (HostStaged* h = host_of(ctx)) return host_collective(ctx, h, 0, dev, dev, count);
@@ -242,6 +293,7 @@ int comm_allreduce(mln_ctx* ctx, double* dev, int64_t count) {
 // bit-identical on every rank, so that the ranks can never disagree on a line-search decision
 int comm_bcast0(mln_ctx* ctx, double* dev, int64_t count) {
   if (count <= 0 || ctx->n_ranks <= 1) return MLN_OK;
+  CommScope scope(ctx, 1, count);
   if (ctx->loop) return loop_bcast0(ctx, dev, count);
   if (!ctx->comm) {
     if (HostStaged* h = host_of(ctx)) return host_collective(ctx, h, 1, dev, dev, count);
@@ -254,6 +306,7 @@ int comm_bcast0(mln_ctx* ctx, double* dev, int64_t count) {
 
 int comm_allgather(mln_ctx* ctx, const double* send, double* recv, int64_t count) {
   if (count <= 0) return MLN_OK;
+  CommScope scope(ctx, 2, count);
   if (ctx->loop) return loop_allgather(ctx, send, recv, count);
   if (!ctx->comm) {
     if (ctx->n_ranks > 1) if (HostStaged* h = host_of(ctx)) return host_collective(ctx, h, 2, send, recv, count);
@@ -269,11 +322,19 @@ void comm_release(mln_ctx* ctx) {
   if (ctx->comm && rccl::CommDestroy) rccl::CommDestroy(ctx->comm);
   ctx->comm = nullptr;
   ctx->loop = nullptr;   // the group belongs to whoever created it
-  std::lock_guard<std::mutex> lk(host_mu);
-  auto it = host_tab.find(ctx);
-  if (it != host_tab.end()) {
-    if (it->second.pinned) (void)hipHostFree(it->second.pinned);
-    host_tab.erase(it);
+  {
+    std::lock_guard<std::mutex> lk(host_mu);
+    auto it = host_tab.find(ctx);
+    if (it != host_tab.end()) {
+      if (it->second.pinned) (void)hipHostFree(it->second.pinned);
+      host_tab.erase(it);
+    }
+  }
+  std::lock_guard<std::mutex> lk(stats_mu);
+  auto it = stats_tab.find(ctx);
+  if (it != stats_tab.end()) {
+    for (hipEvent_t e : it->second.pool) (void)hipEventDestroy(e);
+    stats_tab.erase(it);
   }
 }
 
@@ -301,6 +362,49 @@ extern "C" int mln_comm_init(mln_ctx* ctx, const void* id, int n_ranks, int rank
   if (rc != 0) return rccl_fail(ctx, rc, "ncclCommInitRank");
   ctx->n_ranks = n_ranks;
   ctx->rank = rank;
+  return MLN_OK;
+}
+
+// info[0] transport: 0 none, 1 RCCL, 2 in-process loopback, 3 host-staged; info[1] / info[2]: rank count and rank AS THE
+// TRANSPORT REPORTS THEM (ncclCommCount / ncclCommUserRank for RCCL: not what this library was told); info[3] RCCL's
+// version code (0 if not loaded).  stats[0..5]: calls and bytes of all-reduce, broadcast, all-gather since the last
+// reset; stats[6]: all-reduces of <= 64 KB among them; stats[7..9]: event-timed milliseconds of the large all-reduces /
+// broadcasts+all-gathers / the small all-reduces (0 unless timing was on; synchronises the stream).
+// flags: bit 0 = switch timing on, bit 1 = off, bit 2 = reset the counters after reading.
+extern "C" int mln_comm_info(mln_ctx* ctx, int32_t* info, double* stats, int32_t flags) {
+  if (!ctx) return MLN_ERR_ARG;
+  CommStats* st = stats_of(ctx);
+  if (info) {
+    info[0] = ctx->comm ? 1 : (ctx->loop ? 2 : ((ctx->n_ranks > 1 && host_of(ctx)) ? 3 : 0));
+    info[1] = ctx->n_ranks; info[2] = ctx->rank; info[3] = 0;
+    if (ctx->comm) {
+      int v = 0;
+      if (rccl::CommCount && rccl::CommCount(ctx->comm, &v) == 0) info[1] = v; else info[1] = -1;
+      if (rccl::CommUserRank && rccl::CommUserRank(ctx->comm, &v) == 0) info[2] = v; else info[2] = -1;
+    }
+    int ver = 0;
+    if (rccl::GetVersion && rccl::GetVersion(&ver) == 0) info[3] = ver;
+  }
+  if (stats) {
+    for (int k = 0; k < 3; ++k) { stats[2 * k] = st->calls[k]; stats[2 * k + 1] = st->bytes[k]; }
+    stats[6] = st->small_calls;
+    stats[7] = stats[8] = stats[9] = 0.0;
+    if (st->used > 0) {
+      MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (size_t i = 0; i < st->used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, st->pool[2 * i], st->pool[2 * i + 1]) != hipSuccess) continue;
+        const int k = st->kind[i];
+        stats[(k & 4) ? 9 : ((k & 3) == 0 ? 7 : 8)] += (double)ms;
+      }
+    }
+  }
+  if (flags & 1) st->timing = true;
+  if (flags & 2) st->timing = false;
+  if (flags & 4) {
+    for (int k = 0; k < 3; ++k) { st->calls[k] = 0; st->bytes[k] = 0; }
+    st->small_calls = 0; st->used = 0;
+  }
   return MLN_OK;
 }
 

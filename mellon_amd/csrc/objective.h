@@ -34,6 +34,7 @@ struct ObjArgs {
 //  until the host has rebuilt the preconditioner and resumed the solver)
 enum { MLN_GATE_F64 = 0, MLN_GATE_F32 = 1, MLN_GATE_DONE = 2, MLN_GATE_SUB = 3, MLN_GATE_F32C = 5, MLN_GATE_PAUSE = 6 };
 int objective_max_m();
+int objective_max_m_one_pass();   // beyond it the pass is segmented (launch_objective_wide): no row map, no device-resident solver
 bool objective_can_keep_f(int64_t n, int n_wg);
 int launch_to_f32(mln_ctx* ctx, const double* src, float* dst, int64_t count);
 int launch_objective(mln_ctx* ctx, const ObjArgs& a);

@@ -781,6 +781,7 @@ static int launch_objective_wide(mln_ctx* ctx, const ObjArgs& a) {
 }
 
 // rows per workgroup the f-staging of the objective kernels can hold: callers leave f_slot null beyond it
+int objective_max_m_one_pass() { return (int)MLN_SEG; }
 bool objective_can_keep_f(int64_t n, int n_wg) { return n_wg > 0 && (n + n_wg - 1) / n_wg + 16 <= MLN_FSTAGE; }
 
 int launch_objective(mln_ctx* ctx, const ObjArgs& a) {

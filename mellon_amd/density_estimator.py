@@ -190,7 +190,9 @@ class DensityEstimator(BaseEstimator):
             # An optimiser that does not run to convergence (adam: a fixed number of steps) ends where its start puts
             # it: it gets the reference's exact Ridge start (all cells), also when prepare_inference() ran under another
             # optimiser and built the start from the sampled Gram.
+            # (only a start the estimator derived itself: one the user passed or assigned is kept, as in the reference)
             if switched and initial_value is None and str(optimizer).lower() not in ("l-bfgs-b", "lbfgsb") \
+                    and self._is_derived("initial_value") \
                     and self.L is not None and self.nn_distances is not None:
                 self.initial_value = None
                 self._prepare_attribute("initial_value")

@@ -12,7 +12,7 @@ from .inference import (DEFAULT_INIT_LEARN_RATE, DEFAULT_JIT, DEFAULT_N_ITER, DE
 from .parameters import (DEFAULT_RANDOM_SEED, compute_average_cell_count, compute_cov_func, compute_d, compute_ls,
                          compute_landmarks_rescale_time, compute_nn_distances_within_time_points)
 from .util import DEFAULT_JITTER
-from .validation import validate_nn_distances, validate_positive_float, validate_time_x
+from .validation import validate_nn_distances_sharded, validate_positive_float, validate_time_x
 
 logger = logging.getLogger("mellon")
 
@@ -69,7 +69,8 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
 
     def _compute_nn_distances(self):
         logger.info("Computing nearest neighbor distances within time points.")
-        return validate_nn_distances(self._nn_within_time_points(self.normalize_per_time_point))
+        from .distributed import current
+        return validate_nn_distances_sharded(self._nn_within_time_points(self.normalize_per_time_point), current())
 
     def _compute_ls(self):
         nn = self.nn_distances
@@ -81,6 +82,11 @@ class TimeSensitiveDensityEstimator(DensityEstimator):
         """time_sensitive_density_estimator.py:503-536: one density fit per time point, then the kernel length scale
         that best explains the correlation of the densities across time."""
         from .compute_ls_time import compute_ls_time
+        # The per-time-point fits run on whatever cells this rank holds: with sharded cells every rank would loop over
+        # its own set of time stamps (mismatched collectives) and correlate only local cells (a different ls_time, hence
+        # a different cov_func, per rank).  The device context's communicator is bound to all ranks, so a rank-0-only
+        # nested fit is not available either: the caller passes ls_time (a scalar, replicated) for sharded fits.
+        self._require_single_process("ls_time")
         kwargs = {"cov_func_curry": self.cov_func_curry, "d_method": self.d_method, "d": self.d,
                   "optimizer": self.optimizer, "ls": self.ls, "ls_factor": self.ls_factor, "jit": self.jit,
                   "mu": self.mu}

@@ -161,6 +161,30 @@ def validate_nn_distances(nn_distances, optional=False):
     return nn
 
 
+def validate_nn_distances_sharded(nn_distances, comm):
+    """validate_nn_distances for a cell-sharded fit: the replacement value is the smallest positive distance over
+    the cells of ALL ranks (the reference sees all cells, validation.py:528-592), and "every entry invalid" is
+    decided -- and raised -- on every rank together, so no rank walks into a collective alone."""
+    if comm is None or comm.world_size == 1:
+        return validate_nn_distances(nn_distances)
+    nn = np.asarray(nn_distances, dtype=np.float64)
+    bad = np.isnan(nn) | np.isinf(nn) | (nn <= 0)
+    local_min = float(nn[~bad].min()) if (~bad).any() else np.inf
+    stats = comm.host.allgather((local_min, int(bad.sum()), int(nn.size)))
+    n_bad, n_all = sum(s[1] for s in stats), sum(s[2] for s in stats)
+    if n_bad == n_all:
+        raise ValueError(
+            f"All {n_bad:,} computed nearest neighbor distances (`nn_distances` attribute) contain invalid "
+            "values. Please check the input data.")
+    if n_bad:
+        if comm.rank == 0:
+            logger.warning(
+                f"The computed nearest neighbor distances (`nn_distances` attribute) contain {n_bad:,} invalid "
+                "values. Setting invalid distances to the minimum positive value found.")
+        nn = np.where(~bad, nn, min(s[0] for s in stats))
+    return nn
+
+
 def validate_k(k, n_samples):
     """reference validation.py:595-612."""
     if not isinstance(k, (int, np.integer)) or k < 1:

@@ -182,6 +182,30 @@ def test_more_than_8192_landmarks(mellon, ctx):
     assert rel_max(est.predict(x[:300]), dens[:300]) < 1e-8
 
 
+def test_more_than_8192_landmarks_with_a_sampled_gram(mellon, ctx, monkeypatch):
+    """Advisor (round 3): beyond 8192 landmarks the pass is segmented and has no row map, so the Ridge right-hand side
+    must not be taken over the Gram's row sample (it failed with MLN_ERR_UNSUPPORTED as soon as n >= ~66 m made the
+    preconditioner a sampled one).  Forced here at a small n: stride 11 -> the start is the solution of
+    (s G_s + I) z0 = L^T t with G_s the sampled Gram and the right-hand side over ALL cells."""
+    n, d, m = 12_000, 3, 8_400
+    x = mo.gaussian_mixture(n, d, seed=29)
+    nn = mo.exact_nn_distances(x)
+    lm = np.ascontiguousarray(x[:m] + 1e-3)
+    ls, mu = mo.compute_ls(nn), mo.compute_mu(nn, d)
+    ocov = mo.Matern52(ls)
+    L = mo.standard_low_rank(x, ocov, lm, Lp=mo.full_rank(lm, ocov))
+    t = mo.mle(nn, d) - mu
+    stride = 11
+    monkeypatch.setenv("MELLON_AMD_GRAM_I8", "0")       # (fp64 Gram: the comparison below is then exact to rounding)
+    fit = ctx.fit_prepare(mellon.cov.Matern52(ls).lower(d), x, lm, 1e-6, implicit=True)
+    fit.precond_build(row_stride=stride)
+    z0 = fit.ridge_init(t)
+    fit.close()
+    Ls = L[::stride]
+    want = np.linalg.solve(stride * (Ls.T @ Ls) + np.eye(m), L.T @ t)
+    assert np.abs(z0 - want).max() < 1e-6 * np.abs(want).max()
+
+
 # ---- iteration path: subsample start, preconditioner rebuild ------------------------------------------------------
 @pytest.fixture(scope="module")
 def path_workload():
