@@ -161,6 +161,54 @@ def committed_traffic(n_local, m):
     return t.get("hbm_bytes_per_launch"), t.get("fp32_passes", {}).get("hbm_bytes_per_launch"), src
 
 
+def measure_traffic_pmc(args):
+    """--pmc: HBM bytes per full-size launch of the dominant kernel re-measured NOW: two child runs of one fp64 step of
+    the same workload under `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, no
+    other trace domain -- guides/MI355X_MICROARCH.md 'HBM'), gfx950 correction FETCH_SIZE x 2 (KB units).  Returns
+    (bytes per launch, description) or (None, why not)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found on this box"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="mln_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--extra-steps", "0", "--landmark-method", "device",
+               "--cells", str(args.n), "--dims", str(args.d), "--landmarks", str(args.m), "--kernel", args.kernel,
+               "--seed", str(args.seed)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        env.pop("MELLON_AMD_MIXED", None)
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {counter} child failed (rc {r.returncode}): {r.stderr[-300:]}"
+            con = sqlite3.connect(dbs[0])
+            rows = con.execute("select kernel_name, value, duration from counters_collection where counter_name = ? "
+                               "and kernel_name like '%k_objective<%'", (counter,)).fetchall()
+            if not rows:
+                return None, f"no k_objective rows in the {counter} pass"
+            dmax = max(r_[2] for r_ in rows)
+            full = [r_ for r_ in rows if r_[2] > 0.5 * dmax]          # the full-size launches (not gated off, not strided)
+            got[counter] = (sum(r_[1] for r_ in full) / len(full), len(full), sum(r_[2] for r_ in full) / len(full) / 1e3)
+        except Exception as e:          # noqa: BLE001 -- a profiling problem must not lose the bench line
+            return None, f"rocprofv3 --pmc {counter}: {e!r}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kb, nf, us_f = got["FETCH_SIZE"]
+    write_kb, nw, us_w = got["WRITE_SIZE"]
+    return 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0, (
+        f"measured in THIS run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate child passes of one fp64 step "
+        f"(bench.py --steps 1 --warmup 0 --landmark-method device); mean over the {nf} / {nw} full-size k_objective launches "
+        f"({us_f:.0f} / {us_w:.0f} us under the profiler); FETCH_SIZE {fetch_kb:.0f} KB x 2 (gfx950 correction) + WRITE_SIZE "
+        f"{write_kb:.0f} KB")
+
+
 def c4_workload(n, d, T, seed):
     """BASELINE C4: Gaussian-mixture cells at T equally sized time points whose component means drift
     linearly in time; the time column is appended.  Rows are ordered by time."""
@@ -356,6 +404,9 @@ def main():
     ap.add_argument("--cpu-sample-full", action="store_true",
                     help="SURVEY S8(d) sizes: 2.5e5 and 5e5 cells (needs ~60 GB of host RAM and ~15 min)")
     ap.add_argument("--extra-steps", type=int, default=2, help="steps of the mixed-precision and host-to-host measurements")
+    ap.add_argument("--pmc", action="store_true",
+                    help="re-measure roofline.traffic in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) of one "
+                         "fp64 step, ~1 min each; without it the committed profiles/objective_traffic.json is quoted")
     ap.add_argument("--allow-host-staged", action="store_true",
                     help="with --gpus N > 1: accept host-staged device collectives (RCCL unavailable, or ranks sharing a GPU); "
                          "without it a multi-rank run whose transport is not RCCL over N ranks exits non-zero")
@@ -564,6 +615,12 @@ def main():
     n64 = stats["objective_launches"]
     bytes64 = stats["objective_bytes_per_launch"]
     traffic, traffic32, traffic_src = committed_traffic(hi - lo, m)
+    if args.pmc and world == 1:
+        t_now, src_now = measure_traffic_pmc(args)
+        if t_now is not None:
+            traffic, traffic_src = t_now, src_now
+        else:
+            traffic_src = (traffic_src or "") + f" [--pmc failed: {src_now}]"
     roof = roofline_object("k_objective (fused loss + gradient, ONE pass over the fp64 n x m buffer per evaluation of the MAP "
                            "solve; also the Ridge right-hand side)", bytes64, stats["objective_kernel_s"], n64,
                            step_s if world == 1 else None, traffic, traffic_src)

@@ -11,7 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmellon_hip.so")
 SOURCES = ["api.hip", "alloc.hip", "comm.hip", "cov_grad.hip", "cov_kernels.hip", "cov_rows.hip", "cov_rows_matern32.hip", "cov_rows_matern52.hip", "cov_rows_expquad.hip",
-           "cov_rows_exponential.hip", "predict_rows.hip", "predict_rows_prod.hip", "kernel_rows_prod_matern32.hip", "kernel_rows_prod_matern52.hip",
+           "cov_rows_exponential.hip", "predict_rows.hip", "predict_rows_matern32.hip", "predict_rows_matern52.hip", "predict_rows_expquad.hip", "predict_rows_exponential.hip",
+           "predict_rows_ratquad.hip", "predict_rows_prod.hip", "predict_rows_prod_matern32.hip", "predict_rows_prod_matern52.hip",
+           "predict_rows_prod_expquad.hip", "predict_rows_prod_exponential.hip", "kernel_rows_prod_matern32.hip", "kernel_rows_prod_matern52.hip",
            "kernel_rows_prod_expquad.hip", "kernel_rows_prod_exponential.hip",
            "dgemm.hip", "diag.hip", "precond_rebuild.hip", "rowmin_f16.hip", "gram_i8.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip", "tridiag.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DMLN_POTRF_TIMING"] if __import__("os").environ.get("MLN_POTRF_TIMING") else [])
@@ -52,7 +54,7 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 
-    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(max(8, (os.cpu_count() or 8) // 2), max(1, len(jobs)))) as ex:
         for (src, obj, dep), r in ex.map(cc, jobs):
             if verbose and (r.stdout or r.stderr):
                 sys.stderr.write(r.stdout + r.stderr)

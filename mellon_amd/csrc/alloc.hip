@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "mln_internal.h"
 
@@ -49,8 +50,16 @@ hipError_t mln_dmalloc(void** out, size_t bytes) {
   return e;
 }
 
+// Deferred frees of the calling thread (mln_dfree_defer): a chain that runs on a side stream NEXT TO a long kernel must not
+// sit out that kernel in the device-wide synchronisation of every temporary it releases.
+namespace {
+thread_local std::vector<void*>* t_deferred = nullptr;
+}
+void mln_dfree_defer(std::vector<void*>* sink) { t_deferred = sink; }
+
 hipError_t mln_dfree(void* p) {
   if (!p) return hipSuccess;
+  if (t_deferred) { t_deferred->push_back(p); return hipSuccess; }
   (void)hipDeviceSynchronize();  // same guarantee hipFree gives: nothing in flight touches the block
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_live.find(p);

@@ -4,7 +4,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "linalg.h"
@@ -12,6 +14,8 @@
 #include "objective.h"
 #include "precond_rebuild.h"
 #include "solver.h"
+
+void mln_dfree_defer(std::vector<void*>* sink);   // alloc.hip: frees of the calling thread are collected instead of performed
 
 // ---- errors -------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
@@ -184,6 +188,7 @@ extern "C" void mln_ctx_destroy(mln_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   comm_release(ctx);
+  masked_streams_release(ctx);
   if (ctx->scratch) (void)mln_dfree(ctx->scratch);
   if (ctx->d_info) (void)mln_dfree(ctx->d_info);
   (void)hipStreamDestroy(ctx->stream);
@@ -432,6 +437,36 @@ extern "C" int mln_trsm_lower(mln_ctx* ctx, const double* Lf, int64_t m, int32_t
   return rc;
 }
 
+struct mln_fit;
+// cov(xu, xu) -> Cholesky factor -> block-scaled copies on a second stream, in a helper thread, while the caller runs the
+// kernel-matrix pass on `wide` (see fit_prepare_impl).  The helper works on a COPY of the context with its own stream,
+// scratch and status word; its temporaries are released by the caller after the join (a free synchronises the device,
+// i.e. would sit out the pass).
+struct LandmarkChain {
+  bool running = false;
+  hipStream_t wide = nullptr;
+  mln_ctx* ctx = nullptr;
+  mln_ctx side;
+  std::thread th;
+  int rc = MLN_OK;
+  double seconds = 0.0;
+  double* Lp = nullptr; int64_t ldp = 0;
+  TriInv tri;
+  std::vector<void*> deferred;
+  DevCov cov;
+  int start(mln_ctx* c, mln_fit* f, const double* centers, int64_t m, int d, double jitter);
+  int finish(mln_fit* f);
+  ~LandmarkChain() {
+    if (th.joinable()) th.join();
+    if (running) {                                       // abandoned on an error path: nothing was handed over
+      if (tri.W || tri.W2) triinv_free(&tri);
+      if (side.scratch) deferred.push_back(side.scratch);
+      if (side.d_info) deferred.push_back(side.d_info);
+    }
+    for (void* p : deferred) (void)mln_dfree(p);
+  }
+};
+
 // ---- fit handle --------------------------------------------------------------------------------------
 struct mln_fit {
   mln_ctx* ctx = nullptr;
@@ -502,6 +537,58 @@ struct mln_fit {
   int evals_sub = 0, n_rebuild = 0;
 };
 
+int LandmarkChain::start(mln_ctx* c, mln_fit* f, const double* centers, int64_t m, int d, double jitter) {
+  ctx = c;
+  wide = masked_stream(c, 32);
+  hipStream_t second = masked_stream(c, 0);
+  hipEvent_t ev = masked_stream_event(c, 2);
+  if (!wide || !second || !ev) return MLN_OK;            // no masked streams here: the caller keeps the serial order
+  side = *c;
+  side.stream = second;
+  side.scratch = nullptr; side.scratch_bytes = 0; side.err.clear();
+  side.d_info = nullptr;
+  MLN_HIP(c, mln_dmalloc((void**)&side.d_info, 4 * sizeof(int)));
+  // what has been enqueued so far (the landmarks' upload, the zeroed Lp) precedes both side streams
+  MLN_HIP(c, hipEventRecord(ev, c->stream));
+  MLN_HIP(c, hipStreamWaitEvent(second, ev, 0));
+  MLN_HIP(c, hipStreamWaitEvent(wide, ev, 0));
+  Lp = f->Lp; ldp = f->ldp; cov = f->cov;
+  const int device = c->device;
+  running = true;
+  th = std::thread([this, centers, m, d, jitter, device] {
+    const double t0 = now_s();
+    if (hipSetDevice(device) != hipSuccess) { rc = MLN_ERR_HIP; return; }
+    mln_dfree_defer(&deferred);
+    set_lookahead_disabled(true);
+    rc = launch_kernel_matrix(&side, cov, centers, m, centers, m, d, Lp, ldp, jitter);
+    if (rc == MLN_OK) rc = dev_cholesky_lower(&side, Lp, m, ldp);
+    if (rc == MLN_OK) rc = triinv_build(&side, Lp, m, ldp, true, true, &tri);
+    if (hipStreamSynchronize(side.stream) != hipSuccess && rc == MLN_OK) rc = MLN_ERR_HIP;
+    set_lookahead_disabled(false);
+    mln_dfree_defer(nullptr);
+    seconds = now_s() - t0;
+  });
+  return MLN_OK;
+}
+
+int LandmarkChain::finish(mln_fit* f) {
+  if (th.joinable()) th.join();
+  running = false;
+  if (side.scratch) deferred.push_back(side.scratch);
+  if (side.d_info) deferred.push_back(side.d_info);
+  side.scratch = nullptr; side.d_info = nullptr;
+  for (void* p : deferred) (void)mln_dfree(p);
+  deferred.clear();
+  f->times[1] += seconds;
+  if (rc != MLN_OK) {
+    if (tri.W || tri.W2) triinv_free(&tri);
+    mln_set_error(ctx, side.err.empty() ? std::string("the landmark chain (cov(xu, xu), Cholesky) failed") : side.err);
+    return rc;
+  }
+  f->tri = tri;
+  return MLN_OK;
+}
+
 // rows of this shard in the subsample of stride s: first local index and count
 static void fit_sample_rows(const mln_fit* f, int64_t s, int64_t* first, int64_t* rows) {
   if (s < 1) s = 1;
@@ -571,6 +658,61 @@ static int fit_alloc_workspace(mln_fit* f) {
   return MLN_OK;
 }
 
+// Upload of the cells from pageable host memory in row chunks by a helper thread (see fit_prepare_impl).  A copy from
+// pageable memory blocks its CALLING thread while the runtime stages it through pinned buffers, but not the device: the
+// chunks travel while the main thread's kernels run.  Chunk c is complete on the device when events[c] has fired; the
+// main thread makes its stream wait for that event -- after the helper has recorded it (done > c).
+struct HostUpload {
+  mln_ctx* ctx = nullptr;
+  hipStream_t copy = nullptr;
+  std::vector<hipEvent_t> events;
+  std::atomic<int> done{0};
+  std::atomic<int> failed{0};
+  std::thread th;
+  int n_chunks = 0;
+  int64_t n = 0, chunk_rows = 0;
+  int d = 0;
+  int start(mln_ctx* c, const double* src, double* dst, int64_t n_, int d_) {
+    ctx = c; n = n_; d = d_;
+    // chunks of whole 128-row workgroup tiles, ~64 MB each, at most 16
+    chunk_rows = std::max<int64_t>(128, (((int64_t)64 << 20) / ((int64_t)d * 8) + 127) / 128 * 128);
+    if ((n + chunk_rows - 1) / chunk_rows > 16) chunk_rows = ((n + 15) / 16 + 127) / 128 * 128;
+    n_chunks = (int)((n + chunk_rows - 1) / chunk_rows);
+    MLN_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    events.resize((size_t)n_chunks, nullptr);
+    for (auto& e : events) MLN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const int device = ctx->device;
+    th = std::thread([this, src, dst, device] {
+      if (hipSetDevice(device) != hipSuccess) { failed.store(1); done.store(n_chunks); return; }
+      for (int c = 0; c < n_chunks; ++c) {
+        const int64_t r0 = (int64_t)c * chunk_rows, rows = std::min(chunk_rows, n - r0);
+        hipError_t e = hipMemcpyAsync(dst + r0 * d, src + r0 * d, sizeof(double) * (size_t)(rows * d), hipMemcpyHostToDevice, copy);
+        if (e == hipSuccess) e = hipEventRecord(events[(size_t)c], copy);
+        if (e != hipSuccess) { failed.store(1); done.store(n_chunks, std::memory_order_release); return; }
+        done.store(c + 1, std::memory_order_release);
+      }
+    });
+    return MLN_OK;
+  }
+  int wait_chunk(int c, int64_t* r0, int64_t* rows) {
+    while (done.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+    if (failed.load()) { mln_set_error(ctx, "upload of the cells failed (helper thread)"); return MLN_ERR_HIP; }
+    MLN_HIP(ctx, hipStreamWaitEvent(ctx->stream, events[(size_t)c], 0));
+    *r0 = (int64_t)c * chunk_rows;
+    *rows = std::min(chunk_rows, n - *r0);
+    return MLN_OK;
+  }
+  int finish() {
+    if (th.joinable()) th.join();
+    return failed.load() ? MLN_ERR_HIP : MLN_OK;
+  }
+  ~HostUpload() {
+    if (th.joinable()) th.join();
+    if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+    for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
+  }
+};
+
 static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, int32_t d,
                             const double* xu, int64_t m, double jitter, const double* Lp_in, int32_t flags,
                             mln_fit* f) {
@@ -585,7 +727,21 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
   f->ldp = pad16(m);
   f->ldl = pad16(m);
   DevIn dx, du;
-  MLN_TRY(dx.init(ctx, x, (size_t)n * d));
+  // Cells handed over in HOST memory (the reference's timed region starts there: density_estimator.py:542-581): the upload
+  // -- 0.4 GB at C3, ~8 ms over PCIe -- runs in a helper thread on a copy stream, in row chunks, UNDER the work that needs
+  // only the landmarks (cov(xu, xu), its Cholesky factor, the block-scaled copies) and under the kernel-matrix pass of the
+  // chunks that have already arrived; each chunk's pass waits for that chunk's event only.
+  HostUpload up;
+  const bool pipelined = !f->full && n > 0 && x && !is_device_ptr(x) && (size_t)n * d * sizeof(double) >= ((size_t)32 << 20) &&
+                         !(std::getenv("MELLON_AMD_UPLOAD_PIPELINE") && std::atoi(std::getenv("MELLON_AMD_UPLOAD_PIPELINE")) == 0);
+  if (pipelined) {
+    dx.ctx = ctx;
+    MLN_HIP(ctx, mln_dmalloc((void**)&dx.owned, (size_t)n * d * sizeof(double)));
+    dx.dev = dx.owned;
+    MLN_TRY(up.start(ctx, x, dx.owned, n, d));
+  } else {
+    MLN_TRY(dx.init(ctx, x, (size_t)n * d));
+  }
   if (!f->full) MLN_TRY(du.init(ctx, xu, (size_t)m * d));
   const double* centers = f->full ? dx.dev : du.dev;
 
@@ -594,7 +750,20 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
   const size_t lp_bytes = sizeof(double) * (size_t)m * f->ldp;
   MLN_HIP(ctx, mln_dmalloc((void**)&f->Lp, lp_bytes));
   MLN_HIP(ctx, hipMemsetAsync(f->Lp, 0, lp_bytes, ctx->stream));
-  if (Lp_in) {
+  // Round 4: the landmark-only chain -- cov(xu, xu), its Cholesky factor, the block-scaled copies: ~6 ms at m = 5000, a
+  // latency chain that never fills the chip -- runs in a helper thread on a second stream UNDER the kernel-matrix pass,
+  // which is launched on a stream whose CU mask leaves 32 compute units to it (linalg.h: masked_stream).  Worth it when
+  // the pass is the longer of the two by a margin (the chain is slower with few units): C3 on one GPU, not its 8-rank shard.
+  LandmarkChain chain;
+  {
+    const double km_est = (double)n * (double)m * 3.3e-12, chain_est = 6e-3 * ((double)m / 5000.0) * ((double)m / 5000.0);
+    bool want = !f->full && !Lp_in && n > 0 && m >= 1024 && km_est > 2.0 * chain_est;
+    if (const char* ev = std::getenv("MELLON_AMD_OVERLAP_LANDMARK_CHAIN")) want = want && std::atoi(ev) != 0;
+    if (want) MLN_TRY(chain.start(ctx, f, centers, m, d, jitter));
+  }
+  if (chain.running) {
+    // (its results -- f->Lp, f->tri -- are collected below, after the kernel-matrix pass has been enqueued)
+  } else if (Lp_in) {
     DevIn dl;
     MLN_TRY(dl.init(ctx, Lp_in, (size_t)m * m));
     MLN_TRY(launch_copy_block(ctx, dl.dev, m, f->Lp, f->ldp, m, m));
@@ -606,9 +775,11 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
     t0 = now_s();
     MLN_TRY(dev_cholesky_lower(ctx, f->Lp, m, f->ldp));
   }
-  MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
-  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  f->times[1] += now_s() - t0;
+  if (!chain.running) {
+    MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f->times[1] += now_s() - t0;
+  }
 
   if (f->full) {
     f->L = f->Lp;  // parameters.py:847-850
@@ -646,7 +817,20 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
         else if (std::strcmp(ev, "fixed") == 0 && bounded) f->l32_fixed = 1;
       }
     }
-    MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0, f->L32, f->l32_fixed));
+    hipStream_t const own_stream = ctx->stream;
+    struct StreamRestore { mln_ctx* c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore{ctx, own_stream};   // (early returns included)
+    if (chain.running) ctx->stream = chain.wide;         // the pass leaves 32 compute units to the landmark chain
+    if (pipelined) {
+      for (int c = 0; c < up.n_chunks; ++c) {
+        int64_t r0 = 0, rows = 0;
+        MLN_TRY(up.wait_chunk(c, &r0, &rows));           // (ctx->stream waits for the chunk's event; the host only for its recording)
+        MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev + r0 * d, rows, du.dev, m, d, f->L + r0 * f->ldl, f->ldl, 0.0,
+                                     f->L32 ? f->L32 + r0 * f->ldl : nullptr, f->l32_fixed));
+      }
+      MLN_TRY(up.finish());
+    } else {
+      MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0, f->L32, f->l32_fixed));
+    }
     if (f->L32 && f->l32_fixed)
       if (const char* ev = std::getenv("MELLON_AMD_COPY_BITS")) {   // experiment: the copy rounded to fewer bits
         const int bits = std::atoi(ev);
@@ -654,6 +838,12 @@ static int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const doub
           hipLaunchKernelGGL(k_round_copy_bits, dim3(4096), dim3(256), 0, ctx->stream, reinterpret_cast<unsigned*>(f->L32),
                              (int64_t)n * f->ldl, 32 - bits);
       }
+    if (chain.running) {
+      const int rc_km = (hipStreamSynchronize(ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+      ctx->stream = own_stream;
+      MLN_TRY(chain.finish(f));                          // joins the helper; its error (not positive definite) is the fit's
+      MLN_TRY(rc_km);
+    }
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) fprintf(stderr, "[trace] L kernel matrix done at %.4f s\n", now_s() - t0);
     f->times[0] += now_s() - t0;

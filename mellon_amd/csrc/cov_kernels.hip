@@ -683,19 +683,26 @@ __global__ __launch_bounds__(256) void k_predict_mean_mfma(DevCov cov, const dou
   }
 }
 
-// xx[leaf][i] = sum over the leaf's active dims of x_i^2   (util.py:362)
-__global__ void k_row_sqnorms(DevCov cov, const double* __restrict__ x, int64_t n, int d,
-                              double* __restrict__ xx) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// xx[leaf][i] = sum over the leaf's active dims of x_i^2   (util.py:362).  Eight lanes per row: a wave's load covers eight
+// consecutive rows (3.2 KB of consecutive lines at d = 50) instead of 64 addresses d doubles apart -- one lane per row
+// read the 0.4 GB of C3's cells at 0.47 TB/s (0.85 ms per fit).
+__global__ __launch_bounds__(256) void k_row_sqnorms(DevCov cov, const double* __restrict__ x, int64_t n, int d,
+                                                     double* __restrict__ xx) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int q = threadIdx.x & 7;
+  const bool ok = i < n;
+  const double* row = x + (ok ? i : 0) * (int64_t)d;
   for (int l = 0; l < cov.n_leaves; ++l) {
     const DevLeaf lf = cov.leaves[l];
     double s = 0.0;
-    for (int k = 0; k < lf.ndims; ++k) {
-      double v = x[i * (int64_t)d + cov.dims[lf.dims_off + k]];
+    for (int k = q; k < lf.ndims; k += 8) {
+      const double v = row[cov.dims[lf.dims_off + k]];
       s = fma(v, v, s);
     }
-    xx[(int64_t)l * n + i] = s;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (ok && q == 0) xx[(int64_t)l * n + i] = s;
   }
 }
 
@@ -957,20 +964,31 @@ __global__ void k_row_sumsq(const double* __restrict__ T, int64_t ld, int64_t ro
 
 int sqnorms(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, int d, double* xx) {
   if (n == 0) return MLN_OK;
-  hipLaunchKernelGGL(k_row_sqnorms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cov, x, n, d, xx);
+  hipLaunchKernelGGL(k_row_sqnorms, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, ctx->stream, cov, x, n, d, xx);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
 
 }  // namespace
 
+// The persistent-row kernels (cov_rows_impl.h, kernel_rows_prod_impl.h, predict_rows*.hip) stage centre tiles without
+// bounds checks: they are handed a COPY of the centres followed by ROWS_PAD zero rows (and norms / weights padded alike).
+constexpr int64_t ROWS_PAD = 3 * 64;   // (a predict kernel requests tile t + 2 up to t = ceil(m / 64) - 1)
+static int pad_rows(mln_ctx* ctx, const double* src, int64_t rows, int64_t cols, double* dst) {
+  MLN_HIP(ctx, hipMemcpyAsync(dst, src, sizeof(double) * (size_t)(rows * cols), hipMemcpyDeviceToDevice, ctx->stream));
+  MLN_HIP(ctx, hipMemsetAsync(dst + rows * cols, 0, sizeof(double) * (size_t)(ROWS_PAD * cols), ctx->stream));
+  return MLN_OK;
+}
+
 int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64_t n, const double* y,
                          int64_t m, int d, double* out, int64_t ldo, double add_diag, float* out32, int q32) {
   if (n == 0 || m == 0) return MLN_OK;
   double* norms = nullptr;
-  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)cov.n_leaves * (size_t)(n + m), (void**)&norms));
+  const int64_t mp = m + ROWS_PAD;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * ((size_t)cov.n_leaves * (size_t)(n + mp) + (size_t)(mp * d)), (void**)&norms));
   double* xx = norms;
   double* yy = norms + (int64_t)cov.n_leaves * n;
+  double* ypad = yy + (int64_t)cov.n_leaves * mp;
   MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
   MLN_TRY(sqnorms(ctx, cov, y, m, d, yy));
   const int64_t tiles_n = (ldo + TN - 1) / TN, tiles_m = (n + TM - 1) / TM;   // covers the pad columns too
@@ -984,10 +1002,15 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   static const bool no_rows = std::getenv("MELLON_AMD_KM_NO_ROWS") != nullptr;
   if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD && (!out32 || q32)) {
-    MLN_TRY(launch_kernel_matrix_rows_q(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32, q32));
+    MLN_TRY(pad_rows(ctx, y, m, d, ypad));
+    MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));   // norms of the pad rows
+    MLN_TRY(launch_kernel_matrix_rows_q(ctx, cov, x, n, ypad, m, d, xx, yy, out, ldo, add_diag, out32, q32));
   } else if (!no_mfma && !no_rows && n >= 4096 && m >= 256 && (!out32 || q32) && predict_rows_prod_eligible(cov, d)) {
-    // the time-sensitive product kernel: state leaf x time leaf, both in the persistent-row kernel (leaf 0's norms come first)
-    MLN_TRY(launch_kernel_matrix_rows_prod(ctx, cov, x, n, y, m, d, xx, yy, out, ldo, add_diag, out32, q32));
+    // the time-sensitive product kernel: state leaf x time leaf, both in the persistent-row kernel (leaf 0's norms come
+    // first; leaf 1's, which it does not use, are overwritten by the zero padding)
+    MLN_TRY(pad_rows(ctx, y, m, d, ypad));
+    MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));
+    MLN_TRY(launch_kernel_matrix_rows_prod(ctx, cov, x, n, ypad, m, d, xx, yy, out, ldo, add_diag, out32, q32));
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_kernel_matrix_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, out, ldo, add_diag, tiles_n, out32, q32);
@@ -1005,9 +1028,12 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
                          int64_t m, int d, const double* w, double mu, double* out) {
   if (n == 0) return MLN_OK;
   double* norms = nullptr;
-  MLN_TRY(mln_scratch(ctx, sizeof(double) * (size_t)cov.n_leaves * (size_t)(n + m), (void**)&norms));
+  const int64_t mp = m + ROWS_PAD;
+  MLN_TRY(mln_scratch(ctx, sizeof(double) * ((size_t)cov.n_leaves * (size_t)(n + mp) + (size_t)(mp * (d + 1))), (void**)&norms));
   double* xx = norms;
   double* yy = norms + (int64_t)cov.n_leaves * n;
+  double* ypad = yy + (int64_t)cov.n_leaves * mp;
+  double* wpad = ypad + mp * d;
   MLN_TRY(sqnorms(ctx, cov, x, n, d, xx));
   MLN_TRY(sqnorms(ctx, cov, y, m, d, yy));
   const int64_t nblk = (n + TM - 1) / TM;
@@ -1018,9 +1044,15 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
   if (contiguous && !no_mfma && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE) {
-    MLN_TRY(launch_predict_mean_rows(ctx, cov, x, n, y, m, d, xx, yy, w, mu, out));
+    MLN_TRY(pad_rows(ctx, y, m, d, ypad));
+    MLN_TRY(pad_rows(ctx, w, m, 1, wpad));
+    MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));
+    MLN_TRY(launch_predict_mean_rows(ctx, cov, x, n, ypad, m, d, xx, yy, wpad, mu, out));
   } else if (!no_mfma && n >= 4096 && m >= 256 && predict_rows_prod_eligible(cov, d)) {
-    MLN_TRY(launch_predict_mean_rows_prod(ctx, cov, x, n, y, m, d, xx, yy, w, mu, out));      // leaf 0's norms come first
+    MLN_TRY(pad_rows(ctx, y, m, d, ypad));
+    MLN_TRY(pad_rows(ctx, w, m, 1, wpad));
+    MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));   // (leaf 0's norms come first)
+    MLN_TRY(launch_predict_mean_rows_prod(ctx, cov, x, n, ypad, m, d, xx, yy, wpad, mu, out));
   } else if (contiguous && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_predict_mean_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, w, mu, out);

@@ -5,6 +5,7 @@
 
 #pragma once
 #include "cov_rows.h"
+#include "cov_epilogue.h"
 
 namespace {
 using covrows::NNS;
@@ -24,42 +25,10 @@ using covrows::TN;
 //     just issued, once per tile;
 //   * the centre tile t+2 is REQUESTED at the top of the body (global loads into registers) and written to LDS at the
 //     bottom: the wait in between is vmcnt(#stores issued since), not vmcnt(0);
-//   * sqrt and exp are straight-line code (v_rsq_f64 + Newton, Cody-Waite reduction + degree-12 polynomial +
-//     v_ldexp_f64) instead of the library routines with their special-case selects: <= 2 ulp, ~45 instructions.
+//   * sqrt and exp are straight-line code instead of the library routines with their special-case selects (round 2: ~45
+//     instructions; round 4: 27, cov_epilogue.h -- scaled squared distance, one Newton step, one-FMA range reduction).
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// sqrt(s) for s >= 0 (0 maps to ~1e-150, i.e. to covariance 1 like the reference's sqrt(0) = 0)
-__device__ __forceinline__ double sqrt_pos(double s) {
-  s = fmax(s, 1e-300);
-  double y = __builtin_amdgcn_rsq(s);
-  const double hs = 0.5 * s;
-  y = y * fma(-hs * y, y, 1.5);
-  y = y * fma(-hs * y, y, 1.5);
-  double r = s * y;
-  return fma(0.5 * y, fma(-r, r, s), r);     // one Heron correction: <= 1 ulp
-}
-
-// e^x for x <= 0:  x = k ln2 + t, |t| <= ln2 / 2;  e^t by its Taylor polynomial of degree 12 (|error| < 2e-16)
-__device__ __forceinline__ double exp_nonpos(double x) {
-  const double k = rint(x * 1.4426950408889634);
-  double t = fma(k, -6.93147180369123816490e-01, x);
-  t = fma(k, -1.90821492927058770002e-10, t);
-  double p = 2.08767569878680989792e-09;            // 1/12!
-  p = fma(p, t, 2.50521083854417187751e-08);        // 1/11!
-  p = fma(p, t, 2.75573192239858906526e-07);        // 1/10!
-  p = fma(p, t, 2.75573192239858906526e-06);        // 1/9!
-  p = fma(p, t, 2.48015873015873015873e-05);        // 1/8!
-  p = fma(p, t, 1.98412698412698412698e-04);        // 1/7!
-  p = fma(p, t, 1.38888888888888888889e-03);        // 1/6!
-  p = fma(p, t, 8.33333333333333333333e-03);        // 1/5!
-  p = fma(p, t, 4.16666666666666666667e-02);        // 1/4!
-  p = fma(p, t, 1.66666666666666666667e-01);        // 1/3!
-  p = fma(p, t, 0.5);
-  p = fma(p, t, 1.0);
-  p = fma(p, t, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)fmax(k, -1100.0));   // underflows to 0 like exp()
 }
 
 // the 32-bit copy: the fixed-point number round(v 2^32), 1 stored as 2^32 - 1 -- see mln_internal.h.  (The rows kernels
@@ -71,18 +40,17 @@ __device__ __forceinline__ float surrogate_bits(double v, int) {
   return __uint_as_float((unsigned)__double2loint(fmin(v, 0x1.fffffffep-1) + 0x1p20));
 }
 
+// covariance value from the pre-scaled norms (cov_epilogue.h): xs = c2 (|x|^2 + 1e-12), ys = c2 |y|^2, m2 = -2 c2
 template <int KIND>
-__device__ __forceinline__ double leaf_value_k(const DevLeaf& lf, double xx, double yy, double xy) {
-  const double inv_ls = lf.alpha_inv_ls[1];
-  const double sq = xx - 2.0 * xy + yy + 1e-12;             // util.py:362-366
-  const double dist = sqrt_pos(fmax(sq, 0.0));
-  if (KIND == MLN_K_MATERN32) { const double r = 1.7320508075688772 * dist * inv_ls; return (r + 1.0) * exp_nonpos(-r); }
-  if (KIND == MLN_K_MATERN52) { const double r = 2.23606797749979 * dist * inv_ls; return (r + r * r * 0.3333333333333333 + 1.0) * exp_nonpos(-r); }
-  if (KIND == MLN_K_EXPQUAD) { const double r = dist * inv_ls; return exp_nonpos(-0.5 * (r * r)); }
-  const double r = dist * inv_ls;                           // MLN_K_EXPONENTIAL
-  return exp_nonpos(-0.5 * r);
+__device__ __forceinline__ double leaf_value_k(double m2, double xs, double ys, double xy) {
+  return covepi::leaf_value_s<KIND>(fmax(fma(m2, xy, xs) + ys, 1e-300));
 }
 
+// Contract (round 4): `y` and `yy` are PADDED copies of the centres and of their squared norms -- rows m .. m + 3 TN - 1
+// exist and are zero (cov_kernels.hip: pad_centres) -- so the staging needs neither address clamps nor value masks: a
+// staged load is `global_load v, v_off32, s[tile base]` with a byte offset that never changes, its LDS destination a
+// constant per thread.  The tile loop is unrolled by two, so that the two accumulator sets swap roles instead of being
+// copied (16 v_mov_b64 per tile) and every LDS address of the operand tiles is an immediate.
 template <int KIND, bool HAS32, int KSTEPS>
 __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const double* __restrict__ x, int64_t n,
                                                             const double* __restrict__ y, int64_t m, int d,
@@ -90,11 +58,12 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
                                                             const double* __restrict__ yy,
                                                             double* __restrict__ out, int64_t ldo, double add_diag,
                                                             float* __restrict__ out32, int q32) {
-  __shared__ double ys[2][TN * NNS];   // tile t+1 is consumed while tile t+2 lands in the buffer tile t left
-  __shared__ double yn[3][512];        // norms of the centres: [..][tid < TN] used, the rest absorbs the other threads' stores
-  __shared__ double sink[512];         // where the staging stores of threads without an element go
+  constexpr int YB = TN * NNS + 512;   // one operand buffer: the tile, then a slot per thread for stores without an element
+  __shared__ double ys[2][YB];         // tile t+1 is consumed while tile t+2 lands in the buffer tile t left
+  __shared__ double yn[3][512];        // scaled norms of the centres: [..][tid < TN] used, the rest absorbs the other threads' stores
   constexpr int NST = (TN * 4 * KSTEPS + 511) / 512;   // staging registers per thread: TN x d <= TN x 4 KSTEPS values
-  const DevLeaf lf = cov.leaves[0];
+  constexpr int EPI_VALU = (HAS32 ? 32 : 29) * 16 + 8;   // VALU instructions of one tile's epilogue per lane
+  const double c2 = covepi::sq_scale<KIND>(cov.leaves[0]), m2 = -2.0 * c2;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 16;
@@ -111,54 +80,44 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + lk + 4 * r;
-    xr[r] = (row < n) ? xx[row] : 0.0;
+    xr[r] = (row < n) ? c2 * (xx[row] + 1e-12) : 0.0;       // util.py:362-366's + 1e-12 rides with the row norm
   }
-  // Store addresses of the branch-free epilogue: a wave-uniform base per workgroup (SGPR pair) + a 32-bit element index
-  // per lane, shared by the fp64 buffer and its 32-bit copy.  Two sets of four 64-bit lane addresses pushed the variant
-  // with the copy over its register budget: the compiler then re-issued the staging loads late, each followed by
-  // s_waitcnt vmcnt(0) -- a drain of all 64 stores in flight, seven times per tile (25.3 ms against 21.0 without the copy).
+  // Store addresses of the branch-free epilogue: a wave-uniform base per tile and column group (SGPR pair, scalar
+  // arithmetic) + ONE 32-bit byte offset per lane and row, shared by all 16 column positions (and, halved, by the 32-bit
+  // copy): no vector instruction per store.
   double* const out_wg = out + (int64_t)blockIdx.x * 128 * ldo;
   float* const out32_wg = HAS32 ? out32 + (int64_t)blockIdx.x * 128 * ldo : nullptr;
-  unsigned lrow[4];
+  unsigned lrowb[4], lrowb32[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) lrow[r] = (unsigned)(wave * 16 + lk + 4 * r) * (unsigned)ldo + (unsigned)li;
-  for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;
+  for (int r = 0; r < 4; ++r) {
+    lrowb[r] = ((unsigned)(wave * 16 + lk + 4 * r) * (unsigned)ldo + (unsigned)li) * 8u;
+    lrowb32[r] = lrowb[r] >> 1;
+  }
+  for (int e = tid; e < 2 * YB; e += 512) (&ys[0][0])[e] = 0.0;
   __syncthreads();
   const int cnt = TN * d;
-  // element e of a tile: row e / d, column e % d; its LDS slot never changes from tile to tile.  Loads and stores are
-  // UNCONDITIONAL (clamped address / sink slot, value selected afterwards): an exec-masked load or store is a branch
-  // with its own s_waitcnt vmcnt(0), i.e. a stall on every store the wave has in flight.
-  int slot[NST];
-  int goff[NST];
-  const int64_t last = m * (int64_t)d - 1;
+  // element e of a tile: centre e / d, column e % d; its global byte offset within a tile and its LDS slot never change
+  unsigned goffb[NST];
+  double* dst[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
     const int e = tid + 512 * i;
     const int r = e / d, k = e - r * d;
-    slot[i] = (e < cnt) ? (r * NNS + k) : -1;
-    goff[i] = r * d + k;
+    goffb[i] = (e < cnt) ? (unsigned)e * 8u : 0u;
+    dst[i] = (e < cnt) ? &ys[0][r * NNS + k] : &ys[0][TN * NNS + tid];
   }
+  const unsigned nb = (unsigned)(tid & (TN - 1)) * 8u;
   double sreg[NST], snorm = 0.0;
-  auto stage_load = [&](int64_t tile) {          // raw values only: nothing here may CONSUME a load (see stage_store)
-    const int64_t base = tile * TN * d;
+  auto stage_load = [&](int64_t tile) {          // raw values only: nothing here may CONSUME a load
+    const char* yt = (const char*)(y + tile * TN * d);
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int64_t g = base + goff[i];
-      sreg[i] = y[(g <= last) ? g : last];
-    }
-    const int64_t c = tile * TN + (tid & (TN - 1));
-    snorm = yy[(c < m) ? c : (m - 1)];
+    for (int i = 0; i < NST; ++i) sreg[i] = *(const double*)(yt + goffb[i]);
+    snorm = *(const double*)((const char*)(yy + tile * TN) + nb);
   };
-  auto stage_store = [&](int64_t tile) {         // masks applied here, after the epilogue's stores have been issued
-    double* yb = ys[(int)(tile & 1)];
-    const int64_t base = tile * TN * d;
+  auto stage_store = [&](int par, int nbuf) {    // after the epilogue's stores have been issued
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      double* dst = (slot[i] >= 0) ? (yb + slot[i]) : (sink + tid);
-      *dst = (base + goff[i] <= last) ? sreg[i] : 0.0;
-    }
-    const int64_t c = tile * TN + (tid & (TN - 1));
-    yn[(int)(tile % 3)][tid] = (c < m) ? snorm : 0.0;   // three buffers: the epilogue of tile t reads them one step later
+    for (int i = 0; i < NST; ++i) dst[i][par * YB] = sreg[i];
+    yn[nbuf][tid] = c2 * snorm;                  // three buffers: the epilogue of tile t reads them one step later
   };
   auto mma = [&](int buf, v4d_t (&acc)[4]) {
     const double* yb = &ys[buf][li * NNS + lk];
@@ -172,75 +131,75 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows(DevCov cov, const do
   };
   const int64_t ntiles = (ldo + TN - 1) / TN;   // covers the pad columns of the leading dimension
   const bool interior_rows = (int64_t)blockIdx.x * 128 + 128 <= n;
-  stage_load(0); stage_store(0);
-  if (ntiles > 1) { stage_load(1); stage_store(1); }
+  stage_load(0); stage_store(0, 0);
+  if (ntiles > 1) { stage_load(1); stage_store(1, 1); }
   __syncthreads();
   v4d_t accA[4], accB[4];
   mma(0, accA);
   lds_barrier();
-  // One tile step.  FAST (interior rows, full tile, no diagonal term) is branch-free: the MFMAs of tile t+1, the
-  // epilogue of tile t and its 32 stores form one basic block, so the wait before the LDS writes of tile t+2 counts
-  // the stores issued since the loads (vmcnt(32)) instead of draining them.  The two variants run in SEPARATE loops: a
-  // branch between them inside one loop makes the compiler assume the slow path's (unknown) store count at the join.
-  auto step = [&](int64_t t, auto fast_tag) {
+  // One tile step: the epilogue of tile t (accumulators `cur`) while the MFMAs of tile t+1 fill `nxt`.  FAST (interior
+  // rows, full tile, no diagonal term) is branch-free: the MFMAs, the epilogue and its 16 stores form one basic block, so
+  // the wait before the LDS writes of tile t+2 counts the stores issued since the loads (vmcnt(16)) instead of draining
+  // them.  PAR = t & 1 as a compile-time constant in the unrolled loop.  The two variants run in SEPARATE loops: a branch
+  // between them inside one loop makes the compiler assume the slow path's (unknown) store count at the join.
+  auto step = [&](int64_t t, v4d_t (&cur)[4], v4d_t (&nxt)[4], int par, int ncur, auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
-    const int cur = (int)(t % 3), nxt = (int)((t + 1) & 1);
-    const int64_t t2 = (t + 2 < ntiles) ? (t + 2) : (ntiles - 1);   // unconditional (a clamped re-load near the end)
+    const int64_t t2 = FAST ? (t + 2) : ((t + 2 < ntiles) ? (t + 2) : (ntiles - 1));   // (a clamped re-load near the end)
     stage_load(t2);                                   // requested now, written to LDS after the epilogue
-    mma(nxt, accB);                                   // tile t + 1 (the last one is a dummy on stale data)
+    mma(par ^ 1, nxt);                                // tile t + 1 (the last one is a dummy on stale data)
     const int64_t col0 = t * TN;
     if (FAST) {
+      char* const ob = (char*)(out_wg + col0);
+      char* const ob32 = HAS32 ? (char*)(out32_wg + col0) : nullptr;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        const int64_t c = col0 + 16 * tt + li;
-        const double yc = yn[cur][16 * tt + li];
+        const double yc = yn[ncur][16 * tt + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const double v = leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]);
-          const unsigned e = lrow[r] + (unsigned)col0 + 16u * tt;
-          out_wg[e] = v;
-          if (HAS32) out32_wg[e] = surrogate_bits(v, q32);
+          const double v = leaf_value_k<KIND>(m2, xr[r], yc, cur[tt][r]);
+          *(double*)(ob + 128 * tt + lrowb[r]) = v;
+          if (HAS32) *(float*)(ob32 + 64 * tt + lrowb32[r]) = surrogate_bits(v, q32);
         }
       }
 #pragma unroll
       for (int i = 0; i < 4 * KSTEPS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 800 / (4 * KSTEPS), 0);   // its share of the epilogue VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, EPI_VALU / (4 * KSTEPS), 0);   // its share of the epilogue VALU
       }
     } else {
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int64_t c = col0 + 16 * tt + li;
-        const double yc = yn[cur][16 * tt + li];
+        const double yc = yn[ncur][16 * tt + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t row = row0 + lk + 4 * r;
           if (row < n && c < ldo) {
-            const double v = (c < m) ? leaf_value_k<KIND>(lf, xr[r], yc, accA[tt][r]) + ((row == c) ? add_diag : 0.0) : 0.0;
+            const double v = (c < m) ? leaf_value_k<KIND>(m2, xr[r], yc, cur[tt][r]) + ((row == c) ? add_diag : 0.0) : 0.0;
             out[row * ldo + c] = v;
             if (HAS32) out32[row * ldo + c] = surrogate_bits(v, q32);
           }
         }
       }
     }
-    {                                                 // into the ys buffer of tile t, whose MFMAs finished last step
-      double* yb = ys[(int)(t & 1)];                  // (t2 clamped: the buffer of a finished tile takes a harmless copy)
-      const int64_t base = t2 * TN * d;
-#pragma unroll
-      for (int i = 0; i < NST; ++i) {
-        double* dst = (slot[i] >= 0) ? (yb + slot[i]) : (sink + tid);
-        *dst = (base + goff[i] <= last) ? sreg[i] : 0.0;
-      }
-      const int64_t c = t2 * TN + (tid & (TN - 1));
-      yn[(int)((t + 2) % 3)][tid] = (c < m) ? snorm : 0.0;
-    }
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) accA[tt] = accB[tt];
+    stage_store(par, (ncur == 0) ? 2 : ncur - 1);     // tile t + 2: the ys buffer of tile t (its MFMAs finished last step), yn[(t + 2) % 3]
     lds_barrier();
   };
   const int64_t n_fast = (interior_rows && add_diag == 0.0) ? (m / TN) : 0;   // full tiles of interior rows
-  for (int64_t t = 0; t < n_fast; ++t) step(t, std::true_type{});
-  for (int64_t t = n_fast; t < ntiles; ++t) step(t, std::false_type{});
+  int64_t t = 0;
+  int nc = 0;                                         // t % 3
+  for (; t + 2 <= n_fast; t += 2) {
+    step(t, accA, accB, 0, nc, std::true_type{});
+    nc = (nc == 2) ? 0 : nc + 1;
+    step(t + 1, accB, accA, 1, nc, std::true_type{});
+    nc = (nc == 2) ? 0 : nc + 1;
+  }
+  for (; t < ntiles; ++t) {
+    step(t, accA, accB, (int)(t & 1), nc, std::false_type{});
+    nc = (nc == 2) ? 0 : nc + 1;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) accA[tt] = accB[tt];
+  }
 }
 
 }  // namespace

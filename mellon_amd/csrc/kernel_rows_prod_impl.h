@@ -11,6 +11,7 @@
 
 namespace {
 
+// (staging, loop structure and the padded-copy contract on `y`, `yy`: cov_rows_impl.h)
 template <int KIND, bool HAS32, int KSTEPS>
 __global__ __launch_bounds__(512) void k_kernel_matrix_rows_prod(DevCov cov, const double* __restrict__ x, int64_t n,
                                                                  const double* __restrict__ y, int64_t m, int d,
@@ -18,12 +19,17 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows_prod(DevCov cov, con
                                                                  const double* __restrict__ yy,
                                                                  double* __restrict__ out, int64_t ldo, double add_diag,
                                                                  float* __restrict__ out32, int q32) {
-  __shared__ double ys[2][TN * NNS];
-  __shared__ double yn[3][512];        // |y_state|^2 of the centres ([..][tid < TN] used, the rest absorbs the other threads' stores)
-  __shared__ double yt[3][TN];         // their time stamps
-  __shared__ double sink[512];
+  constexpr int YB = TN * NNS + 512;   // one operand buffer: the state tile, then a slot per thread for stores without an element
+  __shared__ double ys[2][YB];
+  __shared__ double yn[3][512];        // c0^2 |y_state|^2 of the centres ([..][tid < TN] used, the rest absorbs the other threads' stores)
+  __shared__ double yt[3][512];        // c1 * their time stamps (same layout)
   constexpr int NST = (TN * (4 * KSTEPS + 1) + 511) / 512;   // TN x d <= TN x (4 KSTEPS + 1) staged values
-  const DevLeaf lf0 = cov.leaves[0], lf1 = cov.leaves[1];
+  // (cov_epilogue.h) scaled squared distances: state leaf from the pre-scaled norms and the MFMA's dot product; time leaf
+  // directly from the two PRE-SCALED time stamps, s1 = (c1 t_x - c1 t_c)^2 + c1^2 1e-12 -- the reference's
+  // t_x^2 - 2 t_x t_c + t_c^2 + 1e-12 without its cancellation (equal stamps give exactly 1e-12 either way)
+  const double c20 = covepi::sq_scale<KIND>(cov.leaves[0]), m20 = -2.0 * c20;
+  const double c21 = covepi::sq_scale<KIND>(cov.leaves[1]), c1 = sqrt(c21), eps1 = c21 * 1e-12;
+  constexpr int EPI_VALU = (HAS32 ? 41 : 38) * 16 + 12;
   const int ds = d - 1;                // state columns; column d - 1 is the time stamp
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
@@ -37,55 +43,51 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows_prod(DevCov cov, con
       a[ks] = (k < ds) ? x[ar * d + k] : 0.0;
     }
   }
-  double xr[4], xt[4], xt2[4];
+  double xr[4], xt[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = row0 + lk + 4 * r;
-    xr[r] = (row < n) ? xx[row] : 0.0;                 // leaf 0's norms come first in the norms buffer
-    xt[r] = (row < n) ? x[row * d + ds] : 0.0;
-    xt2[r] = xt[r] * xt[r];
+    xr[r] = (row < n) ? c20 * (xx[row] + 1e-12) : 0.0;   // leaf 0's norms come first in the norms buffer
+    xt[r] = (row < n) ? c1 * x[row * d + ds] : 0.0;
   }
   double* const out_wg = out + (int64_t)blockIdx.x * 128 * ldo;
   float* const out32_wg = HAS32 ? out32 + (int64_t)blockIdx.x * 128 * ldo : nullptr;
-  unsigned lrow[4];
+  unsigned lrowb[4], lrowb32[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) lrow[r] = (unsigned)(wave * 16 + lk + 4 * r) * (unsigned)ldo + (unsigned)li;
-  for (int e = tid; e < 2 * TN * NNS; e += 512) (&ys[0][0])[e] = 0.0;
+  for (int r = 0; r < 4; ++r) {
+    lrowb[r] = ((unsigned)(wave * 16 + lk + 4 * r) * (unsigned)ldo + (unsigned)li) * 8u;
+    lrowb32[r] = lrowb[r] >> 1;
+  }
+  for (int e = tid; e < 2 * YB; e += 512) (&ys[0][0])[e] = 0.0;
   __syncthreads();
   const int cnt = TN * d;
-  // element e of a tile: centre e / d, column e % d.  State columns go to the MFMA operand tile, the time column to yt.
-  int slot[NST], tslot[NST], goff[NST];
-  const int64_t last = m * (int64_t)d - 1;
+  // element e of a tile: centre e / d, column e % d.  State columns go to the MFMA operand tile; the time stamps are
+  // fetched once more by the thread that owns the centre's norm (the tile copy of column d - 1 goes to the sink) and
+  // take the norms' three-buffer route, scaled by c1.
+  unsigned goffb[NST];
+  double* dst[NST];
 #pragma unroll
   for (int i = 0; i < NST; ++i) {
     const int e = tid + 512 * i;
     const int r = e / d, k = e - r * d;
-    slot[i] = (e < cnt && k < ds) ? (r * NNS + k) : -1;
-    tslot[i] = (e < cnt && k == ds) ? r : -1;
-    goff[i] = r * d + k;
+    goffb[i] = (e < cnt) ? (unsigned)e * 8u : 0u;
+    dst[i] = (e < cnt && k < ds) ? &ys[0][r * NNS + k] : &ys[0][TN * NNS + tid];
   }
-  double sreg[NST], snorm = 0.0;
+  const unsigned nb = (unsigned)(tid & (TN - 1)) * 8u;
+  const unsigned tb = ((unsigned)(tid & (TN - 1)) * (unsigned)d + (unsigned)ds) * 8u;
+  double sreg[NST], snorm = 0.0, stime = 0.0;
   auto stage_load = [&](int64_t tile) {
-    const int64_t base = tile * TN * d;
+    const char* ytile = (const char*)(y + tile * TN * d);
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int64_t g = base + goff[i];
-      sreg[i] = y[(g <= last) ? g : last];
-    }
-    const int64_t c = tile * TN + (tid & (TN - 1));
-    snorm = yy[(c < m) ? c : (m - 1)];
+    for (int i = 0; i < NST; ++i) sreg[i] = *(const double*)(ytile + goffb[i]);
+    stime = *(const double*)(ytile + tb);
+    snorm = *(const double*)((const char*)(yy + tile * TN) + nb);
   };
-  auto stage_store = [&](int64_t tile, int ybuf, int nbuf) {
-    double* yb = ys[ybuf];
-    double* tb = yt[nbuf];
-    const int64_t base = tile * TN * d;
+  auto stage_store = [&](int par, int nbuf) {
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      double* dst = (slot[i] >= 0) ? (yb + slot[i]) : ((tslot[i] >= 0) ? (tb + tslot[i]) : (sink + tid));
-      *dst = (base + goff[i] <= last) ? sreg[i] : 0.0;
-    }
-    const int64_t c = tile * TN + (tid & (TN - 1));
-    yn[nbuf][tid] = (c < m) ? snorm : 0.0;
+    for (int i = 0; i < NST; ++i) dst[i][par * YB] = sreg[i];
+    yn[nbuf][tid] = c20 * snorm;
+    yt[nbuf][tid] = c1 * stime;
   };
   auto mma = [&](int buf, v4d_t (&acc)[4]) {
     const double* yb = &ys[buf][li * NNS + lk];
@@ -99,48 +101,49 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows_prod(DevCov cov, con
   };
   const int64_t ntiles = (ldo + TN - 1) / TN;
   const bool interior_rows = (int64_t)blockIdx.x * 128 + 128 <= n;
-  stage_load(0); stage_store(0, 0, 0);
-  if (ntiles > 1) { stage_load(1); stage_store(1, 1, 1); }
+  stage_load(0); stage_store(0, 0);
+  if (ntiles > 1) { stage_load(1); stage_store(1, 1); }
   __syncthreads();
   v4d_t accA[4], accB[4];
   mma(0, accA);
   lds_barrier();
-  auto step = [&](int64_t t, auto fast_tag) {
+  auto step = [&](int64_t t, v4d_t (&cur)[4], v4d_t (&nxt)[4], int par, int ncur, auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
-    const int cur = (int)(t % 3), nxt = (int)((t + 1) & 1);
-    const int64_t t2 = (t + 2 < ntiles) ? (t + 2) : (ntiles - 1);
+    const int64_t t2 = FAST ? (t + 2) : ((t + 2 < ntiles) ? (t + 2) : (ntiles - 1));
     stage_load(t2);
-    mma(nxt, accB);
+    mma(par ^ 1, nxt);
     const int64_t col0 = t * TN;
     if (FAST) {
+      char* const ob = (char*)(out_wg + col0);
+      char* const ob32 = HAS32 ? (char*)(out32_wg + col0) : nullptr;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
-        const double yc = yn[cur][16 * tt + li], tc = yt[cur][16 * tt + li];
-        const double tc2 = tc * tc;
+        const double yc = yn[ncur][16 * tt + li], tc = yt[ncur][16 * tt + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const double v = leaf_value_k<KIND>(lf0, xr[r], yc, accA[tt][r]) * leaf_value_k<KIND>(lf1, xt2[r], tc2, xt[r] * tc);
-          const unsigned e = lrow[r] + (unsigned)col0 + 16u * tt;
-          out_wg[e] = v;
-          if (HAS32) out32_wg[e] = surrogate_bits(v, q32);
+          const double dt = xt[r] - tc;
+          const double v = covepi::leaf_product_s<KIND>(fmax(fma(m20, cur[tt][r], xr[r]) + yc, 1e-300), fma(dt, dt, eps1));
+          *(double*)(ob + 128 * tt + lrowb[r]) = v;
+          if (HAS32) *(float*)(ob32 + 64 * tt + lrowb32[r]) = surrogate_bits(v, q32);
         }
       }
 #pragma unroll
       for (int i = 0; i < 4 * KSTEPS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 1500 / (4 * KSTEPS), 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, EPI_VALU / (4 * KSTEPS), 0);
       }
     } else {
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         const int64_t c = col0 + 16 * tt + li;
-        const double yc = yn[cur][16 * tt + li], tc = yt[cur][16 * tt + li];
+        const double yc = yn[ncur][16 * tt + li], tc = yt[ncur][16 * tt + li];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t row = row0 + lk + 4 * r;
           if (row < n && c < ldo) {
-            const double v = (c < m) ? leaf_value_k<KIND>(lf0, xr[r], yc, accA[tt][r]) *
-                                           leaf_value_k<KIND>(lf1, xt2[r], tc * tc, xt[r] * tc) + ((row == c) ? add_diag : 0.0)
+            const double dt = xt[r] - tc;
+            const double v = (c < m) ? covepi::leaf_product_s<KIND>(fmax(fma(m20, cur[tt][r], xr[r]) + yc, 1e-300), fma(dt, dt, eps1))
+                                           + ((row == c) ? add_diag : 0.0)
                                      : 0.0;
             out[row * ldo + c] = v;
             if (HAS32) out32[row * ldo + c] = surrogate_bits(v, q32);
@@ -148,14 +151,24 @@ __global__ __launch_bounds__(512) void k_kernel_matrix_rows_prod(DevCov cov, con
         }
       }
     }
-    stage_store(t2, (int)(t & 1), (int)((t + 2) % 3));   // into the buffers tile t has just released
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) accA[tt] = accB[tt];
+    stage_store(par, (ncur == 0) ? 2 : ncur - 1);   // tile t + 2 into the buffers tile t has just released
     lds_barrier();
   };
   const int64_t n_fast = (interior_rows && add_diag == 0.0) ? (m / TN) : 0;
-  for (int64_t t = 0; t < n_fast; ++t) step(t, std::true_type{});
-  for (int64_t t = n_fast; t < ntiles; ++t) step(t, std::false_type{});
+  int64_t t = 0;
+  int nc = 0;
+  for (; t + 2 <= n_fast; t += 2) {
+    step(t, accA, accB, 0, nc, std::true_type{});
+    nc = (nc == 2) ? 0 : nc + 1;
+    step(t + 1, accB, accA, 1, nc, std::true_type{});
+    nc = (nc == 2) ? 0 : nc + 1;
+  }
+  for (; t < ntiles; ++t) {
+    step(t, accA, accB, (int)(t & 1), nc, std::false_type{});
+    nc = (nc == 2) ? 0 : nc + 1;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) accA[tt] = accB[tt];
+  }
 }
 
 }  // namespace

@@ -7,6 +7,11 @@
 // SYRK as fp64 MFMA GEMMs), and triangular solves as sequences of GEMMs against row-/column-scaled copies of
 // the factor whose 128x128 diagonal blocks are inverted explicitly (the standard GPU TRSM; only
 // diagonal blocks are ever inverted, so the conditioning that enters is that of a 128-block).
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "mln_internal.h"
 #include "linalg.h"
 
@@ -201,6 +206,71 @@ __global__ void k_copy_below_blocks(const double* __restrict__ src, double* __re
 // apply: with <= 39 row tiles a 128-tile launch is 14 us of serial work per CU), the trailing update as one
 // lower-tiles-only GEMM  A22 -= P P^T per PAIR of block columns.  The side matrix is copied under the block diagonal of
 // A at the end.
+// ---- CU-masked side streams ---------------------------------------------------------------------------------------
+namespace {
+struct MaskedStreams {
+  std::map<int, hipStream_t> by_free;     // free_cus -> stream (nullptr: creation failed, do not retry)
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+std::mutex g_ms_mu;
+std::map<mln_ctx*, MaskedStreams> g_ms;
+thread_local bool t_no_lookahead = false;
+}  // namespace
+
+void set_lookahead_disabled(bool off) { t_no_lookahead = off; }
+
+hipStream_t masked_stream(mln_ctx* ctx, int free_cus) {
+  static const bool off = std::getenv("MELLON_AMD_CU_MASK") && std::atoi(std::getenv("MELLON_AMD_CU_MASK")) == 0;
+  if (off) return nullptr;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 0;
+  if (n_cu < 64 || free_cus < 0 || free_cus * 2 > n_cu) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ms_mu);
+  MaskedStreams& ms = g_ms[ctx];
+  auto it = ms.by_free.find(free_cus);
+  if (it != ms.by_free.end()) return it->second;
+  if (free_cus == 0) {                   // the unmasked companion: a second plain stream of this context
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+    ms.by_free[0] = st;
+    return st;
+  }
+  // the LAST free_cus bits stay clear: with the CU index interleaved over the XCDs that is free_cus / 8 units per XCD,
+  // with an XCD-major index a corner of the last one -- both leave the room the side work needs
+  std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+  for (int c = 0; c < n_cu - free_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+  ms.by_free[free_cus] = st;
+  return st;
+}
+
+hipEvent_t masked_stream_event(mln_ctx* ctx, int which) {
+  std::lock_guard<std::mutex> lk(g_ms_mu);
+  MaskedStreams& ms = g_ms[ctx];
+  if (which < 0 || which > 3) return nullptr;
+  if (!ms.ev[which] && hipEventCreateWithFlags(&ms.ev[which], hipEventDisableTiming) != hipSuccess) ms.ev[which] = nullptr;
+  return ms.ev[which];
+}
+
+void masked_streams_release(mln_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_ms_mu);
+  auto it = g_ms.find(ctx);
+  if (it == g_ms.end()) return;
+  for (auto& kv : it->second.by_free) if (kv.second) { (void)hipStreamSynchronize(kv.second); (void)hipStreamDestroy(kv.second); }
+  for (hipEvent_t e : it->second.ev) if (e) (void)hipEventDestroy(e);
+  g_ms.erase(it);
+}
+
+// Right-looking blocked Cholesky, two 128-wide block columns per round.  The critical path of a round is five dependent
+// launches -- diagonal block, panel, the narrow update of the second block column, its diagonal block, its panel: 2 x 50 us
+// of single-workgroup work and three ~14 us GEMMs that are launch + pipeline latency -- followed by the trailing update,
+// the only launch with work for the whole chip (150 us at the start of a 5000 x 5000 factorisation, falling).
+// Round 4, LOOK-AHEAD across kernels: the trailing update is split into the two block columns the NEXT round factors
+// (`ahead`, on the context's own stream: the critical path) and the rest (`behind`, on a stream whose CU mask leaves 64
+// units free), and the next round's critical path runs while `behind` is still at work.  Dependencies: `behind` of round p
+// needs round p's panels (event after the second panel) and follows `behind` of round p - 1 (same stream); `ahead` of
+// round p + 1 overwrites what `behind` of round p wrote (event after `behind`).  Timeline of chol(5000), no look-ahead:
+// 20 x 141 us of critical path + 1.35 ms of trailing updates = 4.15 ms (profiles/r04_step_timeline.txt).
 int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   if (m <= 0) return MLN_OK;
   constexpr int CB = 128;
@@ -211,6 +281,18 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (m > CB) MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)m * (size_t)lda));
   int rc = MLN_OK;
+  static const bool la_env_off = std::getenv("MELLON_AMD_CHOL_LOOKAHEAD") && std::atoi(std::getenv("MELLON_AMD_CHOL_LOOKAHEAD")) == 0;
+  hipStream_t behind = (!la_env_off && !t_no_lookahead && m >= 8 * CB) ? masked_stream(ctx, 64) : nullptr;
+  hipEvent_t ev_panels = behind ? masked_stream_event(ctx, 0) : nullptr;
+  hipEvent_t ev_behind = behind ? masked_stream_event(ctx, 1) : nullptr;
+  if (!ev_panels || !ev_behind) behind = nullptr;
+  hipStream_t const own = ctx->stream;
+  bool behind_pending = false;          // a `behind` update is in flight whose event the next `ahead` must wait for
+  if (behind) {                         // everything enqueued so far (the matrix itself) precedes the side stream's first read
+    hipError_t e = hipEventRecord(ev_panels, own);
+    if (e == hipSuccess) e = hipStreamWaitEvent(behind, ev_panels, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); behind = nullptr; }
+  }
   // Two block columns per round: the second one is brought up to date by a narrow GEMM (K = 128, 128 columns), and the
   // big trailing update then runs ONCE with K = 256 on the two panels side by side in the side matrix -- the same flops
   // as two K = 128 updates over nearly the same area, at half the per-tile prologue/epilogue cost.
@@ -242,12 +324,46 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
     if (rc != MLN_OK || rem2 <= 0) break;
     rc = panel(j1, nb2, rem2);
     if (rc != MLN_OK) break;
+    const int64_t j2 = j1 + nb2;
+    const double* Pw = Ls + j2 * lda + j0;
     GemmArgs t{};     // A22 -= [P1' P2] [P1' P2]^T on lower tiles, K = nb1 + nb2
-    const double* Pw = Ls + (j1 + nb2) * lda + j0;
-    t.A = Pw; t.lda = lda; t.B = Pw; t.ldb = lda; t.C = A + (j1 + nb2) * lda + (j1 + nb2); t.ldc = lda;
+    t.A = Pw; t.lda = lda; t.B = Pw; t.ldb = lda; t.C = A + j2 * lda + j2; t.ldc = lda;
     t.M = rem2; t.N = rem2; t.K = nb1 + nb2; t.alpha = -1.0; t.beta = 1.0; t.ta = 0; t.tb = 1; t.lower_only = 1;
-    rc = launch_dgemm(ctx, t);
+    const int64_t ahead_cols = 2 * CB;
+    if (behind && rem2 > ahead_cols + 4 * CB) {
+      hipError_t e = hipEventRecord(ev_panels, own);                  // both panels of this round are enqueued
+      // `ahead`: the next round's two block columns (all rows below), on the critical path's own stream -- after the
+      // previous round's `behind`, which wrote them last
+      if (e == hipSuccess && behind_pending) e = hipStreamWaitEvent(own, ev_behind, 0);
+      if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
+      GemmArgs a = t;
+      a.N = ahead_cols;                                               // (lower_only: tiles above the diagonal are skipped)
+      rc = launch_dgemm(ctx, a);
+      if (rc != MLN_OK) break;
+      // `behind`: everything to the right of those columns, rows from the same offset on
+      GemmArgs b = t;
+      b.A = Pw + ahead_cols * lda; b.B = b.A; b.C = A + (j2 + ahead_cols) * lda + (j2 + ahead_cols);
+      b.M = rem2 - ahead_cols; b.N = rem2 - ahead_cols;
+      e = hipStreamWaitEvent(behind, ev_panels, 0);
+      if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
+      ctx->stream = behind;
+      rc = launch_dgemm(ctx, b);
+      ctx->stream = own;
+      if (rc != MLN_OK) break;
+      e = hipEventRecord(ev_behind, behind);
+      if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
+      behind_pending = true;
+    } else {
+      if (behind_pending) {                                           // the plain update reads and writes what `behind` wrote
+        hipError_t e = hipStreamWaitEvent(own, ev_behind, 0);
+        if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
+        behind_pending = false;
+      }
+      rc = launch_dgemm(ctx, t);
+    }
   }
+  ctx->stream = own;
+  if (behind_pending) (void)hipStreamWaitEvent(own, ev_behind, 0);    // (also on the error paths: the frees below follow `own`)
   int info = 0;
   if (rc == MLN_OK) {
     if (Ls) hipLaunchKernelGGL(k_copy_below_blocks, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, Ls, A, m, lda);

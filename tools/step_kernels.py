@@ -6,7 +6,9 @@ def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n)
     return re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)[:60]
 km = [i for i, r in enumerate(rows) if "k_kernel_matrix_rows" in r[0] and r[2] - r[1] > 5e6]
-rows = rows[km[-1] - 6:]
+# the step begins with cov(xu, xu) -- the previous k_kernel_matrix_rows launch (small) -- and its row norms
+kuu = [i for i, r in enumerate(rows[:km[-1]]) if "k_kernel_matrix_rows" in r[0]]
+rows = rows[(kuu[-1] - 3) if kuu else (km[-1] - 6):]
 tot = {}
 for n, s, e in rows:
     k = short(n); t = tot.setdefault(k, [0, 0.0]); t[0] += 1; t[1] += (e - s) / 1e6
