@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmellon_hip.so")
-SOURCES = ["api.hip", "alloc.hip", "comm.hip", "cov_grad.hip", "cov_kernels.hip", "cov_rows.hip", "cov_rows_matern32.hip", "cov_rows_matern52.hip", "cov_rows_expquad.hip",
+SOURCES = ["api.hip", "api_fit.hip", "api_precond.hip", "api_solve.hip", "api_noise.hip", "alloc.hip", "comm.hip", "cov_grad.hip", "cov_kernels.hip", "cov_rows.hip", "cov_rows_matern32.hip", "cov_rows_matern52.hip", "cov_rows_expquad.hip",
            "cov_rows_exponential.hip", "predict_rows.hip", "predict_rows_matern32.hip", "predict_rows_matern52.hip", "predict_rows_expquad.hip", "predict_rows_exponential.hip",
            "predict_rows_ratquad.hip", "predict_rows_prod.hip", "predict_rows_prod_matern32.hip", "predict_rows_prod_matern52.hip",
            "predict_rows_prod_expquad.hip", "predict_rows_prod_exponential.hip", "kernel_rows_prod_matern32.hip", "kernel_rows_prod_matern52.hip",

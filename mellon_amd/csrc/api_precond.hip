@@ -1,0 +1,571 @@
+// C ABI, part 3: Gram, whitening, Ridge / preconditioner factor and its rebuild, Ridge start (see api_internal.h).
+#include "api_internal.h"
+
+// G (m x ldg, full symmetric) = alpha * A^T A for the row-major A (rows x m, leading dim lda), all-reduced.
+// `quantised`: A holds covariance values in [0, 1] and the result only feeds a preconditioner -- the Gram of A rounded
+// to 23 fractional bits, exact in integers on the int8 matrix cores (gram_i8.hip).
+int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
+                   int64_t ldg, bool quantised) {
+  int split = quantised ? gram_i8_splits(rows, m) : (int)(rows / 8192);
+  if (split < 1) split = 1;
+  if (split > 16 && !quantised) split = 16;
+  const size_t stride = (size_t)m * ldg;
+  double* parts = nullptr;
+  if (split > 1) MLN_HIP(ctx, mln_dmalloc((void**)&parts, sizeof(double) * stride * split));
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = A; g.ldb = lda;
+  g.C = (split > 1) ? parts : G; g.ldc = ldg;
+  g.M = m; g.N = m; g.K = rows; g.alpha = alpha; g.beta = 0.0; g.ta = 1; g.tb = 0; g.lower_only = 1;
+  g.split_k = split; g.c_split_stride = (int64_t)stride;
+  int rc = MLN_OK;
+  if (split > 1) rc = (hipMemsetAsync(parts, 0, sizeof(double) * stride * split, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  else rc = (hipMemsetAsync(G, 0, sizeof(double) * stride, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  if (rc == MLN_OK && rows > 0)
+    rc = quantised ? launch_gram_i8(ctx, A, lda, rows, m, alpha, g.C, ldg, (int64_t)stride, split) : launch_dgemm(ctx, g);
+  if (rc == MLN_OK && split > 1) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, G, (int64_t)stride, 0.0);
+  if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
+  if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)stride);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (parts) (void)mln_dfree(parts);
+  return rc;
+}
+
+// Test / measurement hook for gram_i8.hip: out (m x m) = the Gram of round(A 8355711) / 8355711^2, A rows x m with values
+// in [0, 1]; ms_out (may be NULL) = milliseconds per call of digit extraction + integer GEMM + sum of the k-chunks.
+extern "C" int mln_diag_gram_i8(mln_ctx* ctx, const double* A, int64_t rows, int64_t m, double* out, int32_t reps,
+                                double* ms_out) {
+  if (!ctx || !A || !out || rows < 1 || m < 1) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  DevIn a;
+  DevOut o;
+  MLN_TRY(a.init(ctx, A, (size_t)rows * m));
+  MLN_TRY(o.init(ctx, out, (size_t)m * m));
+  const int split = gram_i8_splits(rows, m);
+  const size_t stride = (size_t)m * m;
+  double *parts = nullptr, *G = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&parts, sizeof(double) * stride * split));
+  MLN_HIP(ctx, mln_dmalloc((void**)&G, sizeof(double) * stride));
+  hipEvent_t e0, e1;
+  MLN_HIP(ctx, hipEventCreate(&e0));
+  MLN_HIP(ctx, hipEventCreate(&e1));
+  int rc = MLN_OK;
+  if (reps < 1) reps = 1;
+  for (int r = 0; r <= reps && rc == MLN_OK; ++r) {   // round 0 warms up
+    if (r == 1) (void)hipEventRecord(e0, ctx->stream);
+    rc = (hipMemsetAsync(parts, 0, sizeof(double) * stride * split, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+    if (rc == MLN_OK) rc = launch_gram_i8(ctx, a.dev, m, rows, m, 1.0, parts, m, (int64_t)stride, split);
+    if (rc == MLN_OK) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, G, (int64_t)stride, 0.0);
+  }
+  (void)hipEventRecord(e1, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (ms_out) *ms_out = ms / reps;
+  if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, m);
+  if (rc == MLN_OK) rc = launch_copy_block(ctx, G, m, o.dev, m, m, m);
+  if (rc == MLN_OK) rc = o.commit();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(parts); (void)mln_dfree(G);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
+// G ~ L^T L from every `row_stride`-th cell of this rank (scaled by row_stride), all-reduced.
+// ---- column-split m x m work (strong scaling) -----------------------------------------------------------
+// The whitening of the Gram and the inverses behind the per-evaluation products are "m right-hand sides through a
+// triangular solve": replicated, they cost every rank ~3.7 m^3 flops.  From 3 ranks on, rank r solves only its block of
+// columns [r b, (r + 1) b), writes it into a zeroed full matrix, and ONE all-reduce (a sum with zeros: exact, the same
+// bits on every rank) assembles the result -- 4 m^3 / N flops per rank for the whitening, 2 m^3 / N for the inverses.
+// MELLON_AMD_EMULATE_RANKS=N (tools/emulate_rank.py, one process): rank 0's block is timed, the other blocks are
+// computed too (the fit must go on) with their wall time recorded in emu_excluded.
+int split_ranks(const mln_ctx* ctx, int* my_rank, bool* emulate) {
+  *my_rank = ctx->rank; *emulate = false;
+  int n = ctx->n_ranks;
+  if (n <= 1)
+    if (const char* ev = std::getenv("MELLON_AMD_EMULATE_RANKS")) { n = std::atoi(ev); *my_rank = 0; *emulate = n > 1; }
+  static const int from = std::getenv("MELLON_AMD_COLSPLIT_RANKS") ? std::atoi(std::getenv("MELLON_AMD_COLSPLIT_RANKS")) : 3;
+  return (from > 0 && n >= from) ? n : 1;
+}
+
+template <typename Body>
+static int for_my_column_blocks(mln_fit* f, int n_split, int my_rank, bool emulate, int64_t b, Body body) {
+  mln_ctx* ctx = f->ctx;
+  for (int r = 0; r < n_split; ++r) {
+    if (!emulate && r != my_rank) continue;
+    const int64_t c0 = (int64_t)r * b, nb = std::min<int64_t>(b, f->m - c0);
+    if (nb <= 0) continue;
+    const bool excluded = emulate && r != my_rank;
+    double t0 = 0.0;
+    if (excluded) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); t0 = now_s(); }
+    MLN_TRY(body(c0, nb));
+    if (excluded) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); f->emu_excluded += now_s() - t0; }
+  }
+  return MLN_OK;
+}
+
+// G (S = K_s^T K_s, all-reduced, symmetric) <- Lp^-1 S Lp^-T, columns split over the ranks
+int fit_whiten_split(mln_fit* f, double* G, int64_t ldg, int n_split, int my_rank, bool emulate) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
+  DevScratch zb(ctx), tb(ctx), ob(ctx);
+  const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ldg;
+  MLN_HIP(ctx, zb.alloc(blk));
+  MLN_HIP(ctx, tb.alloc(blk));
+  MLN_HIP(ctx, ob.alloc(full));
+  double *Z = zb.p, *T = tb.p, *Out = ob.p;
+  MLN_HIP(ctx, hipMemsetAsync(Out, 0, full, ctx->stream));
+  MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
+    MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
+    MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));             // unit columns c0 .. c0 + nb
+    MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // (Lp^-T)[:, block]
+    GemmArgs g{};                                                       // T = S (Lp^-T)[:, block]
+    g.A = G; g.lda = ldg; g.B = Z; g.ldb = b; g.C = T; g.ldc = b;
+    g.M = m; g.N = nb; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
+    MLN_TRY(launch_dgemm(ctx, g));
+    MLN_TRY(triinv_solve_left(ctx, f->tri, T, nb, b));                  // Lp^-1 S Lp^-T [:, block]
+    return launch_copy_block(ctx, T, b, Out + c0, ldg, m, nb);
+  }));
+  MLN_HIP(ctx, hipMemcpyAsync(G, Out, full, hipMemcpyDeviceToDevice, ctx->stream));
+  MLN_TRY(dev_allreduce(ctx, G, (int64_t)m * ldg));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
+}
+
+// inv (m x ld) <- C^-1 and P (m x ld) <- Lp^-T C^-T, column blocks of [C^-T ; P] split over the ranks (both zeroed
+// by the caller); tc: the block-scaled copies of C
+int fit_inverses_split(mln_fit* f, const TriInv& tc, double* inv, double* P, int64_t ld, int n_split, int my_rank,
+                              bool emulate) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
+  DevScratch zb(ctx), qb(ctx);
+  const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ld;
+  MLN_HIP(ctx, zb.alloc(blk));
+  MLN_HIP(ctx, qb.alloc(2 * full));                                     // [C^-T ; P], this rank's columns only
+  double *Z = zb.p, *Q = qb.p;
+  MLN_HIP(ctx, hipMemsetAsync(Q, 0, 2 * full, ctx->stream));
+  MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
+    MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
+    MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));
+    MLN_TRY(triinv_solve_left_T(ctx, tc, Z, nb, b));                    // (C^-T)[:, block]
+    MLN_TRY(launch_copy_block(ctx, Z, b, Q + c0, ld, m, nb));
+    MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // P[:, block] = Lp^-T (C^-T)[:, block]
+    return launch_copy_block(ctx, Z, b, Q + (size_t)m * ld + c0, ld, m, nb);
+  }));
+  MLN_TRY(dev_allreduce(ctx, Q, 2 * (int64_t)m * ld));
+  MLN_TRY(launch_transpose(ctx, Q, ld, inv, ld, m));                                  // C^-1
+  MLN_TRY(launch_copy_block(ctx, Q + (size_t)m * ld, ld, P, ld, m, ld));              // P
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
+}
+
+__global__ void k_round_bits(double* __restrict__ A, int64_t count, double scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+    A[i] = rint(A[i] * scale) / scale;
+}
+
+// Lp^-1 as an explicit lower-triangular matrix (once per fit).  With it the whitening of a Gram, Lp^-1 S Lp^-T, and
+// P = Lp^-T C^-T are GEMMs over the non-zero K ranges (dgemm kmodes 3 / 4 / 7) instead of chains of 40 dependent block
+// solves: 9.3 -> ~5 ms per whitening, 3.9 -> ~1 ms for P at m = 5000.  The explicit inverse multiplies rounding by
+// cond(Lp) ~ 1e3-1e4 where the block solves are backward stable -- immaterial for a preconditioner built from a Gram
+// quantised to 23 bits, and 1e-12 relative on w = P u.  MELLON_AMD_EXPLICIT_LINV=0 restores the solves.
+bool use_explicit_linv() {
+  static const bool on = !(std::getenv("MELLON_AMD_EXPLICIT_LINV") && std::atoi(std::getenv("MELLON_AMD_EXPLICIT_LINV")) == 0);
+  return on;
+}
+
+int fit_ensure_linv(mln_fit* f) {
+  if (f->Linv) return MLN_OK;
+  mln_ctx* ctx = f->ctx;
+  const size_t bytes = sizeof(double) * (size_t)f->m * f->ldp;
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->Linv, bytes));
+  MLN_HIP(ctx, hipMemsetAsync(f->Linv, 0, bytes, ctx->stream));
+  MLN_TRY(launch_add_diag(ctx, f->Linv, f->m, f->ldp, 1.0));
+  return triinv_solve_left(ctx, f->tri, f->Linv, f->m, f->ldp, true);      // Lp^-1 I, lower triangular right-hand side
+}
+
+// G (symmetric, full storage) <- Lp^-1 G Lp^-T through the explicit inverse: two GEMMs
+int fit_whiten_gemm(mln_fit* f, double* G, int64_t ldg) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m;
+  MLN_TRY(fit_ensure_linv(f));
+  double* T = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&T, sizeof(double) * (size_t)m * ldg));
+  GemmArgs g{};
+  g.A = f->Linv; g.lda = f->ldp; g.B = G; g.ldb = ldg; g.C = T; g.ldc = ldg;           // T = Lp^-1 G   (rows of Lp^-1 end at the diagonal)
+  g.M = m; g.N = m; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.kmode = 3;
+  int rc = launch_dgemm(ctx, g);
+  GemmArgs h{};
+  h.A = T; h.lda = ldg; h.B = f->Linv; h.ldb = f->ldp; h.C = G; h.ldc = ldg;           // G = T Lp^-T, lower tiles (symmetric)
+  h.M = m; h.N = m; h.K = m; h.alpha = 1.0; h.beta = 0.0; h.ta = 0; h.tb = 1; h.kmode = 4; h.lower_only = 1;
+  if (rc == MLN_OK) rc = launch_dgemm(ctx, h);
+  if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(T);
+  return rc;
+}
+
+int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
+  mln_ctx* ctx = f->ctx;
+  if (row_stride < 1) row_stride = 1;
+  // cells whose GLOBAL index is a multiple of row_stride: the sample -- and with it the preconditioner and the
+  // iteration path -- does not depend on how the cells are sharded (up to the order of the all-reduce sum)
+  const int64_t first = (row_stride - f->row0 % row_stride) % row_stride;
+  const int64_t rows = (f->n > first) ? (f->n - first + row_stride - 1) / row_stride : 0;
+  const double* Ls = f->L + first * f->ldl;
+  if (!f->kspace) return gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);
+  // implicit mode: G = Lp^-1 (K_s^T K_s) Lp^-T -- the Gram of the sampled rows of K itself (strided
+  // rows read in place) followed by two m x m block solves.  Rounding in K_s^T K_s is amplified by
+  // |Lp^-1|^2, which would matter for a quantity that enters the result; as a preconditioner the
+  // outcome is spectrally equivalent to the row-solved Gram within 1e-3 (measured), at none of the
+  // n_s m^2 triangular-solve flops.
+  // With many ranks the sampled rows are few per rank (~12 m / N) while the two m x m block solves are replicated:
+  // from N = 7 on it is cheaper for every rank to whiten ITS rows first, L_s = K_s Lp^-T (rows x m^2 flops, < 2 m^3),
+  // and to all-reduce the Gram of those -- the explicit route's arithmetic, no replicated solve, same single
+  // collective.  (The choice depends on the rank count only, so every rank takes the same branch.)
+  static const int row_solve_from = std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS")) : 0;   // superseded by the column split (fit_whiten_split)
+  if (ctx->n_ranks >= row_solve_from && row_solve_from > 0) {
+    double* R = nullptr;
+    const int64_t rr = rows > 0 ? rows : 1;
+    MLN_HIP(ctx, mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl));
+    int rc = MLN_OK;
+    if (rows > 0) rc = launch_copy_block(ctx, Ls, f->ldl * row_stride, R, f->ldl, rows, f->ldl);
+    if (rc == MLN_OK && rows > 0) rc = triinv_solve_right_T(ctx, f->tri, R, rows, f->ldl);
+    if (rc == MLN_OK) rc = gram_of(ctx, R, f->ldl, rows, f->m, (double)row_stride, G, ldg);   // all-reduced
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)mln_dfree(R);
+    return rc;
+  }
+  int rc = MLN_OK;
+  const int qbits = std::getenv("MELLON_AMD_GRAM_QBITS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_QBITS")) : 0;
+  if (qbits > 0) {   // experiment: the Gram of the sampled rows rounded to `qbits` fractional bits
+    double* R = nullptr;
+    const int64_t rr = rows > 0 ? rows : 1;
+    MLN_HIP(ctx, mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl));
+    if (rows > 0) rc = launch_copy_block(ctx, Ls, f->ldl * row_stride, R, f->ldl, rows, f->ldl);
+    if (rc == MLN_OK && rows > 0)
+      hipLaunchKernelGGL(k_round_bits, dim3(2048), dim3(256), 0, ctx->stream, R, rows * f->ldl, std::ldexp(1.0, qbits));
+    if (rc == MLN_OK) rc = gram_of(ctx, R, f->ldl, rows, f->m, (double)row_stride, G, ldg);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)mln_dfree(R);
+  } else {
+    // bounded covariances: 23-bit integer Gram on the int8 matrix cores (the preconditioner needs ~20 bits: gram_i8.hip)
+    // ... and only where the caller asked for a SAMPLED Gram (row_stride > 1: a preconditioner by construction);
+    // row_stride == 1 is the reference's exact Ridge matrix / the Gram whose eigenvalues are results
+    bool quant = f->cov_bounded01 && f->m >= 256 && row_stride > 1;
+    if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
+    rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
+  }
+  {
+    int my_rank = 0; bool emulate = false;
+    const int n_split = split_ranks(ctx, &my_rank, &emulate);
+    if (rc == MLN_OK && n_split > 1) return fit_whiten_split(f, G, ldg, n_split, my_rank, emulate);
+  }
+  if (rc == MLN_OK && use_explicit_linv()) return fit_whiten_gemm(f, G, ldg);
+  double* T = nullptr;
+  if (rc == MLN_OK) {
+    hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)f->m * ldg);
+    if (e == hipSuccess) e = hipMemsetAsync(T, 0, sizeof(double) * (size_t)f->m * ldg, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc Gram temp", __FILE__, __LINE__);
+  }
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, G, f->m, ldg);          // Lp^-1 S
+  if (rc == MLN_OK) rc = launch_transpose(ctx, G, ldg, T, ldg, f->m);           // (Lp^-1 S)^T
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, T, f->m, ldg);          // Lp^-1 S Lp^-T (symmetric)
+  if (rc == MLN_OK) rc = (hipMemcpyAsync(G, T, sizeof(double) * (size_t)f->m * ldg, hipMemcpyDeviceToDevice,
+                                         ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (T) (void)mln_dfree(T);
+  return rc;
+}
+
+// rhs (m) = L^T t over this rank's rows, all-reduced; t is a device vector of length n
+int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev) {
+  mln_ctx* ctx = f->ctx;
+  ObjArgs a = obj_args(f);
+  a.weights = t_dev;
+  a.part_loss = nullptr;
+  MLN_TRY(launch_objective(ctx, a));
+  MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+  MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
+  if (f->kspace) MLN_TRY(triinv_solve_left(ctx, f->tri, f->d_out + 1, 1, 1));   // Lp^-1 (K^T t)
+  MLN_HIP(ctx, hipMemcpyAsync(rhs_dev, f->d_out + 1, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
+  return MLN_OK;
+}
+
+// C C^T = L^T L + I and C^-1 (explicit, lower): the Ridge matrix of parameters.py:895-896 doubles as
+// the preconditioner of the MAP solve, because the MAP Hessian I + L^T diag(e^{f+V}) L equals it
+// wherever e^{f+V} = 1 (i.e. where f matches the nearest-neighbour estimate the Ridge regresses on).
+// With row_stride > 1 the Gram is estimated from every row_stride-th cell: any SPD matrix is a valid
+// preconditioner / initial guess for a strictly convex problem, and ~8 m rows already give the same
+// iteration count as all n (measured), at 1/row_stride of the n m^2 flops.
+void fit_drop_precond_operators(mln_fit* f) {
+  (void)hipStreamSynchronize(f->ctx->stream);
+  void* ptrs[] = {f->Cinv, f->P, f->Q1, f->Q2};
+  for (void* p : ptrs) if (p) (void)mln_dfree(p);
+  f->Cinv = nullptr; f->P = nullptr; f->Q1 = nullptr; f->Q2 = nullptr;
+}
+
+// f->C holds the (whitened) Gram: add the prior's identity, factor C C^T, and build C^-1, P = Lp^-T C^-T and the stacked
+// per-evaluation operators Q1, Q2
+int fit_factor_precond(mln_fit* f) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, ldg = f->ldl;
+  const size_t bytes = sizeof(double) * (size_t)m * ldg;
+  int my_rank = 0; bool emulate = false;
+  const int n_split = f->kspace ? split_ranks(ctx, &my_rank, &emulate) : 1;
+  int rc = launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1 / the prior's Hessian
+  if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, f->C, m, ldg);
+  TriInv t;
+  if (rc == MLN_OK) rc = triinv_build(ctx, f->C, m, ldg, true, false, &t);
+  double* inv = nullptr;
+  if (rc == MLN_OK) {
+    hipError_t e = mln_dmalloc((void**)&inv, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(inv, 0, bytes, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc C^-1", __FILE__, __LINE__);
+  }
+  if (rc == MLN_OK && n_split > 1) {                                // column blocks over the ranks, one all-reduce
+    hipError_t e = mln_dmalloc((void**)&f->P, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(f->P, 0, bytes, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
+    if (rc == MLN_OK) rc = fit_inverses_split(f, t, inv, f->P, ldg, n_split, my_rank, emulate);
+  } else {
+  if (rc == MLN_OK) rc = launch_add_diag(ctx, inv, m, ldg, 1.0);
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg, true);   // C^-1 = C^-1 I (lower triangular B)
+  if (rc == MLN_OK && f->kspace) {                                  // P = Lp^-T C^-T
+    hipError_t e = mln_dmalloc((void**)&f->P, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(f->P, 0, bytes, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
+    if (rc == MLN_OK && use_explicit_linv()) {
+      // P^T = C^-1 Lp^-1: two lower triangular factors, lower triangular product (K range column .. row)
+      rc = fit_ensure_linv(f);
+      double* X = nullptr;
+      if (rc == MLN_OK) {
+        e = mln_dmalloc((void**)&X, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(X, 0, bytes, ctx->stream);
+        if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P^T", __FILE__, __LINE__);
+      }
+      GemmArgs g{};
+      g.A = inv; g.lda = ldg; g.B = f->Linv; g.ldb = f->ldp; g.C = X; g.ldc = ldg;
+      g.M = m; g.N = m; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.kmode = 7; g.lower_only = 1;
+      if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+      if (rc == MLN_OK) rc = launch_transpose(ctx, X, ldg, f->P, ldg, m);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (X) (void)mln_dfree(X);
+    } else {
+    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);
+    if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, f->P, m, ldg, true);   // C^-T is upper triangular
+    }
+  }
+  }
+  if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs
+    const int64_t ld = ldg;
+    const size_t blk = (size_t)m * ld;
+    const int nq1 = f->kspace ? 2 : 1;
+    hipError_t e = mln_dmalloc((void**)&f->Q1, sizeof(double) * blk * nq1);
+    if (e == hipSuccess) e = mln_dmalloc((void**)&f->Q2, sizeof(double) * blk * 2);
+    if (e == hipSuccess) e = hipMemsetAsync(f->Q1, 0, sizeof(double) * blk * nq1, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(f->Q2, 0, sizeof(double) * blk * 2, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc stacked operators", __FILE__, __LINE__);
+    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ld, f->Q1, ld, m);                      // C^-T
+    if (rc == MLN_OK && f->kspace) rc = launch_copy_block(ctx, f->P, ld, f->Q1 + blk, ld, m, ld);   // P below it
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2, ld * 2, m, ld);             // C^-1
+    // explicit factor: g_u = C^-1 (z + L^T(a-1)) = [C^-1 | C^-1] [z ; r] -- the same two-segment product
+    if (rc == MLN_OK && !f->kspace) rc = launch_copy_block(ctx, inv, ld, f->Q2 + ld, ld * 2, m, ld);
+    if (rc == MLN_OK && f->kspace) {                                                           // P^T beside it
+      double* Pt = nullptr;
+      e = mln_dmalloc((void**)&Pt, sizeof(double) * blk);
+      if (e == hipSuccess) e = hipMemsetAsync(Pt, 0, sizeof(double) * blk, ctx->stream);
+      if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P^T", __FILE__, __LINE__);
+      if (rc == MLN_OK) rc = launch_transpose(ctx, f->P, ld, Pt, ld, m);
+      if (rc == MLN_OK) rc = launch_copy_block(ctx, Pt, ld, f->Q2 + ld, ld * 2, m, ld);
+      (void)hipStreamSynchronize(ctx->stream);
+      if (Pt) (void)mln_dfree(Pt);
+    }
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  triinv_free(&t);
+  if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
+  return rc;
+}
+
+int fit_build_precond(mln_fit* f, int64_t row_stride) {
+  if (f->Cinv) return MLN_OK;
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, ldg = f->ldl;
+  const size_t bytes = sizeof(double) * (size_t)m * ldg;
+  double t0 = now_s(), ex0 = f->emu_excluded;
+  const double ex_start = f->emu_excluded;
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
+  int rc = fit_gram(f, f->C, ldg, row_stride);
+  f->times[3] += now_s() - t0 - (f->emu_excluded - ex0);
+  double t1 = now_s(); ex0 = f->emu_excluded;
+  if (rc == MLN_OK) rc = fit_factor_precond(f);
+  f->times[4] += now_s() - t1 - (f->emu_excluded - ex0);
+  if (rc == MLN_OK) { f->precond_stride = row_stride < 1 ? 1 : row_stride; f->build_seconds = now_s() - t0 - (f->emu_excluded - ex_start); }
+  return rc;
+}
+
+// The solver's SECOND preconditioner (precond_rebuild.hip): C C^T = I + sum_i a_i L_i L_i^T estimated from an importance
+// sample of ~rows_per_m * m cells at the point whose rows' f = L z + mu is `f_dev`; replaces C, C^-1, P, Q1, Q2.
+int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m) {
+  mln_ctx* ctx = f->ctx;
+  const int64_t m = f->m, ldg = f->ldl;
+  RebuildSelection sel{};
+  const double target = rows_per_m * (double)m;
+  const bool tr_on = std::getenv("MELLON_AMD_TRACE") != nullptr;
+  double tt[6] = {0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i, double& t0) { if (tr_on) { (void)hipStreamSynchronize(ctx->stream); const double t1 = now_s(); tt[i] += t1 - t0; t0 = t1; } };
+  double tl = now_s();
+  MLN_TRY(rebuild_select_rows(ctx, f_dev, f->V, f->n, f->row0, target, 0x6d656c6c6f6eull, &sel));
+  lap(0, tl);
+  double* R = nullptr;
+  int rc = MLN_OK;
+  const int64_t rr = sel.rows > 0 ? sel.rows : 1;
+  if (mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl) != hipSuccess) rc = MLN_ERR_HIP;
+  if (rc == MLN_OK) rc = launch_gather_scale_rows(ctx, f->L, f->ldl, sel.idx, sel.scale, sel.rows, R);
+  fit_drop_precond_operators(f);
+  lap(1, tl);
+  if (rc == MLN_OK) {
+    // scaled covariances stay in [0, 1]: the integer Gram applies where it did for the first preconditioner
+    bool quant = f->kspace && f->cov_bounded01 && m >= 256;
+    if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
+    rc = gram_of(ctx, R, f->ldl, sel.rows, m, sel.w_max, f->C, ldg, quant);                   // all-reduced
+    // (The integer Gram is that of the rows ROUNDED to 1 / 8355711; the rounding's own Gram, rows * var * I times w_max
+    //  and the whitening's |Lp^-1|^2, is an O(0.1) multiple of K_uu^-1.  Subtracting its expectation was tried: no change
+    //  in the pass count at w_max ~ 5e3, and at w_max ~ 1e5 the subtraction itself made the matrix indefinite.)
+    if (std::getenv("MELLON_AMD_TRACE"))
+      fprintf(stderr, "[trace] rebuild: %lld of %lld local rows kept (target %.0f global), c = %.4g, 1/c = %.4g, w_max = %.4g, sum a = %.6g\n",
+              (long long)sel.rows, (long long)f->n, target, sel.c, 1.0 / sel.c, sel.w_max, sel.sum_a);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  if (R) (void)mln_dfree(R);
+  rebuild_selection_free(ctx, &sel);
+  lap(2, tl);
+  if (rc == MLN_OK && f->kspace) {                                                              // Lp^-1 G Lp^-T
+    int my_rank = 0; bool emulate = false;
+    const int n_split = split_ranks(ctx, &my_rank, &emulate);
+    if (n_split > 1) rc = fit_whiten_split(f, f->C, ldg, n_split, my_rank, emulate);
+    else if (use_explicit_linv()) rc = fit_whiten_gemm(f, f->C, ldg);
+    else {
+      double* T = nullptr;
+      hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)m * ldg);
+      if (e == hipSuccess) e = hipMemsetAsync(T, 0, sizeof(double) * (size_t)m * ldg, ctx->stream);
+      if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc Gram temp", __FILE__, __LINE__);
+      if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, f->C, m, ldg);
+      if (rc == MLN_OK) rc = launch_transpose(ctx, f->C, ldg, T, ldg, m);
+      if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, T, m, ldg);
+      if (rc == MLN_OK) rc = (hipMemcpyAsync(f->C, T, sizeof(double) * (size_t)m * ldg, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
+      (void)hipStreamSynchronize(ctx->stream);
+      if (T) (void)mln_dfree(T);
+    }
+  }
+  lap(3, tl);
+  if (rc == MLN_OK) rc = fit_factor_precond(f);
+  lap(4, tl);
+  if (tr_on) fprintf(stderr, "[trace] rebuild ms: select %.2f, gather+drop %.2f, gram %.2f, whiten %.2f, factor+inverses+stacks %.2f\n",
+                     1e3 * tt[0], 1e3 * tt[1], 1e3 * tt[2], 1e3 * tt[3], 1e3 * tt[4]);
+  return rc;
+}
+
+// y (m) = M^T w  (trans = 1)  or  M w  (trans = 0) for an m x ldl matrix M, via the streaming kernels
+// of objective.hip (GEMV-T mode / f-only mode); all pointers on the device.
+int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* w, double* y) {
+  mln_ctx* ctx = f->ctx;
+  ObjArgs a{};
+  a.L = M; a.ldl = f->ldl; a.n = f->m; a.m = f->m; a.mu = 0.0;
+  a.part_grad = f->part_grad; a.part_hess = nullptr; a.part_loss = nullptr;
+  a.m_pad = f->ldl;
+  int64_t steps = (f->m + 1) / 2;
+  a.n_wg = (int)((steps < f->n_wg_cap) ? (steps > 0 ? steps : 1) : f->n_wg_cap);
+  if (trans) {
+    a.weights = w;
+    MLN_TRY(launch_objective(ctx, a));
+    MLN_TRY(launch_reduce_obj(ctx, a, f->d_tmp));
+    MLN_HIP(ctx, hipMemcpyAsync(y, f->d_tmp + 1, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    a.z = w;
+    a.f_out = y;
+    MLN_TRY(launch_objective(ctx, a));
+  }
+  return MLN_OK;
+}
+
+extern "C" int mln_fit_set_row_offset(mln_fit* f, int64_t global_row0) {
+  if (!f || global_row0 < 0) return MLN_ERR_ARG;
+  f->row0 = global_row0;
+  return MLN_OK;
+}
+
+extern "C" int mln_precond_build(mln_fit* f, int64_t row_stride) {
+  if (!f) return MLN_ERR_ARG;
+  MLN_HIP(f->ctx, hipSetDevice(f->ctx->device));
+  if (row_stride < 1) row_stride = 1;
+  if (f->Cinv && f->precond_stride != row_stride) {
+    // an explicit request for a DIFFERENT sample (e.g. the reference's exact Ridge, stride 1, after a sampled
+    // preconditioner had been built): drop the factor and build the one asked for
+    fit_drop_precond_operators(f);
+    if (f->C) { (void)mln_dfree(f->C); f->C = nullptr; }
+    f->precond_stride = 0;
+  }
+  return fit_build_precond(f, row_stride);
+}
+
+extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
+  if (!f || !z0 || (f->n > 0 && !target)) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_build_precond(f, 1));   // exact Ridge unless a (subsampled) factor was built before
+  double t0 = now_s();
+  DevIn dt;
+  MLN_TRY(dt.init(ctx, target, (size_t)f->n));
+  // z0 = (L^T L + I)^-1 L^T t = C^-T C^-1 (L^T t);  implicit mode: C^-1 L^T t = P^T (K^T t)
+  // With a sampled Gram (stride s >= 11) the right-hand side is taken over the SAME cells, s L_s^T t_s: z0 is then the
+  // exact Ridge solution of the subsample -- the problem the solver's first phase works on -- and costs 1/s of a pass.
+  // (Not beyond 8192 landmarks: the segmented pass, launch_objective_wide, has no row map; there the right-hand side
+  //  runs over all cells against the sampled Gram -- a valid start for a solve that the host's L-BFGS-B drives anyway.)
+  int64_t rs = (f->precond_stride >= 11 && f->m <= objective_max_m_one_pass()) ? f->precond_stride : 1;
+  if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) rs = 1; }
+  ObjArgs a = obj_args(f);
+  a.weights = dt.dev;
+  a.part_loss = nullptr;
+  if (rs > 1) {
+    int64_t first = 0, rows = 0;
+    fit_sample_rows(f, rs, &first, &rows);
+    a.n = rows; a.row_first = first; a.row_stride = rs; a.out_scale = (double)rs;
+  }
+  if (f->kspace) {
+    a.L32 = f->L32;   // the Ridge solution only seeds the solve: its right-hand side may come from the 32-bit copy
+    a.l32_fixed = f->l32_fixed;
+    MLN_TRY(launch_objective(ctx, a));
+    MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+    MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
+    MLN_TRY(fit_small_gemv(f, f->P, 1, f->d_out + 1, f->d_gu));
+  } else {
+    MLN_TRY(launch_objective(ctx, a));
+    MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
+    MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
+    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));
+  }
+  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_gu, f->d_z));       // z0 = C^-T (.)   [d_gu plays the role of u0]
+  MLN_TRY(fit_cache_pair_from_u(f, f->d_gu));
+  MLN_HIP(ctx, hipMemcpyAsync(z0, f->d_z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  f->times[4] += now_s() - t0;
+  return MLN_OK;
+}
+
+// u <-> z of the preconditioned variable  z = C^-T u
+extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, double* out) {
+  if (!f || !in || !out) return MLN_ERR_ARG;
+  mln_ctx* ctx = f->ctx;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_build_precond(f, 1));
+  MLN_HIP(ctx, hipMemcpyAsync(f->d_u, in, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  if (mode == 0) MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));          // u = C^T z
+  else if (mode == 1) MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_gu));  // z = C^-T u
+  else if (mode == 2) MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_u, f->d_gu));  // g_u = C^-1 g_z
+  else { mln_set_error(ctx, "mln_precond_apply: unknown mode"); return MLN_ERR_ARG; }
+  MLN_HIP(ctx, hipMemcpyAsync(out, f->d_gu, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MLN_OK;
+}
+

@@ -281,8 +281,12 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
   if (m > CB) MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)m * (size_t)lda));
   int rc = MLN_OK;
-  static const bool la_env_off = std::getenv("MELLON_AMD_CHOL_LOOKAHEAD") && std::atoi(std::getenv("MELLON_AMD_CHOL_LOOKAHEAD")) == 0;
-  hipStream_t behind = (!la_env_off && !t_no_lookahead && m >= 8 * CB) ? masked_stream(ctx, 64) : nullptr;
+  // MEASURED (round 4, C3 on one MI355X, bench.py --steps 4): look-ahead ON 178.0 ms per fit, OFF 170.5 -- each of the three
+  // factorisations got ~1.2 ms SLOWER: with the trailing update running next to it the diagonal-block kernel takes 65 us
+  // instead of 50 and the small GEMMs of the critical path 18-20 us instead of 14 (they share L2 / HBM with it), which
+  // costs more than the ~45 us per round the overlap hides.  Off unless MELLON_AMD_CHOL_LOOKAHEAD=1.
+  static const bool la_env_on = std::getenv("MELLON_AMD_CHOL_LOOKAHEAD") && std::atoi(std::getenv("MELLON_AMD_CHOL_LOOKAHEAD")) != 0;
+  hipStream_t behind = (la_env_on && !t_no_lookahead && m >= 8 * CB) ? masked_stream(ctx, 64) : nullptr;
   hipEvent_t ev_panels = behind ? masked_stream_event(ctx, 0) : nullptr;
   hipEvent_t ev_behind = behind ? masked_stream_event(ctx, 1) : nullptr;
   if (!ev_panels || !ev_behind) behind = nullptr;
