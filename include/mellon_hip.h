@@ -405,8 +405,11 @@ int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const 
  * from [3] and [4].
  * [12] / [13] kernel seconds / launches of the solver's subsample passes (every [14]-th row: the cells of the preconditioner's
  * Gram); [15] wall seconds and [16] count of preconditioner rebuilds inside mln_map_solve; [17] passes over the n x m buffer in
- * full-fp64-pass equivalents ([6] + [9] / 2 + [13] / [14]).                                                            */
-#define MLN_N_STAGE_TIMES 18
+ * full-fp64-pass equivalents ([6] + [9] / 2 + [13] / [14]); [18] rebuilds that declined (the sample's weights span more
+ * than 1e5) or lost positive definiteness -- the solve went on with the first preconditioner; [19] rebuilt preconditioners
+ * that failed their trial (no convergence within 60 iterations) and were replaced by the first again; [20] halvings of a
+ * start whose loss was not finite or above 1e30.                                                                       */
+#define MLN_N_STAGE_TIMES 21
 int mln_stage_times(mln_fit* fit, double* out /* MLN_N_STAGE_TIMES */);
 
 #ifdef __cplusplus

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -140,6 +141,10 @@ struct mln_fit {
   // handle whose kernel values come from the binding (mln_fit_prepare_from_K): rows received, finished
   bool from_K = false, k_finished = false;
   int64_t k_rows_done = 0;
+  // the FIRST preconditioner (C, C^-1, P, Q1, Q2) while the solve runs on the rebuilt one: put back if that one fails its
+  // trial (solver.h: revert_after); released when the solve ends
+  double* saved_precond[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int n_revert = 0, n_rebuild_skipped = 0, n_start_halvings = 0;
   double build_seconds = 0.0;     // wall time of the first preconditioner build (Gram + factorisation): the rebuild's price
   double times_sub = 0.0, times_rebuild = 0.0, sub_pass_equiv = 0.0;
   int evals_sub = 0, n_rebuild = 0;
@@ -192,7 +197,9 @@ int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev);
 void fit_drop_precond_operators(mln_fit* f);
 int fit_factor_precond(mln_fit* f);
 int fit_build_precond(mln_fit* f, int64_t row_stride);
-int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m);
+int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int* outcome);   // outcome: 0 rebuilt, 1 weights too wild, 2 build failed (old one kept)
+void fit_precond_saved_free(mln_fit* f);
+int fit_precond_revert(mln_fit* f);
 int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* w, double* y);
 int launch_scale_rows_cols(mln_ctx* ctx, double* A, int64_t ld, int64_t rows, int64_t cols, const double* row,
                                   const double* col);

@@ -1,5 +1,6 @@
 // C ABI, part 3: Gram, whitening, Ridge / preconditioner factor and its rebuild, Ridge start (see api_internal.h).
 #include "api_internal.h"
+#include "mln_options.h"
 
 // G (m x ldg, full symmetric) = alpha * A^T A for the row-major A (rows x m, leading dim lda), all-reduced.
 // `quantised`: A holds covariance values in [0, 1] and the result only feeds a preconditioner -- the Gram of A rounded
@@ -83,7 +84,7 @@ int split_ranks(const mln_ctx* ctx, int* my_rank, bool* emulate) {
   int n = ctx->n_ranks;
   if (n <= 1)
     if (const char* ev = std::getenv("MELLON_AMD_EMULATE_RANKS")) { n = std::atoi(ev); *my_rank = 0; *emulate = n > 1; }
-  static const int from = std::getenv("MELLON_AMD_COLSPLIT_RANKS") ? std::atoi(std::getenv("MELLON_AMD_COLSPLIT_RANKS")) : 3;
+  static const int from = mln_experiment("MELLON_AMD_COLSPLIT_RANKS") ? std::atoi(mln_experiment("MELLON_AMD_COLSPLIT_RANKS")) : 3;
   return (from > 0 && n >= from) ? n : 1;
 }
 
@@ -169,7 +170,7 @@ __global__ void k_round_bits(double* __restrict__ A, int64_t count, double scale
 // cond(Lp) ~ 1e3-1e4 where the block solves are backward stable -- immaterial for a preconditioner built from a Gram
 // quantised to 23 bits, and 1e-12 relative on w = P u.  MELLON_AMD_EXPLICIT_LINV=0 restores the solves.
 bool use_explicit_linv() {
-  static const bool on = !(std::getenv("MELLON_AMD_EXPLICIT_LINV") && std::atoi(std::getenv("MELLON_AMD_EXPLICIT_LINV")) == 0);
+  static const bool on = !(mln_experiment("MELLON_AMD_EXPLICIT_LINV") && std::atoi(mln_experiment("MELLON_AMD_EXPLICIT_LINV")) == 0);
   return on;
 }
 
@@ -222,7 +223,7 @@ int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
   // from N = 7 on it is cheaper for every rank to whiten ITS rows first, L_s = K_s Lp^-T (rows x m^2 flops, < 2 m^3),
   // and to all-reduce the Gram of those -- the explicit route's arithmetic, no replicated solve, same single
   // collective.  (The choice depends on the rank count only, so every rank takes the same branch.)
-  static const int row_solve_from = std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_ROWSOLVE_RANKS")) : 0;   // superseded by the column split (fit_whiten_split)
+  static const int row_solve_from = mln_experiment("MELLON_AMD_GRAM_ROWSOLVE_RANKS") ? std::atoi(mln_experiment("MELLON_AMD_GRAM_ROWSOLVE_RANKS")) : 0;   // superseded by the column split (fit_whiten_split)
   if (ctx->n_ranks >= row_solve_from && row_solve_from > 0) {
     double* R = nullptr;
     const int64_t rr = rows > 0 ? rows : 1;
@@ -236,7 +237,7 @@ int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
     return rc;
   }
   int rc = MLN_OK;
-  const int qbits = std::getenv("MELLON_AMD_GRAM_QBITS") ? std::atoi(std::getenv("MELLON_AMD_GRAM_QBITS")) : 0;
+  const int qbits = mln_experiment("MELLON_AMD_GRAM_QBITS") ? std::atoi(mln_experiment("MELLON_AMD_GRAM_QBITS")) : 0;
   if (qbits > 0) {   // experiment: the Gram of the sampled rows rounded to `qbits` fractional bits
     double* R = nullptr;
     const int64_t rr = rows > 0 ? rows : 1;
@@ -252,7 +253,7 @@ int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
     // ... and only where the caller asked for a SAMPLED Gram (row_stride > 1: a preconditioner by construction);
     // row_stride == 1 is the reference's exact Ridge matrix / the Gram whose eigenvalues are results
     bool quant = f->cov_bounded01 && f->m >= 256 && row_stride > 1;
-    if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
+    if (const char* ev = mln_experiment("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
     rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
   }
   {
@@ -406,9 +407,35 @@ int fit_build_precond(mln_fit* f, int64_t row_stride) {
 
 // The solver's SECOND preconditioner (precond_rebuild.hip): C C^T = I + sum_i a_i L_i L_i^T estimated from an importance
 // sample of ~rows_per_m * m cells at the point whose rows' f = L z + mu is `f_dev`; replaces C, C^-1, P, Q1, Q2.
-int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m) {
+void fit_precond_saved_free(mln_fit* f) {
+  bool any = false;
+  for (double* p : f->saved_precond) any = any || p;
+  if (!any) return;
+  (void)hipStreamSynchronize(f->ctx->stream);
+  for (double*& p : f->saved_precond) { if (p) (void)mln_dfree(p); p = nullptr; }
+}
+
+// the saved (first) preconditioner becomes the current one again; the current one is released
+int fit_precond_revert(mln_fit* f) {
+  if (!f->saved_precond[0] || !f->saved_precond[1]) return MLN_ERR_ARG;
+  fit_drop_precond_operators(f);
+  if (f->C) { (void)mln_dfree(f->C); f->C = nullptr; }
+  f->C = f->saved_precond[0]; f->Cinv = f->saved_precond[1]; f->P = f->saved_precond[2];
+  f->Q1 = f->saved_precond[3]; f->Q2 = f->saved_precond[4];
+  for (double*& p : f->saved_precond) p = nullptr;
+  return MLN_OK;
+}
+
+// Round 4 (tools/robustness_sweep_large.py): the rebuild may decline or fail, and the solve then goes on with the
+// preconditioner it has.  outcome 1: the sample's weights span more than 1e5 (w_max c: heaviest weight over the floor
+// 1 / c) -- the pause came on a plateau far from the optimum, the scaled rows' 23-bit digits would hold only the heaviest
+// cells, and the factor built from them stalled the solve for thousands of passes on tree-shaped data.  outcome 2: the
+// Gram's whitening lost positive definiteness (heavy-tailed data, w_max ~ 1e8: "Covariance not positively definite").
+// On success the FIRST preconditioner is kept in f->saved_precond until the solve ends (solver.h: revert_after).
+int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int* outcome) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
+  *outcome = 0;
   RebuildSelection sel{};
   const double target = rows_per_m * (double)m;
   const bool tr_on = std::getenv("MELLON_AMD_TRACE") != nullptr;
@@ -417,24 +444,34 @@ int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m) {
   double tl = now_s();
   MLN_TRY(rebuild_select_rows(ctx, f_dev, f->V, f->n, f->row0, target, 0x6d656c6c6f6eull, &sel));
   lap(0, tl);
+  if (tr_on)
+    fprintf(stderr, "[trace] rebuild: %lld of %lld local rows kept (target %.0f global), c = %.4g, 1/c = %.4g, w_max = %.4g, sum a = %.6g\n",
+            (long long)sel.rows, (long long)f->n, target, sel.c, 1.0 / sel.c, sel.w_max, sel.sum_a);
+  double range_cap = 1e5;
+  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_RANGE")) range_cap = std::atof(ev);
+  if (!(sel.w_max * sel.c <= range_cap) || !std::isfinite(sel.sum_a)) {   // (global quantities: the same decision on every rank)
+    rebuild_selection_free(ctx, &sel);
+    *outcome = 1;
+    return MLN_OK;
+  }
   double* R = nullptr;
   int rc = MLN_OK;
   const int64_t rr = sel.rows > 0 ? sel.rows : 1;
   if (mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl) != hipSuccess) rc = MLN_ERR_HIP;
   if (rc == MLN_OK) rc = launch_gather_scale_rows(ctx, f->L, f->ldl, sel.idx, sel.scale, sel.rows, R);
-  fit_drop_precond_operators(f);
+  // the current preconditioner steps aside (kept: fallback now, revert later); the new one is built in fresh buffers
+  double* old_set[5] = {f->C, f->Cinv, f->P, f->Q1, f->Q2};
+  f->C = nullptr; f->Cinv = nullptr; f->P = nullptr; f->Q1 = nullptr; f->Q2 = nullptr;
+  if (rc == MLN_OK && mln_dmalloc((void**)&f->C, sizeof(double) * (size_t)m * ldg) != hipSuccess) rc = MLN_ERR_HIP;
   lap(1, tl);
   if (rc == MLN_OK) {
     // scaled covariances stay in [0, 1]: the integer Gram applies where it did for the first preconditioner
     bool quant = f->kspace && f->cov_bounded01 && m >= 256;
-    if (const char* ev = std::getenv("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
+    if (const char* ev = mln_experiment("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
     rc = gram_of(ctx, R, f->ldl, sel.rows, m, sel.w_max, f->C, ldg, quant);                   // all-reduced
     // (The integer Gram is that of the rows ROUNDED to 1 / 8355711; the rounding's own Gram, rows * var * I times w_max
     //  and the whitening's |Lp^-1|^2, is an O(0.1) multiple of K_uu^-1.  Subtracting its expectation was tried: no change
     //  in the pass count at w_max ~ 5e3, and at w_max ~ 1e5 the subtraction itself made the matrix indefinite.)
-    if (std::getenv("MELLON_AMD_TRACE"))
-      fprintf(stderr, "[trace] rebuild: %lld of %lld local rows kept (target %.0f global), c = %.4g, 1/c = %.4g, w_max = %.4g, sum a = %.6g\n",
-              (long long)sel.rows, (long long)f->n, target, sel.c, 1.0 / sel.c, sel.w_max, sel.sum_a);
   }
   (void)hipStreamSynchronize(ctx->stream);
   if (R) (void)mln_dfree(R);
@@ -461,9 +498,25 @@ int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m) {
   lap(3, tl);
   if (rc == MLN_OK) rc = fit_factor_precond(f);
   lap(4, tl);
-  if (tr_on) fprintf(stderr, "[trace] rebuild ms: select %.2f, gather+drop %.2f, gram %.2f, whiten %.2f, factor+inverses+stacks %.2f\n",
-                     1e3 * tt[0], 1e3 * tt[1], 1e3 * tt[2], 1e3 * tt[3], 1e3 * tt[4]);
-  return rc;
+  if (tr_on) fprintf(stderr, "[trace] rebuild ms: select %.2f, gather %.2f, gram %.2f, whiten %.2f, factor+inverses+stacks %.2f (rc %d)\n",
+                     1e3 * tt[0], 1e3 * tt[1], 1e3 * tt[2], 1e3 * tt[3], 1e3 * tt[4], rc);
+  if (rc == MLN_ERR_NOT_PD) {
+    // (the factorisation's verdict is a function of all-reduced numbers: every rank lands here together)
+    fit_drop_precond_operators(f);
+    if (f->C) { (void)hipStreamSynchronize(ctx->stream); (void)mln_dfree(f->C); }
+    f->C = old_set[0]; f->Cinv = old_set[1]; f->P = old_set[2]; f->Q1 = old_set[3]; f->Q2 = old_set[4];
+    *outcome = 2;
+    return MLN_OK;
+  }
+  if (rc != MLN_OK) {                        // a real failure: leave the handle consistent (old set back), report it
+    fit_drop_precond_operators(f);
+    if (f->C) { (void)hipStreamSynchronize(ctx->stream); (void)mln_dfree(f->C); }
+    f->C = old_set[0]; f->Cinv = old_set[1]; f->P = old_set[2]; f->Q1 = old_set[3]; f->Q2 = old_set[4];
+    return rc;
+  }
+  fit_precond_saved_free(f);
+  for (int i = 0; i < 5; ++i) f->saved_precond[i] = old_set[i];
+  return MLN_OK;
 }
 
 // y (m) = M^T w  (trans = 1)  or  M w  (trans = 0) for an m x ldl matrix M, via the streaming kernels
@@ -523,7 +576,7 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
   // (Not beyond 8192 landmarks: the segmented pass, launch_objective_wide, has no row map; there the right-hand side
   //  runs over all cells against the sampled Gram -- a valid start for a solve that the host's L-BFGS-B drives anyway.)
   int64_t rs = (f->precond_stride >= 11 && f->m <= objective_max_m_one_pass()) ? f->precond_stride : 1;
-  if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) rs = 1; }
+  if (const char* ev = mln_experiment("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) rs = 1; }
   ObjArgs a = obj_args(f);
   a.weights = dt.dev;
   a.part_loss = nullptr;

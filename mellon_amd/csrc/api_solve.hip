@@ -1,5 +1,6 @@
 // C ABI, part 4: objective, transform, MAP solve, predictor weights (see api_internal.h).
 #include "api_internal.h"
+#include "mln_options.h"
 
 
 void obj_account(mln_fit* f, bool f32) {
@@ -128,7 +129,7 @@ int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32
   ObjArgs a = obj_args(f);
   a.z = f->kspace ? f->d_w : f->d_zr;
   a.gate = gate;
-  static const bool no_fkeep = std::getenv("MELLON_AMD_NO_FKEEP") != nullptr;
+  static const bool no_fkeep = mln_experiment("MELLON_AMD_NO_FKEEP") != nullptr;
   if (gate && !no_fkeep && f->f_keep[0] && objective_can_keep_f(f->n, f->n_wg)) { a.f_keep[0] = f->f_keep[0]; a.f_keep[1] = f->f_keep[1]; a.f_slot = &f->sv.st->f_slot; }
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   if (f->L32 && (gate || use32)) {
@@ -270,24 +271,24 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // progress per iteration below which the 32-bit surrogate is left for the fp64 buffer (relative to the loss):
   // the fp32 copy's optimum sits ~1e-5 (relative loss) from the true one, the fixed-point copy's ~1e-9
   init.ftol32 = f->l32_fixed ? 1e-9 : 3e-6;
-  if (const char* ev = std::getenv("MELLON_AMD_MIXED_FTOL")) init.ftol32 = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_MIXED_FTOL")) init.ftol32 = std::atof(ev);
   // ... and after that first fp64 evaluation the solve continues on the 32-bit copy WITH its first-order correction
   // (solver.hip), the fp64 objective verifying the final point (MELLON_AMD_CORRECTED=0: finish on the fp64 buffer)
   init.use_corr = (phase32 && f->l32_fixed) ? 1 : 0;
-  if (const char* ev = std::getenv("MELLON_AMD_CORRECTED")) init.use_corr = init.use_corr && std::atoi(ev) != 0;
+  if (const char* ev = mln_experiment("MELLON_AMD_CORRECTED")) init.use_corr = init.use_corr && std::atoi(ev) != 0;
   init.prior_const = 0.5 * (double)m * std::log(2.0 * M_PI);
   init.t0 = 1.0;
   init.boost = 0.15;    // solver.hip "step-length memory"; MELLON_AMD_LS_BOOST=0 keeps every first trial at 1
-  if (const char* ev = std::getenv("MELLON_AMD_LS_BOOST")) init.boost = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_LS_BOOST")) init.boost = std::atof(ev);
   // capped start (solver.hip): on the 32-bit copy the likelihood's e^t is continued linearly beyond t = 7 while the loss
   // still falls steeply; MELLON_AMD_EXP_CAP=<t> moves the cap, MELLON_AMD_EXP_CAP=off removes it
   init.cap = phase32 ? 7.0 : __builtin_inf();
-  if (const char* ev = std::getenv("MELLON_AMD_EXP_CAP"))
+  if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP"))
     if (phase32) init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
   init.cap_fall = 0.15;
-  if (const char* ev = std::getenv("MELLON_AMD_EXP_CAP_FALL")) init.cap_fall = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP_FALL")) init.cap_fall = std::atof(ev);
   init.boost_fall = 0.15;
-  if (const char* ev = std::getenv("MELLON_AMD_LS_BOOST_FALL")) init.boost_fall = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_LS_BOOST_FALL")) init.boost_fall = std::atof(ev);
   // Subsample start (solver.h): when the preconditioner's Gram came from every s-th cell (s >= 4), the solve starts
   // on the MAP problem of exactly those cells -- the Ridge matrix is ITS Hessian at a = 1 -- at 1/s of the bytes per
   // pass, and moves to all cells once that problem's progress per iteration is below sub_tol.  The walk down from the
@@ -299,7 +300,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // evaluation finds the loss 60 % above the optimum's and e^{f+V} of unseen cells up to 1e5).
   std::vector<int64_t> sub_strides;
   if (f->precond_stride >= 11) sub_strides.push_back(std::max<int64_t>(2, 3 * f->precond_stride / 16));
-  if (const char* ev = std::getenv("MELLON_AMD_SUB_LEVELS")) {
+  if (const char* ev = mln_experiment("MELLON_AMD_SUB_LEVELS")) {
     if (!sub_strides.empty()) {
       sub_strides.clear();
       for (const char* p = ev; *p;) {
@@ -311,11 +312,11 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
       }
     }
   }
-  if (const char* ev = std::getenv("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) sub_strides.clear(); }
+  if (const char* ev = mln_experiment("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) sub_strides.clear(); }
   const std::vector<int64_t>* subs = sub_strides.empty() ? nullptr : &sub_strides;
   init.gate_full = init.gate;
   init.sub_tol = 1e-3;
-  if (const char* ev = std::getenv("MELLON_AMD_SUB_TOL")) init.sub_tol = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_SUB_TOL")) init.sub_tol = std::atof(ev);
   init.n_sub_levels = (int)sub_strides.size();
   init.sub_level = 0;
   if (subs) { init.gate = MLN_GATE_SUB; init.cap = __builtin_inf(); }
@@ -327,13 +328,13 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // (emulated ranks of C3, tools/emulate_rank.py: the rebuild gains 9 ms per step at 4 ranks -- first build = 8.9 evaluations
   //  -- and loses 2.5 ms at 8 -- 12.7 evaluations: the threshold sits between)
   double want_rebuild = (f->build_seconds > 0.0 && 11.0 * pass_s > f->build_seconds) ? 1.0 : 0.0;
-  if (const char* ev = std::getenv("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
+  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
   if (phase32 && !(f->l32_fixed)) want_rebuild = 0.0;   // (mixed solves pause at their fp64 anchor, which only the corrected fixed-point surrogate has)
   // The rebuild reads the rows' f of the last accepted pass (f_keep), which a rank only has while its shard fits the
   // kernel's f staging: with uneven or very large shards that is a per-rank fact, and the branch at the pause issues
   // collectives (Gram all-reduce, the sample's global sum) -- so the decision is made ONCE, here, for all ranks: rank 0's
   // cost rule AND every rank able to keep f (one all-reduce of two numbers: rank 0's vote, the count of ranks that cannot).
-  static const bool no_fkeep_env = std::getenv("MELLON_AMD_NO_FKEEP") != nullptr;
+  static const bool no_fkeep_env = mln_experiment("MELLON_AMD_NO_FKEEP") != nullptr;
   const bool keeps_f = !no_fkeep_env && f->f_keep[0] && f->f_keep[1] && objective_can_keep_f(f->n, f->n_wg);
   {
     double vote[2] = {ctx->rank == 0 ? want_rebuild : 0.0, keeps_f ? 0.0 : 1.0};
@@ -345,17 +346,22 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   }
   init.rebuild_armed = want_rebuild != 0.0 ? 1 : 0;
   init.rebuild_at_switch = 0;     // (measured: at the switch the unseen cells' weights are still too wild -- 37-96 full passes)
-  if (const char* ev = std::getenv("MELLON_AMD_REBUILD_AT_SWITCH")) init.rebuild_at_switch = std::atoi(ev) != 0 ? 1 : 0;
+  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_AT_SWITCH")) init.rebuild_at_switch = std::atoi(ev) != 0 ? 1 : 0;
   init.switch_t0 = 0.35;
-  if (const char* ev = std::getenv("MELLON_AMD_SWITCH_T0")) init.switch_t0 = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_SWITCH_T0")) init.switch_t0 = std::atof(ev);
   init.gap_tol = 0.2 * o.ftol;     // (tools/solver_sweep.py, seven data seeds at C3: 15.9 -> 14.7 full passes with both rules, log-density
                                    //  within 4e-8 of the old stop -- the spread between two runs of the old rule; 0.5 ftol: 14.3 passes, 1.8e-7)
-  if (const char* ev = std::getenv("MELLON_AMD_GAP_TOL")) init.gap_tol = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_GAP_TOL")) init.gap_tol = std::atof(ev);
   init.dec_prev = 0.0; init.dec_prev2 = 0.0;
   init.rebuild_tol = 1e-3;       // (tools/solver_sweep.py at C3, two seeds: 1e-2 -> 23-28 full passes, 1e-3 -> 20-22, 2e-4 -> 22-26)
-  if (const char* ev = std::getenv("MELLON_AMD_REBUILD_TOL")) init.rebuild_tol = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_TOL")) init.rebuild_tol = std::atof(ev);
+  init.start_cap = 1e30;         // (solver.h: pathological start; C3's Ridge start evaluates to 4.8e9)
+  init.n_shrink = 0;
+  init.revert_after = 0; init.it_at_resume = -1; init.pause_reason = 0;
+  int revert_after = 60;         // accepted iterations a rebuilt preconditioner gets to finish the solve (C3: ~9)
+  if (const char* ev = mln_experiment("MELLON_AMD_REVERT_AFTER")) revert_after = std::atoi(ev);
   double rebuild_rows_per_m = 6.0;   // (6 m, 12 m, 24 m importance-sampled rows: the same pass counts; 6 m is the cheapest Gram)
-  if (const char* ev = std::getenv("MELLON_AMD_REBUILD_ROWS_PER_M")) rebuild_rows_per_m = std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_ROWS_PER_M")) rebuild_rows_per_m = std::atof(ev);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
   const int* gate = &f->sv.st->gate;
   static const bool timing = !(std::getenv("MELLON_AMD_TIMING") && std::atoi(std::getenv("MELLON_AMD_TIMING")) == 0);
@@ -375,7 +381,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // no-ops that use up slots (their events time nothing)
   std::vector<std::pair<int, int>> slot_shift;      // (first trace index, shift)
   int batch = 8;
-  if (const char* ev = std::getenv("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
+  if (const char* ev = mln_experiment("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
   const int64_t hard_cap = (int64_t)o.maxiter * o.maxls + 16;
   for (;;) {
     for (int b = 0; b < batch; ++b) {
@@ -393,8 +399,10 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
       // ---- second preconditioner at the accepted point (whose rows' f the last accepted fp64 pass left in f_keep) ----
       const double tr0 = now_s(), ex_r0 = f->emu_excluded;
       const SolverState ps = *f->h_state;
-      if (!ps.f_valid) {      // (a function of the solver's state, identical on every rank; keeping f was settled collectively above)
-        // no per-row f to weight the cells with: resume with the preconditioner we have
+      const bool revert = ps.pause_reason == 2 && f->saved_precond[0] != nullptr;
+      if (!revert && (ps.pause_reason == 2 || !ps.f_valid)) {
+        // (f_valid is a function of the solver's state, identical on every rank; keeping f was settled collectively above)
+        // no per-row f to weight the cells with / nothing to go back to: resume with the preconditioner we have
         MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0));
       } else {
         double *zt = nullptr, *gz = nullptr, *cz = nullptr;
@@ -405,54 +413,36 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         int rc = fit_small_gemv(f, f->Cinv, 1, f->sv.u, zt);
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 0, f->sv.g, gz);
         if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->C, 0, f->sv.c, cz);
-        // The curvature pairs survive the change of variable u' = T u, T = C'^T C^-T:  s' = T s,  y' = T^-T y  (s'.y' = s.y).
-        // First half here (into z-space, in place), second half once the new factor exists.  Measured (five data seeds at C3):
-        // carrying them over costs 1-3 full passes MORE than starting the history afresh -- the new factor already holds
-        // the curvature the old pairs describe, relative to a metric that is gone -- so they are dropped by default
-        // (MELLON_AMD_REBUILD_KEEP_PAIRS=1 keeps them).
-        const bool keep_pairs = std::getenv("MELLON_AMD_REBUILD_KEEP_PAIRS") && std::atoi(std::getenv("MELLON_AMD_REBUILD_KEEP_PAIRS")) != 0;
-        const int n_pairs = keep_pairs ? ps.k : 0;
-        double* ptmp = zt;     // (reuses zt after z has been consumed below: see order)
-        std::vector<int> slots;
-        for (int j = 0; j < n_pairs; ++j) slots.push_back((ps.head + j) % ps.maxcor);
-        double* pbuf = nullptr;
-        if (n_pairs > 0 && rc == MLN_OK) {
-          if (mln_dmalloc((void**)&pbuf, sizeof(double) * (size_t)f->ldl) != hipSuccess) rc = MLN_ERR_HIP;
-          if (rc == MLN_OK && hipMemsetAsync(pbuf, 0, sizeof(double) * (size_t)f->ldl, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
-          for (int sl : slots) {
-            double* S = f->sv.S + (size_t)sl * f->sv.ld;
-            double* Y = f->sv.Y + (size_t)sl * f->sv.ld;
-            if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 1, S, pbuf);          // s_z = C^-T s
-            if (rc == MLN_OK && hipMemcpyAsync(S, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
-            if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 0, Y, pbuf);             // y_z = C y
-            if (rc == MLN_OK && hipMemcpyAsync(Y, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
-          }
+        // (The curvature pairs could be carried through the change of variable -- s' = T s, y' = T^-T y with T = C'^T C^-T --
+        //  but that measured 1-3 full passes WORSE than a fresh history at C3, five data seeds: the new factor already holds
+        //  the curvature the old pairs describe, relative to a metric that is gone.  They are dropped.)
+        int outcome = 0;
+        if (rc == MLN_OK) rc = revert ? fit_precond_revert(f) : fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m, &outcome);
+        if (rc == MLN_OK && outcome == 0) {
+          // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z
+          rc = fit_small_gemv(f, f->C, 1, zt, f->sv.u);
+          if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, gz, f->sv.g);
+          if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->Cinv, 0, cz, f->sv.c);
         }
-        (void)ptmp;
-        if (rc == MLN_OK) rc = fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m);
-        // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z
-        if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 1, zt, f->sv.u);
-        if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, gz, f->sv.g);
-        if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->Cinv, 0, cz, f->sv.c);
-        for (int sl : slots) {
-          double* S = f->sv.S + (size_t)sl * f->sv.ld;
-          double* Y = f->sv.Y + (size_t)sl * f->sv.ld;
-          if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 1, S, pbuf);               // s' = C'^T s_z
-          if (rc == MLN_OK && hipMemcpyAsync(S, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
-          if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, Y, pbuf);            // y' = C'^-1 y_z
-          if (rc == MLN_OK && hipMemcpyAsync(Y, pbuf, sizeof(double) * m, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
-        }
-        if (rc == MLN_OK && n_pairs > 0) rc = launch_solver_refresh_pairs(ctx, f->sv, ps.maxcor);
         (void)hipStreamSynchronize(ctx->stream);
         (void)mln_dfree(zt);
-        if (pbuf) (void)mln_dfree(pbuf);
         MLN_TRY(rc);
-        MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, n_pairs > 0 ? 0 : 1));
-        if (const char* ev = std::getenv("MELLON_AMD_RESUME_T0")) {     // experiment: first trial step under the new preconditioner
+        if (outcome == 0) {
+          // a rebuilt preconditioner is on trial (solver.h: revert_after); a restored one is not
+          MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1, revert ? 0 : revert_after));
+          if (revert) f->n_revert += 1; else f->n_rebuild += 1;
+        } else {
+          // the rebuild declined (weights too wild) or lost positive definiteness: same variable, same history, carry on
+          MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0));
+          f->n_rebuild_skipped += 1;
+        }
+        if (trace_lvl) fprintf(stderr, "[trace] map_solve pause at evaluation %d: %s\n", ps.n_eval,
+                               revert ? "second preconditioner failed its trial: first one restored"
+                                      : (outcome == 0 ? "preconditioner rebuilt" : (outcome == 1 ? "rebuild declined (weight range)" : "rebuild lost positive definiteness: kept the first")));
+        if (const char* ev = mln_experiment("MELLON_AMD_RESUME_T0")) {     // experiment: first trial step under the new preconditioner
           const double t0v = std::atof(ev);
           MLN_HIP(ctx, hipMemcpyAsync(&f->sv.st->t0, &t0v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         }
-        f->n_rebuild += 1;
       }
       MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
       f->times_rebuild += now_s() - tr0 - (f->emu_excluded - ex_r0);
@@ -463,6 +453,8 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     if (batch < 16 && f->h_state->gate == MLN_GATE_F64) batch = std::min(batch, 6);
   }
   const SolverState st = *f->h_state;
+  fit_precond_saved_free(f);
+  f->n_start_halvings = st.n_shrink;
   // kernel-time accounting from the per-evaluation events (the pass the solver did not select is a ~2 us no-op)
   std::vector<double> tr;
   const int n_done = st.n_eval < 512 ? st.n_eval : 512;
@@ -498,7 +490,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  if (st.f_valid && objective_can_keep_f(f->n, f->n_wg) && !std::getenv("MELLON_AMD_NO_FKEEP")) f->f_final = st.f_slot;   // f = L z + mu at this z is already there (mln_transform)
+  if (st.f_valid && objective_can_keep_f(f->n, f->n_wg) && !mln_experiment("MELLON_AMD_NO_FKEEP")) f->f_final = st.f_slot;   // f = L z + mu at this z is already there (mln_transform)
   if (trace_lvl)
     fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the 32-bit copy, %d on the row subsample of stride %lld), %d iterations, "
             "%d rebuild(s), %d enqueued, status %d\n", st.n_eval, st.n_eval32, st.n_eval_sub, (long long)(subs ? sub_strides[0] : 0), st.it,
@@ -566,6 +558,9 @@ extern "C" int mln_stage_times(mln_fit* f, double* out) {
   out[16] = (double)f->n_rebuild;
   // passes over the n x m buffer in full-fp64-pass equivalents (bytes streamed / bytes of one fp64 pass)
   out[17] = f->times[6] + 0.5 * (double)f->evals32 + f->sub_pass_equiv;
+  out[18] = (double)f->n_rebuild_skipped;               // rebuilds declined (weight range) or failed (not positive definite)
+  out[19] = (double)f->n_revert;                        // second preconditioner failed its trial: first one restored
+  out[20] = (double)f->n_start_halvings;                // halvings of a start whose loss was not finite or above 1e30
   return MLN_OK;
 }
 

@@ -16,6 +16,7 @@
 #include "cov_program.h"
 #include "cov_rows.h"
 #include "cov_rows_q.h"
+#include "mln_options.h"
 
 namespace {
 
@@ -998,8 +999,8 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   bool contiguous = single && cov.leaves[0].ndims == d;
   if (contiguous)
     for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
-  static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
-  static const bool no_rows = std::getenv("MELLON_AMD_KM_NO_ROWS") != nullptr;
+  static const bool no_mfma = mln_experiment("MELLON_AMD_KM_NO_MFMA") != nullptr;
+  static const bool no_rows = mln_experiment("MELLON_AMD_KM_NO_ROWS") != nullptr;
   if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD && (!out32 || q32)) {
     MLN_TRY(pad_rows(ctx, y, m, d, ypad));
@@ -1041,7 +1042,7 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   bool contiguous = single && cov.leaves[0].ndims == d;
   if (contiguous)
     for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
-  static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
+  static const bool no_mfma = mln_experiment("MELLON_AMD_KM_NO_MFMA") != nullptr;
   if (contiguous && !no_mfma && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE) {
     MLN_TRY(pad_rows(ctx, y, m, d, ypad));
@@ -1075,7 +1076,7 @@ int launch_nn_distances_exact(mln_ctx* ctx, const double* x, int64_t n, const do
   double* yy = norms + n;
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, d, xx);
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, y, m, d, yy);
-  static const bool no_mfma = std::getenv("MELLON_AMD_KM_NO_MFMA") != nullptr;
+  static const bool no_mfma = mln_experiment("MELLON_AMD_KM_NO_MFMA") != nullptr;
   if (d <= 64 && !no_mfma && n * m >= 4096)
     hipLaunchKernelGGL(k_nn_distances_mfma, dim3((unsigned)((n + 127) / 128)), dim3(512), 0, ctx->stream, x, n, y, m, d,
                        xx, yy, self_offset, excl, out);

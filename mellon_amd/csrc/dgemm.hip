@@ -16,6 +16,7 @@
 // so a single LDS buffer + two barriers per k-tile leaves the matrix pipe as the limiter.
 #include <cstdlib>
 #include "mln_internal.h"
+#include "mln_options.h"
 
 namespace {
 
@@ -252,7 +253,7 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   {
     const int64_t t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.lower_only ? 2 : 1);
     const int64_t n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    static const int64_t below = std::getenv("MELLON_AMD_GEMM64_BELOW") ? std::atoll(std::getenv("MELLON_AMD_GEMM64_BELOW")) : 0;
+    static const int64_t below = mln_experiment("MELLON_AMD_GEMM64_BELOW") ? std::atoll(mln_experiment("MELLON_AMD_GEMM64_BELOW")) : 0;
     // (below 4 tiles per CU the 128-wide tiling leaves its last round of workgroups mostly empty -- 722 tiles on 512 slots
     //  -- and four times as many 64-wide tiles pack better: factor + inverses 9.1 -> 8.5 ms, rebuild 17.7 -> 17.1 ms at m = 5000)
     if (t128 * (g.split_k > 1 ? g.split_k : 1) < (below > 0 ? below : 4 * n_cu) && !inplace) bt = 64;

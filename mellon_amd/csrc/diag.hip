@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "mln_internal.h"
+#include "mln_options.h"
 
 namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -96,7 +97,7 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
                               int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out) {
   if (!ctx || !ms_out || M < 1 || N < 1 || K < 1 || reps < 1) return MLN_ERR_ARG;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  if (const char* e = std::getenv("MELLON_AMD_GEMM_BK")) dgemm_set_bk(std::atoi(e));
+  if (const char* e = mln_experiment("MELLON_AMD_GEMM_BK")) dgemm_set_bk(std::atoi(e));
   const int64_t lda = ((ta ? M : K) + 15) / 16 * 16, ldb = ((tb ? K : N) + 15) / 16 * 16, ldc = (N + 15) / 16 * 16;
   const size_t a_bytes = sizeof(double) * (size_t)(ta ? K : M) * lda, b_bytes = sizeof(double) * (size_t)(tb ? N : K) * ldb;
   const int split = split_k > 1 ? split_k : 1;
@@ -115,7 +116,7 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
     MLN_HIP(ctx, hipMemcpyAsync((char*)B + off, pat.data(), std::min(pat.size() * 8, b_bytes - off), hipMemcpyHostToDevice, ctx->stream));
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = Cm; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-  g.alpha = 1.0; g.beta = std::getenv("MELLON_AMD_DIAG_BETA") ? std::atof(std::getenv("MELLON_AMD_DIAG_BETA")) : 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
+  g.alpha = 1.0; g.beta = mln_experiment("MELLON_AMD_DIAG_BETA") ? std::atof(mln_experiment("MELLON_AMD_DIAG_BETA")) : 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
   g.c_split_stride = (int64_t)M * ldc;
   hipEvent_t e0, e1;
   MLN_HIP(ctx, hipEventCreate(&e0));

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <vector>
+#include "mln_options.h"
 
 namespace {
 
@@ -268,7 +269,7 @@ int launch_gram_i8(mln_ctx* ctx, const double* K, int64_t ldk, int64_t rows, int
   if (rc == MLN_OK) {
     hipLaunchKernelGGL(k_gram_digits, dim3((unsigned)(Kp / 64), (unsigned)(Mp / 64)), dim3(256), 0, ctx->stream, K, ldk, rows, m,
                        planes, Mp, Kp);
-    static const int n_waves = std::getenv("MELLON_AMD_GRAM_I8_WAVES") ? std::atoi(std::getenv("MELLON_AMD_GRAM_I8_WAVES")) : 8;
+    static const int n_waves = mln_experiment("MELLON_AMD_GRAM_I8_WAVES") ? std::atoi(mln_experiment("MELLON_AMD_GRAM_I8_WAVES")) : 8;
     static bool attr_set = false;
     const int lds_bytes = 2 * GSTAGE;
     if (!attr_set) {

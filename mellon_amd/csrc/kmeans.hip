@@ -16,6 +16,7 @@
 
 #include "mln_internal.h"
 #include "rowmin_f16.h"
+#include "mln_options.h"
 
 namespace {
 constexpr int TM = 64, TN = 64, DK = 16, PADT = 4, SBLK = 1024;
@@ -425,7 +426,7 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   XorShift rng((unsigned long long)seed);
   int64_t cur = (int64_t)(rng.uniform() * (double)n);
   if (cur >= n) cur = n - 1;
-  const bool km_fp16_seed = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
+  const bool km_fp16_seed = !(mln_experiment("MELLON_AMD_KM_FP16") && std::atoi(mln_experiment("MELLON_AMD_KM_FP16")) == 0);
   const bool seed_h = km_fp16_seed && d <= 61 && n * m >= ((int64_t)1 << 24) && m >= 2;
   void* xsplit = nullptr;
   double* prep = nullptr;          // centre and scale of the half-precision copies (rowmin_prepare)
@@ -476,7 +477,7 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   // fp32 accumulation: distances to ~1e-5 relative).  A cell whose two nearest centres tie within that may land on
   // either -- k-means is indifferent -- and the centre update, the stopping test and the final inertia stay fp64.
   // 5e11 fp64 flops per sweep at 1e6 cells x 5000 centres (15 ms) become ~1 ms.  MELLON_AMD_KM_FP16=0 disables.
-  const bool km_fp16 = !(std::getenv("MELLON_AMD_KM_FP16") && std::atoi(std::getenv("MELLON_AMD_KM_FP16")) == 0);
+  const bool km_fp16 = !(mln_experiment("MELLON_AMD_KM_FP16") && std::atoi(mln_experiment("MELLON_AMD_KM_FP16")) == 0);
   const bool fast_assign = km_fp16 && d <= 64 && n * m >= ((int64_t)1 << 24) && m >= 2;
   const bool km_fold = d <= 61;
   void* csplit = nullptr;

@@ -14,6 +14,7 @@
 
 #include "mln_internal.h"
 #include "linalg.h"
+#include "mln_options.h"
 
 namespace {
 
@@ -220,7 +221,7 @@ thread_local bool t_no_lookahead = false;
 void set_lookahead_disabled(bool off) { t_no_lookahead = off; }
 
 hipStream_t masked_stream(mln_ctx* ctx, int free_cus) {
-  static const bool off = std::getenv("MELLON_AMD_CU_MASK") && std::atoi(std::getenv("MELLON_AMD_CU_MASK")) == 0;
+  static const bool off = mln_experiment("MELLON_AMD_CU_MASK") && std::atoi(mln_experiment("MELLON_AMD_CU_MASK")) == 0;
   if (off) return nullptr;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 0;
   if (n_cu < 64 || free_cus < 0 || free_cus * 2 > n_cu) return nullptr;
@@ -285,7 +286,7 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   // factorisations got ~1.2 ms SLOWER: with the trailing update running next to it the diagonal-block kernel takes 65 us
   // instead of 50 and the small GEMMs of the critical path 18-20 us instead of 14 (they share L2 / HBM with it), which
   // costs more than the ~45 us per round the overlap hides.  Off unless MELLON_AMD_CHOL_LOOKAHEAD=1.
-  static const bool la_env_on = std::getenv("MELLON_AMD_CHOL_LOOKAHEAD") && std::atoi(std::getenv("MELLON_AMD_CHOL_LOOKAHEAD")) != 0;
+  static const bool la_env_on = mln_experiment("MELLON_AMD_CHOL_LOOKAHEAD") && std::atoi(mln_experiment("MELLON_AMD_CHOL_LOOKAHEAD")) != 0;
   hipStream_t behind = (la_env_on && !t_no_lookahead && m >= 8 * CB) ? masked_stream(ctx, 64) : nullptr;
   hipEvent_t ev_panels = behind ? masked_stream_event(ctx, 0) : nullptr;
   hipEvent_t ev_behind = behind ? masked_stream_event(ctx, 1) : nullptr;

@@ -55,6 +55,21 @@ struct SolverState {
   // more passes to watch the decrease itself fall below ftol.  0: off (SciPy's ftol test alone).
   double gap_tol;
   double dec_prev, dec_prev2;   // decrease of the loss in the last two accepted iterations on the full objective (0: none yet)
+  // Pathological start (round 4, tools/robustness_sweep_large.py).  The Ridge start regresses on the nearest-neighbour
+  // estimate and may overshoot log-density x volume by HUNDREDS where nearest-neighbour distances span many decades in a
+  // high nominal dimension (1e6 cells of a 3-D tree embedded in 20-D: e^{f+V} overflows; the loss is 1e260 or inf).
+  // From there a quasi-Newton step walks the exponential down one unit per pass, and every relative stopping test is
+  // meaningless.  While the FIRST evaluation is not finite or above start_cap, the start is halved (z = C^-T u is linear
+  // in u; z = 0 is the constant density mu, always finite) and evaluated again -- at most 64 times.
+  double start_cap;
+  int n_shrink;
+  // Second preconditioner on trial: it is built for the end game (a handful of Newton-like iterations).  If the solve has
+  // not converged revert_after accepted iterations after the resume, that preconditioner is not what it was built to be
+  // (weights e^{f+V} spanning too many decades at the pause point for the importance sample): the solver pauses once
+  // more with pause_reason = 2 and the host puts the first preconditioner back.  0: off.
+  int revert_after;
+  int it_at_resume;         // -1: not armed
+  int pause_reason;         // 1 rebuild, 2 revert
 };
 
 struct SolverBuffers {
@@ -75,6 +90,6 @@ int launch_solver_init(mln_ctx* ctx, const SolverBuffers& b, const SolverState& 
 int launch_solver_step(mln_ctx* ctx, const SolverBuffers& b, int m);
 // after a pause: the host has written the accepted point and its gradient in the (new) preconditioned variable into
 // b.u / b.g; the next step starts a line search from there on `gate` (pairs_dropped: the history starts over)
-int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped);
+int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped, int revert_after = 0);
 // the stored pairs were re-expressed in a new variable by the host (S <- T S, Y <- T^-T Y): recompute y.y per slot
 int launch_solver_refresh_pairs(mln_ctx* ctx, const SolverBuffers& b, int maxcor);

@@ -303,7 +303,9 @@ def ridge_row_stride(n_local, m, with_offset=False):
     with_offset: also return the global index of this rank's first cell."""
     import os
     from .distributed import current
-    per_m = int(os.environ.get("MELLON_AMD_RIDGE_ROWS_PER_M", RIDGE_ROWS_PER_LANDMARK))
+    per_m = RIDGE_ROWS_PER_LANDMARK
+    if os.environ.get("MELLON_AMD_EXPERIMENTAL", "0") not in ("", "0"):       # (sweep knob: csrc/mln_options.h)
+        per_m = int(os.environ.get("MELLON_AMD_RIDGE_ROWS_PER_M", per_m))
     offset, n_global = current().global_offset(n_local)
     stride = max(1, n_global // (per_m * int(m))) if n_global > 2 * per_m * int(m) else 1
     return (stride, offset) if with_offset else stride

@@ -1,0 +1,113 @@
+"""Round-4 additions on a real MI355X (-m gpu).
+
+* Inputs the solver's shortcuts were NOT tuned on, at the scale where they used to fail (tools/robustness_sweep_large.py):
+  1e6 cells of a tree-shaped manifold in 20 nominal dimensions (diffusion-map-like: nearest-neighbour distances over four
+  decades -- the Ridge start overflowed, a stopping rule declared convergence at a loss of 1e260, the rebuilt
+  preconditioner stalled the solve until the iteration limit) and heavy tails (the rebuild lost positive definiteness).
+  No oracle finishes at this size: the default path must agree with the plain path (no subsample phase, no rebuild) of the
+  same strictly convex problem and report convergence.
+* A start whose loss is not finite (any size): the solve still reaches the oracle's optimum.
+* The communicator's accounting (mln_comm_info) on thread-ranks.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mellon_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mellon():
+    import mellon_amd
+    return mellon_amd
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mellon_amd import _lib
+    return _lib.default_context()
+
+
+def tree_cells(n, d, rng, branches=6):
+    """Cells along a branching tree of smooth curves in a 3-D latent space, embedded smoothly in d dimensions whose
+    scales decay like a diffusion map's eigenvalues (0.8^k), unevenly populated along pseudo-time."""
+    t = rng.beta(0.7, 1.3, size=n)
+    b = rng.integers(0, branches, size=n)
+    dirs = rng.normal(size=(branches, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    bend = rng.normal(size=(branches, 3)) * 0.5
+    z = t[:, None] * dirs[b] + (t ** 2)[:, None] * bend[b] + 0.02 * (1 + 3 * t)[:, None] * rng.normal(size=(n, 3))
+    W1 = rng.normal(size=(3, d)); W2 = rng.normal(size=(3, d))
+    x = np.tanh(z @ W1) + 0.3 * np.sin(2.0 * z @ W2)
+    return np.ascontiguousarray(x * (0.8 ** np.arange(d))[None, :])
+
+
+def _fit(mellon, xd, lm, nn, monkeypatch, **env):
+    for k in ("MELLON_AMD_MIXED", "MELLON_AMD_SUBSAMPLE", "MELLON_AMD_REBUILD"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+    dens = est.fit_predict(xd)
+    st = est._fit.stage_times()
+    z = np.asarray(est.pre_transformation)
+    loss, grad = est._fit.objective(z)
+    est._fit.close()
+    return dens, est.opt_state, st, loss, np.abs(grad).max()
+
+
+@pytest.mark.parametrize("case", ["tree", "heavy tails"])
+def test_inputs_the_shortcuts_were_not_tuned_on(mellon, ctx, monkeypatch, case):
+    n, d, m = 1_000_000, 20, 2000
+    rng = np.random.default_rng(11)
+    x = tree_cells(n, d, rng) if case == "tree" else rng.standard_t(3, size=(n, d))
+    xd = ctx.to_device(np.ascontiguousarray(x))
+    nn = ctx.nn_distances(xd, xd)
+    lm = ctx.kmeans(x[:100_000], m, seed=42)
+    plain = _fit(mellon, xd, lm, nn, monkeypatch, MELLON_AMD_MIXED="0", MELLON_AMD_SUBSAMPLE="0", MELLON_AMD_REBUILD="0")
+    assert plain[1].success and np.isfinite(plain[3])
+    scale = np.abs(plain[0]).max()
+    for name, env in (("default fp64", {"MELLON_AMD_MIXED": "0"}), ("mixed", {})):
+        dens, state, st, loss, gmax = _fit(mellon, xd, lm, nn, monkeypatch, **env)
+        assert state.success, (case, name, state)
+        assert np.isfinite(dens).all()
+        assert abs(loss - plain[3]) <= 1e-9 * abs(plain[3]), (case, name, loss, plain[3])
+        assert np.abs(dens - plain[0]).max() <= 1e-5 * scale, (case, name)
+    xd.free()
+
+
+def test_a_start_whose_loss_is_not_finite(mellon):
+    """initial_value far outside: e^{f+V} overflows at the first evaluation.  The solver halves the start until the loss is
+    finite and below 1e30, then converges to the (unique) optimum."""
+    n, d, m = 6000, 6, 150
+    x = mo.gaussian_mixture(n, d, seed=41)
+    nn = mo.exact_nn_distances(x)
+    ref = mo.density_fit(x, n_landmarks=m, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    for scale in (40.0, 4000.0):
+        est = mellon.DensityEstimator(landmarks=ref.landmarks, nn_distances=nn, initial_value=scale * np.ones(m))
+        dens = est.fit_predict(x)
+        assert est.opt_state.success
+        assert int(est._fit.stage_times()["start_halvings"]) >= 1
+        assert np.abs(dens - ref.log_density_x).max() < 1e-5 * np.abs(ref.log_density_x).max()
+
+
+def test_comm_info_on_thread_ranks():
+    from mellon_amd import distributed
+
+    def body(comm):
+        ctx = comm.ctx
+        ctx.comm_info(timing=True, reset=True)
+        out = ctx.allreduce_sum(np.full(5001, float(comm.rank + 1)))
+        big = ctx.allreduce_sum(np.ones(20000))
+        info = ctx.comm_info(timing=False)
+        return out[0], big[0], info
+
+    res = distributed.run_loopback(3, body)
+    for r, (a, b, info) in enumerate(res):
+        assert a == 6.0 and b == 3.0
+        assert info["transport"] == "loopback" and info["ranks_reported_by_transport"] == 3
+        assert info["rank_reported_by_transport"] == r
+        assert info["allreduce_calls"] == 2 and info["small_allreduce_calls"] == 1
+        assert info["small_allreduce_ms"] > 0.0 and info["large_allreduce_ms"] > 0.0

@@ -1,5 +1,6 @@
 """Pass counts of the C3 fit against the slope ratio above which the first trial step of the next line search doubles
 (solver.hip "step-length memory"; 0 = every search starts at t = 1)."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import sys; sys.path.insert(0,"/root/repo")
 import numpy as np, mellon_amd
 from oracle import mellon_oracle as mo

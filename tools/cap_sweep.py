@@ -1,5 +1,6 @@
 """Pass counts of the C3 fit against the cap beyond which e^{f+V} is continued linearly during the steep first part of the
 solve (solver.hip "capped start"; "off" = never capped; "c/f": cap c, dropped when the loss falls by less than f per pass)."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

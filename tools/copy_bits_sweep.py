@@ -1,5 +1,6 @@
 """Pass counts of the C3 fit when the 32-bit fixed-point copy is rounded to b bits (MELLON_AMD_COPY_BITS) and the
 switch tolerance of the uncorrected phase scales with the copy's error: how narrow a copy does the corrected solve bear?"""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -8,6 +8,7 @@ comes back as stage_times()["emulation_excluded_s"] and is subtracted here).
 
     python tools/emulate_rank.py 1 2 4 8 > profiles/rNN_emulated_ranks.json
 """
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import gc, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,4 +1,5 @@
 """Evaluation counts of the MAP solve over different landmark sets (mixed vs pure fp64)."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np, bench, mellon_amd

@@ -1,5 +1,6 @@
 """Pass count of the C3 fit when the sampled rows of K entering the preconditioner's Gram are rounded to b fractional
 bits (MELLON_AMD_GRAM_QBITS): how exact must K_s^T K_s be, given that Lp^-1 . Lp^-T amplifies its error?"""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """The preconditioner's integer Gram in isolation at the C3 shape (60 000 sampled cells x 5000 landmarks): ms per call of
 digit extraction + int8 GEMM + sum of the k-chunks, against the fp64 GEMM it replaces."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

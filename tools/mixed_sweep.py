@@ -1,4 +1,5 @@
 """Mixed-precision warm-up of mln_map_solve at C3: evaluations / time / error vs the fp32-phase tolerance."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,6 @@
 """Exact 1-NN on the device: the fp16 pre-filter + fp64 certification against the plain fp64 search.
 Sizes: n cells x 50 dims (default 1e6); also a sharded-style call (rows of a slice against all cells) and k-means timing."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench

@@ -3,6 +3,7 @@ tolerances), pure fp64 unless MIXED=1: pass counts in full-pass equivalents, ste
 
     VARIANTS="SUBSAMPLE=0,REBUILD=0;SUBSAMPLE=1,REBUILD=0;SUBSAMPLE=1,REBUILD=1" SEEDS=3,7 python tools/solver_sweep.py
 (each variant: comma-separated NAME=value pairs, set as MELLON_AMD_NAME)."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

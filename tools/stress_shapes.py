@@ -1,4 +1,5 @@
 """Odd shapes / kernels through the full estimator with the mixed-precision path forced on, vs the oracle."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys
 os.environ["MELLON_AMD_MIXED_MIN_ELEMS"] = "0"
 sys.path.insert(0, ".")

@@ -1,4 +1,5 @@
 """Pass counts and step time of the C3 fit against the format of the 32-bit copy and the switch tolerance."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 os.environ["MELLON_AMD_MIXED"]="1"; os.environ["MELLON_AMD_MIXED_FTOL"]=sys.argv[1]

@@ -1,4 +1,5 @@
 """Composite-kernel predictor gradient: GEMM route against the general kernel and the oracle; timing."""
+import os as _os; _os.environ.setdefault("MELLON_AMD_EXPERIMENTAL", "1")   # this tool turns experiment knobs (csrc/mln_options.h)
 import os
 import sys
 import time
