@@ -432,8 +432,13 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
           MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1, revert ? 0 : revert_after));
           if (revert) f->n_revert += 1; else f->n_rebuild += 1;
         } else {
-          // the rebuild declined (weights too wild) or lost positive definiteness: same variable, same history, carry on
-          MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0));
+          // the rebuild declined (weights too wild) or lost positive definiteness: same variable, same history, carry on --
+          // in the mixed solve WITHOUT the anchor just taken: the pause came far from the optimum (that is what the weights
+          // say), where the fp64 objective and its 32-bit surrogate differ by more than a first-order correction mends (heavy
+          // tails at 1e6 cells: 1e15 in the loss; the corrected surrogate then ran to the iteration limit).  The solve
+          // continues on the plain surrogate and anchors when THAT has converged, as a mixed solve without rebuild does.
+          if (ps.corr && (ps.gate_after_pause & 3) == MLN_GATE_F32) MLN_TRY(launch_solver_resume_plain32(ctx, f->sv, MLN_GATE_F32, (int)m));
+          else MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0));
           f->n_rebuild_skipped += 1;
         }
         if (trace_lvl) fprintf(stderr, "[trace] map_solve pause at evaluation %d: %s\n", ps.n_eval,

@@ -433,7 +433,25 @@ __global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped, in
   }
 }
 
+__global__ void k_solver_resume_plain32(SolverBuffers b, int gate, int m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) b.un[i] = b.u[i];
+  if (i == 0) {
+    SolverState* st = b.st;
+    st->gate = gate;
+    st->mode = MLN_SOLVE_REEVAL;
+    st->corr = 0; st->n_anchor = 0; st->corr_k = 0.0;
+    st->revert_after = 0; st->it_at_resume = -1; st->pause_reason = 0;
+  }
+}
+
 }  // namespace
+
+int launch_solver_resume_plain32(mln_ctx* ctx, const SolverBuffers& b, int gate, int m) {
+  hipLaunchKernelGGL(k_solver_resume_plain32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, b, gate, m);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
 
 int launch_solver_refresh_pairs(mln_ctx* ctx, const SolverBuffers& b, int maxcor) {
   hipLaunchKernelGGL(k_solver_refresh_pairs, dim3((unsigned)maxcor), dim3(ST), 0, ctx->stream, b);
