@@ -155,121 +155,63 @@ int fit_alloc_workspace(mln_fit* f) {
   return MLN_OK;
 }
 
-// Upload of the cells from pageable host memory, in row chunks, UNDER the device work of fit_prepare_impl.
-// What does not work (measured, round 4): hipMemcpyAsync straight from the pageable array in a helper thread -- the
-// runtime's own staging keeps the device's queues busy or locked: host-to-host step 181.4 ms against 184.1 without the helper
-// and 170.5 with resident cells, i.e. no overlap worth the name.  What this does instead: a pool of pinned staging buffers
-// (allocated once per process, 2 x 8 MB per copy thread), T threads that memcpy their slice of every chunk into them and
-// send it on with hipMemcpyAsync from PINNED memory on a stream of their own -- a plain DMA that runs next to kernels --
-// and per (chunk, thread) an event the main stream waits for before the kernel-matrix pass of that chunk.
-struct PinnedPool {
-  static constexpr int T = 8;                          // copy threads
-  static constexpr size_t PIECE = (size_t)8 << 20;     // bytes per staging buffer
-  std::mutex mu;
-  bool busy = false, broken = false;
-  char* base = nullptr;                                // T x 2 x PIECE, pinned
-  hipStream_t streams[T] = {};
-  hipEvent_t piece_done[T][2] = {};
-  bool acquire() {
-    std::lock_guard<std::mutex> lk(mu);
-    if (busy || broken) return false;                  // (busy: another context of this process is uploading -- it takes the plain route)
-    if (!base) {
-      if (hipHostMalloc((void**)&base, (size_t)T * 2 * PIECE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); base = nullptr; broken = true; return false; }
-      for (int t = 0; t < T; ++t) {
-        if (hipStreamCreateWithFlags(&streams[t], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); broken = true; return false; }
-        for (int b = 0; b < 2; ++b)
-          if (hipEventCreateWithFlags(&piece_done[t][b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); broken = true; return false; }
-      }
-    }
-    busy = true;
-    return true;
-  }
-  void release() { std::lock_guard<std::mutex> lk(mu); busy = false; }
-};
-static PinnedPool g_pinned[16];                        // one pool per device
-
+// Upload of the cells from pageable host memory in row chunks by a helper thread (see fit_prepare_impl).
+// MEASURED (round 4, C3, host-to-host step minus the step with resident cells): one plain copy before everything else
+// +13.6 ms; THIS (chunks copied by a helper thread with hipMemcpyAsync from the pageable array, each chunk's kernel-matrix
+// pass waiting for its event) +10.9 ms; a pool of pinned staging buffers filled by eight memcpy threads and sent on by
+// DMA from pinned memory +20 ms (the box's host memcpy is the bottleneck).  The runtime's pageable path does not run
+// next to kernels the way a pinned DMA does; the honest figure is that ~11 ms of the 0.4 GB upload stay exposed.  A copy from
+// pageable memory blocks its CALLING thread while the runtime stages it through pinned buffers, but not the device: the
+// chunks travel while the main thread's kernels run.  Chunk c is complete on the device when events[c] has fired; the
+// main thread makes its stream wait for that event -- after the helper has recorded it (done > c).
 struct HostUpload {
-  static constexpr int T = PinnedPool::T;
   mln_ctx* ctx = nullptr;
-  PinnedPool* pool = nullptr;
-  std::vector<hipEvent_t> events;                      // n_chunks x T
-  std::vector<std::atomic<int>> recorded;              // per chunk: threads that have recorded their event
+  hipStream_t copy = nullptr;
+  std::vector<hipEvent_t> events;
+  std::atomic<int> done{0};
   std::atomic<int> failed{0};
-  std::thread th[T];
+  std::thread th;
   int n_chunks = 0;
   int64_t n = 0, chunk_rows = 0;
   int d = 0;
-  bool active = false;
-  // false (and nothing started) when the pinned pool is not available: the caller uploads the plain way
-  bool start(mln_ctx* c, const double* src, double* dst, int64_t n_, int d_) {
+  int start(mln_ctx* c, const double* src, double* dst, int64_t n_, int d_) {
     ctx = c; n = n_; d = d_;
-    if (c->device < 0 || c->device >= 16) return false;
-    pool = &g_pinned[c->device];
-    if (!pool->acquire()) { pool = nullptr; return false; }
     // chunks of whole 128-row workgroup tiles, ~64 MB each, at most 16
     chunk_rows = std::max<int64_t>(128, (((int64_t)64 << 20) / ((int64_t)d * 8) + 127) / 128 * 128);
     if ((n + chunk_rows - 1) / chunk_rows > 16) chunk_rows = ((n + 15) / 16 + 127) / 128 * 128;
     n_chunks = (int)((n + chunk_rows - 1) / chunk_rows);
-    events.assign((size_t)n_chunks * T, nullptr);
-    for (auto& e : events)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); release_all(); return false; }
-    recorded = std::vector<std::atomic<int>>((size_t)n_chunks);
-    for (auto& r : recorded) r.store(0);
+    MLN_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    events.resize((size_t)n_chunks, nullptr);
+    for (auto& e : events) MLN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const int device = ctx->device;
-    active = true;
-    for (int t = 0; t < T; ++t)
-      th[t] = std::thread([this, src, dst, device, t] {
-        bool ok = hipSetDevice(device) == hipSuccess;
-        char* stage[2] = {pool->base + ((size_t)t * 2) * PinnedPool::PIECE, pool->base + ((size_t)t * 2 + 1) * PinnedPool::PIECE};
-        bool used[2] = {false, false};
-        int b = 0;
-        for (int c = 0; c < n_chunks; ++c) {
-          const int64_t r0 = (int64_t)c * chunk_rows, rows = std::min(chunk_rows, n - r0);
-          // this thread's slice of the chunk, in bytes
-          const size_t total = sizeof(double) * (size_t)(rows * d);
-          const size_t lo = total * (size_t)t / T / 8 * 8, hi = (t + 1 == T) ? total : total * (size_t)(t + 1) / T / 8 * 8;
-          const char* s0 = reinterpret_cast<const char*>(src + r0 * d);
-          char* d0 = reinterpret_cast<char*>(dst + r0 * d);
-          for (size_t off = lo; off < hi && ok; off += PinnedPool::PIECE) {
-            const size_t len = std::min(PinnedPool::PIECE, hi - off);
-            if (used[b]) ok = hipEventSynchronize(pool->piece_done[t][b]) == hipSuccess;   // its previous DMA has drained
-            if (!ok) break;
-            std::memcpy(stage[b], s0 + off, len);
-            ok = hipMemcpyAsync(d0 + off, stage[b], len, hipMemcpyHostToDevice, pool->streams[t]) == hipSuccess;
-            if (ok) ok = hipEventRecord(pool->piece_done[t][b], pool->streams[t]) == hipSuccess;
-            used[b] = true;
-            b ^= 1;
-          }
-          if (ok) ok = hipEventRecord(events[(size_t)c * T + t], pool->streams[t]) == hipSuccess;
-          if (!ok) failed.store(1);
-          recorded[(size_t)c].fetch_add(1, std::memory_order_release);
-        }
-        if (ok) (void)hipStreamSynchronize(pool->streams[t]);
-      });
-    return true;
+    th = std::thread([this, src, dst, device] {
+      if (hipSetDevice(device) != hipSuccess) { failed.store(1); done.store(n_chunks); return; }
+      for (int c = 0; c < n_chunks; ++c) {
+        const int64_t r0 = (int64_t)c * chunk_rows, rows = std::min(chunk_rows, n - r0);
+        hipError_t e = hipMemcpyAsync(dst + r0 * d, src + r0 * d, sizeof(double) * (size_t)(rows * d), hipMemcpyHostToDevice, copy);
+        if (e == hipSuccess) e = hipEventRecord(events[(size_t)c], copy);
+        if (e != hipSuccess) { failed.store(1); done.store(n_chunks, std::memory_order_release); return; }
+        done.store(c + 1, std::memory_order_release);
+      }
+    });
+    return MLN_OK;
   }
   int wait_chunk(int c, int64_t* r0, int64_t* rows) {
-    while (recorded[(size_t)c].load(std::memory_order_acquire) < T) std::this_thread::yield();
-    if (failed.load()) { mln_set_error(ctx, "upload of the cells failed (copy thread)"); return MLN_ERR_HIP; }
-    for (int t = 0; t < T; ++t) MLN_HIP(ctx, hipStreamWaitEvent(ctx->stream, events[(size_t)c * T + t], 0));
+    while (done.load(std::memory_order_acquire) <= c) std::this_thread::yield();
+    if (failed.load()) { mln_set_error(ctx, "upload of the cells failed (helper thread)"); return MLN_ERR_HIP; }
+    MLN_HIP(ctx, hipStreamWaitEvent(ctx->stream, events[(size_t)c], 0));
     *r0 = (int64_t)c * chunk_rows;
     *rows = std::min(chunk_rows, n - *r0);
     return MLN_OK;
   }
   int finish() {
-    join();
+    if (th.joinable()) th.join();
     return failed.load() ? MLN_ERR_HIP : MLN_OK;
   }
-  void join() { for (auto& t : th) if (t.joinable()) t.join(); }
-  void release_all() {
-    for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
-    events.clear();
-    if (pool) { pool->release(); pool = nullptr; }
-  }
   ~HostUpload() {
-    join();
-    if (active && pool) for (int t = 0; t < T; ++t) (void)hipStreamSynchronize(pool->streams[t]);
-    release_all();
+    if (th.joinable()) th.join();
+    if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
+    for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -298,10 +240,7 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     dx.ctx = ctx;
     MLN_HIP(ctx, mln_dmalloc((void**)&dx.owned, (size_t)n * d * sizeof(double)));
     dx.dev = dx.owned;
-    if (!up.start(ctx, x, dx.owned, n, d)) {             // no pinned pool: one plain copy, as for small inputs
-      pipelined = false;
-      MLN_HIP(ctx, hipMemcpyAsync(dx.owned, x, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    }
+    MLN_TRY(up.start(ctx, x, dx.owned, n, d));
   } else {
     MLN_TRY(dx.init(ctx, x, (size_t)n * d));
   }

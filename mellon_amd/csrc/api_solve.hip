@@ -380,13 +380,14 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // evaluation t of the solver's trace ran in enqueue slot t + shift: the chains left in a batch after a pause are
   // no-ops that use up slots (their events time nothing)
   std::vector<std::pair<int, int>> slot_shift;      // (first trace index, shift)
+  const std::vector<int64_t>* subs_live = subs;
   int batch = 8;
   if (const char* ev = mln_experiment("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
   const int64_t hard_cap = (int64_t)o.maxiter * o.maxls + 16;
   for (;;) {
     for (int b = 0; b < batch; ++b) {
       MLN_TRY(launch_solver_step(ctx, f->sv, (int)m));
-      MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), subs));
+      MLN_TRY(fit_enqueue_eval(f, f->sv.un, f->sv.gn, false, gate, events_for(n_enq), subs_live));
       ++n_enq;
     }
     // rank 0's state decides for everyone (it is the same state on every rank by construction: identical inputs,
@@ -395,6 +396,8 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     MLN_HIP(ctx, hipMemcpyAsync(f->h_state, f->sv.st, sizeof(SolverState), hipMemcpyDeviceToHost, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (f->h_state->gate == MLN_GATE_DONE) break;
+    // the subsample phase never comes back: its (gated-off, ~4 us each) launches need not ride along any more
+    if (subs_live && f->h_state->n_eval_sub > 0 && f->h_state->gate != MLN_GATE_SUB) subs_live = nullptr;
     if (f->h_state->gate == MLN_GATE_PAUSE) {
       // ---- second preconditioner at the accepted point (whose rows' f the last accepted fp64 pass left in f_keep) ----
       const double tr0 = now_s(), ex_r0 = f->emu_excluded;

@@ -37,6 +37,18 @@ print(f"# {len(rows)} kernels, {tot / 1e6:.1f} ms of kernel time in total")
 print(f"{'kernel':122s} {'calls':>7s} {'avg us':>12s} {'total ms':>10s} {'%':>6s} {'min us':>10s} {'max us':>10s}")
 for n, c, a, s, mn, mx in rows:
     print(f"{short(n):122s} {c:7d} {a / 1e3:12.2f} {s / 1e6:10.2f} {100 * s / tot:6.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f}")
+# The objective kernels are launched for every evaluation of the device-resident solver and gated on its state: a row above
+# mixes launches that streamed the whole buffer, launches over the row subsample and no-ops.  Per kernel: the launches within
+# 2x of the longest one ("full size") on their own.
+print()
+print("# objective kernels, FULL-SIZE launches only (duration > half of the kernel's longest launch)")
+print(f"{'kernel':122s} {'calls':>7s} {'avg us':>12s} {'total ms':>10s} {'min us':>10s} {'max us':>10s}")
+for (n,) in con.execute("select distinct name from kernels where name like '%k_objective%'").fetchall():
+    d = [r[0] for r in con.execute("select duration from kernels where name = ?", (n,)).fetchall()]
+    full = [v for v in d if v > 0.5 * max(d)]
+    if max(d) < 2e5:
+        continue
+    print(f"{short(n):122s} {len(full):7d} {sum(full) / len(full) / 1e3:12.2f} {sum(full) / 1e6:10.2f} {min(full) / 1e3:10.2f} {max(full) / 1e3:10.2f}")
 PY
 python "$ROOT/tools/make_profiles.py" "$OUT/stats/stats_results.db" "$OUT/fetch/fetch_results.db" "$OUT/write/write_results.db" "$OUT/sq/sq_results.db" 1000000 5000 5008 "$TAG" > "$OUT/make_profiles.out" 2> "$OUT/make_profiles.err"
 python - "$OUT/profiles/objective_traffic.json" "$COMMIT" "$SHA" <<'PY'
