@@ -111,3 +111,94 @@ def test_comm_info_on_thread_ranks():
         assert info["rank_reported_by_transport"] == r
         assert info["allreduce_calls"] == 2 and info["small_allreduce_calls"] == 1
         assert info["small_allreduce_ms"] > 0.0 and info["large_allreduce_ms"] > 0.0
+
+
+@pytest.mark.parametrize("knobs", [{"MELLON_AMD_REBUILD_RANGE": "0"},            # every rebuild declines
+                                   {"MELLON_AMD_REVERT_AFTER": "1"},             # every rebuilt preconditioner fails its trial
+                                   {"MELLON_AMD_REBUILD_RANGE": "0", "MELLON_AMD_MIXED_MIN_ELEMS": "0", "mixed": "1"}])
+def test_rebuild_fallbacks_are_collective(mellon, monkeypatch, knobs):
+    """The decline / revert branches issue collectives (or skip them): every rank must take the same one.  Forced here on
+    3 thread-ranks at a small size, where the guards would not fire by themselves; the result is the unsharded optimum."""
+    from mellon_amd import distributed
+    from sklearn.cluster import k_means
+    n, d, m = 40_000, 10, 300
+    x = mo.gaussian_mixture(n, d, seed=13)
+    nn = mo.exact_nn_distances(x)
+    lm = np.ascontiguousarray(k_means(x[:8000], m, n_init=1, random_state=42)[0])
+    mixed = knobs.get("mixed") == "1"
+    monkeypatch.setenv("MELLON_AMD_REBUILD", "1")
+    monkeypatch.setenv("MELLON_AMD_MIXED", "1" if mixed else "0")
+    for k, v in knobs.items():
+        if k != "mixed":
+            monkeypatch.setenv(k, v)
+    est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+    single = est.fit_predict(x)
+    st = est._fit.stage_times()
+    if "MELLON_AMD_REVERT_AFTER" in knobs:
+        assert int(st["precond_reverts"]) == 1
+    else:
+        assert int(st["precond_rebuilds_declined"]) == 1 and int(st["precond_rebuilds"]) == 0
+    assert est.opt_state.success
+
+    def body(comm):
+        lo, hi = distributed.shard_bounds(n, comm.world_size, comm.rank)
+        e = mellon.DensityEstimator(landmarks=lm, nn_distances=nn[lo:hi], check_rank=False)
+        dens = e.fit_predict(np.ascontiguousarray(x[lo:hi]))
+        s = e._fit.stage_times()
+        return dens, e.opt_state.success, int(s["precond_reverts"]), int(s["precond_rebuilds_declined"])
+
+    parts = distributed.run_loopback(3, body)
+    assert all(p[1] for p in parts)
+    assert len({(p[2], p[3]) for p in parts}) == 1
+    sharded = np.concatenate([p[0] for p in parts])
+    assert np.abs(sharded - single).max() < 2e-6 * np.abs(single).max()
+
+
+def test_kmeans_coarse_to_fine(ctx, monkeypatch):
+    """Above 64 cells per centre mln_kmeans seeds and pre-converges on every s-th cell and only polishes on all of them:
+    same quality (inertia) as the one-level run, every centre the mean of its members, reproducible for a fixed seed."""
+    x = mo.gaussian_mixture(260_000, 10, seed=3)
+    m = 500
+    c2, it2, inertia2 = ctx.kmeans(x, m, seed=42, return_info=True)
+    monkeypatch.setenv("MELLON_AMD_KM_LEVELS", "1")
+    c1, it1, inertia1 = ctx.kmeans(x, m, seed=42, return_info=True)
+    monkeypatch.delenv("MELLON_AMD_KM_LEVELS")
+    assert inertia2 < 1.01 * inertia1, (inertia2, inertia1)
+    lab = np.argmin(mo.distance(x[:20000], c2), axis=1)
+    assert np.isfinite(c2).all() and len(np.unique(lab)) > 0.9 * m
+    c2b = ctx.kmeans(x, m, seed=42)
+    assert np.abs(c2b - c2).max() < 1e-9 * np.abs(c2).max()
+
+
+def test_tree_data_sharded_at_scale(mellon, ctx, monkeypatch):
+    """The guards of the rebuild (decline / trial / revert) decide from all-reduced numbers and the replicated solver state:
+    1e6 tree-shaped cells on 2 thread-ranks reach the unsharded fit's optimum and report the same decisions."""
+    from mellon_amd import distributed
+    n, d, m = 1_000_000, 20, 2000
+    rng = np.random.default_rng(11)
+    x = tree_cells(n, d, rng)
+    xd = ctx.to_device(x)
+    nn = ctx.nn_distances(xd, xd)
+    xd.free()
+    lm = ctx.kmeans(x[:100_000], m, seed=42)
+    monkeypatch.setenv("MELLON_AMD_MIXED", "0")
+    est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+    single = est.fit_predict(x)
+    st1 = est._fit.stage_times()
+    assert est.opt_state.success
+    est._fit.close()
+
+    def body(comm):
+        lo, hi = distributed.shard_bounds(n, comm.world_size, comm.rank)
+        e = mellon.DensityEstimator(landmarks=lm, nn_distances=nn[lo:hi], check_rank=False)
+        dens = e.fit_predict(np.ascontiguousarray(x[lo:hi]))
+        s = e._fit.stage_times()
+        out = dens, e.opt_state.success, (int(s["precond_rebuilds"]), int(s["precond_rebuilds_declined"]), int(s["precond_reverts"]))
+        e._fit.close()
+        return out
+
+    parts = distributed.run_loopback(2, body)
+    assert all(p[1] for p in parts)
+    assert parts[0][2] == parts[1][2]
+    sharded = np.concatenate([p[0] for p in parts])
+    assert np.abs(sharded - single).max() < 1e-5 * np.abs(single).max()
