@@ -442,6 +442,8 @@ int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int*
   double tt[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int i, double& t0) { if (tr_on) { (void)hipStreamSynchronize(ctx->stream); const double t1 = now_s(); tt[i] += t1 - t0; t0 = t1; } };
   double tl = now_s();
+  // (Clipping the weights to a range of 1e3 .. 1e5 instead of declining was tried -- tools/clip_sweep.py,
+  //  profiles/r04_clip_sweep.txt: the clipped preconditioner failed its trial on the tree and helped nowhere.)
   MLN_TRY(rebuild_select_rows(ctx, f_dev, f->V, f->n, f->row0, target, 0x6d656c6c6f6eull, &sel));
   lap(0, tl);
   if (tr_on)

@@ -431,8 +431,13 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         (void)mln_dfree(zt);
         MLN_TRY(rc);
         if (outcome == 0) {
-          // a rebuilt preconditioner is on trial (solver.h: revert_after); a restored one is not
-          MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1, revert ? 0 : revert_after));
+          // a rebuilt preconditioner is on trial (solver.h: revert_after); a restored one is not.  A mixed solve whose
+          // rebuilt preconditioner failed its trial also forgets its anchor (taken at that rebuild's pause point: clip_sweep
+          // on the tree ran the corrected surrogate to the iteration limit) and goes on with the plain 32-bit surrogate.
+          if (revert && ps.corr && (ps.gate_after_pause & 3) == MLN_GATE_F32)
+            MLN_TRY(launch_solver_resume_plain32(ctx, f->sv, MLN_GATE_F32, (int)m, 1));
+          else
+            MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1, revert ? 0 : revert_after));
           if (revert) f->n_revert += 1; else f->n_rebuild += 1;
         } else {
           // the rebuild declined (weights too wild) or lost positive definiteness: same variable, same history, carry on --

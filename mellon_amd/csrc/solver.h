@@ -93,7 +93,8 @@ int launch_solver_step(mln_ctx* ctx, const SolverBuffers& b, int m);
 int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped, int revert_after = 0);
 // after a pause at the mixed solve's early fp64 anchor whose rebuild was declined: forget the anchor (it was taken far from
 // the optimum, where the 32-bit surrogate and the fp64 objective differ by more than a first-order correction mends) and
-// go on with the PLAIN 32-bit surrogate from the same point -- one re-evaluation there on `gate`, history kept
-int launch_solver_resume_plain32(mln_ctx* ctx, const SolverBuffers& b, int gate, int m);
+// go on with the PLAIN 32-bit surrogate from the same point -- one re-evaluation there on `gate`, history kept (or dropped:
+// after a revert of the preconditioner the variable is a new one)
+int launch_solver_resume_plain32(mln_ctx* ctx, const SolverBuffers& b, int gate, int m, int pairs_dropped = 0);
 // the stored pairs were re-expressed in a new variable by the host (S <- T S, Y <- T^-T Y): recompute y.y per slot
 int launch_solver_refresh_pairs(mln_ctx* ctx, const SolverBuffers& b, int maxcor);

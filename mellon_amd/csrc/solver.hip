@@ -225,7 +225,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       // for good and the same point is evaluated once more on the true objective (the curvature pairs stay: they are
       // the true ones for every cell below the cap).  tools/cap_sweep.py, six data seeds at C3: 41.8 -> 39.2 passes.
       if (cap < 1e300 && it >= 3 && (f_old - fx) <= st->cap_fall * fabs(f_old)) { cap = __builtin_inf(); recap = true; }
-      const bool revert = st->revert_after > 0 && st->it_at_resume >= 0 && !approx && it - st->it_at_resume > st->revert_after &&
+      const bool revert = st->revert_after > 0 && st->it_at_resume >= 0 && !phaseS && it - st->it_at_resume > st->revert_after &&
                           (f_old - fx) > st->ftol * fscale;
       if (revert) {
         pause = true; pause_reason = 2;          // (solver.h: revert_after) the host restores the first preconditioner
@@ -433,13 +433,14 @@ __global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped, in
   }
 }
 
-__global__ void k_solver_resume_plain32(SolverBuffers b, int gate, int m) {
+__global__ void k_solver_resume_plain32(SolverBuffers b, int gate, int m, int pairs_dropped) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) b.un[i] = b.u[i];
   if (i == 0) {
     SolverState* st = b.st;
     st->gate = gate;
     st->mode = MLN_SOLVE_REEVAL;
+    if (pairs_dropped) { st->k = 0; st->head = 0; }
     st->corr = 0; st->n_anchor = 0; st->corr_k = 0.0;
     st->revert_after = 0; st->it_at_resume = -1; st->pause_reason = 0;
   }
@@ -447,8 +448,8 @@ __global__ void k_solver_resume_plain32(SolverBuffers b, int gate, int m) {
 
 }  // namespace
 
-int launch_solver_resume_plain32(mln_ctx* ctx, const SolverBuffers& b, int gate, int m) {
-  hipLaunchKernelGGL(k_solver_resume_plain32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, b, gate, m);
+int launch_solver_resume_plain32(mln_ctx* ctx, const SolverBuffers& b, int gate, int m, int pairs_dropped) {
+  hipLaunchKernelGGL(k_solver_resume_plain32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, b, gate, m, pairs_dropped);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
