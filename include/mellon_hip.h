@@ -408,8 +408,9 @@ int mln_predict_mean_covariance(mln_ctx* ctx, const mln_kernel_desc* cov, const 
  * full-fp64-pass equivalents ([6] + [9] / 2 + [13] / [14]); [18] rebuilds that declined (the sample's weights span more
  * than 1e5) or lost positive definiteness -- the solve went on with the first preconditioner; [19] rebuilt preconditioners
  * that failed their trial (no convergence within 60 iterations) and were replaced by the first again; [20] halvings of a
- * start whose loss was not finite or above 1e30.                                                                       */
-#define MLN_N_STAGE_TIMES 21
+ * start whose loss was not finite or above 1e30; [21] how the last mln_fit_gram_rank counted: 1 = inertia of G - x I
+ * (csrc/ldl_inertia.hip), 2 = tridiagonalisation + Sturm counts (csrc/tridiag.hip), 0 = not called.                       */
+#define MLN_N_STAGE_TIMES 22
 int mln_stage_times(mln_fit* fit, double* out /* MLN_N_STAGE_TIMES */);
 
 #ifdef __cplusplus

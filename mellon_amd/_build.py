@@ -15,7 +15,7 @@ SOURCES = ["api.hip", "api_fit.hip", "api_precond.hip", "api_solve.hip", "api_no
            "predict_rows_ratquad.hip", "predict_rows_prod.hip", "predict_rows_prod_matern32.hip", "predict_rows_prod_matern52.hip",
            "predict_rows_prod_expquad.hip", "predict_rows_prod_exponential.hip", "kernel_rows_prod_matern32.hip", "kernel_rows_prod_matern52.hip",
            "kernel_rows_prod_expquad.hip", "kernel_rows_prod_exponential.hip",
-           "dgemm.hip", "diag.hip", "precond_rebuild.hip", "rowmin_f16.hip", "gram_i8.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip", "tridiag.hip"]
+           "dgemm.hip", "diag.hip", "precond_rebuild.hip", "rowmin_f16.hip", "gram_i8.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip", "tridiag.hip", "ldl_inertia.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DMLN_POTRF_TIMING"] if __import__("os").environ.get("MLN_POTRF_TIMING") else [])
 
 

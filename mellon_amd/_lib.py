@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmellon_hip.so")
 
 MLN_OK, MLN_ERR_NOT_PD, MLN_ERR_SHAPE, MLN_ERR_HIP, MLN_ERR_RCCL, MLN_ERR_ARG, MLN_ERR_UNSUPPORTED = range(7)
 MLN_UNIQUE_ID_BYTES = 128
-MLN_N_STAGE_TIMES = 21
+MLN_N_STAGE_TIMES = 22
 
 K_MATERN32, K_MATERN52, K_EXPQUAD, K_EXPONENTIAL, K_RATQUAD, K_LINEAR, K_DISTANCE = 1, 2, 3, 4, 5, 6, 7
 OP_LEAF, OP_CONST, OP_ADD, OP_MUL, OP_POW = 0, 1, 2, 3, 4
@@ -424,7 +424,7 @@ class Context:
         nit, inertia = C.c_int32(), C.c_double()
         self._check(self.lib.mln_kmeans(self.handle, _ptr(x), x.shape[0], x.shape[1], int(m), int(seed),
                                         int(max_iter), float(tol), centers.ctypes.data, C.byref(nit),
-                                        C.byref(inertia)))
+                                        C.byref(inertia) if return_info else None))   # (the inertia is a full fp64 assignment)
         return (centers, nit.value, inertia.value) if return_info else centers
 
     def chol_lower(self, A, add_diag=0.0, jitter=None):
@@ -972,7 +972,7 @@ class Fit:
                 "objective32_kernel_s", "objective32_launches", "copy32_format", "emulation_excluded_s",
                 "objective_sub_kernel_s", "objective_sub_launches", "objective_sub_stride", "precond_rebuild_s",
                 "precond_rebuilds", "objective_pass_equivalents", "precond_rebuilds_declined", "precond_reverts",
-                "start_halvings"]
+                "start_halvings", "rank_path"]
         return dict(zip(keys, out.tolist()))
 
 

@@ -17,6 +17,10 @@ std::mutex g_mu;
 std::unordered_map<void*, std::pair<size_t, int>> g_live;
 std::multimap<size_t, Block> g_free;
 const bool g_enabled = (std::getenv("MELLON_AMD_NO_CACHE") == nullptr);
+// MELLON_AMD_POISON=1 (debugging): every block handed out is filled with 0xFF bytes first (NaN as a double, -1 as an
+// integer), so that a kernel reading memory nobody wrote shows up in the results instead of depending on what the
+// block held before.
+const bool g_poison = (std::getenv("MELLON_AMD_POISON") != nullptr && std::atoi(std::getenv("MELLON_AMD_POISON")) != 0);
 
 void flush_locked() {
   for (auto& kv : g_free) (void)hipFree(kv.second.p);
@@ -36,7 +40,9 @@ hipError_t mln_dmalloc(void** out, size_t bytes) {
       if (it->second.dev != dev) continue;
       *out = it->second.p;
       g_live[*out] = {it->first, dev};
+      const size_t got = it->first;
       g_free.erase(it);
+      if (g_poison) { (void)hipMemset(*out, 0xFF, got); (void)hipDeviceSynchronize(); }
       return hipSuccess;
     }
   }
@@ -47,6 +53,7 @@ hipError_t mln_dmalloc(void** out, size_t bytes) {
     e = hipMalloc(out, bytes);
   }
   if (e == hipSuccess) g_live[*out] = {bytes, dev};
+  if (e == hipSuccess && g_poison) { (void)hipMemset(*out, 0xFF, bytes); (void)hipDeviceSynchronize(); }
   return e;
 }
 

@@ -540,9 +540,19 @@ extern "C" int mln_fit_gram_rank(mln_fit* f, double tol, int64_t* rank_out, doub
   int64_t stride = 1;
   static const bool sampled_ok = !(mln_experiment("MELLON_AMD_RANK_SAMPLED") && std::atoi(mln_experiment("MELLON_AMD_RANK_SAMPLED")) == 0);
   if (sampled_ok && f->kspace && n_est >= 24 * m) stride = std::max<int64_t>(1, n_est / (12 * m));
-  int rc = f->kspace ? fit_gram(f, G, ld, stride) : gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld);
+  auto gram = [&]() { return f->kspace ? fit_gram(f, G, ld, stride) : gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld); };
+  int rc = gram();
   double lmax = 0.0;
-  if (rc == MLN_OK) rc = dev_sym_rank_above(ctx, G, m, ld, tol * tol, rank_out, &lmax);
+  // The count by inertia (ldl_inertia.hip: Lanczos for lambda_max, then the signs of the pivots of G - x I; ~15 ms at
+  // m = 5000) first; where it cannot certify its pivots, the tridiagonal path (0.25 s) on a fresh Gram.
+  const bool ldl_ok = !(mln_experiment("MELLON_AMD_RANK_LDL") && std::atoi(mln_experiment("MELLON_AMD_RANK_LDL")) == 0);
+  bool done = false;
+  if (rc == MLN_OK && ldl_ok) {
+    rc = dev_sym_rank_above_ldl(ctx, G, m, ld, tol * tol, rank_out, &lmax, &done);
+    if (rc == MLN_OK && !done) rc = gram();
+  }
+  if (rc == MLN_OK && !done) rc = dev_sym_rank_above(ctx, G, m, ld, tol * tol, rank_out, &lmax);
+  f->rank_path = done ? 1 : 2;
   (void)hipStreamSynchronize(ctx->stream);
   (void)mln_dfree(G);
   if (rc == MLN_OK && sigma_max_out) *sigma_max_out = std::sqrt(std::max(lmax, 0.0));

@@ -144,7 +144,7 @@ struct mln_fit {
   // the FIRST preconditioner (C, C^-1, P, Q1, Q2) while the solve runs on the rebuilt one: put back if that one fails its
   // trial (solver.h: revert_after); released when the solve ends
   double* saved_precond[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int n_revert = 0, n_rebuild_skipped = 0, n_start_halvings = 0;
+  int n_revert = 0, n_rebuild_skipped = 0, n_start_halvings = 0, rank_path = 0;
   double build_seconds = 0.0;     // wall time of the first preconditioner build (Gram + factorisation): the rebuild's price
   double times_sub = 0.0, times_rebuild = 0.0, sub_pass_equiv = 0.0;
   int evals_sub = 0, n_rebuild = 0;

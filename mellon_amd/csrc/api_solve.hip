@@ -327,7 +327,19 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   const double pass_s = (double)f->n * (double)f->ldl * 8.0 / 6.5e12 + 1.4e-4;
   // (emulated ranks of C3, tools/emulate_rank.py: the rebuild gains 9 ms per step at 4 ranks -- first build = 8.9 evaluations
   //  -- and loses 2.5 ms at 8 -- 12.7 evaluations: the threshold sits between)
-  double want_rebuild = (f->build_seconds > 0.0 && 11.0 * pass_s > f->build_seconds) ? 1.0 : 0.0;
+  // The price of a build comes from a MODEL of it, not from the stopwatch on the first one: a measured time made the
+  // decision -- and with it the iteration path and the last digits of the result -- depend on whether the process was warm
+  // (the first fit of a process: no rebuild, 11 evaluations; every later one: rebuild, 8 evaluations, log-density 2e-5 off
+  // at the default stopping rule on a 100-cell problem).  Model: two factorisation-like chains of m / 128 dependent block
+  // steps (0.25 ms per block: chol(C'), inverses, operators), the integer Gram of this rank's sample rows at 1 POP/s, the
+  // whitening's 2 m^3 flops (column-split over >= 3 ranks) at 45 TFLOP/s -- 18.5 / 12.2 / 11.1 ms at C3 on 1 / 4 / 8 ranks
+  // against the measured 18.7 / 13.6 / 10.9.
+  const double md = (double)f->m;
+  const int n_ranks_r = ctx->n_ranks > 1 ? ctx->n_ranks : 1;
+  const double gram_rows = (double)f->n / (double)(f->precond_stride > 0 ? f->precond_stride : 1);
+  const double build_model_s = 2.5e-4 * std::ceil(md / 128.0) + gram_rows * md * md * 2.0 / 1.0e15 +
+                               2.0 * md * md * md / (n_ranks_r >= 3 ? (double)n_ranks_r : 1.0) / 45e12;
+  double want_rebuild = (f->build_seconds > 0.0 && 11.0 * pass_s > build_model_s) ? 1.0 : 0.0;
   if (const char* ev = mln_experiment("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
   if (phase32 && !(f->l32_fixed)) want_rebuild = 0.0;   // (mixed solves pause at their fp64 anchor, which only the corrected fixed-point surrogate has)
   // The rebuild reads the rows' f of the last accepted pass (f_keep), which a rank only has while its shard fits the
@@ -574,6 +586,7 @@ extern "C" int mln_stage_times(mln_fit* f, double* out) {
   out[18] = (double)f->n_rebuild_skipped;               // rebuilds declined (weight range) or failed (not positive definite)
   out[19] = (double)f->n_revert;                        // second preconditioner failed its trial: first one restored
   out[20] = (double)f->n_start_halvings;                // halvings of a start whose loss was not finite or above 1e30
+  out[21] = (double)f->rank_path;                       // mln_fit_gram_rank: 1 = inertia, 2 = tridiagonalisation
   return MLN_OK;
 }
 

@@ -12,6 +12,7 @@
 //             are reproducible to rounding, not bitwise), stop when the summed squared centre shift
 //             <= tol * mean feature variance (sklearn's rule) or after max_iter sweeps.
 #include <cmath>
+#include <cstdio>
 #include <vector>
 
 #include "mln_internal.h"
@@ -363,19 +364,105 @@ __global__ void k_accumulate(const double* __restrict__ x, int64_t n, int d, con
 }
 
 // new centres (empty clusters keep their previous centre); shift2 += |new - old|^2
+// delta (optional): how far each centre moved (0 for an empty cluster) -- what the distance bounds of the next sweep need
 __global__ void k_finish(double* __restrict__ c, const double* __restrict__ sums, const double* __restrict__ counts,
-                         int64_t m, int d, double* __restrict__ shift2) {
+                         int64_t m, int d, double* __restrict__ shift2, double* __restrict__ delta) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   const double cnt = counts[j];
-  if (cnt <= 0.0) return;
+  if (cnt <= 0.0) { if (delta) delta[j] = 0.0; return; }
   double s = 0.0;
   for (int k = 0; k < d; ++k) {
     const double nv = sums[j * d + k] / cnt, t = nv - c[j * d + k];
     s = fma(t, t, s);
     c[j * d + k] = nv;
   }
+  if (delta) delta[j] = sqrt(s);
   atomicAdd(shift2, s);
+}
+
+// ---- Lloyd's iterations with distance bounds (Hamerly 2010: the same assignments, most of them without a search) --------
+// Per cell: ub >= distance to the centre it is assigned to, lb <= distance to every OTHER centre.  When the centres move by
+// delta_j, ub grows by delta of the own centre and lb shrinks by the largest movement among the others; while ub <= lb the
+// assignment cannot have changed and the cell is skipped.  Otherwise ub is first tightened to the exact distance (d flops),
+// and only if that does not decide either is the cell searched again (rowmin_f16.hip, restricted to the listed rows).
+// dstat: [0] largest delta, [1] second largest, [2] index of the largest.
+__global__ __launch_bounds__(256) void k_km_delta_stats(const double* __restrict__ delta, int64_t m, double* __restrict__ dstat) {
+  __shared__ double s1[256], s2[256];
+  __shared__ int sa[256];
+  double b1 = 0.0, b2 = 0.0;
+  int a = 0;
+  for (int64_t j = threadIdx.x; j < m; j += 256) {
+    const double v = delta[j];
+    if (v > b1) { b2 = b1; b1 = v; a = (int)j; }
+    else if (v > b2) b2 = v;
+  }
+  s1[threadIdx.x] = b1; s2[threadIdx.x] = b2; sa[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double g1 = 0.0, g2 = 0.0;
+    int ga = 0;
+    for (int t = 0; t < 256; ++t) {
+      if (s1[t] > g1) { g2 = fmax(g1, s2[t]); g1 = s1[t]; ga = sa[t]; }
+      else g2 = fmax(g2, s1[t]);
+    }
+    dstat[0] = g1; dstat[1] = g2; dstat[2] = (double)ga;
+  }
+}
+
+// Eight lanes per cell (each reads every eighth coordinate: a wave touches 8 consecutive rows of x, coalesced); the exact
+// distance to the own centre is taken for EVERY cell (n d reads: a tenth of a search sweep), so ub is always tight.
+// A workgroup walks KB_ROWS cells and appends its flagged ones with ONE atomic (one per wave was 125 000 atomics on the
+// same address per sweep: 1.2 ms of a 1.4 ms kernel).
+constexpr int KB_ROWS = 512, KB_IT = KB_ROWS / 32;
+__global__ __launch_bounds__(256) void k_km_bounds(const double* __restrict__ x, int64_t n, int d, const double* __restrict__ c,
+                                                   const int* __restrict__ label, double* __restrict__ ub, double* __restrict__ lb,
+                                                   const double* __restrict__ delta, const double* __restrict__ dstat,
+                                                   int* __restrict__ n_flag, int* __restrict__ flagged) {
+  __shared__ unsigned long long masks[KB_IT * 4];     // per (iteration, wave): ballot of the flagged groups' first lanes
+  __shared__ int offs[KB_IT * 4];
+  __shared__ int base_s;
+  const int sub = threadIdx.x & 7, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double d1 = dstat[0], d2 = dstat[1];
+  const int amax = (int)dstat[2];
+  const int64_t row0 = (int64_t)blockIdx.x * KB_ROWS;
+  for (int it = 0; it < KB_IT; ++it) {
+    const int64_t i = row0 + it * 32 + (threadIdx.x >> 3);
+    bool flag = false;
+    if (i < n) {
+      const int a = label[i];
+      const double* xr = x + i * d;
+      const double* cr = c + (int64_t)a * d;
+      double dd = 0.0;
+      for (int k = sub; k < d; k += 8) { const double t = xr[k] - cr[k]; dd = fma(t, t, dd); }
+      dd += __shfl_xor(dd, 1, 64);
+      dd += __shfl_xor(dd, 2, 64);
+      dd += __shfl_xor(dd, 4, 64);
+      const double u = sqrt(dd);
+      const double l = lb[i] - ((a == amax) ? d2 : d1);
+      if (sub == 0) { ub[i] = u; lb[i] = l; }
+      flag = (sub == 0) && (u > l);
+    }
+    const unsigned long long mask = __ballot(flag);
+    if (lane == 0) masks[it * 4 + wave] = mask;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int e = 0; e < KB_IT * 4; ++e) { offs[e] = run; run += __popcll(masks[e]); }
+    base_s = run > 0 ? atomicAdd(n_flag, run) : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x < KB_IT * 4) {
+    const int e = threadIdx.x, it = e >> 2, w = e & 3;
+    unsigned long long mk = masks[e];
+    int slot = base_s + offs[e];
+    while (mk) {
+      const int ln = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      flagged[slot++] = (int)(row0 + it * 32 + w * 8 + (ln >> 3));
+    }
+  }
 }
 
 struct XorShift {
@@ -434,9 +521,11 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(mln_dmalloc((void**)&prep, sizeof(double) * ROWMIN_PREP_DOUBLES));
     if (rc == MLN_OK) rc = rowmin_prepare(ctx, dx, n, nullptr, 0, d, prep);
   }
+  double* xxs = nullptr;           // squared norms of the centred, scaled cells (the error bound of the fp16 sweep needs them)
+  if (prep && rc == MLN_OK) chk(mln_dmalloc((void**)&xxs, sizeof(double) * (size_t)n));
   if (seed_h && rc == MLN_OK) {
     chk(mln_dmalloc(&xsplit, rowmin_split_bytes(n)));
-    if (rc == MLN_OK) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, 1, prep);   // role 1: -2 x (also the Lloyd sweeps' operand)
+    if (rc == MLN_OK) rc = launch_split_f16(ctx, dx, n, d, xsplit, xxs, nullptr, 1, prep);   // role 1: -2 x (also the Lloyd sweeps' operand)
   }
   if (rc == MLN_OK && seeded) chk(hipMemcpyAsync(dc, dx + cur * d, sizeof(double) * d, hipMemcpyDeviceToDevice, st));
   if (rc == MLN_OK && !seeded) chk(hipMemcpyAsync(dc, init, sizeof(double) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
@@ -489,8 +578,64 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(mln_dmalloc(&csplit, rowmin_split_bytes(m)));
     chk(mln_dmalloc((void**)&ccf, sizeof(float) * (size_t)m));
     chk(mln_dmalloc((void**)&m1f, sizeof(float) * (size_t)n));
-    if (rc == MLN_OK && !have) rc = launch_split_f16(ctx, dx, n, d, xsplit, nullptr, nullptr, km_fold ? 1 : 0, prep);
+    if (rc == MLN_OK && !have) rc = launch_split_f16(ctx, dx, n, d, xsplit, xxs, nullptr, km_fold ? 1 : 0, prep);
   }
+  // With the folded fp16 sweep available the iterations carry distance bounds (see k_km_bounds): sweep 0 searches every
+  // cell, later sweeps only the cells whose bounds no longer decide; the sums of the clusters follow the cells that moved.
+  const bool km_bounds = fast_assign && km_fold && xxs && !(mln_experiment("MELLON_AMD_KM_BOUNDS") && std::atoi(mln_experiment("MELLON_AMD_KM_BOUNDS")) == 0);
+  double *ub = nullptr, *lb = nullptr, *delta = nullptr, *dstat = nullptr, *yy = nullptr, *ymax = nullptr;
+  float* m2f = nullptr;
+  int *argc = nullptr, *nflag = nullptr, *flagged = nullptr;
+  if (km_bounds && rc == MLN_OK) {
+    chk(mln_dmalloc((void**)&ub, sizeof(double) * (size_t)n));
+    chk(mln_dmalloc((void**)&lb, sizeof(double) * (size_t)n));
+    chk(mln_dmalloc((void**)&delta, sizeof(double) * (size_t)m));
+    chk(mln_dmalloc((void**)&dstat, sizeof(double) * 4));
+    chk(mln_dmalloc((void**)&yy, sizeof(double) * (size_t)m));
+    chk(mln_dmalloc((void**)&ymax, sizeof(double)));
+    chk(mln_dmalloc((void**)&m2f, sizeof(float) * (size_t)n));
+    chk(mln_dmalloc((void**)&argc, sizeof(int) * (size_t)n));
+    chk(mln_dmalloc((void**)&nflag, sizeof(int)));
+    chk(mln_dmalloc((void**)&flagged, sizeof(int) * (size_t)n));
+  }
+  int64_t searched_rows = 0;
+  if (km_bounds && rc == MLN_OK) {
+    int64_t F = n;            // rows to search this sweep
+    for (; it < max_iter && rc == MLN_OK; ++it) {
+      rc = launch_split_f16(ctx, dc, m, d, csplit, yy, ccf, 2, prep);
+      if (rc == MLN_OK) rc = launch_max_norm(ctx, yy, m, ymax);
+      if (rc != MLN_OK) break;
+      const bool all = F >= n;
+      if (F > 0) {
+        rc = launch_rowmin_f16x3(ctx, xsplit, all ? n : F, csplit, m, ccf, 0, 0, m1f, m2f, argc, 1, all ? nullptr : flagged);
+        if (rc == MLN_OK) rc = launch_km_resolve(ctx, dx, all ? n : F, all ? nullptr : flagged, dc, m, d, xxs, ymax, prep, m2f, argc,
+                                                 label, ub, lb, it == 0 ? nullptr : sums, it == 0 ? nullptr : counts);
+        if (rc != MLN_OK) break;
+        searched_rows += all ? n : F;
+      }
+      if (it == 0) {
+        chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
+        chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts);
+      }
+      chk(hipMemsetAsync(shift, 0, sizeof(double), st));
+      chk(hipMemsetAsync(nflag, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, shift, delta);
+      hipLaunchKernelGGL(k_km_delta_stats, dim3(1), dim3(256), 0, st, delta, m, dstat);
+      hipLaunchKernelGGL(k_km_bounds, dim3((unsigned)((n + KB_ROWS - 1) / KB_ROWS)), dim3(256), 0, st, dx, n, d, dc, label, ub, lb, delta, dstat,
+                         nflag, flagged);
+      double hs = 0.0;
+      int hf = 0;
+      chk(hipMemcpyAsync(&hs, shift, sizeof(double), hipMemcpyDeviceToHost, st));
+      chk(hipMemcpyAsync(&hf, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+      chk(hipStreamSynchronize(st));
+      F = hf;
+      if (hs <= scaled_tol) { ++it; break; }
+    }
+    if (mln_experiment("MELLON_AMD_KM_VERBOSE"))
+      std::fprintf(stderr, "[kmeans] n=%lld m=%lld sweeps=%d rows searched=%lld (%.2f full sweeps)\n", (long long)n, (long long)m, it,
+                   (long long)searched_rows, (double)searched_rows / (double)n);
+  } else
   for (; it < max_iter && rc == MLN_OK; ++it) {
     hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);
     if (fast_assign) {
@@ -505,7 +650,7 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
     chk(hipMemsetAsync(shift, 0, sizeof(double), st));
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts);
-    hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, shift);
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, shift, (double*)nullptr);
     double hs = 0.0;
     chk(hipMemcpyAsync(&hs, shift, sizeof(double), hipMemcpyDeviceToHost, st));
     chk(hipStreamSynchronize(st));
@@ -531,7 +676,8 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   }
   if (n_iter_out) *n_iter_out = it;
   (void)hipStreamSynchronize(st);
-  void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f, prep};
+  void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f, prep, xxs, ub, lb, delta, dstat, yy, ymax,
+                  m2f, argc, nflag, flagged};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (own_x) (void)mln_dfree(dx);
   return rc;

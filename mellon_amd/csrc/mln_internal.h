@@ -62,6 +62,8 @@ int launch_symmetrize_from_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda
 // partial results `part_stride` doubles apart, to be summed by the caller); K holds values in [0, 1], row pitch ldk
 // tridiag.hip: A (m x m symmetric, full storage, destroyed) -> number of eigenvalues above tol2 * lambda_max
 int dev_sym_rank_above(mln_ctx* ctx, double* A, int64_t m, int64_t ld, double tol2, int64_t* rank, double* lambda_max);
+// ldl_inertia.hip: the same count from the inertia of A - x I (A destroyed); *ok = false: not certified, use the above
+int dev_sym_rank_above_ldl(mln_ctx* ctx, double* A, int64_t m, int64_t ld, double tol2, int64_t* rank, double* lambda_max, bool* ok);
 int gram_i8_splits(int64_t rows, int64_t m);
 int launch_gram_i8(mln_ctx* ctx, const double* K, int64_t ldk, int64_t rows, int64_t m, double alpha, double* parts,
                    int64_t ldg, int64_t part_stride, int n_splits);

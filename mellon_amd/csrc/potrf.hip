@@ -46,11 +46,17 @@ __device__ __forceinline__ double frag(const double* M, int ldm, int r0, int c0,
   return M[(r0 + (lane & 15)) * ldm + c0 + 4 * s + (lane >> 4)];
 }
 
+// SIGNED (the inertia count of ldl_inertia.hip): the block is factored as T S T^T with S = diag(+-1) -- a pivot may be
+// negative, T_kk = sqrt|d_k|, s_k = sign d_k; a zero or NaN pivot is the failure.  Also written then: DinvS = S T^-1 (so that
+// the caller's panel GEMM against it yields L = A_panel T^-T S), the number of negative pivots and the smallest |pivot|.
+template <bool SIGNED>
 __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb, double* __restrict__ Dinv,
-                                                  int* info, int64_t j0) {
+                                                  int* info, int64_t j0, double* __restrict__ DinvS, int* n_neg,
+                                                  unsigned long long* min_piv) {
   extern __shared__ double smem[];
   double* T = smem;                        // NB x LDT
   double* Xd = smem + NB * LDT;            // NMB x MB x LDX: inverses of the 16 x 16 diagonal tiles
+  double* Sg = Xd + NMB * MB * LDX;        // NB signs (SIGNED only)
   __shared__ int bad_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   TS(0);
@@ -106,14 +112,22 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
     // (tried: X by row operations on [L | I] -- k + 1 independent FMAs per pivot instead of the substitution's dependent
     //  chain, but divergent over lanes and 270 more LDS operations: 14 500 instead of 9 100 cycles per tile)
     double dk = bcast_lane(a[0], 0);
+    double sg = 1.0;                                     // sign of the pivot (SIGNED; wave-uniform)
+    double minabs = INFINITY;
+    if (SIGNED) { sg = (dk < 0.0) ? -1.0 : 1.0; dk = fabs(dk); }
     double inv = __builtin_amdgcn_rsq(dk);
     inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
     if (NEWTON2) inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
 #pragma unroll
     for (int k = 0; k < MB; ++k) {
       badk = (!(dk > 0.0) && badk < 0) ? k : badk;        // (reported after the loop: no branch inside the recurrence)
+      if (SIGNED) {
+        minabs = fmin(minabs, (c0 + k < nb) ? dk : INFINITY);      // (identity padding past nb does not count)
+        if (lane == 0) Sg[c0 + k] = sg;
+      }
       const double sq = dk * inv;                        // sqrt(dk) to ~1 ulp
-      const double lik = (li == k) ? sq : ((li > k) ? a[k] * inv : 0.0);
+      const double lsg = SIGNED ? inv * sg : inv;
+      const double lik = (li == k) ? sq : ((li > k) ? a[k] * lsg : 0.0);
       a[k] = lik;
       if (lane < MB && li >= k) Tt[li * LDT + k] = lik;  // column k of L, final (same wave: later reads see it)
       double lcol[MB];
@@ -132,18 +146,27 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
       x[k] = ((s0 + s1) + (s2 + s3)) * inv;
       // (pinning x[k] here with an empty asm, so that the substitution runs under column k's LDS round trip instead of
       //  after the loop, made every pivot slower by more than the tail it removed: 10 300 instead of 9 250 cycles per tile)
-      double dk1 = 1.0, inv1 = 1.0;
+      const double nlik = SIGNED ? -lik * sg : -lik;     // update coefficient: a_j -= L_ik s_k L_jk
+      double dk1 = 1.0, inv1 = 1.0, sg1 = 1.0;
       if (k + 1 < MB) {
-        dk1 = bcast_lane(fma(-lik, lik, a[k + 1]), k + 1);
+        dk1 = bcast_lane(fma(nlik, lik, a[k + 1]), k + 1);
+        if (SIGNED) { sg1 = (dk1 < 0.0) ? -1.0 : 1.0; dk1 = fabs(dk1); }
         inv1 = __builtin_amdgcn_rsq(dk1);
         inv1 = inv1 * fma(-0.5 * dk1, inv1 * inv1, 1.5);
         if (NEWTON2) inv1 = inv1 * fma(-0.5 * dk1, inv1 * inv1, 1.5);
       }
 #pragma unroll
-      for (int j = k + 1; j < MB; ++j) a[j] = fma(-lik, lcol[j], a[j]);
-      dk = dk1; inv = inv1;
+      for (int j = k + 1; j < MB; ++j) a[j] = fma(nlik, lcol[j], a[j]);
+      dk = dk1; inv = inv1; sg = sg1;
     }
     if (badk >= 0 && lane == 0) { atomicCAS(info, 0, (int)(j0 + c0 + badk + 1)); bad_s = 1; }   // first non-positive / NaN pivot
+    if (SIGNED && lane == 0 && c0 < nb) {
+      // (tiles past nb are identity padding: their pivots are 1 and do not count; a partly padded tile counts its real rows)
+      int real_negs = 0;
+      for (int k = 0; k < MB; ++k) real_negs += (c0 + k < nb && Sg[c0 + k] < 0.0) ? 1 : 0;
+      if (real_negs) atomicAdd(n_neg, real_negs);
+      atomicMin(min_piv, (unsigned long long)__double_as_longlong(minabs));
+    }
     if (lane < MB) {
 #pragma unroll
       for (int j = 0; j < MB; ++j) {
@@ -164,7 +187,10 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
     for (int r = 0; r < 4; ++r) acc[r] = T[(r0 + (lane >> 4) + 4 * r) * LDT + q0 + (lane & 15)];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag(T, LDT, r0, c0, s, lane), frag(T, LDT, q0, c0, s, lane), acc, 0, 0, 0);
+    {
+      const double sk = SIGNED ? -Sg[c0 + 4 * s + (lane >> 4)] : -1.0;          // A_ij -= L_ik s_k L_jk
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sk * frag(T, LDT, r0, c0, s, lane), frag(T, LDT, q0, c0, s, lane), acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) T[(r0 + (lane >> 4) + 4 * r) * LDT + q0 + (lane & 15)] = acc[r];
   };
@@ -184,8 +210,9 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(frag(T, LDT, r0, c0, s, lane), frag(Xd + p * MB * LDX, LDX, 0, 0, s, lane),
                                                    acc, 0, 0, 0);
       // the whole tile has been read into A operands before any lane stores (MFMA results depend on all loads)
+      const double sc = SIGNED ? Sg[c0 + (lane & 15)] : 1.0;                    // L_ip = A_ip X_pp^T S_p
 #pragma unroll
-      for (int r = 0; r < 4; ++r) T[(r0 + (lane >> 4) + 4 * r) * LDT + c0 + (lane & 15)] = acc[r];
+      for (int r = 0; r < 4; ++r) T[(r0 + (lane >> 4) + 4 * r) * LDT + c0 + (lane & 15)] = SIGNED ? sc * acc[r] : acc[r];
     }
     __syncthreads();
     TS(3 + 2 * p);
@@ -252,7 +279,10 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
     for (int i = 0; i < NMB; ++i) {
       if (i >= j) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Dinv[(i * MB + (lane >> 4) + 4 * r) * NB + j * MB + (lane & 15)] = X[i][r];
+        for (int r = 0; r < 4; ++r) {
+          Dinv[(i * MB + (lane >> 4) + 4 * r) * NB + j * MB + (lane & 15)] = X[i][r];
+          if (SIGNED) DinvS[(i * MB + (lane >> 4) + 4 * r) * NB + j * MB + (lane & 15)] = Sg[i * MB + (lane >> 4) + 4 * r] * X[i][r];
+        }
       }
     }
   }
@@ -264,13 +294,29 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
 // Factorises the nb x nb (nb <= 128) lower block at A in place and writes T^-1 to Dinv (128 x 128, row-major, leading
 // dimension 128; entries above the diagonal are never written: the caller zeroes the buffer once).
 int launch_potrf128(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, int* info, int64_t j0) {
-  const size_t lds = sizeof(double) * (size_t)(NB * LDT + NMB * MB * LDX);
+  const size_t lds = sizeof(double) * (size_t)(NB * LDT + NMB * MB * LDX + NB);
   static bool configured = false;
   if (!configured) {
-    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  hipLaunchKernelGGL(k_potrf128, dim3(1), dim3(256), lds, ctx->stream, A, lda, nb, Dinv, info, j0);
+  hipLaunchKernelGGL(k_potrf128<false>, dim3(1), dim3(256), lds, ctx->stream, A, lda, nb, Dinv, info, j0, (double*)nullptr,
+                     (int*)nullptr, (unsigned long long*)nullptr);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+// The signed variant (see the kernel): A = T S T^T on the nb x nb block; DinvS = S T^-1; *n_neg += negative pivots;
+// *min_piv = min(*min_piv, bits of the smallest |pivot|).
+int launch_potrf128_signed(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, double* DinvS, int* info, int64_t j0,
+                           int* n_neg, unsigned long long* min_piv) {
+  const size_t lds = sizeof(double) * (size_t)(NB * LDT + NMB * MB * LDX + NB);
+  static bool configured = false;
+  if (!configured) {
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL(k_potrf128<true>, dim3(1), dim3(256), lds, ctx->stream, A, lda, nb, Dinv, info, j0, DinvS, n_neg, min_piv);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

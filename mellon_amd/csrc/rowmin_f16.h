@@ -17,8 +17,14 @@ int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* spli
 // fold: operands split with roles 1 / 2; arg is then the first of four candidates arg + {0, 32, 64, 96} (launch_resolve_labels
 // picks the closest in fp64)
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
-                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold);
+                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold,
+                        const int* row_idx = nullptr);   // row_idx (optional, device): query row r is row row_idx[r] of xs
 int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg);
+// k-means with bounds: label, upper and lower bound of the searched rows from a (TOP2, fold) sweep's m2 / arg (see the kernel)
+int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,
+                      const double* xxs, const double* yy_max, const double* prep, const float* m2, const int* arg,
+                      int* label, double* ub, double* lb, double* sums, double* counts);
+int launch_max_norm(mln_ctx* ctx, const double* xx, int64_t n, double* out);   // out[0] = max xx (one workgroup)
 // exact nearest-neighbour distances via the pre-filter + fp64 certification (+ exact re-search of uncertified rows)
 int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
                              int64_t self_offset, double* out, double* stats);

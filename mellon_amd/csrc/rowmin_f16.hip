@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
                                                       const _Float16* __restrict__ Ys, int64_t m,
                                                       const float* __restrict__ yyf, int64_t self_offset, int exclude_self,
                                                       float* __restrict__ out_m1, float* __restrict__ out_m2,
-                                                      int* __restrict__ out_arg) {
+                                                      int* __restrict__ out_arg, const int* __restrict__ row_idx) {
   extern __shared__ unsigned char lds[];                      // 2 x (RT x PITCH) candidate rows + 2 x RT norms
   float* ynl = reinterpret_cast<float*>(lds + 2 * RT * PITCH);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,7 +130,10 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
   // A operands: this wave's 32 rows, k = 16 ks + 8 lg + e
   h8 ahi[4], alo[4];
   {
-    const int64_t ar = (row0w + lr < n) ? row0w + lr : n - 1;
+    // row_idx (k-means with bounds: the rows whose bounds no longer decide): query row r of this launch is row
+    // row_idx[r] of Xs; the outputs stay in launch order
+    const int64_t ar0 = (row0w + lr < n) ? row0w + lr : n - 1;
+    const int64_t ar = row_idx ? (int64_t)row_idx[ar0] : ar0;
     const _Float16* src = Xs + ar * ROWH + 8 * lg;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -301,6 +304,15 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
   }
 }
 
+// Bound on |s~_j - s_j| for every candidate j of a row with |x| = xn (centred, scaled units) when max_j |y_j| = yn: see the
+// comment in k_nn_certify.
+__device__ __forceinline__ double rowmin_value_bound(double xn, double yn) {
+  const double u = 5.9604644775390625e-08;   // 2^-24
+  const double mag = 2.0 * xn * yn + yn * yn;
+  return 1.25 * (1.9073486328125e-06 * 2.0 * xn * yn + 80.0 * u * mag + 160.0 * u * 9.765625e-04 * mag +
+                 4.0 * u * mag + 64.0 * u * 2.0 * (2.0 * xn + yn) + 1e-300);
+}
+
 // Exact fp64 value of the winner, certification against the runner-up, list of the rows that need the exact search.
 //   s_j = |y_j|^2 - 2 x.y_j (exact);  |s~_j - s_j| <= E_i for every j  =>  j* != arg implies s_{j*} >= m2~ - E_i.
 // fold: the winner is one of arg + {0, 32, 64, 96} (k_rowmin_f16x3 FOLD): all four are evaluated exactly.
@@ -330,10 +342,7 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
   // fp32.  Dropped terms of the split: 2^-19 of 2 |x| |y|; fp32 accumulation: <= 17 roundings per MFMA x 4 MFMAs + slack
   // = 80 u on the magnitudes of the hi.hi terms (2 |x| |y| + |y|^2), 160 u on the 2^-10 smaller cross terms; |y|^2 in
   // fp32 (plain) or as three halves (fold); half-precision subnormals of tiny coordinates (2^-24 each, 64 of them).
-  const double u = 5.9604644775390625e-08;   // 2^-24
-  const double mag = 2.0 * xn * yn + yn * yn;
-  const double E = 1.25 * (1.9073486328125e-06 * 2.0 * xn * yn + 80.0 * u * mag + 160.0 * u * 9.765625e-04 * mag +
-                           4.0 * u * mag + 64.0 * u * 2.0 * (2.0 * xn + yn) + 1e-300);
+  const double E = rowmin_value_bound(xn, yn);
   const bool certified = ((double)m2[i] - E) > s;
   // reported: the winner's distance from its coordinates (sum (x_k - y_k)^2), not from the cancelling |x|^2 - 2 x.y + |y|^2:
   // exact 0 for a duplicated cell, relative error ~eps otherwise (see nn_direct_distance in cov_kernels.hip)
@@ -368,6 +377,60 @@ __global__ __launch_bounds__(256) void k_resolve_labels(const double* __restrict
     if (sv < best) { best = sv; bj = (int)j; }
   }
   arg[i] = bj;
+}
+
+// k-means with distance bounds (kmeans.hip): one searched row -> its label and the two bounds.
+//   the sweep (TOP2, FOLD) returned arg (the winner is one of arg + {0, 32, 64, 96}) and m2~, the second smallest approximate
+//   value; every candidate other than the owner of the smallest has s~_j >= m2~, hence s_j >= m2~ - E.  The four are
+//   evaluated exactly, sum (x_k - c_k)^2 in fp64: label = the closest of them, ub = its distance, and
+//   lb^2 = min(second closest of the four, (|x'|^2 + m2~ - E) / scale^2) bounds the distance to EVERY other centre.
+//   (The label need not be the true nearest centre when two are within E of each other; then ub > lb and the row is
+//   simply searched again next sweep.)
+// rows: r < cnt, i = idx ? idx[r] : r.  sums / counts (optional): the row moves from its old label to the new one.
+__global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x, int64_t cnt, const int* __restrict__ idx,
+                                                    const double* __restrict__ c, int64_t m, int d,
+                                                    const double* __restrict__ xxs, const double* __restrict__ yy_max,
+                                                    const double* __restrict__ prep, const float* __restrict__ m2,
+                                                    const int* __restrict__ arg, int* __restrict__ label,
+                                                    double* __restrict__ ub, double* __restrict__ lb,
+                                                    double* __restrict__ sums, double* __restrict__ counts) {
+  // eight lanes per row, every eighth coordinate each (coalesced over the 8 rows of a wave's load)
+  const int sub = threadIdx.x & 7;
+  const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (r >= cnt) return;                       // (whole groups of eight leave together: the shuffles below stay inside a group)
+  const int64_t i = idx ? (int64_t)idx[r] : r;
+  const double* xr = x + i * d;
+  double best = INFINITY, second = INFINITY;
+  int bj = arg[r];
+  for (int q = 0; q < 4; ++q) {
+    const int64_t j = (int64_t)arg[r] + 32 * q;
+    if (j >= m) continue;
+    const double* cr = c + j * d;
+    double dd = 0.0;
+    for (int k = sub; k < d; k += 8) { const double t = xr[k] - cr[k]; dd = fma(t, t, dd); }
+    dd += __shfl_xor(dd, 1, 64);
+    dd += __shfl_xor(dd, 2, 64);
+    dd += __shfl_xor(dd, 4, 64);
+    if (dd < best) { second = best; best = dd; bj = (int)j; }
+    else if (dd < second) second = dd;
+  }
+  const double sc = prep[64];
+  const double E = rowmin_value_bound(sqrt(xxs[i]), sqrt(yy_max[0]));
+  const double rest = fmax((xxs[i] + (double)m2[r] - E) / (sc * sc), 0.0);
+  const int old = label[i];
+  if (sub == 0) {
+    ub[i] = sqrt(best);
+    lb[i] = sqrt(fmin(second, rest));
+    label[i] = bj;
+  }
+  if (sums && old != bj) {
+    for (int k = sub; k < d; k += 8) {
+      const double v = xr[k];
+      atomicAdd(&sums[(int64_t)old * d + k], -v);
+      atomicAdd(&sums[(int64_t)bj * d + k], v);
+    }
+    if (sub == 0) { atomicAdd(&counts[old], -1.0); atomicAdd(&counts[bj], 1.0); }
+  }
 }
 
 __global__ void k_gather_rows_excl(const double* __restrict__ x, int d, const int* __restrict__ idx, int cnt,
@@ -424,7 +487,7 @@ int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* spli
 }
 
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
-                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold) {
+                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold, const int* row_idx) {
   if (n <= 0 || m <= 0) return MLN_OK;
   if (m > 2147483647LL) { mln_set_error(ctx, "rowmin: too many candidates"); return MLN_ERR_UNSUPPORTED; }
   const size_t lds_bytes = (size_t)2 * RT * PITCH + 2 * RT * sizeof(float);
@@ -438,10 +501,10 @@ int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys,
   const dim3 grid((unsigned)((n + 255) / 256)), block(512);
   const _Float16* X = reinterpret_cast<const _Float16*>(xs);
   const _Float16* Y = reinterpret_cast<const _Float16*>(ys);
-  if (m2 && fold) hipLaunchKernelGGL((k_rowmin_f16x3<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg);
-  else if (m2) hipLaunchKernelGGL((k_rowmin_f16x3<true, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg);
-  else if (fold) hipLaunchKernelGGL((k_rowmin_f16x3<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg);
-  else hipLaunchKernelGGL((k_rowmin_f16x3<false, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg);
+  if (m2 && fold) hipLaunchKernelGGL((k_rowmin_f16x3<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
+  else if (m2) hipLaunchKernelGGL((k_rowmin_f16x3<true, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
+  else if (fold) hipLaunchKernelGGL((k_rowmin_f16x3<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
+  else hipLaunchKernelGGL((k_rowmin_f16x3<false, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -449,6 +512,22 @@ int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys,
 int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg) {
   if (n <= 0) return MLN_OK;
   hipLaunchKernelGGL(k_resolve_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, yy, arg);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,
+                      const double* xxs, const double* yy_max, const double* prep, const float* m2, const int* arg,
+                      int* label, double* ub, double* lb, double* sums, double* counts) {
+  if (cnt <= 0) return MLN_OK;
+  hipLaunchKernelGGL(k_km_resolve, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, ctx->stream, x, cnt, idx, c, m, d, xxs,
+                     yy_max, prep, m2, arg, label, ub, lb, sums, counts);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+int launch_max_norm(mln_ctx* ctx, const double* xx, int64_t n, double* out) {
+  hipLaunchKernelGGL(k_max_norm, dim3(1), dim3(256), 0, ctx->stream, xx, n, out);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -491,7 +570,7 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
   if (rc != MLN_OK) return cleanup(rc);
   hipLaunchKernelGGL(k_max_norm, dim3(1), dim3(256), 0, ctx->stream, yy, m, ymax);
   if (hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
-  rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold);
+  rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr);
   if (rc != MLN_OK) return cleanup(rc);
   hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
                      ymax, fold, self_offset, prep, out, nflag, flagged);

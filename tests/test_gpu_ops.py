@@ -724,5 +724,36 @@ def test_rank_count_by_sturm_sequences(ctx, m):
             rank, smax = fit.gram_rank(tol)
             assert rank == int(np.count_nonzero(ev > tol * ev.max())) == np.linalg.matrix_rank(L, rtol=tol), (m, tol)
             assert abs(smax - s.max()) < 1e-9 * s.max()
+            assert fit.stage_times()["rank_path"] == 1          # counted by inertia (csrc/ldl_inertia.hip)
     finally:
         fit.close()
+
+
+@pytest.mark.parametrize("m", [130, 700])
+def test_rank_count_paths_agree(ctx, m, monkeypatch):
+    """The count from the inertia of G - x I (signed block factorisation, no pivoting, guarded by its smallest pivot) and the
+    count from the tridiagonalised Gram are the same number, also for a Gram with negative entries, a threshold inside a
+    cluster of eigenvalues' gap, and a rank-one Gram (the shape the kernel matrices of a fit have)."""
+    from mellon_amd import _lib
+    rng = np.random.default_rng(7 + m)
+    n = 3 * m
+    cases = [rng.normal(size=(n, m)) @ np.diag(10.0 ** rng.uniform(-4, 0, size=m)),
+             np.outer(rng.uniform(1, 2, size=n), rng.uniform(1, 2, size=m)) + 1e-3 * rng.normal(size=(n, m)),
+             np.abs(rng.normal(size=(n, m))) + 0.5]
+    for L in cases:
+        fit = _lib.Fit.from_L(ctx, np.ascontiguousarray(L))
+        try:
+            for tol in (0.5, 0.1, 1e-2):
+                sv = np.linalg.svd(L, compute_uv=False)
+                if np.any(np.abs(sv / sv.max() - tol) < 0.01 * tol):
+                    continue
+                r1, s1 = fit.gram_rank(tol)
+                assert fit.stage_times()["rank_path"] == 1
+                monkeypatch.setenv("MELLON_AMD_RANK_LDL", "0")
+                r2, s2 = fit.gram_rank(tol)
+                monkeypatch.delenv("MELLON_AMD_RANK_LDL")
+                assert fit.stage_times()["rank_path"] == 2
+                assert r1 == r2 == np.linalg.matrix_rank(L, rtol=tol), (m, tol)
+                assert abs(s1 - sv.max()) < 1e-9 * sv.max() and abs(s2 - s1) < 1e-9 * s1
+        finally:
+            fit.close()

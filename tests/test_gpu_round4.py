@@ -176,6 +176,30 @@ def test_kmeans_coarse_to_fine(ctx, monkeypatch):
     assert np.abs(c2b - c2).max() < 1e-9 * np.abs(c2).max()
 
 
+def test_kmeans_distance_bounds(ctx, monkeypatch):
+    """Lloyd's sweeps with Hamerly's distance bounds skip the cells whose assignment cannot have changed: the same
+    algorithm, so the sweeps, the inertia and the centres are those of the plain sweeps (up to cells that sit within the
+    fp16 pre-filter's error of two centres, which the plain sweep may give to either), and every centre is the mean of its
+    cells although the sums only follow the cells that move."""
+    x = mo.gaussian_mixture(260_000, 12, seed=5)
+    m = 400
+    monkeypatch.setenv("MELLON_AMD_KM_LEVELS", "1")          # one level: the bounds are the only difference
+    cb, itb, inb = ctx.kmeans(x, m, seed=11, return_info=True)
+    monkeypatch.setenv("MELLON_AMD_KM_BOUNDS", "0")
+    cp, itp, inp = ctx.kmeans(x, m, seed=11, return_info=True)
+    monkeypatch.delenv("MELLON_AMD_KM_BOUNDS")
+    assert abs(inb / inp - 1) < 2e-3, (inb, inp)
+    assert abs(itb - itp) <= max(5, itp // 5), (itb, itp)
+    lab = np.argmin(mo.distance(x, cb), axis=1)
+    means = np.stack([x[lab == j].mean(axis=0) if np.any(lab == j) else cb[j] for j in range(m)])
+    # one more Lloyd step from the returned centres moves them by no more than the stopping tolerance allows
+    assert np.sum((means - cb) ** 2) <= 4 * 1e-4 * x.var(axis=0).mean()
+    # two levels (the default at this size) with bounds on both
+    monkeypatch.delenv("MELLON_AMD_KM_LEVELS")
+    c2, it2, in2 = ctx.kmeans(x, m, seed=11, return_info=True)
+    assert in2 < 1.01 * inp
+
+
 def test_tree_data_sharded_at_scale(mellon, ctx, monkeypatch):
     """The guards of the rebuild (decline / trial / revert) decide from all-reduced numbers and the replicated solver state:
     1e6 tree-shaped cells on 2 thread-ranks reach the unsharded fit's optimum and report the same decisions."""
