@@ -21,6 +21,7 @@
 
 #include "mln_internal.h"
 #include "rowmin_f16.h"
+#include "mln_options.h"
 
 namespace {
 
@@ -321,7 +322,8 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
                                                     const float* __restrict__ m2, const int* __restrict__ arg,
                                                     const double* __restrict__ yy_max, int fold, int64_t self_offset,
                                                     const double* __restrict__ prep,
-                                                    double* __restrict__ out, int* __restrict__ n_flag, int* __restrict__ flagged) {
+                                                    double* __restrict__ out, int* __restrict__ n_flag, int* __restrict__ flagged,
+                                                    float* __restrict__ fthr, double* __restrict__ fdd) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   // everything the sweep saw is (x - centre) * scale: xx, yy, m2 and the bound E live in those units; the winner's value
@@ -358,7 +360,141 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
   if (!certified) {
     const int slot = atomicAdd(n_flag, 1);
     flagged[slot] = (int)i;
+    // for the candidate list of k_rowmin_list: a candidate that beats the winner has s_j <= s, hence s~_j <= s + E; the
+    // threshold is that, rounded UP to fp32 (two ulps of slack), and the winner's squared distance goes along
+    if (fthr) {
+      float t = (float)(s + E);
+      t = nextafterf(nextafterf(t, INFINITY), INFINITY);
+      fthr[slot] = (js >= 0) ? t : INFINITY;
+      fdd[slot] = dd;
+    }
   }
+}
+
+// Second sweep over the rows the certification left open (row_idx, cnt of them): instead of the smallest two values, every
+// candidate whose approximate value lies below the row's threshold -- the only ones that can be nearer than the winner --
+// is appended to a list of (row slot, candidate) pairs; k_nn_list_eval then takes the exact minimum over each row's pairs.
+// The fp64 search over ALL candidates that used to resolve these rows (5 % of them at C3: 112 ms of a 0.5 s search) becomes
+// a second fp16 sweep over 5 % of the rows plus a few exact distances per row.  FOLD operands only (d <= 61).
+__global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict__ Xs, int64_t cnt, const int* __restrict__ row_idx,
+                                                     const _Float16* __restrict__ Ys, int64_t m, const float* __restrict__ fthr,
+                                                     int* __restrict__ n_pairs, int cap, int* __restrict__ pair_row,
+                                                     int* __restrict__ pair_col) {
+  extern __shared__ unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lg = lane >> 5;
+  const int64_t row0w = (int64_t)blockIdx.x * 256 + wave * 32;
+  h8 ahi[4], alo[4];
+  {
+    const int64_t ar0 = (row0w + lr < cnt) ? row0w + lr : cnt - 1;
+    const _Float16* src = Xs + (int64_t)row_idx[ar0] * ROWH + 8 * lg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ahi[ks] = *reinterpret_cast<const h8*>(src + 16 * ks);
+      alo[ks] = *reinterpret_cast<const h8*>(src + KP + 16 * ks);
+    }
+  }
+  float thr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = row0w + (r & 3) + 8 * (r >> 2) + 4 * lg;
+    thr[r] = (row < cnt) ? fthr[row] : -INFINITY;
+  }
+  v4i st[4];
+  auto g_load = [&](int64_t col0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = tid + 512 * q, r = piece >> 4, seg = piece & 15;
+      const int64_t c = col0 + r;
+      st[q] = (c < m) ? *reinterpret_cast<const v4i*>(Ys + c * ROWH + seg * 8) : v4i{0, 0, 0, 0};
+    }
+  };
+  auto l_store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int piece = tid + 512 * q, r = piece >> 4, seg = piece & 15;
+      *reinterpret_cast<v4i*>(lds + buf * (RT * PITCH) + r * PITCH + seg * 16) = st[q];
+    }
+  };
+  g_load(0);
+  l_store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t col0 = 0; col0 < m; col0 += RT, buf ^= 1) {
+    const bool more = col0 + RT < m;
+    if (more) g_load(col0 + RT);
+    const unsigned char* base = lds + buf * (RT * PITCH);
+#pragma unroll
+    for (int sp = 0; sp < RT / 64; ++sp) {
+      f16v acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+      const unsigned char* brow0 = base + (sp * 64 + lr) * PITCH + 16 * lg;
+      const unsigned char* brow1 = brow0 + 32 * PITCH;
+      h8 bhi0[4], bhi1[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {          // (the same order of products as k_rowmin_f16x3: the same values)
+        bhi0[ks] = *reinterpret_cast<const h8*>(brow0 + 32 * ks);
+        bhi1[ks] = *reinterpret_cast<const h8*>(brow1 + 32 * ks);
+        const h8 blo0 = *reinterpret_cast<const h8*>(brow0 + 2 * KP + 32 * ks);
+        const h8 blo1 = *reinterpret_cast<const h8*>(brow1 + 2 * KP + 32 * ks);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo1, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi0[ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi1[ks], acc[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi0[ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi1[ks], acc[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t col = col0 + (2 * sp + h) * 32 + lr;
+        // one comparison per element; the append is the rare path
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) any = any || (acc[h][r] < thr[r]);
+        if (any && col < m) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (acc[h][r] < thr[r]) {
+              const int slot = atomicAdd(n_pairs, 1);
+              if (slot < cap) { pair_row[slot] = (int)(row0w + (r & 3) + 8 * (r >> 2) + 4 * lg); pair_col[slot] = (int)col; }
+            }
+          }
+        }
+      }
+    }
+    if (more) l_store(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+// exact squared distance of every listed pair, minimum per row slot (non-negative doubles order like their bit patterns)
+__global__ __launch_bounds__(256) void k_nn_list_eval(const double* __restrict__ x, const double* __restrict__ y, int d,
+                                                      const int* __restrict__ flagged, const int* __restrict__ pair_row,
+                                                      const int* __restrict__ pair_col, int n_pairs, int64_t self_offset,
+                                                      unsigned long long* __restrict__ best) {
+  // (one thread per pair, the coordinates in order: the same sum the certification and the exact search report)
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int rs = pair_row[p];
+  const int64_t i = flagged[rs], j = pair_col[p];
+  if (j == i + self_offset) return;
+  const double* xr = x + i * d;
+  const double* yr = y + j * d;
+  double dd = 0.0;
+  for (int k = 0; k < d; ++k) { const double t = xr[k] - yr[k]; dd = fma(t, t, dd); }
+  atomicMin(&best[rs], (unsigned long long)__double_as_longlong(dd));
+}
+
+__global__ void k_nn_list_finish(const int* __restrict__ flagged, int cnt, const unsigned long long* __restrict__ best,
+                                 const double* __restrict__ fdd, double* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= cnt) return;
+  const double b = __longlong_as_double((long long)best[r]);
+  out[flagged[r]] = sqrt(fmin(b, fdd[r]));
 }
 
 // labels from the fold variant's stage-level args: the closest of the four candidates, in fp64
@@ -572,13 +708,54 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
   if (hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
   rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr);
   if (rc != MLN_OK) return cleanup(rc);
+  float* fthr = nullptr;
+  double* fdd = nullptr;
+  if (fold && (!alloc((void**)&fthr, sizeof(float) * n) || !alloc((void**)&fdd, sizeof(double) * n))) {
+    mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP);
+  }
   hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
-                     ymax, fold, self_offset, prep, out, nflag, flagged);
+                     ymax, fold, self_offset, prep, out, nflag, flagged, fthr, fdd);
   int cnt = 0;
   if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
   if (stats) stats[0] = (double)cnt;
-  if (cnt > 0) {
+  // The open rows: a second fp16 sweep that LISTS the candidates below each row's threshold, exact distances of the listed
+  // pairs.  A list that outgrows its buffer (masses of exact duplicates) falls through to the exact search below.
+  bool listed = false;
+  const bool list_ok = !(mln_experiment("MELLON_AMD_NN_LIST") && std::atoi(mln_experiment("MELLON_AMD_NN_LIST")) == 0);
+  if (cnt > 0 && fold && list_ok) {
+    const int cap = (int)std::min<int64_t>((int64_t)32 * cnt + 65536, (int64_t)1 << 28);
+    int *npairs = nullptr, *prow = nullptr, *pcol = nullptr;
+    unsigned long long* best = nullptr;
+    if (!alloc((void**)&npairs, sizeof(int)) || !alloc((void**)&prow, sizeof(int) * (size_t)cap) ||
+        !alloc((void**)&pcol, sizeof(int) * (size_t)cap) || !alloc((void**)&best, sizeof(unsigned long long) * (size_t)cnt)) {
+      mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP);
+    }
+    if (hipMemsetAsync(npairs, 0, sizeof(int), ctx->stream) != hipSuccess ||
+        hipMemsetAsync(best, 0x7f, sizeof(unsigned long long) * (size_t)cnt, ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+    const size_t lds_bytes = (size_t)2 * RT * PITCH;
+    static bool attr_l = false;
+    if (!attr_l) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_list), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return cleanup(MLN_ERR_HIP);
+      attr_l = true;
+    }
+    hipLaunchKernelGGL(k_rowmin_list, dim3((unsigned)((cnt + 255) / 256)), dim3(512), lds_bytes, ctx->stream,
+                       reinterpret_cast<const _Float16*>(xs), (int64_t)cnt, flagged, reinterpret_cast<const _Float16*>(ys), m, fthr,
+                       npairs, cap, prow, pcol);
+    int np = 0;
+    if (hipMemcpyAsync(&np, npairs, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn list", __FILE__, __LINE__));
+    if (stats) stats[1] = (double)np;
+    if (np <= cap) {
+      if (np > 0)
+        hipLaunchKernelGGL(k_nn_list_eval, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, x, y, d, flagged, prow, pcol, np,
+                           self_offset, best);
+      hipLaunchKernelGGL(k_nn_list_finish, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, flagged, cnt, best, fdd, out);
+      listed = true;
+    }
+  }
+  if (cnt > 0 && !listed) {
     // the uncertified rows: exact fp64 search, each with its own excluded candidate
     double *xg = nullptr, *og = nullptr;
     int64_t* excl = nullptr;

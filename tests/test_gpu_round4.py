@@ -200,6 +200,36 @@ def test_kmeans_distance_bounds(ctx, monkeypatch):
     assert in2 < 1.01 * inp
 
 
+def test_nn_open_rows_resolved_from_a_candidate_list(ctx, monkeypatch):
+    """Rows the fp64 certification leaves open (runner-up within the pre-filter's error of the winner) are resolved by a
+    second fp16 sweep that lists every candidate below the row's threshold and the exact distances of the listed pairs --
+    the distances of the exact fp64 re-search it replaces, and of a tree search; a list that outgrows its buffer
+    (a tight cluster of thousands of mutual near-ties) falls back to that re-search."""
+    rng = np.random.default_rng(21)
+    n, d = 60000, 50
+    x = mo.gaussian_mixture(n, d, seed=9)
+    x[1000:1400] = x[2000:2400] + 3e-4 * rng.normal(size=(400, d))      # near-ties: many open rows, a few candidates each
+    x[5000:5010] = x[5010:5020]                                          # exact duplicates
+    monkeypatch.setenv("MELLON_AMD_NN_PREFILTER_MIN", "1")
+    listed = ctx.nn_distances(x)
+    monkeypatch.setenv("MELLON_AMD_NN_LIST", "0")
+    exact = ctx.nn_distances(x)
+    monkeypatch.delenv("MELLON_AMD_NN_LIST")
+    want = mo.exact_nn_distances(x)
+    # (the exact re-search picks its winner from |x|^2 - 2 x.y + |y|^2 and reports that candidate's direct distance; the list
+    #  takes the minimum of the direct distances: candidates closer together than fp64 cancellation may swap)
+    nz = want > 0
+    assert np.abs(listed[nz] / exact[nz] - 1).max() < 1e-12 and np.array_equal(listed == 0, exact == 0)
+    assert np.abs(listed / np.maximum(want, 1e-300) - 1)[want > 0].max() < 1e-12 and np.all(listed[5000:5020] == 0)
+    # overflow of the list: 4000 cells within the error bound of each other
+    y = x.copy()
+    y[:4000] = 30.0 + 1e-4 * rng.normal(size=(4000, d))
+    got = ctx.nn_distances(y)
+    wanty = mo.exact_nn_distances(y)
+    tol2 = 64 * np.finfo(float).eps * np.linalg.norm(y, axis=1).max() ** 2
+    assert np.abs(got**2 - wanty**2).max() < tol2
+
+
 def test_tree_data_sharded_at_scale(mellon, ctx, monkeypatch):
     """The guards of the rebuild (decline / trial / revert) decide from all-reduced numbers and the replicated solver state:
     1e6 tree-shaped cells on 2 thread-ranks reach the unsharded fit's optimum and report the same decisions."""
