@@ -39,6 +39,29 @@ __device__ __forceinline__ double bcast_lane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Broadcast inside each 16-lane row: v_mov_b64_dpp row_newbcast:K (gfx90a+) -- lane K of every row to all 16 lanes of the
+// row, one instruction, no scalar registers, no LDS round trip.  The diagonal-tile recurrence keeps row i of the
+// tile on lane i of EVERY row (the four rows of the wave compute the same thing), so "the value lane K holds" is exactly
+// what a pivot step needs from the others.  k is a loop counter of fully unrolled loops: the switch folds away.
+template <int K> __device__ __forceinline__ double row_bcast_c(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, false);      // v_mov_b64_dpp (row_newbcast is the one 64-bit DPP control)
+}
+__device__ __forceinline__ double row_bcast(double v, int k) {
+  switch (k) {
+    case 0: return row_bcast_c<0>(v);   case 1: return row_bcast_c<1>(v);   case 2: return row_bcast_c<2>(v);
+    case 3: return row_bcast_c<3>(v);   case 4: return row_bcast_c<4>(v);   case 5: return row_bcast_c<5>(v);
+    case 6: return row_bcast_c<6>(v);   case 7: return row_bcast_c<7>(v);   case 8: return row_bcast_c<8>(v);
+    case 9: return row_bcast_c<9>(v);   case 10: return row_bcast_c<10>(v); case 11: return row_bcast_c<11>(v);
+    case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v);
+    default: return row_bcast_c<15>(v);
+  }
+}
+#ifdef MLN_POTRF_LDS_BCAST
+constexpr bool DPP_BCAST = false;      // (the round-3 form: broadcasts through LDS, 9 100 cycles per tile)
+#else
+constexpr bool DPP_BCAST = true;
+#endif
+
 // MFMA operand fetches from a row-major LDS matrix M (row stride ldm):
 //   A operand of slice s: A[row = lane & 15][k = 4 s + (lane >> 4)] = M[r0 + (lane & 15)][c0 + 4 s + (lane >> 4)]
 //   B operand of slice s holding M^T: B[k][col = lane & 15] = M[r0 + (lane & 15)][c0 + 4 s + (lane >> 4)]  -- same fetch
@@ -94,6 +117,79 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
 
   // (a) diagonal tile p: Cholesky in registers + inverse, by wave 0 alone (every 16-lane group computes the same thing)
   auto diag_tile = [&](int p) {
+    if (DPP_BCAST) {
+      // Round 4b: broadcasts by DPP row_newbcast instead of LDS.  Lane i of each 16-lane row holds row i of the tile in
+      // registers from start to end; what a pivot step needs from other lanes -- the pivot itself (lane k), column k of L
+      // (lane j's L_jk for the update of a_j) and row k of L (lane k's L_kj for the substitution of X = L^-1) -- are all
+      // "the value lane K holds": one v_mov_b64_dpp, where the LDS round trip cost ~130 cycles.  The tile
+      // and its inverse are written to LDS once, at the end.  Critical chain per pivot: L_{k+1,k} -> next pivot ->
+      // v_rsq_f64 + two Newton steps; everything else fills its shadow.
+      const int c0 = p * MB;
+      const int li = lane & 15;
+      double* Tt = T + c0 * LDT + c0;
+      double a[MB], x[MB];
+#pragma unroll
+      for (int j = 0; j < MB; ++j) a[j] = (j <= li) ? Tt[li * LDT + j] : 0.0;
+      int badk = -1;
+      double minabs = INFINITY;
+      double dk = row_bcast(a[0], 0);
+      double sg = 1.0;
+      if (SIGNED) { sg = (dk < 0.0) ? -1.0 : 1.0; dk = fabs(dk); }
+      double inv = __builtin_amdgcn_rsq(dk);
+      inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
+      if (NEWTON2) inv = inv * fma(-0.5 * dk, inv * inv, 1.5);
+#pragma unroll
+      for (int k = 0; k < MB; ++k) {
+        badk = (!(dk > 0.0) && badk < 0) ? k : badk;
+        if (SIGNED) {
+          minabs = fmin(minabs, (c0 + k < nb) ? dk : INFINITY);
+          if (lane == 0) Sg[c0 + k] = sg;
+        }
+        const double sq = dk * inv;
+        const double lsg = SIGNED ? inv * sg : inv;
+        const double lik = (li == k) ? sq : ((li > k) ? a[k] * lsg : 0.0);
+        a[k] = lik;
+        const double nlik = SIGNED ? -lik * sg : -lik;
+        double dk1 = 1.0, inv1 = 1.0, sg1 = 1.0;
+        if (k + 1 < MB) {                                   // the next pivot first: it heads the longest chain
+          a[k + 1] = fma(nlik, row_bcast(lik, k + 1), a[k + 1]);
+          dk1 = row_bcast(a[k + 1], k + 1);
+          if (SIGNED) { sg1 = (dk1 < 0.0) ? -1.0 : 1.0; dk1 = fabs(dk1); }
+          inv1 = __builtin_amdgcn_rsq(dk1);
+          inv1 = inv1 * fma(-0.5 * dk1, inv1 * inv1, 1.5);
+          if (NEWTON2) inv1 = inv1 * fma(-0.5 * dk1, inv1 * inv1, 1.5);
+        }
+#pragma unroll
+        for (int j = k + 2; j < MB; ++j) a[j] = fma(nlik, row_bcast(lik, j), a[j]);
+        // column li of X = L^-1: x_k = (delta_{k,li} - sum_{j<k} L_kj x_j) / L_kk, row k of L from lane k
+        double s0 = (k == li) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < k; ++j) {
+          const double lkj = row_bcast(a[j], k);
+          if ((j & 3) == 0) s0 = fma(-lkj, x[j], s0);
+          else if ((j & 3) == 1) s1 = fma(-lkj, x[j], s1);
+          else if ((j & 3) == 2) s2 = fma(-lkj, x[j], s2);
+          else s3 = fma(-lkj, x[j], s3);
+        }
+        x[k] = ((s0 + s1) + (s2 + s3)) * inv;
+        dk = dk1; inv = inv1; sg = sg1;
+      }
+      if (badk >= 0 && lane == 0) { atomicCAS(info, 0, (int)(j0 + c0 + badk + 1)); bad_s = 1; }
+      if (SIGNED && lane == 0 && c0 < nb) {
+        int real_negs = 0;
+        for (int k = 0; k < MB; ++k) real_negs += (c0 + k < nb && Sg[c0 + k] < 0.0) ? 1 : 0;
+        if (real_negs) atomicAdd(n_neg, real_negs);
+        atomicMin(min_piv, (unsigned long long)__double_as_longlong(minabs));
+      }
+      if (lane < MB) {
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+          Tt[li * LDT + j] = (j <= li) ? a[j] : 0.0;
+          Xd[(p * MB + j) * LDX + li] = x[j];    // X[j][li]
+        }
+      }
+      return;
+    }
     // Broadcasts go through LDS, not through v_readlane: with ~250 lane broadcasts per tile the scalar registers they
     // land in ran out (the compiler spilled 253 of them into VGPR lanes, 822 readlanes in all) and the tile took 11 000
     // cycles.  Here lane i writes L_ik into the tile the moment it is final, and everybody reads column k / row k back

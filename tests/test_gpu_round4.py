@@ -176,6 +176,26 @@ def test_kmeans_coarse_to_fine(ctx, monkeypatch):
     assert np.abs(c2b - c2).max() < 1e-9 * np.abs(c2).max()
 
 
+def test_first_fit_of_a_process_equals_the_later_ones(mellon):
+    """Whether the second preconditioner is built is decided from a cost MODEL of the build (csrc/api_solve.hip), not from the
+    stopwatch on the first one: a cold process (slow first build -> no rebuild -> another iteration path -> other last digits at
+    the default stopping rule) and a warm one take the same decisions.  Two fits of the same data are the same bits, with the
+    same evaluation count -- also when the library has just been handed a huge unrelated problem (allocator state)."""
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(300, 3)) @ np.array([[2.0, 0.0, 0.0], [1.0, 1.0, 0.0], [0.3, 0.2, 0.5]]).T
+    outs, evals = [], []
+    for rep in range(3):
+        est = mellon.DensityEstimator(n_landmarks=40)
+        outs.append(est.fit_predict(x))
+        evals.append(est.loss_func.n_eval)
+        est._fit.close()
+        if rep == 0:
+            big = mo.gaussian_mixture(30000, 10, seed=1)
+            mellon.DensityEstimator(n_landmarks=300).fit_predict(big)
+    assert evals[0] == evals[1] == evals[2], evals
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+
+
 def test_kmeans_distance_bounds(ctx, monkeypatch):
     """Lloyd's sweeps with Hamerly's distance bounds skip the cells whose assignment cannot have changed: the same
     algorithm, so the sweeps, the inertia and the centres are those of the plain sweeps (up to cells that sit within the
