@@ -437,7 +437,12 @@ int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int*
   const int64_t m = f->m, ldg = f->ldl;
   *outcome = 0;
   RebuildSelection sel{};
-  const double target = rows_per_m * (double)m;
+  double target = rows_per_m * (double)m;
+  // (tools/emulate_rank.py: one process stands for rank 0 of N and sees only its shard -- "global" sums are local there, and
+  //  the importance sample would come out N times this rank's real share: 30 000 rows instead of 3 750 at 8 ranks, a Gram
+  //  eight times too expensive.  The emulation asks for the share.)
+  if (ctx->n_ranks <= 1)
+    if (const char* ev = std::getenv("MELLON_AMD_EMULATE_RANKS")) { const int n_emu = std::atoi(ev); if (n_emu > 1) target /= (double)n_emu; }
   const bool tr_on = std::getenv("MELLON_AMD_TRACE") != nullptr;
   double tt[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int i, double& t0) { if (tr_on) { (void)hipStreamSynchronize(ctx->stream); const double t1 = now_s(); tt[i] += t1 - t0; t0 = t1; } };

@@ -325,8 +325,11 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // measurement of the first build, the same on every rank.  An evaluation = one pass of this rank's rows + ~0.14 ms of
   // small launches.  MELLON_AMD_REBUILD=0 / 1 forces the decision.
   const double pass_s = (double)f->n * (double)f->ldl * 8.0 / 6.5e12 + 1.4e-4;
-  // (emulated ranks of C3, tools/emulate_rank.py: the rebuild gains 9 ms per step at 4 ranks -- first build = 8.9 evaluations
-  //  -- and loses 2.5 ms at 8 -- 12.7 evaluations: the threshold sits between)
+  // (Emulated ranks of C3, tools/emulate_rank.py.  Until round 4 the emulation drew the WHOLE importance sample from rank 0's
+  //  shard -- 30 000 rows at 8 ranks where a real rank contributes 3 750 -- and so priced the rebuild at 15 ms there, a loss of
+  //  2.5 ms per step; with the rank's share it costs 10.9 ms and the step falls from 55.2 to 50.7 ms.  The solve without it
+  //  needs 29-33 full passes at C3, with it 14: the rebuild is worth ~15 passes, and the threshold is 13 of them -- on at
+  //  8 ranks (11.8 ms of passes against 10.9 ms of build), off from 16 ranks on (6.8 against 10.4).)
   // The price of a build comes from a MODEL of it, not from the stopwatch on the first one: a measured time made the
   // decision -- and with it the iteration path and the last digits of the result -- depend on whether the process was warm
   // (the first fit of a process: no rebuild, 11 evaluations; every later one: rebuild, 8 evaluations, log-density 2e-5 off
@@ -335,11 +338,12 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // whitening's 2 m^3 flops (column-split over >= 3 ranks) at 45 TFLOP/s -- 18.5 / 12.2 / 11.1 ms at C3 on 1 / 4 / 8 ranks
   // against the measured 18.7 / 13.6 / 10.9.
   const double md = (double)f->m;
-  const int n_ranks_r = ctx->n_ranks > 1 ? ctx->n_ranks : 1;
+  int split_rank_unused = 0; bool split_emulated = false;
+  const int n_ranks_r = split_ranks(ctx, &split_rank_unused, &split_emulated);     // (ranks the m x m work is split over: 1 below 3)
   const double gram_rows = (double)f->n / (double)(f->precond_stride > 0 ? f->precond_stride : 1);
   const double build_model_s = 2.5e-4 * std::ceil(md / 128.0) + gram_rows * md * md * 2.0 / 1.0e15 +
-                               2.0 * md * md * md / (n_ranks_r >= 3 ? (double)n_ranks_r : 1.0) / 45e12;
-  double want_rebuild = (f->build_seconds > 0.0 && 11.0 * pass_s > build_model_s) ? 1.0 : 0.0;
+                               2.0 * md * md * md / (double)n_ranks_r / 45e12;
+  double want_rebuild = (f->build_seconds > 0.0 && 13.0 * pass_s > build_model_s) ? 1.0 : 0.0;
   if (const char* ev = mln_experiment("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
   if (phase32 && !(f->l32_fixed)) want_rebuild = 0.0;   // (mixed solves pause at their fp64 anchor, which only the corrected fixed-point surrogate has)
   // The rebuild reads the rows' f of the last accepted pass (f_keep), which a rank only has while its shard fits the

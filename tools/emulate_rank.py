@@ -70,4 +70,26 @@ distributed.set_current(distributed.Communicator())
 one = out.get("1", {}).get("step_ms")
 for k, v in out.items():
     v["speedup_without_communication"] = None if not one else one / v["step_ms"]
+# COMPOSED estimate.  The emulation solves rank 0's shard as if it were the whole problem, so its evaluation COUNT is that of
+# an n / N-cell problem (and its rebuilt preconditioner comes from this rank's share of the sample alone).  A real N-rank
+# run follows the trajectory of the whole problem -- the sums are the same numbers however many ranks add them -- i.e. the
+# counts of the N = 1 line.  Per-launch costs from this rank's emulation, counts from N = 1:
+#   step(N) = [step(N) - objective kernels(N) - rebuild(N)]        replicated set-up, per-evaluation launches, host
+#             * evaluations(1) / evaluations(N) on the per-evaluation part (0.14 ms each)
+#             + full passes(1) * fp64 pass(N) + sub passes(1) * sub pass(N) + rebuild(N) if the N = 1 solve rebuilt
+ref = out.get("1")
+if ref:
+    for k, v in out.items():
+        per_eval_ms = 0.14
+        other = v["step_ms"] - v["objective_kernels_ms"] - v["sub_passes_ms"] - v["rebuild_ms"]
+        other += per_eval_ms * (ref["evaluations"] - v["evaluations"])
+        sub_ms = v["sub_passes_ms"] / max(v["sub_evaluations"], 1)
+        reb = v["rebuild_ms"] if v["rebuilds"] else None
+        comp = other + ref["fp64_launches"] * v["fp64_pass_ms"] + ref["sub_evaluations"] * sub_ms
+        v["composed_global_trajectory_ms"] = None if (ref["rebuilds"] and reb is None) else comp + (reb or 0.0)
+        v["composed_note"] = ("N = 1 counts (%d full + %d sub passes, %d rebuild) at this rank's per-launch costs"
+                              % (ref["fp64_launches"], ref["sub_evaluations"], ref["rebuilds"])) + \
+                             ("" if reb is not None or not ref["rebuilds"] else "; this emulation did not rebuild: run with MELLON_AMD_REBUILD=1")
+        if v["composed_global_trajectory_ms"]:
+            v["composed_speedup_without_communication"] = ref["step_ms"] / v["composed_global_trajectory_ms"]
 print(json.dumps(out, indent=1))
