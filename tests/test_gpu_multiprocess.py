@@ -60,20 +60,28 @@ def test_sharded_fit_in_separate_processes(tmp_path, world):
     assert np.abs(dens - ref.log_density_x).max() < 1e-5 * np.abs(ref.log_density_x).max()
 
 
-def test_bench_two_ranks_under_the_launcher(tmp_path):
-    """The driver's launch line for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), small sizes."""
+@pytest.mark.parametrize("scaling", [None, "strong"])
+def test_bench_two_ranks_under_the_launcher(tmp_path, scaling):
+    """The driver's launch line for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), small sizes: the default
+    (weak: --cells per GPU, one model on all of them, the strong-scaling step measured beside it) and --scaling strong."""
     port = _free_port()
     env = dict(os.environ)
     env.update(MELLON_AMD_SHARE_GPU="1", MELLON_AMD_COMM_TIMEOUT="120", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--cells", "60000", "--dims", "10", "--landmarks", "400", "--landmark-method", "device", "--cpu-sample", "0",
-           "--extra-steps", "1"]
+           "--extra-steps", "1"] + (["--scaling", scaling] if scaling else [])
     run = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-4000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["dtype"] == "f64" and out["value"] > 0
-    assert out["config"]["n_per_gpu"] == 30000 and out["scaling"] == "strong"
+    if scaling == "strong":
+        assert out["config"]["n_per_gpu"] == 30000 and out["config"]["n"] == 60000 and out["scaling"] == "strong"
+        assert "strong_scaling" not in out
+    else:
+        assert out["config"]["n_per_gpu"] == 60000 and out["config"]["n"] == 120000 and out["scaling"] == "weak"
+        st = out["strong_scaling"]
+        assert st["n"] == 60000 and st["n_per_gpu"] == 30000 and st["value"] > 0 and st["ms_per_step"] > 0
     assert out["roofline"]["frac"] > 0 and out["config"]["predict_equals_fit_predict_rel_max"] < 1e-8
