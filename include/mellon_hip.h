@@ -152,7 +152,9 @@ int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, 
 /* k-means landmarks (S8f rank 1): k-means++ seeding + Lloyd sweeps on the device, the algorithm
  * family of sklearn.cluster.k_means(x, m, n_init=1, random_state) that parameters.compute_landmarks
  * calls (parameters.py:275-291).  Own RNG stream / summation order: centroids are equivalent in
- * quality, not bit-compatible with sklearn.  d <= 64.  centers: m x d.                           */
+ * quality, not bit-compatible with sklearn.  d <= 64.  centers: m x d.  The sweeps carry Hamerly's
+ * distance bounds (same assignments, searched only where the bounds do not decide).  n_iter_out and
+ * inertia_out may be NULL; the inertia is a full fp64 assignment of all cells to the final centres. */
 int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int64_t seed,
                int32_t max_iter, double tol, double* centers, int32_t* n_iter_out, double* inertia_out);
 

@@ -187,11 +187,19 @@ int dev_sym_rank_above_ldl(mln_ctx* ctx, double* A, int64_t m, int64_t ld, doubl
   constexpr int CB = 128;
   double *Dinv = nullptr, *Ls = nullptr, *Ls2 = nullptr;
   int* cnt = nullptr;      // [0] negative pivots, [2..3] bits of the smallest |pivot|
-  MLN_HIP(ctx, mln_dmalloc((void**)&Dinv, sizeof(double) * 2 * CB * CB));
-  MLN_HIP(ctx, mln_dmalloc((void**)&cnt, 16));
-  if (m > CB) {
-    MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)m * (size_t)ld));
-    MLN_HIP(ctx, mln_dmalloc((void**)&Ls2, sizeof(double) * (size_t)m * (size_t)ld));
+  auto release = [&]() {
+    (void)hipStreamSynchronize(ctx->stream);
+    if (Dinv) (void)mln_dfree(Dinv);
+    if (cnt) (void)mln_dfree(cnt);
+    if (Ls) (void)mln_dfree(Ls);
+    if (Ls2) (void)mln_dfree(Ls2);
+  };
+  {
+    hipError_t ea = mln_dmalloc((void**)&Dinv, sizeof(double) * 2 * CB * CB);
+    if (ea == hipSuccess) ea = mln_dmalloc((void**)&cnt, 16);
+    if (ea == hipSuccess && m > CB) ea = mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)m * (size_t)ld);
+    if (ea == hipSuccess && m > CB) ea = mln_dmalloc((void**)&Ls2, sizeof(double) * (size_t)m * (size_t)ld);
+    if (ea != hipSuccess) { release(); return mln_hip_fail(ctx, ea, "ldl work space", __FILE__, __LINE__); }
   }
   double* DinvS = Dinv + CB * CB;
   unsigned long long* minp = reinterpret_cast<unsigned long long*>(cnt + 2);
@@ -232,10 +240,7 @@ int dev_sym_rank_above_ldl(mln_ctx* ctx, double* A, int64_t m, int64_t ld, doubl
   } else {
     (void)hipStreamSynchronize(ctx->stream);
   }
-  (void)mln_dfree(Dinv);
-  (void)mln_dfree(cnt);
-  if (Ls) (void)mln_dfree(Ls);
-  if (Ls2) (void)mln_dfree(Ls2);
+  release();
   if (rc != MLN_OK) return rc;
   unsigned long long bits = 0;
   std::memcpy(&bits, hcnt + 2, 8);
