@@ -72,12 +72,11 @@ def test_covariance_lowering_and_json():
 def test_tools_compile():
     """The measurement scripts under tools/ are run by hand on the GPU box; here at least every one of them parses, and the
     shell scripts pass `bash -n`."""
-    import py_compile
     import subprocess
     tools = os.path.join(ROOT, "tools")
     for f in sorted(os.listdir(tools)):
         path = os.path.join(tools, f)
         if f.endswith(".py"):
-            py_compile.compile(path, doraise=True, cfile=os.devnull)
+            compile(open(path).read(), path, "exec")
         elif f.endswith(".sh"):
             assert subprocess.run(["bash", "-n", path]).returncode == 0, f
