@@ -91,6 +91,10 @@ int split_ranks(const mln_ctx* ctx, int* my_rank, bool* emulate) {
 template <typename Body>
 static int for_my_column_blocks(mln_fit* f, int n_split, int my_rank, bool emulate, int64_t b, Body body) {
   mln_ctx* ctx = f->ctx;
+  // (Tried: 2 N half-width blocks, rank r owning blocks r and 2 N - 1 - r, to even out a cost that grows with the column offset
+  //  -- the K range of a triangular factor ends at the diagonal.  Twice the block solves and narrower GEMMs cost more than the
+  //  imbalance: 86.5 instead of 47.1 ms per emulated step at 8 ranks.  With whole blocks the last rank's whitening GEMM is the
+  //  longest, by ~0.6 ms at 8 ranks over rank 0's, which the emulation times.)
   for (int r = 0; r < n_split; ++r) {
     if (!emulate && r != my_rank) continue;
     const int64_t c0 = (int64_t)r * b, nb = std::min<int64_t>(b, f->m - c0);
@@ -115,6 +119,23 @@ int fit_whiten_split(mln_fit* f, double* G, int64_t ldg, int n_split, int my_ran
   MLN_HIP(ctx, ob.alloc(full));
   double *Z = zb.p, *T = tb.p, *Out = ob.p;
   MLN_HIP(ctx, hipMemsetAsync(Out, 0, full, ctx->stream));
+  // Round 4b: with the explicit Lp^-1 (fit_ensure_linv, replicated: 1.7 ms once per fit) a rank's column block is two GEMMs --
+  // T = S (Lp^-1)[block, 0 : c0 + nb]^T (rows of the lower triangular inverse end at the diagonal), then Lp^-1 T over the
+  // non-zero K range -- instead of two blocked substitutions of 39 + 40 dependent launches on a right-hand side only
+  // m / N columns wide: those launches are pure latency (19-42 us each), 2.4 ms per whitening at 8 ranks however narrow the block.
+  if (use_explicit_linv()) {
+    MLN_TRY(fit_ensure_linv(f));
+    MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
+      GemmArgs g{};
+      g.A = G; g.lda = ldg; g.B = f->Linv + c0 * f->ldp; g.ldb = f->ldp; g.C = T; g.ldc = b;
+      g.M = m; g.N = nb; g.K = c0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
+      MLN_TRY(launch_dgemm(ctx, g));
+      GemmArgs h{};
+      h.A = f->Linv; h.lda = f->ldp; h.B = T; h.ldb = b; h.C = Out + c0; h.ldc = ldg;
+      h.M = m; h.N = nb; h.K = m; h.alpha = 1.0; h.beta = 0.0; h.ta = 0; h.tb = 0; h.kmode = 3;
+      return launch_dgemm(ctx, h);
+    }));
+  } else
   MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
     MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
     MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));             // unit columns c0 .. c0 + nb
@@ -144,11 +165,21 @@ int fit_inverses_split(mln_fit* f, const TriInv& tc, double* inv, double* P, int
   MLN_HIP(ctx, qb.alloc(2 * full));                                     // [C^-T ; P], this rank's columns only
   double *Z = zb.p, *Q = qb.p;
   MLN_HIP(ctx, hipMemsetAsync(Q, 0, 2 * full, ctx->stream));
+  const bool explicit_linv = use_explicit_linv();
+  if (explicit_linv) MLN_TRY(fit_ensure_linv(f));
   MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
     MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
     MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));
     MLN_TRY(triinv_solve_left_T(ctx, tc, Z, nb, b));                    // (C^-T)[:, block]
     MLN_TRY(launch_copy_block(ctx, Z, b, Q + c0, ld, m, nb));
+    if (explicit_linv) {
+      // P[:, block] = Lp^-T (C^-T)[:, block] as one GEMM with the explicit inverse: the block of the upper triangular C^-T is
+      // zero below row c0 + nb, and so is the result
+      GemmArgs g{};
+      g.A = f->Linv; g.lda = f->ldp; g.B = Z; g.ldb = b; g.C = Q + (size_t)m * ld + c0; g.ldc = ld;
+      g.M = c0 + nb; g.N = nb; g.K = c0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;
+      return launch_dgemm(ctx, g);
+    }
     MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // P[:, block] = Lp^-T (C^-T)[:, block]
     return launch_copy_block(ctx, Z, b, Q + (size_t)m * ld + c0, ld, m, nb);
   }));
