@@ -125,64 +125,86 @@ __global__ __launch_bounds__(1024) void k_seed_update_h(const _Float16* __restri
 }
 
 // One k-means++ draw on the device (no host round trip per centre): total of the block sums, the block and then the cell
-// where the running sum of D^2 passes u * total -- the same sequential sums the host used to form -- and the cell's
-// coordinates copied into the next centre's slot.  u: this step's uniform draw (the whole sequence is uploaded once).
+// where the running sum of D^2 passes u * total, and the cell's coordinates copied into the next centre's slot.  u: this
+// step's uniform draw (the whole sequence is uploaded once).  Both levels are a 256-wide inclusive scan (wave shuffles + four
+// wave totals) and a search for the one thread whose interval [exclusive, inclusive) holds the target -- fixed order, no
+// atomics: the same draw in every run.  (Round 3 had thread 0 walk the 256 partial sums, twice: 13 us per draw, 65 ms of a
+// 5000-centre seeding, most of it LDS latency.)
+__device__ __forceinline__ void seed_scan_find(double v, double target, int t, double* wtot, int* owner, double* rem) {
+  const int lane = t & 63, wave = t >> 6;
+  double inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  if (t == 0) { *owner = -1; }
+  __syncthreads();
+  double base = 0.0;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  const double incl = base + inc, excl = incl - v;
+  // values are non-negative: the inclusive sums are non-decreasing and at most one thread has excl <= target < incl
+  if (v > 0.0 && !(target < excl) && target < incl) { *owner = t; *rem = target - excl; }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_seed_select(const double* __restrict__ bsum, int64_t nblk, const double* __restrict__ mind,
                                                      int64_t n, double u, const double* __restrict__ x, int d,
                                                      double* __restrict__ c_next) {
-  __shared__ double part[256];
-  __shared__ int64_t chosen, blk;
-  __shared__ double tgt;
+  __shared__ double wtot[4];
+  __shared__ int owner;
+  __shared__ double rem;
+  __shared__ int64_t chosen;
   const int t = threadIdx.x;
-  // level 1: which block of SBLK cells.  Thread t sums its run of block sums, thread 0 walks the 256 partial sums, the
-  // owner of the run walks its few entries: fixed order, no atomics -- the same draw in every run.
+  // level 1: which block of SBLK cells.  Thread t sums its run of block sums; the scan finds the run, its owner the block.
   const int64_t per = (nblk + 255) / 256;
   const int64_t b0 = t * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
   double ps = 0.0;
   for (int64_t b = b0; b < b1; ++b) ps += bsum[b];
-  part[t] = ps;
-  __syncthreads();
-  if (t == 0) {
-    double total = 0.0;
-    for (int q = 0; q < 256; ++q) total += part[q];
-    blk = -1; chosen = 0;
-    if (!(total > 0.0)) {                      // all cells coincide with centres: any cell will do
-      const int64_t cur = (int64_t)(u * (double)n);
-      chosen = cur >= n ? n - 1 : cur;
-    } else {
-      double target = u * total;
-      int q = 0;
-      for (; q < 255; ++q) { if (target < part[q]) break; target -= part[q]; }
-      int64_t b = (int64_t)q * per;
-      const int64_t bend = (b + per < nblk) ? b + per : nblk;
-      if (b >= nblk) b = nblk - 1;
-      for (; b + 1 < bend; ++b) { if (target < bsum[b]) break; target -= bsum[b]; }
-      blk = b; tgt = target;
+  // total = the last inclusive sum: one more pass of the same scan gives it to everybody
+  double inc = ps;
+  {
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
     }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
   }
+  const double total = ((wtot[0] + wtot[1]) + wtot[2]) + wtot[3];
   __syncthreads();
-  if (blk >= 0) {
+  if (!(total > 0.0)) {                          // all cells coincide with centres: any cell will do
+    if (t == 0) { const int64_t cur = (int64_t)(u * (double)n); chosen = cur >= n ? n - 1 : cur; }
+    __syncthreads();
+  } else {
+    seed_scan_find(ps, u * total, t, wtot, &owner, &rem);
+    // (rounding can leave the target at or beyond the last inclusive sum: then the last non-empty run)
+    int own = owner;
+    double target = rem;
+    if (own < 0) { own = 255; while (own > 0 && !((int64_t)own * per < nblk)) --own; target = INFINITY; }
+    int64_t blk = (int64_t)own * per;
+    {
+      const int64_t bend = (blk + per < nblk) ? blk + per : nblk;
+      for (; blk + 1 < bend; ++blk) { if (target < bsum[blk]) break; target -= bsum[blk]; }
+    }
+    __syncthreads();
     // level 2: which cell of the block, the same way (4 cells per thread)
     const int64_t lo = blk * SBLK, hi = (lo + SBLK < n) ? lo + SBLK : n;
     constexpr int CPT = SBLK / 256;
     double v[CPT], ls = 0.0;
 #pragma unroll
     for (int e = 0; e < CPT; ++e) { const int64_t i = lo + t * CPT + e; v[e] = (i < hi) ? mind[i] : 0.0; ls += v[e]; }
-    __syncthreads();
-    part[t] = ls;
-    __syncthreads();
-    if (t == 0) {
-      double target = tgt;
-      int q = 0;
-      for (; q < 255; ++q) { if (!(target >= part[q])) break; target -= part[q]; }
-      blk = q; tgt = target;                    // (reused: the owning thread and what is left of the target)
-    }
-    __syncthreads();
-    if (t == (int)blk) {
+    seed_scan_find(ls, target, t, wtot, &owner, &rem);
+    if (owner < 0) {                             // target beyond the block's sum (rounding): its last cell
+      if (t == 0) chosen = hi - 1;
+    } else if (t == owner) {
       double run = 0.0;
       int64_t pick = lo + t * CPT + CPT - 1;
 #pragma unroll
-      for (int e = 0; e < CPT; ++e) { run += v[e]; if (run > tgt) { pick = lo + t * CPT + e; break; } }
+      for (int e = 0; e < CPT; ++e) { run += v[e]; if (run > rem) { pick = lo + t * CPT + e; break; } }
       chosen = pick < hi ? pick : hi - 1;
     }
     __syncthreads();
