@@ -398,7 +398,9 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
                                                      int* __restrict__ n_pairs, int cap, int* __restrict__ pair_row,
                                                      int* __restrict__ pair_col) {
   extern __shared__ unsigned char lds[];
+  __shared__ int stop_s[2];     // (two slots by stage parity: the slot a stage reads is not written again before its barrier)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { stop_s[0] = 0; stop_s[1] = 0; }
   const int lr = lane & 31, lg = lane >> 5;
   const int64_t row0w = (int64_t)blockIdx.x * 256 + wave * 32;
   h8 ahi[4], alo[4];
@@ -438,6 +440,11 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
   __syncthreads();
   int buf = 0;
   for (int64_t col0 = 0; col0 < m; col0 += RT, buf ^= 1) {
+    // A list that has outgrown its buffer is abandoned by the caller (exact search instead): stop feeding it.  Without this a
+    // tight cluster of 50 000 mutual near-ties appends 2.5e9 pairs -- seconds of atomics on one address, and a 32-bit counter
+    // that wraps to negative slots (found by tools/robustness_sweep_large.py as a write fault).  The test is the same for
+    // (Thread 0 reads the counter before the barrier that ends a stage; everybody acts on that one value after it.)
+    if (stop_s[buf]) return;
     const bool more = col0 + RT < m;
     if (more) g_load(col0 + RT);
     const unsigned char* base = lds + buf * (RT * PITCH);
@@ -477,13 +484,14 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
           for (int r = 0; r < 16; ++r) {
             if (acc[h][r] < thr[r]) {
               const int slot = atomicAdd(n_pairs, 1);
-              if (slot < cap) { pair_row[slot] = (int)(row0w + (r & 3) + 8 * (r >> 2) + 4 * lg); pair_col[slot] = (int)col; }
+              if (slot >= 0 && slot < cap) { pair_row[slot] = (int)(row0w + (r & 3) + 8 * (r >> 2) + 4 * lg); pair_col[slot] = (int)col; }
             }
           }
         }
       }
     }
     if (more) l_store(buf ^ 1);
+    if (tid == 0) stop_s[buf ^ 1] = __hip_atomic_load(n_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cap ? 1 : 0;
     __syncthreads();
   }
 }

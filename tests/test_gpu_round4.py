@@ -248,6 +248,12 @@ def test_nn_open_rows_resolved_from_a_candidate_list(ctx, monkeypatch):
     wanty = mo.exact_nn_distances(y)
     tol2 = 64 * np.finfo(float).eps * np.linalg.norm(y, axis=1).max() ** 2
     assert np.abs(got**2 - wanty**2).max() < tol2
+    # ... and so many that the pair counter would pass 2^31 (50 000 mutual near-ties: 2.5e9 pairs; this was a write fault
+    # through a wrapped 32-bit slot index until the sweep stopped feeding an abandoned list)
+    z = np.concatenate([4.0 + 0.01 * rng.normal(size=(50_000, 20)), mo.gaussian_mixture(30_000, 20, seed=4)])
+    gz = ctx.nn_distances(z)
+    wz = mo.exact_nn_distances(z)
+    assert np.all(np.isfinite(gz)) and np.abs(gz**2 - wz**2).max() < 64 * np.finfo(float).eps * np.linalg.norm(z, axis=1).max() ** 2
 
 
 def test_tree_data_sharded_at_scale(mellon, ctx, monkeypatch):
