@@ -5,6 +5,70 @@
 // G (m x ldg, full symmetric) = alpha * A^T A for the row-major A (rows x m, leading dim lda), all-reduced.
 // `quantised`: A holds covariance values in [0, 1] and the result only feeds a preconditioner -- the Gram of A rounded
 // to 23 fractional bits, exact in integers on the int8 matrix cores (gram_i8.hip).
+// ---- collectives that move what is there, not what the layout suggests (round 4b) --------------------------------------------
+// The m x m collectives of a fit were all-reduces of full row-major matrices: the Gram (symmetric: half of it is a copy) and the
+// column-split results (every rank's matrix is zero outside its own column block: a SUM with zeros of N matrices to deliver N
+// blocks).  Per build 200 + 200 + 400 MB of all-reduce payload, ~4 ms on 8 xGMI-connected GPUs, twice per fit.  Now: the Gram's
+// lower triangle packed (m (m + 1) / 2 doubles), summed, unpacked into both halves; the column blocks packed and ALL-GATHERED
+// (each rank sends its block once and receives the others': half the traffic of the all-reduce of the same matrix, and no
+// arithmetic -- the assembled matrix is the same bits on every rank by construction).
+namespace {
+__global__ void k_pack_lower(const double* __restrict__ G, int64_t m, int64_t ld, double* __restrict__ out) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= i) out[i * (i + 1) / 2 + j] = G[i * ld + j];
+}
+__global__ void k_unpack_symmetric(const double* __restrict__ in, int64_t m, int64_t ld, double* __restrict__ G) {
+  const int64_t i = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) G[i * ld + j] = (j <= i) ? in[i * (i + 1) / 2 + j] : in[j * (j + 1) / 2 + i];
+}
+}  // namespace
+
+// G (m x m, lower triangle valid on every rank) <- the sum over ranks, both triangles filled
+int allreduce_symmetric_lower(mln_ctx* ctx, double* G, int64_t m, int64_t ldg) {
+  const int64_t cnt = m * (m + 1) / 2;
+  double* packed = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&packed, sizeof(double) * (size_t)cnt));
+  const dim3 grid((unsigned)((m + 255) / 256), (unsigned)m), block(256);
+  hipLaunchKernelGGL(k_pack_lower, grid, block, 0, ctx->stream, G, m, ldg, packed);
+  int rc = dev_allreduce(ctx, packed, cnt);
+  if (rc == MLN_OK) {
+    hipLaunchKernelGGL(k_unpack_symmetric, grid, block, 0, ctx->stream, packed, m, ldg, G);
+    if (hipGetLastError() != hipSuccess) rc = MLN_ERR_HIP;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(packed);
+  return rc;
+}
+
+// n_mats matrices (m x ld each, `mat_stride` doubles apart) whose column block [r b, (r + 1) b) is valid on rank r only: every
+// rank receives every block.  (Emulated ranks and single-rank contexts hold all blocks already.)
+int assemble_column_blocks(mln_ctx* ctx, double* M, int64_t m, int64_t ld, int n_mats, size_t mat_stride, int n_split, int my_rank,
+                           bool emulate, int64_t b) {
+  if (emulate || ctx->n_ranks <= 1 || n_split <= 1) return MLN_OK;
+  const size_t slot = (size_t)n_mats * (size_t)m * (size_t)b;
+  double* AG = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&AG, sizeof(double) * slot * (size_t)n_split));
+  int rc = MLN_OK;
+  auto cols_of = [&](int r) { const int64_t c0 = (int64_t)r * b; return std::max<int64_t>(0, std::min<int64_t>(b, m - c0)); };
+  if (hipMemsetAsync(AG + slot * (size_t)my_rank, 0, sizeof(double) * slot, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
+  for (int k = 0; k < n_mats && rc == MLN_OK; ++k)
+    if (cols_of(my_rank) > 0)
+      rc = launch_copy_block(ctx, M + (size_t)k * mat_stride + (int64_t)my_rank * b, ld,
+                             AG + slot * (size_t)my_rank + (size_t)k * (size_t)m * (size_t)b, b, m, cols_of(my_rank));
+  if (rc == MLN_OK) rc = comm_allgather(ctx, AG + slot * (size_t)my_rank, AG, (int64_t)slot);
+  for (int r = 0; r < n_split && rc == MLN_OK; ++r) {
+    if (r == my_rank || cols_of(r) <= 0) continue;
+    for (int k = 0; k < n_mats && rc == MLN_OK; ++k)
+      rc = launch_copy_block(ctx, AG + slot * (size_t)r + (size_t)k * (size_t)m * (size_t)b, b,
+                             M + (size_t)k * mat_stride + (int64_t)r * b, ld, m, cols_of(r));
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(AG);
+  return rc;
+}
+
 int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
                    int64_t ldg, bool quantised) {
   int split = quantised ? gram_i8_splits(rows, m) : (int)(rows / 8192);
@@ -24,8 +88,8 @@ int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m,
   if (rc == MLN_OK && rows > 0)
     rc = quantised ? launch_gram_i8(ctx, A, lda, rows, m, alpha, g.C, ldg, (int64_t)stride, split) : launch_dgemm(ctx, g);
   if (rc == MLN_OK && split > 1) rc = launch_sum_partials(ctx, parts, split, (int64_t)stride, G, (int64_t)stride, 0.0);
-  if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
-  if (rc == MLN_OK) rc = dev_allreduce(ctx, G, (int64_t)stride);
+  if (rc == MLN_OK && ctx->n_ranks > 1) rc = allreduce_symmetric_lower(ctx, G, m, ldg);      // half the payload: a Gram is symmetric
+  else if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
   (void)hipStreamSynchronize(ctx->stream);
   if (parts) (void)mln_dfree(parts);
   return rc;
@@ -148,7 +212,7 @@ int fit_whiten_split(mln_fit* f, double* G, int64_t ldg, int n_split, int my_ran
     return launch_copy_block(ctx, T, b, Out + c0, ldg, m, nb);
   }));
   MLN_HIP(ctx, hipMemcpyAsync(G, Out, full, hipMemcpyDeviceToDevice, ctx->stream));
-  MLN_TRY(dev_allreduce(ctx, G, (int64_t)m * ldg));
+  MLN_TRY(assemble_column_blocks(ctx, G, m, ldg, 1, 0, n_split, my_rank, emulate, b));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MLN_OK;
 }
@@ -183,7 +247,7 @@ int fit_inverses_split(mln_fit* f, const TriInv& tc, double* inv, double* P, int
     MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // P[:, block] = Lp^-T (C^-T)[:, block]
     return launch_copy_block(ctx, Z, b, Q + (size_t)m * ld + c0, ld, m, nb);
   }));
-  MLN_TRY(dev_allreduce(ctx, Q, 2 * (int64_t)m * ld));
+  MLN_TRY(assemble_column_blocks(ctx, Q, m, ld, 2, (size_t)m * (size_t)ld, n_split, my_rank, emulate, b));
   MLN_TRY(launch_transpose(ctx, Q, ld, inv, ld, m));                                  // C^-1
   MLN_TRY(launch_copy_block(ctx, Q + (size_t)m * ld, ld, P, ld, m, ld));              // P
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
