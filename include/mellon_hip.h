@@ -377,6 +377,13 @@ int mln_predict_mean(mln_ctx* ctx, const mln_kernel_desc* cov, const double* xne
 int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* result);
 int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
                    int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out);
+/* The GEMM's mixed-tile pipelined kernel against its single-size kernels on the same pseudo-random operands
+ * (alpha = 0.75, the given beta; lower_only 0..3 and kmode 0..7 as the internal GEMM takes them: whole matrix / a triangle of
+ * tiles, full / block-diagonal / triangular K ranges -- decomposition.py:111-123,205-210 and conditional.py:57-66 reach
+ * it in every one of them).  out[0] = largest absolute difference (0 expected: the same summation order per element),
+ * out[1] = largest absolute value.  any_size != 0: the mixed kernel also below the size where the policy selects it. */
+int mln_diag_dgemm_compare(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K, int32_t lower_only,
+                           int32_t kmode, double beta, int32_t any_size, double* out);
 /* The integer Gram of the preconditioner in isolation (csrc/gram_i8.hip): out (m x m) = Q^T Q / 8355711^2 with
  * Q = round(A * 8355711), A rows x m with values in [0, 1] (host or device); terms below 2^-23 relative are dropped.
  * ms_out (may be NULL): milliseconds per call over `reps` calls.  Not a reference operation: the reference forms the

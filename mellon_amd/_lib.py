@@ -120,6 +120,7 @@ SYMBOLS = [
     ("mln_diag_overlap", C.c_int, [_vp, _i64, _i64, _i32, _i64, _dp]),
     ("mln_diag_gram_i8", C.c_int, [_vp, _vp, _i64, _i64, _vp, _i32, C.POINTER(_dbl)]),
     ("mln_diag_dgemm", C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _i32, C.POINTER(_dbl)]),
+    ("mln_diag_dgemm_compare", C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _dbl, _i32, C.POINTER(_dbl)]),
 ]
 
 _lib = None
@@ -694,6 +695,13 @@ class Context:
         if isinstance(desc, BlockEvaluatedCov):
             return Fit.from_blocks(self, desc, x, landmarks, jitter, Lp, implicit)
         return Fit(self, desc, x, landmarks, jitter, Lp, implicit)
+
+    def diag_dgemm_compare(self, ta, tb, M, N, K, lower_only=0, kmode=0, beta=0.0, any_size=True):
+        """(largest |mixed-tile kernel - single-size kernels|, largest |value|) on the same operands (mln_diag_dgemm_compare)."""
+        r = (C.c_double * 2)()
+        self._check(self.lib.mln_diag_dgemm_compare(self.handle, int(ta), int(tb), M, N, K, lower_only, kmode, float(beta),
+                                                    1 if any_size else 0, r))
+        return float(r[0]), float(r[1])
 
     def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None):
         """out = alpha op(A) op(B) + beta out on the fp64 matrix cores (mln_gemm); A, B, out host arrays or

@@ -15,6 +15,7 @@
 // fp64 MFMA on gfx950 runs at the fp64 vector rate (64 cycles per 16x16x4 instruction per SIMD),
 // so a single LDS buffer + two barriers per k-tile leaves the matrix pipe as the limiter.
 #include <cstdlib>
+#include <type_traits>
 #include "mln_internal.h"
 #include "mln_options.h"
 
@@ -200,6 +201,235 @@ __global__ __launch_bounds__(256, 2) void k_dgemm(GemmArgs g, int64_t tiles_n, i
       }
 }
 
+// ---- round 4c: the pipelined tile ------------------------------------------------------------------------------------
+// The same tile as above with the two things its ISA showed missing: (1) TWO LDS buffers per operand, so that the next
+// k-tile's registers are stored while this one's matrix instructions run and ONE barrier per k-tile is left (the single
+// buffer needed two, and the 16 ds_write_b64 between them ran with the matrix pipe of that wave idle); (2) the barrier
+// waits for LDS traffic only ("s_waitcnt lgkmcnt(0); s_barrier": __syncthreads() also drains vmcnt, i.e. the global loads
+// of the tile after next, which are meant to stay in flight across it).  The operand fragments of the next four k are read
+// while the 16 (4) matrix instructions of the current four run.
+//
+// And a launch may MIX the tile sizes: the first `n_big` active tiles (in launch order) are 128 x 128, every later one is
+// cut into its four 64 x 64 quadrants, each a workgroup of its own.  722 lower tiles of a Cholesky update or the 1600
+// tiles of a 5000 x 5000 product on 512 workgroup slots leave a last round that is 40 % resp. 12 % full; cut in four,
+// the stragglers take a quarter of the time each and spread over all CUs.  A quadrant keeps the K range of its PARENT tile
+// and every element sums its k in the same order under either tiling: the result is the same bits whatever the mix is.
+struct TileMap {
+  int64_t tiles_m, tiles_n;   // 128-wide tile grid
+  int64_t n_active;           // tiles that are computed (all, or the triangle lower_only names)
+  int64_t n_big;              // the first n_big of them (launch order) as 128-tiles, the rest as quadrants
+  int order;                  // 0 row-major, 1 row-major reversed, 2 column-major reversed (the heavy-first orders)
+};
+
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// t-th tile of the triangle {tn <= tm} (strict: tn < tm) enumerated row by row
+__device__ __forceinline__ void tri_tile(int64_t t, bool strict, int64_t& tm, int64_t& tn) {
+  int64_t r = (int64_t)((__dsqrt_rn(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (r * (r + 1) / 2 > t) --r;
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  tm = strict ? r + 1 : r;
+  tn = t - r * (r + 1) / 2;
+}
+
+// Unmasked staging loads of a k-tile that lies inside the operand (rows o0 .. o0 + BT below O, k0 + BKT <= kend): `p` is the
+// calling thread's element (o, k) = (o0 + its row, k0 + its first k) resp. (k0 + its k, o0 + its first row), see tile_load.
+// (Round 4c also measured a branch-free variant of ALL loads -- indices clamped into the operand, zeros selected when the
+//  registers go to LDS, with a ring of four register sets for the 64-wide tile: 8192^3 at 0.80 of the fp64 matrix peak
+//  against 0.92 for the split below, the 64-wide tile 5-10 % slower as well: the 64-bit clamps cost more issue slots than
+//  the masked loads of the few edge tiles cost time.  tools/gemm_mix_probe.py, profiles/r04c_gemm_mix_probe.txt.)
+template <bool KCONTIG, int BT, int BKT, bool VEC>
+__device__ __forceinline__ void tile_load_inside(const double* __restrict__ p, double (&r)[BT * BKT / 256]) {
+  constexpr int NL = BT * BKT / 256;
+  if (VEC) {
+#pragma unroll
+    for (int q = 0; q < NL; q += 2) {
+      const d2v v = *reinterpret_cast<const d2v*>(p + q);
+      r[q] = v.x; r[q + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < NL; ++q) r[q] = p[q];
+  }
+}
+
+template <bool KCONTIG, int BT, int BKT>
+__device__ __forceinline__ const double* tile_thread_ptr(const double* P, int64_t ld, int64_t o0, int64_t k0) {
+  constexpr int NL = BT * BKT / 256;
+  const int t = threadIdx.x;
+  if (KCONTIG) {
+    constexpr int TPR = 256 / BT;
+    return P + (o0 + t / TPR) * ld + k0 + (t % TPR) * NL;
+  }
+  constexpr int TPK = 256 / BKT;
+  return P + (k0 + t / TPK) * ld + o0 + (t % TPK) * NL;
+}
+
+template <bool AK, bool BKC, int BT, bool VEC>
+__device__ __forceinline__ void gemm_tile_pipelined(const GemmArgs& g, double* C, const int64_t m0, const int64_t n0,
+                                                    const int64_t kbeg, const int64_t kend, double* smem) {
+  constexpr int BKT = 16;
+  constexpr int TW = BT / 32;
+  constexpr int LD = BT + LPAD;
+  typedef double (*Tile)[LD];
+  double* const a_base = smem;                     // As[2][BKT][LD]
+  double* const b_base = smem + 2 * BKT * LD;       // Bs[2][BKT][LD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
+  const int lk = lane >> 4, li = lane & 15;
+
+  v4d acc[TW][TW];
+  double ra[BT * BKT / 256], rb[BT * BKT / 256];
+  if (kbeg < kend) {
+    tile_load<AK, BT, BKT, VEC>(g.A, g.lda, m0, kbeg, g.M, kend, ra);
+    tile_load<BKC, BT, BKT, VEC>(g.B, g.ldb, n0, kbeg, g.N, kend, rb);
+  }
+  const bool use_beta = (g.split_k <= 1) && (g.beta != 0.0);
+  const bool beta_in_acc = use_beta && g.alpha != 0.0;
+  if (beta_in_acc) {
+    const double bs = g.beta / g.alpha;
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = m0 + wm + i * 16 + lk + 4 * r;
+          const int64_t col = n0 + wn + j * 16 + li;
+          const int64_t rc = (row < g.M) ? row : (g.M - 1), cc = (col < g.N) ? col : (g.N - 1);
+          acc[i][j][r] = bs * C[rc * g.ldc + cc];
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int j = 0; j < TW; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  if (kbeg < kend) {
+    tile_store<AK, BT, BKT>(reinterpret_cast<Tile>(a_base), ra);
+    tile_store<BKC, BT, BKT>(reinterpret_cast<Tile>(b_base), rb);
+    if (kbeg + BKT < kend) {
+      tile_load<AK, BT, BKT, VEC>(g.A, g.lda, m0, kbeg + BKT, g.M, kend, ra);
+      tile_load<BKC, BT, BKT, VEC>(g.B, g.ldb, n0, kbeg + BKT, g.N, kend, rb);
+    }
+  }
+  lds_only_barrier();
+  int cur = 0;
+  // this thread's staging addresses for the k-tile two ahead of the one being multiplied (the steady-state loop only)
+  const double* pa = tile_thread_ptr<AK, BT, BKT>(g.A, g.lda, m0, kbeg + 2 * BKT);
+  const double* pb = tile_thread_ptr<BKC, BT, BKT>(g.B, g.ldb, n0, kbeg + 2 * BKT);
+  const int64_t a_step = AK ? (int64_t)BKT : (int64_t)BKT * g.lda, b_step = BKC ? (int64_t)BKT : (int64_t)BKT * g.ldb;
+
+  // one k-tile: fragments of the next four k are read while the matrix instructions of the current four run; after the
+  // first group has been issued the registers (k-tile + 1, requested an iteration ago) go into the other LDS buffer --
+  // every wave finished reading that one before the barrier that ended the previous iteration -- and k-tile + 2 is requested.
+  // STEADY: k-tile + 2 exists and lies inside both operands: no masks, no branches in the body.
+  auto k_tile = [&](auto steady, const int64_t k0) {
+    constexpr bool STEADY = decltype(steady)::value;
+    const Tile Ac = reinterpret_cast<Tile>(a_base + cur * (BKT * LD)), Bc = reinterpret_cast<Tile>(b_base + cur * (BKT * LD));
+    const Tile An = reinterpret_cast<Tile>(a_base + (cur ^ 1) * (BKT * LD)), Bn = reinterpret_cast<Tile>(b_base + (cur ^ 1) * (BKT * LD));
+    double a[2][TW], b[2][TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+      a[0][t] = Ac[lk][wm + t * 16 + li];
+      b[0][t] = Bc[lk][wn + t * 16 + li];
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKT; kk += 4) {
+      const int s = (kk >> 2) & 1;
+      if (kk + 4 < BKT) {
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          a[s ^ 1][t] = Ac[kk + 4 + lk][wm + t * 16 + li];
+          b[s ^ 1][t] = Bc[kk + 4 + lk][wn + t * 16 + li];
+        }
+      }
+      if (kk == 4) {
+        if (STEADY) {
+          tile_store<AK, BT, BKT>(An, ra);
+          tile_store<BKC, BT, BKT>(Bn, rb);
+          tile_load_inside<AK, BT, BKT, VEC>(pa, ra);
+          tile_load_inside<BKC, BT, BKT, VEC>(pb, rb);
+          pa += a_step; pb += b_step;
+        } else if (k0 + BKT < kend) {
+          tile_store<AK, BT, BKT>(An, ra);
+          tile_store<BKC, BT, BKT>(Bn, rb);
+          if (k0 + 2 * BKT < kend) {
+            tile_load<AK, BT, BKT, VEC>(g.A, g.lda, m0, k0 + 2 * BKT, g.M, kend, ra);
+            tile_load<BKC, BT, BKT, VEC>(g.B, g.ldb, n0, k0 + 2 * BKT, g.N, kend, rb);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+    }
+    lds_only_barrier();
+    cur ^= 1;
+  };
+  int64_t k0 = kbeg;
+  if (m0 + BT <= g.M && n0 + BT <= g.N)
+    for (; k0 + 3 * BKT <= kend; k0 += BKT) k_tile(std::true_type{}, k0);
+  for (; k0 < kend; k0 += BKT) k_tile(std::false_type{}, k0);
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm + i * 16 + lk + 4 * r;
+        const int64_t col = n0 + wn + j * 16 + li;
+        if (row < g.M && col < g.N) {
+          double v = g.alpha * acc[i][j][r];
+          if (use_beta && !beta_in_acc) v += g.beta * C[row * g.ldc + col];
+          C[row * g.ldc + col] = v;
+        }
+      }
+}
+
+// K range of the 128-wide tile at (m0, n0) (the same rules as k_dgemm above)
+__device__ __forceinline__ void tile_k_range(const GemmArgs& g, int64_t m0, int64_t n0, int64_t kchunk, int64_t& kbeg, int64_t& kend) {
+  kbeg = (int64_t)blockIdx.y * kchunk;
+  kend = (kbeg + kchunk < g.K) ? (kbeg + kchunk) : g.K;
+  if (g.kmode == 1) { kbeg = m0; kend = (m0 + 128 < g.K) ? (m0 + 128) : g.K; }
+  else if (g.kmode == 2) { kbeg = n0; kend = (n0 + 128 < g.K) ? (n0 + 128) : g.K; }
+  else if (g.kmode == 3) { kend = (m0 + 128 < kend) ? (m0 + 128) : kend; }
+  else if (g.kmode == 4) { kend = (n0 + 128 < kend) ? (n0 + 128) : kend; }
+  else if (g.kmode == 7) {
+    kbeg = (n0 > kbeg) ? n0 : kbeg;
+    kend = (m0 + 128 < kend) ? (m0 + 128) : kend;
+  }
+}
+
+template <bool AK, bool BKC, bool VEC, bool ONLY64>
+__global__ __launch_bounds__(256, ONLY64 ? 4 : 2) void k_dgemm_mix(GemmArgs g, TileMap tmap, int64_t kchunk) {
+  extern __shared__ __attribute__((aligned(16))) double dgemm_smem[];
+  const int64_t bid = blockIdx.x;
+  const bool big = !ONLY64 && bid < tmap.n_big;
+  int64_t t = big ? bid : tmap.n_big + ((bid - tmap.n_big) >> 2);
+  const int quad = big ? 0 : (int)((bid - tmap.n_big) & 3);
+  if (tmap.order != 0) t = tmap.n_active - 1 - t;
+  int64_t tm, tn;
+  if (g.lower_only == 1) tri_tile(t, false, tm, tn);
+  else if (g.lower_only == 2) tri_tile(t, true, tm, tn);
+  else if (g.lower_only == 3) { tri_tile(t, false, tn, tm); }            // upper: the transpose of the lower enumeration
+  else if (tmap.order == 2) { tm = t % tmap.tiles_m; tn = t / tmap.tiles_m; }
+  else { tm = t / tmap.tiles_n; tn = t % tmap.tiles_n; }
+  const int64_t m0 = tm * 128, n0 = tn * 128;
+  int64_t kbeg, kend;
+  tile_k_range(g, m0, n0, kchunk, kbeg, kend);
+  double* C = g.C + (int64_t)blockIdx.y * g.c_split_stride;
+  if (!ONLY64 && big) {
+    gemm_tile_pipelined<AK, BKC, 128, VEC>(g, C, m0, n0, kbeg, kend, dgemm_smem);
+  } else {
+    const int64_t qm = m0 + 64 * (quad >> 1), qn = n0 + 64 * (quad & 1);
+    if (qm >= g.M || qn >= g.N) return;
+    gemm_tile_pipelined<AK, BKC, 64, VEC>(g, C, qm, qn, kbeg, kend, dgemm_smem);
+  }
+}
+
 __global__ void k_sum_partials(const double* __restrict__ parts, int n_parts, int64_t stride,
                                double* __restrict__ out, int64_t count, double beta) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
@@ -222,8 +452,85 @@ static void dispatch(const GemmArgs& g, dim3 grid, hipStream_t st, int64_t tiles
   else hipLaunchKernelGGL((k_dgemm<false, false, BT, BKT, VEC>), grid, block, 0, st, g, tiles_n, kchunk);
 }
 
+static int64_t count_active(int lower_only, int64_t tm, int64_t tn) {
+  if (lower_only == 0) return tm * tn;
+  const int64_t q = tm < tn ? tm : tn;
+  if (lower_only == 1) return q * (q + 1) / 2 + (tm > tn ? (tm - tn) * tn : 0);        // tn <= tm
+  if (lower_only == 2) return (q > 0 ? q * (q - 1) / 2 : 0) + (tm > tn ? (tm - tn) * tn : 0);   // tn < tm
+  return q * (q + 1) / 2 + (tn > tm ? (tn - tm) * tm : 0);                             // tn >= tm
+}
+
+template <bool VEC, bool ONLY64>
+static hipError_t dispatch_mix(const GemmArgs& g, const TileMap& tmap, dim3 grid, size_t lds, hipStream_t st, int64_t kchunk) {
+  const bool ak = (g.ta == 0), bk = (g.tb == 1);
+  dim3 block(256);
+#define MLN_MIX_LAUNCH(A_, B_)                                                                                              \
+  do {                                                                                                                      \
+    static bool attr_set = false;                                                                                           \
+    if (!attr_set) {                                                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mix<A_, B_, VEC, ONLY64>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * (128 + LPAD) * 8);            \
+      if (e != hipSuccess) return e;                                                                                        \
+      attr_set = true;                                                                                                      \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((k_dgemm_mix<A_, B_, VEC, ONLY64>), grid, block, lds, st, g, tmap, kchunk);                          \
+  } while (0)
+  if (ak && bk) MLN_MIX_LAUNCH(true, true);
+  else if (ak && !bk) MLN_MIX_LAUNCH(true, false);
+  else if (!ak && bk) MLN_MIX_LAUNCH(false, true);
+  else MLN_MIX_LAUNCH(false, false);
+#undef MLN_MIX_LAUNCH
+  return hipGetLastError();
+}
+
+// MLN_ERR_UNSUPPORTED: not a launch for this kernel (the caller goes on to the single-size kernels)
+static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_size) {
+  const int64_t tiles_m = (g.M + 127) / 128, tiles_n = (g.N + 127) / 128;
+  // the triangle enumeration is written for square tile grids
+  if (g.lower_only != 0 && tiles_m != tiles_n) return MLN_ERR_UNSUPPORTED;
+  const int64_t n_active = count_active(g.lower_only, tiles_m, tiles_n);
+  const int64_t n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const int64_t slots = 2 * n_cu;
+  const int split = g.split_k > 1 ? g.split_k : 1;
+  static const int64_t min_tiles = mln_experiment("MELLON_AMD_GEMM_MIX_MIN") ? std::atoll(mln_experiment("MELLON_AMD_GEMM_MIX_MIN")) : -1;
+  // (below one round of 128-tiles the launch is all quadrants, served by the ONLY64 instance -- 95 registers, 40 KB of LDS,
+  //  four workgroups per CU.  Measured against k_dgemm's 64-wide tiles on the chains of the factorisations (A/B on one box,
+  //  tools/r04c_ab.sh): chol(5000) 4.5 -> 4.2 ms, Ridge solve 8.6 -> 8.2 ms, rebuild 17.0 -> 16.5 ms.  MELLON_AMD_GEMM_MIX_MIN
+  //  restores a threshold in 128-tiles for experiments.)
+  if (!any_size && n_active * split < (min_tiles >= 0 ? min_tiles : 0)) return MLN_ERR_UNSUPPORTED;
+  TileMap tmap;
+  tmap.tiles_m = tiles_m; tmap.tiles_n = tiles_n; tmap.n_active = n_active;
+  const bool heavy_last = g.kmode == 3 || g.kmode == 7 || g.kmode == 4;
+  tmap.order = heavy_last ? ((g.kmode == 4 && g.lower_only == 0) ? 2 : 1) : 0;
+  // whole rounds as 128-tiles; a last round that is at least three quarters full stays 128-wide as well
+  const int64_t per_round = slots / split > 0 ? slots / split : 1;
+  int64_t n_big = (n_active / per_round) * per_round;
+  if ((n_active - n_big) * 4 >= 3 * per_round || mode == 2) n_big = n_active;
+  if (mode == 3) n_big = 0;
+  tmap.n_big = n_big;
+  const int64_t nblk = n_big + 4 * (n_active - n_big);
+  if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }
+  const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0);
+  int64_t kchunk = (g.K + split - 1) / split;
+  kchunk = ((kchunk + 15) / 16) * 16;
+  if (kchunk <= 0) kchunk = 16;
+  dim3 grid((unsigned)nblk, (unsigned)split);
+  hipError_t e;
+  if (n_big == 0) {
+    const size_t lds = 4 * 16 * (64 + LPAD) * 8;
+    e = vec ? dispatch_mix<true, true>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, true>(g, tmap, grid, lds, ctx->stream, kchunk);
+  } else {
+    const size_t lds = 4 * 16 * (128 + LPAD) * 8;
+    e = vec ? dispatch_mix<true, false>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, false>(g, tmap, grid, lds, ctx->stream, kchunk);
+  }
+  MLN_HIP(ctx, e);
+  return MLN_OK;
+}
+
 static int g_bk_override = -1;   // diagnostics: force the tile size (128 / 64); -1 = automatic
 void dgemm_set_bk(int bk) { g_bk_override = bk; }
+static int g_mix_override = -1;  // diagnostics: -1 = policy; 0 = single-size kernels only; 1 = mixed kernel for every launch it can serve
+void dgemm_set_mix(int mode) { g_mix_override = mode; }
 
 int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return MLN_OK;
@@ -260,6 +567,14 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   }
   if (g_bk_override == 128 || g_bk_override == 64) bt = inplace ? 128 : g_bk_override;
   if (g.kmode == 1 || g.kmode == 2) bt = 128;   // the block-diagonal modes are defined on 128-wide blocks
+  {
+    // the pipelined kernel with mixed tile sizes (see TileMap): whole rounds of 128-tiles, the rest as quadrants
+    static const int mix_mode = mln_experiment("MELLON_AMD_GEMM_MIX") ? std::atoi(mln_experiment("MELLON_AMD_GEMM_MIX")) : 1;
+    if (g_mix_override != 0 && mix_mode > 0 && !inplace && g_bk_override < 0) {
+      int rc = launch_dgemm_mix(ctx, g, mix_mode, g_mix_override == 1);
+      if (rc != MLN_ERR_UNSUPPORTED) return rc;
+    }
+  }
   const int64_t tiles_m = (g.M + bt - 1) / bt, tiles_n = (g.N + bt - 1) / bt;
   const int64_t nblk = tiles_m * tiles_n;
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }

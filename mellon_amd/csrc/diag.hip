@@ -118,6 +118,7 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = Cm; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.alpha = 1.0; g.beta = mln_experiment("MELLON_AMD_DIAG_BETA") ? std::atof(mln_experiment("MELLON_AMD_DIAG_BETA")) : 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
   g.c_split_stride = (int64_t)M * ldc;
+  if (const char* e = mln_experiment("MELLON_AMD_DIAG_KMODE")) g.kmode = std::atoi(e);   // triangular K ranges (probes)
   hipEvent_t e0, e1;
   MLN_HIP(ctx, hipEventCreate(&e0));
   MLN_HIP(ctx, hipEventCreate(&e1));
@@ -132,6 +133,93 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
   (void)mln_dfree(A); (void)mln_dfree(B); (void)mln_dfree(Cm);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return MLN_OK;
+}
+
+// The mixed-size pipelined kernel against the single-size kernels on the same operands: out[0] = largest |difference| of
+// the two results (every element sums its k in the same order under either tiling: 0 is the expected value), out[1] =
+// largest |value|.  kmode / lower_only as in GemmArgs; any_size: also shapes below the policy's threshold.
+void dgemm_set_mix(int mode);
+// (lower_only: only the elements BOTH tilings are asked to produce -- a 128-wide diagonal tile also fills its upper quadrant)
+__global__ void k_diag_absdiff(const double* __restrict__ a, const double* __restrict__ b, int64_t count, int64_t ldc, int lower_only,
+                               double* __restrict__ out) {
+  double d = 0.0, v = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / ldc, col = i % ldc;
+    if ((lower_only == 1 && col > row) || (lower_only == 2 && col / 128 >= row / 128) || (lower_only == 3 && col < row)) continue;
+    const double x = a[i], y = b[i];
+    const double e = (x == y) ? 0.0 : ((x != x || y != y) ? INFINITY : fabs(x - y));
+    d = e > d ? e : d;
+    v = fabs(x) > v ? fabs(x) : v;
+  }
+  for (int o = 32; o > 0; o >>= 1) { d = fmax(d, __shfl_down(d, o)); v = fmax(v, __shfl_down(v, o)); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(d));       // non-negative doubles order as integers
+    atomicMax(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)__double_as_longlong(v));
+  }
+}
+// zero the strictly upper (which = 0) or strictly lower (1) triangle of a stored rows x cols matrix
+__global__ void k_diag_zero_triangle(double* __restrict__ P, int64_t rows, int64_t cols, int64_t ld, int which) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    if ((which == 0 && c > r) || (which == 1 && r > c)) P[r * ld + c] = 0.0;
+  }
+}
+extern "C" int mln_diag_dgemm_compare(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K, int32_t lower_only,
+                                      int32_t kmode, double beta, int32_t any_size, double* out) {
+  if (!ctx || !out || M < 1 || N < 1 || K < 1) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t lda = ((ta ? M : K) + 15) / 16 * 16, ldb = ((tb ? K : N) + 15) / 16 * 16, ldc = (N + 15) / 16 * 16;
+  const size_t a_bytes = sizeof(double) * (size_t)(ta ? K : M) * lda, b_bytes = sizeof(double) * (size_t)(tb ? N : K) * ldb;
+  const size_t c_count = (size_t)M * ldc;
+  double *A = nullptr, *B = nullptr, *C0 = nullptr, *C1 = nullptr, *res = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&A, a_bytes));
+  MLN_HIP(ctx, mln_dmalloc((void**)&B, b_bytes));
+  MLN_HIP(ctx, mln_dmalloc((void**)&C0, c_count * 8));
+  MLN_HIP(ctx, mln_dmalloc((void**)&C1, c_count * 8));
+  MLN_HIP(ctx, mln_dmalloc((void**)&res, 16));
+  std::vector<double> pat((1 << 20) + 7);
+  unsigned long long s = 88172645463325252ULL;
+  for (auto& v : pat) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
+  auto fill = [&](double* p, size_t bytes) -> hipError_t {
+    for (size_t off = 0; off < bytes; off += pat.size() * 8) {
+      hipError_t e = hipMemcpyAsync((char*)p + off, pat.data(), std::min(pat.size() * 8, bytes - off), hipMemcpyHostToDevice, ctx->stream);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  };
+  MLN_HIP(ctx, fill(A, a_bytes));
+  MLN_HIP(ctx, fill(B, b_bytes));
+  MLN_HIP(ctx, fill(C0, c_count * 8));     // the untouched part (upper triangle, beta * C) is the same in both
+  MLN_HIP(ctx, fill(C1, c_count * 8));
+  MLN_HIP(ctx, hipMemsetAsync(res, 0, 16, ctx->stream));
+  // the triangular K ranges are defined on 128-wide blocks for the 128-wide tiles and on 64-wide ones for the 64-wide: the
+  // operand has to BE triangular for the two to mean the same product (every caller's is)
+  if (kmode == 3 || kmode == 7)      // op(A)[row, k] = 0 for k > row
+    hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, A, ta ? K : M, ta ? M : K, lda, ta ? 1 : 0);
+  if (kmode == 4)                    // op(B)[k, col] = 0 for k > col
+    hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, B, tb ? N : K, tb ? K : N, ldb, tb ? 0 : 1);
+  if (kmode == 7)                    // op(B)[k, col] = 0 for k < col
+    hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, B, tb ? N : K, tb ? K : N, ldb, tb ? 1 : 0);
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.alpha = 0.75; g.beta = beta; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = 1; g.kmode = kmode;
+  int rc = MLN_OK;
+  dgemm_set_mix(0);
+  g.C = C0;
+  rc = launch_dgemm(ctx, g);
+  dgemm_set_mix(any_size ? 1 : -1);
+  g.C = C1;
+  if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+  dgemm_set_mix(-1);
+  if (rc == MLN_OK) {
+    hipLaunchKernelGGL(k_diag_absdiff, dim3(1024), dim3(256), 0, ctx->stream, C0, C1, (int64_t)c_count, ldc, (int)lower_only, res);
+    hipError_t e = hipMemcpyAsync(out, res, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "dgemm compare", __FILE__, __LINE__);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(A); (void)mln_dfree(B); (void)mln_dfree(C0); (void)mln_dfree(C1); (void)mln_dfree(res);
+  return rc;
 }
 
 // ---- stream-overlap probe: does a second stream's MFMA-bound GEMM / latency-bound Cholesky run concurrently

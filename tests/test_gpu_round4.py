@@ -288,3 +288,36 @@ def test_tree_data_sharded_at_scale(mellon, ctx, monkeypatch):
     assert parts[0][2] == parts[1][2]
     sharded = np.concatenate([p[0] for p in parts])
     assert np.abs(sharded - single).max() < 1e-5 * np.abs(single).max()
+
+
+# ---- round 4c: the GEMM's mixed-tile pipelined kernel -------------------------------------------------------------------
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_mixed_tiles_same_bits_as_single_size(ta, tb):
+    """k_dgemm_mix (whole rounds of 128-tiles, the stragglers as 64-wide quadrants, two LDS buffers) sums every element's
+    k in the order the single-size kernels do: the results are the same bits, for every tile set and K-range mode the
+    factorisations and the preconditioner build use (decomposition.py:111-123, conditional.py:57-66)."""
+    from mellon_amd import _lib
+    ctx = _lib.default_context()
+    cases = [  # M, N, K, lower_only, kmode, beta
+        (700, 900, 300, 0, 0, 0.0),      # ragged edges in both directions, K not a multiple of 16
+        (645, 645, 517, 1, 0, -1.0),     # lower triangle of tiles (Cholesky trailing update), beta in the accumulators
+        (645, 645, 645, 2, 0, 0.0),      # strictly lower
+        (645, 645, 645, 3, 0, 0.0),      # upper
+        (768, 768, 768, 0, 1, 0.0),      # block-diagonal op(A)
+        (768, 700, 768, 0, 2, 1.0),      # block-diagonal op(B)
+        (900, 900, 900, 0, 3, 0.0),      # k <= row
+        (900, 900, 900, 0, 4, 0.0),      # k <= column
+        (900, 900, 900, 1, 7, 0.0),      # column <= k <= row, lower tiles
+        (130, 70, 40, 0, 0, 0.5),        # two tiles
+        (64, 64, 8, 0, 0, 0.0),          # one quadrant, one partial k-tile
+    ]
+    for (M, N, K, lo, km, beta) in cases:
+        if km in (1, 3, 7) and K != M:
+            continue
+        d, v = ctx.diag_dgemm_compare(ta, tb, M, N, K, lower_only=lo, kmode=km, beta=beta, any_size=True)
+        assert v > 0.0 and d == 0.0, (M, N, K, lo, km, beta, d, v)
+    # at the size where the policy itself selects the mixed kernel (more than one round of 128-tiles on this GPU)
+    d, v = ctx.diag_dgemm_compare(ta, tb, 3200, 3100, 200, lower_only=0, kmode=0, beta=0.0, any_size=False)
+    assert v > 0.0 and d == 0.0
+    d, v = ctx.diag_dgemm_compare(ta, tb, 4500, 4500, 256, lower_only=1, kmode=0, beta=-1.0, any_size=False)
+    assert v > 0.0 and d == 0.0
