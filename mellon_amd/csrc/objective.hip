@@ -677,55 +677,6 @@ __global__ __launch_bounds__(256) void k_gemv_rows_tri(GemvTri g) {
   }
 }
 
-// The same product with a WORKGROUP per row (round 4c).  With one wave per row a 5000-column row is ten dependent trips of
-// that wave's loop -- ten memory latencies in a row, 38-43 us per launch at 2.3-2.6 TB/s, twice per objective evaluation --
-// while the whole operator is 100 MB.  Here the 256 lanes of a workgroup share the row and every lane asks for up to five
-// 16-byte pieces of it (and of x) before it waits for any: two latencies for the longest row of m = 5000, one for half of
-// the rows.  Pieces past the row's triangle are re-reads of its last piece and are not added.  40 registers: eight
-// workgroups per CU.  Sums: lanes by wave shuffles, the four waves in fixed order -- the same bits on every call.
-// (Measured and dropped: 1024 threads per FOUR rows with three pieces per lane and row -- 71 registers left room for one
-//  workgroup of 16 waves per CU, 51-65 us per launch.)
-__global__ __launch_bounds__(256) void k_gemv_tri_wg(GemvTri g) {
-  if (g.gate && (*g.gate & 3) == MLN_GATE_DONE) return;
-  __shared__ double red[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t r = blockIdx.x;
-  const int64_t i = r % g.blk;
-  const int64_t c_lo = g.upper ? (i & ~(int64_t)1) : 0, c_hi = g.upper ? g.ncol : i + 1;
-  const int64_t p_lo = c_lo / 2, p_hi = c_hi / 2;            // pairs [p_lo, p_hi) are complete
-  double s = 0.0;
-  const int nseg = g.mseg ? 2 : 1;
-  for (int sg = 0; sg < nseg; ++sg) {
-    const double* __restrict__ rb = g.M + r * g.ld + sg * g.mseg;
-    const double* __restrict__ xb = g.x + sg * g.xseg;
-    const d2* __restrict__ row = reinterpret_cast<const d2*>(rb);
-    const d2* __restrict__ xv = reinterpret_cast<const d2*>(xb);
-    for (int64_t p0 = p_lo; p0 < p_hi; p0 += 5 * 256) {
-      d2 a[5], b[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const int64_t p = p0 + tid + 256 * j;
-        const int64_t pc = p < p_hi ? p : p_hi - 1;
-        a[j] = row[pc];
-        b[j] = xv[pc];
-      }
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (p0 + tid + 256 * j < p_hi) s = fma(a[j].y, b[j].y, fma(a[j].x, b[j].x, s));
-    }
-    if ((c_hi & 1) && tid == 0) s = fma(rb[c_hi - 1], xb[c_hi - 1], s);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
-  if (tid == 0) {
-    const double v = (red[0] + red[1]) + (red[2] + red[3]);
-    if (g.y2 && r >= g.blk) g.y2[r - g.blk] = v;
-    else g.y[r] = v;
-  }
-}
-
 template <int CPT, int R, bool VEC = false>
 int launch_mode(mln_ctx* ctx, const ObjArgs& a, int mode) {
   dim3 grid((unsigned)a.n_wg), block(WG);
@@ -900,9 +851,7 @@ int launch_gemv_tri(mln_ctx* ctx, const GemvTri& g) {
     mln_set_error(ctx, "gemv_rows_tri: unaligned operands");
     return MLN_ERR_ARG;
   }
-  static const bool wide = !(mln_experiment("MELLON_AMD_GEMV_WIDE") && std::atoi(mln_experiment("MELLON_AMD_GEMV_WIDE")) == 0);
-  if (wide) hipLaunchKernelGGL(k_gemv_tri_wg, dim3((unsigned)g.rows), dim3(256), 0, ctx->stream, g);
-  else hipLaunchKernelGGL(k_gemv_rows_tri, dim3((unsigned)((g.rows + 3) / 4)), dim3(256), 0, ctx->stream, g);
+  hipLaunchKernelGGL(k_gemv_rows_tri, dim3((unsigned)((g.rows + 3) / 4)), dim3(256), 0, ctx->stream, g);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
