@@ -219,6 +219,7 @@ struct TileMap {
   int64_t n_active;           // tiles that are computed (all, or the triangle lower_only names)
   int64_t n_big;              // the first n_big of them (launch order) as 128-tiles, the rest as quadrants
   int order;                  // 0 row-major, 1 row-major reversed, 2 column-major reversed (the heavy-first orders)
+  int ring;                   // quadrants with four k-tiles in flight where their K range allows (gemm_tile64_ring)
 };
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -389,6 +390,140 @@ __device__ __forceinline__ void gemm_tile_pipelined(const GemmArgs& g, double* C
       }
 }
 
+// The 64-wide tile with FOUR k-tiles in flight (a ring of four register sets, 8 registers each).  A chain link of the
+// factorisations -- 150 workgroups, K = 128 -- and the quadrants at the end of a mixed launch have their CU to themselves:
+// nobody hides the ~2 us a request takes, and with one k-tile in flight each of them waited for it (2.9 us per k-tile of 16
+// matrix instructions per wave).  Conditions (the caller checks them): 16-byte loads possible, the K range a whole number
+// of k-tiles.  Rows past the operand are clamped ONCE, in the thread's base address (they only feed rows / columns of C
+// that are never stored), so the requests themselves are unmasked.
+template <bool AK, bool BKC>
+__device__ __forceinline__ void gemm_tile64_ring(const GemmArgs& g, double* C, const int64_t m0, const int64_t n0,
+                                                 const int64_t kbeg, const int64_t kend, double* smem) {
+  constexpr int BT = 64, BKT = 16, TW = 2, LD = BT + LPAD, NL = 4, D = 4;
+  typedef double (*Tile)[LD];
+  double* const a_base = smem;                     // As[2][BKT][LD]
+  double* const b_base = smem + 2 * BKT * LD;       // Bs[2][BKT][LD]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
+  const int lk = lane >> 4, li = lane & 15;
+  const int64_t T = (kend - kbeg) / BKT;
+
+  // this thread's two 16-byte pieces of each operand's k-tile (see tile_load for who stages what)
+  auto piece_ptrs = [&](auto kcontig, const double* P, int64_t ld, int64_t o0, int64_t O, const double*& q0, const double*& q1, int64_t& step) {
+    if (decltype(kcontig)::value) {
+      int64_t o = o0 + t / 4;
+      o = o < O ? o : O - 1;
+      q0 = P + o * ld + kbeg + (t % 4) * NL;
+      q1 = q0 + 2;
+      step = BKT;
+    } else {
+      const int64_t omax = (O - 1) & ~(int64_t)1;       // (ld is even: the piece that starts at the last even column is in the row)
+      int64_t o = o0 + (t % 16) * NL, o2 = o + 2;
+      o = o < omax ? o : omax;
+      o2 = o2 < omax ? o2 : omax;
+      const double* row = P + (kbeg + t / 16) * ld;
+      q0 = row + o; q1 = row + o2;
+      step = BKT * ld;
+    }
+  };
+  const double *pa0, *pa1, *pb0, *pb1;
+  int64_t a_step, b_step;
+  piece_ptrs(std::integral_constant<bool, AK>{}, g.A, g.lda, m0, g.M, pa0, pa1, a_step);
+  piece_ptrs(std::integral_constant<bool, BKC>{}, g.B, g.ldb, n0, g.N, pb0, pb1, b_step);
+  double ra[D][NL], rb[D][NL];
+  int64_t requested = 0;
+  auto request = [&](auto slot) {       // the next k-tile (if there is one) into register set `slot`
+    constexpr int S = decltype(slot)::value;
+    if (requested < T) {
+      const d2v a0 = *reinterpret_cast<const d2v*>(pa0), a1 = *reinterpret_cast<const d2v*>(pa1);
+      const d2v b0 = *reinterpret_cast<const d2v*>(pb0), b1 = *reinterpret_cast<const d2v*>(pb1);
+      ra[S][0] = a0.x; ra[S][1] = a0.y; ra[S][2] = a1.x; ra[S][3] = a1.y;
+      rb[S][0] = b0.x; rb[S][1] = b0.y; rb[S][2] = b1.x; rb[S][3] = b1.y;
+      pa0 += a_step; pa1 += a_step; pb0 += b_step; pb1 += b_step;
+    }
+    ++requested;
+  };
+  request(std::integral_constant<int, 0>{});
+  request(std::integral_constant<int, 1>{});
+  request(std::integral_constant<int, 2>{});
+  request(std::integral_constant<int, 3>{});
+
+  v4d acc[TW][TW];
+  const bool use_beta = (g.split_k <= 1) && (g.beta != 0.0);
+  const bool beta_in_acc = use_beta && g.alpha != 0.0;
+  if (beta_in_acc) {
+    const double bs = g.beta / g.alpha;
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = m0 + wm + i * 16 + lk + 4 * r;
+          const int64_t col = n0 + wn + j * 16 + li;
+          const int64_t rc = (row < g.M) ? row : (g.M - 1), cc = (col < g.N) ? col : (g.N - 1);
+          acc[i][j][r] = bs * C[rc * g.ldc + cc];
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+      for (int j = 0; j < TW; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  tile_store<AK, BT, BKT>(reinterpret_cast<Tile>(a_base), ra[0]);
+  tile_store<BKC, BT, BKT>(reinterpret_cast<Tile>(b_base), rb[0]);
+  request(std::integral_constant<int, 0>{});          // k-tile 4 into the set k-tile 0 has left
+  lds_only_barrier();
+  int cur = 0;
+  // k-tile j is in LDS buffer `cur`, the registers hold k-tiles j + 1 .. j + 4 (k-tile j + 1 in set S1)
+  auto k_tile = [&](auto slot1, const int64_t j) {
+    constexpr int S1 = decltype(slot1)::value;
+    const Tile Ac = reinterpret_cast<Tile>(a_base + cur * (BKT * LD)), Bc = reinterpret_cast<Tile>(b_base + cur * (BKT * LD));
+    const Tile An = reinterpret_cast<Tile>(a_base + (cur ^ 1) * (BKT * LD)), Bn = reinterpret_cast<Tile>(b_base + (cur ^ 1) * (BKT * LD));
+#pragma unroll
+    for (int kk = 0; kk < BKT; kk += 4) {
+      double a[TW], b[TW];
+#pragma unroll
+      for (int tt = 0; tt < TW; ++tt) {
+        a[tt] = Ac[kk + lk][wm + tt * 16 + li];
+        b[tt] = Bc[kk + lk][wn + tt * 16 + li];
+      }
+      if (kk == 4 && j + 1 < T) {
+        tile_store<AK, BT, BKT>(An, ra[S1]);
+        tile_store<BKC, BT, BKT>(Bn, rb[S1]);
+        request(std::integral_constant<int, S1>{});
+      }
+#pragma unroll
+      for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < TW; ++j2)
+          acc[i][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j2], acc[i][j2], 0, 0, 0);
+    }
+    lds_only_barrier();
+    cur ^= 1;
+  };
+  for (int64_t j0 = 0; j0 < T; j0 += D) {
+    k_tile(std::integral_constant<int, 1>{}, j0);
+    if (j0 + 1 < T) k_tile(std::integral_constant<int, 2>{}, j0 + 1);
+    if (j0 + 2 < T) k_tile(std::integral_constant<int, 3>{}, j0 + 2);
+    if (j0 + 3 < T) k_tile(std::integral_constant<int, 0>{}, j0 + 3);
+  }
+#pragma unroll
+  for (int i = 0; i < TW; ++i)
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm + i * 16 + lk + 4 * r;
+        const int64_t col = n0 + wn + j * 16 + li;
+        if (row < g.M && col < g.N) {
+          double v = g.alpha * acc[i][j][r];
+          if (use_beta && !beta_in_acc) v += g.beta * C[row * g.ldc + col];
+          C[row * g.ldc + col] = v;
+        }
+      }
+}
+
 // K range of the 128-wide tile at (m0, n0) (the same rules as k_dgemm above)
 __device__ __forceinline__ void tile_k_range(const GemmArgs& g, int64_t m0, int64_t n0, int64_t kchunk, int64_t& kbeg, int64_t& kend) {
   kbeg = (int64_t)blockIdx.y * kchunk;
@@ -404,7 +539,7 @@ __device__ __forceinline__ void tile_k_range(const GemmArgs& g, int64_t m0, int6
 }
 
 template <bool AK, bool BKC, bool VEC, bool ONLY64>
-__global__ __launch_bounds__(256, ONLY64 ? 4 : 2) void k_dgemm_mix(GemmArgs g, TileMap tmap, int64_t kchunk) {
+__global__ __launch_bounds__(256, ONLY64 ? 3 : 2) void k_dgemm_mix(GemmArgs g, TileMap tmap, int64_t kchunk) {
   extern __shared__ __attribute__((aligned(16))) double dgemm_smem[];
   const int64_t bid = blockIdx.x;
   const bool big = !ONLY64 && bid < tmap.n_big;
@@ -426,7 +561,10 @@ __global__ __launch_bounds__(256, ONLY64 ? 4 : 2) void k_dgemm_mix(GemmArgs g, T
   } else {
     const int64_t qm = m0 + 64 * (quad >> 1), qn = n0 + 64 * (quad & 1);
     if (qm >= g.M || qn >= g.N) return;
-    gemm_tile_pipelined<AK, BKC, 64, VEC>(g, C, qm, qn, kbeg, kend, dgemm_smem);
+    if (VEC && tmap.ring && kend - kbeg >= 5 * 16 && ((kend - kbeg) & 15) == 0)
+      gemm_tile64_ring<AK, BKC>(g, C, qm, qn, kbeg, kend, dgemm_smem);
+    else
+      gemm_tile_pipelined<AK, BKC, 64, VEC>(g, C, qm, qn, kbeg, kend, dgemm_smem);
   }
 }
 
@@ -508,6 +646,8 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   if ((n_active - n_big) * 4 >= 3 * per_round || mode == 2) n_big = n_active;
   if (mode == 3) n_big = 0;
   tmap.n_big = n_big;
+  static const int ring = mln_experiment("MELLON_AMD_GEMM_RING") ? std::atoi(mln_experiment("MELLON_AMD_GEMM_RING")) : 1;
+  tmap.ring = ring;
   const int64_t nblk = n_big + 4 * (n_active - n_big);
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }
   const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0);

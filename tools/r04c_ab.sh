@@ -1,14 +1,14 @@
 #!/bin/bash
-# A/B of the round-4c GEMM policy on ONE box (run through gpurun): the same bench command under each setting, twice,
-# interleaved.  default = k_dgemm_mix for every launch that does not alias its operands; mix0 = the single-size kernels of
-# round 3 (MELLON_AMD_GEMM_MIX=0); mixmin512 = k_dgemm_mix only from one round of 128-tiles up.
+# A/B of the round-4c GEMM switches on ONE box (run through gpurun): the same bench command under each setting, twice,
+# interleaved.  default = k_dgemm_mix for every launch that does not alias its operands, quadrants with four k-tiles in
+# flight; ring0 = quadrants with one k-tile in flight; mix0 = the single-size kernels of round 3.
 B="python bench.py --landmark-method device --cpu-sample 0 --steps 6 --warmup 2 --extra-steps 0"
-O=gpurun_out/ab; mkdir -p $O
+O=gpurun_out/ab; mkdir -p $O; rm -f $O/*
 $B > $O/warm.json 2> $O/warm.err
 for rep in 1 2; do
   $B > $O/default_$rep.json 2> $O/default_$rep.err
+  MELLON_AMD_EXPERIMENTAL=1 MELLON_AMD_GEMM_RING=0 $B > $O/ring0_$rep.json 2> $O/ring0_$rep.err
   MELLON_AMD_EXPERIMENTAL=1 MELLON_AMD_GEMM_MIX=0 $B > $O/mix0_$rep.json 2> $O/mix0_$rep.err
-  MELLON_AMD_EXPERIMENTAL=1 MELLON_AMD_GEMM_MIX_MIN=512 $B > $O/mixmin512_$rep.json 2> $O/mixmin512_$rep.err
 done
 python - <<'PY'
 import json, glob
