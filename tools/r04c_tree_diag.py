@@ -16,6 +16,18 @@ x = tree_cells(n, d, rng)
 xd = ctx.to_device(np.ascontiguousarray(x))
 nn = ctx.nn_distances(xd, xd)
 lm = ctx.kmeans(x[:100_000], m, seed=42)
+if "--suite-order" in sys.argv:        # the fits tests/test_gpu_round4.py runs before the guard-off ones, in its order
+    for env in ({"MELLON_AMD_MIXED": "0", "MELLON_AMD_SUBSAMPLE": "0", "MELLON_AMD_REBUILD": "0"}, {"MELLON_AMD_MIXED": "0"}, {}):
+        for k in ("MELLON_AMD_MIXED", "MELLON_AMD_SUBSAMPLE", "MELLON_AMD_REBUILD", "MELLON_AMD_REBUILD_RANGE"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        est = mellon_amd.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
+        est.fit_predict(xd)
+        print(f"(before) {env} success={est.opt_state.success} nfev={est.opt_state.nfev}", flush=True)
+        est._fit.close()
+    for k in ("MELLON_AMD_MIXED", "MELLON_AMD_SUBSAMPLE", "MELLON_AMD_REBUILD"):
+        os.environ.pop(k, None)
+    os.environ["MELLON_AMD_REBUILD_RANGE"] = "1e300"
 for mixed in ("0", "1"):
     os.environ["MELLON_AMD_MIXED"] = mixed
     est = mellon_amd.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
