@@ -394,7 +394,7 @@ __device__ __forceinline__ void gemm_tile_pipelined(const GemmArgs& g, double* C
 // factorisations -- 150 workgroups, K = 128 -- and the quadrants at the end of a mixed launch have their CU to themselves:
 // nobody hides the ~2 us a request takes, and with one k-tile in flight each of them waited for it (2.9 us per k-tile of 16
 // matrix instructions per wave).  Conditions (the caller checks them): 16-byte loads possible, the K range a whole number
-// of k-tiles.  Rows past the operand are clamped ONCE, in the thread's base address (they only feed rows / columns of C
+// of GROUPS of four k-tiles (the block sizes of the factorisations are: 128, 256, ...).  Rows past the operand are clamped ONCE, in the thread's base address (they only feed rows / columns of C
 // that are never stored), so the requests themselves are unmasked.
 template <bool AK, bool BKC>
 __device__ __forceinline__ void gemm_tile64_ring(const GemmArgs& g, double* C, const int64_t m0, const int64_t n0,
@@ -432,16 +432,18 @@ __device__ __forceinline__ void gemm_tile64_ring(const GemmArgs& g, double* C, c
   piece_ptrs(std::integral_constant<bool, BKC>{}, g.B, g.ldb, n0, g.N, pb0, pb1, b_step);
   double ra[D][NL], rb[D][NL];
   int64_t requested = 0;
-  auto request = [&](auto slot) {       // the next k-tile (if there is one) into register set `slot`
+  // the next k-tile into register set `slot`.  No branch: past the last k-tile the pointers stop and the request is a
+  // re-read of that one (never multiplied) -- a branch around the loads makes the compiler's wait-count bookkeeping give up
+  // at the join and wait for EVERY outstanding load (vmcnt(0)) before each store, which is the ring undone.
+  auto request = [&](auto slot) {
     constexpr int S = decltype(slot)::value;
-    if (requested < T) {
-      const d2v a0 = *reinterpret_cast<const d2v*>(pa0), a1 = *reinterpret_cast<const d2v*>(pa1);
-      const d2v b0 = *reinterpret_cast<const d2v*>(pb0), b1 = *reinterpret_cast<const d2v*>(pb1);
-      ra[S][0] = a0.x; ra[S][1] = a0.y; ra[S][2] = a1.x; ra[S][3] = a1.y;
-      rb[S][0] = b0.x; rb[S][1] = b0.y; rb[S][2] = b1.x; rb[S][3] = b1.y;
-      pa0 += a_step; pa1 += a_step; pb0 += b_step; pb1 += b_step;
-    }
+    const d2v a0 = *reinterpret_cast<const d2v*>(pa0), a1 = *reinterpret_cast<const d2v*>(pa1);
+    const d2v b0 = *reinterpret_cast<const d2v*>(pb0), b1 = *reinterpret_cast<const d2v*>(pb1);
+    ra[S][0] = a0.x; ra[S][1] = a0.y; ra[S][2] = a1.x; ra[S][3] = a1.y;
+    rb[S][0] = b0.x; rb[S][1] = b0.y; rb[S][2] = b1.x; rb[S][3] = b1.y;
     ++requested;
+    const int64_t sa = requested < T ? a_step : 0, sb = requested < T ? b_step : 0;
+    pa0 += sa; pa1 += sa; pb0 += sb; pb1 += sb;
   };
   request(std::integral_constant<int, 0>{});
   request(std::integral_constant<int, 1>{});
@@ -488,7 +490,7 @@ __device__ __forceinline__ void gemm_tile64_ring(const GemmArgs& g, double* C, c
         a[tt] = Ac[kk + lk][wm + tt * 16 + li];
         b[tt] = Bc[kk + lk][wn + tt * 16 + li];
       }
-      if (kk == 4 && j + 1 < T) {
+      if (kk == 4) {          // (after the last k-tile: a store nobody reads, a request nobody uses)
         tile_store<AK, BT, BKT>(An, ra[S1]);
         tile_store<BKC, BT, BKT>(Bn, rb[S1]);
         request(std::integral_constant<int, S1>{});
@@ -502,11 +504,11 @@ __device__ __forceinline__ void gemm_tile64_ring(const GemmArgs& g, double* C, c
     lds_only_barrier();
     cur ^= 1;
   };
-  for (int64_t j0 = 0; j0 < T; j0 += D) {
+  for (int64_t j0 = 0; j0 < T; j0 += D) {        // T is a multiple of four (the caller's condition)
     k_tile(std::integral_constant<int, 1>{}, j0);
-    if (j0 + 1 < T) k_tile(std::integral_constant<int, 2>{}, j0 + 1);
-    if (j0 + 2 < T) k_tile(std::integral_constant<int, 3>{}, j0 + 2);
-    if (j0 + 3 < T) k_tile(std::integral_constant<int, 0>{}, j0 + 3);
+    k_tile(std::integral_constant<int, 2>{}, j0 + 1);
+    k_tile(std::integral_constant<int, 3>{}, j0 + 2);
+    k_tile(std::integral_constant<int, 0>{}, j0 + 3);
   }
 #pragma unroll
   for (int i = 0; i < TW; ++i)
@@ -538,8 +540,13 @@ __device__ __forceinline__ void tile_k_range(const GemmArgs& g, int64_t m0, int6
   }
 }
 
-template <bool AK, bool BKC, bool VEC, bool ONLY64>
-__global__ __launch_bounds__(256, ONLY64 ? 3 : 2) void k_dgemm_mix(GemmArgs g, TileMap tmap, int64_t kchunk) {
+// MODE 0: 128-tiles and quadrants (252 registers, 72 KB of LDS: two workgroups per CU).  MODE 1: quadrants only, one k-tile in
+// flight (95 registers, 40 KB: four per CU) -- launches with more quadrants than two per CU, where the neighbours hide the
+// latency and occupancy is what counts (2000^3: 0.35 ms against 0.42 with the ring's 150 registers).  MODE 2: quadrants only,
+// four k-tiles in flight (three per CU) -- the chain links.
+template <bool AK, bool BKC, bool VEC, int MODE>
+__global__ __launch_bounds__(256, MODE == 1 ? 4 : (MODE == 2 ? 3 : 2)) void k_dgemm_mix(GemmArgs g, TileMap tmap, int64_t kchunk) {
+  constexpr bool ONLY64 = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) double dgemm_smem[];
   const int64_t bid = blockIdx.x;
   const bool big = !ONLY64 && bid < tmap.n_big;
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256, ONLY64 ? 3 : 2) void k_dgemm_mix(GemmArgs g, T
   } else {
     const int64_t qm = m0 + 64 * (quad >> 1), qn = n0 + 64 * (quad & 1);
     if (qm >= g.M || qn >= g.N) return;
-    if (VEC && tmap.ring && kend - kbeg >= 5 * 16 && ((kend - kbeg) & 15) == 0)
+    if (VEC && MODE != 1 && tmap.ring && kend - kbeg >= 8 * 16 && ((kend - kbeg) & 63) == 0)
       gemm_tile64_ring<AK, BKC>(g, C, qm, qn, kbeg, kend, dgemm_smem);
     else
       gemm_tile_pipelined<AK, BKC, 64, VEC>(g, C, qm, qn, kbeg, kend, dgemm_smem);
@@ -598,7 +605,7 @@ static int64_t count_active(int lower_only, int64_t tm, int64_t tn) {
   return q * (q + 1) / 2 + (tn > tm ? (tn - tm) * tm : 0);                             // tn >= tm
 }
 
-template <bool VEC, bool ONLY64>
+template <bool VEC, int MODE>
 static hipError_t dispatch_mix(const GemmArgs& g, const TileMap& tmap, dim3 grid, size_t lds, hipStream_t st, int64_t kchunk) {
   const bool ak = (g.ta == 0), bk = (g.tb == 1);
   dim3 block(256);
@@ -606,12 +613,12 @@ static hipError_t dispatch_mix(const GemmArgs& g, const TileMap& tmap, dim3 grid
   do {                                                                                                                      \
     static bool attr_set = false;                                                                                           \
     if (!attr_set) {                                                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mix<A_, B_, VEC, ONLY64>),                   \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_mix<A_, B_, VEC, MODE>),                   \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * (128 + LPAD) * 8);            \
       if (e != hipSuccess) return e;                                                                                        \
       attr_set = true;                                                                                                      \
     }                                                                                                                       \
-    hipLaunchKernelGGL((k_dgemm_mix<A_, B_, VEC, ONLY64>), grid, block, lds, st, g, tmap, kchunk);                          \
+    hipLaunchKernelGGL((k_dgemm_mix<A_, B_, VEC, MODE>), grid, block, lds, st, g, tmap, kchunk);                          \
   } while (0)
   if (ak && bk) MLN_MIX_LAUNCH(true, true);
   else if (ak && !bk) MLN_MIX_LAUNCH(true, false);
@@ -658,10 +665,11 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   hipError_t e;
   if (n_big == 0) {
     const size_t lds = 4 * 16 * (64 + LPAD) * 8;
-    e = vec ? dispatch_mix<true, true>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, true>(g, tmap, grid, lds, ctx->stream, kchunk);
+    if (vec && tmap.ring && nblk * split <= 2 * n_cu) e = dispatch_mix<true, 2>(g, tmap, grid, lds, ctx->stream, kchunk);
+    else e = vec ? dispatch_mix<true, 1>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, 1>(g, tmap, grid, lds, ctx->stream, kchunk);
   } else {
     const size_t lds = 4 * 16 * (128 + LPAD) * 8;
-    e = vec ? dispatch_mix<true, false>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, false>(g, tmap, grid, lds, ctx->stream, kchunk);
+    e = vec ? dispatch_mix<true, 0>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, 0>(g, tmap, grid, lds, ctx->stream, kchunk);
   }
   MLN_HIP(ctx, e);
   return MLN_OK;
