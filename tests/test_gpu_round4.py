@@ -65,7 +65,11 @@ def test_inputs_the_shortcuts_were_not_tuned_on(mellon, ctx, monkeypatch, case):
     x = tree_cells(n, d, rng) if case == "tree" else rng.standard_t(3, size=(n, d))
     xd = ctx.to_device(np.ascontiguousarray(x))
     nn = ctx.nn_distances(xd, xd)
-    lm = ctx.kmeans(x[:100_000], m, seed=42)
+    # Landmarks: a seeded subset of the cells.  (Until round 4c: mln_kmeans -- whose fp64 atomics make the centres reproducible
+    # to rounding, not bitwise, csrc/kmeans.hip -- so that the guard-off variants below, 500-1000-pass solves that are chaotic
+    # in the low-order bits, passed or failed from run to run of the very same code: tools/r04c_tree_inputs_determinism.py.
+    # The fit itself is bit-reproducible on identical inputs.)
+    lm = np.ascontiguousarray(x[np.sort(np.random.default_rng(42).choice(100_000, m, replace=False))])
     plain = _fit(mellon, xd, lm, nn, monkeypatch, MELLON_AMD_MIXED="0", MELLON_AMD_SUBSAMPLE="0", MELLON_AMD_REBUILD="0")
     assert plain[1].success and np.isfinite(plain[3])
     scale = np.abs(plain[0]).max()
