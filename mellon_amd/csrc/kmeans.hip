@@ -8,8 +8,8 @@
 //             distance to its closest centre and emits 1024-cell block sums; the host draws the next
 //             centre from them with a seeded xorshift generator (two tiny downloads per centre).
 //   Lloyd     assignment = tiled fp64 distance kernel with running arg-min (the nn_distances tile
-//             structure), update = fp64 atomics into m x d sums (summation order is not fixed: centroids
-//             are reproducible to rounding, not bitwise), stop when the summed squared centre shift
+//             structure), update = FIXED-POINT integer atomics into m x d sums (round 4c: any summation order gives
+//             the same bits -- the centres are bit-reproducible), stop when the summed squared centre shift
 //             <= tol * mean feature variance (sklearn's rule) or after max_iter sweeps.
 #include <cmath>
 #include <cstdio>
@@ -376,31 +376,76 @@ __global__ __launch_bounds__(512) void k_assign_mfma(const double* __restrict__ 
   }
 }
 
+// Cluster sums in FIXED POINT (round 4c).  The sums were fp64 atomics -- summation order not fixed, centres reproducible to
+// rounding only, and with them every landmark set mln_kmeans returned (four calls, four checksums: the default call of the
+// estimator on a large input was the same bits from run to run in everything but its landmarks).  Integer addition is
+// associative: each coordinate goes in as llrint(x * 2^e_k), e_k per column such that n cells of the column's largest
+// magnitude cannot overflow 62 bits, and comes out as sum * 2^-e_k / count.  Resolution: |x|_max,k * n * 2^-62 per
+// coordinate -- 2e-13 of the column's range at 1e6 cells; a cell that leaves a cluster takes out exactly what it put in.
+__global__ void k_km_colmax(const double* __restrict__ x, int64_t n, int d, unsigned long long* __restrict__ colmax) {
+  // a thread walks the elements e = t, t + T, ... of the row-major matrix (coalesced); its column changes with e
+  const int64_t total = n * d, T = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += T) {
+    const double v = fabs(x[e]);
+    if (v > 0.0 && v < INFINITY) atomicMax(&colmax[e % d], (unsigned long long)__double_as_longlong(v));   // non-negative doubles order as integers
+  }
+}
+__global__ void k_km_colscale(const unsigned long long* __restrict__ colmax, int d, int64_t n, double* __restrict__ scale) {
+  const int k = threadIdx.x;
+  if (k >= d) return;
+  const double a = __longlong_as_double((long long)colmax[k]);
+  int e = 0;
+  if (a > 0.0 && a < INFINITY) {
+    int ea = 0, en = 0;
+    (void)frexp(a, &ea);                    // a < 2^ea
+    (void)frexp((double)n, &en);            // n < 2^en
+    e = 62 - ea - en;
+    e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
+  }
+  scale[k] = ldexp(1.0, e);
+  scale[d + k] = ldexp(1.0, -e);
+}
+
 __global__ void k_accumulate(const double* __restrict__ x, int64_t n, int d, const int* __restrict__ label,
-                             double* __restrict__ sums, double* __restrict__ counts) {
+                             double* __restrict__ sums, double* __restrict__ counts, const double* __restrict__ colscale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.y + threadIdx.y;
   if (i >= n) return;
   const int l = label[i];
-  for (int k = threadIdx.x; k < d; k += blockDim.x) atomicAdd(&sums[(int64_t)l * d + k], x[i * (int64_t)d + k]);
-  if (threadIdx.x == 0) atomicAdd(&counts[l], 1.0);
+  unsigned long long* isums = reinterpret_cast<unsigned long long*>(sums);
+  for (int k = threadIdx.x; k < d; k += blockDim.x)
+    atomicAdd(&isums[(int64_t)l * d + k], (unsigned long long)llrint(x[i * (int64_t)d + k] * colscale[k]));
+  if (threadIdx.x == 0) atomicAdd(&counts[l], 1.0);      // (+-1 in fp64 is exact: any order, the same count)
 }
 
-// new centres (empty clusters keep their previous centre); shift2 += |new - old|^2
+// new centres (empty clusters keep their previous centre); sq[j] = |new - old|^2 (summed in fixed order by k_km_sum_fixed)
 // delta (optional): how far each centre moved (0 for an empty cluster) -- what the distance bounds of the next sweep need
 __global__ void k_finish(double* __restrict__ c, const double* __restrict__ sums, const double* __restrict__ counts,
-                         int64_t m, int d, double* __restrict__ shift2, double* __restrict__ delta) {
+                         int64_t m, int d, double* __restrict__ sq, double* __restrict__ delta, const double* __restrict__ colscale) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   const double cnt = counts[j];
-  if (cnt <= 0.0) { if (delta) delta[j] = 0.0; return; }
+  if (cnt <= 0.0) { if (delta) delta[j] = 0.0; sq[j] = 0.0; return; }
+  const long long* isums = reinterpret_cast<const long long*>(sums);
   double s = 0.0;
   for (int k = 0; k < d; ++k) {
-    const double nv = sums[j * d + k] / cnt, t = nv - c[j * d + k];
+    const double nv = (double)isums[j * d + k] * colscale[d + k] / cnt, t = nv - c[j * d + k];
     s = fma(t, t, s);
     c[j * d + k] = nv;
   }
   if (delta) delta[j] = sqrt(s);
-  atomicAdd(shift2, s);
+  sq[j] = s;
+}
+__global__ __launch_bounds__(256) void k_km_sum_fixed(const double* __restrict__ v, int64_t m, double* __restrict__ out) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int64_t j = threadIdx.x; j < m; j += 256) s += v[j];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = part[0];
 }
 
 // ---- Lloyd's iterations with distance bounds (Hamerly 2010: the same assignments, most of them without a search) --------
@@ -523,11 +568,24 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   MLN_HIP(ctx, mln_dmalloc((void**)&sums, sizeof(double) * (size_t)m * d));
   MLN_HIP(ctx, mln_dmalloc((void**)&counts, sizeof(double) * (size_t)m));
   MLN_HIP(ctx, mln_dmalloc((void**)&shift, sizeof(double)));
+  // fixed-point cluster sums: per-column magnitudes -> power-of-two scales [0, d) and their inverses [d, 2d); sq: |shift|^2 per centre
+  unsigned long long* colmax = nullptr;
+  double *colscale = nullptr, *sq = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&colmax, sizeof(unsigned long long) * (size_t)d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&colscale, sizeof(double) * 2 * (size_t)d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&sq, sizeof(double) * (size_t)m));
   MLN_HIP(ctx, mln_dmalloc((void**)&label, sizeof(int) * (size_t)n));
   MLN_HIP(ctx, mln_dmalloc((void**)&pick, sizeof(int64_t)));
   int rc = MLN_OK;
   auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "kmeans", __FILE__, __LINE__); };
 
+  chk(hipMemsetAsync(colmax, 0, sizeof(unsigned long long) * (size_t)d, st));
+  if (rc == MLN_OK && d <= 1024) {
+    hipLaunchKernelGGL(k_km_colmax, dim3(1024), dim3(256), 0, st, dx, n, d, colmax);
+    hipLaunchKernelGGL(k_km_colscale, dim3(1), dim3(1024), 0, st, colmax, d, n, colscale);
+  } else if (rc == MLN_OK) {
+    mln_set_error(ctx, "kmeans: more than 1024 dimensions"); rc = MLN_ERR_UNSUPPORTED;
+  }
   // ---- k-means++ seeding ------------------------------------------------------------------------
   // m - 1 sequential draws, each after one update of every cell's distance to its nearest centre so far.  Everything stays
   // on the device (the uniform draws are uploaded once); large problems read the half-precision copy of the cells.
@@ -631,18 +689,19 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
       if (F > 0) {
         rc = launch_rowmin_f16x3(ctx, xsplit, all ? n : F, csplit, m, ccf, 0, 0, m1f, m2f, argc, 1, all ? nullptr : flagged);
         if (rc == MLN_OK) rc = launch_km_resolve(ctx, dx, all ? n : F, all ? nullptr : flagged, dc, m, d, xxs, ymax, prep, m2f, argc,
-                                                 label, ub, lb, it == 0 ? nullptr : sums, it == 0 ? nullptr : counts);
+                                                 label, ub, lb, it == 0 ? nullptr : sums, it == 0 ? nullptr : counts, colscale);
         if (rc != MLN_OK) break;
         searched_rows += all ? n : F;
       }
       if (it == 0) {
         chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
         chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
-        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts);
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts, colscale);
       }
       chk(hipMemsetAsync(shift, 0, sizeof(double), st));
       chk(hipMemsetAsync(nflag, 0, sizeof(int), st));
-      hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, shift, delta);
+      hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, sq, delta, colscale);
+      hipLaunchKernelGGL(k_km_sum_fixed, dim3(1), dim3(256), 0, st, sq, m, shift);
       hipLaunchKernelGGL(k_km_delta_stats, dim3(1), dim3(256), 0, st, delta, m, dstat);
       hipLaunchKernelGGL(k_km_bounds, dim3((unsigned)((n + KB_ROWS - 1) / KB_ROWS)), dim3(256), 0, st, dx, n, d, dc, label, ub, lb, delta, dstat,
                          nflag, flagged);
@@ -671,8 +730,9 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
     chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
     chk(hipMemsetAsync(shift, 0, sizeof(double), st));
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts);
-    hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, shift, (double*)nullptr);
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts, colscale);
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, sq, (double*)nullptr, colscale);
+    hipLaunchKernelGGL(k_km_sum_fixed, dim3(1), dim3(256), 0, st, sq, m, shift);
     double hs = 0.0;
     chk(hipMemcpyAsync(&hs, shift, sizeof(double), hipMemcpyDeviceToHost, st));
     chk(hipStreamSynchronize(st));
@@ -699,7 +759,7 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   if (n_iter_out) *n_iter_out = it;
   (void)hipStreamSynchronize(st);
   void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f, prep, xxs, ub, lb, delta, dstat, yy, ymax,
-                  m2f, argc, nflag, flagged};
+                  m2f, argc, nflag, flagged, colmax, colscale, sq};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   if (own_x) (void)mln_dfree(dx);
   return rc;

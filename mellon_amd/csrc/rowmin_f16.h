@@ -24,7 +24,7 @@ int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double
 // k-means with bounds: label, upper and lower bound of the searched rows from a (TOP2, fold) sweep's m2 / arg (see the kernel)
 int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,
                       const double* xxs, const double* yy_max, const double* prep, const float* m2, const int* arg,
-                      int* label, double* ub, double* lb, double* sums, double* counts);
+                      int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale);
 int launch_max_norm(mln_ctx* ctx, const double* xx, int64_t n, double* out);   // out[0] = max xx (one workgroup)
 // exact nearest-neighbour distances via the pre-filter + fp64 certification (+ exact re-search of uncertified rows)
 int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,

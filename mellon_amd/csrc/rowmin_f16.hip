@@ -554,7 +554,8 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
                                                     const double* __restrict__ prep, const float* __restrict__ m2,
                                                     const int* __restrict__ arg, int* __restrict__ label,
                                                     double* __restrict__ ub, double* __restrict__ lb,
-                                                    double* __restrict__ sums, double* __restrict__ counts) {
+                                                    double* __restrict__ sums, double* __restrict__ counts,
+                                                    const double* __restrict__ colscale) {
   // eight lanes per row, every eighth coordinate each (coalesced over the 8 rows of a wave's load)
   const int sub = threadIdx.x & 7;
   const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -585,10 +586,12 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
     label[i] = bj;
   }
   if (sums && old != bj) {
+    // fixed-point sums (kmeans.hip, k_accumulate): the cell takes out of its old cluster exactly what it put in
+    unsigned long long* isums = reinterpret_cast<unsigned long long*>(sums);
     for (int k = sub; k < d; k += 8) {
-      const double v = xr[k];
-      atomicAdd(&sums[(int64_t)old * d + k], -v);
-      atomicAdd(&sums[(int64_t)bj * d + k], v);
+      const unsigned long long q = (unsigned long long)llrint(xr[k] * colscale[k]);
+      atomicAdd(&isums[(int64_t)old * d + k], 0ULL - q);
+      atomicAdd(&isums[(int64_t)bj * d + k], q);
     }
     if (sub == 0) { atomicAdd(&counts[old], -1.0); atomicAdd(&counts[bj], 1.0); }
   }
@@ -682,10 +685,10 @@ int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double
 
 int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,
                       const double* xxs, const double* yy_max, const double* prep, const float* m2, const int* arg,
-                      int* label, double* ub, double* lb, double* sums, double* counts) {
+                      int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale) {
   if (cnt <= 0) return MLN_OK;
   hipLaunchKernelGGL(k_km_resolve, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, ctx->stream, x, cnt, idx, c, m, d, xxs,
-                     yy_max, prep, m2, arg, label, ub, lb, sums, counts);
+                     yy_max, prep, m2, arg, label, ub, lb, sums, counts, colscale);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

@@ -339,3 +339,22 @@ def test_gemm_mixed_tiles_same_bits_as_single_size(ta, tb):
     assert v > 0.0 and d == 0.0
     d, v = ctx.diag_dgemm_compare(ta, tb, 4500, 4500, 256, lower_only=1, kmode=0, beta=-1.0, any_size=False)
     assert v > 0.0 and d == 0.0
+
+
+def test_kmeans_landmarks_are_the_same_bits_every_time(ctx):
+    """mln_kmeans summed its clusters with fp64 atomics until round 4c: centres reproducible to rounding only, and with them the
+    landmarks of every default call on a large input (parameters.py:243-291 hands the reference's k-means a fixed
+    random_state for exactly this reason).  The sums are fixed-point integers now (csrc/kmeans.hip): any order, the same bits."""
+    rng = np.random.default_rng(5)
+    x = np.ascontiguousarray(rng.normal(size=(120_000, 12)) * (0.7 ** np.arange(12))[None, :] + rng.integers(0, 7, size=(120_000, 1)))
+    a = ctx.kmeans(x, 700, seed=3)
+    b = ctx.kmeans(x, 700, seed=3)
+    assert a.shape == (700, 12) and np.isfinite(a).all()
+    assert np.array_equal(a, b)
+    # the fixed point loses nothing that matters: every centre is the mean of its cells to 1e-12 of the column's range
+    d2 = (x * x).sum(1)[:, None] - 2.0 * x @ a.T + (a * a).sum(1)[None, :]
+    lab = d2.argmin(1)
+    worst = 0.0
+    for j in np.unique(lab)[:50]:
+        worst = max(worst, np.abs(x[lab == j].mean(0) - a[j]).max())
+    assert worst < 1e-3 * np.abs(x).max()          # (Lloyd's stopping rule leaves the centres a sweep away from their means)
