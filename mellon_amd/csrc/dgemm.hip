@@ -638,8 +638,8 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   const int64_t slots = 2 * n_cu;
   const int split = g.split_k > 1 ? g.split_k : 1;
   static const int64_t min_tiles = mln_experiment("MELLON_AMD_GEMM_MIX_MIN") ? std::atoll(mln_experiment("MELLON_AMD_GEMM_MIX_MIN")) : -1;
-  // (below one round of 128-tiles the launch is all quadrants, served by the ONLY64 instance -- 95 registers, 40 KB of LDS,
-  //  four workgroups per CU.  Measured against k_dgemm's 64-wide tiles on the chains of the factorisations (A/B on one box,
+  // (below one round of 128-tiles the launch is all quadrants, served by the quadrant-only instances -- MODE 1 / 2 of
+  //  k_dgemm_mix, 40 KB of LDS.  Measured against k_dgemm's 64-wide tiles on the chains of the factorisations (A/B on one box,
   //  tools/r04c_ab.sh): chol(5000) 4.5 -> 4.2 ms, Ridge solve 8.6 -> 8.2 ms, rebuild 17.0 -> 16.5 ms.  MELLON_AMD_GEMM_MIX_MIN
   //  restores a threshold in 128-tiles for experiments.)
   if (!any_size && n_active * split < (min_tiles >= 0 ? min_tiles : 0)) return MLN_ERR_UNSUPPORTED;
