@@ -647,10 +647,12 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   tmap.tiles_m = tiles_m; tmap.tiles_n = tiles_n; tmap.n_active = n_active;
   const bool heavy_last = g.kmode == 3 || g.kmode == 7 || g.kmode == 4;
   tmap.order = heavy_last ? ((g.kmode == 4 && g.lower_only == 0) ? 2 : 1) : 0;
-  // whole rounds as 128-tiles; a last round that is at least three quarters full stays 128-wide as well
+  // whole rounds as 128-tiles; a last round that is at least seven eighths full stays 128-wide as well (K = 128 links of the
+  // triangular inverses: 384 tiles as 128-tiles 53.6 us, 375 as 1500 quadrants 45.6 us -- the crossover is near 440 of 512)
   const int64_t per_round = slots / split > 0 ? slots / split : 1;
   int64_t n_big = (n_active / per_round) * per_round;
-  if ((n_active - n_big) * 4 >= 3 * per_round || mode == 2) n_big = n_active;
+  static const int64_t keep8 = mln_experiment("MELLON_AMD_GEMM_KEEP8") ? std::atoll(mln_experiment("MELLON_AMD_GEMM_KEEP8")) : 7;
+  if ((n_active - n_big) * 8 >= keep8 * per_round || mode == 2) n_big = n_active;
   if (mode == 3) n_big = 0;
   tmap.n_big = n_big;
   static const int ring = mln_experiment("MELLON_AMD_GEMM_RING") ? std::atoi(mln_experiment("MELLON_AMD_GEMM_RING")) : 1;
@@ -665,7 +667,10 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   hipError_t e;
   if (n_big == 0) {
     const size_t lds = 4 * 16 * (64 + LPAD) * 8;
-    if (vec && tmap.ring && nblk * split <= 2 * n_cu) e = dispatch_mix<true, 2>(g, tmap, grid, lds, ctx->stream, kchunk);
+    // the ring: launches of at most two quadrants per CU, and (MELLON_AMD_GEMM_RING=2, experiment) every launch all of whose K
+    // ranges qualify for it -- full K, a whole number of groups of four k-tiles
+    const bool all_ring = tmap.ring >= 2 && g.kmode == 0 && split == 1 && g.K >= 128 && (g.K & 63) == 0;
+    if (vec && tmap.ring && (nblk * split <= 2 * n_cu || all_ring)) e = dispatch_mix<true, 2>(g, tmap, grid, lds, ctx->stream, kchunk);
     else e = vec ? dispatch_mix<true, 1>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, 1>(g, tmap, grid, lds, ctx->stream, kchunk);
   } else {
     const size_t lds = 4 * 16 * (128 + LPAD) * 8;
