@@ -391,19 +391,19 @@ __global__ void k_km_colmax(const double* __restrict__ x, int64_t n, int d, unsi
   }
 }
 __global__ void k_km_colscale(const unsigned long long* __restrict__ colmax, int d, int64_t n, double* __restrict__ scale) {
-  const int k = threadIdx.x;
-  if (k >= d) return;
-  const double a = __longlong_as_double((long long)colmax[k]);
-  int e = 0;
-  if (a > 0.0 && a < INFINITY) {
-    int ea = 0, en = 0;
-    (void)frexp(a, &ea);                    // a < 2^ea
-    (void)frexp((double)n, &en);            // n < 2^en
-    e = 62 - ea - en;
-    e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
+  for (int k = threadIdx.x; k < d; k += blockDim.x) {
+    const double a = __longlong_as_double((long long)colmax[k]);
+    int e = 0;
+    if (a > 0.0 && a < INFINITY) {
+      int ea = 0, en = 0;
+      (void)frexp(a, &ea);                    // a < 2^ea
+      (void)frexp((double)n, &en);            // n < 2^en
+      e = 62 - ea - en;
+      e = e > 1000 ? 1000 : (e < -1000 ? -1000 : e);
+    }
+    scale[k] = ldexp(1.0, e);
+    scale[d + k] = ldexp(1.0, -e);
   }
-  scale[k] = ldexp(1.0, e);
-  scale[d + k] = ldexp(1.0, -e);
 }
 
 __global__ void k_accumulate(const double* __restrict__ x, int64_t n, int d, const int* __restrict__ label,
@@ -580,11 +580,9 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "kmeans", __FILE__, __LINE__); };
 
   chk(hipMemsetAsync(colmax, 0, sizeof(unsigned long long) * (size_t)d, st));
-  if (rc == MLN_OK && d <= 1024) {
+  if (rc == MLN_OK) {
     hipLaunchKernelGGL(k_km_colmax, dim3(1024), dim3(256), 0, st, dx, n, d, colmax);
-    hipLaunchKernelGGL(k_km_colscale, dim3(1), dim3(1024), 0, st, colmax, d, n, colscale);
-  } else if (rc == MLN_OK) {
-    mln_set_error(ctx, "kmeans: more than 1024 dimensions"); rc = MLN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_km_colscale, dim3(1), dim3(256), 0, st, colmax, d, n, colscale);
   }
   // ---- k-means++ seeding ------------------------------------------------------------------------
   // m - 1 sequential draws, each after one update of every cell's distance to its nearest centre so far.  Everything stays
