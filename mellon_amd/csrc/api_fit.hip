@@ -2,89 +2,6 @@
 #include "api_internal.h"
 #include "mln_options.h"
 
-struct mln_fit;
-// cov(xu, xu) -> Cholesky factor -> block-scaled copies on a second stream, in a helper thread, while the caller runs the
-// kernel-matrix pass on `wide` (see fit_prepare_impl).  The helper works on a COPY of the context with its own stream,
-// scratch and status word; its temporaries are released by the caller after the join (a free synchronises the device,
-// i.e. would sit out the pass).
-struct LandmarkChain {
-  bool running = false;
-  hipStream_t wide = nullptr;
-  mln_ctx* ctx = nullptr;
-  mln_ctx side;
-  std::thread th;
-  int rc = MLN_OK;
-  double seconds = 0.0;
-  double* Lp = nullptr; int64_t ldp = 0;
-  TriInv tri;
-  std::vector<void*> deferred;
-  DevCov cov;
-  int start(mln_ctx* c, mln_fit* f, const double* centers, int64_t m, int d, double jitter);
-  int finish(mln_fit* f);
-  ~LandmarkChain() {
-    if (th.joinable()) th.join();
-    if (running) {                                       // abandoned on an error path: nothing was handed over
-      if (tri.W || tri.W2) triinv_free(&tri);
-      if (side.scratch) deferred.push_back(side.scratch);
-      if (side.d_info) deferred.push_back(side.d_info);
-    }
-    for (void* p : deferred) (void)mln_dfree(p);
-  }
-};
-
-
-int LandmarkChain::start(mln_ctx* c, mln_fit* f, const double* centers, int64_t m, int d, double jitter) {
-  ctx = c;
-  wide = masked_stream(c, 32);
-  hipStream_t second = masked_stream(c, 0);
-  hipEvent_t ev = masked_stream_event(c, 2);
-  if (!wide || !second || !ev) return MLN_OK;            // no masked streams here: the caller keeps the serial order
-  side = *c;
-  side.stream = second;
-  side.scratch = nullptr; side.scratch_bytes = 0; side.err.clear();
-  side.d_info = nullptr;
-  MLN_HIP(c, mln_dmalloc((void**)&side.d_info, 4 * sizeof(int)));
-  // what has been enqueued so far (the landmarks' upload, the zeroed Lp) precedes both side streams
-  MLN_HIP(c, hipEventRecord(ev, c->stream));
-  MLN_HIP(c, hipStreamWaitEvent(second, ev, 0));
-  MLN_HIP(c, hipStreamWaitEvent(wide, ev, 0));
-  Lp = f->Lp; ldp = f->ldp; cov = f->cov;
-  const int device = c->device;
-  running = true;
-  th = std::thread([this, centers, m, d, jitter, device] {
-    const double t0 = now_s();
-    if (hipSetDevice(device) != hipSuccess) { rc = MLN_ERR_HIP; return; }
-    mln_dfree_defer(&deferred);
-    set_lookahead_disabled(true);
-    rc = launch_kernel_matrix(&side, cov, centers, m, centers, m, d, Lp, ldp, jitter);
-    if (rc == MLN_OK) rc = dev_cholesky_lower(&side, Lp, m, ldp);
-    if (rc == MLN_OK) rc = triinv_build(&side, Lp, m, ldp, true, true, &tri);
-    if (hipStreamSynchronize(side.stream) != hipSuccess && rc == MLN_OK) rc = MLN_ERR_HIP;
-    set_lookahead_disabled(false);
-    mln_dfree_defer(nullptr);
-    seconds = now_s() - t0;
-  });
-  return MLN_OK;
-}
-
-int LandmarkChain::finish(mln_fit* f) {
-  if (th.joinable()) th.join();
-  running = false;
-  if (side.scratch) deferred.push_back(side.scratch);
-  if (side.d_info) deferred.push_back(side.d_info);
-  side.scratch = nullptr; side.d_info = nullptr;
-  for (void* p : deferred) (void)mln_dfree(p);
-  deferred.clear();
-  f->times[1] += seconds;
-  if (rc != MLN_OK) {
-    if (tri.W || tri.W2) triinv_free(&tri);
-    mln_set_error(ctx, side.err.empty() ? std::string("the landmark chain (cov(xu, xu), Cholesky) failed") : side.err);
-    return rc;
-  }
-  f->tri = tri;
-  return MLN_OK;
-}
-
 // rows of this shard in the subsample of stride s: first local index and count
 void fit_sample_rows(const mln_fit* f, int64_t s, int64_t* first, int64_t* rows) {
   if (s < 1) s = 1;
@@ -102,7 +19,7 @@ void fit_free(mln_fit* f) {
   triinv_free(&f->tri);
   void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
                   f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w, f->d_w_cached,
-                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block, f->f_keep[0], f->f_keep[1], f->Linv};
+                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block, f->f_keep[0], f->f_keep[1], f->Kj};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   for (double* p : f->saved_precond) if (p) (void)mln_dfree(p);
   if (f->h_state) (void)hipHostFree(f->h_state);
@@ -252,41 +169,29 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
   const size_t lp_bytes = sizeof(double) * (size_t)m * f->ldp;
   MLN_HIP(ctx, mln_dmalloc((void**)&f->Lp, lp_bytes));
   MLN_HIP(ctx, hipMemsetAsync(f->Lp, 0, lp_bytes, ctx->stream));
-  // Round 4: the landmark-only chain -- cov(xu, xu), its Cholesky factor, the block-scaled copies: ~6 ms at m = 5000, a
-  // latency chain that never fills the chip -- runs in a helper thread on a second stream UNDER the kernel-matrix pass,
-  // which is launched on a stream whose CU mask leaves 32 compute units to it (linalg.h: masked_stream).  Worth it when
-  // the pass is the longer of the two by a margin (the chain is slower with few units): C3 on one GPU, not its 8-rank shard.
-  LandmarkChain chain;
-  {
-    const double km_est = (double)n * (double)m * 3.3e-12, chain_est = 6e-3 * ((double)m / 5000.0) * ((double)m / 5000.0);
-    bool want = !f->full && !Lp_in && n > 0 && m >= 1024 && km_est > 2.0 * chain_est;
-    // MEASURED (round 4, C3 on one MI355X): the pass on 224 units 19.9 instead of 17.0 ms with the chain (13.8 ms on its
-    // 32 units instead of 4.8 on all) hidden under it -- 1.9 ms less kernel time, yet the step came out 2.3 ms LONGER
-    // (172.1 against 169.7 ms; the helper thread's set-up and the joins cost more than the overlap returns).  Off unless
-    // MELLON_AMD_OVERLAP_LANDMARK_CHAIN=1.
-    const char* ev_chain = mln_experiment("MELLON_AMD_OVERLAP_LANDMARK_CHAIN");
-    want = want && ev_chain && std::atoi(ev_chain) != 0;
-    if (want) MLN_TRY(chain.start(ctx, f, centers, m, d, jitter));
-  }
-  if (chain.running) {
-    // (its results -- f->Lp, f->tri -- are collected below, after the kernel-matrix pass has been enqueued)
-  } else if (Lp_in) {
+  // (Round 4 built the landmark-only chain -- cov(xu, xu), its Cholesky factor, the block-scaled copies -- in a helper thread
+  //  on a second stream UNDER the kernel-matrix pass on a CU-masked stream: 1.9 ms less kernel time, 2.3 ms more wall time;
+  //  taken out in round 5, profiles/HISTORY.md.)
+  if (Lp_in) {
     DevIn dl;
     MLN_TRY(dl.init(ctx, Lp_in, (size_t)m * m));
     MLN_TRY(launch_copy_block(ctx, dl.dev, m, f->Lp, f->ldp, m, m));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
     MLN_TRY(launch_kernel_matrix(ctx, f->cov, centers, m, centers, m, d, f->Lp, f->ldp, jitter));
+    if (!f->full && (flags & MLN_FIT_IMPLICIT)) {
+      // Kj = cov(xu, xu) + jitter I survives the factorisation: the prior's Hessian in w-space (fit_build_precond)
+      MLN_HIP(ctx, mln_dmalloc((void**)&f->Kj, lp_bytes));
+      MLN_HIP(ctx, hipMemcpyAsync(f->Kj, f->Lp, lp_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     f->times[0] += now_s() - t0;
     t0 = now_s();
     MLN_TRY(dev_cholesky_lower(ctx, f->Lp, m, f->ldp));
   }
-  if (!chain.running) {
-    MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
-    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    f->times[1] += now_s() - t0;
-  }
+  MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  f->times[1] += now_s() - t0;
 
   if (f->full) {
     f->L = f->Lp;  // parameters.py:847-850
@@ -324,9 +229,6 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
         else if (std::strcmp(ev, "fixed") == 0 && bounded) f->l32_fixed = 1;
       }
     }
-    hipStream_t const own_stream = ctx->stream;
-    struct StreamRestore { mln_ctx* c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore{ctx, own_stream};   // (early returns included)
-    if (chain.running) ctx->stream = chain.wide;         // the pass leaves 32 compute units to the landmark chain
     if (pipelined) {
       for (int c = 0; c < up.n_chunks; ++c) {
         int64_t r0 = 0, rows = 0;
@@ -345,12 +247,6 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
           hipLaunchKernelGGL(k_round_copy_bits, dim3(4096), dim3(256), 0, ctx->stream, reinterpret_cast<unsigned*>(f->L32),
                              (int64_t)n * f->ldl, 32 - bits);
       }
-    if (chain.running) {
-      const int rc_km = (hipStreamSynchronize(ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-      ctx->stream = own_stream;
-      MLN_TRY(chain.finish(f));                          // joins the helper; its error (not positive definite) is the fit's
-      MLN_TRY(rc_km);
-    }
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) fprintf(stderr, "[trace] L kernel matrix done at %.4f s\n", now_s() - t0);
     f->times[0] += now_s() - t0;

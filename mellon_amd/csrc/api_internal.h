@@ -103,7 +103,10 @@ struct mln_fit {
   // into the m-vectors:  L z = K (Lp^-T z),  L^T v = Lp^-1 (K^T v).  No n x m triangular solve.
   bool kspace = false;
   double* P = nullptr;    // Lp^-T C^-T  (m x ldl), so that  w = Lp^-T z = P u  for z = C^-T u
-  double* Linv = nullptr; // Lp^-1 (m x ldp, lower), formed once: the whitening of a Gram and P are then plain GEMMs
+  // Round 5, implicit mode: the preconditioner is factored in w-space.  With M = s K_s^T K_s + Kj (Kj = cov(xu, xu) +
+  // jitter I = Lp Lp^T) and R R^T = M, the square root C = Lp^-1 R of C C^T = I + Lp^-1 (s K_s^T K_s) Lp^-T is never
+  // formed and the Gram is never whitened:  f->C holds R,  P = R^-T,  f->Cinv = C^-1 = R^-1 Lp  (both triangular).
+  double* Kj = nullptr;   // cov(xu, xu) + jitter I, full symmetric (m x ldp); implicit fits only
   double* d_w = nullptr;  // m
   // last vector pair (z, w = Lp^-T z) produced by the library itself (Ridge init / MAP solve): lets
   // mln_transform / mln_weights_cholesky on that same z skip the triangular solve
@@ -185,14 +188,10 @@ int fit_objective_u(mln_fit* f, const double* u, double* loss, double* grad_u, d
 int fit_solver_alloc(mln_fit* f, int maxcor);
 int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
                    int64_t ldg, bool quantised = false);
-int split_ranks(const mln_ctx* ctx, int* my_rank, bool* emulate);
-int fit_whiten_split(mln_fit* f, double* G, int64_t ldg, int n_split, int my_rank, bool emulate);
-int fit_inverses_split(mln_fit* f, const TriInv& tc, double* inv, double* P, int64_t ld, int n_split, int my_rank,
-                              bool emulate);
-bool use_explicit_linv();
-int fit_ensure_linv(mln_fit* f);
-int fit_whiten_gemm(mln_fit* f, double* G, int64_t ldg);
-int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride);
+int emulated_ranks(const mln_ctx* ctx);
+int fit_ensure_kj(mln_fit* f);
+// whiten = true: Lp^-1 (.) Lp^-T applied (implicit mode; a Gram whose eigenvalues are results); false: the raw K_s^T K_s
+int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride, bool whiten = true);
 int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev);
 void fit_drop_precond_operators(mln_fit* f);
 int fit_factor_precond(mln_fit* f);

@@ -42,33 +42,6 @@ int allreduce_symmetric_lower(mln_ctx* ctx, double* G, int64_t m, int64_t ldg) {
   return rc;
 }
 
-// n_mats matrices (m x ld each, `mat_stride` doubles apart) whose column block [r b, (r + 1) b) is valid on rank r only: every
-// rank receives every block.  (Emulated ranks and single-rank contexts hold all blocks already.)
-int assemble_column_blocks(mln_ctx* ctx, double* M, int64_t m, int64_t ld, int n_mats, size_t mat_stride, int n_split, int my_rank,
-                           bool emulate, int64_t b) {
-  if (emulate || ctx->n_ranks <= 1 || n_split <= 1) return MLN_OK;
-  const size_t slot = (size_t)n_mats * (size_t)m * (size_t)b;
-  double* AG = nullptr;
-  MLN_HIP(ctx, mln_dmalloc((void**)&AG, sizeof(double) * slot * (size_t)n_split));
-  int rc = MLN_OK;
-  auto cols_of = [&](int r) { const int64_t c0 = (int64_t)r * b; return std::max<int64_t>(0, std::min<int64_t>(b, m - c0)); };
-  if (hipMemsetAsync(AG + slot * (size_t)my_rank, 0, sizeof(double) * slot, ctx->stream) != hipSuccess) rc = MLN_ERR_HIP;
-  for (int k = 0; k < n_mats && rc == MLN_OK; ++k)
-    if (cols_of(my_rank) > 0)
-      rc = launch_copy_block(ctx, M + (size_t)k * mat_stride + (int64_t)my_rank * b, ld,
-                             AG + slot * (size_t)my_rank + (size_t)k * (size_t)m * (size_t)b, b, m, cols_of(my_rank));
-  if (rc == MLN_OK) rc = comm_allgather(ctx, AG + slot * (size_t)my_rank, AG, (int64_t)slot);
-  for (int r = 0; r < n_split && rc == MLN_OK; ++r) {
-    if (r == my_rank || cols_of(r) <= 0) continue;
-    for (int k = 0; k < n_mats && rc == MLN_OK; ++k)
-      rc = launch_copy_block(ctx, AG + slot * (size_t)r + (size_t)k * (size_t)m * (size_t)b, b,
-                             M + (size_t)k * mat_stride + (int64_t)r * b, ld, m, cols_of(r));
-  }
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)mln_dfree(AG);
-  return rc;
-}
-
 int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m, double alpha, double* G,
                    int64_t ldg, bool quantised) {
   int split = quantised ? gram_i8_splits(rows, m) : (int)(rows / 8192);
@@ -135,172 +108,35 @@ extern "C" int mln_diag_gram_i8(mln_ctx* ctx, const double* A, int64_t rows, int
   return rc;
 }
 
-// G ~ L^T L from every `row_stride`-th cell of this rank (scaled by row_stride), all-reduced.
-// ---- column-split m x m work (strong scaling) -----------------------------------------------------------
-// The whitening of the Gram and the inverses behind the per-evaluation products are "m right-hand sides through a
-// triangular solve": replicated, they cost every rank ~3.7 m^3 flops.  From 3 ranks on, rank r solves only its block of
-// columns [r b, (r + 1) b), writes it into a zeroed full matrix, and ONE all-reduce (a sum with zeros: exact, the same
-// bits on every rank) assembles the result -- 4 m^3 / N flops per rank for the whitening, 2 m^3 / N for the inverses.
-// MELLON_AMD_EMULATE_RANKS=N (tools/emulate_rank.py, one process): rank 0's block is timed, the other blocks are
-// computed too (the fit must go on) with their wall time recorded in emu_excluded.
-int split_ranks(const mln_ctx* ctx, int* my_rank, bool* emulate) {
-  *my_rank = ctx->rank; *emulate = false;
-  int n = ctx->n_ranks;
-  if (n <= 1)
-    if (const char* ev = std::getenv("MELLON_AMD_EMULATE_RANKS")) { n = std::atoi(ev); *my_rank = 0; *emulate = n > 1; }
-  static const int from = mln_experiment("MELLON_AMD_COLSPLIT_RANKS") ? std::atoi(mln_experiment("MELLON_AMD_COLSPLIT_RANKS")) : 3;
-  return (from > 0 && n >= from) ? n : 1;
+// MELLON_AMD_EMULATE_RANKS=N (tools/emulate_rank.py): one process does the work of rank 0 of N -- 0 when not emulating
+int emulated_ranks(const mln_ctx* ctx) {
+  if (ctx->n_ranks > 1) return 0;
+  if (const char* ev = std::getenv("MELLON_AMD_EMULATE_RANKS")) { const int n = std::atoi(ev); return n > 1 ? n : 0; }
+  return 0;
 }
 
-template <typename Body>
-static int for_my_column_blocks(mln_fit* f, int n_split, int my_rank, bool emulate, int64_t b, Body body) {
+// Kj = cov(xu, xu) + jitter I (full symmetric): stored by fit_prepare before the factorisation overwrites it; for handles
+// that were given the factor itself, Lp Lp^T.
+int fit_ensure_kj(mln_fit* f) {
+  if (f->Kj) return MLN_OK;
   mln_ctx* ctx = f->ctx;
-  // (Tried: 2 N half-width blocks, rank r owning blocks r and 2 N - 1 - r, to even out a cost that grows with the column offset
-  //  -- the K range of a triangular factor ends at the diagonal.  Twice the block solves and narrower GEMMs cost more than the
-  //  imbalance: 86.5 instead of 47.1 ms per emulated step at 8 ranks.  With whole blocks the last rank's whitening GEMM is the
-  //  longest, by ~0.6 ms at 8 ranks over rank 0's, which the emulation times.)
-  for (int r = 0; r < n_split; ++r) {
-    if (!emulate && r != my_rank) continue;
-    const int64_t c0 = (int64_t)r * b, nb = std::min<int64_t>(b, f->m - c0);
-    if (nb <= 0) continue;
-    const bool excluded = emulate && r != my_rank;
-    double t0 = 0.0;
-    if (excluded) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); t0 = now_s(); }
-    MLN_TRY(body(c0, nb));
-    if (excluded) { MLN_HIP(ctx, hipStreamSynchronize(ctx->stream)); f->emu_excluded += now_s() - t0; }
-  }
-  return MLN_OK;
-}
-
-// G (S = K_s^T K_s, all-reduced, symmetric) <- Lp^-1 S Lp^-T, columns split over the ranks
-int fit_whiten_split(mln_fit* f, double* G, int64_t ldg, int n_split, int my_rank, bool emulate) {
-  mln_ctx* ctx = f->ctx;
-  const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
-  DevScratch zb(ctx), tb(ctx), ob(ctx);
-  const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ldg;
-  MLN_HIP(ctx, zb.alloc(blk));
-  MLN_HIP(ctx, tb.alloc(blk));
-  MLN_HIP(ctx, ob.alloc(full));
-  double *Z = zb.p, *T = tb.p, *Out = ob.p;
-  MLN_HIP(ctx, hipMemsetAsync(Out, 0, full, ctx->stream));
-  // Round 4b: with the explicit Lp^-1 (fit_ensure_linv, replicated: 1.7 ms once per fit) a rank's column block is two GEMMs --
-  // T = S (Lp^-1)[block, 0 : c0 + nb]^T (rows of the lower triangular inverse end at the diagonal), then Lp^-1 T over the
-  // non-zero K range -- instead of two blocked substitutions of 39 + 40 dependent launches on a right-hand side only
-  // m / N columns wide: those launches are pure latency (19-42 us each), 2.4 ms per whitening at 8 ranks however narrow the block.
-  if (use_explicit_linv()) {
-    MLN_TRY(fit_ensure_linv(f));
-    MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
-      GemmArgs g{};
-      g.A = G; g.lda = ldg; g.B = f->Linv + c0 * f->ldp; g.ldb = f->ldp; g.C = T; g.ldc = b;
-      g.M = m; g.N = nb; g.K = c0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
-      MLN_TRY(launch_dgemm(ctx, g));
-      GemmArgs h{};
-      h.A = f->Linv; h.lda = f->ldp; h.B = T; h.ldb = b; h.C = Out + c0; h.ldc = ldg;
-      h.M = m; h.N = nb; h.K = m; h.alpha = 1.0; h.beta = 0.0; h.ta = 0; h.tb = 0; h.kmode = 3;
-      return launch_dgemm(ctx, h);
-    }));
-  } else
-  MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
-    MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
-    MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));             // unit columns c0 .. c0 + nb
-    MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // (Lp^-T)[:, block]
-    GemmArgs g{};                                                       // T = S (Lp^-T)[:, block]
-    g.A = G; g.lda = ldg; g.B = Z; g.ldb = b; g.C = T; g.ldc = b;
-    g.M = m; g.N = nb; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0;
-    MLN_TRY(launch_dgemm(ctx, g));
-    MLN_TRY(triinv_solve_left(ctx, f->tri, T, nb, b));                  // Lp^-1 S Lp^-T [:, block]
-    return launch_copy_block(ctx, T, b, Out + c0, ldg, m, nb);
-  }));
-  MLN_HIP(ctx, hipMemcpyAsync(G, Out, full, hipMemcpyDeviceToDevice, ctx->stream));
-  MLN_TRY(assemble_column_blocks(ctx, G, m, ldg, 1, 0, n_split, my_rank, emulate, b));
-  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MLN_OK;
-}
-
-// inv (m x ld) <- C^-1 and P (m x ld) <- Lp^-T C^-T, column blocks of [C^-T ; P] split over the ranks (both zeroed
-// by the caller); tc: the block-scaled copies of C
-int fit_inverses_split(mln_fit* f, const TriInv& tc, double* inv, double* P, int64_t ld, int n_split, int my_rank,
-                              bool emulate) {
-  mln_ctx* ctx = f->ctx;
-  const int64_t m = f->m, b = pad16((m + n_split - 1) / n_split);
-  DevScratch zb(ctx), qb(ctx);
-  const size_t blk = sizeof(double) * (size_t)m * b, full = sizeof(double) * (size_t)m * ld;
-  MLN_HIP(ctx, zb.alloc(blk));
-  MLN_HIP(ctx, qb.alloc(2 * full));                                     // [C^-T ; P], this rank's columns only
-  double *Z = zb.p, *Q = qb.p;
-  MLN_HIP(ctx, hipMemsetAsync(Q, 0, 2 * full, ctx->stream));
-  const bool explicit_linv = use_explicit_linv();
-  if (explicit_linv) MLN_TRY(fit_ensure_linv(f));
-  MLN_TRY(for_my_column_blocks(f, n_split, my_rank, emulate, b, [&](int64_t c0, int64_t nb) -> int {
-    MLN_HIP(ctx, hipMemsetAsync(Z, 0, blk, ctx->stream));
-    MLN_TRY(launch_add_diag(ctx, Z + c0 * b, nb, b, 1.0));
-    MLN_TRY(triinv_solve_left_T(ctx, tc, Z, nb, b));                    // (C^-T)[:, block]
-    MLN_TRY(launch_copy_block(ctx, Z, b, Q + c0, ld, m, nb));
-    if (explicit_linv) {
-      // P[:, block] = Lp^-T (C^-T)[:, block] as one GEMM with the explicit inverse: the block of the upper triangular C^-T is
-      // zero below row c0 + nb, and so is the result
-      GemmArgs g{};
-      g.A = f->Linv; g.lda = f->ldp; g.B = Z; g.ldb = b; g.C = Q + (size_t)m * ld + c0; g.ldc = ld;
-      g.M = c0 + nb; g.N = nb; g.K = c0 + nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 1; g.tb = 0;
-      return launch_dgemm(ctx, g);
-    }
-    MLN_TRY(triinv_solve_left_T(ctx, f->tri, Z, nb, b));                // P[:, block] = Lp^-T (C^-T)[:, block]
-    return launch_copy_block(ctx, Z, b, Q + (size_t)m * ld + c0, ld, m, nb);
-  }));
-  MLN_TRY(assemble_column_blocks(ctx, Q, m, ld, 2, (size_t)m * (size_t)ld, n_split, my_rank, emulate, b));
-  MLN_TRY(launch_transpose(ctx, Q, ld, inv, ld, m));                                  // C^-1
-  MLN_TRY(launch_copy_block(ctx, Q + (size_t)m * ld, ld, P, ld, m, ld));              // P
-  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MLN_OK;
-}
-
-__global__ void k_round_bits(double* __restrict__ A, int64_t count, double scale) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-    A[i] = rint(A[i] * scale) / scale;
-}
-
-// Lp^-1 as an explicit lower-triangular matrix (once per fit).  With it the whitening of a Gram, Lp^-1 S Lp^-T, and
-// P = Lp^-T C^-T are GEMMs over the non-zero K ranges (dgemm kmodes 3 / 4 / 7) instead of chains of 40 dependent block
-// solves: 9.3 -> ~5 ms per whitening, 3.9 -> ~1 ms for P at m = 5000.  The explicit inverse multiplies rounding by
-// cond(Lp) ~ 1e3-1e4 where the block solves are backward stable -- immaterial for a preconditioner built from a Gram
-// quantised to 23 bits, and 1e-12 relative on w = P u.  MELLON_AMD_EXPLICIT_LINV=0 restores the solves.
-bool use_explicit_linv() {
-  static const bool on = !(mln_experiment("MELLON_AMD_EXPLICIT_LINV") && std::atoi(mln_experiment("MELLON_AMD_EXPLICIT_LINV")) == 0);
-  return on;
-}
-
-int fit_ensure_linv(mln_fit* f) {
-  if (f->Linv) return MLN_OK;
-  mln_ctx* ctx = f->ctx;
+  if (!f->Lp) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   const size_t bytes = sizeof(double) * (size_t)f->m * f->ldp;
-  MLN_HIP(ctx, mln_dmalloc((void**)&f->Linv, bytes));
-  MLN_HIP(ctx, hipMemsetAsync(f->Linv, 0, bytes, ctx->stream));
-  MLN_TRY(launch_add_diag(ctx, f->Linv, f->m, f->ldp, 1.0));
-  return triinv_solve_left(ctx, f->tri, f->Linv, f->m, f->ldp, true);      // Lp^-1 I, lower triangular right-hand side
-}
-
-// G (symmetric, full storage) <- Lp^-1 G Lp^-T through the explicit inverse: two GEMMs
-int fit_whiten_gemm(mln_fit* f, double* G, int64_t ldg) {
-  mln_ctx* ctx = f->ctx;
-  const int64_t m = f->m;
-  MLN_TRY(fit_ensure_linv(f));
-  double* T = nullptr;
-  MLN_HIP(ctx, mln_dmalloc((void**)&T, sizeof(double) * (size_t)m * ldg));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->Kj, bytes));
+  MLN_HIP(ctx, hipMemsetAsync(f->Kj, 0, bytes, ctx->stream));
   GemmArgs g{};
-  g.A = f->Linv; g.lda = f->ldp; g.B = G; g.ldb = ldg; g.C = T; g.ldc = ldg;           // T = Lp^-1 G   (rows of Lp^-1 end at the diagonal)
-  g.M = m; g.N = m; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.kmode = 3;
-  int rc = launch_dgemm(ctx, g);
-  GemmArgs h{};
-  h.A = T; h.lda = ldg; h.B = f->Linv; h.ldb = f->ldp; h.C = G; h.ldc = ldg;           // G = T Lp^-T, lower tiles (symmetric)
-  h.M = m; h.N = m; h.K = m; h.alpha = 1.0; h.beta = 0.0; h.ta = 0; h.tb = 1; h.kmode = 4; h.lower_only = 1;
-  if (rc == MLN_OK) rc = launch_dgemm(ctx, h);
-  if (rc == MLN_OK) rc = launch_symmetrize_from_lower(ctx, G, m, ldg);
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)mln_dfree(T);
-  return rc;
+  g.A = f->Lp; g.lda = f->ldp; g.B = f->Lp; g.ldb = f->ldp; g.C = f->Kj; g.ldc = f->ldp;
+  g.M = f->m; g.N = f->m; g.K = f->m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1; g.lower_only = 1;
+  MLN_TRY(launch_dgemm(ctx, g));
+  return launch_symmetrize_from_lower(ctx, f->Kj, f->m, f->ldp);
 }
 
-int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
+// G ~ L^T L from every `row_stride`-th cell of this rank (scaled by row_stride), all-reduced.
+// Implicit mode: the n x m buffer holds K, so the Gram of its rows is S = s K_s^T K_s.
+//   whiten = true   G = Lp^-1 S Lp^-T = L_s^T L_s by two backward-stable block solves: the callers whose Gram is a RESULT
+//                   (spectrum / rank of L, the noisy conditionals of the function estimator);
+//   whiten = false  G = S itself: the preconditioner, which is factored in w-space (fit_build_precond) and never whitened.
+int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride, bool whiten) {
   mln_ctx* ctx = f->ctx;
   if (row_stride < 1) row_stride = 1;
   // cells whose GLOBAL index is a multiple of row_stride: the sample -- and with it the preconditioner and the
@@ -309,56 +145,15 @@ int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride) {
   const int64_t rows = (f->n > first) ? (f->n - first + row_stride - 1) / row_stride : 0;
   const double* Ls = f->L + first * f->ldl;
   if (!f->kspace) return gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg);
-  // implicit mode: G = Lp^-1 (K_s^T K_s) Lp^-T -- the Gram of the sampled rows of K itself (strided
-  // rows read in place) followed by two m x m block solves.  Rounding in K_s^T K_s is amplified by
-  // |Lp^-1|^2, which would matter for a quantity that enters the result; as a preconditioner the
-  // outcome is spectrally equivalent to the row-solved Gram within 1e-3 (measured), at none of the
-  // n_s m^2 triangular-solve flops.
-  // With many ranks the sampled rows are few per rank (~12 m / N) while the two m x m block solves are replicated:
-  // from N = 7 on it is cheaper for every rank to whiten ITS rows first, L_s = K_s Lp^-T (rows x m^2 flops, < 2 m^3),
-  // and to all-reduce the Gram of those -- the explicit route's arithmetic, no replicated solve, same single
-  // collective.  (The choice depends on the rank count only, so every rank takes the same branch.)
-  static const int row_solve_from = mln_experiment("MELLON_AMD_GRAM_ROWSOLVE_RANKS") ? std::atoi(mln_experiment("MELLON_AMD_GRAM_ROWSOLVE_RANKS")) : 0;   // superseded by the column split (fit_whiten_split)
-  if (ctx->n_ranks >= row_solve_from && row_solve_from > 0) {
-    double* R = nullptr;
-    const int64_t rr = rows > 0 ? rows : 1;
-    MLN_HIP(ctx, mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl));
-    int rc = MLN_OK;
-    if (rows > 0) rc = launch_copy_block(ctx, Ls, f->ldl * row_stride, R, f->ldl, rows, f->ldl);
-    if (rc == MLN_OK && rows > 0) rc = triinv_solve_right_T(ctx, f->tri, R, rows, f->ldl);
-    if (rc == MLN_OK) rc = gram_of(ctx, R, f->ldl, rows, f->m, (double)row_stride, G, ldg);   // all-reduced
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)mln_dfree(R);
-    return rc;
-  }
-  int rc = MLN_OK;
-  const int qbits = mln_experiment("MELLON_AMD_GRAM_QBITS") ? std::atoi(mln_experiment("MELLON_AMD_GRAM_QBITS")) : 0;
-  if (qbits > 0) {   // experiment: the Gram of the sampled rows rounded to `qbits` fractional bits
-    double* R = nullptr;
-    const int64_t rr = rows > 0 ? rows : 1;
-    MLN_HIP(ctx, mln_dmalloc((void**)&R, sizeof(double) * (size_t)rr * f->ldl));
-    if (rows > 0) rc = launch_copy_block(ctx, Ls, f->ldl * row_stride, R, f->ldl, rows, f->ldl);
-    if (rc == MLN_OK && rows > 0)
-      hipLaunchKernelGGL(k_round_bits, dim3(2048), dim3(256), 0, ctx->stream, R, rows * f->ldl, std::ldexp(1.0, qbits));
-    if (rc == MLN_OK) rc = gram_of(ctx, R, f->ldl, rows, f->m, (double)row_stride, G, ldg);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)mln_dfree(R);
-  } else {
-    // bounded covariances: 23-bit integer Gram on the int8 matrix cores (the preconditioner needs ~20 bits: gram_i8.hip)
-    // ... and only where the caller asked for a SAMPLED Gram (row_stride > 1: a preconditioner by construction);
-    // row_stride == 1 is the reference's exact Ridge matrix / the Gram whose eigenvalues are results
-    bool quant = f->cov_bounded01 && f->m >= 256 && row_stride > 1;
-    if (const char* ev = mln_experiment("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
-    rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
-  }
-  {
-    int my_rank = 0; bool emulate = false;
-    const int n_split = split_ranks(ctx, &my_rank, &emulate);
-    if (rc == MLN_OK && n_split > 1) return fit_whiten_split(f, G, ldg, n_split, my_rank, emulate);
-  }
-  if (rc == MLN_OK && use_explicit_linv()) return fit_whiten_gemm(f, G, ldg);
+  // bounded covariances: 23-bit integer Gram on the int8 matrix cores (the preconditioner needs ~20 bits: gram_i8.hip)
+  // ... and only where the caller asked for a SAMPLED Gram (row_stride > 1: a preconditioner or a diagnostic by
+  // construction); row_stride == 1 is the reference's exact Ridge matrix / the Gram whose eigenvalues are results
+  bool quant = f->cov_bounded01 && f->m >= 256 && row_stride > 1;
+  if (const char* ev = mln_experiment("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
+  int rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
+  if (rc != MLN_OK || !whiten) return rc;
   double* T = nullptr;
-  if (rc == MLN_OK) {
+  {
     hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)f->m * ldg);
     if (e == hipSuccess) e = hipMemsetAsync(T, 0, sizeof(double) * (size_t)f->m * ldg, ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc Gram temp", __FILE__, __LINE__);
@@ -400,57 +195,42 @@ void fit_drop_precond_operators(mln_fit* f) {
   f->Cinv = nullptr; f->P = nullptr; f->Q1 = nullptr; f->Q2 = nullptr;
 }
 
-// f->C holds the (whitened) Gram: add the prior's identity, factor C C^T, and build C^-1, P = Lp^-T C^-T and the stacked
-// per-evaluation operators Q1, Q2
+// f->C holds the matrix to factor -- explicit mode: the Gram L_s^T L_s (the prior's identity is added here); implicit
+// mode: M = s K_s^T K_s + Kj, the same Hessian at a = 1 in w-space (w = Lp^-T z), never whitened.  Factor it, and build
+// C^-1, P = Lp^-T C^-T and the stacked per-evaluation operators Q1 = [C^-T ; P], Q2 = [C^-1 | P^T].
+// Implicit mode (round 5): R R^T = M.  C = Lp^-1 R satisfies C C^T = I + Lp^-1 (s K_s^T K_s) Lp^-T -- the matrix rounds
+// 2-4 obtained by whitening the Gram with an explicit Lp^-1 (1.5 ms) and two m^3 GEMMs (3.7 ms) and then factored.  C is
+// not triangular, but every operator the solve needs is:  P = Lp^-T C^-T = R^-T,  C^-1 = R^-1 Lp (lower x lower),
+// C^-T = Lp^T R^-T.  One triangular product instead of the whitening, no explicit Lp^-1, and M -- a sum of a positive
+// semi-definite integer Gram and Kj -- cannot lose positive definiteness to the quantisation of its rows the way the
+// whitened matrix did on heavy-tailed data (round 4: "rebuild lost positive definiteness").
 int fit_factor_precond(mln_fit* f) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
   const size_t bytes = sizeof(double) * (size_t)m * ldg;
-  int my_rank = 0; bool emulate = false;
-  const int n_split = f->kspace ? split_ranks(ctx, &my_rank, &emulate) : 1;
-  int rc = launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1 / the prior's Hessian
+  int rc = f->kspace ? MLN_OK : launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1 / the prior's Hessian
   if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, f->C, m, ldg);
   TriInv t;
   if (rc == MLN_OK) rc = triinv_build(ctx, f->C, m, ldg, true, false, &t);
-  double* inv = nullptr;
-  if (rc == MLN_OK) {
-    hipError_t e = mln_dmalloc((void**)&inv, bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(inv, 0, bytes, ctx->stream);
-    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc C^-1", __FILE__, __LINE__);
-  }
-  if (rc == MLN_OK && n_split > 1) {                                // column blocks over the ranks, one all-reduce
-    hipError_t e = mln_dmalloc((void**)&f->P, bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(f->P, 0, bytes, ctx->stream);
-    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
-    if (rc == MLN_OK) rc = fit_inverses_split(f, t, inv, f->P, ldg, n_split, my_rank, emulate);
-  } else {
+  double *inv = nullptr, *cinv = nullptr;         // inv: the factor's explicit inverse; cinv: C^-1 (implicit mode: R^-1 Lp)
+  auto zeroed = [&](double** p, const char* what) {
+    hipError_t e = mln_dmalloc((void**)p, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, ctx->stream);
+    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, what, __FILE__, __LINE__);
+  };
+  if (rc == MLN_OK) zeroed(&inv, "alloc factor inverse");
   if (rc == MLN_OK) rc = launch_add_diag(ctx, inv, m, ldg, 1.0);
-  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg, true);   // C^-1 = C^-1 I (lower triangular B)
-  if (rc == MLN_OK && f->kspace) {                                  // P = Lp^-T C^-T
-    hipError_t e = mln_dmalloc((void**)&f->P, bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(f->P, 0, bytes, ctx->stream);
-    if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P", __FILE__, __LINE__);
-    if (rc == MLN_OK && use_explicit_linv()) {
-      // P^T = C^-1 Lp^-1: two lower triangular factors, lower triangular product (K range column .. row)
-      rc = fit_ensure_linv(f);
-      double* X = nullptr;
-      if (rc == MLN_OK) {
-        e = mln_dmalloc((void**)&X, bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(X, 0, bytes, ctx->stream);
-        if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P^T", __FILE__, __LINE__);
-      }
-      GemmArgs g{};
-      g.A = inv; g.lda = ldg; g.B = f->Linv; g.ldb = f->ldp; g.C = X; g.ldc = ldg;
-      g.M = m; g.N = m; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.kmode = 7; g.lower_only = 1;
-      if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
-      if (rc == MLN_OK) rc = launch_transpose(ctx, X, ldg, f->P, ldg, m);
-      (void)hipStreamSynchronize(ctx->stream);
-      if (X) (void)mln_dfree(X);
-    } else {
-    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);
-    if (rc == MLN_OK) rc = triinv_solve_left_T(ctx, f->tri, f->P, m, ldg, true);   // C^-T is upper triangular
-    }
-  }
+  if (rc == MLN_OK) rc = triinv_solve_left(ctx, t, inv, m, ldg, true);   // R^-1 I (lower triangular right-hand side)
+  if (rc == MLN_OK && f->kspace) {
+    zeroed(&f->P, "alloc P");
+    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);        // P = R^-T
+    if (rc == MLN_OK) zeroed(&cinv, "alloc C^-1");
+    GemmArgs g{};                                                                  // C^-1 = R^-1 Lp: column <= k <= row
+    g.A = inv; g.lda = ldg; g.B = f->Lp; g.ldb = f->ldp; g.C = cinv; g.ldc = ldg;
+    g.M = m; g.N = m; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.kmode = 7; g.lower_only = 1;
+    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+  } else {
+    cinv = inv;
   }
   if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs
     const int64_t ld = ldg;
@@ -461,25 +241,17 @@ int fit_factor_precond(mln_fit* f) {
     if (e == hipSuccess) e = hipMemsetAsync(f->Q1, 0, sizeof(double) * blk * nq1, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(f->Q2, 0, sizeof(double) * blk * 2, ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc stacked operators", __FILE__, __LINE__);
-    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ld, f->Q1, ld, m);                      // C^-T
+    if (rc == MLN_OK) rc = launch_transpose(ctx, cinv, ld, f->Q1, ld, m);                     // C^-T
     if (rc == MLN_OK && f->kspace) rc = launch_copy_block(ctx, f->P, ld, f->Q1 + blk, ld, m, ld);   // P below it
-    if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2, ld * 2, m, ld);             // C^-1
-    // explicit factor: g_u = C^-1 (z + L^T(a-1)) = [C^-1 | C^-1] [z ; r] -- the same two-segment product
-    if (rc == MLN_OK && !f->kspace) rc = launch_copy_block(ctx, inv, ld, f->Q2 + ld, ld * 2, m, ld);
-    if (rc == MLN_OK && f->kspace) {                                                           // P^T beside it
-      double* Pt = nullptr;
-      e = mln_dmalloc((void**)&Pt, sizeof(double) * blk);
-      if (e == hipSuccess) e = hipMemsetAsync(Pt, 0, sizeof(double) * blk, ctx->stream);
-      if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc P^T", __FILE__, __LINE__);
-      if (rc == MLN_OK) rc = launch_transpose(ctx, f->P, ld, Pt, ld, m);
-      if (rc == MLN_OK) rc = launch_copy_block(ctx, Pt, ld, f->Q2 + ld, ld * 2, m, ld);
-      (void)hipStreamSynchronize(ctx->stream);
-      if (Pt) (void)mln_dfree(Pt);
-    }
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, cinv, ld, f->Q2, ld * 2, m, ld);            // C^-1
+    // explicit factor: g_u = C^-1 (z + L^T(a-1)) = [C^-1 | C^-1] [z ; r] -- the same two-segment product;
+    // implicit: P^T = R^-1 beside it
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2 + ld, ld * 2, m, ld);
   }
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&t);
-  if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
+  if (cinv != inv && inv) (void)mln_dfree(inv);
+  if (rc == MLN_OK) f->Cinv = cinv; else if (cinv) (void)mln_dfree(cinv);
   return rc;
 }
 
@@ -488,15 +260,17 @@ int fit_build_precond(mln_fit* f, int64_t row_stride) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
   const size_t bytes = sizeof(double) * (size_t)m * ldg;
-  double t0 = now_s(), ex0 = f->emu_excluded;
-  const double ex_start = f->emu_excluded;
+  double t0 = now_s();
   MLN_HIP(ctx, mln_dmalloc((void**)&f->C, bytes));
-  int rc = fit_gram(f, f->C, ldg, row_stride);
-  f->times[3] += now_s() - t0 - (f->emu_excluded - ex0);
-  double t1 = now_s(); ex0 = f->emu_excluded;
+  int rc = fit_gram(f, f->C, ldg, row_stride, false);
+  if (rc == MLN_OK && f->kspace) rc = fit_ensure_kj(f);
+  if (rc == MLN_OK && f->kspace) rc = launch_axpby(ctx, m * ldg, 1.0, f->Kj, 1.0, f->C);      // M = s K_s^T K_s + Kj
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  f->times[3] += now_s() - t0;
+  double t1 = now_s();
   if (rc == MLN_OK) rc = fit_factor_precond(f);
-  f->times[4] += now_s() - t1 - (f->emu_excluded - ex0);
-  if (rc == MLN_OK) { f->precond_stride = row_stride < 1 ? 1 : row_stride; f->build_seconds = now_s() - t0 - (f->emu_excluded - ex_start); }
+  f->times[4] += now_s() - t1;
+  if (rc == MLN_OK) { f->precond_stride = row_stride < 1 ? 1 : row_stride; f->build_seconds = now_s() - t0; }
   return rc;
 }
 
@@ -536,8 +310,7 @@ int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int*
   // (tools/emulate_rank.py: one process stands for rank 0 of N and sees only its shard -- "global" sums are local there, and
   //  the importance sample would come out N times this rank's real share: 30 000 rows instead of 3 750 at 8 ranks, a Gram
   //  eight times too expensive.  The emulation asks for the share.)
-  if (ctx->n_ranks <= 1)
-    if (const char* ev = std::getenv("MELLON_AMD_EMULATE_RANKS")) { const int n_emu = std::atoi(ev); if (n_emu > 1) target /= (double)n_emu; }
+  if (const int n_emu = emulated_ranks(ctx)) target /= (double)n_emu;
   const bool tr_on = std::getenv("MELLON_AMD_TRACE") != nullptr;
   double tt[6] = {0, 0, 0, 0, 0, 0};
   auto lap = [&](int i, double& t0) { if (tr_on) { (void)hipStreamSynchronize(ctx->stream); const double t1 = now_s(); tt[i] += t1 - t0; t0 = t1; } };
@@ -579,28 +352,12 @@ int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int*
   if (R) (void)mln_dfree(R);
   rebuild_selection_free(ctx, &sel);
   lap(2, tl);
-  if (rc == MLN_OK && f->kspace) {                                                              // Lp^-1 G Lp^-T
-    int my_rank = 0; bool emulate = false;
-    const int n_split = split_ranks(ctx, &my_rank, &emulate);
-    if (n_split > 1) rc = fit_whiten_split(f, f->C, ldg, n_split, my_rank, emulate);
-    else if (use_explicit_linv()) rc = fit_whiten_gemm(f, f->C, ldg);
-    else {
-      double* T = nullptr;
-      hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)m * ldg);
-      if (e == hipSuccess) e = hipMemsetAsync(T, 0, sizeof(double) * (size_t)m * ldg, ctx->stream);
-      if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc Gram temp", __FILE__, __LINE__);
-      if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, f->C, m, ldg);
-      if (rc == MLN_OK) rc = launch_transpose(ctx, f->C, ldg, T, ldg, m);
-      if (rc == MLN_OK) rc = triinv_solve_left(ctx, f->tri, T, m, ldg);
-      if (rc == MLN_OK) rc = (hipMemcpyAsync(f->C, T, sizeof(double) * (size_t)m * ldg, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? MLN_OK : MLN_ERR_HIP;
-      (void)hipStreamSynchronize(ctx->stream);
-      if (T) (void)mln_dfree(T);
-    }
-  }
+  if (rc == MLN_OK && f->kspace) rc = fit_ensure_kj(f);
+  if (rc == MLN_OK && f->kspace) rc = launch_axpby(ctx, m * ldg, 1.0, f->Kj, 1.0, f->C);       // M' = sum_i a_i K_i K_i^T + Kj
   lap(3, tl);
   if (rc == MLN_OK) rc = fit_factor_precond(f);
   lap(4, tl);
-  if (tr_on) fprintf(stderr, "[trace] rebuild ms: select %.2f, gather %.2f, gram %.2f, whiten %.2f, factor+inverses+stacks %.2f (rc %d)\n",
+  if (tr_on) fprintf(stderr, "[trace] rebuild ms: select %.2f, gather %.2f, gram %.2f, + Kj %.2f, factor+inverses+stacks %.2f (rc %d)\n",
                      1e3 * tt[0], 1e3 * tt[1], 1e3 * tt[2], 1e3 * tt[3], 1e3 * tt[4], rc);
   if (rc == MLN_ERR_NOT_PD) {
     // (the factorisation's verdict is a function of all-reduced numbers: every rank lands here together)
@@ -715,7 +472,11 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   MLN_TRY(fit_build_precond(f, 1));
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, in, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
-  if (mode == 0) MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));          // u = C^T z
+  if (mode == 0 && f->kspace) {                                                  // u = C^T z = R^T (Lp^-T z)
+    MLN_TRY(fit_w_from_z(f, f->d_u, f->d_w, is_device_ptr(in) ? nullptr : in));
+    MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_w, f->d_gu));
+  }
+  else if (mode == 0) MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));     // u = C^T z
   else if (mode == 1) MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_gu));  // z = C^-T u
   else if (mode == 2) MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_u, f->d_gu));  // g_u = C^-1 g_z
   else { mln_set_error(ctx, "mln_precond_apply: unknown mode"); return MLN_ERR_ARG; }

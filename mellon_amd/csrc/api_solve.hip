@@ -252,9 +252,14 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   for (int b = 0; b < 2; ++b)
     if (!f->f_keep[b]) MLN_HIP(ctx, mln_dmalloc((void**)&f->f_keep[b], sizeof(double) * (size_t)(f->n > 0 ? f->n : 1)));
   f->f_final = -1;
-  // u0 = C^T z0, identical on every rank
+  // u0 = C^T z0, identical on every rank (implicit mode: C^T z0 = R^T (Lp^-T z0), api_precond.hip fit_factor_precond)
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, z0, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
-  MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));
+  if (f->kspace) {
+    MLN_TRY(fit_w_from_z(f, f->d_u, f->d_w, is_device_ptr(z0) ? nullptr : z0));
+    MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_w, f->d_gu));
+  } else {
+    MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));
+  }
   MLN_TRY(dev_bcast0(ctx, f->d_gu, m));
   // Mixed precision: while an fp32 copy of the n x m buffer exists, the first passes stream it (half the bytes);
   // the solver switches to the fp64 buffer by itself (see k_solver_step) and finishes at the same tolerances as
@@ -337,12 +342,11 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // steps (0.25 ms per block: chol(C'), inverses, operators), the integer Gram of this rank's sample rows at 1 POP/s, the
   // whitening's 2 m^3 flops (column-split over >= 3 ranks) at 45 TFLOP/s -- 18.5 / 12.2 / 11.1 ms at C3 on 1 / 4 / 8 ranks
   // against the measured 18.7 / 13.6 / 10.9.
+  // Round 5: the Gram is no longer whitened (w-space factor, api_precond.hip): a build is the Gram of this rank's sample rows
+  // plus ONE factorisation-like chain with its inverse and the triangular product C^-1 = R^-1 Lp.
   const double md = (double)f->m;
-  int split_rank_unused = 0; bool split_emulated = false;
-  const int n_ranks_r = split_ranks(ctx, &split_rank_unused, &split_emulated);     // (ranks the m x m work is split over: 1 below 3)
   const double gram_rows = (double)f->n / (double)(f->precond_stride > 0 ? f->precond_stride : 1);
-  const double build_model_s = 2.5e-4 * std::ceil(md / 128.0) + gram_rows * md * md * 2.0 / 1.0e15 +
-                               2.0 * md * md * md / (double)n_ranks_r / 45e12;
+  const double build_model_s = 2.2e-4 * std::ceil(md / 128.0) + gram_rows * md * md * 2.0 / 1.0e15;
   double want_rebuild = (f->build_seconds > 0.0 && 13.0 * pass_s > build_model_s) ? 1.0 : 0.0;
   if (const char* ev = mln_experiment("MELLON_AMD_REBUILD")) want_rebuild = std::atoi(ev) != 0 ? 1.0 : 0.0;
   if (phase32 && !(f->l32_fixed)) want_rebuild = 0.0;   // (mixed solves pause at their fp64 anchor, which only the corrected fixed-point surrogate has)
@@ -428,8 +432,9 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         MLN_HIP(ctx, mln_dmalloc((void**)&zt, sizeof(double) * 3 * (size_t)f->ldl));
         gz = zt + f->ldl; cz = gz + f->ldl;
         MLN_HIP(ctx, hipMemsetAsync(zt, 0, sizeof(double) * 3 * (size_t)f->ldl, ctx->stream));
-        // old variable -> z-space:  z = C^-T u,  g_z = C g_u  (and the surrogate's correction c, a gradient in u, likewise)
-        int rc = fit_small_gemv(f, f->Cinv, 1, f->sv.u, zt);
+        // old variable -> z-space:  z = C^-T u,  g_z = C g_u  (and the surrogate's correction c, a gradient in u, likewise);
+        // implicit mode -> w-space (w = Lp^-T z):  w = P u = R^-T u,  g_w = R g_u   (f->C holds R there, P^T = R^-1)
+        int rc = f->kspace ? fit_small_gemv(f, f->P, 0, f->sv.u, zt) : fit_small_gemv(f, f->Cinv, 1, f->sv.u, zt);
         if (rc == MLN_OK) rc = fit_small_gemv(f, f->C, 0, f->sv.g, gz);
         if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->C, 0, f->sv.c, cz);
         // (The curvature pairs could be carried through the change of variable -- s' = T s, y' = T^-T y with T = C'^T C^-T --
@@ -438,10 +443,10 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         int outcome = 0;
         if (rc == MLN_OK) rc = revert ? fit_precond_revert(f) : fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m, &outcome);
         if (rc == MLN_OK && outcome == 0) {
-          // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z
+          // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z      (w-space:  u = R^T w,  g_u = R^-1 g_w = P^T g_w)
           rc = fit_small_gemv(f, f->C, 1, zt, f->sv.u);
-          if (rc == MLN_OK) rc = fit_small_gemv(f, f->Cinv, 0, gz, f->sv.g);
-          if (rc == MLN_OK && ps.corr) rc = fit_small_gemv(f, f->Cinv, 0, cz, f->sv.c);
+          if (rc == MLN_OK) rc = f->kspace ? fit_small_gemv(f, f->P, 1, gz, f->sv.g) : fit_small_gemv(f, f->Cinv, 0, gz, f->sv.g);
+          if (rc == MLN_OK && ps.corr) rc = f->kspace ? fit_small_gemv(f, f->P, 1, cz, f->sv.c) : fit_small_gemv(f, f->Cinv, 0, cz, f->sv.c);
         }
         (void)hipStreamSynchronize(ctx->stream);
         (void)mln_dfree(zt);
