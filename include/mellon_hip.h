@@ -204,6 +204,11 @@ int mln_fit_from_L(mln_ctx* ctx, const double* L, int64_t n_local, int64_t m, co
  *   mln_fit_set_K_rows      rows [row0, row0 + n_rows) of cov(x, xu), n_rows x m, host or device
  *   mln_fit_finish_K        after the last block: L = K Lp^-T unless implicit; the handle is then a normal fit     */
 #define MLN_FIT_FULL 2
+/* MLN_FIT_DEFER_LP (with MLN_FIT_IMPLICIT, no Lp given): Lp = chol(cov(xu, xu) + jitter I) is not factored inside
+ * mln_fit_prepare but together with the preconditioner's matrix in mln_precond_build / mln_ridge_init (two
+ * factorisations in one chain of launches), or by the first call that needs it; MLN_ERR_NOT_PD then comes from
+ * that call, its message starting with "cov(xu, xu)". */
+#define MLN_FIT_DEFER_LP 4
 int mln_fit_prepare_from_K(mln_ctx* ctx, const double* Kuu, int64_t n_local, int64_t m, double jitter,
                            const double* Lp_in, int32_t flags, mln_fit** out);
 int mln_fit_set_K_rows(mln_fit* fit, int64_t row0, int64_t n_rows, const double* K_rows);

@@ -831,7 +831,7 @@ class Fit:
     def gram_eigh(self):
         """Eigenvalues (ascending) of L^T L over all cells of all ranks; eigenvectors stay on the device."""
         w, sw = np.empty(self.m), _i32(0)
-        self.ctx._check(self.lib.mln_fit_gram_eigh(self.handle, w.ctypes.data, C.byref(sw)))
+        self._check(self.lib.mln_fit_gram_eigh(self.handle, w.ctypes.data, C.byref(sw)))
         self.last_eigh_sweeps = int(sw.value)
         return w
 
@@ -839,7 +839,7 @@ class Fit:
         """(number of singular values of L above tol * the largest, the largest): Sturm counts on the tridiagonalised
         Gram of all cells of all ranks -- no eigendecomposition."""
         r, smax = _i64(0), C.c_double()
-        self.ctx._check(self.lib.mln_fit_gram_rank(self.handle, float(tol), C.byref(r), C.byref(smax)))
+        self._check(self.lib.mln_fit_gram_rank(self.handle, float(tol), C.byref(r), C.byref(smax)))
         return int(r.value), smax.value
 
     def project(self, p):
@@ -847,7 +847,7 @@ class Fit:
         new = Fit.__new__(Fit)
         new.ctx, new.lib, new.handle = self.ctx, self.lib, None
         h = C.c_void_p()
-        self.ctx._check(self.lib.mln_fit_project(self.handle, int(p), C.byref(h)))
+        self._check(self.lib.mln_fit_project(self.handle, int(p), C.byref(h)))
         new.handle = h.value
         new.n, new.d, new.m, new.jitter = self.n, None, int(p), None
         new.implicit = False
@@ -865,11 +865,21 @@ class Fit:
         if Lp_ is not None and Lp_.shape != (m, m):
             raise ValueError(f"Lp has shape {Lp_.shape}, expected {(m, m)}")
         h = C.c_void_p()
+        # implicit fits: the landmark factor Lp is deferred (MLN_FIT_DEFER_LP = 4) -- it is factored in one chain of launches
+        # with the preconditioner's matrix (mln_precond_build / mln_ridge_init), or by the first call that needs it
+        flags = (1 | (4 if Lp_ is None else 0)) if self.implicit else 0
         ctx._check(self.lib.mln_fit_prepare(ctx.handle, desc.ref, _ptr(x), n, d, _ptr(xu), m, float(jitter),
-                                            _ptr(Lp_), 1 if self.implicit else 0, C.byref(h)), jitter=jitter)
+                                            _ptr(Lp_), flags, C.byref(h)), jitter=jitter)
         self.handle = h.value
         self.n, self.d, self.m, self.jitter = n, d, m, jitter
         self._has_lp = True
+
+    def _check(self, rc, jitter=None):
+        """Context._check, with the reference's message for a deferred landmark factor that turns out not to be
+        positive definite (decomposition.py:116-122: the jitter named is the fit's)."""
+        if rc == MLN_ERR_NOT_PD and self.lib.mln_last_error(self.ctx.handle).startswith(b"cov(xu, xu)"):
+            jitter = self.jitter
+        self.ctx._check(rc, jitter=jitter)
 
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
@@ -884,32 +894,32 @@ class Fit:
 
     def Lp(self):
         out = np.empty((self.m, self.m), dtype=np.float64)
-        self.ctx._check(self.lib.mln_fit_get_Lp(self.handle, out.ctypes.data))
+        self._check(self.lib.mln_fit_get_Lp(self.handle, out.ctypes.data))
         return out
 
     def L(self, row0=0, n_rows=None):
         n_rows = self.n - row0 if n_rows is None else n_rows
         out = np.empty((n_rows, self.m), dtype=np.float64)
-        self.ctx._check(self.lib.mln_fit_get_L(self.handle, row0, n_rows, out.ctypes.data))
+        self._check(self.lib.mln_fit_get_L(self.handle, row0, n_rows, out.ctypes.data))
         return out
 
     def ridge_init(self, target):
         target = target if isinstance(target, DeviceArray) else _f64(target)
         z0 = np.empty(self.m, dtype=np.float64)
-        self.ctx._check(self.lib.mln_ridge_init(self.handle, _ptr(target), z0.ctypes.data), jitter="ridge")
+        self._check(self.lib.mln_ridge_init(self.handle, _ptr(target), z0.ctypes.data), jitter="ridge")
         return z0
 
     def set_likelihood(self, V, Vdr, mu):
         V = V if isinstance(V, DeviceArray) else _f64(V)
         Vdr = Vdr if isinstance(Vdr, DeviceArray) else _f64(Vdr)
-        self.ctx._check(self.lib.mln_fit_set_likelihood(self.handle, _ptr(V), _ptr(Vdr), float(mu)))
+        self._check(self.lib.mln_fit_set_likelihood(self.handle, _ptr(V), _ptr(Vdr), float(mu)))
 
     def objective(self, z, with_hess=False):
         z = _f64(z)
         loss = C.c_double()
         grad = np.empty(self.m, dtype=np.float64)
         hess = np.empty(self.m, dtype=np.float64) if with_hess else None
-        self.ctx._check(self.lib.mln_objective(self.handle, z.ctypes.data, C.byref(loss), grad.ctypes.data,
+        self._check(self.lib.mln_objective(self.handle, z.ctypes.data, C.byref(loss), grad.ctypes.data,
                                                _ptr(hess)))
         return (loss.value, grad, hess) if with_hess else (loss.value, grad)
 
@@ -920,15 +930,15 @@ class Fit:
         built = getattr(self, "_precond_stride", None)
         if built is not None and (not force or built == int(row_stride)):
             return
-        self.ctx._check(self.lib.mln_fit_set_row_offset(self.handle, int(row_offset)))
-        self.ctx._check(self.lib.mln_precond_build(self.handle, int(row_stride)), jitter="ridge")
+        self._check(self.lib.mln_fit_set_row_offset(self.handle, int(row_offset)))
+        self._check(self.lib.mln_precond_build(self.handle, int(row_stride)), jitter="ridge")
         self._precond_stride = max(1, int(row_stride))
 
     def precond_apply(self, mode, v):
         """mode 0: u = C^T z; 1: z = C^-T u; 2: g_u = C^-1 g_z  (C C^T = L^T L + I)."""
         v = _f64(v)
         out = np.empty(self.m, dtype=np.float64)
-        self.ctx._check(self.lib.mln_precond_apply(self.handle, int(mode), v.ctypes.data, out.ctypes.data),
+        self._check(self.lib.mln_precond_apply(self.handle, int(mode), v.ctypes.data, out.ctypes.data),
                         jitter="ridge")
         return out
 
@@ -938,7 +948,7 @@ class Fit:
         loss = C.c_double()
         grad = np.empty(self.m, dtype=np.float64)
         z = np.empty(self.m, dtype=np.float64)
-        self.ctx._check(self.lib.mln_objective_precond(self.handle, u.ctypes.data, C.byref(loss), grad.ctypes.data,
+        self._check(self.lib.mln_objective_precond(self.handle, u.ctypes.data, C.byref(loss), grad.ctypes.data,
                                                        z.ctypes.data), jitter="ridge")
         return loss.value, grad, z
 
@@ -948,7 +958,7 @@ class Fit:
         opts = SolverOpts(int(maxiter), int(maxcor), int(maxls), float(ftol), float(gtol))
         z = np.empty(self.m, dtype=np.float64)
         loss, nev, nit, st = C.c_double(), C.c_int32(), C.c_int32(), C.c_int32()
-        self.ctx._check(self.lib.mln_map_solve(self.handle, z0.ctypes.data, C.byref(opts), z.ctypes.data,
+        self._check(self.lib.mln_map_solve(self.handle, z0.ctypes.data, C.byref(opts), z.ctypes.data,
                                                C.byref(loss), C.byref(nev), C.byref(nit), C.byref(st)),
                         jitter="ridge")
         return z, loss.value, nev.value, nit.value, st.value
@@ -956,25 +966,25 @@ class Fit:
     def transform(self, z, mu, out=None):
         z = _f64(z)
         ret = np.empty(self.n, dtype=np.float64) if out is None else out
-        self.ctx._check(self.lib.mln_transform(self.handle, z.ctypes.data, float(mu), _ptr(ret)))
+        self._check(self.lib.mln_transform(self.handle, z.ctypes.data, float(mu), _ptr(ret)))
         return ret
 
     def weights_cholesky(self, z):
         z = _f64(z)
         w = np.empty(self.m, dtype=np.float64)
-        self.ctx._check(self.lib.mln_weights_cholesky(self.handle, z.ctypes.data, w.ctypes.data))
+        self._check(self.lib.mln_weights_cholesky(self.handle, z.ctypes.data, w.ctypes.data))
         return w
 
     def weights_full(self, y, mu):
         y2 = _f64(y)
         p = 1 if y2.ndim == 1 else y2.shape[1]
         w = np.empty_like(y2)
-        self.ctx._check(self.lib.mln_weights_full(self.handle, y2.ctypes.data, p, float(mu), w.ctypes.data))
+        self._check(self.lib.mln_weights_full(self.handle, y2.ctypes.data, p, float(mu), w.ctypes.data))
         return w
 
     def stage_times(self):
         out = np.zeros(MLN_N_STAGE_TIMES, dtype=np.float64)
-        self.ctx._check(self.lib.mln_stage_times(self.handle, out.ctypes.data))
+        self._check(self.lib.mln_stage_times(self.handle, out.ctypes.data))
         keys = ["kernel_matrix_s", "cholesky_s", "trsm_s", "ridge_gram_s", "ridge_solve_s",
                 "objective_kernel_s", "objective_launches", "objective_bytes_per_launch",
                 "objective32_kernel_s", "objective32_launches", "copy32_format", "emulation_excluded_s",

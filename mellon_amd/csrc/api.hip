@@ -126,7 +126,6 @@ extern "C" void mln_ctx_destroy(mln_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   comm_release(ctx);
-  masked_streams_release(ctx);
   if (ctx->scratch) (void)mln_dfree(ctx->scratch);
   if (ctx->d_info) (void)mln_dfree(ctx->d_info);
   (void)hipStreamDestroy(ctx->stream);

@@ -132,6 +132,32 @@ struct HostUpload {
   }
 };
 
+// ---- deferred Lp (MLN_FIT_DEFER_LP) --------------------------------------------------------------------------------------
+// rc_chol: what the factorisation of f->Lp (alone or batched with the preconditioner's matrix) returned
+int fit_lp_finish(mln_fit* f, int rc_chol, double t0) {
+  mln_ctx* ctx = f->ctx;
+  if (rc_chol == MLN_ERR_NOT_PD) {
+    f->lp_failed = true;
+    char buf[160];
+    snprintf(buf, sizeof buf, "cov(xu, xu) + jitter I is not positive definite (jitter = %g): %s", f->jitter, ctx->err.c_str());
+    mln_set_error(ctx, buf);
+    return rc_chol;
+  }
+  MLN_TRY(rc_chol);
+  MLN_TRY(triinv_build(ctx, f->Lp, f->m, f->ldp, true, true, &f->tri));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  f->lp_pending = false;
+  f->times[1] += now_s() - t0;
+  return MLN_OK;
+}
+
+int fit_ensure_lp(mln_fit* f) {
+  if (f->lp_failed) { mln_set_error(f->ctx, "cov(xu, xu) + jitter I is not positive definite"); return MLN_ERR_NOT_PD; }
+  if (!f->lp_pending) return MLN_OK;
+  const double t0 = now_s();
+  return fit_lp_finish(f, dev_cholesky_lower(f->ctx, f->Lp, f->m, f->ldp), t0);
+}
+
 int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, int32_t d,
                             const double* xu, int64_t m, double jitter, const double* Lp_in, int32_t flags,
                             mln_fit* f) {
@@ -179,7 +205,8 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
     MLN_TRY(launch_kernel_matrix(ctx, f->cov, centers, m, centers, m, d, f->Lp, f->ldp, jitter));
-    if (!f->full && (flags & MLN_FIT_IMPLICIT)) {
+    const bool implicit = !f->full && (flags & MLN_FIT_IMPLICIT) != 0;
+    if (implicit) {
       // Kj = cov(xu, xu) + jitter I survives the factorisation: the prior's Hessian in w-space (fit_build_precond)
       MLN_HIP(ctx, mln_dmalloc((void**)&f->Kj, lp_bytes));
       MLN_HIP(ctx, hipMemcpyAsync(f->Kj, f->Lp, lp_bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -187,11 +214,17 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     f->times[0] += now_s() - t0;
     t0 = now_s();
-    MLN_TRY(dev_cholesky_lower(ctx, f->Lp, m, f->ldp));
+    // MLN_FIT_DEFER_LP: nothing between here and the preconditioner needs the factor (the n x m buffer keeps K itself), and
+    // its chain of 40 dependent block steps rides along with the preconditioner's (api_precond.hip fit_factor_precond)
+    if (implicit && (flags & MLN_FIT_DEFER_LP)) f->lp_pending = true;
+    else MLN_TRY(dev_cholesky_lower(ctx, f->Lp, m, f->ldp));
   }
-  MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
-  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  f->times[1] += now_s() - t0;
+  f->jitter = jitter;
+  if (!f->lp_pending) {
+    MLN_TRY(triinv_build(ctx, f->Lp, m, f->ldp, true, true, &f->tri));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    f->times[1] += now_s() - t0;
+  }
 
   if (f->full) {
     f->L = f->Lp;  // parameters.py:847-850
@@ -498,6 +531,7 @@ extern "C" int mln_fit_get_Lp(mln_fit* f, double* out) {
   mln_ctx* ctx = f->ctx;
   if (!f->Lp) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_ensure_lp(f));
   DevOut o;
   MLN_TRY(o.init(ctx, out, (size_t)f->m * f->m));
   MLN_TRY(launch_copy_block(ctx, f->Lp, f->ldp, o.dev, f->m, f->m, f->m));
@@ -513,6 +547,7 @@ extern "C" int mln_fit_get_L(mln_fit* f, int64_t row0, int64_t n_rows, double* o
   DevOut o;
   MLN_TRY(o.init(ctx, out, (size_t)n_rows * f->m));
   if (f->kspace) {  // materialise the requested rows of L = K Lp^-T on demand
+    MLN_TRY(fit_ensure_lp(f));
     double* tmp = nullptr;
     MLN_HIP(ctx, mln_dmalloc((void**)&tmp, sizeof(double) * (size_t)n_rows * f->ldl));
     int rc = launch_copy_block(ctx, f->L + row0 * f->ldl, f->ldl, tmp, f->ldl, n_rows, f->ldl);

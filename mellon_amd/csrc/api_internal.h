@@ -107,6 +107,10 @@ struct mln_fit {
   // jitter I = Lp Lp^T) and R R^T = M, the square root C = Lp^-1 R of C C^T = I + Lp^-1 (s K_s^T K_s) Lp^-T is never
   // formed and the Gram is never whitened:  f->C holds R,  P = R^-T,  f->Cinv = C^-1 = R^-1 Lp  (both triangular).
   double* Kj = nullptr;   // cov(xu, xu) + jitter I, full symmetric (m x ldp); implicit fits only
+  // MLN_FIT_DEFER_LP: f->Lp still holds Kj; it is factored together with the preconditioner's matrix (one batched chain of
+  // launches, linalg.hip dev_cholesky_lower2) or on first use (fit_ensure_lp), whichever comes first
+  bool lp_pending = false, lp_failed = false;
+  double jitter = 0.0;
   double* d_w = nullptr;  // m
   // last vector pair (z, w = Lp^-T z) produced by the library itself (Ridge init / MAP solve): lets
   // mln_transform / mln_weights_cholesky on that same z skip the triangular solve
@@ -190,6 +194,8 @@ int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m,
                    int64_t ldg, bool quantised = false);
 int emulated_ranks(const mln_ctx* ctx);
 int fit_ensure_kj(mln_fit* f);
+int fit_ensure_lp(mln_fit* f);     // a deferred Lp = chol(Kj) is factored now (no-op otherwise)
+int fit_lp_finish(mln_fit* f, int rc_chol, double t0);   // after either route factored f->Lp: block-scaled copies, bookkeeping
 // whiten = true: Lp^-1 (.) Lp^-T applied (implicit mode; a Gram whose eigenvalues are results); false: the raw K_s^T K_s
 int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride, bool whiten = true);
 int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev);

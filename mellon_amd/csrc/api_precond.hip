@@ -152,6 +152,7 @@ int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride, bool whiten
   if (const char* ev = mln_experiment("MELLON_AMD_GRAM_I8")) quant = quant && std::atoi(ev) != 0;
   int rc = gram_of(ctx, Ls, f->ldl * row_stride, rows, f->m, (double)row_stride, G, ldg, quant);   // all-reduced
   if (rc != MLN_OK || !whiten) return rc;
+  MLN_TRY(fit_ensure_lp(f));
   double* T = nullptr;
   {
     hipError_t e = mln_dmalloc((void**)&T, sizeof(double) * (size_t)f->m * ldg);
@@ -177,7 +178,7 @@ int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev) {
   MLN_TRY(launch_objective(ctx, a));
   MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
   MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
-  if (f->kspace) MLN_TRY(triinv_solve_left(ctx, f->tri, f->d_out + 1, 1, 1));   // Lp^-1 (K^T t)
+  if (f->kspace) { MLN_TRY(fit_ensure_lp(f)); MLN_TRY(triinv_solve_left(ctx, f->tri, f->d_out + 1, 1, 1)); }   // Lp^-1 (K^T t)
   MLN_HIP(ctx, hipMemcpyAsync(rhs_dev, f->d_out + 1, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
   return MLN_OK;
 }
@@ -196,23 +197,39 @@ void fit_drop_precond_operators(mln_fit* f) {
 }
 
 // f->C holds the matrix to factor -- explicit mode: the Gram L_s^T L_s (the prior's identity is added here); implicit
-// mode: M = s K_s^T K_s + Kj, the same Hessian at a = 1 in w-space (w = Lp^-T z), never whitened.  Factor it, and build
-// C^-1, P = Lp^-T C^-T and the stacked per-evaluation operators Q1 = [C^-T ; P], Q2 = [C^-1 | P^T].
+// mode: M = s K_s^T K_s + Kj, the same Hessian at a = 1 in w-space (w = Lp^-T z), never whitened.
+// Explicit mode: C C^T = that, C^-1, and the stacked per-evaluation operators Q1 = C^-T, Q2 = [C^-1 | C^-1].
 // Implicit mode (round 5): R R^T = M.  C = Lp^-1 R satisfies C C^T = I + Lp^-1 (s K_s^T K_s) Lp^-T -- the matrix rounds
 // 2-4 obtained by whitening the Gram with an explicit Lp^-1 (1.5 ms) and two m^3 GEMMs (3.7 ms) and then factored.  C is
-// not triangular, but every operator the solve needs is:  P = Lp^-T C^-T = R^-T,  C^-1 = R^-1 Lp (lower x lower),
-// C^-T = Lp^T R^-T.  One triangular product instead of the whitening, no explicit Lp^-1, and M -- a sum of a positive
-// semi-definite integer Gram and Kj -- cannot lose positive definiteness to the quantisation of its rows the way the
-// whitened matrix did on heavy-tailed data (round 4: "rebuild lost positive definiteness").
+// never formed.  With z = C^-T u the evaluation needs  w = Lp^-T z = R^-T u,  the prior 1/2 |z|^2 = 1/2 w^T Kj w  and
+// g_u = C^-1 z + R^-1 K^T (a - 1) = R^-1 (Kj w + K^T (a - 1)):  P = R^-T, R^-1 and Kj itself -- no product with Lp at all,
+// so the factor Lp is not even needed before the solve ends (fit_prepare may defer it: it then shares THIS chain of
+// launches, dev_cholesky_lower2).  M -- a sum of a positive semi-definite integer Gram and Kj -- cannot lose positive
+// definiteness to the quantisation of its rows the way the whitened matrix did on heavy-tailed data (round 4).
+//   f->C = R,  f->Cinv = R^-1 (lower),  f->P = R^-T (upper);  Q1, Q2 stay empty.
 int fit_factor_precond(mln_fit* f) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
   const size_t bytes = sizeof(double) * (size_t)m * ldg;
   int rc = f->kspace ? MLN_OK : launch_add_diag(ctx, f->C, m, ldg, 1.0);  // Ridge alpha = 1 / the prior's Hessian
-  if (rc == MLN_OK) rc = dev_cholesky_lower(ctx, f->C, m, ldg);
+  if (rc == MLN_OK && f->kspace && f->lp_pending && !f->lp_failed && f->ldp == ldg) {
+    // both factorisations in one chain: its 40 dependent block steps are latency, the second matrix only adds flops
+    const double t0 = now_s();
+    int bad = 0;
+    rc = dev_cholesky_lower2(ctx, f->C, f->Lp, m, ldg, &bad);
+    const int rc_lp = (rc == MLN_ERR_NOT_PD && !(bad & 2)) ? MLN_OK : rc;   // (bit 1 clear: only the preconditioner's matrix failed, Lp is fine)
+    if (rc == MLN_OK || rc == MLN_ERR_NOT_PD) {
+      const std::string msg = ctx->err;
+      const int rl = fit_lp_finish(f, rc_lp, t0);
+      if (rl != MLN_OK) return rl;                       // "cov(xu, xu) ...": the landmarks' own matrix is the failure
+      if (rc != MLN_OK) mln_set_error(ctx, msg);
+    }
+  } else if (rc == MLN_OK) {
+    rc = dev_cholesky_lower(ctx, f->C, m, ldg);
+  }
   TriInv t;
   if (rc == MLN_OK) rc = triinv_build(ctx, f->C, m, ldg, true, false, &t);
-  double *inv = nullptr, *cinv = nullptr;         // inv: the factor's explicit inverse; cinv: C^-1 (implicit mode: R^-1 Lp)
+  double* inv = nullptr;                             // the factor's explicit inverse
   auto zeroed = [&](double** p, const char* what) {
     hipError_t e = mln_dmalloc((void**)p, bytes);
     if (e == hipSuccess) e = hipMemsetAsync(*p, 0, bytes, ctx->stream);
@@ -224,34 +241,22 @@ int fit_factor_precond(mln_fit* f) {
   if (rc == MLN_OK && f->kspace) {
     zeroed(&f->P, "alloc P");
     if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ldg, f->P, ldg, m);        // P = R^-T
-    if (rc == MLN_OK) zeroed(&cinv, "alloc C^-1");
-    GemmArgs g{};                                                                  // C^-1 = R^-1 Lp: column <= k <= row
-    g.A = inv; g.lda = ldg; g.B = f->Lp; g.ldb = f->ldp; g.C = cinv; g.ldc = ldg;
-    g.M = m; g.N = m; g.K = m; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 0; g.kmode = 7; g.lower_only = 1;
-    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
-  } else {
-    cinv = inv;
-  }
-  if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs
+  } else if (rc == MLN_OK) {   // stacked operators for the per-evaluation row-GEMVs of the explicit factor
     const int64_t ld = ldg;
     const size_t blk = (size_t)m * ld;
-    const int nq1 = f->kspace ? 2 : 1;
-    hipError_t e = mln_dmalloc((void**)&f->Q1, sizeof(double) * blk * nq1);
+    hipError_t e = mln_dmalloc((void**)&f->Q1, sizeof(double) * blk);
     if (e == hipSuccess) e = mln_dmalloc((void**)&f->Q2, sizeof(double) * blk * 2);
-    if (e == hipSuccess) e = hipMemsetAsync(f->Q1, 0, sizeof(double) * blk * nq1, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(f->Q1, 0, sizeof(double) * blk, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(f->Q2, 0, sizeof(double) * blk * 2, ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "alloc stacked operators", __FILE__, __LINE__);
-    if (rc == MLN_OK) rc = launch_transpose(ctx, cinv, ld, f->Q1, ld, m);                     // C^-T
-    if (rc == MLN_OK && f->kspace) rc = launch_copy_block(ctx, f->P, ld, f->Q1 + blk, ld, m, ld);   // P below it
-    if (rc == MLN_OK) rc = launch_copy_block(ctx, cinv, ld, f->Q2, ld * 2, m, ld);            // C^-1
-    // explicit factor: g_u = C^-1 (z + L^T(a-1)) = [C^-1 | C^-1] [z ; r] -- the same two-segment product;
-    // implicit: P^T = R^-1 beside it
+    if (rc == MLN_OK) rc = launch_transpose(ctx, inv, ld, f->Q1, ld, m);                      // C^-T
+    if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2, ld * 2, m, ld);             // C^-1
+    // g_u = C^-1 (z + L^T(a-1)) = [C^-1 | C^-1] [z ; r] -- a two-segment product
     if (rc == MLN_OK) rc = launch_copy_block(ctx, inv, ld, f->Q2 + ld, ld * 2, m, ld);
   }
   (void)hipStreamSynchronize(ctx->stream);
   triinv_free(&t);
-  if (cinv != inv && inv) (void)mln_dfree(inv);
-  if (rc == MLN_OK) f->Cinv = cinv; else if (cinv) (void)mln_dfree(cinv);
+  if (rc == MLN_OK) f->Cinv = inv; else if (inv) (void)mln_dfree(inv);
   return rc;
 }
 
@@ -450,14 +455,18 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
     MLN_TRY(launch_objective(ctx, a));
     MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
     MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
-    MLN_TRY(fit_small_gemv(f, f->P, 1, f->d_out + 1, f->d_gu));
+    // u0 = R^-1 (s K_s^T t) ;  w0 = R^-T u0 ;  z0 = Lp^T w0
+    MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));
+    MLN_TRY(fit_small_gemv(f, f->P, 0, f->d_gu, f->d_w));
+    MLN_TRY(fit_ensure_lp(f));
+    MLN_TRY(fit_small_gemv(f, f->Lp, 1, f->d_w, f->d_z));
   } else {
     MLN_TRY(launch_objective(ctx, a));
     MLN_TRY(launch_reduce_obj(ctx, a, f->d_out));
     MLN_TRY(dev_allreduce(ctx, f->d_out, 1 + f->m));
     MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));
   }
-  MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_gu, f->d_z));       // z0 = C^-T (.)   [d_gu plays the role of u0]
+  if (!f->kspace) MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_gu, f->d_z));       // z0 = C^-T (.)   [d_gu plays the role of u0]
   MLN_TRY(fit_cache_pair_from_u(f, f->d_gu));
   MLN_HIP(ctx, hipMemcpyAsync(z0, f->d_z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -472,9 +481,19 @@ extern "C" int mln_precond_apply(mln_fit* f, int32_t mode, const double* in, dou
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   MLN_TRY(fit_build_precond(f, 1));
   MLN_HIP(ctx, hipMemcpyAsync(f->d_u, in, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
-  if (mode == 0 && f->kspace) {                                                  // u = C^T z = R^T (Lp^-T z)
-    MLN_TRY(fit_w_from_z(f, f->d_u, f->d_w, is_device_ptr(in) ? nullptr : in));
-    MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_w, f->d_gu));
+  if (f->kspace && mode >= 0 && mode <= 2) {
+    // C = Lp^-1 R (never formed):  u = C^T z = R^T (Lp^-T z) ;  z = C^-T u = Lp^T (R^-T u) ;  g_u = C^-1 g_z = R^-1 (Lp g_z)
+    MLN_TRY(fit_ensure_lp(f));
+    if (mode == 0) {
+      MLN_TRY(fit_w_from_z(f, f->d_u, f->d_w, is_device_ptr(in) ? nullptr : in));
+      MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_w, f->d_gu));
+    } else if (mode == 1) {
+      MLN_TRY(fit_small_gemv(f, f->P, 0, f->d_u, f->d_w));
+      MLN_TRY(fit_small_gemv(f, f->Lp, 1, f->d_w, f->d_gu));
+    } else {
+      MLN_TRY(fit_small_gemv(f, f->Lp, 0, f->d_u, f->d_w));
+      MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_w, f->d_gu));
+    }
   }
   else if (mode == 0) MLN_TRY(fit_small_gemv(f, f->C, 1, f->d_u, f->d_gu));     // u = C^T z
   else if (mode == 1) MLN_TRY(fit_small_gemv(f, f->Cinv, 1, f->d_u, f->d_gu));  // z = C^-T u

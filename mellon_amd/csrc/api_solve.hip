@@ -25,11 +25,12 @@ int fit_w_from_z(mln_fit* f, const double* z_dev, double* w_dev, const double* z
     MLN_HIP(ctx, hipMemcpyAsync(w_dev, f->d_w_cached, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
     return MLN_OK;
   }
+  MLN_TRY(fit_ensure_lp(f));
   MLN_HIP(ctx, hipMemcpyAsync(w_dev, z_dev, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
   return triinv_solve_left_T(ctx, f->tri, w_dev, 1, 1);
 }
 
-// remember (z, w) computed from the preconditioned variable: z = C^-T u (d_z), w = P u
+// remember (z, w) computed from the preconditioned variable: z = C^-T u (already in d_z), w = P u
 int fit_cache_pair_from_u(mln_fit* f, const double* u_dev) {
   mln_ctx* ctx = f->ctx;
   f->z_cached.assign((size_t)f->m, 0.0);
@@ -48,6 +49,7 @@ extern "C" int mln_objective(mln_fit* f, const double* z, double* loss, double* 
     return MLN_ERR_UNSUPPORTED;
   }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_ensure_lp(f));
   const int64_t m = f->m;
   MLN_HIP(ctx, hipMemcpyAsync(f->d_z, z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
@@ -113,10 +115,10 @@ extern "C" int mln_transform(mln_fit* f, const double* z, double mu, double* f_o
 }
 
 // One evaluation of the preconditioned objective at the device vector `u`, enqueued without any host wait:
-//   [z ; w] = Q1 u  ->  one pass over the n x m buffer  ->  fixed-order reduction  ->  all-reduce of [r ; lik]
-//   ->  g_u = Q2 [z ; r]                                     (z -> d_zr, r -> d_zr + ld2, lik -> d_zr[ld2 + m], g_u -> gn)
-//   explicit mode: f = L z + mu,            g_u = C^-1 (z + L^T (a - 1))             Q2 = [C^-1 | C^-1]
-//   implicit mode: f = K (P u) + mu,        g_u = C^-1 z + P^T (K^T (a - 1)),        Q2 = [C^-1 | P^T],  P = Lp^-T C^-T
+//   explicit mode: z = C^-T u  ->  one pass over the n x m buffer (f = L z + mu)  ->  fixed-order reduction  ->  all-reduce
+//                  of [r ; lik]  ->  g_u = C^-1 (z + r)      (z -> d_zr, r -> d_zr + ld2, lik -> d_zr[ld2 + m], g_u -> gn)
+//   implicit mode: w = R^-T u (d_w),  q = Kj w (d_zr)  ->  the pass (f = K w + mu)  ->  reduction, all-reduce
+//                  ->  g_u = R^-1 (q + r);  prior = 1/2 w . q   (api_precond.hip fit_factor_precond)
 // gate == nullptr: `use32` picks the streamed copy.  gate != nullptr (device-resident solver): both objective kernels
 // are launched and the one the solver's state does not select returns at once; everything is a no-op after DONE.
 // ev (optional): three events -- before the fp32 pass, between the two, after the fp64 pass.
@@ -124,8 +126,16 @@ int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32
                             hipEvent_t* ev, const std::vector<int64_t>* sub_strides) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ld = f->ldl, ld2 = f->ld2;
-  GemvTri g1{f->Q1, ld, f->kspace ? 2 * m : m, u_dev, f->d_zr, f->kspace ? f->d_w : nullptr, 1, m, m, 0, 0, gate};
-  MLN_TRY(launch_gemv_tri(ctx, g1));                                   // C^-T, P: upper triangular blocks
+  if (f->kspace) {
+    // w = R^-T u (upper triangular rows), then q = Kj w (full rows; the solver's prior is 1/2 w . q)
+    GemvTri g1{f->P, ld, m, u_dev, f->d_w, nullptr, 1, m, m, 0, 0, gate};
+    MLN_TRY(launch_gemv_tri(ctx, g1));
+    GemvTri gk{f->Kj, f->ldp, m, f->d_w, f->d_zr, nullptr, 2, m, m, 0, 0, gate};
+    MLN_TRY(launch_gemv_tri(ctx, gk));
+  } else {
+    GemvTri g1{f->Q1, ld, m, u_dev, f->d_zr, nullptr, 1, m, m, 0, 0, gate};
+    MLN_TRY(launch_gemv_tri(ctx, g1));                                 // z = C^-T u: upper triangular rows
+  }
   ObjArgs a = obj_args(f);
   a.z = f->kspace ? f->d_w : f->d_zr;
   a.gate = gate;
@@ -164,8 +174,14 @@ int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
   MLN_TRY(launch_reduce_obj2(ctx, a, f->d_zr + ld2 + m, f->d_zr + ld2));
   MLN_TRY(dev_allreduce(ctx, f->d_zr + ld2, m + 1));
-  GemvTri g2{f->Q2, 2 * ld, m, f->d_zr, gn_dev, nullptr, 0, m, m, ld, ld2, gate};
-  MLN_TRY(launch_gemv_tri(ctx, g2));                                   // C^-1 | P^T: lower triangular blocks
+  if (f->kspace) {
+    GemvTri g2{f->Cinv, ld, m, f->d_zr, gn_dev, nullptr, 0, m, m, 0, 0, gate};      // g_u = R^-1 (q + r)
+    g2.xadd = f->d_zr + ld2;
+    MLN_TRY(launch_gemv_tri(ctx, g2));
+  } else {
+    GemvTri g2{f->Q2, 2 * ld, m, f->d_zr, gn_dev, nullptr, 0, m, m, ld, ld2, gate};
+    MLN_TRY(launch_gemv_tri(ctx, g2));                                 // [C^-1 | C^-1] [z ; r]: lower triangular blocks
+  }
   return MLN_OK;
 }
 
@@ -179,14 +195,23 @@ int fit_objective_u(mln_fit* f, const double* u, double* loss, double* grad_u, d
   MLN_TRY(fit_enqueue_eval(f, f->d_u, f->d_gu, use32, nullptr, ev));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out, f->d_zr + f->ld2 + m, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipMemcpyAsync(f->h_out + 1, f->d_gu, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
-  MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->d_zr, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  // prior: 1/2 |z|^2 (explicit) = 1/2 w . (Kj w) (implicit: d_zr holds q = Kj w, d_w holds w)
+  MLN_HIP(ctx, hipMemcpyAsync(f->h_z, f->kspace ? f->d_w : f->d_zr, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+  if (f->kspace) MLN_HIP(ctx, hipMemcpyAsync(f->h_out + 1 + m, f->d_zr, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
   MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   obj_account(f, use32);
   double zz = 0.0;
-  for (int64_t j = 0; j < m; ++j) zz += f->h_z[j] * f->h_z[j];
+  for (int64_t j = 0; j < m; ++j) zz += f->h_z[j] * (f->kspace ? f->h_out[1 + m + j] : f->h_z[j]);
   *loss = f->h_out[0] + 0.5 * zz + 0.5 * (double)m * std::log(2.0 * M_PI);
   std::memcpy(grad_u, f->h_out + 1, sizeof(double) * m);
-  if (z_out) std::memcpy(z_out, f->h_z, sizeof(double) * m);
+  if (z_out && f->kspace) {                       // z = C^-T u = Lp^T w
+    MLN_TRY(fit_ensure_lp(f));
+    MLN_TRY(fit_small_gemv(f, f->Lp, 1, f->d_w, f->d_z));
+    MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
+    MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else if (z_out) {
+    std::memcpy(z_out, f->h_z, sizeof(double) * m);
+  }
   return MLN_OK;
 }
 
@@ -223,7 +248,8 @@ int fit_solver_alloc(mln_fit* f, int maxcor) {
   b.trace = p; p += 4 * 512;
   b.st = (SolverState*)p;
   b.ld = (int64_t)ld;
-  b.z = f->d_zr;
+  b.z = f->kspace ? f->d_w : f->d_zr;
+  b.z2 = f->kspace ? f->d_zr : nullptr;      // implicit mode: prior = 1/2 w . (Kj w)
   b.lik = f->d_zr + f->ld2 + f->m;
   f->sv_maxcor = maxcor;
   if (!f->h_state) MLN_HIP(ctx, hipHostMalloc((void**)&f->h_state, sizeof(SolverState), hipHostMallocDefault));
@@ -515,10 +541,17 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         fprintf(stderr, "[eval %d] %s mode=%d t=%.3g f=%.15g\n", i, ((int)tr[4 * i + 3] & 15) == MLN_GATE_F32 ? "f32" : (((int)tr[4 * i + 3] & 15) == MLN_GATE_F32C ? "f32c" : (((int)tr[4 * i + 3] & 15) == MLN_GATE_SUB ? (((int)tr[4 * i + 3] >> 4) ? "sub1" : "sub0") : "f64")),
                 (int)tr[4 * i + 2], tr[4 * i + 1], tr[4 * i]);
   }
-  // z = C^-T u and w = P u at the accepted point (one stacked product), remembered for transform / predictor weights
+  // z = C^-T u and w = P u at the accepted point, remembered for transform / predictor weights
   {
-    GemvTri g1{f->Q1, f->ldl, f->kspace ? 2 * m : m, f->sv.u, f->d_z, f->kspace ? f->d_w_cached : nullptr, 1, m, m, 0, 0, nullptr};
-    MLN_TRY(launch_gemv_tri(ctx, g1));
+    if (f->kspace) {                              // w = R^-T u, z = Lp^T w
+      GemvTri g1{f->P, f->ldl, m, f->sv.u, f->d_w_cached, nullptr, 1, m, m, 0, 0, nullptr};
+      MLN_TRY(launch_gemv_tri(ctx, g1));
+      MLN_TRY(fit_ensure_lp(f));
+      MLN_TRY(fit_small_gemv(f, f->Lp, 1, f->d_w_cached, f->d_z));
+    } else {
+      GemvTri g1{f->Q1, f->ldl, m, f->sv.u, f->d_z, nullptr, 1, m, m, 0, 0, nullptr};
+      MLN_TRY(launch_gemv_tri(ctx, g1));
+    }
     f->z_cached.assign((size_t)m, 0.0);
     MLN_HIP(ctx, hipMemcpyAsync(f->z_cached.data(), f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
     MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
@@ -539,8 +572,9 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
 extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
   if (!f || !z || !w) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
-  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_ensure_lp(f));
+  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   DevOut o;
   MLN_TRY(o.init(ctx, w, (size_t)f->m));
   if (f->kspace && !is_device_ptr(z) && f->z_cached.size() == (size_t)f->m &&
@@ -556,8 +590,9 @@ extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
 extern "C" int mln_weights_full(mln_fit* f, const double* y, int64_t p, double mu, double* w) {
   if (!f || !y || !w || p < 1) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
-  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_TRY(fit_ensure_lp(f));
+  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   const int64_t cnt = f->m * p;
   DevOut o;
   MLN_TRY(o.init(ctx, w, (size_t)cnt));

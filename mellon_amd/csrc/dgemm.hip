@@ -104,6 +104,7 @@ __device__ __forceinline__ void tile_store(double (*S)[BT + LPAD], const double 
 template <bool AK, bool BKC, int BT, int BKT, bool VEC>
 __global__ __launch_bounds__(256, 2) void k_dgemm(GemmArgs g, int64_t tiles_n, int64_t kchunk) {
   constexpr int TW = BT / 32;   // MFMA tiles per wave and dimension
+  if (g.batch > 1) { g.A += (int64_t)blockIdx.z * g.bsa; g.B += (int64_t)blockIdx.z * g.bsb; g.C += (int64_t)blockIdx.z * g.bsc; }
   __shared__ double As[BKT][BT + LPAD];
   __shared__ double Bs[BKT][BT + LPAD];
   // K-range modes 3 / 7: a tile's work grows with its row block (k <= row), so the row-major launch order ran the heaviest
@@ -548,6 +549,7 @@ template <bool AK, bool BKC, bool VEC, int MODE>
 __global__ __launch_bounds__(256, MODE == 1 ? 4 : (MODE == 2 ? 3 : 2)) void k_dgemm_mix(GemmArgs g, TileMap tmap, int64_t kchunk) {
   constexpr bool ONLY64 = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) double dgemm_smem[];
+  if (g.batch > 1) { g.A += (int64_t)blockIdx.z * g.bsa; g.B += (int64_t)blockIdx.z * g.bsb; g.C += (int64_t)blockIdx.z * g.bsc; }
   const int64_t bid = blockIdx.x;
   const bool big = !ONLY64 && bid < tmap.n_big;
   int64_t t = big ? bid : tmap.n_big + ((bid - tmap.n_big) >> 2);
@@ -636,7 +638,8 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   const int64_t n_active = count_active(g.lower_only, tiles_m, tiles_n);
   const int64_t n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int64_t slots = 2 * n_cu;
-  const int split = g.split_k > 1 ? g.split_k : 1;
+  const int nbatch = g.batch > 1 ? g.batch : 1;
+  const int split = (g.split_k > 1 ? g.split_k : 1) * nbatch;      // (for the tile policy a batch counts like a k-split: more workgroups per tile)
   static const int64_t min_tiles = mln_experiment("MELLON_AMD_GEMM_MIX_MIN") ? std::atoll(mln_experiment("MELLON_AMD_GEMM_MIX_MIN")) : -1;
   // (below one round of 128-tiles the launch is all quadrants, served by the quadrant-only instances -- MODE 1 / 2 of
   //  k_dgemm_mix, 40 KB of LDS.  Measured against k_dgemm's 64-wide tiles on the chains of the factorisations (A/B on one box,
@@ -659,17 +662,18 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   tmap.ring = ring;
   const int64_t nblk = n_big + 4 * (n_active - n_big);
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }
-  const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0);
-  int64_t kchunk = (g.K + split - 1) / split;
+  const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0) && (g.bsa % 2 == 0) && (g.bsb % 2 == 0);
+  const int ksplit = split / nbatch;
+  int64_t kchunk = (g.K + ksplit - 1) / ksplit;
   kchunk = ((kchunk + 15) / 16) * 16;
   if (kchunk <= 0) kchunk = 16;
-  dim3 grid((unsigned)nblk, (unsigned)split);
+  dim3 grid((unsigned)nblk, (unsigned)ksplit, (unsigned)nbatch);
   hipError_t e;
   if (n_big == 0) {
     const size_t lds = 4 * 16 * (64 + LPAD) * 8;
     // the ring: launches of at most two quadrants per CU, and (MELLON_AMD_GEMM_RING=2, experiment) every launch all of whose K
     // ranges qualify for it -- full K, a whole number of groups of four k-tiles
-    const bool all_ring = tmap.ring >= 2 && g.kmode == 0 && split == 1 && g.K >= 128 && (g.K & 63) == 0;
+    const bool all_ring = tmap.ring >= 2 && g.kmode == 0 && ksplit == 1 && g.K >= 128 && (g.K & 63) == 0;
     if (vec && tmap.ring && (nblk * split <= 2 * n_cu || all_ring)) e = dispatch_mix<true, 2>(g, tmap, grid, lds, ctx->stream, kchunk);
     else e = vec ? dispatch_mix<true, 1>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, 1>(g, tmap, grid, lds, ctx->stream, kchunk);
   } else {
@@ -731,13 +735,13 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   const int64_t tiles_m = (g.M + bt - 1) / bt, tiles_n = (g.N + bt - 1) / bt;
   const int64_t nblk = tiles_m * tiles_n;
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }
-  const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0);
+  const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0) && (g.bsa % 2 == 0) && (g.bsb % 2 == 0);
   constexpr int bkt = 16;   // measured: BK=32 (246 VGPRs, 74 KB LDS) is 10-20 % slower than BK=16 on every shape
   int split = g.split_k > 1 ? g.split_k : 1;
   int64_t kchunk = (g.K + split - 1) / split;
   kchunk = ((kchunk + bkt - 1) / bkt) * bkt;
   if (kchunk <= 0) kchunk = bkt;
-  dim3 grid((unsigned)nblk, (unsigned)split);
+  dim3 grid((unsigned)nblk, (unsigned)split, (unsigned)(g.batch > 1 ? g.batch : 1));
   if (bt == 64) {
     if (vec) dispatch<64, 16, true>(g, grid, ctx->stream, tiles_n, kchunk);
     else dispatch<64, 16, false>(g, grid, ctx->stream, tiles_n, kchunk);

@@ -22,15 +22,6 @@ int launch_copy_block(mln_ctx* ctx, const double* src, int64_t lds, double* dst,
 int launch_transpose(mln_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t m);  // dst = src^T (m x m)
 // potrf.hip: Cholesky of one nb x nb (nb <= 128) diagonal block in place + the inverse of its factor (Dinv: 128 x 128,
 // leading dimension 128, strictly-upper blocks untouched); *info = global pivot index + 1 on a bad pivot
-int launch_potrf128(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, int* info, int64_t j0);
+// nbatch > 1: the same block of nbatch matrices a_bs doubles apart (Dinv: nbatch slabs of 128 x 128, info: nbatch words)
+int launch_potrf128(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, int* info, int64_t j0, int nbatch = 1, int64_t a_bs = 0);
 
-// CU-masked side streams (linalg.hip).  Kernels of two streams only run side by side on this GPU when neither fills the
-// dispatcher (round 1: a second stream next to the 7813-workgroup kernel-matrix pass gained nothing).  A stream whose CU
-// mask leaves `free_cus` compute units out guarantees room for whatever the context's own (unmasked) stream launches
-// meanwhile.  Streams are created once per (context, free_cus) and live as long as the context; nullptr when the runtime
-// refuses (callers then keep everything on ctx->stream).  lookahead_disabled(): thread-local switch for a caller that
-// already shares the GPU with a long kernel (fit_prepare's landmark chain).
-hipStream_t masked_stream(mln_ctx* ctx, int free_cus);
-hipEvent_t masked_stream_event(mln_ctx* ctx, int which);     // four reusable events per context (timing disabled)
-void masked_streams_release(mln_ctx* ctx);
-void set_lookahead_disabled(bool off);

@@ -207,97 +207,30 @@ __global__ void k_copy_below_blocks(const double* __restrict__ src, double* __re
 // apply: with <= 39 row tiles a 128-tile launch is 14 us of serial work per CU), the trailing update as one
 // lower-tiles-only GEMM  A22 -= P P^T per PAIR of block columns.  The side matrix is copied under the block diagonal of
 // A at the end.
-// ---- CU-masked side streams ---------------------------------------------------------------------------------------
-namespace {
-struct MaskedStreams {
-  std::map<int, hipStream_t> by_free;     // free_cus -> stream (nullptr: creation failed, do not retry)
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-};
-std::mutex g_ms_mu;
-std::map<mln_ctx*, MaskedStreams> g_ms;
-thread_local bool t_no_lookahead = false;
-}  // namespace
-
-void set_lookahead_disabled(bool off) { t_no_lookahead = off; }
-
-hipStream_t masked_stream(mln_ctx* ctx, int free_cus) {
-  static const bool off = mln_experiment("MELLON_AMD_CU_MASK") && std::atoi(mln_experiment("MELLON_AMD_CU_MASK")) == 0;
-  if (off) return nullptr;
-  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 0;
-  if (n_cu < 64 || free_cus < 0 || free_cus * 2 > n_cu) return nullptr;
-  std::lock_guard<std::mutex> lk(g_ms_mu);
-  MaskedStreams& ms = g_ms[ctx];
-  auto it = ms.by_free.find(free_cus);
-  if (it != ms.by_free.end()) return it->second;
-  if (free_cus == 0) {                   // the unmasked companion: a second plain stream of this context
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
-    ms.by_free[0] = st;
-    return st;
-  }
-  // the LAST free_cus bits stay clear: with the CU index interleaved over the XCDs that is free_cus / 8 units per XCD,
-  // with an XCD-major index a corner of the last one -- both leave the room the side work needs
-  std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
-  for (int c = 0; c < n_cu - free_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
-  hipStream_t st = nullptr;
-  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
-  ms.by_free[free_cus] = st;
-  return st;
-}
-
-hipEvent_t masked_stream_event(mln_ctx* ctx, int which) {
-  std::lock_guard<std::mutex> lk(g_ms_mu);
-  MaskedStreams& ms = g_ms[ctx];
-  if (which < 0 || which > 3) return nullptr;
-  if (!ms.ev[which] && hipEventCreateWithFlags(&ms.ev[which], hipEventDisableTiming) != hipSuccess) ms.ev[which] = nullptr;
-  return ms.ev[which];
-}
-
-void masked_streams_release(mln_ctx* ctx) {
-  std::lock_guard<std::mutex> lk(g_ms_mu);
-  auto it = g_ms.find(ctx);
-  if (it == g_ms.end()) return;
-  for (auto& kv : it->second.by_free) if (kv.second) { (void)hipStreamSynchronize(kv.second); (void)hipStreamDestroy(kv.second); }
-  for (hipEvent_t e : it->second.ev) if (e) (void)hipEventDestroy(e);
-  g_ms.erase(it);
-}
-
 // Right-looking blocked Cholesky, two 128-wide block columns per round.  The critical path of a round is five dependent
-// launches -- diagonal block, panel, the narrow update of the second block column, its diagonal block, its panel: 2 x 50 us
-// of single-workgroup work and three ~14 us GEMMs that are launch + pipeline latency -- followed by the trailing update,
+// launches -- diagonal block, panel, the narrow update of the second block column, its diagonal block, its panel: 2 x 45 us
+// of single-workgroup work and three ~10 us GEMMs that are launch + pipeline latency -- followed by the trailing update,
 // the only launch with work for the whole chip (150 us at the start of a 5000 x 5000 factorisation, falling).
-// Round 4, LOOK-AHEAD across kernels: the trailing update is split into the two block columns the NEXT round factors
-// (`ahead`, on the context's own stream: the critical path) and the rest (`behind`, on a stream whose CU mask leaves 64
-// units free), and the next round's critical path runs while `behind` is still at work.  Dependencies: `behind` of round p
-// needs round p's panels (event after the second panel) and follows `behind` of round p - 1 (same stream); `ahead` of
-// round p + 1 overwrites what `behind` of round p wrote (event after `behind`).  Timeline of chol(5000), no look-ahead:
-// 20 x 141 us of critical path + 1.35 ms of trailing updates = 4.15 ms (profiles/r04_step_timeline.txt).
-int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
+// Timeline of chol(5000): 20 x 121 us of critical path + 1.1 ms of trailing updates = 3.5 ms (profiles/r04_step_timeline.txt).
+// (Round 4 measured LOOK-AHEAD across kernels -- the trailing update split into the next round's two block columns and the
+//  rest on a CU-masked side stream: each factorisation got ~1.2 ms SLOWER, the diagonal-block kernel 65 us instead of 50 next
+//  to the big GEMM; taken out in round 5, profiles/HISTORY.md.)
+// Round 5: nbatch (1 or 2) matrices of one shape go through the SAME chain of launches (grid z of the GEMMs, workgroup b of
+// the diagonal-block kernel): the chain is latency, so the second factorisation costs only its trailing-update flops --
+// chol(Kj) rides along with the preconditioner's chol(M) instead of taking 4.1 ms of its own before the kernel-matrix pass.
+static int cholesky_lower_batched(mln_ctx* ctx, double* A, int64_t m, int64_t lda, int nbatch, int64_t a_bs, int* bad) {
+  if (bad) *bad = 0;
   if (m <= 0) return MLN_OK;
   constexpr int CB = 128;
   double* Dinv = nullptr;
   double* Ls = nullptr;
-  MLN_HIP(ctx, mln_dmalloc((void**)&Dinv, sizeof(double) * CB * CB));
-  MLN_HIP(ctx, hipMemsetAsync(Dinv, 0, sizeof(double) * CB * CB, ctx->stream));
-  MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
-  if (m > CB) MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * (size_t)m * (size_t)lda));
+  const size_t mat = (size_t)m * (size_t)lda;
+  MLN_HIP(ctx, mln_dmalloc((void**)&Dinv, sizeof(double) * CB * CB * nbatch));
+  MLN_HIP(ctx, hipMemsetAsync(Dinv, 0, sizeof(double) * CB * CB * nbatch, ctx->stream));
+  MLN_HIP(ctx, hipMemsetAsync(ctx->d_info, 0, sizeof(int) * 2, ctx->stream));
+  if (m > CB) MLN_HIP(ctx, mln_dmalloc((void**)&Ls, sizeof(double) * mat * nbatch));
   int rc = MLN_OK;
-  // MEASURED (round 4, C3 on one MI355X, bench.py --steps 4): look-ahead ON 178.0 ms per fit, OFF 170.5 -- each of the three
-  // factorisations got ~1.2 ms SLOWER: with the trailing update running next to it the diagonal-block kernel takes 65 us
-  // instead of 50 and the small GEMMs of the critical path 18-20 us instead of 14 (they share L2 / HBM with it), which
-  // costs more than the ~45 us per round the overlap hides.  Off unless MELLON_AMD_CHOL_LOOKAHEAD=1.
-  static const bool la_env_on = mln_experiment("MELLON_AMD_CHOL_LOOKAHEAD") && std::atoi(mln_experiment("MELLON_AMD_CHOL_LOOKAHEAD")) != 0;
-  hipStream_t behind = (la_env_on && !t_no_lookahead && m >= 8 * CB) ? masked_stream(ctx, 64) : nullptr;
-  hipEvent_t ev_panels = behind ? masked_stream_event(ctx, 0) : nullptr;
-  hipEvent_t ev_behind = behind ? masked_stream_event(ctx, 1) : nullptr;
-  if (!ev_panels || !ev_behind) behind = nullptr;
-  hipStream_t const own = ctx->stream;
-  bool behind_pending = false;          // a `behind` update is in flight whose event the next `ahead` must wait for
-  if (behind) {                         // everything enqueued so far (the matrix itself) precedes the side stream's first read
-    hipError_t e = hipEventRecord(ev_panels, own);
-    if (e == hipSuccess) e = hipStreamWaitEvent(behind, ev_panels, 0);
-    if (e != hipSuccess) { (void)hipGetLastError(); behind = nullptr; }
-  }
+  auto batched = [&](GemmArgs& g, int64_t bsa, int64_t bsb, int64_t bsc) { if (nbatch > 1) { g.batch = nbatch; g.bsa = bsa; g.bsb = bsb; g.bsc = bsc; } };
   // Two block columns per round: the second one is brought up to date by a narrow GEMM (K = 128, 128 columns), and the
   // big trailing update then runs ONCE with K = 256 on the two panels side by side in the side matrix -- the same flops
   // as two K = 128 updates over nearly the same area, at half the per-tile prologue/epilogue cost.
@@ -305,11 +238,12 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
     GemmArgs g{};
     g.A = A + (j + nb) * lda + j; g.lda = lda; g.B = Dinv; g.ldb = CB; g.C = Ls + (j + nb) * lda + j; g.ldc = lda;
     g.M = rem; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
+    batched(g, a_bs, (int64_t)CB * CB, (int64_t)mat);
     return launch_dgemm(ctx, g);
   };
   for (int64_t j0 = 0; j0 < m && rc == MLN_OK; j0 += 2 * CB) {
     const int nb1 = (int)((m - j0 < CB) ? (m - j0) : CB);
-    rc = launch_potrf128(ctx, A + j0 * lda + j0, lda, nb1, Dinv, ctx->d_info, j0);
+    rc = launch_potrf128(ctx, A + j0 * lda + j0, lda, nb1, Dinv, ctx->d_info, j0, nbatch, a_bs);
     const int64_t rem1 = m - j0 - nb1;
     if (rc != MLN_OK || rem1 <= 0) break;
     rc = panel(j0, nb1, rem1);
@@ -321,10 +255,11 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
       GemmArgs u{};   // block column j1 only: A[j1.., j1..j1+nb2] -= P1 P1[0:nb2]^T
       u.A = P1; u.lda = lda; u.B = P1; u.ldb = lda; u.C = A + j1 * lda + j1; u.ldc = lda;
       u.M = rem1; u.N = nb2; u.K = nb1; u.alpha = -1.0; u.beta = 1.0; u.ta = 0; u.tb = 1;
+      batched(u, (int64_t)mat, (int64_t)mat, a_bs);
       rc = launch_dgemm(ctx, u);
       if (rc != MLN_OK) break;
     }
-    rc = launch_potrf128(ctx, A + j1 * lda + j1, lda, nb2, Dinv, ctx->d_info, j1);
+    rc = launch_potrf128(ctx, A + j1 * lda + j1, lda, nb2, Dinv, ctx->d_info, j1, nbatch, a_bs);
     const int64_t rem2 = rem1 - nb2;
     if (rc != MLN_OK || rem2 <= 0) break;
     rc = panel(j1, nb2, rem2);
@@ -334,46 +269,16 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
     GemmArgs t{};     // A22 -= [P1' P2] [P1' P2]^T on lower tiles, K = nb1 + nb2
     t.A = Pw; t.lda = lda; t.B = Pw; t.ldb = lda; t.C = A + j2 * lda + j2; t.ldc = lda;
     t.M = rem2; t.N = rem2; t.K = nb1 + nb2; t.alpha = -1.0; t.beta = 1.0; t.ta = 0; t.tb = 1; t.lower_only = 1;
-    const int64_t ahead_cols = 2 * CB;
-    if (behind && rem2 > ahead_cols + 4 * CB) {
-      hipError_t e = hipEventRecord(ev_panels, own);                  // both panels of this round are enqueued
-      // `ahead`: the next round's two block columns (all rows below), on the critical path's own stream -- after the
-      // previous round's `behind`, which wrote them last
-      if (e == hipSuccess && behind_pending) e = hipStreamWaitEvent(own, ev_behind, 0);
-      if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
-      GemmArgs a = t;
-      a.N = ahead_cols;                                               // (lower_only: tiles above the diagonal are skipped)
-      rc = launch_dgemm(ctx, a);
-      if (rc != MLN_OK) break;
-      // `behind`: everything to the right of those columns, rows from the same offset on
-      GemmArgs b = t;
-      b.A = Pw + ahead_cols * lda; b.B = b.A; b.C = A + (j2 + ahead_cols) * lda + (j2 + ahead_cols);
-      b.M = rem2 - ahead_cols; b.N = rem2 - ahead_cols;
-      e = hipStreamWaitEvent(behind, ev_panels, 0);
-      if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
-      ctx->stream = behind;
-      rc = launch_dgemm(ctx, b);
-      ctx->stream = own;
-      if (rc != MLN_OK) break;
-      e = hipEventRecord(ev_behind, behind);
-      if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
-      behind_pending = true;
-    } else {
-      if (behind_pending) {                                           // the plain update reads and writes what `behind` wrote
-        hipError_t e = hipStreamWaitEvent(own, ev_behind, 0);
-        if (e != hipSuccess) { rc = mln_hip_fail(ctx, e, "cholesky look-ahead events", __FILE__, __LINE__); break; }
-        behind_pending = false;
-      }
-      rc = launch_dgemm(ctx, t);
-    }
+    batched(t, (int64_t)mat, (int64_t)mat, a_bs);
+    rc = launch_dgemm(ctx, t);
   }
-  ctx->stream = own;
-  if (behind_pending) (void)hipStreamWaitEvent(own, ev_behind, 0);    // (also on the error paths: the frees below follow `own`)
-  int info = 0;
+  int info[2] = {0, 0};
   if (rc == MLN_OK) {
-    if (Ls) hipLaunchKernelGGL(k_copy_below_blocks, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, Ls, A, m, lda);
-    hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, A, m, lda);
-    hipError_t e = hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    for (int b = 0; b < nbatch; ++b) {
+      if (Ls) hipLaunchKernelGGL(k_copy_below_blocks, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, Ls + (size_t)b * mat, A + (int64_t)b * a_bs, m, lda);
+      hipLaunchKernelGGL(k_zero_upper, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, A + (int64_t)b * a_bs, m, lda);
+    }
+    hipError_t e = hipMemcpyAsync(info, ctx->d_info, sizeof(int) * 2, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "cholesky sync", __FILE__, __LINE__);
   } else {
@@ -381,11 +286,20 @@ int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) {
   }
   (void)mln_dfree(Dinv);
   if (Ls) (void)mln_dfree(Ls);
-  if (rc == MLN_OK && info != 0) {
-    mln_set_error(ctx, "Cholesky failed: non-positive or NaN pivot at index " + std::to_string(info - 1));
-    return MLN_ERR_NOT_PD;
-  }
+  if (rc != MLN_OK) return rc;
+  for (int b = nbatch - 1; b >= 0; --b)
+    if (info[b] != 0) {
+      if (bad) *bad |= 1 << b;
+      mln_set_error(ctx, "Cholesky failed: non-positive or NaN pivot at index " + std::to_string(info[b] - 1));
+      rc = MLN_ERR_NOT_PD;
+    }
   return rc;
+}
+
+int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda) { return cholesky_lower_batched(ctx, A, m, lda, 1, 0, nullptr); }
+
+int dev_cholesky_lower2(mln_ctx* ctx, double* A, double* A2, int64_t m, int64_t lda, int* bad) {
+  return cholesky_lower_batched(ctx, A, m, lda, 2, (int64_t)(A2 - A), bad);
 }
 
 // ---- triangular solves through block-scaled copies of the factor ------------------------------

@@ -49,6 +49,9 @@ struct GemmArgs {
   int lower_only;
   int split_k; int64_t c_split_stride;
   int kmode;
+  // batch > 1: that many independent products in ONE launch (grid z); operand b sits bsa / bsb / bsc doubles after operand 0
+  // (any sign: two separately allocated matrices are a batch of two).  Same shapes, same leading dimensions.
+  int batch; int64_t bsa, bsb, bsc;
 };
 int launch_dgemm(mln_ctx* ctx, const GemmArgs& g);
 int launch_sum_partials(mln_ctx* ctx, const double* parts, int n_parts, int64_t stride, double* out,
@@ -56,6 +59,9 @@ int launch_sum_partials(mln_ctx* ctx, const double* parts, int n_parts, int64_t 
 
 // linalg.hip (block-solve helpers are declared in linalg.h)
 int dev_cholesky_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda);       // in place; zeroes upper
+// the same for TWO matrices of one shape in one chain of launches (A2 may be anywhere: the pointer difference is the batch
+// stride); *bad (may be NULL): bit 0 / bit 1 set when the first / second matrix hit a non-positive pivot (MLN_ERR_NOT_PD then)
+int dev_cholesky_lower2(mln_ctx* ctx, double* A, double* A2, int64_t m, int64_t lda, int* bad);
 int launch_add_diag(mln_ctx* ctx, double* A, int64_t m, int64_t lda, double v);
 int launch_symmetrize_from_lower(mln_ctx* ctx, double* A, int64_t m, int64_t lda);
 // gram_i8.hip: lower 128-tiles of alpha * Q^T Q, Q = round(K 8355711) in three int8 digit planes, per k-chunk (`n_splits`

@@ -50,8 +50,10 @@ int launch_gemv_rows_tri(mln_ctx* ctx, const double* M, int64_t ld, int64_t rows
 struct GemvTri {
   const double* M; int64_t ld; int64_t rows;
   const double* x; double* y; double* y2;
-  int upper; int64_t blk, ncol, mseg, xseg;
+  int upper;                 // 0: lower triangular blocks, 1: upper triangular blocks, 2: full rows (columns [0, ncol))
+  int64_t blk, ncol, mseg, xseg;
   const int* gate;
+  const double* xadd;        // if given: the product is taken with x + xadd (first segment)
 };
 int launch_gemv_tri(mln_ctx* ctx, const GemvTri& g);
 

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows_tri(GemvTri g) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= g.rows) return;
   const int64_t i = r % g.blk;
-  const int64_t c_lo = g.upper ? (i & ~(int64_t)1) : 0, c_hi = g.upper ? g.ncol : i + 1;
+  const int64_t c_lo = (g.upper == 1) ? (i & ~(int64_t)1) : 0, c_hi = g.upper ? g.ncol : i + 1;
   const double* __restrict__ rowp = g.M + r * g.ld;
   double s0 = 0.0, s1 = 0.0;
   const int nseg = g.mseg ? 2 : 1;
@@ -647,26 +647,34 @@ __global__ __launch_bounds__(256) void k_gemv_rows_tri(GemvTri g) {
     const double* __restrict__ xb = g.x + sg * g.xseg;
     const d2* __restrict__ row = reinterpret_cast<const d2*>(rb);
     const d2* __restrict__ xv = reinterpret_cast<const d2*>(xb);
+    // x + xadd in the first segment (the implicit mode's last product: R^-1 (Kj w + K^T (a - 1)))
+    const d2* __restrict__ xa = (g.xadd && sg == 0) ? reinterpret_cast<const d2*>(g.xadd) : nullptr;
     // four 16-byte loads per lane in flight (a single one per iteration left the row at ~2 TB/s: latency-bound)
     int64_t p = c_lo / 2 + lane;
     const int64_t p_end = c_hi / 2;            // pairs [p, p_end) are complete
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
     for (; p + 192 < p_end; p += 256) {
       const d2 a0 = row[p], a1 = row[p + 64], a2 = row[p + 128], a3 = row[p + 192];
-      const d2 b0 = xv[p], b1 = xv[p + 64], b2 = xv[p + 128], b3 = xv[p + 192];
+      d2 b0 = xv[p], b1 = xv[p + 64], b2 = xv[p + 128], b3 = xv[p + 192];
+      if (xa) {
+        const d2 c0 = xa[p], c1 = xa[p + 64], c2 = xa[p + 128], c3 = xa[p + 192];
+        b0.x += c0.x; b0.y += c0.y; b1.x += c1.x; b1.y += c1.y; b2.x += c2.x; b2.y += c2.y; b3.x += c3.x; b3.y += c3.y;
+      }
       s0 = fma(a0.x, b0.x, s0); s1 = fma(a0.y, b0.y, s1);
       t0 = fma(a1.x, b1.x, t0); t1 = fma(a1.y, b1.y, t1);
       t2 = fma(a2.x, b2.x, t2); t3 = fma(a2.y, b2.y, t3);
       t4 = fma(a3.x, b3.x, t4); t5 = fma(a3.y, b3.y, t5);
     }
     for (; p < p_end; p += 64) {
-      const d2 a = row[p], b = xv[p];
+      const d2 a = row[p];
+      d2 b = xv[p];
+      if (xa) { const d2 c = xa[p]; b.x += c.x; b.y += c.y; }
       s0 = fma(a.x, b.x, s0);
       s1 = fma(a.y, b.y, s1);
     }
     s0 += (t0 + t2) + t4;
     s1 += (t1 + t3) + t5;
-    if ((c_hi & 1) && lane == 0) s0 = fma(rb[c_hi - 1], xb[c_hi - 1], s0);
+    if ((c_hi & 1) && lane == 0) s0 = fma(rb[c_hi - 1], xb[c_hi - 1] + (xa ? g.xadd[c_hi - 1] : 0.0), s0);
   }
   double s = s0 + s1;
 #pragma unroll

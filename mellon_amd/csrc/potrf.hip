@@ -75,8 +75,10 @@ __device__ __forceinline__ double frag(const double* M, int ldm, int r0, int c0,
 template <bool SIGNED>
 __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb, double* __restrict__ Dinv,
                                                   int* info, int64_t j0, double* __restrict__ DinvS, int* n_neg,
-                                                  unsigned long long* min_piv) {
+                                                  unsigned long long* min_piv, int64_t a_bs) {
   extern __shared__ double smem[];
+  // batched launch (dev_cholesky_lower2): workgroup b factors the block of matrix b -- its own Dinv slab and info word
+  A += (int64_t)blockIdx.x * a_bs; Dinv += (int64_t)blockIdx.x * NB * NB; info += blockIdx.x;
   double* T = smem;                        // NB x LDT
   double* Xd = smem + NB * LDT;            // NMB x MB x LDX: inverses of the 16 x 16 diagonal tiles
   double* Sg = Xd + NMB * MB * LDX;        // NB signs (SIGNED only)
@@ -389,15 +391,15 @@ __global__ __launch_bounds__(256) void k_potrf128(double* A, int64_t lda, int nb
 
 // Factorises the nb x nb (nb <= 128) lower block at A in place and writes T^-1 to Dinv (128 x 128, row-major, leading
 // dimension 128; entries above the diagonal are never written: the caller zeroes the buffer once).
-int launch_potrf128(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, int* info, int64_t j0) {
+int launch_potrf128(mln_ctx* ctx, double* A, int64_t lda, int nb, double* Dinv, int* info, int64_t j0, int nbatch, int64_t a_bs) {
   const size_t lds = sizeof(double) * (size_t)(NB * LDT + NMB * MB * LDX + NB);
   static bool configured = false;
   if (!configured) {
     MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf128<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  hipLaunchKernelGGL(k_potrf128<false>, dim3(1), dim3(256), lds, ctx->stream, A, lda, nb, Dinv, info, j0, (double*)nullptr,
-                     (int*)nullptr, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(k_potrf128<false>, dim3((unsigned)(nbatch > 1 ? nbatch : 1)), dim3(256), lds, ctx->stream, A, lda, nb, Dinv, info, j0,
+                     (double*)nullptr, (int*)nullptr, (unsigned long long*)nullptr, a_bs);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -412,7 +414,7 @@ int launch_potrf128_signed(mln_ctx* ctx, double* A, int64_t lda, int nb, double*
     MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf128<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
-  hipLaunchKernelGGL(k_potrf128<true>, dim3(1), dim3(256), lds, ctx->stream, A, lda, nb, Dinv, info, j0, DinvS, n_neg, min_piv);
+  hipLaunchKernelGGL(k_potrf128<true>, dim3(1), dim3(256), lds, ctx->stream, A, lda, nb, Dinv, info, j0, DinvS, n_neg, min_piv, (int64_t)0);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

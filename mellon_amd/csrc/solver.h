@@ -78,7 +78,8 @@ struct SolverBuffers {
   double *S, *Y;                 // maxcor x ld
   double *rho, *yy;              // maxcor each: 1 / s.y and y.y
   double* c;                     // m: gradient of (fp64 objective - 32-bit surrogate) at the last anchor
-  const double* z;               // z = C^-T un of the evaluation in flight (m)
+  const double* z;               // z = C^-T un of the evaluation in flight (m): the prior is 1/2 |z|^2 ...
+  const double* z2;              // ... or, when given, 1/2 z . z2  (implicit mode: z = w, z2 = Kj w: 1/2 w^T Kj w = 1/2 |Lp^T w|^2)
   const double* lik;             // its (all-reduced) likelihood sum
   int64_t ld;
   double* trace;                 // optional: 4 doubles per evaluation (loss, step, mode, gate), 512 entries

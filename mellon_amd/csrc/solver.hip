@@ -86,7 +86,8 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     gn[e] = on[e] ? b.gn[idx[e]] : 0.0;
     d[e] = on[e] ? b.d[idx[e]] : 0.0;
     const double zv = on[e] ? b.z[idx[e]] : 0.0;
-    zz = fma(zv, zv, zz);
+    const double z2v = b.z2 ? (on[e] ? b.z2[idx[e]] : 0.0) : zv;
+    zz = fma(zv, z2v, zz);
   }
   // ---- the evaluation that just finished: loss = 1/2 |z|^2 + (m/2) log 2 pi + likelihood sum (inference.py:45-46,89-91)
   zz = block_sum(zz, red);
