@@ -703,6 +703,12 @@ class Context:
                                                     1 if any_size else 0, r))
         return float(r[0]), float(r[1])
 
+    def diag_dgemm_batch(self, ta, tb, M, N, K, lower_only=0, kmode=0, beta=0.0):
+        """largest |one launch with batch = 2 - the two single launches| (mln_diag_dgemm_compare, any_size = 2)."""
+        r = (C.c_double * 2)()
+        self._check(self.lib.mln_diag_dgemm_compare(self.handle, int(ta), int(tb), M, N, K, lower_only, kmode, float(beta), 2, r))
+        return float(r[0])
+
     def gemm(self, A, B, ta=False, tb=False, alpha=1.0, beta=0.0, out=None):
         """out = alpha op(A) op(B) + beta out on the fp64 matrix cores (mln_gemm); A, B, out host arrays or
         DeviceArrays (2-D, row-major).  Returns a DeviceArray unless `out` is a host array."""

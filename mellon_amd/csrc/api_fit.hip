@@ -144,18 +144,26 @@ int fit_lp_finish(mln_fit* f, int rc_chol, double t0) {
     return rc_chol;
   }
   MLN_TRY(rc_chol);
-  MLN_TRY(triinv_build(ctx, f->Lp, f->m, f->ldp, true, true, &f->tri));
-  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   f->lp_pending = false;
+  f->tri_pending = true;       // the block-scaled copies for triangular SOLVES with Lp: built by the first call that solves
   f->times[1] += now_s() - t0;
   return MLN_OK;
 }
 
-int fit_ensure_lp(mln_fit* f) {
+int fit_ensure_lp(mln_fit* f, bool need_tri) {
   if (f->lp_failed) { mln_set_error(f->ctx, "cov(xu, xu) + jitter I is not positive definite"); return MLN_ERR_NOT_PD; }
-  if (!f->lp_pending) return MLN_OK;
-  const double t0 = now_s();
-  return fit_lp_finish(f, dev_cholesky_lower(f->ctx, f->Lp, f->m, f->ldp), t0);
+  if (f->lp_pending) {
+    const double t0 = now_s();
+    MLN_TRY(fit_lp_finish(f, dev_cholesky_lower(f->ctx, f->Lp, f->m, f->ldp), t0));
+  }
+  if (need_tri && f->tri_pending) {
+    const double t0 = now_s();
+    MLN_TRY(triinv_build(f->ctx, f->Lp, f->m, f->ldp, true, true, &f->tri));
+    MLN_HIP(f->ctx, hipStreamSynchronize(f->ctx->stream));
+    f->tri_pending = false;
+    f->times[1] += now_s() - t0;
+  }
+  return MLN_OK;
 }
 
 int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, int64_t n, int32_t d,
@@ -235,11 +243,13 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     const bool trace = std::getenv("MELLON_AMD_TRACE") != nullptr;
     MLN_HIP(ctx, mln_dmalloc((void**)&f->L, l_bytes));
     if (trace) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, "[trace] L alloc %.4f s\n", now_s() - t0); }
-    // Mixed precision (default on for large implicit fits, MELLON_AMD_MIXED=0 disables): the kernel-matrix
-    // pass also writes an fp32 copy, which the first passes of the MAP solve stream instead of the fp64 one.
+    // Mixed precision (OPT-IN since round 5: MELLON_AMD_MIXED=1, large implicit fits): the kernel-matrix pass also writes
+    // a 32-bit copy, which the first passes of the MAP solve stream instead of the fp64 one.  The product default is the
+    // pure-fp64 solve: with the subsample phase and the rebuilt preconditioner the mixed solve measured no faster
+    // (174.3 against 176.9 ms at C3) for +20 GB of HBM and a surrogate-correction state machine on the path.
     int64_t mixed_min = (int64_t)1 << 27;
-    bool mixed = (flags & MLN_FIT_IMPLICIT) != 0;
-    if (const char* ev = std::getenv("MELLON_AMD_MIXED")) mixed = mixed && std::atoi(ev) != 0;
+    bool mixed = false;
+    if (const char* ev = std::getenv("MELLON_AMD_MIXED")) mixed = (flags & MLN_FIT_IMPLICIT) != 0 && std::atoi(ev) != 0;
     if (const char* ev = std::getenv("MELLON_AMD_MIXED_MIN_ELEMS")) mixed_min = std::atoll(ev);
     if (mixed && n * m >= mixed_min && n > 0 && m <= 8192)     // (beyond 8192 landmarks the pass is segmented: objective.hip)
       MLN_HIP(ctx, mln_dmalloc((void**)&f->L32, sizeof(float) * (size_t)n * f->ldl));
@@ -273,6 +283,8 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     } else {
       MLN_TRY(launch_kernel_matrix(ctx, f->cov, dx.dev, n, du.dev, m, d, f->L, f->ldl, 0.0, f->L32, f->l32_fixed));
     }
+    // the evaluation workspace (device vectors, pinned mirrors, events: ~0.5 ms of host calls) while the pass runs
+    MLN_TRY(fit_alloc_workspace(f));
     if (f->L32 && f->l32_fixed)
       if (const char* ev = mln_experiment("MELLON_AMD_COPY_BITS")) {   // experiment: the copy rounded to fewer bits
         const int bits = std::atoi(ev);
@@ -292,7 +304,7 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
       f->times[2] += now_s() - t0;
     }
   }
-  MLN_TRY(fit_alloc_workspace(f));
+  if (!f->d_u) MLN_TRY(fit_alloc_workspace(f));
   return MLN_OK;
 }
 
@@ -531,7 +543,7 @@ extern "C" int mln_fit_get_Lp(mln_fit* f, double* out) {
   mln_ctx* ctx = f->ctx;
   if (!f->Lp) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  MLN_TRY(fit_ensure_lp(f));
+  MLN_TRY(fit_ensure_lp(f, false));
   DevOut o;
   MLN_TRY(o.init(ctx, out, (size_t)f->m * f->m));
   MLN_TRY(launch_copy_block(ctx, f->Lp, f->ldp, o.dev, f->m, f->m, f->m));

@@ -109,7 +109,7 @@ struct mln_fit {
   double* Kj = nullptr;   // cov(xu, xu) + jitter I, full symmetric (m x ldp); implicit fits only
   // MLN_FIT_DEFER_LP: f->Lp still holds Kj; it is factored together with the preconditioner's matrix (one batched chain of
   // launches, linalg.hip dev_cholesky_lower2) or on first use (fit_ensure_lp), whichever comes first
-  bool lp_pending = false, lp_failed = false;
+  bool lp_pending = false, lp_failed = false, tri_pending = false;
   double jitter = 0.0;
   double* d_w = nullptr;  // m
   // last vector pair (z, w = Lp^-T z) produced by the library itself (Ridge init / MAP solve): lets
@@ -194,7 +194,7 @@ int gram_of(mln_ctx* ctx, const double* A, int64_t lda, int64_t rows, int64_t m,
                    int64_t ldg, bool quantised = false);
 int emulated_ranks(const mln_ctx* ctx);
 int fit_ensure_kj(mln_fit* f);
-int fit_ensure_lp(mln_fit* f);     // a deferred Lp = chol(Kj) is factored now (no-op otherwise)
+int fit_ensure_lp(mln_fit* f, bool need_tri = true);   // a deferred Lp = chol(Kj) is factored now, its solve operands built (no-ops otherwise)
 int fit_lp_finish(mln_fit* f, int rc_chol, double t0);   // after either route factored f->Lp: block-scaled copies, bookkeeping
 // whiten = true: Lp^-1 (.) Lp^-T applied (implicit mode; a Gram whose eigenvalues are results); false: the raw K_s^T K_s
 int fit_gram(mln_fit* f, double* G, int64_t ldg, int64_t row_stride, bool whiten = true);

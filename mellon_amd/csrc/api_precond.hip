@@ -458,7 +458,7 @@ extern "C" int mln_ridge_init(mln_fit* f, const double* target, double* z0) {
     // u0 = R^-1 (s K_s^T t) ;  w0 = R^-T u0 ;  z0 = Lp^T w0
     MLN_TRY(fit_small_gemv(f, f->Cinv, 0, f->d_out + 1, f->d_gu));
     MLN_TRY(fit_small_gemv(f, f->P, 0, f->d_gu, f->d_w));
-    MLN_TRY(fit_ensure_lp(f));
+    MLN_TRY(fit_ensure_lp(f, false));
     MLN_TRY(fit_small_gemv(f, f->Lp, 1, f->d_w, f->d_z));
   } else {
     MLN_TRY(launch_objective(ctx, a));

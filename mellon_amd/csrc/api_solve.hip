@@ -205,7 +205,7 @@ int fit_objective_u(mln_fit* f, const double* u, double* loss, double* grad_u, d
   *loss = f->h_out[0] + 0.5 * zz + 0.5 * (double)m * std::log(2.0 * M_PI);
   std::memcpy(grad_u, f->h_out + 1, sizeof(double) * m);
   if (z_out && f->kspace) {                       // z = C^-T u = Lp^T w
-    MLN_TRY(fit_ensure_lp(f));
+    MLN_TRY(fit_ensure_lp(f, false));
     MLN_TRY(fit_small_gemv(f, f->Lp, 1, f->d_w, f->d_z));
     MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDeviceToHost, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -546,7 +546,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     if (f->kspace) {                              // w = R^-T u, z = Lp^T w
       GemvTri g1{f->P, f->ldl, m, f->sv.u, f->d_w_cached, nullptr, 1, m, m, 0, 0, nullptr};
       MLN_TRY(launch_gemv_tri(ctx, g1));
-      MLN_TRY(fit_ensure_lp(f));
+      MLN_TRY(fit_ensure_lp(f, false));
       MLN_TRY(fit_small_gemv(f, f->Lp, 1, f->d_w_cached, f->d_z));
     } else {
       GemvTri g1{f->Q1, f->ldl, m, f->sv.u, f->d_z, nullptr, 1, m, m, 0, 0, nullptr};
@@ -573,8 +573,7 @@ extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
   if (!f || !z || !w) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  MLN_TRY(fit_ensure_lp(f));
-  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
+  if (!f->Lp) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   DevOut o;
   MLN_TRY(o.init(ctx, w, (size_t)f->m));
   if (f->kspace && !is_device_ptr(z) && f->z_cached.size() == (size_t)f->m &&
@@ -582,6 +581,7 @@ extern "C" int mln_weights_cholesky(mln_fit* f, const double* z, double* w) {
     MLN_HIP(ctx, hipMemcpyAsync(o.dev, f->d_w_cached, sizeof(double) * f->m, hipMemcpyDeviceToDevice, ctx->stream));
     return o.commit();
   }
+  MLN_TRY(fit_ensure_lp(f));
   MLN_HIP(ctx, hipMemcpyAsync(o.dev, z, sizeof(double) * f->m, hipMemcpyDefault, ctx->stream));
   MLN_TRY(triinv_solve_left_T(ctx, f->tri, o.dev, 1, 1));  // conditional.py:818
   return o.commit();
@@ -591,8 +591,8 @@ extern "C" int mln_weights_full(mln_fit* f, const double* y, int64_t p, double m
   if (!f || !y || !w || p < 1) return MLN_ERR_ARG;
   mln_ctx* ctx = f->ctx;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
+  if (!f->Lp) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   MLN_TRY(fit_ensure_lp(f));
-  if (!f->tri.W2) { mln_set_error(ctx, "this fit handle holds no Lp"); return MLN_ERR_ARG; }
   const int64_t cnt = f->m * p;
   DevOut o;
   MLN_TRY(o.init(ctx, w, (size_t)cnt));

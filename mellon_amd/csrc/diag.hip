@@ -172,47 +172,64 @@ extern "C" int mln_diag_dgemm_compare(mln_ctx* ctx, int32_t ta, int32_t tb, int6
   const size_t a_bytes = sizeof(double) * (size_t)(ta ? K : M) * lda, b_bytes = sizeof(double) * (size_t)(tb ? N : K) * ldb;
   const size_t c_count = (size_t)M * ldc;
   double *A = nullptr, *B = nullptr, *C0 = nullptr, *C1 = nullptr, *res = nullptr;
-  MLN_HIP(ctx, mln_dmalloc((void**)&A, a_bytes));
-  MLN_HIP(ctx, mln_dmalloc((void**)&B, b_bytes));
-  MLN_HIP(ctx, mln_dmalloc((void**)&C0, c_count * 8));
-  MLN_HIP(ctx, mln_dmalloc((void**)&C1, c_count * 8));
+  // any_size == 2 (round 5): the BATCH dimension -- two products on different operands, once as two launches, once as one
+  // launch with batch = 2; everything twice as large, kmode / lower_only as given
+  const bool batch_mode = any_size == 2;
+  const size_t nb = batch_mode ? 2 : 1;
+  MLN_HIP(ctx, mln_dmalloc((void**)&A, a_bytes * nb));
+  MLN_HIP(ctx, mln_dmalloc((void**)&B, b_bytes * nb));
+  MLN_HIP(ctx, mln_dmalloc((void**)&C0, c_count * 8 * nb));
+  MLN_HIP(ctx, mln_dmalloc((void**)&C1, c_count * 8 * nb));
   MLN_HIP(ctx, mln_dmalloc((void**)&res, 16));
   std::vector<double> pat((1 << 20) + 7);
   unsigned long long s = 88172645463325252ULL;
   for (auto& v : pat) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (double)(s >> 11) / 9007199254740992.0 - 0.5; }
-  auto fill = [&](double* p, size_t bytes) -> hipError_t {
-    for (size_t off = 0; off < bytes; off += pat.size() * 8) {
-      hipError_t e = hipMemcpyAsync((char*)p + off, pat.data(), std::min(pat.size() * 8, bytes - off), hipMemcpyHostToDevice, ctx->stream);
+  auto fill = [&](double* p, size_t bytes, size_t phase) -> hipError_t {
+    for (size_t off = 0; off < bytes; off += (pat.size() - phase) * 8) {
+      hipError_t e = hipMemcpyAsync((char*)p + off, pat.data() + phase, std::min((pat.size() - phase) * 8, bytes - off), hipMemcpyHostToDevice, ctx->stream);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
   };
-  MLN_HIP(ctx, fill(A, a_bytes));
-  MLN_HIP(ctx, fill(B, b_bytes));
-  MLN_HIP(ctx, fill(C0, c_count * 8));     // the untouched part (upper triangle, beta * C) is the same in both
-  MLN_HIP(ctx, fill(C1, c_count * 8));
+  MLN_HIP(ctx, fill(A, a_bytes * nb, 0));
+  MLN_HIP(ctx, fill(B, b_bytes * nb, 3));
+  MLN_HIP(ctx, fill(C0, c_count * 8 * nb, 5));     // the untouched part (upper triangle, beta * C) is the same in both
+  MLN_HIP(ctx, fill(C1, c_count * 8 * nb, 5));
   MLN_HIP(ctx, hipMemsetAsync(res, 0, 16, ctx->stream));
   // the triangular K ranges are defined on 128-wide blocks for the 128-wide tiles and on 64-wide ones for the 64-wide: the
   // operand has to BE triangular for the two to mean the same product (every caller's is)
-  if (kmode == 3 || kmode == 7)      // op(A)[row, k] = 0 for k > row
-    hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, A, ta ? K : M, ta ? M : K, lda, ta ? 1 : 0);
-  if (kmode == 4)                    // op(B)[k, col] = 0 for k > col
-    hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, B, tb ? N : K, tb ? K : N, ldb, tb ? 0 : 1);
-  if (kmode == 7)                    // op(B)[k, col] = 0 for k < col
-    hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, B, tb ? N : K, tb ? K : N, ldb, tb ? 1 : 0);
+  for (size_t b = 0; b < nb; ++b) {
+    double* Ab = A + b * (a_bytes / 8); double* Bb = B + b * (b_bytes / 8);
+    if (kmode == 3 || kmode == 7)      // op(A)[row, k] = 0 for k > row
+      hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, Ab, ta ? K : M, ta ? M : K, lda, ta ? 1 : 0);
+    if (kmode == 4)                    // op(B)[k, col] = 0 for k > col
+      hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, Bb, tb ? N : K, tb ? K : N, ldb, tb ? 0 : 1);
+    if (kmode == 7)                    // op(B)[k, col] = 0 for k < col
+      hipLaunchKernelGGL(k_diag_zero_triangle, dim3(1024), dim3(256), 0, ctx->stream, Bb, tb ? N : K, tb ? K : N, ldb, tb ? 1 : 0);
+  }
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.alpha = 0.75; g.beta = beta; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = 1; g.kmode = kmode;
   int rc = MLN_OK;
-  dgemm_set_mix(0);
-  g.C = C0;
-  rc = launch_dgemm(ctx, g);
-  dgemm_set_mix(any_size ? 1 : -1);
-  g.C = C1;
-  if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
-  dgemm_set_mix(-1);
+  if (batch_mode) {
+    for (size_t b = 0; b < nb && rc == MLN_OK; ++b) {
+      GemmArgs h = g;
+      h.A = A + b * (a_bytes / 8); h.B = B + b * (b_bytes / 8); h.C = C0 + b * c_count;
+      rc = launch_dgemm(ctx, h);
+    }
+    g.C = C1; g.batch = 2; g.bsa = (int64_t)(a_bytes / 8); g.bsb = (int64_t)(b_bytes / 8); g.bsc = (int64_t)c_count;
+    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+  } else {
+    dgemm_set_mix(0);
+    g.C = C0;
+    rc = launch_dgemm(ctx, g);
+    dgemm_set_mix(any_size ? 1 : -1);
+    g.C = C1;
+    if (rc == MLN_OK) rc = launch_dgemm(ctx, g);
+    dgemm_set_mix(-1);
+  }
   if (rc == MLN_OK) {
-    hipLaunchKernelGGL(k_diag_absdiff, dim3(1024), dim3(256), 0, ctx->stream, C0, C1, (int64_t)c_count, ldc, (int)lower_only, res);
+    hipLaunchKernelGGL(k_diag_absdiff, dim3(1024), dim3(256), 0, ctx->stream, C0, C1, (int64_t)(c_count * nb), ldc, batch_mode ? 0 : (int)lower_only, res);
     hipError_t e = hipMemcpyAsync(out, res, 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "dgemm compare", __FILE__, __LINE__);

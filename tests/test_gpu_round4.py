@@ -75,9 +75,9 @@ def test_inputs_the_shortcuts_were_not_tuned_on(mellon, ctx, monkeypatch, case):
     scale = np.abs(plain[0]).max()
     # (last two: the range guard of the rebuild switched off -- on the tree the rebuilt preconditioner is then garbage, fails
     #  its trial and is replaced by the first one again; in the mixed solve the anchor taken at that point is dropped too)
-    for name, env in (("default fp64", {"MELLON_AMD_MIXED": "0"}), ("mixed", {}),
+    for name, env in (("default fp64", {"MELLON_AMD_MIXED": "0"}), ("mixed", {"MELLON_AMD_MIXED": "1"}),
                       ("fp64, rebuild never declines", {"MELLON_AMD_MIXED": "0", "MELLON_AMD_REBUILD_RANGE": "1e300"}),
-                      ("mixed, rebuild never declines", {"MELLON_AMD_REBUILD_RANGE": "1e300"})):
+                      ("mixed, rebuild never declines", {"MELLON_AMD_MIXED": "1", "MELLON_AMD_REBUILD_RANGE": "1e300"})):
         if case != "tree" and "never declines" in name:
             continue                     # (heavy tails: without the guard the whitening loses positive definiteness -- the fallback of its own test)
         dens, state, st, loss, gmax = _fit(mellon, xd, lm, nn, monkeypatch, **env)

@@ -1,0 +1,127 @@
+"""Round 5 (-m gpu): the preconditioner factored in w-space, the deferred landmark factor and its batched factorisation,
+the GEMM's batch dimension.  Everything goes through libmellon_hip.so; the oracle is the checker."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from oracle import mellon_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mellon_amd import _lib
+    return _lib.default_context()
+
+
+def _pair(product_cov):
+    return mo.Covariance.from_dict(product_cov.to_dict())
+
+
+def relmax(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _problem(n, d, m, seed):
+    x = mo.gaussian_mixture(n, d, seed=seed)
+    nn = mo.exact_nn_distances(x)
+    ls = mo.compute_ls(nn)
+    mu = mo.compute_mu(nn, d)
+    rng = np.random.default_rng(seed)
+    xu = x[np.sort(rng.choice(n, m, replace=False))]
+    return x, nn, ls, mu, xu
+
+
+@pytest.mark.parametrize("n,d,m,stride", [(4000, 6, 300, 1), (9000, 10, 517, 4), (3000, 4, 129, 3)])
+def test_implicit_fit_deferred_lp_and_w_space_preconditioner(ctx, n, d, m, stride):
+    """Implicit fits defer Lp = chol(cov(xu, xu) + jitter I) and factor it in ONE chain of launches with the preconditioner's
+    matrix M = s K_s^T K_s + Kj (dev_cholesky_lower2).  Checked here: the deferred factor equals the oracle's
+    (decomposition.py:111-123); the Ridge start equals the oracle's on the same cells (parameters.py:895-896); the variable
+    change z = C^-T u with C = Lp^-1 R round-trips and whitens the Ridge matrix; and the preconditioned objective is the
+    reference's objective of z (inference.py:167-192)."""
+    from mellon_amd import cov
+    x, nn, ls, mu, xu = _problem(n, d, m, seed=n + m)
+    c = cov.Matern52(ls)
+    oc = _pair(c)
+    fit = ctx.fit_prepare(c.lower(d), x, xu, 1e-6, implicit=True)
+    V, Vdr = mo.nn_likelihood_constants(nn, d)
+    fit.set_likelihood(V, Vdr, mu)
+    fit.precond_build(stride, 0, force=True)                 # batched: chol(M) and chol(Kj) side by side
+    Lp_ref = mo.full_rank(xu, oc)
+    assert relmax(fit.Lp(), Lp_ref) < 1e-8
+    L_ref = mo.standard_low_rank(x, oc, xu, Lp=Lp_ref)
+    # round trip of the variable change and the defining property C C^T = I + s L_s^T L_s  (mode 0: u = C^T z; 2: g_u = C^-1 g_z)
+    rng = np.random.default_rng(1)
+    z = rng.normal(size=m)
+    u = fit.precond_apply(0, z)
+    assert relmax(fit.precond_apply(1, u), z) < 1e-9
+    Ls = L_ref[::stride]
+    H = np.eye(m) + stride * (Ls.T @ Ls)
+    # C^-1 H C^-T = I  <=>  C^-1 (H (C^-T v)) = v
+    v = rng.normal(size=m)
+    zz = fit.precond_apply(1, v)                             # C^-T v
+    back = fit.precond_apply(2, H @ zz)                      # C^-1 H C^-T v
+    # (stride 1: the exact fp64 Gram -- what is left is eps * |M| / lambda_min(M), M = K^T K + Kj with lambda_min ~ the
+    #  jitter: the same bound the whitened form had through |Lp^-1|^2; a sampled Gram is the 23-bit integer one)
+    tol = 1e-4 if stride == 1 else 2e-3
+    assert relmax(back, v) < tol, relmax(back, v)
+    # the preconditioned objective is the reference's objective at z = C^-T u, its gradient C^-1 grad_z
+    loss_u, grad_u, z_of_u = fit.objective_precond(u)
+    loss_ref, grad_ref = mo.loss_and_grad(z, L_ref, mu, V, Vdr)
+    assert relmax(z_of_u, z) < 1e-9
+    assert abs(loss_u - loss_ref) / abs(loss_ref) < 1e-11
+    assert relmax(grad_u, fit.precond_apply(2, grad_ref)) < 1e-8
+    if stride == 1:
+        z0 = fit.ridge_init(mo.mle(nn, d) - mu)
+        assert relmax(z0, mo.compute_initial_value(nn, d, mu, L_ref)) < 1e-5   # (a start value: same conditioning remark)
+
+
+def test_deferred_lp_not_positive_definite_raises_the_reference_error(ctx):
+    """A deferred landmark factor that fails surfaces as the reference's ValueError (decomposition.py:116-122) with the FIT's
+    jitter in the message, from whichever call factors it: the batched chain of the preconditioner, or a direct request."""
+    from mellon_amd import cov
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(400, 3))
+    bad = (cov.Matern52(1.0) * -1.0).lower(3)
+    fit = ctx.fit_prepare(bad, x, x[:64], 1e-6, implicit=True)          # deferred: nothing factored yet
+    with pytest.raises(ValueError, match=r"not positively definite with jitter=1e-06"):
+        fit.precond_build(1, 0, force=True)
+    fit2 = ctx.fit_prepare(bad, x, x[:64], 1e-6, implicit=True)
+    with pytest.raises(ValueError, match=r"not positively definite with jitter=1e-06"):
+        fit2.Lp()
+    # the explicit route factors inside fit_prepare, as before
+    with pytest.raises(ValueError, match="not positively definite"):
+        ctx.fit_prepare(bad, x, x[:64], 1e-6)
+
+
+def test_estimator_default_is_pure_fp64_and_matches_the_oracle(ctx, monkeypatch):
+    """Round 5: the product default is the pure-fp64 solve (the 32-bit copy is opt-in, MELLON_AMD_MIXED=1); the default call
+    reproduces the oracle's tight optimum to the 1e-5 of BASELINE.json, Lp and the pre-transformation included."""
+    import mellon_amd as mellon
+    monkeypatch.delenv("MELLON_AMD_MIXED", raising=False)
+    monkeypatch.setenv("MELLON_AMD_MIXED_MIN_ELEMS", "0")                # (would force the copy if mixed were still the default)
+    x = mo.gaussian_mixture(8000, 8, seed=11)
+    nn = mo.exact_nn_distances(x)
+    rng = np.random.default_rng(3)
+    lm = x[np.sort(rng.choice(8000, 400, replace=False))]
+    ref = mo.density_fit(x, landmarks=lm, nn_distances=nn, lbfgsb_options=mo.LBFGSB_TIGHT)
+    est = mellon.DensityEstimator(landmarks=lm, nn_distances=nn)
+    dens = est.fit_predict(x)
+    st = est._fit.stage_times()
+    assert st["objective32_launches"] == 0 and st["objective_launches"] > 0
+    scale = np.abs(ref.log_density_x).max()
+    assert np.abs(dens - ref.log_density_x).max() / scale < 1e-5
+    assert np.std(dens - ref.log_density_x) / np.std(ref.log_density_x) < 1e-5
+    assert relmax(np.asarray(est.Lp), ref.Lp) < 1e-8
+    z = np.asarray(est.pre_transformation)
+    assert relmax(z, ref.pre_transformation) < 1e-4                      # (z carries cond(Lp); the density above is the contract)
+    # predict(X) == fit_predict(X)  (tests/test_density_estimator.py:40-44)
+    assert np.abs(est.predict(x[:500]) - dens[:500]).max() / scale < 1e-9
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
+def test_gemm_batch_dimension(ctx, ta, tb):
+    """GemmArgs.batch: two independent products in one launch (grid z) equal the two single launches bit for bit."""
+    r = ctx.diag_dgemm_batch(ta, tb, 700, 333, 256)
+    assert r == 0.0, r

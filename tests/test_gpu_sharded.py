@@ -112,6 +112,7 @@ def test_sharded_fit_mixed_precision_and_uneven_shards(workload, monkeypatch):
     """The fp32 warm-up passes (forced at this size) and shards of unequal length (n not divisible by N)."""
     x, nn, lm = workload
     x, nn = x[:-5], nn[:-5]
+    monkeypatch.setenv("MELLON_AMD_MIXED", "1")
     monkeypatch.setenv("MELLON_AMD_MIXED_MIN_ELEMS", "1")
     est1, dens1 = _fit_single(x, nn, lm)
     res = _fit_sharded(3, x, nn, lm)
