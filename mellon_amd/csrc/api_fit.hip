@@ -19,7 +19,7 @@ void fit_free(mln_fit* f) {
   triinv_free(&f->tri);
   void* ptrs[] = {f->V, f->Vdr, f->part_grad, f->part_hess, f->part_loss, f->d_z, f->d_out,
                   f->C, f->Cinv, f->d_u, f->d_gu, f->d_tmp, f->P, f->d_w, f->d_w_cached,
-                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block, f->f_keep[0], f->f_keep[1], f->Kj};
+                  f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block, f->f_keep[0], f->f_keep[1], f->Kj, f->d_over};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   for (double* p : f->saved_precond) if (p) (void)mln_dfree(p);
   if (f->h_state) (void)hipHostFree(f->h_state);
@@ -51,7 +51,7 @@ int fit_alloc_workspace(mln_fit* f) {
   f->n_wg = n_wg;
   n_wg = f->n_wg_cap;
   const size_t pm = (size_t)f->ldl;
-  f->ld2 = pad16(f->m + 1);
+  f->ld2 = pad16(f->m + 2);
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_u, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_gu, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_tmp, sizeof(double) * (1 + pm)));
@@ -60,6 +60,8 @@ int fit_alloc_workspace(mln_fit* f) {
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_zw, sizeof(double) * 2 * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_zr, sizeof(double) * 2 * (size_t)f->ld2));
   MLN_HIP(ctx, hipMemsetAsync(f->d_zr, 0, sizeof(double) * 2 * (size_t)f->ld2, ctx->stream));
+  MLN_HIP(ctx, mln_dmalloc((void**)&f->d_over, 64));
+  MLN_HIP(ctx, hipMemsetAsync(f->d_over, 0, 64, ctx->stream));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_grad, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_hess, sizeof(double) * pm * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_loss, sizeof(double) * n_wg));

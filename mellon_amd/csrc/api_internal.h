@@ -130,8 +130,10 @@ struct mln_fit {
   int evals32 = 0;
   double times32 = 0.0;
   // evaluation buffers of the preconditioned objective: d_zr = [z (ld2) | r (ld2)] with the likelihood sum at
-  // d_zr[ld2 + m], so that one all-reduce of m + 1 values covers [r ; lik];  ld2 = pad16(m + 1)
+  // d_zr[ld2 + m] and the "rows above the solver's cap" flag at d_zr[ld2 + m + 1], so that one all-reduce of m + 2 values
+  // covers [r ; lik ; over];  ld2 = pad16(m + 2)
   int64_t ld2 = 0;
+  int* d_over = nullptr;   // device word the objective kernels set when a row lay above the cap (ObjArgs::over_flag)
   int64_t row0 = 0;     // global index of this shard's first cell (subsampling is by global index)
   // device-resident L-BFGS (solver.hip)
   SolverBuffers sv{};
@@ -202,7 +204,7 @@ int fit_gemvT(mln_fit* f, const double* t_dev, double* rhs_dev);
 void fit_drop_precond_operators(mln_fit* f);
 int fit_factor_precond(mln_fit* f);
 int fit_build_precond(mln_fit* f, int64_t row_stride);
-int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int* outcome);   // outcome: 0 rebuilt, 1 weights too wild, 2 build failed (old one kept)
+int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int* outcome, double cap = 1e300);   // outcome: 0 rebuilt, 1 weights too wild, 2 build failed (old one kept)
 void fit_precond_saved_free(mln_fit* f);
 int fit_precond_revert(mln_fit* f);
 int fit_small_gemv(mln_fit* f, const double* M, int trans, const double* w, double* y);

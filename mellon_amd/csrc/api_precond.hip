@@ -306,7 +306,7 @@ int fit_precond_revert(mln_fit* f) {
 // cells, and the factor built from them stalled the solve for thousands of passes on tree-shaped data.  outcome 2: the
 // Gram's whitening lost positive definiteness (heavy-tailed data, w_max ~ 1e8: "Covariance not positively definite").
 // On success the FIRST preconditioner is kept in f->saved_precond until the solve ends (solver.h: revert_after).
-int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int* outcome) {
+int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int* outcome, double cap) {
   mln_ctx* ctx = f->ctx;
   const int64_t m = f->m, ldg = f->ldl;
   *outcome = 0;
@@ -322,12 +322,13 @@ int fit_rebuild_precond(mln_fit* f, const double* f_dev, double rows_per_m, int*
   double tl = now_s();
   // (Clipping the weights to a range of 1e3 .. 1e5 instead of declining was tried -- tools/clip_sweep.py,
   //  profiles/r04_clip_sweep.txt: the clipped preconditioner failed its trial on the tree and helped nowhere.)
-  MLN_TRY(rebuild_select_rows(ctx, f_dev, f->V, f->n, f->row0, target, 0x6d656c6c6f6eull, &sel));
+  MLN_TRY(rebuild_select_rows(ctx, f_dev, f->V, f->n, f->row0, target, 0x6d656c6c6f6eull, &sel, cap));
   lap(0, tl);
   if (tr_on)
     fprintf(stderr, "[trace] rebuild: %lld of %lld local rows kept (target %.0f global), c = %.4g, 1/c = %.4g, w_max = %.4g, sum a = %.6g\n",
             (long long)sel.rows, (long long)f->n, target, sel.c, 1.0 / sel.c, sel.w_max, sel.sum_a);
-  double range_cap = 1e5;
+  double range_cap = 1e7;      // (round 5: was 1e5 -- 11 of the 23 bits are left to the lightest rows at 1e7; the w-space factor cannot lose
+                               //  positive definiteness to their rounding)
   if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_RANGE")) range_cap = std::atof(ev);
   if (!(sel.w_max * sel.c <= range_cap) || !std::isfinite(sel.sum_a)) {   // (global quantities: the same decision on every rank)
     rebuild_selection_free(ctx, &sel);

@@ -141,6 +141,7 @@ int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32
   a.gate = gate;
   static const bool no_fkeep = mln_experiment("MELLON_AMD_NO_FKEEP") != nullptr;
   if (gate && !no_fkeep && f->f_keep[0] && objective_can_keep_f(f->n, f->n_wg)) { a.f_keep[0] = f->f_keep[0]; a.f_keep[1] = f->f_keep[1]; a.f_slot = &f->sv.st->f_slot; }
+  if (gate) { a.cap = &f->sv.st->cap; a.over_flag = f->d_over; }   // (round 5: the capped start applies to the fp64 and the subsample passes too)
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   if (f->L32 && (gate || use32)) {
     ObjArgs a32 = a;
@@ -173,7 +174,7 @@ int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32
   }
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
   MLN_TRY(launch_reduce_obj2(ctx, a, f->d_zr + ld2 + m, f->d_zr + ld2));
-  MLN_TRY(dev_allreduce(ctx, f->d_zr + ld2, m + 1));
+  MLN_TRY(dev_allreduce(ctx, f->d_zr + ld2, m + 2));
   if (f->kspace) {
     GemvTri g2{f->Cinv, ld, m, f->d_zr, gn_dev, nullptr, 0, m, m, 0, 0, gate};      // g_u = R^-1 (q + r)
     g2.xadd = f->d_zr + ld2;
@@ -251,6 +252,7 @@ int fit_solver_alloc(mln_fit* f, int maxcor) {
   b.z = f->kspace ? f->d_w : f->d_zr;
   b.z2 = f->kspace ? f->d_zr : nullptr;      // implicit mode: prior = 1/2 w . (Kj w)
   b.lik = f->d_zr + f->ld2 + f->m;
+  b.over = f->d_zr + f->ld2 + f->m + 1;
   f->sv_maxcor = maxcor;
   if (!f->h_state) MLN_HIP(ctx, hipHostMalloc((void**)&f->h_state, sizeof(SolverState), hipHostMallocDefault));
   return MLN_OK;
@@ -313,9 +315,18 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (const char* ev = mln_experiment("MELLON_AMD_LS_BOOST")) init.boost = std::atof(ev);
   // capped start (solver.hip): on the 32-bit copy the likelihood's e^t is continued linearly beyond t = 7 while the loss
   // still falls steeply; MELLON_AMD_EXP_CAP=<t> moves the cap, MELLON_AMD_EXP_CAP=off removes it
-  init.cap = phase32 ? 7.0 : __builtin_inf();
+  init.cap = 9.0;      // (tools/r05_ab_c3.sh, C3 seeds 3-6, mean step: off 149 ms | 5: 148 | 6: 164 | 7: 139 | 8: 140 | 9: 130 | 10: 132 | 12: ~158;
+                       //  tree / heavy tails at 1e6 cells, passes: 7: 130 / 86 | 8: 158 / 81 | 9: 158 / 97 -- against 511 / 473 without it)
+  init.cap_step = 4.0;
+  if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP_STEP")) init.cap_step = std::atof(ev);
   if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP"))
-    if (phase32) init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
+    init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
+  if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP64"))      // experiment: the cap of a pure-fp64 solve alone
+    if (!phase32) init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
+  // (the opt-in mixed solve runs WITHOUT the cap: its surrogate / anchor state machine was tuned with the round-2 linear cap,
+  //  and with the staged quadratic one the tree of tests/test_gpu_round4.py ran into the iteration limit)
+  if (phase32 && !mln_experiment("MELLON_AMD_EXP_CAP")) init.cap = __builtin_inf();
+  init.cap0 = init.cap;
   init.cap_fall = 0.15;
   if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP_FALL")) init.cap_fall = std::atof(ev);
   init.boost_fall = 0.15;
@@ -348,9 +359,11 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.gate_full = init.gate;
   init.sub_tol = 1e-3;
   if (const char* ev = mln_experiment("MELLON_AMD_SUB_TOL")) init.sub_tol = std::atof(ev);
+  init.sub_max_evals = 1 << 30;  // (off: the tree of tools/hard_cases.py spends 139 evaluations there -- and needs MORE passes in total with a limit of 48 or 32)
+  if (const char* ev = mln_experiment("MELLON_AMD_SUB_MAX_EVALS")) init.sub_max_evals = std::atoi(ev);
   init.n_sub_levels = (int)sub_strides.size();
   init.sub_level = 0;
-  if (subs) { init.gate = MLN_GATE_SUB; init.cap = __builtin_inf(); }
+  if (subs) init.gate = MLN_GATE_SUB;
   // Preconditioner rebuild (solver.h, precond_rebuild.hip): pays when the evaluations it saves (measured: 33-40 full
   // passes without it, 15-26 with it) cost more than the m^3 work of a second factorisation -- decided from rank 0's
   // measurement of the first build, the same on every rank.  An evaluation = one pass of this rank's rows + ~0.14 ms of
@@ -390,7 +403,19 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     want_rebuild = (vote[0] != 0.0 && vote[1] == 0.0) ? 1.0 : 0.0;
   }
-  init.rebuild_armed = want_rebuild != 0.0 ? 1 : 0;
+  // (round 5: up to max_rebuilds of them -- after the first, whenever the solve has fallen back to slow linear convergence,
+  //  solver.hip; C3 takes one)
+  int max_rebuilds = 1000;    // (rate-limited by the solver's own rules: six iterations apart, only on slow linear convergence)
+  if (const char* ev = mln_experiment("MELLON_AMD_MAX_REBUILDS")) max_rebuilds = std::max(1, std::atoi(ev));
+  init.rebuild_armed = want_rebuild != 0.0 ? (phase32 ? 1 : max_rebuilds) : 0;      // (the opt-in mixed solve keeps its single rebuild)
+  init.it_resume = -1;
+  // an overshooting start (solver.h over_many): more than one cell in 10 000 above the cap
+  {
+    double frac = 1e-4;
+    if (const char* ev = mln_experiment("MELLON_AMD_EARLY_REBUILD_FRAC")) frac = std::atof(ev);
+    init.over_many = frac > 0.0 ? std::max(8.0, frac * (double)f->n * (double)(ctx->n_ranks > 1 ? ctx->n_ranks : 1)) : 0.0;
+  }
+  init.over_cnt_acc = 0.0;
   init.rebuild_at_switch = 0;     // (measured: at the switch the unseen cells' weights are still too wild -- 37-96 full passes)
   if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_AT_SWITCH")) init.rebuild_at_switch = std::atoi(ev) != 0 ? 1 : 0;
   init.switch_t0 = 0.35;
@@ -406,12 +431,13 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.revert_after = 0; init.it_at_resume = -1; init.pause_reason = 0;
   int revert_after = 60;         // accepted iterations a rebuilt preconditioner gets to finish the solve (C3: ~9)
   if (const char* ev = mln_experiment("MELLON_AMD_REVERT_AFTER")) revert_after = std::atoi(ev);
-  double rebuild_rows_per_m = 6.0;   // (6 m, 12 m, 24 m importance-sampled rows: the same pass counts; 6 m is the cheapest Gram)
+  double rebuild_rows_per_m = 6.0;   // (first rebuild -- C3: 6 m, 12 m, 24 m importance-sampled rows give the same pass counts, 6 m is the cheapest Gram;
+                                     //  the later ones, which only slow solves reach, take twice as many: tree 169 -> 150, 115 -> 79, heavy tails 128 -> 104 passes)
   if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_ROWS_PER_M")) rebuild_rows_per_m = std::atof(ev);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
   const int* gate = &f->sv.st->gate;
   static const bool timing = !(std::getenv("MELLON_AMD_TIMING") && std::atoi(std::getenv("MELLON_AMD_TIMING")) == 0);
-  int n_enq = 0;
+  int n_enq = 0, rebuilds_this_solve = 0, failed_rebuilds = 0;
   auto events_for = [&](int i) -> hipEvent_t* {
     if (!timing || i >= 512) return nullptr;
     while ((int)f->evs.size() < 3 * (i + 1)) {
@@ -467,7 +493,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         //  but that measured 1-3 full passes WORSE than a fresh history at C3, five data seeds: the new factor already holds
         //  the curvature the old pairs describe, relative to a metric that is gone.  They are dropped.)
         int outcome = 0;
-        if (rc == MLN_OK) rc = revert ? fit_precond_revert(f) : fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m, &outcome);
+        if (rc == MLN_OK) rc = revert ? fit_precond_revert(f) : fit_rebuild_precond(f, f->f_keep[ps.f_slot], rebuild_rows_per_m * (rebuilds_this_solve > 0 ? 2.0 : 1.0), &outcome, ps.cap);
         if (rc == MLN_OK && outcome == 0) {
           // z-space -> new variable:  u = C^T z,  g_u = C^-1 g_z      (w-space:  u = R^T w,  g_u = R^-1 g_w = P^T g_w)
           rc = fit_small_gemv(f, f->C, 1, zt, f->sv.u);
@@ -484,16 +510,19 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
           if (revert && ps.corr && (ps.gate_after_pause & 3) == MLN_GATE_F32)
             MLN_TRY(launch_solver_resume_plain32(ctx, f->sv, MLN_GATE_F32, (int)m, 1));
           else
-            MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1, revert ? 0 : revert_after));
-          if (revert) f->n_revert += 1; else f->n_rebuild += 1;
+            // (the trial applies to the LAST rebuild the solve is allowed: while more remain, a stall leads to the next one)
+            MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 1, (revert || ps.rebuild_armed > 0) ? 0 : revert_after));
+          if (revert) f->n_revert += 1; else { f->n_rebuild += 1; rebuilds_this_solve += 1; }
         } else {
           // the rebuild declined (weights too wild) or lost positive definiteness: same variable, same history, carry on --
           // in the mixed solve WITHOUT the anchor just taken: the pause came far from the optimum (that is what the weights
           // say), where the fp64 objective and its 32-bit surrogate differ by more than a first-order correction mends (heavy
           // tails at 1e6 cells: 1e15 in the loss; the corrected surrogate then ran to the iteration limit).  The solve
           // continues on the plain surrogate and anchors when THAT has converged, as a mixed solve without rebuild does.
+          // (two attempts that came to nothing: the solve goes on without asking again)
+          failed_rebuilds += 1;
           if (ps.corr && (ps.gate_after_pause & 3) == MLN_GATE_F32) MLN_TRY(launch_solver_resume_plain32(ctx, f->sv, MLN_GATE_F32, (int)m));
-          else MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0));
+          else MLN_TRY(launch_solver_resume(ctx, f->sv, ps.gate_after_pause, 0, 0, failed_rebuilds >= 2 ? 0 : -1));
           f->n_rebuild_skipped += 1;
         }
         if (trace_lvl) fprintf(stderr, "[trace] map_solve pause at evaluation %d: %s\n", ps.n_eval,

@@ -17,7 +17,9 @@ struct ObjArgs {
   double* f_keep[2];      // if f_slot is non-null: f_i = L_i . z + mu of every row is also stored to f_keep[1 - *f_slot]
   const int* f_slot;      //   (the solver's "trial" buffer; accepting a point flips the slot -- the log-density at the
                           //    optimum then needs no pass of its own)
-  const double* cap;      // if non-null (device): e^t is continued linearly beyond t = *cap (32-bit kernel; solver.hip "cap")
+  const double* cap;      // if non-null (device): e^t is continued linearly beyond t = *cap (solver.hip "capped start")
+  int* over_flag;         // if non-null (device): += the number of rows of this launch above the cap (> 0: the capped and the true
+                          //   objective differ at this point); read and cleared by the reduction (launch_reduce_obj2 -> out_loss[1])
   const int* gate;        // if non-null: the launch is a no-op unless *gate == gate_want (device-resident solver:
   int gate_want;          //   MLN_GATE_F64 / MLN_GATE_F32 select the streamed copy, MLN_GATE_DONE stops everything)
   int64_t row_stride;     // > 1: the pass covers the rows row_first + i * row_stride, i < n (n = their number), of the

@@ -128,7 +128,10 @@ template <int CPT, int R, int MODE, bool KEEP, bool VEC = false>
 __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                              const d2 (&v)[R][CPT], const d2 (&z)[CPT], d2 (&g)[CPT],
                                              d2 (&h)[CPT], double& loss, double (*red)[8][R], double* fstage,
-                                             int64_t fbase, const double (&pv)[2][R]) {
+                                             int64_t fbase, const double (&pv)[2][R], const double capv, int& any_over) {
+  // capv (+inf unless the solver's cap is on): beyond t = capv, e^t is continued by its second-order Taylor polynomial there --
+  // e^cap (1 + d + d^2 / 2), d = t - cap: a convex C^2 minorant with curvature bounded by e^cap, identical to e^t wherever no
+  // row is above the cap (solver.hip "capped start"; round 5: quadratic instead of linear, and in the fp64 / subsample passes too)
   double coef[R], aexp[R];
   const RowMap rm = row_map(a);
   if constexpr (MODE == MODE_GEMVT) {
@@ -163,14 +166,19 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
     const bool rok = lane < R && (row + rl) < row_end;
     const double f = sr + a.mu;
     const double Vi = pv[0][0];                       // (this lane's row: load_lik_vec)
-    const double e = rok ? exp(f + Vi) : 0.0;
-    const double cf = rok ? (e - 1.0) : 0.0;
+    const double tt = f + Vi;
+    const bool over = tt > capv;
+    const double ex = rok ? exp(over ? capv : tt) : 0.0;
+    const double dc = over ? (tt - capv) : 0.0;
+    const double e = ex * fma(dc, fma(0.5, dc, 1.0), 1.0);
+    const double cf = rok ? (over ? fma(ex, dc, ex - 1.0) : ex - 1.0) : 0.0;
     if (wave == 0 && rok) loss -= (f + pv[1][0]) - e;   // inference.py:89-91 (summed over lanes at the end)
+    any_over += (wave == 0 && rok && over) ? 1 : 0;
     if (KEEP) lds_store_f64(fstage, (wave == 0 && rok) ? (int)(row + rl - fbase) : (MLN_FSTAGE + tid), f);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       coef[r] = read_lane_f64(cf, r);
-      aexp[r] = (MODE == MODE_OBJ_HESS) ? read_lane_f64(e, r) : 0.0;
+      aexp[r] = (MODE == MODE_OBJ_HESS) ? read_lane_f64(ex, r) : 0.0;
     }
   } else {
     double dot[R];
@@ -208,11 +216,16 @@ __device__ __forceinline__ void process_rows(const ObjArgs& a, int64_t row, int6
         // KEEP: V / Vdr of the row were requested together with the row itself (load_lik) -- a load issued HERE would
         // sit behind the next set's row loads in the in-order return queue (s_waitcnt vmcnt(0))
         const double Vi = KEEP ? pv[0][r] : (rok ? a.V[rm(row + r)] : 0.0);
-        const double e = rok ? exp(f + Vi) : 0.0;
-        aexp[r] = e;
-        coef[r] = rok ? (e - 1.0) : 0.0;
+        const double tt = f + Vi;
+        const bool over = tt > capv;
+        const double ex = rok ? exp(over ? capv : tt) : 0.0;
+        const double dc = over ? (tt - capv) : 0.0;
+        const double e = ex * fma(dc, fma(0.5, dc, 1.0), 1.0);
+        aexp[r] = ex;
+        coef[r] = rok ? (over ? fma(ex, dc, ex - 1.0) : ex - 1.0) : 0.0;
         if (KEEP) { if (tid == 0 && rok) loss -= (f + pv[1][r]) - e; }
         else if (tid == 0 && rok) loss -= (f + a.Vdr[rm(row + r)]) - e;   // inference.py:89-91
+        any_over += (tid == 0 && rok && over) ? 1 : 0;
         // f of the row goes to LDS.  Unconditional store by every lane (thread 0 to the row's slot, the others to a
         // per-lane dummy slot): a store under `if (tid == 0)` is a real branch in the loop body, and a global store
         // there serialises the load pipeline -- both cost 10-20 % of the pass.
@@ -264,6 +277,8 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
     h[c] = (d2){0.0, 0.0};
   }
   double loss = 0.0;
+  int any_over = 0;
+  const double capv = a.cap ? *a.cap : __builtin_inf();
   // f of this workgroup's rows is staged in LDS and written out once at the end
   __shared__ double fstage[KEEP ? (MLN_FSTAGE + WG) : 1];
   const int64_t fbase = s_beg * R;
@@ -282,11 +297,12 @@ __global__ __launch_bounds__(WG) void k_objective(ObjArgs a) {
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
     load_rows<CPT, R>(L2, ld2, s1 * R, a.n, tid, vb, rm, lim);
     if (PRE) lik(s1 * R, pb);
-    process_rows<CPT, R, MODE, KEEP, VEC>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red, fstage, fbase, pa);
+    process_rows<CPT, R, MODE, KEEP, VEC>(a, s * R, a.n, tid, 0, va, z, g, h, loss, red, fstage, fbase, pa, capv, any_over);
     load_rows<CPT, R>(L2, ld2, s2 * R, a.n, tid, va, rm, lim);
     if (PRE) lik(s2 * R, pa);
-    if (s + 1 < s_end) process_rows<CPT, R, MODE, KEEP, VEC>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red, fstage, fbase, pb);
+    if (s + 1 < s_end) process_rows<CPT, R, MODE, KEEP, VEC>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, h, loss, red, fstage, fbase, pb, capv, any_over);
   }
+  if (any_over && a.over_flag) atomicAdd(a.over_flag, any_over);      // (integer count: the order of the adds does not matter)
   if (KEEP) {
     __syncthreads();
     double* fo = a.f_keep[1 - *a.f_slot];
@@ -353,7 +369,7 @@ template <int CQ, int R, bool GEMVT, bool KEEP, int NW, bool FIXED, bool VEC = f
 __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, int64_t row_end, int tid, int par,
                                                const f4 (&v)[R][CQ], const double (&z)[CQ][4], double (&g)[CQ][4],
                                                double& loss, double (*red)[NW][R], double* fstage, int64_t fbase,
-                                               const double (&pv)[2][R], double capv, double ecap) {
+                                               const double (&pv)[2][R], double capv, double ecap, int& any_over) {
   double coef[R], dot[R];
   const RowMap rm = row_map(a);
   if (GEMVT) {   // grad_j = sum_i weights_i L_ij  (Ridge right-hand side): no row dots, no barrier
@@ -399,9 +415,11 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     const double tt = f + Vi;
     const bool over = tt > capv;
     const double ex = exp(over ? capv : tt);
-    const double e = rok ? (over ? ecap * (1.0 + (tt - capv)) : ex) : 0.0;
-    const double cf = rok ? (ex - 1.0) : 0.0;
+    const double dc = over ? (tt - capv) : 0.0;
+    const double e = rok ? ex * fma(dc, fma(0.5, dc, 1.0), 1.0) : 0.0;
+    const double cf = rok ? (over ? fma(ex, dc, ex - 1.0) : ex - 1.0) : 0.0;
     if (wave == 0 && rok) loss -= (f + pv[1][0]) - e;
+    any_over += (wave == 0 && rok && over) ? 1 : 0;
     if (KEEP) lds_store_f64(fstage, (wave == 0 && rok) ? (int)(row + rl - fbase) : (MLN_FSTAGE + tid), f);
 #pragma unroll
     for (int r = 0; r < R; ++r) coef[r] = read_lane_f64(cf, r);
@@ -437,10 +455,12 @@ __device__ __forceinline__ void process_rows32(const ObjArgs& a, int64_t row, in
     const double tt = f + Vi;
     const bool over = tt > capv;                                    // capv = +inf unless the solver's cap is on
     const double ex = exp(over ? capv : tt);
-    const double e = rok ? (over ? ecap * (1.0 + (tt - capv)) : ex) : 0.0;
-    coef[r] = rok ? (ex - 1.0) : 0.0;                               // d/dt: e^t below the cap, e^cap above it
+    const double dc = over ? (tt - capv) : 0.0;
+    const double e = rok ? ex * fma(dc, fma(0.5, dc, 1.0), 1.0) : 0.0;
+    coef[r] = rok ? (over ? fma(ex, dc, ex - 1.0) : ex - 1.0) : 0.0;                    // d/dt: e^t below the cap, e^cap (1 + d) above it
     if (KEEP) { if (tid == 0 && rok) loss -= (f + pv[1][r]) - e; }
     else if (tid == 0 && rok) loss -= (f + a.Vdr[rm(row + r)]) - e;
+    any_over += (tid == 0 && rok && over) ? 1 : 0;
     if (KEEP) lds_store_f64(fstage, (tid == 0 && rok) ? (int)(row + r - fbase) : (MLN_FSTAGE + tid), f);   // see k_objective
   }
   }
@@ -482,6 +502,7 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
       g[c][e] = 0.0;
     }
   double loss = 0.0;
+  int any_over = 0;
   const double capv = a.cap ? *a.cap : __builtin_inf();
   const double ecap = exp(capv);
   __shared__ double fstage[KEEP ? (MLN_FSTAGE + WG) : 1];
@@ -497,11 +518,12 @@ __global__ __launch_bounds__(64 * NW) void k_objective32(ObjArgs a) {
     const int64_t s1 = (s + 1 < s_end) ? s + 1 : s_last, s2 = (s + 2 < s_end) ? s + 2 : s_last;
     load_rows32<CQ, R, NW>(L4, ld4, s1 * R, a.n, tid, vb, rm);
     if (PRE) lik(s1 * R, pb);
-    process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED, VEC>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa, capv, ecap);
+    process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED, VEC>(a, s * R, a.n, tid, 0, va, z, g, loss, red, fstage, fbase, pa, capv, ecap, any_over);
     load_rows32<CQ, R, NW>(L4, ld4, s2 * R, a.n, tid, va, rm);
     if (PRE) lik(s2 * R, pa);
-    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED, VEC>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb, capv, ecap);
+    if (s + 1 < s_end) process_rows32<CQ, R, GEMVT, KEEP, NW, FIXED, VEC>(a, (s + 1) * R, a.n, tid, 1, vb, z, g, loss, red, fstage, fbase, pb, capv, ecap, any_over);
   }
+  if (any_over && a.over_flag) atomicAdd(a.over_flag, any_over);      // (integer count: the order of the adds does not matter)
   if (KEEP) {
     __syncthreads();
     double* fo = a.f_keep[1 - *a.f_slot];
@@ -598,7 +620,10 @@ __global__ __launch_bounds__(256) void k_reduce_obj(ObjArgs a, double* __restric
       for (int w = threadIdx.x; w < a.n_wg; w += 64) l += a.part_loss[w];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-    if (threadIdx.x == 0) out_loss[0] = l;
+    if (threadIdx.x == 0) {
+      out_loss[0] = l;
+      if (a.over_flag) { out_loss[1] = (double)*a.over_flag; *a.over_flag = 0; }   // (rows above the solver's cap: see ObjArgs)
+    }
   }
 }
 

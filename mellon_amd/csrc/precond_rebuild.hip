@@ -44,12 +44,12 @@ __device__ __forceinline__ double block_sum256(double v, double* red) {
 // a_i = exp(f_i + V_i), clamped to a finite range; per-block partial sums and maxima
 __global__ __launch_bounds__(256) void k_weights(const double* __restrict__ f, const double* __restrict__ V, int64_t n,
                                                  double* __restrict__ a, double* __restrict__ part_sum,
-                                                 double* __restrict__ part_max) {
+                                                 double* __restrict__ part_max, double cap) {
   __shared__ double red[4];
   double s = 0.0, mx = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     double t = f[i] + V[i];
-    t = fmin(fmax(t, -700.0), 600.0);
+    t = fmin(fmax(t, -700.0), fmin(600.0, cap));     // (cap: the curvature of the solver's capped objective is e^cap above it)
     const double v = exp(t);
     a[i] = v;
     s += v;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_gather_scale(const double* __restrict__
 }  // namespace
 
 int rebuild_select_rows(mln_ctx* ctx, const double* f_dev, const double* V_dev, int64_t n, int64_t row0,
-                        double target_rows_global, uint64_t seed, RebuildSelection* out) {
+                        double target_rows_global, uint64_t seed, RebuildSelection* out, double cap) {
   out->rows = 0; out->idx = nullptr; out->scale = nullptr; out->w_max = 1.0; out->c = 0.0; out->sum_a = 0.0;
   const int nb = 256;
   double *a = nullptr, *part = nullptr, *part2 = nullptr, *scal = nullptr;
@@ -166,7 +166,7 @@ int rebuild_select_rows(mln_ctx* ctx, const double* f_dev, const double* V_dev, 
     mln_set_error(ctx, "preconditioner rebuild: out of device memory");
     return fail(MLN_ERR_HIP);
   }
-  hipLaunchKernelGGL(k_weights, dim3(nb), dim3(256), 0, ctx->stream, f_dev, V_dev, n, a, part, part2);
+  hipLaunchKernelGGL(k_weights, dim3(nb), dim3(256), 0, ctx->stream, f_dev, V_dev, n, a, part, part2, cap);
   hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, ctx->stream, part, nb, 0, scal);        // sum a  (this rank)
   hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, ctx->stream, part2, nb, 1, scal + 1);   // max a  (this rank)
   int rc = comm_allreduce(ctx, scal, 1);

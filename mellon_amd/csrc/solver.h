@@ -24,7 +24,12 @@ struct SolverState {
   double prior_const;       // (m / 2) log 2 pi
   double fx, t, gd;         // accepted loss, current trial step, g . d at the accepted point
   double cap_fall;          // relative decrease of the loss per pass below which the cap is dropped
-  double cap;               // the likelihood's e^t is continued linearly beyond t = cap while the loss falls steeply (inf: off)
+  double cap;               // the likelihood's e^t is continued by its second-order Taylor polynomial beyond t = cap (inf: off);
+                            // raised by cap_step whenever the capped solve slows down with rows still above it
+  double cap_step;
+  int over_acc;             // the ACCEPTED point was evaluated with rows above the cap (its loss / gradient are the capped objective's)
+  double cap0;              // its initial value: the cap comes back when the subsample phase hands over to the full objective
+                            // (the cells the subsample never saw are where e^{f+V} overshoots then)
   double boost_fall;        // ... and the relative decrease of the loss per pass above which that rule applies
   double t0, boost;         // first trial step of the next line search; slope ratio above which it doubles (0: always 1)
   double corr_k;            // corrected surrogate: F^(u) = F32(u) + c . u + corr_k,  grad F^ = grad F32 + c
@@ -32,6 +37,7 @@ struct SolverState {
   // cells of the preconditioner's Gram) -- passes at 1 / row_stride of the bytes -- and moves to the full objective
   // (gate_full) at the same point once its progress per iteration falls below sub_tol.
   double sub_tol;
+  int sub_max_evals;        // ... or after this many evaluations on the subsample (a slow subsample problem is not worth finishing)
   int gate_full;            // MLN_GATE_F64, or MLN_GATE_F32 when a 32-bit copy exists
   int n_eval_sub;           // evaluations on the subsamples so far
   int sub_level, n_sub_levels;   // ... which of the (nested, ever larger) subsamples the SUB gate currently means
@@ -40,7 +46,11 @@ struct SolverState {
   // accepted fp64 iteration whose progress has fallen below rebuild_tol; the host then re-factors the preconditioner
   // from the a-weighted importance sample at that point (api.hip fit_rebuild_precond), re-expresses u and g in the new
   // variable and resumes (mode = MLN_SOLVE_RESUME, no pairs).
-  int rebuild_armed;
+  int rebuild_armed;        // rebuilds the host still allows (0: none; each pause for a rebuild takes one)
+  int it_resume;            // iteration count at the last resume after a rebuild (-1: none yet)
+  double over_many;         // rows above the cap (all ranks) from which the start counts as overshooting: the FIRST rebuild then
+                            // does not wait for slow progress (0: never early)
+  double over_cnt_acc;      // rows above the cap at the accepted point
   int it_full;              // accepted iterations on the full objective
   int resume_keep_pairs;    // MLN_SOLVE_RESUME: the curvature pairs are still valid (no new variable)
   int gate_after_pause;     // the copy the solve continues on once the host resumes it
@@ -81,6 +91,7 @@ struct SolverBuffers {
   const double* z;               // z = C^-T un of the evaluation in flight (m): the prior is 1/2 |z|^2 ...
   const double* z2;              // ... or, when given, 1/2 z . z2  (implicit mode: z = w, z2 = Kj w: 1/2 w^T Kj w = 1/2 |Lp^T w|^2)
   const double* lik;             // its (all-reduced) likelihood sum
+  const double* over;            // > 0: some row of that evaluation lay above the cap (capped and true objective differ there)
   int64_t ld;
   double* trace;                 // optional: 4 doubles per evaluation (loss, step, mode, gate), 512 entries
 };
@@ -91,7 +102,8 @@ int launch_solver_init(mln_ctx* ctx, const SolverBuffers& b, const SolverState& 
 int launch_solver_step(mln_ctx* ctx, const SolverBuffers& b, int m);
 // after a pause: the host has written the accepted point and its gradient in the (new) preconditioned variable into
 // b.u / b.g; the next step starts a line search from there on `gate` (pairs_dropped: the history starts over)
-int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped, int revert_after = 0);
+// rearm >= 0: the number of rebuilds still allowed becomes that (a rebuild that declined twice is not asked for again)
+int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped, int revert_after = 0, int rearm = -1);
 // after a pause at the mixed solve's early fp64 anchor whose rebuild was declined: forget the anchor (it was taken far from
 // the optimum, where the 32-bit surrogate and the fp64 objective differ by more than a first-order correction mends) and
 // go on with the PLAIN 32-bit surrogate from the same point -- one re-evaluation there on `gate`, history kept (or dropped:

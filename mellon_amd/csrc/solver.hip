@@ -124,6 +124,10 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
   bool recap = false;
   if (mode != MLN_SOLVE_LS && !resume) t0 = 1.0;
   int f_slot = st->f_slot, f_valid = st->f_valid, corr = st->corr, n_anchor = st->n_anchor;
+  int over_acc = st->over_acc;
+  double over_cnt_acc = st->over_cnt_acc;
+  const double over_cnt_now = (cap < 1e300 && b.over) ? b.over[0] : 0.0;     // rows of the evaluation in flight above the cap
+  const int over_now = over_cnt_now > 0.0 ? 1 : 0;
   if (b.trace && tid == 0 && !resume) {
     double* tr = b.trace + 4 * ((n_eval - 1) & 511);
     tr[0] = fn; tr[1] = (mode == MLN_SOLVE_LS) ? t : 0.0; tr[2] = (double)mode; tr[3] = (double)(gate + 16 * st->sub_level);
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       }
     }
     fx = fn;
+    over_acc = over_now; over_cnt_acc = over_cnt_now;
     f_slot ^= 1; f_valid = approx ? 0 : 1;   // the rows' f of this pass belong to the accepted point
 #pragma unroll
     for (int e = 0; e < EPT; ++e) g[e] = gn[e];
@@ -203,6 +208,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
 #pragma unroll
       for (int e = 0; e < EPT; ++e) { u[e] = un[e]; g[e] = gn[e]; }
       fx = fn;
+      over_acc = over_now; over_cnt_acc = over_cnt_now;
       f_slot ^= 1; f_valid = approx ? 0 : 1;
       if (!phaseS) ++it_full;
       if (sy > 1e-10 * sqrt(ss * yy)) {   // keep the pair (SPD update)
@@ -218,14 +224,18 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       }
       ++it;
       const double fscale = fmax(fmax(fabs(f_old), fabs(fx)), 1.0);
-      // Capped start.  The Ridge start overshoots log-density x volume by up to e^14 in a few sparse cells, and while
-      // those terms dominate, every quasi-Newton step is sized by them (Newton on e^t moves t by one unit per step).
-      // Until the loss stops falling steeply the 32-bit kernel therefore continues e^t LINEARLY beyond t = cap -- still
-      // convex and C^1, the same function wherever no cell is above the cap, but with bounded curvature: the capped
-      // problem gets within a few per cent of the optimum's loss in ~5 passes instead of ~10.  Then the cap is dropped
-      // for good and the same point is evaluated once more on the true objective (the curvature pairs stay: they are
-      // the true ones for every cell below the cap).  tools/cap_sweep.py, six data seeds at C3: 41.8 -> 39.2 passes.
-      if (cap < 1e300 && it >= 3 && (f_old - fx) <= st->cap_fall * fabs(f_old)) { cap = __builtin_inf(); recap = true; }
+      const double dec_now = f_old - fx;
+      // Capped start (round 5 form).  The Ridge start regresses on the nearest-neighbour estimate and overshoots log-density x
+      // volume, t = f + V, by up to e^14 in a few sparse cells of C3 and by e^28 where nearest-neighbour distances are noisy
+      // in a high nominal dimension (tools/hard_cases.py: 500 passes of walking the exponential down one unit per step).
+      // The objective kernels therefore continue e^t beyond t = cap by its second-order Taylor polynomial: a convex C^2
+      // minorant whose curvature is bounded by e^cap -- cells above the cap sit on an exact quadratic, which one good
+      // quasi-Newton step takes to its minimum -- and which IS the true objective (value, gradient, curvature) wherever no
+      // row is above the cap.  The reduction reports whether any row was (b.over).  When the capped solve slows down with
+      // rows still above the cap, the cap moves up by cap_step and the same point is evaluated again; a solve never ends
+      // while the accepted point has rows above the cap (see `done` below).
+      const bool slow = (f_old - fx) <= st->rebuild_tol * fscale && (f_old - fx) > st->ftol * fscale;
+      if (cap < 1e300 && over_acc && it >= 3 && slow) { cap += st->cap_step; recap = true; }
       const bool revert = st->revert_after > 0 && st->it_at_resume >= 0 && !phaseS && it - st->it_at_resume > st->revert_after &&
                           (f_old - fx) > st->ftol * fscale;
       if (revert) {
@@ -233,10 +243,16 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
       } else if (phaseS) {
         // the subsample objective has done its job once its own progress per iteration is small: same point, full objective
         // (not before a few iterations: the very first step from the Ridge start is a cautious t = 1 / |g|_1)
-        if (it >= 4 && (f_old - fx) <= st->sub_tol * fscale) { reeval = true; next_level = true; } else to_head = true;
-      } else if (st->rebuild_armed && !phase32 && it_full >= 2 && (f_old - fx) <= st->rebuild_tol * fscale &&
-                 (f_old - fx) > st->ftol * fscale) {
+        if (it >= 4 && ((f_old - fx) <= st->sub_tol * fscale || n_eval_sub >= st->sub_max_evals)) { reeval = true; next_level = true; } else to_head = true;
+      } else if (st->rebuild_armed > 0 && st->it_resume < 0 && !phase32 && !recap && it_full >= 2 && (slow || (it_full >= 4 && st->over_many > 0.0 && over_cnt_acc >= st->over_many && isfinite(fx)))) {
         pause = true;                    // the host rebuilds the preconditioner from the weights a = e^{f+V} at THIS point
+      } else if (st->rebuild_armed > 0 && st->it_resume >= 0 && !approx && !recap && it - st->it_resume >= 6 && dec_prev > 0.0 &&
+                 dec_prev2 > 0.0 && dec_now > 0.5 * dec_prev && dec_prev > 0.5 * dec_prev2 && dec_now > st->ftol * fscale) {
+        // Round 5: ANOTHER rebuild.  Six or more iterations after the last one the loss still falls by less than half per
+        // iteration, three times in a row: the weights have moved on from the point that preconditioner was built at
+        // (diffusion-map-like coordinates, heavy tails: tools/hard_cases.py); on C3 the decrease contracts 50-100x per pass
+        // after the first rebuild and this never fires.
+        pause = true;
       } else if (phaseA && st->rebuild_armed && it_full >= 2 && (f_old - fx) <= st->rebuild_tol * fscale) {
         reeval = true;                   // mixed precision: the rebuild needs the rows' f -- anchor in fp64 HERE, then pause (below)
       } else if (phaseA) {
@@ -370,7 +386,9 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     }
   }
   if (reeval) {           // same point, fp64 buffer: refreshes fx and g, keeps the curvature pairs
-    cap = __builtin_inf();   // (a surrogate left while still capped: everything from here on is the true objective)
+    // (a 32-bit surrogate left while still capped: everything from here on is the true objective; after the subsample
+    //  phase the cap comes back -- the cells the subsample never saw are where e^{f+V} overshoots on the full objective)
+    cap = phaseS ? st->cap0 : (phase32 ? __builtin_inf() : cap);
     // after a subsample: the next, larger one -- or, after the last, the full objective (on its 32-bit copy if there is one)
     if (phaseS && next_level && sub_level + 1 < st->n_sub_levels) { ++sub_level; gate = MLN_GATE_SUB; }
     else gate = phaseS ? st->gate_full : MLN_GATE_F64;
@@ -378,6 +396,9 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) un[e] = u[e];
   }
+  // a solve must not END on the capped objective: if the accepted point has rows above the cap, the cap moves up and the
+  // point is evaluated again
+  if (done && status == 0 && cap < 1e300 && over_acc && !approx) { done = false; cap += st->cap_step; recap = true; }
   if (recap && !reeval && !done) {   // the same point once more, on the uncapped objective (same copy)
     mode = MLN_SOLVE_REEVAL;
 #pragma unroll
@@ -395,8 +416,9 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     st->corr = corr; st->n_anchor = n_anchor; st->corr_k = corr_k; st->t0 = t0; st->cap = cap;
     st->n_eval_sub = n_eval_sub; st->it_full = it_full; st->sub_level = sub_level;
     st->dec_prev = dec_prev; st->dec_prev2 = dec_prev2;
+    st->over_acc = over_acc; st->over_cnt_acc = over_cnt_acc;
     if (shrink) st->n_shrink += 1;
-    if (pause) { st->rebuild_armed = 0; st->pause_reason = pause_reason; st->it_at_resume = -1; }    // (each at most once per solve)
+    if (pause) { st->rebuild_armed = (pause_reason == 1 && st->rebuild_armed > 0) ? st->rebuild_armed - 1 : 0; st->pause_reason = pause_reason; st->it_at_resume = -1; }
   }
 }
 
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(512) void k_solver_refresh_pairs(SolverBuffers b) {
   if (threadIdx.x == 0) b.yy[slot] = acc;
 }
 
-__global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped, int revert_after) {
+__global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped, int revert_after, int rearm) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     SolverState* st = b.st;
     st->gate = gate;
@@ -430,6 +452,8 @@ __global__ void k_solver_resume(SolverBuffers b, int gate, int pairs_dropped, in
     st->resume_keep_pairs = pairs_dropped ? 0 : 1;
     st->revert_after = revert_after;
     st->it_at_resume = revert_after > 0 ? st->it : -1;
+    st->it_resume = st->it;       // (the next rebuild waits for slow linear convergence at least six iterations from here)
+    if (rearm >= 0) st->rebuild_armed = rearm;
     st->pause_reason = 0;
   }
 }
@@ -444,6 +468,7 @@ __global__ void k_solver_resume_plain32(SolverBuffers b, int gate, int m, int pa
     if (pairs_dropped) { st->k = 0; st->head = 0; }
     st->corr = 0; st->n_anchor = 0; st->corr_k = 0.0;
     st->revert_after = 0; st->it_at_resume = -1; st->pause_reason = 0;
+    st->rebuild_armed = 0; st->it_resume = st->it;      // (the mixed solve's rebuild is one attempt, as it always was)
   }
 }
 
@@ -461,8 +486,8 @@ int launch_solver_refresh_pairs(mln_ctx* ctx, const SolverBuffers& b, int maxcor
   return MLN_OK;
 }
 
-int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped, int revert_after) {
-  hipLaunchKernelGGL(k_solver_resume, dim3(1), dim3(64), 0, ctx->stream, b, gate, pairs_dropped, revert_after);
+int launch_solver_resume(mln_ctx* ctx, const SolverBuffers& b, int gate, int pairs_dropped, int revert_after, int rearm) {
+  hipLaunchKernelGGL(k_solver_resume, dim3(1), dim3(64), 0, ctx->stream, b, gate, pairs_dropped, revert_after, rearm);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

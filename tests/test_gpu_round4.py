@@ -109,7 +109,8 @@ def test_a_start_whose_loss_is_not_finite(mellon):
         est = mellon.DensityEstimator(landmarks=ref.landmarks, nn_distances=nn, initial_value=scale * np.ones(m))
         dens = est.fit_predict(x)
         assert est.opt_state.success
-        assert int(est._fit.stage_times()["start_halvings"]) >= 1
+        # (rounds 3-4 asserted start_halvings >= 1 here; since round 5 the quadratically continued likelihood keeps the loss
+        #  of such a start finite and below 1e30, and the solve walks down from it without halving)
         assert np.abs(dens - ref.log_density_x).max() < 1e-5 * np.abs(ref.log_density_x).max()
 
 
@@ -134,7 +135,7 @@ def test_comm_info_on_thread_ranks():
 
 
 @pytest.mark.parametrize("knobs", [{"MELLON_AMD_REBUILD_RANGE": "0"},            # every rebuild declines
-                                   {"MELLON_AMD_REVERT_AFTER": "1"},             # every rebuilt preconditioner fails its trial
+                                   {"MELLON_AMD_REVERT_AFTER": "1", "MELLON_AMD_MAX_REBUILDS": "1"},   # the one rebuilt preconditioner fails its trial
                                    {"MELLON_AMD_REBUILD_RANGE": "0", "MELLON_AMD_MIXED_MIN_ELEMS": "0", "mixed": "1"}])
 def test_rebuild_fallbacks_are_collective(mellon, monkeypatch, knobs):
     """The decline / revert branches issue collectives (or skip them): every rank must take the same one.  Forced here on
@@ -157,7 +158,8 @@ def test_rebuild_fallbacks_are_collective(mellon, monkeypatch, knobs):
     if "MELLON_AMD_REVERT_AFTER" in knobs:
         assert int(st["precond_reverts"]) == 1
     else:
-        assert int(st["precond_rebuilds_declined"]) == 1 and int(st["precond_rebuilds"]) == 0
+        # (round 5: a solve may ask for a rebuild more than once; after two attempts that came to nothing it stops asking)
+        assert 1 <= int(st["precond_rebuilds_declined"]) <= 2 and int(st["precond_rebuilds"]) == 0
     assert est.opt_state.success
 
     def body(comm):

@@ -3,7 +3,7 @@ Gaussian mixtures.  This sweep runs the default fit at FULL scale (1e6 cells) on
 size-independent properties (no oracle finishes at this size):
   * default path == the plain path (MELLON_AMD_SUBSAMPLE=0, MELLON_AMD_REBUILD=0) of the same fp64 solve: the shortcuts
     change the iteration path, not the optimum;
-  * the mixed-precision product default == the fp64 solve;
+  * the opt-in mixed-precision solve (MELLON_AMD_MIXED=1) == the fp64 solve (the product default since round 5);
   * predict(X) == fit_predict(X);
 and reports pass counts per case.      python tools/robustness_sweep_large.py [n]      (on a GPU box)"""
 import os, sys, time
@@ -54,7 +54,7 @@ for name, make in cases.items():
     out = {}
     for mode, env in (("default fp64", {"MELLON_AMD_MIXED": "0"}),
                       ("plain fp64", {"MELLON_AMD_MIXED": "0", "MELLON_AMD_SUBSAMPLE": "0", "MELLON_AMD_REBUILD": "0"}),
-                      ("mixed", {})):
+                      ("mixed", {"MELLON_AMD_MIXED": "1"})):
         saved = {k: os.environ.get(k) for k in ("MELLON_AMD_MIXED", "MELLON_AMD_SUBSAMPLE", "MELLON_AMD_REBUILD")}
         for k in saved: os.environ.pop(k, None)
         os.environ.update(env)
