@@ -94,6 +94,12 @@ int mln_synchronize(mln_ctx* ctx);
 int mln_malloc(mln_ctx* ctx, int64_t bytes, void** dev_ptr);
 int mln_free(mln_ctx* ctx, void* dev_ptr);
 int mln_memcpy(mln_ctx* ctx, void* dst, const void* src, int64_t bytes); /* any host/device mix */
+/* Page-lock a HOST array of the caller (hipHostRegister) so that the library's uploads from it are DMA transfers that run
+ * under its kernels: the reference's timed region starts from X in host memory (density_estimator.py:542-581), and from
+ * pageable memory ~11 ms of C3's 0.4 GB upload stay exposed.  Registration itself costs ~0.1 ms per MB: once per array,
+ * not per fit.  The caller unregisters before freeing the array.  Both return MLN_ERR_HIP when the runtime refuses.   */
+int mln_host_register(mln_ctx* ctx, const void* host_ptr, int64_t bytes);
+int mln_host_unregister(mln_ctx* ctx, const void* host_ptr);
 /* Internal buffers (the 8*n*m-byte factor, Gram partials, ...) are recycled by a caching
  * allocator so that repeated fits do not pay hipMalloc / page-mapping again; this returns all
  * cached blocks to the driver.                                                                */

@@ -151,6 +151,40 @@ def _sparse_solve_per_output(ctx, desc, x, xu, y, mu, sigma, jitter):
     return ctx.sparse_solve_noise(desc, x, xu, y, mu, sig, ctx.SIGMA_PER_OUTPUT, jitter)
 
 
+def _sigma_to_y_cov_factor(sigma, y_cov_factor, n):
+    """conditional.py:101-135: the left factor of the observation noise from `sigma`, or the caller's own `y_cov_factor`
+    (one or the other); pinned by the reference's tests/test_sigma_to_y_cov_factor.py:6-43."""
+    if sigma is None and y_cov_factor is None:
+        raise ValueError("No input uncertainty specified. Make sure to set `sigma` or `pre_transformation_std`, "
+                         'e.g., by using `optimizer="advi", to quantify uncertainty of the prediction.')
+    if y_cov_factor is not None and sigma is not None and np.any(np.asarray(sigma) > 0):
+        raise ValueError("One can specify either `sigma` or `y_cov_factor` to describe input noise, but not both.")
+    if y_cov_factor is not None:
+        return np.asarray(y_cov_factor, dtype=np.float64)
+    sig = np.asarray(sigma, dtype=np.float64)
+    if sig.ndim == 0:
+        return np.eye(n) * float(sig)
+    if sig.ndim == 1:
+        return np.diag(sig)
+    out = np.zeros((n,) + sig.shape)              # a leading dimension for the diagonal (conditional.py:122-131)
+    out[np.arange(n), np.arange(n), ...] = sig
+    return out
+
+
+def _chol_with_noise_factor(ctx, K, M, jitter):
+    """chol(K + M M^T + diag(max(jitter - diag(M M^T), 0)))  (util.add_variance's matrix branch, util.py:326-330, inside
+    conditional._get_L, conditional.py:69-81); M M^T accumulates on the matrix cores (mln_gemm), the factorisation is the
+    device Cholesky."""
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    if M.ndim != 2 or M.shape[0] != K.shape[0]:
+        raise NotImplementedError("y_cov_factor must be a matrix with one row per training point.")
+    Kp = np.array(K, dtype=np.float64)
+    ctx.gemm(M, M, tb=True, alpha=1.0, beta=1.0, out=Kp)
+    noise_diag = np.einsum("ij,ij->i", M, M)
+    Kp[np.diag_indices_from(Kp)] += np.where(noise_diag < jitter, jitter - noise_diag, 0.0)
+    return ctx.chol_lower(Kp, jitter=jitter)
+
+
 def _chol_with_diag(ctx, K, diag_values, jitter):
     M = np.array(K, dtype=np.float64)
     M[np.diag_indices_from(M)] += diag_values
@@ -193,6 +227,7 @@ class _FullConditional:
         per_cell = (not per_feature and sigma is not None and np.ndim(sigma) == 1 and L is None and not y_is_mean)
         fit = None
         var_state = None
+        Lh_ycf = ycf_h = None      # factor and noise factor of the `y_cov_factor=` route
         if per_feature:
             # one solve per output with chol(K + sigma_g^2 I + jitter I) (conditional.py:239-251); outputs that share
             # a noise level share the factorisation, and everything a level needs is done while its factor is resident
@@ -246,15 +281,23 @@ class _FullConditional:
                 if y_is_mean:
                     diag = jitter                                            # _get_L(x, cov, jitter)
                 else:
-                    s = _scalar_sigma(sigma)
-                    if s is None and y_cov_factor is None:
-                        raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
-                                         "`pre_transformation_std` to quantify uncertainty of the prediction.")
                     if y_cov_factor is not None:
-                        raise NotImplementedError("y_cov_factor is outside the accelerated path.")
-                    diag = max(s * s, jitter)                                # add_variance, util.py:296-331
-                fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
-            weights = fit.weights_full(yh, mu)                               # conditional.py:263-264
+                        # the caller's own noise factor: L = chol(K + M M^T [+ diagonal up to the jitter])  (conditional.py:260-262)
+                        ycf_h = _sigma_to_y_cov_factor(sigma, y_cov_factor, n)
+                        K = ctx.kernel_matrix(cov_func.lower(x.shape[1]), x, x)
+                        Lh_ycf = _chol_with_noise_factor(ctx, K, ycf_h, jitter)
+                    else:
+                        s = _scalar_sigma(sigma)
+                        if s is None:
+                            raise ValueError("No input uncertainty specified. Make sure to set `sigma` or "
+                                             "`pre_transformation_std` to quantify uncertainty of the prediction.")
+                        diag = max(s * s, jitter)                            # add_variance, util.py:296-331
+                if Lh_ycf is None:
+                    fit = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, diag)
+            if Lh_ycf is not None:
+                weights = ctx.trsm_lower(Lh_ycf, ctx.trsm_lower(Lh_ycf, yh - mu), trans=True)
+            else:
+                weights = fit.weights_full(yh, mu)                           # conditional.py:263-264
         Predictor.__init__(self, cov_func, x, weights, mu, n_obs=x.shape[0], jitter=jitter, sigma=sigma)
         self.per_feature_sigma = bool(per_feature)
         if obs_variance:      # conditional.py:305-362: smoothed HC3 observation variance
@@ -286,6 +329,11 @@ class _FullConditional:
             # noise-free covariance, no mean covariance (conditional.py:288-291)
             self.L = ctx.fit_prepare(cov_func.lower(x.shape[1]), x, None, jitter).Lp()
             self._state_variables |= {"L"}
+        elif with_uncertainty and Lh_ycf is not None:
+            # W = L^-T L^-1 y_cov_factor with the caller's factor (conditional.py:302-306)
+            self.L = Lh_ycf
+            self.W = ctx.trsm_lower(Lh_ycf, ctx.trsm_lower(Lh_ycf, np.ascontiguousarray(ycf_h)), trans=True)
+            self._state_variables |= {"L", "W"}
         elif with_uncertainty:
             # noisy observations (conditional.py:285-304): L = chol(K + sigma^2 I) and
             # W = L^-T L^-1 y_cov_factor with y_cov_factor = sigma I (diag(sigma) for one sigma per cell)

@@ -169,6 +169,21 @@ extern "C" int mln_free(mln_ctx* ctx, void* dev_ptr) {
   return MLN_OK;
 }
 
+extern "C" int mln_host_register(mln_ctx* ctx, const void* host_ptr, int64_t bytes) {
+  if (!ctx || !host_ptr || bytes < 1) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_HIP(ctx, hipHostRegister(const_cast<void*>(host_ptr), (size_t)bytes, hipHostRegisterDefault));
+  return MLN_OK;
+}
+
+extern "C" int mln_host_unregister(mln_ctx* ctx, const void* host_ptr) {
+  if (!ctx || !host_ptr) return MLN_ERR_ARG;
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MLN_HIP(ctx, hipHostUnregister(const_cast<void*>(host_ptr)));
+  return MLN_OK;
+}
+
 extern "C" int mln_release_cached_memory(void) {
   mln_dcache_flush();
   return MLN_OK;

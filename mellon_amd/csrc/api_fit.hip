@@ -102,6 +102,22 @@ struct HostUpload {
     MLN_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
     events.resize((size_t)n_chunks, nullptr);
     for (auto& e : events) MLN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // a page-locked source (mln_host_register): the copies are DMA transfers the runtime queues without blocking -- all of
+    // them are enqueued here, by the calling thread, and run under whatever the main stream does meanwhile
+    {
+      hipPointerAttribute_t attr;
+      const bool pinned_src = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
+      if (!pinned_src) (void)hipGetLastError();
+      if (pinned_src) {
+        for (int c = 0; c < n_chunks; ++c) {
+          const int64_t r0 = (int64_t)c * chunk_rows, rows = std::min(chunk_rows, n - r0);
+          MLN_HIP(ctx, hipMemcpyAsync(dst + r0 * d, src + r0 * d, sizeof(double) * (size_t)(rows * d), hipMemcpyHostToDevice, copy));
+          MLN_HIP(ctx, hipEventRecord(events[(size_t)c], copy));
+        }
+        done.store(n_chunks, std::memory_order_release);
+        return MLN_OK;
+      }
+    }
     const int device = ctx->device;
     th = std::thread([this, src, dst, device] {
       if (hipSetDevice(device) != hipSuccess) { failed.store(1); done.store(n_chunks); return; }

@@ -1000,7 +1000,11 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   if (contiguous)
     for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
   static const bool no_mfma = mln_experiment("MELLON_AMD_KM_NO_MFMA") != nullptr;
-  static const bool no_rows = mln_experiment("MELLON_AMD_KM_NO_ROWS") != nullptr;
+  static const bool no_rows_env = mln_experiment("MELLON_AMD_KM_NO_ROWS") != nullptr;
+  // (the persistent-row kernels read the centres WITHOUT bounds checks up to tile ceil(ldo / 64) + 1: the zero rows pad_rows
+  //  appends cover that only while the output's leading dimension stays within 64 columns of m -- every caller passes
+  //  ldo = m or pad16(m); anything wider takes the tiled kernels)
+  const bool no_rows = no_rows_env || ldo > m + 64;
   if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD && (!out32 || q32)) {
     MLN_TRY(pad_rows(ctx, y, m, d, ypad));

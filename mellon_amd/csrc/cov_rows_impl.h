@@ -47,7 +47,7 @@ __device__ __forceinline__ double leaf_value_k(double m2, double xs, double ys, 
 }
 
 // Contract (round 4): `y` and `yy` are PADDED copies of the centres and of their squared norms -- rows m .. m + 3 TN - 1
-// exist and are zero (cov_kernels.hip: pad_centres) -- so the staging needs neither address clamps nor value masks: a
+// exist and are zero (cov_kernels.hip: pad_rows; launch_kernel_matrix takes these kernels only while ldo <= m + 64) -- so the staging needs neither address clamps nor value masks: a
 // staged load is `global_load v, v_off32, s[tile base]` with a byte offset that never changes, its LDS destination a
 // constant per thread.  The tile loop is unrolled by two, so that the two accumulator sets swap roles instead of being
 // copied (16 v_mov_b64 per tile) and every LDS address of the operand tiles is an immediate.

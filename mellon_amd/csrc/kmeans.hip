@@ -143,8 +143,11 @@ __device__ __forceinline__ void seed_scan_find(double v, double target, int t, d
   __syncthreads();
   double base = 0.0;
   for (int w = 0; w < wave; ++w) base += wtot[w];
-  const double incl = base + inc, excl = incl - v;
-  // values are non-negative: the inclusive sums are non-decreasing and at most one thread has excl <= target < incl
+  // exclusive sum = the PREVIOUS lane's inclusive one (the wave's base for lane 0), not incl - v: the intervals then tile
+  // [0, total) exactly -- no overlap (two owners writing owner / rem unsynchronised), no gap (owner left at -1)
+  const double prev = __shfl_up(inc, 1, 64);
+  const double incl = base + inc, excl = (lane == 0) ? base : base + prev;
+  // values are non-negative: the inclusive sums are non-decreasing and exactly one thread has excl <= target < incl
   if (v > 0.0 && !(target < excl) && target < incl) { *owner = t; *rem = target - excl; }
   __syncthreads();
 }
@@ -198,8 +201,14 @@ __global__ __launch_bounds__(256) void k_seed_select(const double* __restrict__ 
 #pragma unroll
     for (int e = 0; e < CPT; ++e) { const int64_t i = lo + t * CPT + e; v[e] = (i < hi) ? mind[i] : 0.0; ls += v[e]; }
     seed_scan_find(ls, target, t, wtot, &owner, &rem);
-    if (owner < 0) {                             // target beyond the block's sum (rounding): its last cell
-      if (t == 0) chosen = hi - 1;
+    if (owner < 0) {                             // target beyond the block's sum (rounding): its last cell that is not a centre yet
+      int last = -1;
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) if (v[e] > 0.0) last = t * CPT + e;
+      __syncthreads();
+      if (last >= 0) atomicMax(&owner, last);    // (integer maximum: order-independent)
+      __syncthreads();
+      if (t == 0) chosen = owner >= 0 ? lo + owner : hi - 1;
     } else if (t == owner) {
       double run = 0.0;
       int64_t pick = lo + t * CPT + CPT - 1;
@@ -388,6 +397,7 @@ __global__ void k_km_colmax(const double* __restrict__ x, int64_t n, int d, unsi
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += T) {
     const double v = fabs(x[e]);
     if (v > 0.0 && v < INFINITY) atomicMax(&colmax[e % d], (unsigned long long)__double_as_longlong(v));   // non-negative doubles order as integers
+    else if (!(v < INFINITY)) atomicMax(&colmax[d], 1ull);      // NaN / inf: the fixed-point sums (llrint) would turn it into garbage silently
   }
 }
 __global__ void k_km_colscale(const unsigned long long* __restrict__ colmax, int d, int64_t n, double* __restrict__ scale) {
@@ -571,7 +581,7 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   // fixed-point cluster sums: per-column magnitudes -> power-of-two scales [0, d) and their inverses [d, 2d); sq: |shift|^2 per centre
   unsigned long long* colmax = nullptr;
   double *colscale = nullptr, *sq = nullptr;
-  MLN_HIP(ctx, mln_dmalloc((void**)&colmax, sizeof(unsigned long long) * (size_t)d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&colmax, sizeof(unsigned long long) * (size_t)(d + 1)));
   MLN_HIP(ctx, mln_dmalloc((void**)&colscale, sizeof(double) * 2 * (size_t)d));
   MLN_HIP(ctx, mln_dmalloc((void**)&sq, sizeof(double) * (size_t)m));
   MLN_HIP(ctx, mln_dmalloc((void**)&label, sizeof(int) * (size_t)n));
@@ -579,10 +589,14 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   int rc = MLN_OK;
   auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "kmeans", __FILE__, __LINE__); };
 
-  chk(hipMemsetAsync(colmax, 0, sizeof(unsigned long long) * (size_t)d, st));
+  chk(hipMemsetAsync(colmax, 0, sizeof(unsigned long long) * (size_t)(d + 1), st));
   if (rc == MLN_OK) {
     hipLaunchKernelGGL(k_km_colmax, dim3(1024), dim3(256), 0, st, dx, n, d, colmax);
     hipLaunchKernelGGL(k_km_colscale, dim3(1), dim3(256), 0, st, colmax, d, n, colscale);
+    unsigned long long bad = 0;
+    chk(hipMemcpyAsync(&bad, colmax + d, sizeof(bad), hipMemcpyDeviceToHost, st));
+    chk(hipStreamSynchronize(st));
+    if (rc == MLN_OK && bad) { mln_set_error(ctx, "kmeans: x holds non-finite values"); rc = MLN_ERR_ARG; }
   }
   // ---- k-means++ seeding ------------------------------------------------------------------------
   // m - 1 sequential draws, each after one update of every cell's distance to its nearest centre so far.  Everything stays

@@ -119,6 +119,23 @@ double tridiag_lambda_max(const std::vector<double>& d, const std::vector<double
   return 0.5 * (a + b);
 }
 
+// |last component| of the unit eigenvector of the k x k tridiagonal (d, e) for its eigenvalue lam, by the three-term
+// recurrence (rescaled as it goes).  With the NEXT off-diagonal beta_k this is the residual of the Ritz pair in the full
+// matrix: |A y - lam y| = beta_k |s_k|.
+double tridiag_last_component(const std::vector<double>& d, const std::vector<double>& e, size_t k, double lam) {
+  if (k <= 1) return 1.0;
+  double pm = 0.0, p = 1.0, sq = 1.0;                 // p_{j-1}, p_j, sum of squares so far
+  for (size_t j = 0; j + 1 < k; ++j) {
+    const double ej = e[j];
+    if (!(std::fabs(ej) > 0.0)) return 1.0;           // (a split matrix: no bound from here)
+    double pn = ((lam - d[j]) * p - (j > 0 ? e[j - 1] * pm : 0.0)) / ej;
+    pm = p; p = pn;
+    sq += p * p;
+    if (sq > 1e200) { const double s = 1e-100; pm *= s; p *= s; sq *= s * s; }
+  }
+  return std::isfinite(p) && sq > 0.0 ? std::fabs(p) / std::sqrt(sq) : 1.0;
+}
+
 }  // namespace
 
 // lambda_max of the symmetric A (m x m, full storage, untouched) by Lanczos; *converged = false when 480 steps did not
@@ -162,7 +179,13 @@ int dev_sym_lambda_max(mln_ctx* ctx, const double* A, int64_t m, int64_t ld, dou
     for (int j = 0; j < done; ++j)
       if (!(hab[(size_t)(max_steps + j + 1)] > 0.0)) { k = (size_t)j + 1; broke = true; break; }
     lmax = tridiag_lambda_max(d, e, k);
-    if (broke || done >= m || (prev >= 0.0 && std::fabs(lmax - prev) <= 1e-14 * std::fabs(lmax))) { *converged = true; break; }
+    // settled = two Ritz values 24 steps apart agree AND the Ritz pair's residual beta_k |s_k| is small: agreement alone is
+    // also what stagnation on a cluster of top eigenvalues looks like, and a lambda_max that is too small lowers the
+    // threshold tol^2 lambda_max the ranks are counted against
+    const double beta_next = hab[(size_t)(max_steps + (int)k)];
+    // (an eigenvalue of A lies within the residual of the Ritz value; the Ritz value itself converges like its square)
+    const bool residual_ok = beta_next * tridiag_last_component(d, e, k, lmax) <= 1e-6 * std::fabs(lmax);
+    if (broke || done >= m || (prev >= 0.0 && std::fabs(lmax - prev) <= 1e-14 * std::fabs(lmax) && residual_ok)) { *converged = true; break; }
     prev = lmax;
   }
   (void)mln_dfree(work);

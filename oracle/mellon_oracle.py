@@ -673,7 +673,7 @@ def _get_L(x, cov_func, jitter=DEFAULT_JITTER, y_cov_factor=None, K=None):
 
 
 def sigma_to_y_cov_factor(sigma, y_cov_factor, n):
-    """conditional.py:100-135 (scalar / vector sigma only)."""
+    """conditional.py:100-135."""
     if sigma is None and y_cov_factor is None:
         raise ValueError("No input uncertainty specified.")
     if y_cov_factor is not None and sigma is not None and np.any(np.asarray(sigma) > 0):
@@ -685,7 +685,10 @@ def sigma_to_y_cov_factor(sigma, y_cov_factor, n):
         return np.eye(n) * sigma
     if sigma.ndim == 1:
         return np.diag(sigma)
-    raise ValueError("Unsupported sigma dimensions in the oracle.")
+    out = np.zeros((n,) + sigma.shape)                  # conditional.py:122-131: a leading dimension for the diagonal
+    for i in range(n):
+        out[i, i, ...] = sigma[i]
+    return out
 
 
 def is_per_feature_sigma(sigma, y):
@@ -916,8 +919,8 @@ class Predictor:
 
 
 def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTER,
-                     y_is_mean=False, with_uncertainty=False, obs_variance=False):
-    """conditional.py:183-362, scalar and per-feature sigma."""
+                     y_is_mean=False, with_uncertainty=False, obs_variance=False, y_cov_factor=None):
+    """conditional.py:183-362, scalar and per-feature sigma, or the caller's own noise factor `y_cov_factor`."""
     x = ensure_2d(x)
     n = x.shape[0]
     per_feature = is_per_feature_sigma(sigma, y)
@@ -935,7 +938,7 @@ def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTE
             if y_is_mean:
                 L = _get_L(x, cov_func, jitter)
             else:
-                L = _get_L(x, cov_func, jitter, sigma_to_y_cov_factor(sigma, None, n))
+                L = _get_L(x, cov_func, jitter, sigma_to_y_cov_factor(sigma, y_cov_factor, n))
         r = y - mu
         w = _sp_trsolve(L.T, _sp_trsolve(L, r, lower=True), lower=False)
     pred = Predictor(cov_func, x, w, mu, n)
@@ -966,7 +969,7 @@ def full_conditional(x, y, mu, cov_func, L=None, sigma=0.0, jitter=DEFAULT_JITTE
     if with_uncertainty and per_feature:                       # conditional.py:288-291: noise-free covariance, no W
         pred.L = _get_L(x, cov_func, jitter)
     elif with_uncertainty:                                     # conditional.py:292-304
-        ycf = sigma_to_y_cov_factor(sigma, None, n)
+        ycf = sigma_to_y_cov_factor(sigma, y_cov_factor, n)
         pred.L = L
         pred.W = _sp_trsolve(L.T, _sp_trsolve(L, ycf, lower=True), lower=False)
     return pred

@@ -167,3 +167,27 @@ def test_hard_data_against_the_oracle(case, monkeypatch):
     st = est._fit.stage_times()
     print(f"{case}: device {est.loss_func.n_eval} evaluations / {st['objective_pass_equivalents']:.1f} pass-equivalents, "
           f"{int(st['precond_rebuilds'])} rebuilds, {err:.1e} from the tight optimum; reference as run: {err_as_run:.1e}")
+
+
+def test_full_conditional_with_y_cov_factor(ctx):
+    """`y_cov_factor=`: the caller's own left factor of the observation noise (conditional.py:69-81,101-135,253-306) --
+    L = chol(K + M M^T [+ diagonal up to the jitter]), weights = L^-T L^-1 (y - mu), W = L^-T L^-1 M -- against the oracle:
+    mean, covariance and mean covariance of the predictor."""
+    from mellon_amd import cov
+    from mellon_amd.conditional import FullConditional
+    rng = np.random.default_rng(8)
+    n, d = 700, 3
+    x = rng.normal(size=(n, d))
+    y = np.sin(x @ rng.normal(size=d)) + 0.1 * rng.normal(size=n)
+    M = np.concatenate([0.3 * rng.normal(size=(n, 2)), np.diag(np.full(n, 0.05))[:, :5]], axis=1)   # n x 7
+    M[n // 2:, :] *= 1e-5                                   # rows whose noise variance is under the jitter: the diagonal correction acts
+    c = cov.Matern52(1.3)
+    oc = _pair(c)
+    got = FullConditional(x, y, 0.2, c, y_cov_factor=M, sigma=None, with_uncertainty=True)
+    ref = mo.full_conditional(x, y, 0.2, oc, sigma=None, y_cov_factor=M, with_uncertainty=True)
+    xq = rng.normal(size=(300, d))
+    assert relmax(got.mean(xq), ref.mean(xq)) < 1e-7
+    assert relmax(got.covariance(xq), ref.covariance(xq)) < 1e-6
+    assert relmax(got.mean_covariance(xq), ref.mean_covariance(xq)) < 1e-6
+    with pytest.raises(ValueError, match="either `sigma` or `y_cov_factor`"):
+        FullConditional(x, y, 0.2, c, y_cov_factor=M, sigma=0.3)

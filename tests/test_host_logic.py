@@ -225,3 +225,23 @@ def test_normalize_per_time_point_validation_and_target_counts():
     assert _target_cell_count({0.0: 10, 1.5: 20, 4.0: 30}, times[1], 7.0, times) == 20
     assert _target_cell_count([10, 20, 30], times[2], 7.0, times) == 30
     assert _target_cell_count(np.array([10, 20, 30]), times[0], 7.0, times) == 10
+
+
+def test_sigma_to_y_cov_factor_reference_cases():
+    """The reference's tests/test_sigma_to_y_cov_factor.py:6-43 as data -- scalar, vector and higher-dimensional sigma, and
+    the two refusals -- against the product's restatement (mellon_amd/conditional.py) and the oracle's."""
+    import numpy as np
+    import pytest
+    from mellon_amd.conditional import _sigma_to_y_cov_factor as product
+    from oracle.mellon_oracle import sigma_to_y_cov_factor as oracle
+    for fn in (product, oracle):
+        assert np.allclose(fn(0.5, None, 3), np.eye(3) * 0.5)
+        assert np.allclose(fn(np.array([1.0, 2.0, 3.0]), None, 3), np.diag([1.0, 2.0, 3.0]))
+        got = fn(np.array([[1.0, 2.0], [3.0, 4.0]]), None, 2)
+        assert np.allclose(got, np.array([[[1.0, 2.0], [0.0, 0.0]], [[0.0, 0.0], [3.0, 4.0]]]))
+        with pytest.raises(ValueError):
+            fn(np.array([1.0, 2.0, 3.0]), np.eye(3), 3)
+        with pytest.raises(ValueError):
+            fn(None, None, 3)
+        M = np.arange(6.0).reshape(3, 2)
+        assert fn(None, M, 3) is M or np.array_equal(fn(None, M, 3), M)
