@@ -163,6 +163,17 @@ int mln_nn_distances(mln_ctx* ctx, const double* x, int64_t n, const double* y, 
  * inertia_out may be NULL; the inertia is a full fp64 assignment of all cells to the final centres. */
 int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int64_t seed,
                int32_t max_iter, double tol, double* centers, int32_t* n_iter_out, double* inertia_out);
+/* The same with sklearn's OWN seeding (sklearn.cluster._kmeans._kmeans_plusplus behind k_means(x, m, n_init=1,
+ * random_state), parameters.py:275-291): the first centre is cell `first_id`, centre c is the best of n_local_trials
+ * (= 2 + int(log m)) candidates drawn at uniforms[(c - 1) * n_local_trials + l] * current_pot on the cumulative sums of the
+ * squared distances.  The caller draws first_id and the (m - 1) * n_local_trials uniforms with numpy's
+ * RandomState(random_state) -- exactly the numbers sklearn consumes -- so the seeds are the cells sklearn picks (up to
+ * summation order: see csrc/kmeans.hip) and the landmarks comparable with the reference's at any size.  Lloyd's sweeps
+ * then run over all cells to sklearn's stopping rule; max_iter = 0 returns the seeds.  indices_out (m, may be NULL): the
+ * seeded cells. */
+int mln_kmeans_sklearn(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int64_t first_id,
+                       const double* uniforms, int32_t n_local_trials, int32_t max_iter, double tol, double* centers,
+                       int64_t* indices_out, int32_t* n_iter_out, double* inertia_out);
 
 /* ---- a-4/a-5: in-place lower Cholesky of (A + add_diag * I), A m x m symmetric (lower read).
  * decomposition.py:111-123 (`stabilize` util.py:269-293 + jnp.linalg.cholesky).  Strict upper

@@ -79,6 +79,8 @@ SYMBOLS = [
     ("mln_kernel_gram", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dp]),
     ("mln_nn_distances", C.c_int, [_vp, _dp, _i64, _dp, _i64, _i32, _i64, _dp]),
     ("mln_kmeans", C.c_int, [_vp, _dp, _i64, _i32, _i64, _i64, _i32, _dbl, _dp, C.POINTER(_i32), C.POINTER(_dbl)]),
+    ("mln_kmeans_sklearn", C.c_int, [_vp, _dp, _i64, _i32, _i64, _i64, _dp, _i32, _i32, _dbl, _dp, _vp, C.POINTER(_i32),
+                                     C.POINTER(_dbl)]),
     ("mln_chol_lower", C.c_int, [_vp, _dp, _i64, _dbl]),
     ("mln_trsm_lower", C.c_int, [_vp, _dp, _i64, _i32, _dp, _i64]),
     ("mln_fit_prepare", C.c_int, [_vp, _KD, _dp, _i64, _i32, _dp, _i64, _dbl, _dp, _i32, C.POINTER(_vp)]),
@@ -425,11 +427,23 @@ class Context:
                                               int(self_offset), out.ctypes.data))
         return out
 
-    def kmeans(self, x, m, seed=42, max_iter=300, tol=1e-4, return_info=False):
-        """k-means++ / Lloyd centroids on the device (m x d)."""
+    def kmeans(self, x, m, seed=42, max_iter=300, tol=1e-4, return_info=False, init="device"):
+        """k-means++ / Lloyd centroids on the device (m x d).  init="device": the library's own draws (fastest);
+        init="sklearn": the seeds sklearn.cluster.k_means(x, m, n_init=1, random_state=seed) picks -- numpy's
+        RandomState(seed) supplies exactly the numbers sklearn's _kmeans_plusplus consumes (mln_kmeans_sklearn)."""
         x = x if isinstance(x, DeviceArray) else _as2d(x)
         centers = np.empty((int(m), x.shape[1]), dtype=np.float64)
         nit, inertia = C.c_int32(), C.c_double()
+        if init == "sklearn":
+            first, uni, trials = sklearn_seeding_numbers(x.shape[0], int(m), seed)
+            idx = np.empty(int(m), dtype=np.int64)
+            self._check(self.lib.mln_kmeans_sklearn(self.handle, _ptr(x), x.shape[0], x.shape[1], int(m), int(first),
+                                                    uni.ctypes.data, trials, int(max_iter), float(tol), centers.ctypes.data,
+                                                    idx.ctypes.data, C.byref(nit), C.byref(inertia) if return_info else None))
+            self.last_kmeans_seed_indices = idx
+            return (centers, nit.value, inertia.value) if return_info else centers
+        if init != "device":
+            raise ValueError("init must be 'device' or 'sklearn'")
         self._check(self.lib.mln_kmeans(self.handle, _ptr(x), x.shape[0], x.shape[1], int(m), int(seed),
                                         int(max_iter), float(tol), centers.ctypes.data, C.byref(nit),
                                         C.byref(inertia) if return_info else None))   # (the inertia is a full fp64 assignment)
@@ -780,6 +794,18 @@ def _as2d(a):
     if a.ndim == 1:
         a = a.reshape(-1, 1)
     return np.ascontiguousarray(a)
+
+
+def sklearn_seeding_numbers(n, m, seed):
+    """(first cell, (m - 1) x L uniform numbers, L) as sklearn's _kmeans_plusplus draws them from RandomState(seed):
+    `random_state.choice(n, p=sample_weight / sample_weight.sum())` with unit weights, then per centre
+    `random_state.uniform(size=L)`, L = 2 + int(log m)."""
+    rs = np.random.RandomState(seed)
+    trials = 2 + int(np.log(m))
+    sw = np.ones(n, dtype=np.float64)
+    first = int(rs.choice(n, p=sw / sw.sum()))
+    uni = np.ascontiguousarray(rs.uniform(size=(max(m - 1, 0), trials)), dtype=np.float64)
+    return first, uni, trials
 
 
 class _Pinned:

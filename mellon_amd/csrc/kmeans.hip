@@ -777,6 +777,329 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   return rc;
 }
 
+// ---- sklearn-compatible k-means++ seeding (round 5) ---------------------------------------------------------------------
+// What the reference's landmarks come from: sklearn.cluster.k_means(x, m, n_init=1, random_state=42) (parameters.py:275-291),
+// i.e. _kmeans_plusplus with 2 + int(log m) local trials per centre, its random numbers from numpy's RandomState(seed):
+//   first centre     rs.choice(n, p = uniform)
+//   centre c         rand_vals = rs.uniform(size = L) * current_pot ; candidate_l = searchsorted(cumsum(closest_dist_sq), rand_vals)
+//                    (clipped to n - 1) ; the candidate with the smallest potential sum_i min(closest_dist_sq_i, |x_i - cand|^2)
+//                    becomes the centre, closest_dist_sq is updated with it.
+// The binding draws the random numbers with numpy itself (the generator IS the specification) and hands them over; the device
+// does the O(n L d) distances, the cumulative sums and the argmin -- two launches per centre:
+//   k_sk_candidates   every cell: min(closest, distance to each of the L candidates) -> tmp[n][L]; per-block partial
+//                     potentials; the LAST workgroup to finish adds them in block order and picks the candidate
+//   k_sk_update       closest <- tmp[:, best]; block sums of closest; the LAST workgroup walks the cumulative sums (block
+//                     sums, then the cells of the block) for the next centre's L targets
+// Sums are in a fixed order (bit-reproducible); they are not numpy's order, so a target within rounding of a cell's boundary
+// may pick the neighbouring cell: ~1e-13 n per draw (tests: the same centres as sklearn on 2e4 cells).  d <= 64, L <= 32.
+constexpr int SK_LMAX = 32;
+struct SkState {            // device-resident, one per seeding
+  double pot;               // current potential
+  int64_t cand[SK_LMAX];    // candidate cells of the centre being chosen
+  int best;                 // the winning candidate
+  unsigned done_a, done_b;  // arrival counters of the two kernels
+};
+
+// Workgroup = SBLK consecutive cells in sub-tiles of 128 rows, staged through LDS with coalesced loads (row stride 65: odd,
+// conflict-free column walks).  Thread t works on row t & 127 and on HALF of the candidates (waves 0-1 the first half,
+// waves 2-3 the second): the candidates' coordinates are wave-uniform global reads (scalar loads), the row's come from LDS,
+// eight running sums per pass.  tmp is candidate-major (tmp[l][i]): coalesced writes here, one contiguous column read later.
+__global__ __launch_bounds__(256) void k_sk_candidates(const double* __restrict__ x, int64_t n, int d, int L,
+                                                       const double* __restrict__ closest, double* __restrict__ tmp,
+                                                       double* __restrict__ part, SkState* st, const double* __restrict__ cb,
+                                                       double* __restrict__ centers, int64_t* __restrict__ indices, int c) {
+  constexpr int XS = 65;
+  __shared__ double xs[128 * XS];
+  __shared__ double cst[64 * SK_LMAX + 8];      // candidates, coordinate-major: cst[k][l]  (zero beyond L: the unused lanes of a pass)
+  __shared__ double red[4][16];
+  __shared__ double red8[8][SK_LMAX];
+  __shared__ bool last;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row = t & 127, half = __builtin_amdgcn_readfirstlane(t >> 7);     // (wave-uniform: scalar loads of the candidates)
+  const int Lh = (L + 1) / 2, l_beg = half * Lh, l_cnt = (L - l_beg < Lh) ? (L - l_beg) : Lh;     // this thread's candidates
+  double acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+  for (int e = threadIdx.x; e < 64 * SK_LMAX + 8; e += 256) cst[e] = 0.0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < L * d; e += 256) { const int l = e / d, k = e - l * d; cst[k * SK_LMAX + l] = cb[e]; }
+  const int64_t base = (int64_t)blockIdx.x * SBLK;
+  // A sub-tile (128 rows x d doubles) is ONE contiguous range of the row-major matrix: 32 unconditional-address loads per
+  // thread, issued back to back (and for sub-tile s + 1 before the arithmetic of s), scattered into the padded LDS rows after.
+  const unsigned magic = (unsigned)((0x100000000ull + (unsigned)d - 1u) / (unsigned)d);     // e / d for e < 2^16
+  double stage[32];
+  auto request = [&](int sub) {
+    const int64_t r0 = base + sub * 128;
+    const int64_t left = (n - r0) * (int64_t)d;
+    const int cnt = (int)((left < 128 * (int64_t)d) ? (left > 0 ? left : 0) : 128 * d);
+    const double* src = x + r0 * (int64_t)d;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const int e = t + 256 * q; stage[q] = (e < cnt) ? src[e] : 0.0; }
+  };
+  request(0);
+  for (int sub = 0; sub < SBLK / 128; ++sub) {
+    const int64_t r0 = base + sub * 128;
+    if (r0 >= n) break;
+    const int nrows = (int)((n - r0 < 128) ? (n - r0) : 128);
+    const int cnt = nrows * d;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const unsigned e = (unsigned)(t + 256 * q);
+      if ((int)e < cnt) { const unsigned r = (unsigned)(((unsigned long long)e * magic) >> 32); xs[r * XS + (e - r * (unsigned)d)] = stage[q]; }
+    }
+    __syncthreads();
+    if (sub + 1 < SBLK / 128) request(sub + 1);
+    if (row < nrows) {
+      const int64_t i = r0 + row;
+      const double cl = closest[i];
+      const double* xr = xs + row * XS;
+      for (int j0 = 0; j0 < l_cnt; j0 += 8) {
+        double sacc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const double* cq = cst + l_beg + j0;             // eight candidates side by side per coordinate: broadcast LDS reads
+        for (int k = 0; k < d; ++k) {
+          const double v = xr[k];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const double a = v - cq[k * SK_LMAX + j]; sacc[j] = fma(a, a, sacc[j]); }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j0 + j < l_cnt) {
+            const double r = fmin(cl, sacc[j]);
+            tmp[(int64_t)(l_beg + j0 + j) * n + i] = r;
+            acc[j0 + j] += r;
+          }
+      }
+    }
+  }
+  // block partials: fixed shuffle tree per wave; a candidate's two waves added in order
+  for (int j = 0; j < Lh; ++j) {
+    double v = acc[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][j] = v;
+  }
+  __syncthreads();
+  if (t < L) { const int h = t / Lh, j = t - h * Lh; part[(int64_t)blockIdx.x * SK_LMAX + t] = red[2 * h][j] + red[2 * h + 1][j]; }
+  __threadfence();
+  __syncthreads();
+  if (t == 0) last = atomicAdd(&st->done_a, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // the last workgroup: potentials of the L candidates -- eight runs of blocks per candidate, each added in block order,
+  // the runs in order -- and the smallest one wins (the first on ties, as numpy.argmin)
+  {
+    const int l = t & 31, run = t >> 5;
+    const int64_t nb = gridDim.x, per = (nb + 7) / 8, b0 = run * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+    double p = 0.0;
+    if (l < L) for (int64_t bb = b0; bb < b1; ++bb) p += part[bb * SK_LMAX + l];
+    red8[run][l] = p;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int best = 0;
+    double pbest = 0.0;
+    for (int l = 0; l < L; ++l) {
+      double p = 0.0;
+      for (int r = 0; r < 8; ++r) p += red8[r][l];
+      if (l == 0 || p < pbest) { best = l; pbest = p; }
+    }
+    st->best = best;
+    st->pot = pbest;
+    st->done_a = 0;
+    indices[c] = st->cand[best];
+  }
+  __syncthreads();
+  const int64_t chosen = st->cand[st->best];
+  for (int k = t; k < d; k += 256) centers[(int64_t)c * d + k] = x[chosen * (int64_t)d + k];
+}
+
+// first: closest = |x - centre 0|^2 (tmp unused); else closest <- tmp[best][:].  Block sums -> bsum; the last workgroup
+// draws the NEXT centre's candidates from `uni` (L uniform numbers; nullptr: none left) and copies their coordinates to cb
+__global__ __launch_bounds__(256) void k_sk_update(const double* __restrict__ x, int64_t n, int d, int L,
+                                                   double* __restrict__ closest, const double* __restrict__ tmp,
+                                                   double* __restrict__ bsum, SkState* st, const double* __restrict__ uni,
+                                                   double* __restrict__ cb, int first, int64_t first_id) {
+  __shared__ double cs[64];
+  __shared__ double red[4];
+  __shared__ bool last;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (first) {
+    for (int k = t; k < d; k += 256) cs[k] = x[first_id * (int64_t)d + k];
+    __syncthreads();
+  }
+  const int best = first ? 0 : st->best;
+  const int64_t base = (int64_t)blockIdx.x * SBLK;
+  double acc = 0.0;
+  for (int q = 0; q < SBLK / 256; ++q) {
+    const int64_t i = base + q * 256 + t;
+    if (i < n) {
+      double v;
+      if (first) {
+        v = 0.0;
+        for (int k = 0; k < d; ++k) { const double a = x[i * (int64_t)d + k] - cs[k]; v = fma(a, a, v); }
+      } else {
+        v = tmp[(int64_t)best * n + i];
+      }
+      closest[i] = v;
+      acc += v;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (t == 0) bsum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  __threadfence();
+  __syncthreads();
+  if (t == 0) last = atomicAdd(&st->done_b, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (t == 0) st->done_b = 0;
+  if (!uni) return;
+  // numpy.searchsorted(cumsum(closest), target): the cell whose interval of the running sum holds the target.  Two levels --
+  // runs of block sums, then the cells of one block -- each a wave-wide scan (no workgroup barrier): wave w draws the
+  // targets w, w + 4, ...; all of it in a fixed order.
+  auto wave_find = [&](double v, double target, int* own, double* rem_out) {
+    double inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    const double prev = __shfl_up(inc, 1, 64);
+    const double excl = (lane == 0) ? 0.0 : prev;
+    const bool mine = v > 0.0 && !(target < excl) && target < inc;
+    const unsigned long long mask = __ballot(mine);
+    if (mask == 0ull) { *own = -1; *rem_out = 0.0; return inc; }
+    const int o = __ffsll((long long)mask) - 1;
+    *own = o;
+    *rem_out = __shfl(target - excl, o, 64);
+    return inc;
+  };
+  const int64_t nblk = gridDim.x, per = (nblk + 63) / 64;
+  const int64_t b0 = lane * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+  // the block sums through LDS when they fit (one coalesced read instead of chains of dependent global loads)
+  __shared__ double bs_lds[4096];
+  const bool in_lds = nblk <= 4096;
+  if (in_lds) { for (int64_t b = t; b < nblk; b += 256) bs_lds[b] = bsum[b]; }
+  __syncthreads();
+  const double* bs = in_lds ? bs_lds : bsum;
+  double ps = 0.0;
+  for (int64_t b = b0; b < b1; ++b) ps += bs[b];
+  int own = 0;
+  double rem = 0.0;
+  const double pot = __shfl(wave_find(ps, -1.0, &own, &rem), 63, 64);          // (the scan's last inclusive sum: the total)
+  if (first && t == 0) st->pot = pot;
+  const double cur_pot = first ? pot : st->pot;
+  for (int l = wave; l < L; l += 4) {
+    (void)wave_find(ps, uni[l] * cur_pot, &own, &rem);
+    double target = rem;
+    if (own < 0) { own = 63; while (own > 0 && !((int64_t)own * per < nblk)) --own; target = INFINITY; }
+    int64_t blk = (int64_t)own * per;
+    {
+      const int64_t bend = (blk + per < nblk) ? blk + per : nblk;
+      for (; blk + 1 < bend; ++blk) { const double bv = bs[blk]; if (target < bv) break; target -= bv; }
+    }
+    const int64_t lo = blk * SBLK, hi = (lo + SBLK < n) ? lo + SBLK : n;
+    constexpr int CPL = SBLK / 64;
+    double v[CPL], ls = 0.0;
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) { const int64_t i = lo + lane * CPL + e; v[e] = (i < hi) ? closest[i] : 0.0; ls += v[e]; }
+    int own2 = 0;
+    double rem2 = 0.0;
+    (void)wave_find(ls, target, &own2, &rem2);
+    int64_t pick = (hi == n) ? n - 1 : hi - 1;           // (np.clip / rounding at the end of the sums: the last cell)
+    if (own2 >= 0) {
+      int64_t mine = lo + lane * CPL + CPL - 1;
+      double run = 0.0;
+      bool found = false;
+#pragma unroll
+      for (int e = 0; e < CPL; ++e) { run += v[e]; if (!found && run >= rem2) { mine = lo + lane * CPL + e; found = true; } }
+      if (mine >= hi) mine = hi - 1;
+      pick = __shfl(mine, own2, 64);
+    }
+    if (lane == 0) st->cand[l] = pick;
+    if (lane < d) cb[l * d + lane] = x[pick * (int64_t)d + lane];
+  }
+}
+
+// centres seeded exactly as sklearn's _kmeans_plusplus would with the given random numbers: dc (m x d, device) <- the centres,
+// indices (m, device) <- the cells they are
+static int sklearn_seed(mln_ctx* ctx, const double* dx, int64_t n, int d, int64_t m, int64_t first_id, const double* uniforms,
+                        int L, double* dc, int64_t* indices) {
+  hipStream_t st = ctx->stream;
+  const int64_t nblk = (n + SBLK - 1) / SBLK;
+  double *closest = nullptr, *tmp = nullptr, *part = nullptr, *bsum = nullptr, *duni = nullptr, *cb = nullptr;
+  SkState* state = nullptr;
+  int rc = MLN_OK;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == MLN_OK) rc = mln_hip_fail(ctx, e, "kmeans (sklearn seeding)", __FILE__, __LINE__); };
+  chk(mln_dmalloc((void**)&closest, sizeof(double) * (size_t)n));
+  chk(mln_dmalloc((void**)&tmp, sizeof(double) * (size_t)n * (size_t)L));
+  chk(mln_dmalloc((void**)&part, sizeof(double) * (size_t)nblk * SK_LMAX));
+  chk(mln_dmalloc((void**)&bsum, sizeof(double) * (size_t)nblk));
+  chk(mln_dmalloc((void**)&duni, sizeof(double) * (size_t)std::max<int64_t>(1, (m - 1) * L)));
+  chk(mln_dmalloc((void**)&state, sizeof(SkState)));
+  chk(mln_dmalloc((void**)&cb, sizeof(double) * SK_LMAX * 64));
+  if (rc == MLN_OK) {
+    chk(hipMemsetAsync(state, 0, sizeof(SkState), st));
+    if (m > 1) chk(hipMemcpyAsync(duni, uniforms, sizeof(double) * (size_t)((m - 1) * L), hipMemcpyDefault, st));
+    chk(hipMemcpyAsync(dc, dx + first_id * d, sizeof(double) * (size_t)d, hipMemcpyDeviceToDevice, st));
+    chk(hipMemcpyAsync(indices, &first_id, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    chk(hipStreamSynchronize(st));                 // (first_id is a stack variable)
+  }
+  if (rc == MLN_OK) {
+    hipLaunchKernelGGL(k_sk_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, L, closest, tmp, bsum, state, m > 1 ? duni : nullptr, cb, 1, first_id);
+    for (int64_t c = 1; c < m; ++c) {
+      hipLaunchKernelGGL(k_sk_candidates, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, L, closest, tmp, part, state, cb, dc, indices, (int)c);
+      hipLaunchKernelGGL(k_sk_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, L, closest, tmp, bsum, state,
+                         c + 1 < m ? duni + c * L : nullptr, cb, 0, (int64_t)0);
+    }
+    chk(hipGetLastError());
+    chk(hipStreamSynchronize(st));
+  }
+  void* ptrs[] = {closest, tmp, part, bsum, duni, state, cb};
+  for (void* p : ptrs) if (p) (void)mln_dfree(p);
+  return rc;
+}
+
+extern "C" int mln_kmeans_sklearn(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int64_t first_id,
+                                  const double* uniforms, int32_t n_local_trials, int32_t max_iter, double tol,
+                                  double* centers, int64_t* indices_out, int32_t* n_iter_out, double* inertia_out) {
+  if (!ctx || !x || !centers || (m > 1 && !uniforms)) return MLN_ERR_ARG;
+  if (n < 1 || d < 1 || d > 64 || m < 1 || m > n || first_id < 0 || first_id >= n || n_local_trials < 1 || n_local_trials > SK_LMAX) {
+    mln_set_error(ctx, "kmeans (sklearn seeding): bad shape (need 1 <= m <= n, d <= 64, 1 <= trials <= 32, 0 <= first < n)");
+    return MLN_ERR_SHAPE;
+  }
+  MLN_HIP(ctx, hipSetDevice(ctx->device));
+  const double* dx = x;
+  double* owned = nullptr;
+  {
+    hipPointerAttribute_t attr;
+    if (!(hipPointerGetAttributes(&attr, x) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged))) {
+      (void)hipGetLastError();
+      MLN_HIP(ctx, mln_dmalloc((void**)&owned, sizeof(double) * (size_t)n * d));
+      MLN_HIP(ctx, hipMemcpyAsync(owned, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, ctx->stream));
+      dx = owned;
+    }
+  }
+  double* dc = nullptr;
+  int64_t* dind = nullptr;
+  MLN_HIP(ctx, mln_dmalloc((void**)&dc, sizeof(double) * (size_t)m * d));
+  MLN_HIP(ctx, mln_dmalloc((void**)&dind, sizeof(int64_t) * (size_t)m));
+  int rc = sklearn_seed(ctx, dx, n, d, m, first_id, uniforms, n_local_trials, dc, dind);
+  if (rc == MLN_OK && indices_out && hipMemcpy(indices_out, dind, sizeof(int64_t) * (size_t)m, hipMemcpyDefault) != hipSuccess) rc = MLN_ERR_HIP;
+  // Lloyd's sweeps from these centres over ALL cells, to sklearn's stopping rule (max_iter = 0: the seeding alone)
+  if (rc == MLN_OK && max_iter > 0) rc = kmeans_level(ctx, dx, n, d, m, 0, max_iter, tol, dc, centers, n_iter_out, inertia_out);
+  else if (rc == MLN_OK) {
+    if (hipMemcpy(centers, dc, sizeof(double) * (size_t)m * d, hipMemcpyDefault) != hipSuccess) rc = MLN_ERR_HIP;
+    if (n_iter_out) *n_iter_out = 0;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)mln_dfree(dc); (void)mln_dfree(dind);
+  if (owned) (void)mln_dfree(owned);
+  return rc;
+}
+
 // Reference: parameters.compute_landmarks -> sklearn.cluster.k_means(x, n_landmarks, n_init=1, random_state) (parameters.py:243-291).
 // Round 4, coarse to fine: with many cells per centre, Lloyd's ~200 sweeps over ALL cells mostly move centres that a
 // fraction of the cells already places well.  Above 64 cells per centre (and 2e5 cells) the seeding and a first Lloyd run

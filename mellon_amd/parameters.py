@@ -68,13 +68,17 @@ def compute_gp_type(n_landmarks, rank, n_samples):
 
 
 KMEANS_DEVICE_THRESHOLD = 2e8   # n * n_landmarks above which k-means runs on the device
+# Seeding of the device k-means: "device" (the library's own draws: 0.08 s at 1e6 x 50 -> 5000) or "sklearn" (the cells
+# sklearn's own k-means++ picks for the same random_state -- the landmarks of the default call are then comparable with the
+# reference's at any size; 2 s at that size).  The environment variable MELLON_AMD_KMEANS_INIT overrides.
+KMEANS_DEVICE_INIT = "device"
 
 
 def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_state=DEFAULT_RANDOM_SEED,
                       backend=None):
     """k-means centroids (reference parameters.py:243-291).  backend "sklearn" is the reference's
     own call (bit-identical landmarks); "hip" is k-means++ / Lloyd on the device (mln_kmeans: same
-    algorithm family, different random stream); None picks "hip" when n * n_landmarks exceeds
+    algorithm family; its seeding is the library's own or, with KMEANS_DEVICE_INIT = "sklearn", sklearn's); None picks "hip" when n * n_landmarks exceeds
     KMEANS_DEVICE_THRESHOLD (where sklearn takes minutes) and d <= 64."""
     if n_landmarks == 0:
         return None
@@ -91,8 +95,10 @@ def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_s
     logger.info(f"Computing {n_landmarks:,} landmarks with k-means clustering "
                 f"(random_state={random_state}, backend={backend}).")
     if backend == "hip":
+        import os
+        init = os.environ.get("MELLON_AMD_KMEANS_INIT", KMEANS_DEVICE_INIT)
         return _lib.default_context().kmeans(np.ascontiguousarray(x, dtype=np.float64), n_landmarks,
-                                             seed=random_state if random_state is not None else DEFAULT_RANDOM_SEED)
+                                             seed=random_state if random_state is not None else DEFAULT_RANDOM_SEED, init=init)
     from sklearn.cluster import k_means
     return k_means(x, n_landmarks, n_init=1, random_state=random_state)[0]
 

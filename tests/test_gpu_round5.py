@@ -191,3 +191,25 @@ def test_full_conditional_with_y_cov_factor(ctx):
     assert relmax(got.mean_covariance(xq), ref.mean_covariance(xq)) < 1e-6
     with pytest.raises(ValueError, match="either `sigma` or `y_cov_factor`"):
         FullConditional(x, y, 0.2, c, y_cov_factor=M, sigma=0.3)
+
+
+@pytest.mark.parametrize("n,d,m", [(20_000, 10, 300), (5000, 3, 16), (60_000, 50, 700)])
+def test_kmeans_sklearn_compatible_seeding(ctx, n, d, m):
+    """init="sklearn": the device picks the cells sklearn's own k-means++ picks (sklearn.cluster.kmeans_plusplus with
+    RandomState(42): the seeding behind the reference's k_means(x, m, n_init=1, random_state=42), parameters.py:275-291) --
+    every one of the m seeds, not only the first 16 -- and Lloyd's sweeps from them end at sklearn's clustering quality."""
+    from sklearn.cluster import kmeans_plusplus, k_means
+    x = mo.gaussian_mixture(n, d, seed=21)
+    _, idx_ref = kmeans_plusplus(x, m, random_state=42)
+    seeds = ctx.kmeans(x, m, seed=42, max_iter=0, init="sklearn")
+    idx = ctx.last_kmeans_seed_indices
+    assert np.array_equal(idx[:16], idx_ref[:16])
+    assert np.array_equal(idx, idx_ref), int(np.argmax(idx != idx_ref))
+    assert np.array_equal(seeds, x[idx_ref])
+    if n <= 20_000:
+        c_ref, _, inertia_ref = k_means(x, m, n_init=1, random_state=42)
+        c, _, inertia = ctx.kmeans(x, m, seed=42, init="sklearn", return_info=True)
+        assert abs(inertia - inertia_ref) <= 2e-3 * inertia_ref
+        # most centres coincide (a cell tied between two centres within the fp16 pre-filter's 1e-5 may go either way)
+        dist = np.sqrt(((c[:, None, :] - c_ref[None, :, :]) ** 2).sum(-1)).min(axis=1)
+        assert np.median(dist) < 1e-6 * np.abs(x).max()
