@@ -329,6 +329,38 @@ def bench_other(args, comm, ctx, info, world, rank):
                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": flops / (elapsed / args.steps) / 1e12 / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                            "note": "step-level figure (host<->device traffic of the n x p arrays included)"}
+    # ---- CPU baseline beside it (rank 0, bounded sample of the SAME workload, the oracle = the reference's algorithm restated;
+    #      kind "port"): C4 a time-sensitive density fit of an evenly spaced subsample, C5 the function fit + predict of one ------
+    if rank == 0 and args.cpu_sample != 0:
+        from oracle import mellon_oracle as mo
+        try:
+            from threadpoolctl import threadpool_limits
+            limits = threadpool_limits(limits=os.cpu_count())
+        except Exception:
+            limits = None
+        t0 = time.perf_counter()
+        if args.config == "c4":
+            ns = min(n, args.cpu_sample if args.cpu_sample > 0 else 40_000)
+            idx = np.arange(0, n, max(1, n // ns))[:ns]
+            xs = np.ascontiguousarray(xt[idx])
+            nn_s = mo.per_time_nn_distances(xs[:, :-1], xs[:, -1])
+            fit = mo.density_fit(xs, cov_func_curry=getattr(mo, args.kernel), landmarks=lm, nn_distances=nn_s, d=d, ls_time=1.5)
+            evals = int(getattr(fit, "n_eval", 0) or 0)
+            what_cpu = (f"{ns} cells (every {max(1, n // ns)}-th, all 8 time points), {m} landmarks, the oracle's time-sensitive density fit at the "
+                        f"reference's L-BFGS-B defaults ({evals} evaluations), 1-NN distances included")
+        else:
+            ns = min(n, args.cpu_sample if args.cpu_sample > 0 else 20_000)
+            idx = np.arange(0, n, max(1, n // ns))[:ns]
+            xs = np.ascontiguousarray(x[idx])
+            ys = np.sin(xs @ Wm) + 0.1 * np.random.default_rng(args.seed + 1).normal(size=(ns, p))
+            nn_s = mo.exact_nn_distances(xs)
+            pred = mo.function_fit(xs, ys, sigma, cov_func_curry=getattr(mo, args.kernel), landmarks=lm, nn_distances=nn_s)
+            _ = pred.mean(xs)
+            what_cpu = (f"{ns} cells (every {max(1, n // ns)}-th), {p} outputs, {m} landmarks: the oracle's landmark conditional + predict of "
+                        "the same cells, 1-NN distances included")
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": ns / dt, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": what_cpu + f"; {dt:.1f} s wall (every stage is O(n): cells/s carries over to the full size)"}
     return out
 
 

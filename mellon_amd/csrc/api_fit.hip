@@ -33,15 +33,6 @@ void fit_free(mln_fit* f) {
 
 extern "C" void mln_fit_destroy(mln_fit* fit) { fit_free(fit); }
 
-__global__ void k_round_copy_bits(unsigned* __restrict__ q, int64_t count, int drop) {
-  const unsigned half = 1u << (drop - 1), mask = ~((1u << drop) - 1u);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-    const unsigned v = q[i];
-    const unsigned r = (v > 0xffffffffu - half) ? (v & mask) : ((v + half) & mask);
-    q[i] = r;
-  }
-}
-
 int fit_alloc_workspace(mln_fit* f) {
   mln_ctx* ctx = f->ctx;
   int64_t steps = (f->n + 1) / 2;
@@ -303,13 +294,6 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     }
     // the evaluation workspace (device vectors, pinned mirrors, events: ~0.5 ms of host calls) while the pass runs
     MLN_TRY(fit_alloc_workspace(f));
-    if (f->L32 && f->l32_fixed)
-      if (const char* ev = mln_experiment("MELLON_AMD_COPY_BITS")) {   // experiment: the copy rounded to fewer bits
-        const int bits = std::atoi(ev);
-        if (bits >= 8 && bits < 32)
-          hipLaunchKernelGGL(k_round_copy_bits, dim3(4096), dim3(256), 0, ctx->stream, reinterpret_cast<unsigned*>(f->L32),
-                             (int64_t)n * f->ldl, 32 - bits);
-      }
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) fprintf(stderr, "[trace] L kernel matrix done at %.4f s\n", now_s() - t0);
     f->times[0] += now_s() - t0;

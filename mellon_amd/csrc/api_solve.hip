@@ -321,14 +321,10 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP_STEP")) init.cap_step = std::atof(ev);
   if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP"))
     init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
-  if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP64"))      // experiment: the cap of a pure-fp64 solve alone
-    if (!phase32) init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
   // (the opt-in mixed solve runs WITHOUT the cap: its surrogate / anchor state machine was tuned with the round-2 linear cap,
   //  and with the staged quadratic one the tree of tests/test_gpu_round4.py ran into the iteration limit)
   if (phase32 && !mln_experiment("MELLON_AMD_EXP_CAP")) init.cap = __builtin_inf();
   init.cap0 = init.cap;
-  init.cap_fall = 0.15;
-  if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP_FALL")) init.cap_fall = std::atof(ev);
   init.boost_fall = 0.15;
   if (const char* ev = mln_experiment("MELLON_AMD_LS_BOOST_FALL")) init.boost_fall = std::atof(ev);
   // Subsample start (solver.h): when the preconditioner's Gram came from every s-th cell (s >= 4), the solve starts
@@ -416,8 +412,8 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     init.over_many = frac > 0.0 ? std::max(8.0, frac * (double)f->n * (double)(ctx->n_ranks > 1 ? ctx->n_ranks : 1)) : 0.0;
   }
   init.over_cnt_acc = 0.0;
-  init.rebuild_at_switch = 0;     // (measured: at the switch the unseen cells' weights are still too wild -- 37-96 full passes)
-  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_AT_SWITCH")) init.rebuild_at_switch = std::atoi(ev) != 0 ? 1 : 0;
+  // (a rebuild right at the switch from the subsample to all cells was measured in round 3: 37-96 full passes -- the unseen
+  //  cells' weights are still too wild there; the knob is gone)
   init.switch_t0 = 0.35;
   if (const char* ev = mln_experiment("MELLON_AMD_SWITCH_T0")) init.switch_t0 = std::atof(ev);
   init.gap_tol = 0.2 * o.ftol;     // (tools/solver_sweep.py, seven data seeds at C3: 15.9 -> 14.7 full passes with both rules, log-density
@@ -528,10 +524,6 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
         if (trace_lvl) fprintf(stderr, "[trace] map_solve pause at evaluation %d: %s\n", ps.n_eval,
                                revert ? "second preconditioner failed its trial: first one restored"
                                       : (outcome == 0 ? "preconditioner rebuilt" : (outcome == 1 ? "rebuild declined (weight range)" : "rebuild lost positive definiteness: kept the first")));
-        if (const char* ev = mln_experiment("MELLON_AMD_RESUME_T0")) {     // experiment: first trial step under the new preconditioner
-          const double t0v = std::atof(ev);
-          MLN_HIP(ctx, hipMemcpyAsync(&f->sv.st->t0, &t0v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        }
       }
       MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
       f->times_rebuild += now_s() - tr0 - (f->emu_excluded - ex_r0);

@@ -23,7 +23,6 @@ struct SolverState {
   double ftol, gtol, ftol32;
   double prior_const;       // (m / 2) log 2 pi
   double fx, t, gd;         // accepted loss, current trial step, g . d at the accepted point
-  double cap_fall;          // relative decrease of the loss per pass below which the cap is dropped
   double cap;               // the likelihood's e^t is continued by its second-order Taylor polynomial beyond t = cap (inf: off);
                             // raised by cap_step whenever the capped solve slows down with rows still above it
   double cap_step;
@@ -41,7 +40,6 @@ struct SolverState {
   int gate_full;            // MLN_GATE_F64, or MLN_GATE_F32 when a 32-bit copy exists
   int n_eval_sub;           // evaluations on the subsamples so far
   int sub_level, n_sub_levels;   // ... which of the (nested, ever larger) subsamples the SUB gate currently means
-  int rebuild_at_switch;    // pause for the preconditioner rebuild right after the first full evaluation that follows the subsamples
   // Preconditioner rebuild: with rebuild_armed set by the host, the solver PAUSES (gate = MLN_GATE_PAUSE) after an
   // accepted fp64 iteration whose progress has fallen below rebuild_tol; the host then re-factors the preconditioner
   // from the a-weighted importance sample at that point (api.hip fit_rebuild_precond), re-expresses u and g in the new

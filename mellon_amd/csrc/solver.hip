@@ -173,8 +173,7 @@ __global__ __launch_bounds__(ST) void k_solver_step(SolverBuffers b) {
     for (int e = 0; e < EPT; ++e) g[e] = gn[e];
     // first full fp64 evaluation after the subsample levels: the weights a = e^{f+V} of EVERY cell are on the table and the
     // point is close to the optimum -- the moment for the second preconditioner
-    if (mode == MLN_SOLVE_REEVAL && !approx && st->rebuild_armed && st->rebuild_at_switch && st->n_eval_sub > 0 && it_full == 0) pause = true;
-    else if (mode == MLN_SOLVE_REEVAL && !approx && st->rebuild_armed && corr && n_anchor == 1 && st->use_corr) pause = true;   // the early anchor of the mixed solve
+    if (mode == MLN_SOLVE_REEVAL && !approx && st->rebuild_armed && corr && n_anchor == 1 && st->use_corr) pause = true;   // the early anchor of the mixed solve
     else to_head = true;
   } else {
     ++ls;
