@@ -392,13 +392,21 @@ __global__ __launch_bounds__(512) void k_assign_mfma(const double* __restrict__ 
 // magnitude cannot overflow 62 bits, and comes out as sum * 2^-e_k / count.  Resolution: |x|_max,k * n * 2^-62 per
 // coordinate -- 2e-13 of the column's range at 1e6 cells; a cell that leaves a cluster takes out exactly what it put in.
 __global__ void k_km_colmax(const double* __restrict__ x, int64_t n, int d, unsigned long long* __restrict__ colmax) {
-  // a thread walks the elements e = t, t + T, ... of the row-major matrix (coalesced); its column changes with e
-  const int64_t total = n * d, T = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += T) {
+  // The first (blockDim / d) * d threads of every workgroup walk the row-major matrix with a stride that is a multiple of d:
+  // a thread's column never changes, its maximum stays in a register, ONE atomic per thread at the end.  (Round 4 issued an
+  // atomicMax per ELEMENT: 16 ms at 1e6 x 50, twice per k-means.)
+  const int usable = ((int)blockDim.x / d) * d;
+  if ((int)threadIdx.x >= usable) return;
+  const int64_t total = n * d, T = (int64_t)gridDim.x * usable;
+  double mx = 0.0;
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * usable + threadIdx.x; e < total; e += T) {
     const double v = fabs(x[e]);
-    if (v > 0.0 && v < INFINITY) atomicMax(&colmax[e % d], (unsigned long long)__double_as_longlong(v));   // non-negative doubles order as integers
-    else if (!(v < INFINITY)) atomicMax(&colmax[d], 1ull);      // NaN / inf: the fixed-point sums (llrint) would turn it into garbage silently
+    if (v < INFINITY) mx = fmax(mx, v); else bad = true;     // NaN / inf: the fixed-point sums (llrint) would turn it into garbage silently
   }
+  const int col = (int)(((int64_t)blockIdx.x * usable + threadIdx.x) % d);
+  if (mx > 0.0) atomicMax(&colmax[col], (unsigned long long)__double_as_longlong(mx));   // non-negative doubles order as integers
+  if (bad) atomicMax(&colmax[d], 1ull);
 }
 __global__ void k_km_colscale(const unsigned long long* __restrict__ colmax, int d, int64_t n, double* __restrict__ scale) {
   for (int k = threadIdx.x; k < d; k += blockDim.x) {
