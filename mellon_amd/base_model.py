@@ -12,7 +12,7 @@ from .inference import (DEFAULT_INIT_LEARN_RATE, DEFAULT_JIT, DEFAULT_N_ITER, DE
                         compute_laplace_std, minimize_adam, minimize_lbfgsb, run_advi)
 from .parameter_validation import validate_cov_func, validate_cov_func_curry, validate_params
 from .parameters import (DEFAULT_RANDOM_SEED, compute_cov_func, compute_gp_type, compute_landmarks,
-                         compute_ls, compute_n_landmarks, compute_nn_distances, compute_rank)
+                         compute_ls, compute_n_landmarks, compute_nn_distances, compute_rank, landmarks_backend)
 from .util import DEFAULT_JITTER, GaussianProcessType, ensure_2d
 from .validation import (validate_array, validate_bool, validate_float, validate_float_or_int,
                          validate_float_or_iterable_numerical, validate_nn_distances, validate_nn_distances_sharded,
@@ -142,17 +142,53 @@ class BaseEstimator:
             cached = self._x_all = (np.ascontiguousarray(np.concatenate(parts, axis=0)), lo)
         return cached
 
-    def _compute_landmarks(self):
+    # -- one HBM copy of the cells for the steps before the fit ---------------------------------------------
+    DEVICE_X_MIN_BYTES = 1 << 26      # below this the three uploads (1-NN, k-means, fit) cost less than the bookkeeping
+
+    def _x_on_device(self):
+        """The cells in HBM: uploaded ONCE for the 1-NN search, the k-means landmarks and the fit instead of once per
+        step (single rank, host x of at least DEVICE_X_MIN_BYTES); else self.x itself.  Released by
+        _release_x_on_device() when prepare_inference() is through."""
+        from .distributed import current
+        if isinstance(self.x, _lib.DeviceArray) or self.x is None:
+            return self.x
+        held = self.__dict__.get("_x_dev")
+        if held is not None and held[0] is self.x and held[1].ptr is not None:
+            return held[1]
+        if current().world_size > 1 or self.x.ndim != 2 or self.x.nbytes < self.DEVICE_X_MIN_BYTES:
+            return self.x
+        dev = _lib.default_context().to_device(np.ascontiguousarray(self.x, dtype=np.float64))
+        self._x_dev = (self.x, dev)
+        return dev
+
+    def _x_for_fit(self):
+        """The HBM copy if an earlier step made one, else self.x (a host array is uploaded by the fit itself, in chunks
+        under its first kernels)."""
+        held = self.__dict__.get("_x_dev")
+        if held is not None and held[0] is self.x and held[1].ptr is not None:
+            return held[1]
+        return self.x if isinstance(self.x, _lib.DeviceArray) else np.ascontiguousarray(self.x)
+
+    def _release_x_on_device(self):
+        held = self.__dict__.pop("_x_dev", None)
+        if held is not None:
+            held[1].free()
+
+    def _compute_landmarks(self, ctx=None):
         from .distributed import current
         comm = current()
-        x_all, _ = self._all_cells()
-        n = x_all.shape[0]
+        n = self._n_cells_global()
         if n > 100 * self.n_landmarks and n > 1e6:
             logger.info(f"Large number of {n:,} cells and small number of {self.n_landmarks:,} landmarks. Consider "
                         "computing k-means on a subset of cells and passing the results as 'landmarks'.")
         if comm.world_size == 1:
-            return compute_landmarks(self.x, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed())
+            x = self.x
+            if not isinstance(x, _lib.DeviceArray) and self.n_landmarks and self.n_landmarks < x.shape[0] and \
+                    landmarks_backend(x.shape[0], x.shape[1], self.n_landmarks) == "hip":
+                x = self._x_on_device()
+            return compute_landmarks(x, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed(), ctx=ctx)
         # replicated input: rank 0 clusters the gathered cells, every rank receives the same bits
+        x_all, _ = self._all_cells()
         lm = compute_landmarks(x_all, self.gp_type, n_landmarks=self.n_landmarks, random_state=self._seed()) \
             if comm.rank == 0 else None
         return comm.broadcast(None if lm is None else np.ascontiguousarray(lm, dtype=np.float64), src=0)
@@ -161,7 +197,7 @@ class BaseEstimator:
         logger.info("Computing nearest neighbor distances.")
         from .distributed import current
         if current().world_size == 1:
-            return validate_nn_distances(compute_nn_distances(self.x, seed=self._seed()))
+            return validate_nn_distances(compute_nn_distances(self._x_on_device(), seed=self._seed()))
         x_all, lo = self._all_cells()
         n_loc = self.x.shape[0]
         # this rank's cells against the cells of all ranks, the pair (i, lo + i) excluded
@@ -190,7 +226,7 @@ class BaseEstimator:
             self._fit = _full_decomposition_low_rank(self.x, self.cov_func, rank=self.rank, jitter=self.jitter).fit
         elif given_L is None and self.gp_type == GaussianProcessType.SPARSE_NYSTROEM:
             logger.info("Computing improved Nystroem rank reduction on the landmarks.")
-            xin = self.x if isinstance(self.x, _lib.DeviceArray) else np.ascontiguousarray(self.x)
+            xin = self._x_for_fit()
             self._fit = _modified_low_rank(xin, self.cov_func, self.landmarks, rank=self.rank,
                                            jitter=self.jitter).fit
         elif given_L is not None:
@@ -202,7 +238,7 @@ class BaseEstimator:
             Lp = None if self.Lp is None else np.asarray(self.Lp, dtype=np.float64)
             full = self.gp_type == GaussianProcessType.FULL or self.landmarks is None
             logger.info("Computing Lp.")
-            xin = self.x if isinstance(self.x, _lib.DeviceArray) else np.ascontiguousarray(self.x)
+            xin = self._x_for_fit()
             # implicit mode: stream K = cov(x, landmarks) and fold Lp^-T into the m-vectors (no n x m
             # triangular solve); the explicit factor is only needed for the diagonal Laplace.
             self._fit = ctx.fit_prepare(self.cov_func.lower(self.x.shape[1]), xin,

@@ -64,10 +64,27 @@ thread_local std::vector<void*>* t_deferred = nullptr;
 }
 void mln_dfree_defer(std::vector<void*>* sink) { t_deferred = sink; }
 
+namespace {
+hipError_t release_block(void* p);
+}
+
 hipError_t mln_dfree(void* p) {
   if (!p) return hipSuccess;
   if (t_deferred) { t_deferred->push_back(p); return hipSuccess; }
   (void)hipDeviceSynchronize();  // same guarantee hipFree gives: nothing in flight touches the block
+  return release_block(p);
+}
+
+// The caller has synchronised the ONE stream every user of the block was enqueued on: no device-wide wait, so a call that
+// runs beside another context's long kernel (k-means landmarks beside the 1-NN search) does not sit that kernel out.
+hipError_t mln_dfree_synced(void* p) {
+  if (!p) return hipSuccess;
+  if (t_deferred) { t_deferred->push_back(p); return hipSuccess; }
+  return release_block(p);
+}
+
+namespace {
+hipError_t release_block(void* p) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_live.find(p);
   if (it == g_live.end()) return hipFree(p);
@@ -78,6 +95,7 @@ hipError_t mln_dfree(void* p) {
   g_free.insert({bytes, Block{p, dev}});
   return hipSuccess;
 }
+}  // namespace
 
 void mln_dcache_flush() {
   std::lock_guard<std::mutex> lk(g_mu);

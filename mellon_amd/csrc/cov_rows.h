@@ -6,7 +6,7 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 namespace covrows {
 constexpr int TN = 64;    // centres per tile
-constexpr int NNS = 68;   // LDS row stride (doubles): = 4 mod 32, 16 rows x 4 k touch every bank pair twice
+constexpr int NNS = 65;   // LDS row stride (doubles), odd: the 16 lanes of one ds_read2_b64 group (li = 0..15, one k) land on 16 distinct bank pairs
 }  // namespace covrows
 
 // persistent-row launchers: one stationary leaf over all d <= 64 contiguous columns

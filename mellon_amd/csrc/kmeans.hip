@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "mln_internal.h"
+
+hipError_t mln_dfree_synced(void* p);   // alloc.hip: release after the caller synchronised the only stream that used p
 #include "rowmin_f16.h"
 #include "mln_options.h"
 
@@ -780,8 +782,8 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   (void)hipStreamSynchronize(st);
   void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f, prep, xxs, ub, lb, delta, dstat, yy, ymax,
                   m2f, argc, nflag, flagged, colmax, colscale, sq};
-  for (void* p : ptrs) if (p) (void)mln_dfree(p);
-  if (own_x) (void)mln_dfree(dx);
+  for (void* p : ptrs) if (p) (void)mln_dfree_synced(p);      // everything ran on st, synchronised above
+  if (own_x) (void)mln_dfree_synced(dx);
   return rc;
 }
 
@@ -1147,8 +1149,8 @@ extern "C" int mln_kmeans(mln_ctx* ctx, const double* x, int64_t n, int32_t d, i
   if (rc == MLN_OK) rc = kmeans_level(ctx, dx, n, d, m, seed, max_iter, tol, c0, centers, &it1, inertia_out);
   if (n_iter_out) *n_iter_out = it0 + it1;
   (void)hipStreamSynchronize(st);
-  if (xs) (void)mln_dfree(xs);
-  if (c0) (void)mln_dfree(c0);
-  if (owned) (void)mln_dfree(owned);
+  if (xs) (void)mln_dfree_synced(xs);
+  if (c0) (void)mln_dfree_synced(c0);
+  if (owned) (void)mln_dfree_synced(owned);
   return rc;
 }

@@ -22,6 +22,8 @@
 #include <vector>
 
 #include "mln_internal.h"
+
+hipError_t mln_dfree_synced(void* p);   // alloc.hip: release after the caller synchronised the only stream that used p
 #include "rowmin_f16.h"
 #include "mln_options.h"
 
@@ -716,7 +718,7 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
   };
   auto cleanup = [&](int rc) {
     (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : owned) (void)mln_dfree(p);
+    for (void* p : owned) (void)mln_dfree_synced(p);
     return rc;
   };
   const int fold = (d <= KP - 3) ? 1 : 0;       // (three spare k slots carry |y|^2)

@@ -136,6 +136,12 @@ class DensityEstimator(BaseEstimator):
         elif self.x is not None and self.x is not x:
             raise ValueError("self.x has been set already, but is not equal to the argument x.")
         self.set_x(x)
+        try:
+            return self._prepare_pipeline()
+        finally:
+            self._release_x_on_device()      # the one HBM copy of host cells the steps before the fit shared
+
+    def _prepare_pipeline(self):
         worker = None
         for attr in self._PIPELINE:
             if attr is None:

@@ -74,15 +74,22 @@ KMEANS_DEVICE_THRESHOLD = 2e8   # n * n_landmarks above which k-means runs on th
 KMEANS_DEVICE_INIT = "device"
 
 
+def landmarks_backend(n, d, n_landmarks):
+    """Where compute_landmarks runs by default: "hip" when n * n_landmarks exceeds KMEANS_DEVICE_THRESHOLD and d <= 64."""
+    return "hip" if (n * n_landmarks > KMEANS_DEVICE_THRESHOLD and d <= 64) else "sklearn"
+
+
 def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_state=DEFAULT_RANDOM_SEED,
-                      backend=None):
+                      backend=None, ctx=None):
     """k-means centroids (reference parameters.py:243-291).  backend "sklearn" is the reference's
     own call (bit-identical landmarks); "hip" is k-means++ / Lloyd on the device (mln_kmeans: same
     algorithm family; its seeding is the library's own or, with KMEANS_DEVICE_INIT = "sklearn", sklearn's); None picks "hip" when n * n_landmarks exceeds
-    KMEANS_DEVICE_THRESHOLD (where sklearn takes minutes) and d <= 64."""
+    KMEANS_DEVICE_THRESHOLD (where sklearn takes minutes) and d <= 64.  x may be HBM-resident (a DeviceArray: "hip" only);
+    ctx: the device context to run on (default: the calling thread's)."""
     if n_landmarks == 0:
         return None
-    x = ensure_2d(x)
+    on_device = isinstance(x, _lib.DeviceArray)
+    x = x if on_device else ensure_2d(x)
     n = x.shape[0]
     assert n_landmarks > 1, "n_landmarks musst be larger 1 or euqual to 0"
     if n_landmarks >= n:
@@ -91,14 +98,17 @@ def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_s
             return x
         return None
     if backend is None:
-        backend = "hip" if (n * n_landmarks > KMEANS_DEVICE_THRESHOLD and x.shape[1] <= 64) else "sklearn"
+        backend = "hip" if on_device else landmarks_backend(n, x.shape[1], n_landmarks)
     logger.info(f"Computing {n_landmarks:,} landmarks with k-means clustering "
                 f"(random_state={random_state}, backend={backend}).")
     if backend == "hip":
         import os
         init = os.environ.get("MELLON_AMD_KMEANS_INIT", KMEANS_DEVICE_INIT)
-        return _lib.default_context().kmeans(np.ascontiguousarray(x, dtype=np.float64), n_landmarks,
-                                             seed=random_state if random_state is not None else DEFAULT_RANDOM_SEED, init=init)
+        return (ctx or _lib.default_context()).kmeans(x if on_device else np.ascontiguousarray(x, dtype=np.float64), n_landmarks,
+                                                      seed=random_state if random_state is not None else DEFAULT_RANDOM_SEED,
+                                                      init=init)
+    if on_device:
+        x = x.to_host()
     from sklearn.cluster import k_means
     return k_means(x, n_landmarks, n_init=1, random_state=random_state)[0]
 
@@ -137,6 +147,9 @@ def compute_distances(x, k, seed=DEFAULT_RANDOM_SEED):
 def compute_nn_distances(x, seed=DEFAULT_RANDOM_SEED):
     """reference parameters.py:408-433 -- exact, brute force on the device (mln_nn_distances);
     the reference's pynndescent search is approximate and `seed` only matters there."""
+    if isinstance(x, _lib.DeviceArray):          # HBM-resident cells (validated when they were uploaded)
+        validate_k(1, x.shape[0])
+        return _lib.default_context().nn_distances(x)
     x = ensure_2d(validate_array(x, "x"))
     if x.shape[0] == 0:
         raise ValueError("Input data x is empty.")

@@ -213,3 +213,33 @@ def test_kmeans_sklearn_compatible_seeding(ctx, n, d, m):
         # most centres coincide (a cell tied between two centres within the fp16 pre-filter's 1e-5 may go either way)
         dist = np.sqrt(((c[:, None, :] - c_ref[None, :, :]) ** 2).sum(-1)).min(axis=1)
         assert np.median(dist) < 1e-6 * np.abs(x).max()
+
+
+def test_one_upload_for_the_steps_before_the_fit(ctx):
+    """DensityEstimator.prepare_inference uploads large host cells ONCE for the 1-NN search, the k-means landmarks and the fit
+    (reference density_estimator.py:404-470 hands the same host array to each step): the landmarks, distances and densities
+    are those of the steps run one by one from the host array, and the HBM copy is gone afterwards."""
+    import mellon_amd
+    from mellon_amd import _lib
+    from mellon_amd.parameters import compute_landmarks, compute_nn_distances
+    n, d, m = 180_000, 50, 1500                    # n m > KMEANS_DEVICE_THRESHOLD, 72 MB of cells
+    x = mo.gaussian_mixture(n, d, seed=5)
+    est = mellon_amd.DensityEstimator(n_landmarks=m, check_rank=False)
+    est.set_x(x)
+    dev = est._x_on_device()
+    assert isinstance(dev, _lib.DeviceArray) and est._x_on_device() is dev and est._x_for_fit() is dev
+    est._release_x_on_device()
+    assert est._x_for_fit() is est.x
+    est = mellon_amd.DensityEstimator(n_landmarks=m, check_rank=False)
+    dens = est.fit_predict(x)
+    assert "_x_dev" not in est.__dict__            # released when prepare_inference() is through
+    lm = compute_landmarks(x, n_landmarks=m, random_state=est.random_state)
+    nn = compute_nn_distances(x)
+    assert np.array_equal(np.asarray(est.landmarks), lm)
+    assert np.array_equal(np.asarray(est.nn_distances), nn)
+    ref = mellon_amd.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False).fit_predict(x)
+    assert relmax(dens, ref) < 1e-9
+    # small inputs are handed to each step as they are
+    small = mellon_amd.DensityEstimator(n_landmarks=50, check_rank=False)
+    small.set_x(x[:2000])
+    assert small._x_on_device() is small.x

@@ -1,6 +1,8 @@
 """Per-kernel averages of the counters in one or more rocprofv3 --pmc databases (one row per kernel and counter).
 
-    python tools/pmc_summary.py <db> [<db> ...] [--match substr] > profiles/rNN_pmc.txt
+    python tools/pmc_summary.py <db> [<db> ...] [--match substr] [--min-us T] > profiles/rNN_pmc.txt
+
+--min-us T: only launches that ran at least T microseconds (a kernel launched at two very different sizes).
 """
 import re
 import sqlite3
@@ -19,11 +21,16 @@ def main(argv):
         i = argv.index("--match")
         match = argv[i + 1]
         argv = argv[:i] + argv[i + 2:]
+    min_ns = 0.0
+    if "--min-us" in argv:
+        i = argv.index("--min-us")
+        min_ns = 1e3 * float(argv[i + 1])
+        argv = argv[:i] + argv[i + 2:]
     table = {}
     for path in argv:
         con = sqlite3.connect(path)
         rows = con.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration) "
-                           "from counters_collection group by kernel_name, counter_name").fetchall()
+                           "from counters_collection where duration >= ? group by kernel_name, counter_name", (min_ns,)).fetchall()
         for k, c, n, v, d in rows:
             k = short(k)
             if match and match not in k:
