@@ -194,8 +194,7 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
   // only the landmarks (cov(xu, xu), its Cholesky factor, the block-scaled copies) and under the kernel-matrix pass of the
   // chunks that have already arrived; each chunk's pass waits for that chunk's event only.
   HostUpload up;
-  bool pipelined = !f->full && n > 0 && x && !is_device_ptr(x) && (size_t)n * d * sizeof(double) >= ((size_t)32 << 20) &&
-                         !(mln_experiment("MELLON_AMD_UPLOAD_PIPELINE") && std::atoi(mln_experiment("MELLON_AMD_UPLOAD_PIPELINE")) == 0);
+  bool pipelined = !f->full && n > 0 && x && !is_device_ptr(x) && (size_t)n * d * sizeof(double) >= ((size_t)32 << 20);
   if (pipelined) {
     dx.ctx = ctx;
     MLN_HIP(ctx, mln_dmalloc((void**)&dx.owned, (size_t)n * d * sizeof(double)));
@@ -481,8 +480,7 @@ extern "C" int mln_fit_gram_rank(mln_fit* f, double tol, int64_t* rank_out, doub
   const int n_ranks = ctx->n_ranks > 1 ? ctx->n_ranks : 1;
   const int64_t n_est = f->n * n_ranks;
   int64_t stride = 1;
-  static const bool sampled_ok = !(mln_experiment("MELLON_AMD_RANK_SAMPLED") && std::atoi(mln_experiment("MELLON_AMD_RANK_SAMPLED")) == 0);
-  if (sampled_ok && f->kspace && n_est >= 24 * m) stride = std::max<int64_t>(1, n_est / (12 * m));
+  if (f->kspace && n_est >= 24 * m) stride = std::max<int64_t>(1, n_est / (12 * m));
   auto gram = [&]() { return f->kspace ? fit_gram(f, G, ld, stride) : gram_of(ctx, f->L, f->ldl, f->n, m, 1.0, G, ld); };
   int rc = gram();
   double lmax = 0.0;

@@ -139,8 +139,7 @@ int fit_enqueue_eval(mln_fit* f, const double* u_dev, double* gn_dev, bool use32
   ObjArgs a = obj_args(f);
   a.z = f->kspace ? f->d_w : f->d_zr;
   a.gate = gate;
-  static const bool no_fkeep = mln_experiment("MELLON_AMD_NO_FKEEP") != nullptr;
-  if (gate && !no_fkeep && f->f_keep[0] && objective_can_keep_f(f->n, f->n_wg)) { a.f_keep[0] = f->f_keep[0]; a.f_keep[1] = f->f_keep[1]; a.f_slot = &f->sv.st->f_slot; }
+  if (gate && f->f_keep[0] && objective_can_keep_f(f->n, f->n_wg)) { a.f_keep[0] = f->f_keep[0]; a.f_keep[1] = f->f_keep[1]; a.f_slot = &f->sv.st->f_slot; }
   if (gate) { a.cap = &f->sv.st->cap; a.over_flag = f->d_over; }   // (round 5: the capped start applies to the fp64 and the subsample passes too)
   if (ev) MLN_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
   if (f->L32 && (gate || use32)) {
@@ -318,7 +317,6 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.cap = 9.0;      // (tools/r05_ab_c3.sh, C3 seeds 3-6, mean step: off 149 ms | 5: 148 | 6: 164 | 7: 139 | 8: 140 | 9: 130 | 10: 132 | 12: ~158;
                        //  tree / heavy tails at 1e6 cells, passes: 7: 130 / 86 | 8: 158 / 81 | 9: 158 / 97 -- against 511 / 473 without it)
   init.cap_step = 4.0;
-  if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP_STEP")) init.cap_step = std::atof(ev);
   if (const char* ev = mln_experiment("MELLON_AMD_EXP_CAP"))
     init.cap = (std::strcmp(ev, "off") == 0 || std::atof(ev) <= 0.0) ? __builtin_inf() : std::atof(ev);
   // (the opt-in mixed solve runs WITHOUT the cap: its surrogate / anchor state machine was tuned with the round-2 linear cap,
@@ -330,33 +328,18 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // Subsample start (solver.h): when the preconditioner's Gram came from every s-th cell (s >= 4), the solve starts
   // on the MAP problem of exactly those cells -- the Ridge matrix is ITS Hessian at a = 1 -- at 1/s of the bytes per
   // pass, and moves to all cells once that problem's progress per iteration is below sub_tol.  The walk down from the
-  // Ridge start (a dozen passes) then costs about two.  MELLON_AMD_SUBSAMPLE=0 disables, MELLON_AMD_SUB_TOL moves it.
-  // Which cells: ~32 m of them (every (3 s / 16)-th cell for a Gram stride s = n / 6 m; nested levels are possible,
-  // MELLON_AMD_SUB_LEVELS="16:8", but did not pay).  tools/solver_sweep.py, five data seeds at C3, mean step in ms:
+  // Ridge start (a dozen passes) then costs about two.  MELLON_AMD_SUBSAMPLE=0 disables.
+  // Which cells: ~32 m of them (every (3 s / 16)-th cell for a Gram stride s = n / 6 m; nested levels did not pay).  tools/solver_sweep.py, five data seeds at C3, mean step in ms:
   // no subsample 302 | stride 16: 241 | 12: 204 | 8: 203 | 6: 193 | 4: 203 | 16 then 8: 213 | 16 then 4: 215.
   // The smaller the sample, the cheaper its passes but the more its optimum overfits (at stride 16 the first full
   // evaluation finds the loss 60 % above the optimum's and e^{f+V} of unseen cells up to 1e5).
   std::vector<int64_t> sub_strides;
   if (f->precond_stride >= 11) sub_strides.push_back(std::max<int64_t>(2, 3 * f->precond_stride / 16));
-  if (const char* ev = mln_experiment("MELLON_AMD_SUB_LEVELS")) {
-    if (!sub_strides.empty()) {
-      sub_strides.clear();
-      for (const char* p = ev; *p;) {
-        char* end = nullptr;
-        const long long v = std::strtoll(p, &end, 10);
-        if (end == p) break;
-        if (v >= 2) sub_strides.push_back((int64_t)v);
-        p = (*end != 0) ? end + 1 : end;        // any one separator character ("16,4", "16:4")
-      }
-    }
-  }
   if (const char* ev = mln_experiment("MELLON_AMD_SUBSAMPLE")) { if (std::atoi(ev) == 0) sub_strides.clear(); }
   const std::vector<int64_t>* subs = sub_strides.empty() ? nullptr : &sub_strides;
   init.gate_full = init.gate;
   init.sub_tol = 1e-3;
-  if (const char* ev = mln_experiment("MELLON_AMD_SUB_TOL")) init.sub_tol = std::atof(ev);
   init.sub_max_evals = 1 << 30;  // (off: the tree of tools/hard_cases.py spends 139 evaluations there -- and needs MORE passes in total with a limit of 48 or 32)
-  if (const char* ev = mln_experiment("MELLON_AMD_SUB_MAX_EVALS")) init.sub_max_evals = std::atoi(ev);
   init.n_sub_levels = (int)sub_strides.size();
   init.sub_level = 0;
   if (subs) init.gate = MLN_GATE_SUB;
@@ -389,8 +372,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // kernel's f staging: with uneven or very large shards that is a per-rank fact, and the branch at the pause issues
   // collectives (Gram all-reduce, the sample's global sum) -- so the decision is made ONCE, here, for all ranks: rank 0's
   // cost rule AND every rank able to keep f (one all-reduce of two numbers: rank 0's vote, the count of ranks that cannot).
-  static const bool no_fkeep_env = mln_experiment("MELLON_AMD_NO_FKEEP") != nullptr;
-  const bool keeps_f = !no_fkeep_env && f->f_keep[0] && f->f_keep[1] && objective_can_keep_f(f->n, f->n_wg);
+  const bool keeps_f = f->f_keep[0] && f->f_keep[1] && objective_can_keep_f(f->n, f->n_wg);
   {
     double vote[2] = {ctx->rank == 0 ? want_rebuild : 0.0, keeps_f ? 0.0 : 1.0};
     MLN_HIP(ctx, hipMemcpyAsync(f->d_tmp, vote, sizeof(vote), hipMemcpyHostToDevice, ctx->stream));
@@ -406,22 +388,15 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   init.rebuild_armed = want_rebuild != 0.0 ? (phase32 ? 1 : max_rebuilds) : 0;      // (the opt-in mixed solve keeps its single rebuild)
   init.it_resume = -1;
   // an overshooting start (solver.h over_many): more than one cell in 10 000 above the cap
-  {
-    double frac = 1e-4;
-    if (const char* ev = mln_experiment("MELLON_AMD_EARLY_REBUILD_FRAC")) frac = std::atof(ev);
-    init.over_many = frac > 0.0 ? std::max(8.0, frac * (double)f->n * (double)(ctx->n_ranks > 1 ? ctx->n_ranks : 1)) : 0.0;
-  }
+  init.over_many = std::max(8.0, 1e-4 * (double)f->n * (double)(ctx->n_ranks > 1 ? ctx->n_ranks : 1));
   init.over_cnt_acc = 0.0;
   // (a rebuild right at the switch from the subsample to all cells was measured in round 3: 37-96 full passes -- the unseen
   //  cells' weights are still too wild there; the knob is gone)
   init.switch_t0 = 0.35;
-  if (const char* ev = mln_experiment("MELLON_AMD_SWITCH_T0")) init.switch_t0 = std::atof(ev);
   init.gap_tol = 0.2 * o.ftol;     // (tools/solver_sweep.py, seven data seeds at C3: 15.9 -> 14.7 full passes with both rules, log-density
                                    //  within 4e-8 of the old stop -- the spread between two runs of the old rule; 0.5 ftol: 14.3 passes, 1.8e-7)
-  if (const char* ev = mln_experiment("MELLON_AMD_GAP_TOL")) init.gap_tol = std::atof(ev);
   init.dec_prev = 0.0; init.dec_prev2 = 0.0;
   init.rebuild_tol = 1e-3;       // (tools/solver_sweep.py at C3, two seeds: 1e-2 -> 23-28 full passes, 1e-3 -> 20-22, 2e-4 -> 22-26)
-  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_TOL")) init.rebuild_tol = std::atof(ev);
   init.start_cap = 1e30;         // (solver.h: pathological start; C3's Ridge start evaluates to 4.8e9)
   init.n_shrink = 0;
   init.revert_after = 0; init.it_at_resume = -1; init.pause_reason = 0;
@@ -429,7 +404,6 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (const char* ev = mln_experiment("MELLON_AMD_REVERT_AFTER")) revert_after = std::atoi(ev);
   double rebuild_rows_per_m = 6.0;   // (first rebuild -- C3: 6 m, 12 m, 24 m importance-sampled rows give the same pass counts, 6 m is the cheapest Gram;
                                      //  the later ones, which only slow solves reach, take twice as many: tree 169 -> 150, 115 -> 79, heavy tails 128 -> 104 passes)
-  if (const char* ev = mln_experiment("MELLON_AMD_REBUILD_ROWS_PER_M")) rebuild_rows_per_m = std::atof(ev);
   MLN_TRY(launch_solver_init(ctx, f->sv, init, f->d_gu));
   const int* gate = &f->sv.st->gate;
   static const bool timing = !(std::getenv("MELLON_AMD_TIMING") && std::atoi(std::getenv("MELLON_AMD_TIMING")) == 0);
@@ -450,7 +424,6 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   std::vector<std::pair<int, int>> slot_shift;      // (first trace index, shift)
   const std::vector<int64_t>* subs_live = subs;
   int batch = 8;
-  if (const char* ev = mln_experiment("MELLON_AMD_SOLVER_BATCH")) batch = std::max(1, std::atoi(ev));
   const int64_t hard_cap = (int64_t)o.maxiter * o.maxls + 16;
   for (;;) {
     for (int b = 0; b < batch; ++b) {
@@ -578,7 +551,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     MLN_HIP(ctx, hipMemcpyAsync(z_out, f->d_z, sizeof(double) * m, hipMemcpyDefault, ctx->stream));
     MLN_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  if (st.f_valid && objective_can_keep_f(f->n, f->n_wg) && !mln_experiment("MELLON_AMD_NO_FKEEP")) f->f_final = st.f_slot;   // f = L z + mu at this z is already there (mln_transform)
+  if (st.f_valid && objective_can_keep_f(f->n, f->n_wg)) f->f_final = st.f_slot;   // f = L z + mu at this z is already there (mln_transform)
   if (trace_lvl)
     fprintf(stderr, "[trace] map_solve: %d evaluations (%d on the 32-bit copy, %d on the row subsample of stride %lld), %d iterations, "
             "%d rebuild(s), %d enqueued, status %d\n", st.n_eval, st.n_eval32, st.n_eval_sub, (long long)(subs ? sub_strides[0] : 0), st.it,

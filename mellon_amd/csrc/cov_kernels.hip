@@ -999,24 +999,23 @@ int launch_kernel_matrix(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   bool contiguous = single && cov.leaves[0].ndims == d;
   if (contiguous)
     for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
-  static const bool no_mfma = mln_experiment("MELLON_AMD_KM_NO_MFMA") != nullptr;
   static const bool no_rows_env = mln_experiment("MELLON_AMD_KM_NO_ROWS") != nullptr;
   // (the persistent-row kernels read the centres WITHOUT bounds checks up to tile ceil(ldo / 64) + 1: the zero rows pad_rows
   //  appends cover that only while the output's leading dimension stays within 64 columns of m -- every caller passes
   //  ldo = m or pad16(m); anything wider takes the tiled kernels)
   const bool no_rows = no_rows_env || ldo > m + 64;
-  if (contiguous && !no_mfma && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
+  if (contiguous && !no_rows && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE && cov.leaves[0].kind != MLN_K_RATQUAD && (!out32 || q32)) {
     MLN_TRY(pad_rows(ctx, y, m, d, ypad));
     MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));   // norms of the pad rows
     MLN_TRY(launch_kernel_matrix_rows_q(ctx, cov, x, n, ypad, m, d, xx, yy, out, ldo, add_diag, out32, q32));
-  } else if (!no_mfma && !no_rows && n >= 4096 && m >= 256 && (!out32 || q32) && predict_rows_prod_eligible(cov, d)) {
+  } else if (!no_rows && n >= 4096 && m >= 256 && (!out32 || q32) && predict_rows_prod_eligible(cov, d)) {
     // the time-sensitive product kernel: state leaf x time leaf, both in the persistent-row kernel (leaf 0's norms come
     // first; leaf 1's, which it does not use, are overwritten by the zero padding)
     MLN_TRY(pad_rows(ctx, y, m, d, ypad));
     MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));
     MLN_TRY(launch_kernel_matrix_rows_prod(ctx, cov, x, n, ypad, m, d, xx, yy, out, ldo, add_diag, out32, q32));
-  } else if (contiguous && !no_mfma && n * m >= 4096)
+  } else if (contiguous && n * m >= 4096)
     hipLaunchKernelGGL(k_kernel_matrix_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, out, ldo, add_diag, tiles_n, out32, q32);
   else if (single)
@@ -1046,19 +1045,18 @@ int launch_predict_mean1(mln_ctx* ctx, const DevCov& cov, const double* x, int64
   bool contiguous = single && cov.leaves[0].ndims == d;
   if (contiguous)
     for (int k = 0; k < d; ++k) contiguous = contiguous && cov.dims[cov.leaves[0].dims_off + k] == k;
-  static const bool no_mfma = mln_experiment("MELLON_AMD_KM_NO_MFMA") != nullptr;
-  if (contiguous && !no_mfma && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
+  if (contiguous && d <= 64 && n >= 4096 && m >= 256 && cov.leaves[0].kind != MLN_K_LINEAR &&
       cov.leaves[0].kind != MLN_K_DISTANCE) {
     MLN_TRY(pad_rows(ctx, y, m, d, ypad));
     MLN_TRY(pad_rows(ctx, w, m, 1, wpad));
     MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));
     MLN_TRY(launch_predict_mean_rows(ctx, cov, x, n, ypad, m, d, xx, yy, wpad, mu, out));
-  } else if (!no_mfma && n >= 4096 && m >= 256 && predict_rows_prod_eligible(cov, d)) {
+  } else if (n >= 4096 && m >= 256 && predict_rows_prod_eligible(cov, d)) {
     MLN_TRY(pad_rows(ctx, y, m, d, ypad));
     MLN_TRY(pad_rows(ctx, w, m, 1, wpad));
     MLN_HIP(ctx, hipMemsetAsync(yy + m, 0, sizeof(double) * (size_t)ROWS_PAD, ctx->stream));   // (leaf 0's norms come first)
     MLN_TRY(launch_predict_mean_rows_prod(ctx, cov, x, n, ypad, m, d, xx, yy, wpad, mu, out));
-  } else if (contiguous && !no_mfma && n * m >= 4096)
+  } else if (contiguous && n * m >= 4096)
     hipLaunchKernelGGL(k_predict_mean_mfma, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, cov, x, n, y, m, d,
                        xx, yy, w, mu, out);
   else if (single)
@@ -1080,8 +1078,7 @@ int launch_nn_distances_exact(mln_ctx* ctx, const double* x, int64_t n, const do
   double* yy = norms + n;
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, d, xx);
   hipLaunchKernelGGL(k_row_sqnorms_all, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, y, m, d, yy);
-  static const bool no_mfma = mln_experiment("MELLON_AMD_KM_NO_MFMA") != nullptr;
-  if (d <= 64 && !no_mfma && n * m >= 4096)
+  if (d <= 64 && n * m >= 4096)
     hipLaunchKernelGGL(k_nn_distances_mfma, dim3((unsigned)((n + 127) / 128)), dim3(512), 0, ctx->stream, x, n, y, m, d,
                        xx, yy, self_offset, excl, out);
   else

@@ -640,12 +640,9 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   const int64_t slots = 2 * n_cu;
   const int nbatch = g.batch > 1 ? g.batch : 1;
   const int split = (g.split_k > 1 ? g.split_k : 1) * nbatch;      // (for the tile policy a batch counts like a k-split: more workgroups per tile)
-  static const int64_t min_tiles = mln_experiment("MELLON_AMD_GEMM_MIX_MIN") ? std::atoll(mln_experiment("MELLON_AMD_GEMM_MIX_MIN")) : -1;
   // (below one round of 128-tiles the launch is all quadrants, served by the quadrant-only instances -- MODE 1 / 2 of
   //  k_dgemm_mix, 40 KB of LDS.  Measured against k_dgemm's 64-wide tiles on the chains of the factorisations (A/B on one box,
-  //  tools/r04c_ab.sh): chol(5000) 4.5 -> 4.2 ms, Ridge solve 8.6 -> 8.2 ms, rebuild 17.0 -> 16.5 ms.  MELLON_AMD_GEMM_MIX_MIN
-  //  restores a threshold in 128-tiles for experiments.)
-  if (!any_size && n_active * split < (min_tiles >= 0 ? min_tiles : 0)) return MLN_ERR_UNSUPPORTED;
+  //  tools/r04c_ab.sh): chol(5000) 4.5 -> 4.2 ms, Ridge solve 8.6 -> 8.2 ms, rebuild 17.0 -> 16.5 ms.)
   TileMap tmap;
   tmap.tiles_m = tiles_m; tmap.tiles_n = tiles_n; tmap.n_active = n_active;
   const bool heavy_last = g.kmode == 3 || g.kmode == 7 || g.kmode == 4;
@@ -684,8 +681,6 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   return MLN_OK;
 }
 
-static int g_bk_override = -1;   // diagnostics: force the tile size (128 / 64); -1 = automatic
-void dgemm_set_bk(int bk) { g_bk_override = bk; }
 static int g_mix_override = -1;  // diagnostics: -1 = policy; 0 = single-size kernels only; 1 = mixed kernel for every launch it can serve
 void dgemm_set_mix(int mode) { g_mix_override = mode; }
 
@@ -717,17 +712,15 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   {
     const int64_t t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) / (g.lower_only ? 2 : 1);
     const int64_t n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    static const int64_t below = mln_experiment("MELLON_AMD_GEMM64_BELOW") ? std::atoll(mln_experiment("MELLON_AMD_GEMM64_BELOW")) : 0;
     // (below 4 tiles per CU the 128-wide tiling leaves its last round of workgroups mostly empty -- 722 tiles on 512 slots
     //  -- and four times as many 64-wide tiles pack better: factor + inverses 9.1 -> 8.5 ms, rebuild 17.7 -> 17.1 ms at m = 5000)
-    if (t128 * (g.split_k > 1 ? g.split_k : 1) < (below > 0 ? below : 4 * n_cu) && !inplace) bt = 64;
+    if (t128 * (g.split_k > 1 ? g.split_k : 1) < 4 * n_cu && !inplace) bt = 64;
   }
-  if (g_bk_override == 128 || g_bk_override == 64) bt = inplace ? 128 : g_bk_override;
   if (g.kmode == 1 || g.kmode == 2) bt = 128;   // the block-diagonal modes are defined on 128-wide blocks
   {
     // the pipelined kernel with mixed tile sizes (see TileMap): whole rounds of 128-tiles, the rest as quadrants
     static const int mix_mode = mln_experiment("MELLON_AMD_GEMM_MIX") ? std::atoi(mln_experiment("MELLON_AMD_GEMM_MIX")) : 1;
-    if (g_mix_override != 0 && mix_mode > 0 && !inplace && g_bk_override < 0) {
+    if (g_mix_override != 0 && mix_mode > 0 && !inplace) {
       int rc = launch_dgemm_mix(ctx, g, mix_mode, g_mix_override == 1);
       if (rc != MLN_ERR_UNSUPPORTED) return rc;
     }

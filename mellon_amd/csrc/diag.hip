@@ -90,14 +90,12 @@ extern "C" int mln_diag_peak(mln_ctx* ctx, int32_t what, int64_t bytes, double* 
   return MLN_OK;
 }
 
-void dgemm_set_bk(int bk);
 
 // Times C = op(A) op(B) on random-free (zero-initialised + diagonal) device data; returns ms per call.
 extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, int64_t N, int64_t K,
                               int32_t lower_only, int32_t split_k, int32_t reps, double* ms_out) {
   if (!ctx || !ms_out || M < 1 || N < 1 || K < 1 || reps < 1) return MLN_ERR_ARG;
   MLN_HIP(ctx, hipSetDevice(ctx->device));
-  if (const char* e = mln_experiment("MELLON_AMD_GEMM_BK")) dgemm_set_bk(std::atoi(e));
   const int64_t lda = ((ta ? M : K) + 15) / 16 * 16, ldb = ((tb ? K : N) + 15) / 16 * 16, ldc = (N + 15) / 16 * 16;
   const size_t a_bytes = sizeof(double) * (size_t)(ta ? K : M) * lda, b_bytes = sizeof(double) * (size_t)(tb ? N : K) * ldb;
   const int split = split_k > 1 ? split_k : 1;
@@ -116,7 +114,7 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
     MLN_HIP(ctx, hipMemcpyAsync((char*)B + off, pat.data(), std::min(pat.size() * 8, b_bytes - off), hipMemcpyHostToDevice, ctx->stream));
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = Cm; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
-  g.alpha = 1.0; g.beta = mln_experiment("MELLON_AMD_DIAG_BETA") ? std::atof(mln_experiment("MELLON_AMD_DIAG_BETA")) : 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
+  g.alpha = 1.0; g.beta = 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
   g.c_split_stride = (int64_t)M * ldc;
   if (const char* e = mln_experiment("MELLON_AMD_DIAG_KMODE")) g.kmode = std::atoi(e);   // triangular K ranges (probes)
   hipEvent_t e0, e1;

@@ -332,7 +332,6 @@ int dev_eigh(mln_ctx* ctx, const double* A, int64_t m, int64_t lda, double* w_ho
   a.tol = 2.0 * std::sqrt((double)m) * 2.220446049250313e-16 * std::sqrt(fro2);
   a.rotations = d_rot;
   a.max_local = 2;   // measured: 1-3 local sweeps per visit give the same number of outer sweeps
-  if (const char* ev = mln_experiment("MELLON_AMD_EIGH_LOCAL")) a.max_local = atoi(ev);
   const int max_sweeps = 40;
   int sweep = 0;
   bool converged = (fro2 == 0.0);

@@ -567,8 +567,6 @@ template <int CQ, int R, bool VEC = false>
 int launch_f32(mln_ctx* ctx, const ObjArgs& a) {
   const int64_t ld4 = a.ldl / 4;
   int nw = (int)((ld4 + 64 * CQ - 1) / (64 * CQ));
-  static const int force = mln_experiment("MELLON_AMD_OBJ32_WAVES") ? std::atoi(mln_experiment("MELLON_AMD_OBJ32_WAVES")) : 0;
-  if (force >= 6 && force <= 8 && (int64_t)force * 64 * CQ >= ld4) nw = force;
   if (nw <= 6) return launch_f32_nw<CQ, R, 6, VEC>(ctx, a);
   if (nw == 7) return launch_f32_nw<CQ, R, 7, VEC>(ctx, a);
   return launch_f32_nw<CQ, R, 8, VEC>(ctx, a);
@@ -827,22 +825,14 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   else if (a.part_hess) mode = MODE_OBJ_HESS;
   if (a.L32 && (mode == MODE_OBJ || mode == MODE_GEMVT) && a.ldl % 4 == 0) {   // fp32 copy: 4 columns per 16-byte lane load
     const int cq = (int)((a.ldl / 4 + WG - 1) / WG);
-    const char* ev32 = mln_experiment("MELLON_AMD_OBJ_VEC");
-    const bool vec32 = !(ev32 && std::atoi(ev32) == 0) && mode == MODE_OBJ;
+    const bool vec32 = mode == MODE_OBJ;
     switch (cq) {
       case 1: return vec32 ? launch_f32<1, 8, true>(ctx, a) : launch_f32<1, 8>(ctx, a);     // (R = 16 / 8 spill: the widening to
       case 2: return vec32 ? launch_f32<2, 4, true>(ctx, a) : launch_f32<2, 4>(ctx, a);     //  fp64 doubles the registers per element)
-      case 3: {
-        static const int r3 = mln_experiment("MELLON_AMD_OBJ32_ROWS") ? std::atoi(mln_experiment("MELLON_AMD_OBJ32_ROWS")) : 3;
+      case 3:
         // row-per-lane likelihood (see process_rows): m = 5000, 7 waves: <3, 2, VEC> 2.93 ms per pass = 0.855 of the HBM
         // spec against 3.19 ms = 0.786 for the plain <3, 3>; <3, 4, VEC> 3.16 ms
-        if (vec32 && !mln_experiment("MELLON_AMD_OBJ32_ROWS")) return launch_f32<3, 2, true>(ctx, a);
-        if (r3 == 4) return launch_f32<3, 4>(ctx, a);
-        if (r3 == 5) return launch_f32<3, 5>(ctx, a);
-        if (r3 == 2) return launch_f32<3, 2>(ctx, a);
-        if (r3 == 1) return launch_f32<3, 1>(ctx, a);
-        return launch_f32<3, 3>(ctx, a);
-      }
+        return vec32 ? launch_f32<3, 2, true>(ctx, a) : launch_f32<3, 3>(ctx, a);
       default: return launch_f32<4, 2>(ctx, a);
     }
   }
@@ -850,10 +840,8 @@ int launch_objective(mln_ctx* ctx, const ObjArgs& a) {
   const int64_t pairs = a.seg_cols > 0 ? (a.seg_cols + 1) / 2 : a.ldl / 2;
   const int cpt = (int)((pairs + WG - 1) / WG);
   // rows per step chosen so that one register set holds <= 12 double2 per thread
-  // (few column pairs per thread: the row-per-lane likelihood with more rows per barrier, see process_rows;
-  //  MELLON_AMD_OBJ_VEC=0 selects the plain variants)
-  const char* ev = mln_experiment("MELLON_AMD_OBJ_VEC");
-  const bool vec = !(ev && std::atoi(ev) == 0) && (mode == MODE_OBJ || mode == MODE_OBJ_HESS);
+  // (few column pairs per thread: the row-per-lane likelihood with more rows per barrier, see process_rows)
+  const bool vec = mode == MODE_OBJ || mode == MODE_OBJ_HESS;
   switch (cpt) {
     case 1: return vec ? launch_mode<1, 8, true>(ctx, a, mode) : launch_mode<1, 8>(ctx, a, mode);     // (R = 16 spills)
     case 2: return vec ? launch_mode<2, 8, true>(ctx, a, mode) : launch_mode<2, 5>(ctx, a, mode);

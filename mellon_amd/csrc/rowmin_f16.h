@@ -18,8 +18,7 @@ int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* spli
 // picks the closest in fp64)
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
                         int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold,
-                        const int* row_idx = nullptr,    // row_idx (optional, device): query row r is row row_idx[r] of xs
-                        int hi_only = 0);                // fold + m2 only: the hi.hi product alone (values to ~2^-9 |x||y|)
+                        const int* row_idx = nullptr);   // row_idx (optional, device): query row r is row row_idx[r] of xs
 int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg);
 // k-means with bounds: label, upper and lower bound of the searched rows from a (TOP2, fold) sweep's m2 / arg (see the kernel)
 int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,

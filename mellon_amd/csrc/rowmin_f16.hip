@@ -121,9 +121,7 @@ __global__ void k_max_norm(const double* __restrict__ xx, int64_t n, double* __r
 // VALU instructions per element (v_med3_f32 keeps the runner-up, v_min_f32 the winner).  With TOP2 the winner's column is
 // then only known per STAGE of 128 candidates and lane: out_arg = the stage's first candidate of that lane, the winner is
 // one of out_arg + {0, 32, 64, 96}; without TOP2 (labels) the exact column is tracked (three instructions per element).  (With the full 7-instruction epilogue the sweep took 510 ms at 1e6 x 1e6: VALU-bound.)
-// HI_ONLY (FOLD): only the hi.hi product -- a third of the matrix work, values good to ~2^-9 |x||y| instead of ~2^-18: the
-// first sweep of the 1-NN search, which certifies the rows whose runner-up is further away than THAT (most of them).
-template <bool TOP2, bool FOLD, bool HI_ONLY = false>
+template <bool TOP2, bool FOLD>
 __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict__ Xs, int64_t n,
                                                       const _Float16* __restrict__ Ys, int64_t m,
                                                       const float* __restrict__ yyf, int64_t self_offset, int exclude_self,
@@ -202,14 +200,12 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
         for (int ks = 0; ks < 4; ++ks) {
           bhi0[ks] = *reinterpret_cast<const h8*>(brow0 + 32 * ks);
           bhi1[ks] = *reinterpret_cast<const h8*>(brow1 + 32 * ks);
-          if (!HI_ONLY) {
-            const h8 blo0 = *reinterpret_cast<const h8*>(brow0 + 2 * KP + 32 * ks);
-            const h8 blo1 = *reinterpret_cast<const h8*>(brow1 + 2 * KP + 32 * ks);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo1, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi0[ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi1[ks], acc[1], 0, 0, 0);
-          }
+          const h8 blo0 = *reinterpret_cast<const h8*>(brow0 + 2 * KP + 32 * ks);
+          const h8 blo1 = *reinterpret_cast<const h8*>(brow1 + 2 * KP + 32 * ks);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo0, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo1, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi0[ks], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi1[ks], acc[1], 0, 0, 0);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -322,16 +318,6 @@ __device__ __forceinline__ double rowmin_value_bound(double xn, double yn) {
                  4.0 * u * mag + 64.0 * u * 2.0 * (2.0 * xn + yn) + 1e-300);
 }
 
-// The same for the hi.hi product alone (k_rowmin_f16x3 HI_ONLY): both operands rounded to half precision, relative 2^-11
-// each, on every term of -2 x.y: 2^-10 (1 + 2^-12) 2 |x| |y| by Cauchy-Schwarz; |y|^2 still travels as three halves; the
-// fp32 accumulation and the subnormal terms as above.
-__device__ __forceinline__ double rowmin_value_bound_hi(double xn, double yn) {
-  const double u = 5.9604644775390625e-08;   // 2^-24
-  const double mag = 2.0 * xn * yn + yn * yn;
-  return 1.25 * (9.765625e-04 * 1.000244140625 * 2.0 * xn * yn + 80.0 * u * mag + 4.0 * u * mag +
-                 64.0 * u * 2.0 * (2.0 * xn + yn) + 1e-300);
-}
-
 // Exact fp64 value of the winner, certification against the runner-up, list of the rows that need the exact search.
 //   s_j = |y_j|^2 - 2 x.y_j (exact);  |s~_j - s_j| <= E_i for every j  =>  j* != arg implies s_{j*} >= m2~ - E_i.
 // fold: the winner is one of arg + {0, 32, 64, 96} (k_rowmin_f16x3 FOLD): all four are evaluated exactly.
@@ -341,7 +327,7 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
                                                     const double* __restrict__ yy_max, int fold, int64_t self_offset,
                                                     const double* __restrict__ prep,
                                                     double* __restrict__ out, int* __restrict__ n_flag, int* __restrict__ flagged,
-                                                    float* __restrict__ fthr, double* __restrict__ fdd, int hi_only) {
+                                                    float* __restrict__ fthr, double* __restrict__ fdd) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   // everything the sweep saw is (x - centre) * scale: xx, yy, m2 and the bound E live in those units; the winner's value
@@ -362,9 +348,8 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
   // fp32.  Dropped terms of the split: 2^-19 of 2 |x| |y|; fp32 accumulation: <= 17 roundings per MFMA x 4 MFMAs + slack
   // = 80 u on the magnitudes of the hi.hi terms (2 |x| |y| + |y|^2), 160 u on the 2^-10 smaller cross terms; |y|^2 in
   // fp32 (plain) or as three halves (fold); half-precision subnormals of tiny coordinates (2^-24 each, 64 of them).
-  const double E = rowmin_value_bound(xn, yn);                                  // of the three-product values (the list sweep's)
-  const double Ec = hi_only ? rowmin_value_bound_hi(xn, yn) : E;              // of the values THIS sweep compared
-  const bool certified = ((double)m2[i] - Ec) > s;
+  const double E = rowmin_value_bound(xn, yn);
+  const bool certified = ((double)m2[i] - E) > s;
   // reported: the winner's distance from its coordinates (sum (x_k - y_k)^2), not from the cancelling |x|^2 - 2 x.y + |y|^2:
   // exact 0 for a duplicated cell, relative error ~eps otherwise (see nn_direct_distance in cov_kernels.hip)
   double dd = INFINITY;
@@ -653,24 +638,21 @@ int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* spli
 }
 
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
-                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold, const int* row_idx,
-                        int hi_only) {
+                        int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold, const int* row_idx) {
   if (n <= 0 || m <= 0) return MLN_OK;
   if (m > 2147483647LL) { mln_set_error(ctx, "rowmin: too many candidates"); return MLN_ERR_UNSUPPORTED; }
   const size_t lds_bytes = (size_t)2 * RT * PITCH + 2 * RT * sizeof(float);
   static bool attr = false;
   if (!attr) {
     const void* fns[] = {reinterpret_cast<const void*>(k_rowmin_f16x3<true, false>), reinterpret_cast<const void*>(k_rowmin_f16x3<false, false>),
-                         reinterpret_cast<const void*>(k_rowmin_f16x3<true, true>), reinterpret_cast<const void*>(k_rowmin_f16x3<false, true>),
-                         reinterpret_cast<const void*>(k_rowmin_f16x3<true, true, true>)};
+                         reinterpret_cast<const void*>(k_rowmin_f16x3<true, true>), reinterpret_cast<const void*>(k_rowmin_f16x3<false, true>)};
     for (const void* fn : fns) MLN_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr = true;
   }
   const dim3 grid((unsigned)((n + 255) / 256)), block(512);
   const _Float16* X = reinterpret_cast<const _Float16*>(xs);
   const _Float16* Y = reinterpret_cast<const _Float16*>(ys);
-  if (m2 && fold && hi_only) hipLaunchKernelGGL((k_rowmin_f16x3<true, true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
-  else if (m2 && fold) hipLaunchKernelGGL((k_rowmin_f16x3<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
+  if (m2 && fold) hipLaunchKernelGGL((k_rowmin_f16x3<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
   else if (m2) hipLaunchKernelGGL((k_rowmin_f16x3<true, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
   else if (fold) hipLaunchKernelGGL((k_rowmin_f16x3<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
   else hipLaunchKernelGGL((k_rowmin_f16x3<false, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
@@ -745,28 +727,19 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
     mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP);
   }
   const bool list_ok = !(mln_experiment("MELLON_AMD_NN_LIST") && std::atoi(mln_experiment("MELLON_AMD_NN_LIST")) == 0);
-  // MEASURED AND OFF (MELLON_AMD_NN_HI_ONLY=1 turns it on): a first sweep with the hi.hi product alone -- a third of the
-  // matrix work, values to 2^-9 |x||y| instead of 2^-18 -- that certifies the rows whose runner-up is further than that from
-  // the winner and sends the rest to the candidate list.  At C3 (1e6 x 50) it leaves 55 % of the rows open (in 50 dimensions
-  // the gap to the second neighbour is a few per cent of |x||y|) and takes 249 ms against the three-product sweep's 360 --
-  // its epilogue, two VALU instructions per element, is as long as its MFMAs -- so the fallback below runs almost always:
-  // 0.65 s instead of 0.40 s.  (When it leaves more than 30 % open the three-product sweep runs over all rows after all.)
-  int hi_only = (fold && list_ok && mln_experiment("MELLON_AMD_NN_HI_ONLY") && std::atoi(mln_experiment("MELLON_AMD_NN_HI_ONLY")) != 0) ? 1 : 0;
+  // (Measured and taken out, round 5: a first sweep with the hi.hi product alone -- a third of the matrix work, values to
+  //  2^-9 |x||y| instead of 2^-18.  At C3 it left 55 % of the rows open -- in 50 dimensions the gap to the second neighbour
+  //  is a few per cent of |x||y| -- and took 249 ms against the three-product sweep's 360: its two-instruction epilogue is
+  //  as long as its MFMAs.)
   int cnt = 0;
-  for (;;) {
-    if (hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
-    rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr, hi_only);
-    if (rc != MLN_OK) return cleanup(rc);
-    hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
-                       ymax, fold, self_offset, prep, out, nflag, flagged, fthr, fdd, hi_only);
-    if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
-    if (stats) stats[2] = (double)(hi_only ? cnt : -1);
-    if (std::getenv("MELLON_AMD_TRACE"))
-      std::fprintf(stderr, "[trace] nn_distances: %s sweep left %d of %lld rows open\n", hi_only ? "hi.hi" : "three-product", cnt, (long long)n);
-    if (!hi_only || (int64_t)cnt * 10 <= (int64_t)n * 3) break;
-    hi_only = 0;
-  }
+  rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr);
+  if (rc != MLN_OK) return cleanup(rc);
+  hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
+                     ymax, fold, self_offset, prep, out, nflag, flagged, fthr, fdd);
+  if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
+  if (std::getenv("MELLON_AMD_TRACE"))
+    std::fprintf(stderr, "[trace] nn_distances: the sweep left %d of %lld rows open\n", cnt, (long long)n);
   if (stats) stats[0] = (double)cnt;
   // The open rows: a second fp16 sweep that LISTS the candidates below each row's threshold, exact distances of the listed
   // pairs.  A list that outgrows its buffer (masses of exact duplicates) falls through to the exact search below.
