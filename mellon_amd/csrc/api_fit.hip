@@ -65,15 +65,14 @@ int fit_alloc_workspace(mln_fit* f) {
   return MLN_OK;
 }
 
-// Upload of the cells from pageable host memory in row chunks by a helper thread (see fit_prepare_impl).
-// MEASURED (round 4, C3, host-to-host step minus the step with resident cells): one plain copy before everything else
-// +13.6 ms; THIS (chunks copied by a helper thread with hipMemcpyAsync from the pageable array, each chunk's kernel-matrix
-// pass waiting for its event) +10.9 ms; a pool of pinned staging buffers filled by eight memcpy threads and sent on by
-// DMA from pinned memory +20 ms (the box's host memcpy is the bottleneck).  The runtime's pageable path does not run
-// next to kernels the way a pinned DMA does; the honest figure is that ~11 ms of the 0.4 GB upload stay exposed.  A copy from
-// pageable memory blocks its CALLING thread while the runtime stages it through pinned buffers, but not the device: the
-// chunks travel while the main thread's kernels run.  Chunk c is complete on the device when events[c] has fired; the
-// main thread makes its stream wait for that event -- after the helper has recorded it (done > c).
+// Upload of the cells from host memory in row chunks UNDER the kernel-matrix pass (see fit_prepare_impl).
+// History (C3, host-to-host step minus the step with resident cells): one plain copy before everything else +13.6 ms; sixteen
+// equal chunks copied by a helper thread, each chunk's pass waiting for its event +10.9 ms (round 4); a pool of pinned staging
+// buffers filled by eight memcpy threads +20 ms; page-locked source (mln_host_register), copies enqueued by the calling thread
+// +6.8 ms (round 5); growing chunks (below) take the pass's own share of that from +2.0 to +0.8 ms.
+// A copy from pageable memory blocks its CALLING thread while the runtime stages it, but not the device: a helper thread
+// issues those.  Chunk c is complete on the device when events[c] has fired; the main thread makes its stream wait for that
+// event -- after it has been recorded (done > c).
 struct HostUpload {
   mln_ctx* ctx = nullptr;
   hipStream_t copy = nullptr;
@@ -82,14 +81,28 @@ struct HostUpload {
   std::atomic<int> failed{0};
   std::thread th;
   int n_chunks = 0;
-  int64_t n = 0, chunk_rows = 0;
+  int64_t n = 0;
+  std::vector<int64_t> row0;     // chunk c = rows [row0[c], row0[c + 1])
   int d = 0;
   int start(mln_ctx* c, const double* src, double* dst, int64_t n_, int d_) {
     ctx = c; n = n_; d = d_;
-    // chunks of whole 128-row workgroup tiles, ~64 MB each, at most 16
-    chunk_rows = std::max<int64_t>(128, (((int64_t)64 << 20) / ((int64_t)d * 8) + 127) / 128 * 128);
-    if ((n + chunk_rows - 1) / chunk_rows > 16) chunk_rows = ((n + 15) / 16 + 127) / 128 * 128;
-    n_chunks = (int)((n + chunk_rows - 1) / chunk_rows);
+    // Chunks of whole 128-row workgroup tiles, GROWING: 1/32, 1/32, 1/16, 1/8, 1/4 of the cells and the rest.  The copy
+    // (56 GB/s measured, pageable or page-locked: tools/h2d_probe.py) delivers a cell 2.3x faster than the kernel-matrix
+    // pass consumes it, so after the first chunk (0.2 ms at C3) every chunk is there before the pass of the one before it
+    // ends -- and six launches have six tails where round 4's sixteen equal chunks had sixteen (each launch ends with CUs
+    // idling behind its slowest workgroups: +2.0 ms on the pass at C3).
+    {
+      const int64_t tiles = (n + 127) / 128;
+      int64_t size = std::max<int64_t>(1, tiles / 32), at = 0;
+      row0.assign(1, 0);
+      for (int k = 0; at < tiles; ++k) {
+        const int64_t take = (tiles - at <= 2 * size || k >= 14) ? tiles - at : size;   // the rest once it is within two steps
+        at += take;
+        row0.push_back(std::min(n, at * 128));
+        if (k >= 1) size *= 2;
+      }
+      n_chunks = (int)row0.size() - 1;
+    }
     MLN_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
     events.resize((size_t)n_chunks, nullptr);
     for (auto& e : events) MLN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -101,7 +114,7 @@ struct HostUpload {
       if (!pinned_src) (void)hipGetLastError();
       if (pinned_src) {
         for (int c = 0; c < n_chunks; ++c) {
-          const int64_t r0 = (int64_t)c * chunk_rows, rows = std::min(chunk_rows, n - r0);
+          const int64_t r0 = row0[(size_t)c], rows = row0[(size_t)c + 1] - r0;
           MLN_HIP(ctx, hipMemcpyAsync(dst + r0 * d, src + r0 * d, sizeof(double) * (size_t)(rows * d), hipMemcpyHostToDevice, copy));
           MLN_HIP(ctx, hipEventRecord(events[(size_t)c], copy));
         }
@@ -113,7 +126,7 @@ struct HostUpload {
     th = std::thread([this, src, dst, device] {
       if (hipSetDevice(device) != hipSuccess) { failed.store(1); done.store(n_chunks); return; }
       for (int c = 0; c < n_chunks; ++c) {
-        const int64_t r0 = (int64_t)c * chunk_rows, rows = std::min(chunk_rows, n - r0);
+        const int64_t r0 = row0[(size_t)c], rows = row0[(size_t)c + 1] - r0;
         hipError_t e = hipMemcpyAsync(dst + r0 * d, src + r0 * d, sizeof(double) * (size_t)(rows * d), hipMemcpyHostToDevice, copy);
         if (e == hipSuccess) e = hipEventRecord(events[(size_t)c], copy);
         if (e != hipSuccess) { failed.store(1); done.store(n_chunks, std::memory_order_release); return; }
@@ -126,8 +139,8 @@ struct HostUpload {
     while (done.load(std::memory_order_acquire) <= c) std::this_thread::yield();
     if (failed.load()) { mln_set_error(ctx, "upload of the cells failed (helper thread)"); return MLN_ERR_HIP; }
     MLN_HIP(ctx, hipStreamWaitEvent(ctx->stream, events[(size_t)c], 0));
-    *r0 = (int64_t)c * chunk_rows;
-    *rows = std::min(chunk_rows, n - *r0);
+    *r0 = row0[(size_t)c];
+    *rows = row0[(size_t)c + 1] - *r0;
     return MLN_OK;
   }
   int finish() {

@@ -12,6 +12,8 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "device"
 def run(xin):
     est = mellon_amd.DensityEstimator(landmarks=lm, nn_distances=nn, check_rank=False)
     out = est.fit_predict(xin)
+    global last_stages
+    last_stages = est._fit.stage_times()
     est._fit.close()
     return out
 def go(xin):
@@ -19,6 +21,7 @@ def go(xin):
     t0 = time.perf_counter(); run(xin); print(mode, "step ms", 1e3 * (time.perf_counter() - t0))
     pr = cProfile.Profile(); pr.enable(); run(xin); pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+    print({k: round(1e3 * v, 2) for k, v in last_stages.items() if k.endswith("_s")})
 if mode == "device": go(xd)
 elif mode == "host": go(x)
 else:
