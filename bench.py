@@ -440,7 +440,7 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=330.0, help="wall-clock budget of the default CPU baseline")
     ap.add_argument("--cpu-sample-full", action="store_true",
                     help="SURVEY S8(d) sizes: 2.5e5 and 5e5 cells (needs ~60 GB of host RAM and ~15 min)")
-    ap.add_argument("--extra-steps", type=int, default=2, help="steps of the mixed-precision and host-to-host measurements")
+    ap.add_argument("--extra-steps", type=int, default=4, help="steps of the mixed-precision and host-to-host measurements")
     ap.add_argument("--pmc", action="store_true",
                     help="re-measure roofline.traffic in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) of one "
                          "fp64 step, ~1 min each; without it the committed profiles/objective_traffic.json is quoted")

@@ -84,7 +84,7 @@ def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_s
     """k-means centroids (reference parameters.py:243-291).  backend "sklearn" is the reference's
     own call (bit-identical landmarks); "hip" is k-means++ / Lloyd on the device (mln_kmeans: same
     algorithm family; its seeding is the library's own or, with KMEANS_DEVICE_INIT = "sklearn", sklearn's); None picks "hip" when n * n_landmarks exceeds
-    KMEANS_DEVICE_THRESHOLD (where sklearn takes minutes) and d <= 64.  x may be HBM-resident (a DeviceArray: "hip" only);
+    KMEANS_DEVICE_THRESHOLD (where sklearn takes minutes) and d <= 64.  x may be HBM-resident (a DeviceArray);
     ctx: the device context to run on (default: the calling thread's)."""
     if n_landmarks == 0:
         return None
@@ -98,7 +98,7 @@ def compute_landmarks(x, gp_type=None, n_landmarks=DEFAULT_N_LANDMARKS, random_s
             return x
         return None
     if backend is None:
-        backend = "hip" if on_device else landmarks_backend(n, x.shape[1], n_landmarks)
+        backend = landmarks_backend(n, x.shape[1], n_landmarks)      # (HBM-resident cells follow the same rule: sklearn gets a host copy)
     logger.info(f"Computing {n_landmarks:,} landmarks with k-means clustering "
                 f"(random_state={random_state}, backend={backend}).")
     if backend == "hip":
