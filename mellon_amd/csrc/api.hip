@@ -121,11 +121,14 @@ extern "C" int mln_ctx_create(int device, mln_ctx** out) {
   return MLN_OK;
 }
 
+void fit_release_copy_lane(mln_ctx* ctx);   // api_fit.hip: the context's copy stream and events
+
 extern "C" void mln_ctx_destroy(mln_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   comm_release(ctx);
+  fit_release_copy_lane(ctx);
   if (ctx->scratch) (void)mln_dfree(ctx->scratch);
   if (ctx->d_info) (void)mln_dfree(ctx->d_info);
   (void)hipStreamDestroy(ctx->stream);

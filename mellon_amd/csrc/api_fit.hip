@@ -1,6 +1,8 @@
 // C ABI, part 2: the fit handle (see api_internal.h for the map of the api*.hip files).
 #include "api_internal.h"
 #include "mln_options.h"
+#include <mutex>
+#include <unordered_map>
 
 // rows of this shard in the subsample of stride s: first local index and count
 void fit_sample_rows(const mln_fit* f, int64_t s, int64_t* first, int64_t* rows) {
@@ -73,6 +75,38 @@ int fit_alloc_workspace(mln_fit* f) {
 // A copy from pageable memory blocks its CALLING thread while the runtime stages it, but not the device: a helper thread
 // issues those.  Chunk c is complete on the device when events[c] has fired; the main thread makes its stream wait for that
 // event -- after it has been recorded (done > c).
+// The copy stream and its events live as long as the context (created by the first upload, released by mln_ctx_destroy):
+// hipStreamCreate alone costs ~3 ms, which every host-to-host fit paid before the first chunk was even enqueued
+// (MELLON_AMD_TRACE: "upload started at 0.0031 s").
+namespace {
+struct CopyLane { hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
+std::mutex g_copy_mu;
+std::unordered_map<mln_ctx*, CopyLane> g_copy_lanes;
+}  // namespace
+
+static int copy_lane_get(mln_ctx* ctx, int n_events, hipStream_t* stream, std::vector<hipEvent_t>* events) {
+  std::lock_guard<std::mutex> lk(g_copy_mu);
+  CopyLane& lane = g_copy_lanes[ctx];
+  if (!lane.stream) MLN_HIP(ctx, hipStreamCreateWithFlags(&lane.stream, hipStreamNonBlocking));
+  while ((int)lane.events.size() < n_events) {
+    hipEvent_t e = nullptr;
+    MLN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    lane.events.push_back(e);
+  }
+  *stream = lane.stream;
+  events->assign(lane.events.begin(), lane.events.begin() + n_events);
+  return MLN_OK;
+}
+
+void fit_release_copy_lane(mln_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_copy_mu);
+  auto it = g_copy_lanes.find(ctx);
+  if (it == g_copy_lanes.end()) return;
+  if (it->second.stream) { (void)hipStreamSynchronize(it->second.stream); (void)hipStreamDestroy(it->second.stream); }
+  for (hipEvent_t e : it->second.events) if (e) (void)hipEventDestroy(e);
+  g_copy_lanes.erase(it);
+}
+
 struct HostUpload {
   mln_ctx* ctx = nullptr;
   hipStream_t copy = nullptr;
@@ -103,9 +137,7 @@ struct HostUpload {
       }
       n_chunks = (int)row0.size() - 1;
     }
-    MLN_HIP(ctx, hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-    events.resize((size_t)n_chunks, nullptr);
-    for (auto& e : events) MLN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    MLN_TRY(copy_lane_get(ctx, n_chunks, &copy, &events));     // (the context's own: not created or destroyed per fit)
     // a page-locked source (mln_host_register): the copies are DMA transfers the runtime queues without blocking -- all of
     // them are enqueued here, by the calling thread, and run under whatever the main stream does meanwhile
     {
@@ -149,8 +181,7 @@ struct HostUpload {
   }
   ~HostUpload() {
     if (th.joinable()) th.join();
-    if (copy) { (void)hipStreamSynchronize(copy); (void)hipStreamDestroy(copy); }
-    for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
+    if (copy) (void)hipStreamSynchronize(copy);
   }
 };
 
@@ -192,6 +223,8 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
                             const double* xu, int64_t m, double jitter, const double* Lp_in, int32_t flags,
                             mln_fit* f) {
   f->ctx = ctx;
+  const double t_enter = now_s();
+  const bool trace_all = std::getenv("MELLON_AMD_TRACE") != nullptr;
   MLN_TRY(mln_lower_cov(ctx, cov, d, &f->cov));
   f->d = d; f->n = n; f->full = (xu == nullptr);
   if (f->full) m = n;
@@ -213,6 +246,7 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     MLN_HIP(ctx, mln_dmalloc((void**)&dx.owned, (size_t)n * d * sizeof(double)));
     dx.dev = dx.owned;
     MLN_TRY(up.start(ctx, x, dx.owned, n, d));
+    if (trace_all) fprintf(stderr, "[trace] fit_prepare: upload started at %.4f s (%d chunks)\n", now_s() - t_enter, up.n_chunks);
   } else {
     MLN_TRY(dx.init(ctx, x, (size_t)n * d));
   }
@@ -319,6 +353,7 @@ int fit_prepare_impl(mln_ctx* ctx, const mln_kernel_desc* cov, const double* x, 
     }
   }
   if (!f->d_u) MLN_TRY(fit_alloc_workspace(f));
+  if (trace_all) fprintf(stderr, "[trace] fit_prepare: body done at %.4f s\n", now_s() - t_enter);
   return MLN_OK;
 }
 
@@ -330,7 +365,9 @@ extern "C" int mln_fit_prepare(mln_ctx* ctx, const mln_kernel_desc* cov, const d
   if (n_local < 0 || d < 1 || (n_local > 0 && !x)) { mln_set_error(ctx, "bad shape"); return MLN_ERR_SHAPE; }
   MLN_HIP(ctx, hipSetDevice(ctx->device));
   mln_fit* f = new mln_fit();
+  const double t_call = now_s();
   int rc = fit_prepare_impl(ctx, cov, x, n_local, d, xu, m, jitter, Lp_in, flags, f);
+  if (std::getenv("MELLON_AMD_TRACE")) fprintf(stderr, "[trace] mln_fit_prepare: %.4f s with the upload's teardown\n", now_s() - t_call);
   if (rc != MLN_OK) { fit_free(f); return rc; }
   *out = f;
   return MLN_OK;
