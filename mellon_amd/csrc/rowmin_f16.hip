@@ -116,6 +116,17 @@ __global__ void k_max_norm(const double* __restrict__ xx, int64_t n, double* __r
   if (threadIdx.x == 0) out[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+// min of two floats as ONE v_min_f32.  fminf() is llvm.minnum, and in IEEE mode the compiler has to quiet a possible
+// signalling NaN first: a v_max_f32 x, x in front of every operand it cannot prove clean -- here the MFMA accumulator of
+// every element and the running minimum, i.e. four vector instructions per element where the epilogue is meant to be two
+// (round 5, counters: 5.5 vector instructions per element, matrix cores busy 0.48 of the sweep).  The hardware instruction
+// itself returns the other operand for a quiet NaN, which is all an MFMA can produce.
+__device__ __forceinline__ float vmin_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // TOP2: also the second-smallest value per row (1-NN certification); else only the arg of the smallest (k-means labels).
 // FOLD: the operands carry -2 and |y|^2 (k_split_f16 roles 1 / 2): the accumulator IS the value, and the epilogue is two
 // VALU instructions per element (v_med3_f32 keeps the runner-up, v_min_f32 the winner).  With TOP2 the winner's column is
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
             for (int r = 0; r < 16; ++r) {
               if (TOP2) m2[r] = __builtin_amdgcn_fmed3f(m1[r], m2[r], acc[h][r]);
               else a1[r] = (acc[h][r] < m1[r]) ? col : a1[r];          // (labels: the exact column, three instructions)
-              m1[r] = fminf(m1[r], acc[h][r]);
+              m1[r] = vmin_raw(m1[r], acc[h][r]);
             }
           } else {
             const bool valid = col < m;                            // (a padded candidate row is all zero: value 0)
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
               const float sv = (valid && !(exclude_self && (int64_t)col == row + self_offset)) ? acc[h][r] : INFINITY;
               if (TOP2) m2[r] = __builtin_amdgcn_fmed3f(m1[r], m2[r], sv);
               else a1[r] = (sv < m1[r]) ? col : a1[r];
-              m1[r] = fminf(m1[r], sv);
+              m1[r] = vmin_raw(m1[r], sv);
             }
           }
         }
