@@ -119,7 +119,7 @@ __global__ void k_max_norm(const double* __restrict__ xx, int64_t n, double* __r
 // min of two floats as ONE v_min_f32.  fminf() is llvm.minnum, and in IEEE mode the compiler has to quiet a possible
 // signalling NaN first: a v_max_f32 x, x in front of every operand it cannot prove clean -- here the MFMA accumulator of
 // every element and the running minimum, i.e. four vector instructions per element where the epilogue is meant to be two
-// (round 5, counters: 5.5 vector instructions per element, matrix cores busy 0.48 of the sweep).  The hardware instruction
+// (round 5, counters: 5.5 vector instructions per element, matrix cores busy 0.48 of the sweep; worth 3 % of the sweep).  The hardware instruction
 // itself returns the other operand for a quiet NaN, which is all an MFMA can produce.
 __device__ __forceinline__ float vmin_raw(float a, float b) {
   float r;
