@@ -97,6 +97,44 @@ hipError_t release_block(void* p) {
 }
 }  // namespace
 
+// ---- page-locked host blocks (a fit's mirrors of its m-vectors and of the solver's state) -----------------------------------
+// hipHostMalloc pins pages: 0.1-1 ms normally, tens of milliseconds when the kernel has to compact memory first -- per fit,
+// three times.  Freed blocks are kept and handed back to requests of the same size (a process fits the same m again and again).
+namespace {
+std::mutex g_hmu;
+std::unordered_map<void*, size_t> g_hlive;
+std::multimap<size_t, void*> g_hfree;
+}  // namespace
+
+hipError_t mln_hmalloc(void** out, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  {
+    std::lock_guard<std::mutex> lk(g_hmu);
+    auto it = g_hfree.find(bytes);
+    if (g_enabled && it != g_hfree.end()) {
+      *out = it->second;
+      g_hlive[*out] = bytes;
+      g_hfree.erase(it);
+      return hipSuccess;
+    }
+  }
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_hmu); g_hlive[*out] = bytes; }
+  return e;
+}
+
+hipError_t mln_hfree(void* p) {
+  if (!p) return hipSuccess;
+  std::lock_guard<std::mutex> lk(g_hmu);
+  auto it = g_hlive.find(p);
+  if (it == g_hlive.end()) return hipHostFree(p);
+  const size_t bytes = it->second;
+  g_hlive.erase(it);
+  if (!g_enabled || g_hfree.size() >= 64) return hipHostFree(p);     // (a bounded pool: 64 blocks of m-vector size)
+  g_hfree.insert({bytes, p});
+  return hipSuccess;
+}
+
 void mln_dcache_flush() {
   std::lock_guard<std::mutex> lk(g_mu);
   flush_locked();

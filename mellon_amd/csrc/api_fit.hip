@@ -24,10 +24,10 @@ void fit_free(mln_fit* f) {
                   f->Q1, f->Q2, f->d_zw, f->d_zr, f->eigU, f->L32, f->sv_block, f->f_keep[0], f->f_keep[1], f->Kj, f->d_over};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   for (double* p : f->saved_precond) if (p) (void)mln_dfree(p);
-  if (f->h_state) (void)hipHostFree(f->h_state);
+  if (f->h_state) (void)mln_hfree(f->h_state);
   for (hipEvent_t e : f->evs) (void)hipEventDestroy(e);
-  if (f->h_z) (void)hipHostFree(f->h_z);
-  if (f->h_out) (void)hipHostFree(f->h_out);
+  if (f->h_z) (void)mln_hfree(f->h_z);
+  if (f->h_out) (void)mln_hfree(f->h_out);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
   if (f->ev1) (void)hipEventDestroy(f->ev1);
   delete f;
@@ -60,8 +60,8 @@ int fit_alloc_workspace(mln_fit* f) {
   MLN_HIP(ctx, mln_dmalloc((void**)&f->part_loss, sizeof(double) * n_wg));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_z, sizeof(double) * pm));
   MLN_HIP(ctx, mln_dmalloc((void**)&f->d_out, sizeof(double) * (1 + 2 * pm)));
-  MLN_HIP(ctx, hipHostMalloc((void**)&f->h_z, sizeof(double) * pm, hipHostMallocDefault));
-  MLN_HIP(ctx, hipHostMalloc((void**)&f->h_out, sizeof(double) * (1 + 2 * pm), hipHostMallocDefault));
+  MLN_HIP(ctx, mln_hmalloc((void**)&f->h_z, sizeof(double) * pm));
+  MLN_HIP(ctx, mln_hmalloc((void**)&f->h_out, sizeof(double) * (1 + 2 * pm)));
   MLN_HIP(ctx, hipEventCreate(&f->ev0));
   MLN_HIP(ctx, hipEventCreate(&f->ev1));
   return MLN_OK;

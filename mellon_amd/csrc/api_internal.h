@@ -24,6 +24,9 @@
 #include "precond_rebuild.h"
 #include "solver.h"
 
+hipError_t mln_hmalloc(void** out, size_t bytes);   // alloc.hip: page-locked host blocks, cached by size
+hipError_t mln_hfree(void* p);
+
 void mln_dfree_defer(std::vector<void*>* sink);   // alloc.hip: frees of the calling thread are collected instead of performed
 bool is_device_ptr(const void* p);
 double now_s();

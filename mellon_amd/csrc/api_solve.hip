@@ -253,7 +253,7 @@ int fit_solver_alloc(mln_fit* f, int maxcor) {
   b.lik = f->d_zr + f->ld2 + f->m;
   b.over = f->d_zr + f->ld2 + f->m + 1;
   f->sv_maxcor = maxcor;
-  if (!f->h_state) MLN_HIP(ctx, hipHostMalloc((void**)&f->h_state, sizeof(SolverState), hipHostMallocDefault));
+  if (!f->h_state) MLN_HIP(ctx, mln_hmalloc((void**)&f->h_state, sizeof(SolverState)));
   return MLN_OK;
 }
 
