@@ -25,7 +25,7 @@ void fit_free(mln_fit* f) {
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   for (double* p : f->saved_precond) if (p) (void)mln_dfree(p);
   if (f->h_state) (void)mln_hfree(f->h_state);
-  for (hipEvent_t e : f->evs) (void)hipEventDestroy(e);
+  fit_events_return(ctx, &f->evs);
   if (f->h_z) (void)mln_hfree(f->h_z);
   if (f->h_out) (void)mln_hfree(f->h_out);
   if (f->ev0) (void)hipEventDestroy(f->ev0);
@@ -98,8 +98,27 @@ static int copy_lane_get(mln_ctx* ctx, int n_events, hipStream_t* stream, std::v
   return MLN_OK;
 }
 
+// The per-evaluation timing events of the device-resident solver (three per evaluation, ~100 per fit) are the context's too:
+// a solve borrows them into its handle and hands them back (fit_free does so for a solve that ended early).
+namespace {
+std::unordered_map<mln_ctx*, std::vector<hipEvent_t>> g_event_pools;
+}  // namespace
+void fit_events_borrow(mln_ctx* ctx, std::vector<hipEvent_t>* evs) {
+  std::lock_guard<std::mutex> lk(g_copy_mu);
+  auto& pool = g_event_pools[ctx];
+  if (evs->empty()) evs->swap(pool);
+}
+void fit_events_return(mln_ctx* ctx, std::vector<hipEvent_t>* evs) {
+  std::lock_guard<std::mutex> lk(g_copy_mu);
+  auto& pool = g_event_pools[ctx];
+  if (pool.empty()) pool.swap(*evs);
+  else { for (hipEvent_t e : *evs) (void)hipEventDestroy(e); evs->clear(); }
+}
+
 void fit_release_copy_lane(mln_ctx* ctx) {
   std::lock_guard<std::mutex> lk(g_copy_mu);
+  auto pe = g_event_pools.find(ctx);
+  if (pe != g_event_pools.end()) { for (hipEvent_t e : pe->second) (void)hipEventDestroy(e); g_event_pools.erase(pe); }
   auto it = g_copy_lanes.find(ctx);
   if (it == g_copy_lanes.end()) return;
   if (it->second.stream) { (void)hipStreamSynchronize(it->second.stream); (void)hipStreamDestroy(it->second.stream); }

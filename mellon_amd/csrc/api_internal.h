@@ -26,6 +26,8 @@
 
 hipError_t mln_hmalloc(void** out, size_t bytes);   // alloc.hip: page-locked host blocks, cached by size
 hipError_t mln_hfree(void* p);
+void fit_events_borrow(mln_ctx* ctx, std::vector<hipEvent_t>* evs);   // api_fit.hip: the context's pool of timing events
+void fit_events_return(mln_ctx* ctx, std::vector<hipEvent_t>* evs);
 
 void mln_dfree_defer(std::vector<void*>* sink);   // alloc.hip: frees of the calling thread are collected instead of performed
 bool is_device_ptr(const void* p);

@@ -269,6 +269,7 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
     return MLN_ERR_UNSUPPORTED;
   }
   MLN_TRY(fit_build_precond(f, 1));
+  fit_events_borrow(ctx, &f->evs);       // (handed back by fit_free, with the handle)
   mln_solver_opts o = {5000, 10, 30, 1e-13, 1e-7};
   if (opts_in) o = *opts_in;
   if (o.maxcor < 1) o.maxcor = 1;
