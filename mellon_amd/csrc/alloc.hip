@@ -102,24 +102,26 @@ hipError_t release_block(void* p) {
 // three times.  Freed blocks are kept and handed back to requests of the same size (a process fits the same m again and again).
 namespace {
 std::mutex g_hmu;
-std::unordered_map<void*, size_t> g_hlive;
-std::multimap<size_t, void*> g_hfree;
+std::unordered_map<void*, std::pair<size_t, int>> g_hlive;      // block -> (bytes, device current when it was pinned)
+std::multimap<std::pair<size_t, int>, void*> g_hfree;
 }  // namespace
 
 hipError_t mln_hmalloc(void** out, size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   {
     std::lock_guard<std::mutex> lk(g_hmu);
-    auto it = g_hfree.find(bytes);
+    auto it = g_hfree.find({bytes, dev});
     if (g_enabled && it != g_hfree.end()) {
       *out = it->second;
-      g_hlive[*out] = bytes;
+      g_hlive[*out] = {bytes, dev};
       g_hfree.erase(it);
       return hipSuccess;
     }
   }
   const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
-  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_hmu); g_hlive[*out] = bytes; }
+  if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_hmu); g_hlive[*out] = {bytes, dev}; }
   return e;
 }
 
@@ -128,10 +130,10 @@ hipError_t mln_hfree(void* p) {
   std::lock_guard<std::mutex> lk(g_hmu);
   auto it = g_hlive.find(p);
   if (it == g_hlive.end()) return hipHostFree(p);
-  const size_t bytes = it->second;
+  const std::pair<size_t, int> key = it->second;
   g_hlive.erase(it);
   if (!g_enabled || g_hfree.size() >= 64) return hipHostFree(p);     // (a bounded pool: 64 blocks of m-vector size)
-  g_hfree.insert({bytes, p});
+  g_hfree.insert({key, p});
   return hipSuccess;
 }
 
