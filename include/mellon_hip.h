@@ -321,7 +321,8 @@ int mln_objective(mln_fit* fit, const double* z, double* loss, double* grad /* m
  * bounds behind jaxopt.ScipyMinimize; this is the same limited-memory BFGS with the same stopping
  * tests (relative loss decrease <= ftol, max|grad| <= gtol, maxiter), run inside the library on the
  * preconditioned variable so that one evaluation = one device pass with no host framework in between.
- * status: 0 converged, 1 maxiter, 2 line search failed.                                         */
+ * status: 0 converged, 1 maxiter, 2 line search failed; + 4 when a solve that did NOT converge stopped with cells above the
+ * likelihood cap (its loss / gradient are then the capped objective's, a minorant of inference.py:35-92's).   */
 typedef struct {
   int32_t maxiter; /* 5000  */
   int32_t maxcor;  /* 10    L-BFGS memory (<= 64)    */

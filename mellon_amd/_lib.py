@@ -435,6 +435,11 @@ class Context:
         centers = np.empty((int(m), x.shape[1]), dtype=np.float64)
         nit, inertia = C.c_int32(), C.c_double()
         if init == "sklearn":
+            if not sklearn_seeding_compatible():
+                import warnings
+                warnings.warn("kmeans(init='sklearn'): the installed sklearn does not draw its k-means++ seeds the way this "
+                              "library replays them (or is not importable); the seeds are k-means++ seeds of RandomState(seed), "
+                              "but not necessarily the cells sklearn.cluster.k_means would pick.", RuntimeWarning)
             first, uni, trials = sklearn_seeding_numbers(x.shape[0], int(m), seed)
             idx = np.empty(int(m), dtype=np.int64)
             self._check(self.lib.mln_kmeans_sklearn(self.handle, _ptr(x), x.shape[0], x.shape[1], int(m), int(first),
@@ -806,6 +811,44 @@ def sklearn_seeding_numbers(n, m, seed):
     first = int(rs.choice(n, p=sw / sw.sum()))
     uni = np.ascontiguousarray(rs.uniform(size=(max(m - 1, 0), trials)), dtype=np.float64)
     return first, uni, trials
+
+
+_sklearn_seeding_ok = None
+
+
+def sklearn_seeding_compatible():
+    """Does the installed sklearn draw its k-means++ seeds the way sklearn_seeding_numbers() assumes (first centre by
+    `RandomState.choice(n, p=...)`, 2 + int(log m) uniform trials per further centre)?  Checked ONCE against
+    sklearn.cluster.kmeans_plusplus on 60 well-separated cells: all seed indices must agree with a NumPy replay of the
+    published algorithm fed by sklearn_seeding_numbers.  False (with a warning from the caller) when sklearn is another
+    version or not importable -- the seeds are then valid k-means++ seeds, but not sklearn's.
+    Tie rule of the device search (documented difference): a cumulative-potential target selects the first cell with
+    excl <= target < incl and cells at distance zero are never selected, where NumPy's searchsorted(side="left") takes the
+    first cell with incl >= target; the two differ only on exact ties of the cumulative sum or a target of exactly 0."""
+    global _sklearn_seeding_ok
+    if _sklearn_seeding_ok is not None:
+        return _sklearn_seeding_ok
+    try:
+        from sklearn.cluster import kmeans_plusplus
+        n, m, seed = 60, 6, 11
+        g = np.random.RandomState(5)
+        x = np.ascontiguousarray(g.normal(size=(n, 3)) + 20.0 * g.randint(0, 6, size=(n, 1)))
+        _, want = kmeans_plusplus(x, m, random_state=seed)
+        first, uni, trials = sklearn_seeding_numbers(n, m, seed)
+        got = [first]
+        d2 = ((x - x[first]) ** 2).sum(1)
+        for c in range(1, m):
+            cand = np.searchsorted(np.cumsum(d2), uni[c - 1] * d2.sum())
+            cand = np.clip(cand, None, n - 1)
+            dc = ((x[cand][:, None, :] - x[None, :, :]) ** 2).sum(2)
+            pots = np.minimum(d2[None, :], dc).sum(1)
+            best = int(np.argmin(pots))
+            got.append(int(cand[best]))
+            d2 = np.minimum(d2, dc[best])
+        _sklearn_seeding_ok = [int(v) for v in want] == got
+    except Exception:
+        _sklearn_seeding_ok = False
+    return _sklearn_seeding_ok
 
 
 class _Pinned:

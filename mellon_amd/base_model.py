@@ -174,6 +174,21 @@ class BaseEstimator:
         if held is not None:
             held[1].free()
 
+    # the HBM copy is a handle of this process, not state: copies and pickles of an estimator never carry it
+    _TRANSIENT = ("_x_dev", "_x_all")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._TRANSIENT}
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._TRANSIENT:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _compute_landmarks(self, ctx=None):
         from .distributed import current
         comm = current()

@@ -138,6 +138,12 @@ hipError_t mln_hfree(void* p) {
 }
 
 void mln_dcache_flush() {
-  std::lock_guard<std::mutex> lk(g_mu);
-  flush_locked();
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    flush_locked();
+  }
+  // ... and the page-locked pool: "all cached blocks back to the driver" (mln_release_cached_memory) includes pinned host pages
+  std::lock_guard<std::mutex> lk(g_hmu);
+  for (auto& kv : g_hfree) (void)hipHostFree(kv.second);
+  g_hfree.clear();
 }

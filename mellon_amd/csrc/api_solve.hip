@@ -560,7 +560,10 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (loss_out) *loss_out = st.fx;
   if (n_eval_out) *n_eval_out = st.n_eval;
   if (n_iter_out) *n_iter_out = st.it;
-  if (status_out) *status_out = st.status;
+  // A solve that stops on its iteration limit / an exhausted line search while the accepted point still has rows above the
+  // likelihood cap reports the loss and gradient of the capped minorant, not of inference.py's objective: bit 2 of the
+  // status says so (a converged solve never ends capped: k_solver_step raises the cap and re-evaluates first).
+  if (status_out) *status_out = st.status | ((st.status != 0 && st.over_acc && st.cap < 1e300) ? 4 : 0);
   return MLN_OK;
 }
 

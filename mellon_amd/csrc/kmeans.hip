@@ -1067,6 +1067,13 @@ static int sklearn_seed(mln_ctx* ctx, const double* dx, int64_t n, int d, int64_
     chk(hipGetLastError());
     chk(hipStreamSynchronize(st));
   }
+  if (rc == MLN_OK) {
+    // a NaN / inf coordinate makes the potential non-finite, every target then fails its interval test and the seeding would
+    // silently pick last cells (with max_iter = 0 kmeans_level's own check never runs): refuse, like mln_kmeans
+    SkState h;
+    chk(hipMemcpy(&h, state, sizeof(SkState), hipMemcpyDeviceToHost));
+    if (rc == MLN_OK && !std::isfinite(h.pot)) { mln_set_error(ctx, "kmeans (sklearn seeding): x contains non-finite values"); rc = MLN_ERR_ARG; }
+  }
   void* ptrs[] = {closest, tmp, part, bsum, duni, state, cb};
   for (void* p : ptrs) if (p) (void)mln_dfree(p);
   return rc;
@@ -1088,15 +1095,21 @@ extern "C" int mln_kmeans_sklearn(mln_ctx* ctx, const double* x, int64_t n, int3
     if (!(hipPointerGetAttributes(&attr, x) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged))) {
       (void)hipGetLastError();
       MLN_HIP(ctx, mln_dmalloc((void**)&owned, sizeof(double) * (size_t)n * d));
-      MLN_HIP(ctx, hipMemcpyAsync(owned, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, ctx->stream));
+      const hipError_t ce = hipMemcpyAsync(owned, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, ctx->stream);
+      if (ce != hipSuccess) { (void)mln_dfree(owned); return mln_hip_fail(ctx, ce, "kmeans (sklearn seeding): upload", __FILE__, __LINE__); }
       dx = owned;
     }
   }
   double* dc = nullptr;
   int64_t* dind = nullptr;
-  MLN_HIP(ctx, mln_dmalloc((void**)&dc, sizeof(double) * (size_t)m * d));
-  MLN_HIP(ctx, mln_dmalloc((void**)&dind, sizeof(int64_t) * (size_t)m));
-  int rc = sklearn_seed(ctx, dx, n, d, m, first_id, uniforms, n_local_trials, dc, dind);
+  int rc = MLN_OK;
+  if (mln_dmalloc((void**)&dc, sizeof(double) * (size_t)m * d) != hipSuccess ||
+      mln_dmalloc((void**)&dind, sizeof(int64_t) * (size_t)m) != hipSuccess) {
+    (void)hipGetLastError();
+    mln_set_error(ctx, "kmeans (sklearn seeding): out of device memory");
+    rc = MLN_ERR_HIP;                    // (falls through to the clean-up below: `owned` may be an n x d upload)
+  }
+  if (rc == MLN_OK) rc = sklearn_seed(ctx, dx, n, d, m, first_id, uniforms, n_local_trials, dc, dind);
   if (rc == MLN_OK && indices_out && hipMemcpy(indices_out, dind, sizeof(int64_t) * (size_t)m, hipMemcpyDefault) != hipSuccess) rc = MLN_ERR_HIP;
   // Lloyd's sweeps from these centres over ALL cells, to sklearn's stopping rule (max_iter = 0: the seeding alone)
   if (rc == MLN_OK && max_iter > 0) rc = kmeans_level(ctx, dx, n, d, m, 0, max_iter, tol, dc, centers, n_iter_out, inertia_out);
@@ -1105,7 +1118,8 @@ extern "C" int mln_kmeans_sklearn(mln_ctx* ctx, const double* x, int64_t n, int3
     if (n_iter_out) *n_iter_out = 0;
   }
   (void)hipStreamSynchronize(ctx->stream);
-  (void)mln_dfree(dc); (void)mln_dfree(dind);
+  if (dc) (void)mln_dfree(dc);
+  if (dind) (void)mln_dfree(dind);
   if (owned) (void)mln_dfree(owned);
   return rc;
 }

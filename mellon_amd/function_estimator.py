@@ -41,13 +41,16 @@ class FunctionEstimator(BaseEstimator):
     def prepare_inference(self, x):
         """reference function_estimator.py:295-316."""
         self.set_x(x)
-        self._prepare_attribute("n_landmarks")
-        self._prepare_attribute("gp_type")
-        if self.ls is None and self.cov_func is None:
-            self._prepare_attribute("nn_distances")
-        self._prepare_attribute("ls")
-        self._prepare_attribute("cov_func")
-        self._prepare_attribute("landmarks")
+        try:
+            self._prepare_attribute("n_landmarks")
+            self._prepare_attribute("gp_type")
+            if self.ls is None and self.cov_func is None:
+                self._prepare_attribute("nn_distances")
+            self._prepare_attribute("ls")
+            self._prepare_attribute("cov_func")
+            self._prepare_attribute("landmarks")
+        finally:
+            self._release_x_on_device()      # the HBM copy the 1-NN search / k-means shared: the conditional never uses it
 
     def _compute_ls(self):
         if self.cov_func is not None:

@@ -145,12 +145,16 @@ def minimize_lbfgsb(loss_func, initial_value, jit=DEFAULT_JIT, options=None):
                 z0, maxiter=opts["maxiter"], maxcor=opts["maxcor"], ftol=opts["ftol"], gtol=opts["gtol"])
             loss_func.n_eval += n_eval
             State = namedtuple("State", "fun_val nfev nit status success")
+            capped, status = bool(status & 4), status & 3     # bit 2: stopped with cells above the likelihood cap (mln_map_solve)
             if status != 0 or not np.isfinite(loss):
                 # (the reference's jaxopt wrapper reports non-convergence in its state only; a density that is not the MAP
                 #  estimate deserves a line in the log)
                 logger.warning("L-BFGS did not converge (status %d: %s) after %d evaluations, loss %.6g; the returned "
                                "pre_transformation is the last accepted point.", status,
                                {1: "iteration limit", 2: "line search failed"}.get(status, "?"), n_eval, loss)
+                if capped:
+                    logger.warning("The solve stopped with cells above the likelihood cap: the reported loss is the capped "
+                                   "(quadratically continued) objective's, a lower bound of the reference's loss at that point.")
             return Results(z, State(loss, n_eval, n_iter, status, status == 0), float(loss))
         res = _sp_minimize(loss_func.value_and_grad_u, loss_func.u_from_z(z0), jac=True, method="L-BFGS-B",
                            options=opts)
