@@ -11,12 +11,12 @@ Workload: BASELINE config 3 -- 1e6 cells x 50 dims Gaussian mixture, 5 000 landm
            --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: ONE model, its cells sharded over the N ranks -- one process per GPU, RCCL all-reduce of (loss, grad) per evaluation
-and of the Ridge Gram once per fit; no collective touches the n x m buffer.  Default `"scaling": "weak"`: 1e6 cells PER GPU
-(one model on N x 1e6 cells; N = 1 is BASELINE config 3 itself) -- the units (cells) are sharded and per-GPU work is fixed,
-which is how the task statement asks a partitioned path to be reported.  The STRONG-scaling step -- the same 1e6 cells split
-N ways, Amdahl-bound by the replicated m^3 work -- is measured in the same run and reported beside it under
-`strong_scaling`; `--scaling strong` makes it the headline instead.  Only the launcher's environment variables
-(RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) are used; the ranks' host sides talk over a Unix socket.
+and of the preconditioner's Gram once per build; no collective touches the n x m buffer.  Default `"scaling": "strong"`: the
+1e6 cells of BASELINE config 3 IN TOTAL, split N ways -- at every N the workload is the one BASELINE.json names and north_star's
+">= 6x at 8 GPUs" is quoted on; `value` = 1e6 cells x steps / time.  The WEAK step (1e6 cells PER GPU, one model on N x 1e6
+cells) is measured in the same run and reported beside it under `weak_scaling`; `--scaling weak` makes it the headline instead.
+Only the launcher's environment variables (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) are used; the ranks' host sides talk
+over a Unix socket.
 
 Prints ONE JSON line on rank 0 (fields documented in DESIGN.md S6).  The K timed steps are PURE FLOAT64: every pass
 of the MAP solve streams the fp64 n x m buffer (MELLON_AMD_MIXED=0), so `value`, `ms_per_step`, `roofline` and
@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 FP64_MFMA_PEAK_TFLOPS = 78.6   # fp64 matrix = fp64 vector rate on gfx950 (public spec)
+PREDICT_EPILOGUE_FLOPS = 14.0  # c_k of SURVEY S8(d)'s predict formula: 12 + 1 exp + 1 sqrt per kernel-matrix element
 
 
 def gaussian_mixture(n, d, seed, k=10, shard=0):
@@ -116,6 +117,30 @@ def cpu_baseline(x, landmarks, nn, kern_name, samples, n_target):
             "points": pts,
             "extrapolated_seconds_at_full_size": None if extrap is None else round(extrap, 1),
             "extrapolated_cells_per_s_at_full_size": None if not extrap else n_target / extrap}
+
+
+def cpu_baseline_predict(x, landmarks, state, kern_name, gpu_pred, sample=60_000, block=10_000):
+    """The oracle's Predictor (mu + cov(Xnew, landmarks) w: conditional.py:899-906 restated in NumPy) timed on the first
+    `sample` cells with the weights of the device fit; also the parity of the device prediction on those rows."""
+    from oracle import mellon_oracle as mo
+    ls, w, mu = state
+    s = min(sample, x.shape[0])
+    pred = mo.Predictor(getattr(mo, kern_name)(ls), landmarks, w, mu, x.shape[0])
+    out = np.empty(s)
+    t0 = time.perf_counter()
+    for i0 in range(0, s, block):
+        out[i0:i0 + block] = pred(x[i0:i0 + block])
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p_.get("num_threads", 1) for p_ in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": s / dt, "unit": "cells/s", "cores": int(threads), "kind": "port",
+            "sample": f"oracle Predictor.__call__ on the first {s} cells in blocks of {block}, m={landmarks.shape[0]}, "
+                      f"d={x.shape[1]}, weights of the device fit, os.cpu_count()={os.cpu_count()}",
+            "seconds": round(dt, 2),
+            "device_vs_oracle_rel_max": float(np.abs(gpu_pred[:s] - out).max() / np.abs(out).max())}
 
 
 def _stdout_to_stderr():
@@ -426,9 +451,10 @@ def main():
                     help="BASELINE.json config: c3 = the headline (1e6 x 50, 5000 landmarks, Matern52); c2 / c4 / c5 time "
                          "the other configs under the same contract")
     ap.add_argument("--cells", dest="n", type=int, default=None, help="cells in total (strong) / per GPU (weak)")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
-                    help="weak (default): --cells per GPU, one model on N x cells; strong: --cells in total, split N ways.  "
-                         "With N > 1 the other mode's step is measured too (--extra-steps) and reported beside the headline")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): --cells in total, split N ways -- at every N the workload is BASELINE config 3 itself "
+                         "(1e6 cells), which is what north_star's '>= 6x at 8 GPUs' is quoted on; weak: --cells per GPU, one model "
+                         "on N x cells.  With N > 1 the other mode's step is measured too (--extra-steps) and reported beside the headline")
     ap.add_argument("--dims", dest="d", type=int, default=None)
     ap.add_argument("--landmarks", dest="m", type=int, default=None)
     ap.add_argument("--landmark-method", choices=["sklearn", "device"], default="sklearn")
@@ -530,36 +556,39 @@ def main():
     # replicated inputs must be BIT-identical on every rank (they steer the shared optimiser): rank 0 computes them
     lm_pack = make_landmarks(x0, m, args.landmark_method, ctx) if rank == 0 else None
     landmarks, lm_note = comm.broadcast(lm_pack, src=0)
-    t_nn = 0.0
-    if weak:
-        # rank r owns shard r (n cells); exact 1-NN among ALL world * n cells: every rank regenerates the
-        # other shards (deterministic streams, no communication) and keeps the running minimum
-        n_total = n * world
-        lo, hi = 0, n
-        x_loc = x0 if rank == 0 else gaussian_mixture(n, d, args.seed, shard=rank)
-        x_loc_dev = ctx.to_device(x_loc)
-        nn_loc = None
-        for s_ in range(world):
-            xs = x_loc if s_ == rank else (x0 if s_ == 0 else gaussian_mixture(n, d, args.seed, shard=s_))
-            xs_dev = x_loc_dev if s_ == rank else ctx.to_device(xs)
-            t0 = time.perf_counter()
-            part = ctx.nn_distances(x_loc_dev, xs_dev, self_offset=0 if s_ == rank else -(n + 1))
-            t_nn += time.perf_counter() - t0
-            nn_loc = part if nn_loc is None else np.minimum(nn_loc, part)
-            if s_ != rank:
-                xs_dev.free()
-            del xs
-    else:
-        n_total = n
-        lo, hi = distributed.shard_bounds(n, world, rank)
-        x_loc = np.ascontiguousarray(x0[lo:hi])
+
+    def prepare(weak_mode):
+        """(x_loc host, x_loc in HBM, exact 1-NN distances of this rank's cells, cells in total, [lo, hi), seconds in the search)"""
+        t_search = 0.0
+        if weak_mode:
+            # rank r owns shard r (n cells); exact 1-NN among ALL world * n cells: every rank regenerates the
+            # other shards (deterministic streams, no communication) and keeps the running minimum
+            xl = x0 if rank == 0 else gaussian_mixture(n, d, args.seed, shard=rank)
+            xl_dev = ctx.to_device(xl)
+            nnl = None
+            for s_ in range(world):
+                xs = xl if s_ == rank else (x0 if s_ == 0 else gaussian_mixture(n, d, args.seed, shard=s_))
+                xs_dev = xl_dev if s_ == rank else ctx.to_device(xs)
+                t0 = time.perf_counter()
+                part = ctx.nn_distances(xl_dev, xs_dev, self_offset=0 if s_ == rank else -(n + 1))
+                t_search += time.perf_counter() - t0
+                nnl = part if nnl is None else np.minimum(nnl, part)
+                if s_ != rank:
+                    xs_dev.free()
+                del xs
+            return xl, xl_dev, nnl, n * world, 0, n, t_search
+        lo_, hi_ = distributed.shard_bounds(n, world, rank)
+        xl = np.ascontiguousarray(x0[lo_:hi_])
         x_all_dev = ctx.to_device(x0)
-        x_loc_dev = ctx.to_device(x_loc) if world > 1 else x_all_dev
+        xl_dev = ctx.to_device(xl) if world > 1 else x_all_dev
         t0 = time.perf_counter()
-        nn_loc = ctx.nn_distances(x_loc_dev, x_all_dev, self_offset=lo)      # exact 1-NN, excluded from timing
-        t_nn = time.perf_counter() - t0
+        nnl = ctx.nn_distances(xl_dev, x_all_dev, self_offset=lo_)      # exact 1-NN, excluded from timing
+        t_search = time.perf_counter() - t0
         if world > 1:
             x_all_dev.free()
+        return xl, xl_dev, nnl, n, lo_, hi_, t_search
+
+    x_loc, x_loc_dev, nn_loc, n_total, lo, hi, t_nn = prepare(weak)
     t_gen = time.perf_counter() - t_gen
     kern = getattr(mellon_amd.cov, args.kernel)
 
@@ -615,6 +644,36 @@ def main():
     k = min(20000, hi - lo)
     xq = x_loc[:k]
     prop = float(np.abs(est.predict(xq) - dens[:k]).max() / np.abs(dens[:k]).max())
+
+    # ---- the second half of SURVEY S8(d)'s metric: n' / wall(predict).  est.predict(X) for this rank's cells (resident in HBM;
+    #      the log-density lands in host memory), landmarks and weights cached by the predictor: K(X, xu) is never materialised
+    #      (conditional.py:899-906, base_predictor.py:180-257).  No collective: every rank predicts its own rows. -------------
+    predict_line = predict_state = pd = None
+    if args.extra_steps > 0:
+        predictor = est.predict
+        pd = predictor(x_loc_dev)                       # builds the predictor (weights w = Lp^-T z), warms the kernel
+        predict_state = (float(est.ls), np.array(predictor.weights), float(predictor.mu))
+        gc.collect()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.extra_steps):
+            pd = predictor(x_loc_dev)
+        fence()
+        e_pr = time.perf_counter() - t0
+        e_pr = float(comm.allreduce_sum(np.eye(world)[rank] * e_pr).max())
+        flops_cell = (2.0 * d + PREDICT_EPILOGUE_FLOPS + 2.0) * m
+        tf = flops_cell * (hi - lo) * args.extra_steps / e_pr / 1e12
+        predict_line = {
+            "metric": "cells/sec predict", "value": n_total * args.extra_steps / e_pr, "unit": "cells/s",
+            "ms_per_call": 1e3 * e_pr / args.extra_steps, "steps": args.extra_steps, "cells_per_call_per_gpu": hi - lo,
+            "region": "X resident in HBM -> log-density in host memory; predictor (landmarks, weights) built once, untimed",
+            "equals_fit_predict_rel_max": float(np.abs(pd - dens).max() / np.abs(dens).max()),
+            "roofline": {"bound": "mfma", "kernel": "k_predict_mean_rows (distances on the fp64 matrix cores, kernel epilogue and "
+                         "the dot with the weights on the fp64 vector pipe -- ONE fp64 datapath per SIMD on gfx950, so the bound is "
+                         "the fp64 pipe; whole call, per GPU)", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_cell": flops_cell,
+                         "formula": f"(2 d + c_k + 2) m per cell, c_k = {PREDICT_EPILOGUE_FLOPS:.0f} (SURVEY S8(d): 12 + 1 exp + 1 sqrt)"}}
     release(est)
     del est
 
@@ -643,21 +702,20 @@ def main():
         extra["mixed_vs_fp64_rel_max"] = float(np.abs(dens_mx - dens).max() / np.abs(dens).max())
         os.environ["MELLON_AMD_MIXED"] = "0"
 
-    # ---- the other scaling mode beside the headline (N > 1, headline weak): the SAME 1e6 cells of shard 0 split N ways ------
-    if world > 1 and weak and args.extra_steps > 0:
-        lo2, hi2 = distributed.shard_bounds(n, world, rank)
-        x0_dev = ctx.to_device(x0)
-        xs_dev = ctx.to_device(np.ascontiguousarray(x0[lo2:hi2]))
-        nn_cur[0] = ctx.nn_distances(xs_dev, x0_dev, self_offset=lo2)
-        x0_dev.free()
+    # ---- the other scaling mode beside the headline (N > 1): strong headline -> the weak step (1e6 cells PER GPU, one model on
+    #      N x 1e6 cells) as the companion, and the other way round -------------------------------------------------------------
+    if world > 1 and args.extra_steps > 0:
+        _, xs_dev, nn_other, n_tot2, lo2, hi2, _ = prepare(not weak)
+        nn_cur[0] = nn_other
         one_step(xs_dev)[0]._fit.close()                                                 # allocator warm-up at the new sizes
         e_st, (_, dens_st, stats_st, n_eval_st), _, _ = timed(args.extra_steps, xs_dev)
-        extra["strong_scaling"] = {
-            "note": f"the same {n} cells (shard 0 of the weak run = the 1-GPU workload) split over {world} GPUs, one model; "
-                    f"{args.extra_steps} fp64 steps between the same fences, MAX over ranks; Amdahl-bound by the replicated "
-                    "m^3 work (DESIGN.md S5)",
-            "n": n, "n_per_gpu": hi2 - lo2, "ms_per_step": 1e3 * e_st / args.extra_steps,
-            "value": n * args.extra_steps / e_st, "unit": "cells/s", "objective_evaluations": int(n_eval_st),
+        extra["weak_scaling" if not weak else "strong_scaling"] = {
+            "note": (f"{n} cells PER GPU (rank r owns an independent shard of the same mixture), one model on {n_tot2} cells; "
+                     if not weak else
+                     f"the same {n} cells (shard 0 of the weak run = the 1-GPU workload) split over {world} GPUs, one model; ")
+                    + f"{args.extra_steps} fp64 steps between the same fences, MAX over ranks",
+            "n": n_tot2, "n_per_gpu": hi2 - lo2, "ms_per_step": 1e3 * e_st / args.extra_steps,
+            "value": n_tot2 * args.extra_steps / e_st, "unit": "cells/s", "objective_evaluations": int(n_eval_st),
             "precond_rebuilds": stats_st.get("precond_rebuilds")}
         xs_dev.free()
         nn_cur[0] = nn_loc
@@ -690,6 +748,8 @@ def main():
             extra["n1_note"] = f"{n} cells unsharded on rank 0's GPU alone, {args.extra_steps} fp64 steps, same process, same landmarks"
             if "strong_scaling" in extra:
                 extra["strong_scaling"]["speedup_vs_n1"] = n1_ms / extra["strong_scaling"]["ms_per_step"]
+            if "weak_scaling" in extra:
+                extra["weak_scaling"]["throughput_vs_n1"] = extra["weak_scaling"]["value"] / (n / (1e-3 * n1_ms))
             if not weak:
                 extra["speedup_vs_n1"] = n1_ms / (1e3 * elapsed / args.steps)
 
@@ -765,6 +825,10 @@ def main():
             out["mfma"] = json.load(open(mfile))
         except Exception:
             pass
+    if predict_line is not None:
+        out["predict"] = predict_line
+        if world == 1 and args.cpu_sample != 0:
+            out["predict"]["cpu_baseline"] = cpu_baseline_predict(x0, landmarks, predict_state, args.kernel, pd)
     if world == 1 and args.cpu_sample != 0:
         gc.collect()
         samples, why = pick_cpu_samples(args, n, host_memory_gb())
