@@ -197,7 +197,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_gram_i8(const int8_t* __restrict
   const int n_steps = (int)(kchunk / GBK);
   const int64_t plane_sz = Mp * Kp;
   // global -> register -> LDS staging: 16-byte chunks, one 64-bit address per operand, the rest wave-uniform
-  const int seg = t & 3, r0 = t >> 2;
+  // Row of the staged tile a thread moves: rows 0, 4 | 1, 5 | 2, 6 | 3, 7 of every 8-row block go to CONSECUTIVE groups of
+  // four lanes.  A ds_write_b128 is serviced in groups of 8 contiguous lanes against 32 banks (128 B): with rows r, r + 1 in
+  // a group (pitch 80 B) the second row's [80, 144) wraps onto the first row's first 16 bytes -- a 2-way conflict on every
+  // store, 29 % of all LDS cycles (profiles/r05_gram_i8_pmc.txt); rows r, r + 4 sit 320 = 64 (mod 128) bytes apart and
+  // tile the 128-byte bank row exactly.  The 32 lanes of a half-wave still cover 8 rows x 64 B = 512 contiguous bytes of
+  // the tiled global layout (full cache lines), and the b128 operand READS (pitch 80 B: 16 distinct 16-byte slots per lane
+  // group) are unchanged.
+  const int seg = t & 3, q = t >> 2, r0 = (q & ~7) | ((q & 1) << 2) | ((q >> 1) & 3);
   const int8_t* gA = planes + (((int64_t)tl.ti * (Kp >> 6) + (kbeg >> 6)) * GT + r0) * GBK + seg * 16;   // tiled layout, see k_gram_digits
   const int8_t* gB = planes + (((int64_t)tl.tj * (Kp >> 6) + (kbeg >> 6)) * GT + r0) * GBK + seg * 16;
   const int64_t half = 64 * GBK;
