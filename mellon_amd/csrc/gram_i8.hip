@@ -124,43 +124,68 @@ __device__ __forceinline__ void gram_sweep(unsigned char* lds, const int8_t* gA,
 #pragma unroll
       for (int bj = 0; bj < NBJ; ++bj) acc[w][bi][bj] = v16i_t{};
 
+  // Operand fetches run ONE HALF-STAGE ahead of the matrix instructions that consume them (round 6): the 32 cells of
+  // half-stage h + 1 are requested from LDS before the MFMAs of half-stage h are issued, so a wave's LDS latency is covered
+  // by its own matrix work.  Before, every stage began with all its ds_reads and `s_waitcnt lgkmcnt(0)`, and the two waves
+  // of a SIMD -- kept in step by the stage barrier -- sat out their LDS phases TOGETHER: the matrix cores were busy 0.53 of
+  // the kernel with no bank conflict left (profiles/r06_gram_i8_pmc.txt).  The barrier now sits between the two
+  // half-stages: it is reached with half a stage of MFMAs still in the pipe.
+  struct Ops { v4i_t A[NP][2], B[NP][NBJ]; };
+  auto read_ops = [&](Ops& o, int buf, int ks) {
+    const unsigned char* base = lds + buf * GSTAGE;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) o.A[a][b] = *reinterpret_cast<const v4i_t*>(base + fa + (a * GT + b * 32) * GROW + ks * 32);
+#pragma unroll
+      for (int b = 0; b < NBJ; ++b) o.B[a][b] = *reinterpret_cast<const v4i_t*>(base + fb + (a * GT + b * 32) * GROW + ks * 32);
+    }
+  };
+  auto mfmas = [&](const Ops& o, int bi) {
+#pragma unroll
+    for (int bj = 0; bj < NBJ; ++bj) {
+      if constexpr (PASS == 0) {
+        acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[2][bj], acc[0][bi][bj], 0, 0, 0);
+        acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[2][bj], acc[1][bi][bj], 0, 0, 0);
+        acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[2][bj], acc[2][bi][bj], 0, 0, 0);
+        acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[1][bj], acc[1][bi][bj], 0, 0, 0);
+        acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[1][bj], acc[2][bi][bj], 0, 0, 0);
+        acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[0][bj], acc[2][bi][bj], 0, 0, 0);
+      } else {
+        acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[1][bj], acc[0][bi][bj], 0, 0, 0);
+        acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[0][bj], acc[1][bi][bj], 0, 0, 0);
+        acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[0][bj], acc[0][bi][bj], 0, 0, 0);
+      }
+    }
+  };
+  // Stage st lives in LDS buffer st & 1; the registers `stage` hold the data of stage st + 2 while stage st is multiplied:
+  //   request the second half-stage's operands | MFMAs of the first | BARRIER (buffer of stage st + 1 complete; every read
+  //   of stage st's buffer has landed, so it is free) | request stage st + 1's first operands | MFMAs of the second
+  //   half-stage with, in their shadow, stage st + 2 going from registers to the freed buffer and the request for st + 3.
+  // The scheduling fences keep the compiler from sinking the first half-stage's MFMAs below the barrier (it did: matrix
+  // instructions touch no memory), which would leave the barrier wait with an empty matrix pipe.
   g_load(0); l_store(0);
   if (n_steps > 1) g_load(1);
   lds_barrier();
+  Ops o0, o1;
+  read_ops(o0, 0, 0);
+  if (n_steps > 1) l_store(1);
+  if (n_steps > 2) g_load(2);
   for (int st = 0; st < n_steps; ++st) {
     const int buf = st & 1;
-    if (st + 1 < n_steps) l_store(buf ^ 1);       // stage st + 1: requested one stage ago; its LDS buffer was released
-    if (st + 2 < n_steps) g_load(st + 2);         // by the barrier that ended stage st - 1
-    const unsigned char* base = lds + buf * GSTAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      v4i_t A[NP][2], B[NP][NBJ];
-#pragma unroll
-      for (int a = 0; a < NP; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) A[a][b] = *reinterpret_cast<const v4i_t*>(base + fa + (a * GT + b * 32) * GROW + ks * 32);
-#pragma unroll
-        for (int b = 0; b < NBJ; ++b) B[a][b] = *reinterpret_cast<const v4i_t*>(base + fb + (a * GT + b * 32) * GROW + ks * 32);
-      }
-#pragma unroll
-      for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-        for (int bj = 0; bj < NBJ; ++bj) {
-          if constexpr (PASS == 0) {
-            acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2][bi], B[2][bj], acc[0][bi][bj], 0, 0, 0);
-            acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][bi], B[2][bj], acc[1][bi][bj], 0, 0, 0);
-            acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2][bi], B[1][bj], acc[1][bi][bj], 0, 0, 0);
-            acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][bi], B[2][bj], acc[2][bi][bj], 0, 0, 0);
-            acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][bi], B[1][bj], acc[2][bi][bj], 0, 0, 0);
-            acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[2][bi], B[0][bj], acc[2][bi][bj], 0, 0, 0);
-          } else {
-            acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][bi], B[1][bj], acc[0][bi][bj], 0, 0, 0);
-            acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[1][bi], B[0][bj], acc[0][bi][bj], 0, 0, 0);
-            acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0][bi], B[0][bj], acc[1][bi][bj], 0, 0, 0);
-          }
-        }
-    }
+    read_ops(o1, buf, 1);
+    mfmas(o0, 0); mfmas(o0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // (no branch around the requests: at a join the compiler's wait-count bookkeeping gives up and waits for EVERYTHING
+    //  before the next matrix instruction.  Past the last stage the reads fetch a buffer nobody multiplies, the stores put
+    //  stale registers into a buffer nobody reads, and the global request re-reads the last stage.)
+    read_ops(o0, buf ^ 1, 0);
+    mfmas(o1, 0);
+    l_store(buf);
+    g_load(st + 3 < n_steps ? st + 3 : n_steps - 1);
+    mfmas(o1, 1);
   }
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
