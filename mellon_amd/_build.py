@@ -15,8 +15,13 @@ SOURCES = ["api.hip", "api_fit.hip", "api_precond.hip", "api_solve.hip", "api_no
            "predict_rows_ratquad.hip", "predict_rows_prod.hip", "predict_rows_prod_matern32.hip", "predict_rows_prod_matern52.hip",
            "predict_rows_prod_expquad.hip", "predict_rows_prod_exponential.hip", "kernel_rows_prod_matern32.hip", "kernel_rows_prod_matern52.hip",
            "kernel_rows_prod_expquad.hip", "kernel_rows_prod_exponential.hip",
-           "dgemm.hip", "diag.hip", "precond_rebuild.hip", "rowmin_f16.hip", "gram_i8.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip", "tridiag.hip", "ldl_inertia.hip"]
+           "dgemm.hip", "diag.hip", "precond_rebuild.hip", "rowmin_f16.hip", "rowmin_w64.hip", "gram_i8.hip", "eigh.hip", "kmeans.hip", "linalg.hip", "potrf.hip", "objective.hip", "solver.hip", "tridiag.hip", "ldl_inertia.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DMLN_POTRF_TIMING"] if __import__("os").environ.get("MLN_POTRF_TIMING") else [])
+
+
+# per-source extras: the one-wave-per-SIMD row-minimum sweep keeps its MFMA accumulators in architectural VGPRs (its vector
+# epilogue reads them directly; in AGPRs every element costs a v_accvgpr_read)
+EXTRA_FLAGS = {"rowmin_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _deps(depfile, src):
@@ -50,7 +55,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj, dep = job
-        cmd = [hipcc] + FLAGS + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-MMD", "-MF", dep, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 

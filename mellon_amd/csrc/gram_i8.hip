@@ -141,22 +141,29 @@ __device__ __forceinline__ void gram_sweep(unsigned char* lds, const int8_t* gA,
       for (int b = 0; b < NBJ; ++b) o.B[a][b] = *reinterpret_cast<const v4i_t*>(base + fb + (a * GT + b * 32) * GROW + ks * 32);
     }
   };
-  auto mfmas = [&](const Ops& o, int bi) {
-#pragma unroll
-    for (int bj = 0; bj < NBJ; ++bj) {
-      if constexpr (PASS == 0) {
-        acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[2][bj], acc[0][bi][bj], 0, 0, 0);
-        acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[2][bj], acc[1][bi][bj], 0, 0, 0);
-        acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[2][bj], acc[2][bi][bj], 0, 0, 0);
-        acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[1][bj], acc[1][bi][bj], 0, 0, 0);
-        acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[1][bj], acc[2][bi][bj], 0, 0, 0);
-        acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[0][bj], acc[2][bi][bj], 0, 0, 0);
-      } else {
-        acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[1][bj], acc[0][bi][bj], 0, 0, 0);
-        acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[0][bj], acc[1][bi][bj], 0, 0, 0);
-        acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[0][bj], acc[0][bi][bj], 0, 0, 0);
-      }
+  // One row block bi: its digit products, ordered so that no two CONSECUTIVE matrix instructions write the same accumulator
+  // when the two row blocks are issued alternately (mfmas2): a dependent 32 x 32 MFMA waits for its predecessor's full latency.
+  auto mfma1 = [&](const Ops& o, int bi, int bj, int k) {
+    if constexpr (PASS == 0) {
+      if (k == 0) acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[2][bj], acc[0][bi][bj], 0, 0, 0);
+      if (k == 1) acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[2][bj], acc[1][bi][bj], 0, 0, 0);
+      if (k == 2) acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[2][bj], acc[2][bi][bj], 0, 0, 0);
+      if (k == 3) acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[1][bj], acc[1][bi][bj], 0, 0, 0);
+      if (k == 4) acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[1][bj], acc[2][bi][bj], 0, 0, 0);
+      if (k == 5) acc[2][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[2][bi], o.B[0][bj], acc[2][bi][bj], 0, 0, 0);
+    } else {
+      if (k == 0) acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[1][bj], acc[0][bi][bj], 0, 0, 0);
+      if (k == 1) acc[1][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[0][bi], o.B[0][bj], acc[1][bi][bj], 0, 0, 0);
+      if (k == 2) acc[0][bi][bj] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.A[1][bi], o.B[0][bj], acc[0][bi][bj], 0, 0, 0);
     }
+  };
+  // both row blocks, alternating: products k of bi = 0 and bi = 1 back to back
+  constexpr int NK = PASS == 0 ? 6 : 3;
+  auto mfmas2 = [&](const Ops& o, int k0, int k1) {
+#pragma unroll
+    for (int k = k0; k < k1; ++k)
+#pragma unroll
+      for (int bj = 0; bj < NBJ; ++bj) { mfma1(o, 0, bj, k); mfma1(o, 1, bj, k); }
   };
   // Stage st lives in LDS buffer st & 1; the registers `stage` hold the data of stage st + 2 while stage st is multiplied:
   //   request the second half-stage's operands | MFMAs of the first | BARRIER (buffer of stage st + 1 complete; every read
@@ -174,7 +181,7 @@ __device__ __forceinline__ void gram_sweep(unsigned char* lds, const int8_t* gA,
   for (int st = 0; st < n_steps; ++st) {
     const int buf = st & 1;
     read_ops(o1, buf, 1);
-    mfmas(o0, 0); mfmas(o0, 1);
+    mfmas2(o0, 0, NK);
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -182,10 +189,10 @@ __device__ __forceinline__ void gram_sweep(unsigned char* lds, const int8_t* gA,
     //  before the next matrix instruction.  Past the last stage the reads fetch a buffer nobody multiplies, the stores put
     //  stale registers into a buffer nobody reads, and the global request re-reads the last stage.)
     read_ops(o0, buf ^ 1, 0);
-    mfmas(o1, 0);
+    mfmas2(o1, 0, NK / 2);
     l_store(buf);
     g_load(st + 3 < n_steps ? st + 3 : n_steps - 1);
-    mfmas(o1, 1);
+    mfmas2(o1, NK / 2, NK);
   }
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)

@@ -67,14 +67,29 @@ __global__ __launch_bounds__(256) void k_weights(const double* __restrict__ f, c
   }
 }
 
-// per-block partial of sum_i min(1, c a_i)
+// per-block partials of g(c) = sum_i min(1, c a_i) and of its slope g'(c) = sum of the a_i with c a_i < 1
 __global__ __launch_bounds__(256) void k_expected(const double* __restrict__ a, int64_t n, double c,
-                                                  double* __restrict__ part) {
+                                                  double* __restrict__ part, double* __restrict__ part_slope) {
   __shared__ double red[4];
-  double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += fmin(1.0, c * a[i]);
+  double s = 0.0, sl = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = a[i], ca = c * v;
+    s += fmin(1.0, ca);
+    sl += (ca < 1.0) ? v : 0.0;
+  }
   s = block_sum256(s, red);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  sl = block_sum256(sl, red);
+  if (threadIdx.x == 0) { part[blockIdx.x] = s; part_slope[blockIdx.x] = sl; }
+}
+
+// fixed-order sums of both into out[0], out[1]
+__global__ void k_fold2(const double* __restrict__ p0, const double* __restrict__ p1, int n_part, double* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x < 2) {
+    const double* p = threadIdx.x == 0 ? p0 : p1;
+    double s = 0.0;
+    for (int i = 0; i < n_part; ++i) s += p[i];
+    out[threadIdx.x] = s;
+  }
 }
 
 // fixed-order sum (or max) of the block partials into out[0]
@@ -187,20 +202,27 @@ int rebuild_select_rows(mln_ctx* ctx, const double* f_dev, const double* V_dev, 
   for (int r = 0; r < nr; ++r) a_max = std::max(a_max, h[r]);
   const double sum_a = h[nr];
   if (!(sum_a > 0.0) || !std::isfinite(sum_a)) { mln_set_error(ctx, "preconditioner rebuild: degenerate weights"); return fail(MLN_ERR_ARG); }
-  // c with  sum_i min(1, c a_i) = target  (monotone in c: multiplicative fixed point, a dozen rounds)
+  // c with  g(c) = sum_i min(1, c a_i) = target.  g is concave, increasing and piecewise linear; Newton's iteration from the
+  // left (c0 = target / sum a <= c*, since min(1, x) <= x) rises monotonically and never overshoots -- a tangent of a concave
+  // function lies above it -- and lands exactly once no breakpoint is left between the iterate and c*: 3-4 rounds where the
+  // multiplicative fixed point c *= target / g(c) took 9 (each round is a launch pair, an all-reduce and a host round trip:
+  // 0.5 ms of a C2 step, 0.7-1 ms on 8 ranks).  Every rank computes the same c from the same all-reduced pair.
   double c = target_rows_global / sum_a;
   for (int it = 0; it < 14; ++it) {
-    hipLaunchKernelGGL(k_expected, dim3(nb), dim3(256), 0, ctx->stream, a, n, c, part);
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, ctx->stream, part, nb, 0, scal + 2);
-    rc = comm_allreduce(ctx, scal + 2, 1);
-    double cnt = 0.0;
-    if (rc == MLN_OK && (hipMemcpyAsync(&cnt, scal + 2, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+    hipLaunchKernelGGL(k_expected, dim3(nb), dim3(256), 0, ctx->stream, a, n, c, part, part2);
+    hipLaunchKernelGGL(k_fold2, dim3(1), dim3(64), 0, ctx->stream, part, part2, nb, scal + 2);
+    rc = comm_allreduce(ctx, scal + 2, 2);
+    double gs[2] = {0.0, 0.0};
+    if (rc == MLN_OK && (hipMemcpyAsync(gs, scal + 2, sizeof(gs), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                          hipStreamSynchronize(ctx->stream) != hipSuccess)) rc = MLN_ERR_HIP;
     if (rc != MLN_OK) return fail(rc);
+    const double cnt = gs[0], slope = gs[1];
     if (!(cnt > 0.0)) break;
-    const double ratio = target_rows_global / cnt;
-    if (std::fabs(ratio - 1.0) < 1e-3) break;
-    c *= ratio;
+    if (std::fabs(target_rows_global / cnt - 1.0) < 1e-3) break;
+    if (!(slope > 0.0)) break;            // every cell saturated: g(c) = n < target cannot be raised
+    const double c_new = c + (target_rows_global - cnt) / slope;
+    if (!(c_new > c) || !std::isfinite(c_new)) break;
+    c = c_new;
     if (c * a_max > 1e12) break;          // (almost) every cell is kept: nothing left to solve for
   }
   // weights are a_i / p_i = max(a_i, 1 / c); rows are scaled by sqrt(w_i / w_max) so that the scaled covariances stay

@@ -25,6 +25,9 @@
 
 hipError_t mln_dfree_synced(void* p);   // alloc.hip: release after the caller synchronised the only stream that used p
 #include "rowmin_f16.h"
+// rowmin_w64.hip: the folded sweep, one wave per SIMD (round 6)
+int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16* Y, int64_t m, int64_t self_offset, int exclude_self,
+                      float* m1, float* m2, int* arg, const int* row_idx);
 #include "mln_options.h"
 
 namespace {
@@ -331,7 +334,7 @@ __device__ __forceinline__ double rowmin_value_bound(double xn, double yn) {
 
 // Exact fp64 value of the winner, certification against the runner-up, list of the rows that need the exact search.
 //   s_j = |y_j|^2 - 2 x.y_j (exact);  |s~_j - s_j| <= E_i for every j  =>  j* != arg implies s_{j*} >= m2~ - E_i.
-// fold: the winner is one of arg + {0, 32, 64, 96} (k_rowmin_f16x3 FOLD): all four are evaluated exactly.
+// fold > 0: the winner is one of arg + 32 q, q < fold (rowmin_fold_candidates()): all of them are evaluated exactly.
 __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x, int64_t n, const double* __restrict__ y, int64_t m, int d,
                                                     const double* __restrict__ xx, const double* __restrict__ yy,
                                                     const float* __restrict__ m2, const int* __restrict__ arg,
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
   const double sc = prep[64];
   double s = INFINITY;
   int64_t js = -1;
-  for (int q = 0; q < (fold ? 4 : 1); ++q) {
+  for (int q = 0; q < (fold ? fold : 1); ++q) {        // fold: the number of candidates a folded arg stands for (0: exact column)
     const int64_t j = (int64_t)arg[i] + 32 * q;
     if (j >= m || j == i + self_offset) continue;
     double dot = 0.0;
@@ -520,14 +523,14 @@ __global__ void k_nn_list_finish(const int* __restrict__ flagged, int cnt, const
   out[flagged[r]] = sqrt(fmin(b, fdd[r]));
 }
 
-// labels from the fold variant's stage-level args: the closest of the four candidates, in fp64
+// labels from the fold variant's stage-level args: the closest of the ncand candidates, in fp64
 __global__ __launch_bounds__(256) void k_resolve_labels(const double* __restrict__ x, int64_t n, const double* __restrict__ y, int64_t m,
-                                                        int d, const double* __restrict__ yy, int* __restrict__ arg) {
+                                                        int d, const double* __restrict__ yy, int* __restrict__ arg, int ncand) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double best = INFINITY;
   int bj = arg[i];
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < ncand; ++q) {
     const int64_t j = (int64_t)arg[i] + 32 * q;
     if (j >= m) continue;
     double dot = 0.0;
@@ -539,10 +542,10 @@ __global__ __launch_bounds__(256) void k_resolve_labels(const double* __restrict
 }
 
 // k-means with distance bounds (kmeans.hip): one searched row -> its label and the two bounds.
-//   the sweep (TOP2, FOLD) returned arg (the winner is one of arg + {0, 32, 64, 96}) and m2~, the second smallest approximate
-//   value; every candidate other than the owner of the smallest has s~_j >= m2~, hence s_j >= m2~ - E.  The four are
+//   the sweep (TOP2, FOLD) returned arg (the winner is one of arg + 32 q, q < ncand) and m2~, the second smallest approximate
+//   value; every candidate other than the owner of the smallest has s~_j >= m2~, hence s_j >= m2~ - E.  They are
 //   evaluated exactly, sum (x_k - c_k)^2 in fp64: label = the closest of them, ub = its distance, and
-//   lb^2 = min(second closest of the four, (|x'|^2 + m2~ - E) / scale^2) bounds the distance to EVERY other centre.
+//   lb^2 = min(second closest of them, (|x'|^2 + m2~ - E) / scale^2) bounds the distance to EVERY other centre.
 //   (The label need not be the true nearest centre when two are within E of each other; then ub > lb and the row is
 //   simply searched again next sweep.)
 // rows: r < cnt, i = idx ? idx[r] : r.  sums / counts (optional): the row moves from its old label to the new one.
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
                                                     const int* __restrict__ arg, int* __restrict__ label,
                                                     double* __restrict__ ub, double* __restrict__ lb,
                                                     double* __restrict__ sums, double* __restrict__ counts,
-                                                    const double* __restrict__ colscale) {
+                                                    const double* __restrict__ colscale, int ncand) {
   // eight lanes per row, every eighth coordinate each (coalesced over the 8 rows of a wave's load)
   const int sub = threadIdx.x & 7;
   const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
   const double* xr = x + i * d;
   double best = INFINITY, second = INFINITY;
   int bj = arg[r];
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < ncand; ++q) {
     const int64_t j = (int64_t)arg[r] + 32 * q;
     if (j >= m) continue;
     const double* cr = c + j * d;
@@ -648,6 +651,14 @@ int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* spli
   return MLN_OK;
 }
 
+// A folded sweep reports, with the runner-up tracked, the winner's column only per stage and lane: it is one of
+// arg + 32 q, q < rowmin_fold_candidates() -- 8 for the one-wave-per-SIMD sweep (256-candidate stages), 4 for the 8 x 32 shape.
+static bool rowmin_use_w64() {
+  static const bool w64 = !(mln_experiment("MELLON_AMD_ROWMIN_W64") && std::atoi(mln_experiment("MELLON_AMD_ROWMIN_W64")) == 0);
+  return w64;
+}
+int rowmin_fold_candidates() { return rowmin_use_w64() ? 8 : 4; }
+
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
                         int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold, const int* row_idx) {
   if (n <= 0 || m <= 0) return MLN_OK;
@@ -663,6 +674,8 @@ int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys,
   const dim3 grid((unsigned)((n + 255) / 256)), block(512);
   const _Float16* X = reinterpret_cast<const _Float16*>(xs);
   const _Float16* Y = reinterpret_cast<const _Float16*>(ys);
+  // folded operands: the one-wave-per-SIMD sweep (round 6); MELLON_AMD_ROWMIN_W64=0 keeps the 8 x 32 shape (A/B)
+  if (fold && rowmin_use_w64()) return launch_rowmin_w64(ctx, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx);
   if (m2 && fold) hipLaunchKernelGGL((k_rowmin_f16x3<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
   else if (m2) hipLaunchKernelGGL((k_rowmin_f16x3<true, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
   else if (fold) hipLaunchKernelGGL((k_rowmin_f16x3<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
@@ -673,7 +686,7 @@ int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys,
 
 int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg) {
   if (n <= 0) return MLN_OK;
-  hipLaunchKernelGGL(k_resolve_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, yy, arg);
+  hipLaunchKernelGGL(k_resolve_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, yy, arg, rowmin_fold_candidates());
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -683,7 +696,7 @@ int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx
                       int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale) {
   if (cnt <= 0) return MLN_OK;
   hipLaunchKernelGGL(k_km_resolve, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, ctx->stream, x, cnt, idx, c, m, d, xxs,
-                     yy_max, prep, m2, arg, label, ub, lb, sums, counts, colscale);
+                     yy_max, prep, m2, arg, label, ub, lb, sums, counts, colscale, rowmin_fold_candidates());
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -746,7 +759,7 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
   rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr);
   if (rc != MLN_OK) return cleanup(rc);
   hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
-                     ymax, fold, self_offset, prep, out, nflag, flagged, fthr, fdd);
+                     ymax, fold ? rowmin_fold_candidates() : 0, self_offset, prep, out, nflag, flagged, fthr, fdd);
   if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
   if (std::getenv("MELLON_AMD_TRACE"))
