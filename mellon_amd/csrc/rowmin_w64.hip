@@ -17,6 +17,11 @@
 //     spills per stage) and the accumulators went to AGPRs (one v_accvgpr_read per element);
 //   * the stage body has no branch: a stage that holds a padded candidate or meets the wave's diagonal band (the excluded
 //     pair) takes the masked body instead -- at most three stages per wave.
+// Measured and taken out (round 6): the same interleave with 32 rows per wave and TWO independent workgroups per CU (the
+// micro-benchmark tools/ubench/f16_overlap.hip: one wave per SIMD reaches 0.86 of the fp16 MFMA rate alone and 0.72 with four
+// vector instructions per MFMA in its stream, two waves reach the rate) -- matrix cores busy 0.60 instead of 0.56, but at
+// 1.77 GHz instead of 2.06: the sweep is POWER-bound, and the shape with twice the LDS reads and 27 % more vector
+// instructions lost what the second wave won (1-NN at C3: 0.423 s against 0.405 on the same box; round-5 kernel 0.441).
 // Built with -mllvm -amdgpu-mfma-vgpr-form (mellon_amd/_build.py): the accumulators are architectural VGPRs, which the
 // epilogue's vector instructions read directly.
 #include <cmath>
