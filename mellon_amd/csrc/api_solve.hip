@@ -304,7 +304,6 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   // progress per iteration below which the 32-bit surrogate is left for the fp64 buffer (relative to the loss):
   // the fp32 copy's optimum sits ~1e-5 (relative loss) from the true one, the fixed-point copy's ~1e-9
   init.ftol32 = f->l32_fixed ? 1e-9 : 3e-6;
-  if (const char* ev = mln_experiment("MELLON_AMD_MIXED_FTOL")) init.ftol32 = std::atof(ev);
   // ... and after that first fp64 evaluation the solve continues on the 32-bit copy WITH its first-order correction
   // (solver.hip), the fp64 objective verifying the final point (MELLON_AMD_CORRECTED=0: finish on the fp64 buffer)
   init.use_corr = (phase32 && f->l32_fixed) ? 1 : 0;
@@ -325,7 +324,6 @@ extern "C" int mln_map_solve(mln_fit* f, const double* z0, const mln_solver_opts
   if (phase32 && !mln_experiment("MELLON_AMD_EXP_CAP")) init.cap = __builtin_inf();
   init.cap0 = init.cap;
   init.boost_fall = 0.15;
-  if (const char* ev = mln_experiment("MELLON_AMD_LS_BOOST_FALL")) init.boost_fall = std::atof(ev);
   // Subsample start (solver.h): when the preconditioner's Gram came from every s-th cell (s >= 4), the solve starts
   // on the MAP problem of exactly those cells -- the Ridge matrix is ITS Hessian at a = 1 -- at 1/s of the bytes per
   // pass, and moves to all cells once that problem's progress per iteration is below sub_tol.  The walk down from the

@@ -14,7 +14,6 @@
 #include <cstdlib>
 #include "mln_internal.h"
 #include "cov_program.h"
-#include "mln_options.h"
 
 namespace {
 
@@ -216,7 +215,7 @@ int launch_predict_gradient(mln_ctx* ctx, const DevCov& cov, const double* x, in
   // composite program whose leaves are all stationary: the same idea with one coefficient matrix per leaf
   bool stationary = cov.n_leaves >= 1;
   for (int l = 0; l < cov.n_leaves; ++l) stationary = stationary && cov.leaves[l].kind != MLN_K_LINEAR;
-  if (stationary && n * m >= (int64_t)1 << 16 && !mln_experiment("MELLON_AMD_GRAD_NO_GEMM"))
+  if (stationary && n * m >= (int64_t)1 << 16)
     return launch_predict_gradient_gemm_multi(ctx, cov, x, n, c, m, d, w, out);
   const size_t lds = sizeof(double) * ((size_t)2 * d * GR + (size_t)GC * d + GC + (size_t)MLN_MAX_LEAVES * GC);
   if (lds > 160 * 1024) { mln_set_error(ctx, "predict_gradient: too many dimensions for the LDS layout"); return MLN_ERR_UNSUPPORTED; }

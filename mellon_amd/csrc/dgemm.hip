@@ -651,12 +651,11 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   // triangular inverses: 384 tiles as 128-tiles 53.6 us, 375 as 1500 quadrants 45.6 us -- the crossover is near 440 of 512)
   const int64_t per_round = slots / split > 0 ? slots / split : 1;
   int64_t n_big = (n_active / per_round) * per_round;
-  static const int64_t keep8 = mln_experiment("MELLON_AMD_GEMM_KEEP8") ? std::atoll(mln_experiment("MELLON_AMD_GEMM_KEEP8")) : 7;
+  constexpr int64_t keep8 = 7;      // (tools sweep of round 4c: 6, 7, 8 within 0.3 ms of each other at step level)
   if ((n_active - n_big) * 8 >= keep8 * per_round || mode == 2) n_big = n_active;
   if (mode == 3) n_big = 0;
   tmap.n_big = n_big;
-  static const int ring = mln_experiment("MELLON_AMD_GEMM_RING") ? std::atoi(mln_experiment("MELLON_AMD_GEMM_RING")) : 1;
-  tmap.ring = ring;
+  tmap.ring = 1;      // (the ring for launches of at most two quadrants per CU; "everywhere" measured +0.4 ms: profiles/r04c_ab_ring_everywhere_and_keep8.txt)
   const int64_t nblk = n_big + 4 * (n_active - n_big);
   if (nblk > 0x7fffffffLL) { mln_set_error(ctx, "dgemm grid too large"); return MLN_ERR_UNSUPPORTED; }
   const bool vec = ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0) && (g.lda % 2 == 0) && (g.ldb % 2 == 0) && (g.bsa % 2 == 0) && (g.bsb % 2 == 0);
@@ -668,10 +667,8 @@ static int launch_dgemm_mix(mln_ctx* ctx, const GemmArgs& g, int mode, bool any_
   hipError_t e;
   if (n_big == 0) {
     const size_t lds = 4 * 16 * (64 + LPAD) * 8;
-    // the ring: launches of at most two quadrants per CU, and (MELLON_AMD_GEMM_RING=2, experiment) every launch all of whose K
-    // ranges qualify for it -- full K, a whole number of groups of four k-tiles
-    const bool all_ring = tmap.ring >= 2 && g.kmode == 0 && ksplit == 1 && g.K >= 128 && (g.K & 63) == 0;
-    if (vec && tmap.ring && (nblk * split <= 2 * n_cu || all_ring)) e = dispatch_mix<true, 2>(g, tmap, grid, lds, ctx->stream, kchunk);
+    // the ring: launches of at most two quadrants per CU
+    if (vec && tmap.ring && nblk * split <= 2 * n_cu) e = dispatch_mix<true, 2>(g, tmap, grid, lds, ctx->stream, kchunk);
     else e = vec ? dispatch_mix<true, 1>(g, tmap, grid, lds, ctx->stream, kchunk) : dispatch_mix<false, 1>(g, tmap, grid, lds, ctx->stream, kchunk);
   } else {
     const size_t lds = 4 * 16 * (128 + LPAD) * 8;
@@ -719,7 +716,7 @@ int launch_dgemm(mln_ctx* ctx, const GemmArgs& g) {
   if (g.kmode == 1 || g.kmode == 2) bt = 128;   // the block-diagonal modes are defined on 128-wide blocks
   {
     // the pipelined kernel with mixed tile sizes (see TileMap): whole rounds of 128-tiles, the rest as quadrants
-    static const int mix_mode = mln_experiment("MELLON_AMD_GEMM_MIX") ? std::atoi(mln_experiment("MELLON_AMD_GEMM_MIX")) : 1;
+    constexpr int mix_mode = 1;
     if (g_mix_override != 0 && mix_mode > 0 && !inplace) {
       int rc = launch_dgemm_mix(ctx, g, mix_mode, g_mix_override == 1);
       if (rc != MLN_ERR_UNSUPPORTED) return rc;

@@ -4,7 +4,6 @@
 #include <vector>
 
 #include "mln_internal.h"
-#include "mln_options.h"
 
 namespace {
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -116,7 +115,6 @@ extern "C" int mln_diag_dgemm(mln_ctx* ctx, int32_t ta, int32_t tb, int64_t M, i
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = Cm; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.alpha = 1.0; g.beta = 0.0; g.ta = ta; g.tb = tb; g.lower_only = lower_only; g.split_k = split;
   g.c_split_stride = (int64_t)M * ldc;
-  if (const char* e = mln_experiment("MELLON_AMD_DIAG_KMODE")) g.kmode = std::atoi(e);   // triangular K ranges (probes)
   hipEvent_t e0, e1;
   MLN_HIP(ctx, hipEventCreate(&e0));
   MLN_HIP(ctx, hipEventCreate(&e1));

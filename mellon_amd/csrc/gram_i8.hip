@@ -22,7 +22,6 @@
 #include <algorithm>
 #include <cmath>
 #include <vector>
-#include "mln_options.h"
 
 namespace {
 
@@ -308,13 +307,11 @@ int launch_gram_i8(mln_ctx* ctx, const double* K, int64_t ldk, int64_t rows, int
   if (rc == MLN_OK) {
     hipLaunchKernelGGL(k_gram_digits, dim3((unsigned)(Kp / 64), (unsigned)(Mp / 64)), dim3(256), 0, ctx->stream, K, ldk, rows, m,
                        planes, Mp, Kp);
-    static const int n_waves = mln_experiment("MELLON_AMD_GRAM_I8_WAVES") ? std::atoi(mln_experiment("MELLON_AMD_GRAM_I8_WAVES")) : 8;
     static bool attr_set = false;
     const int lds_bytes = 2 * GSTAGE;
     if (!attr_set) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_i8<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_i8<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      // (eight waves: wave tile 64 x 32, two waves per SIMD; the four-wave 64 x 64 variant was 12 % slower and is gone)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram_i8<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
       if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "gram_i8 LDS size", __FILE__, __LINE__);
       attr_set = true;
     }
@@ -322,12 +319,8 @@ int launch_gram_i8(mln_ctx* ctx, const double* K, int64_t ldk, int64_t rows, int
       const int n_wg = n_tiles * n_splits;
       const int grid = (n_wg + 7) / 8 * 8;
       const double scale = alpha / ((double)GQ_SCALE * (double)GQ_SCALE);
-      if (n_waves == 4)
-        hipLaunchKernelGGL(k_gram_i8<4>, dim3((unsigned)grid), dim3(256), lds_bytes, ctx->stream, planes, Mp, Kp, kchunk, d_tiles,
-                           n_tiles, n_wg, scale, parts, ldg, part_stride, m);
-      else
-        hipLaunchKernelGGL(k_gram_i8<8>, dim3((unsigned)grid), dim3(512), lds_bytes, ctx->stream, planes, Mp, Kp, kchunk, d_tiles,
-                           n_tiles, n_wg, scale, parts, ldg, part_stride, m);
+      hipLaunchKernelGGL(k_gram_i8<8>, dim3((unsigned)grid), dim3(512), lds_bytes, ctx->stream, planes, Mp, Kp, kchunk, d_tiles,
+                         n_tiles, n_wg, scale, parts, ldg, part_stride, m);
       e = hipGetLastError();
       if (e != hipSuccess) rc = mln_hip_fail(ctx, e, "k_gram_i8", __FILE__, __LINE__);
     }

@@ -700,7 +700,6 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(mln_dmalloc((void**)&nflag, sizeof(int)));
     chk(mln_dmalloc((void**)&flagged, sizeof(int) * (size_t)n));
   }
-  int64_t searched_rows = 0;
   if (km_bounds && rc == MLN_OK) {
     int64_t F = n;            // rows to search this sweep
     for (; it < max_iter && rc == MLN_OK; ++it) {
@@ -713,7 +712,6 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
         if (rc == MLN_OK) rc = launch_km_resolve(ctx, dx, all ? n : F, all ? nullptr : flagged, dc, m, d, xxs, ymax, prep, m2f, argc,
                                                  label, ub, lb, it == 0 ? nullptr : sums, it == 0 ? nullptr : counts, colscale);
         if (rc != MLN_OK) break;
-        searched_rows += all ? n : F;
       }
       if (it == 0) {
         chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
@@ -735,9 +733,6 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
       F = hf;
       if (hs <= scaled_tol) { ++it; break; }
     }
-    if (mln_experiment("MELLON_AMD_KM_VERBOSE"))
-      std::fprintf(stderr, "[kmeans] n=%lld m=%lld sweeps=%d rows searched=%lld (%.2f full sweeps)\n", (long long)n, (long long)m, it,
-                   (long long)searched_rows, (double)searched_rows / (double)n);
   } else
   for (; it < max_iter && rc == MLN_OK; ++it) {
     hipLaunchKernelGGL(k_sqnorm_rows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, m, d, cc);

@@ -130,12 +130,10 @@ __device__ __forceinline__ float vmin_raw(float a, float b) {
   return r;
 }
 
-// TOP2: also the second-smallest value per row (1-NN certification); else only the arg of the smallest (k-means labels).
-// FOLD: the operands carry -2 and |y|^2 (k_split_f16 roles 1 / 2): the accumulator IS the value, and the epilogue is two
-// VALU instructions per element (v_med3_f32 keeps the runner-up, v_min_f32 the winner).  With TOP2 the winner's column is
-// then only known per STAGE of 128 candidates and lane: out_arg = the stage's first candidate of that lane, the winner is
-// one of out_arg + {0, 32, 64, 96}; without TOP2 (labels) the exact column is tracked (three instructions per element).  (With the full 7-instruction epilogue the sweep took 510 ms at 1e6 x 1e6: VALU-bound.)
-template <bool TOP2, bool FOLD>
+// The sweep for PLAIN split operands (d > 61: no spare k slots for the folded |y|^2 and -2; the folded sweep is
+// rowmin_w64.hip).  TOP2: also the second-smallest value per row (1-NN certification); else only the arg of the smallest
+// (k-means labels).
+template <bool TOP2>
 __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict__ Xs, int64_t n,
                                                       const _Float16* __restrict__ Ys, int64_t m,
                                                       const float* __restrict__ yyf, int64_t self_offset, int exclude_self,
@@ -193,72 +191,6 @@ __global__ __launch_bounds__(512) void k_rowmin_f16x3(const _Float16* __restrict
     const bool more = col0 + RT < m;
     if (more) g_load(col0 + RT);
     const unsigned char* base = lds + buf * (RT * PITCH);
-    if (FOLD) {
-      float m1_in[16];
-      if (TOP2) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m1_in[r] = m1[r];
-      }
-      // two sub-tiles at a time, their MFMA chains interleaved: an accumulator is only touched every other instruction
-      // (a chain of dependent 32x32 MFMAs runs at their 64-cycle latency, not at the 32-cycle issue rate)
-#pragma unroll
-      for (int sp = 0; sp < RT / 64; ++sp) {
-        f16v acc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-        const unsigned char* brow0 = base + (sp * 64 + lr) * PITCH + 16 * lg;
-        const unsigned char* brow1 = brow0 + 32 * PITCH;
-        h8 bhi0[4], bhi1[4];
-        // the small cross terms first, the hi.hi terms on top: the fp32 roundings that matter are those of the last four
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          bhi0[ks] = *reinterpret_cast<const h8*>(brow0 + 32 * ks);
-          bhi1[ks] = *reinterpret_cast<const h8*>(brow1 + 32 * ks);
-          const h8 blo0 = *reinterpret_cast<const h8*>(brow0 + 2 * KP + 32 * ks);
-          const h8 blo1 = *reinterpret_cast<const h8*>(brow1 + 2 * KP + 32 * ks);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo0, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo1, acc[1], 0, 0, 0);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi0[ks], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi1[ks], acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi0[ks], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi1[ks], acc[1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int sub = 2 * sp + h;
-          // fast path: every candidate of the stage exists and none is the excluded one -- two instructions per element
-          const int64_t lo_c = col0 + sub * 32, d0 = row0w + self_offset;
-          const bool diag = exclude_self && lo_c < d0 + 32 && lo_c + 32 > d0;
-          const int col = (int)(col0 + sub * 32 + lr);
-          if (!diag && col0 + RT <= m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              if (TOP2) m2[r] = __builtin_amdgcn_fmed3f(m1[r], m2[r], acc[h][r]);
-              else a1[r] = (acc[h][r] < m1[r]) ? col : a1[r];          // (labels: the exact column, three instructions)
-              m1[r] = vmin_raw(m1[r], acc[h][r]);
-            }
-          } else {
-            const bool valid = col < m;                            // (a padded candidate row is all zero: value 0)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int64_t row = row0w + (r & 3) + 8 * (r >> 2) + 4 * lg;
-              const float sv = (valid && !(exclude_self && (int64_t)col == row + self_offset)) ? acc[h][r] : INFINITY;
-              if (TOP2) m2[r] = __builtin_amdgcn_fmed3f(m1[r], m2[r], sv);
-              else a1[r] = (sv < m1[r]) ? col : a1[r];
-              m1[r] = vmin_raw(m1[r], sv);
-            }
-          }
-        }
-      }
-      if (TOP2) {
-        const int stage_col = (int)(col0 + lr);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[r] = (m1[r] < m1_in[r]) ? stage_col : a1[r];
-      }
-    } else
 #pragma unroll
     for (int sub = 0; sub < RT / 32; ++sub) {
       f16v hh, cx;
@@ -651,35 +583,27 @@ int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* spli
   return MLN_OK;
 }
 
-// A folded sweep reports, with the runner-up tracked, the winner's column only per stage and lane: it is one of
-// arg + 32 q, q < rowmin_fold_candidates() -- 8 for the one-wave-per-SIMD sweep (256-candidate stages), 4 for the 8 x 32 shape.
-static bool rowmin_use_w64() {
-  static const bool w64 = !(mln_experiment("MELLON_AMD_ROWMIN_W64") && std::atoi(mln_experiment("MELLON_AMD_ROWMIN_W64")) == 0);
-  return w64;
-}
-int rowmin_fold_candidates() { return rowmin_use_w64() ? 8 : 4; }
+// A folded sweep (rowmin_w64.hip: 256-candidate stages) reports, with the runner-up tracked, the winner's column only per stage
+// and lane: it is one of arg + 32 q, q < rowmin_fold_candidates().
+int rowmin_fold_candidates() { return 8; }
 
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
                         int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold, const int* row_idx) {
   if (n <= 0 || m <= 0) return MLN_OK;
   if (m > 2147483647LL) { mln_set_error(ctx, "rowmin: too many candidates"); return MLN_ERR_UNSUPPORTED; }
+  const _Float16* X = reinterpret_cast<const _Float16*>(xs);
+  const _Float16* Y = reinterpret_cast<const _Float16*>(ys);
+  if (fold) return launch_rowmin_w64(ctx, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx);
   const size_t lds_bytes = (size_t)2 * RT * PITCH + 2 * RT * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    const void* fns[] = {reinterpret_cast<const void*>(k_rowmin_f16x3<true, false>), reinterpret_cast<const void*>(k_rowmin_f16x3<false, false>),
-                         reinterpret_cast<const void*>(k_rowmin_f16x3<true, true>), reinterpret_cast<const void*>(k_rowmin_f16x3<false, true>)};
-    for (const void* fn : fns) MLN_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_f16x3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_f16x3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr = true;
   }
   const dim3 grid((unsigned)((n + 255) / 256)), block(512);
-  const _Float16* X = reinterpret_cast<const _Float16*>(xs);
-  const _Float16* Y = reinterpret_cast<const _Float16*>(ys);
-  // folded operands: the one-wave-per-SIMD sweep (round 6); MELLON_AMD_ROWMIN_W64=0 keeps the 8 x 32 shape (A/B)
-  if (fold && rowmin_use_w64()) return launch_rowmin_w64(ctx, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx);
-  if (m2 && fold) hipLaunchKernelGGL((k_rowmin_f16x3<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
-  else if (m2) hipLaunchKernelGGL((k_rowmin_f16x3<true, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
-  else if (fold) hipLaunchKernelGGL((k_rowmin_f16x3<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
-  else hipLaunchKernelGGL((k_rowmin_f16x3<false, false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
+  if (m2) hipLaunchKernelGGL((k_rowmin_f16x3<true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, m2, arg, row_idx);
+  else hipLaunchKernelGGL((k_rowmin_f16x3<false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, yyf, self_offset, exclude_self, m1, nullptr, arg, row_idx);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

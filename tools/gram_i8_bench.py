@@ -9,7 +9,6 @@ ctx = _lib.default_context()
 rng = np.random.default_rng(0)
 a = rng.random((60000, 5000))
 got, ms = ctx.diag_gram_i8(a, reps=5)
-print("int8 gram ms", ms, "Pop/s (9 digit products, lower tiles)", 9 * 60000 * 5000 * 5000 / ms / 1e12,
-      "waves", os.environ.get("MELLON_AMD_GRAM_I8_WAVES", "8"))
+print("int8 gram ms", ms, "Pop/s (9 digit products, lower tiles)", 9 * 60000 * 5000 * 5000 / ms / 1e12)
 if "--fp64" in sys.argv:
     print("dgemm lower ms", ctx.diag_dgemm(1, 0, 5000, 5000, 60000, lower_only=1, split_k=7, reps=3))
