@@ -65,8 +65,10 @@ def nn_likelihood_constants(nn_distances, d):
     r = np.asarray(nn_distances, dtype=np.float64)
     d = np.asarray(d, dtype=np.float64)
     const = (d * np.log(np.pi) / 2) - gammaln(d / 2 + 1)
-    V = np.log(r) * d + const
-    Vdr = np.log(d) + ((d - 1) * np.log(r)) + const
+    from .util import log_nn
+    log_r = log_nn(nn_distances)
+    V = log_r * d + const
+    Vdr = np.log(d) + ((d - 1) * log_r) + const
     return np.ascontiguousarray(np.broadcast_to(V, r.shape)), np.ascontiguousarray(np.broadcast_to(Vdr, r.shape))
 
 

@@ -234,7 +234,8 @@ def compute_mu(nn_distances, d):
 def compute_ls(nn_distances):
     """reference parameters.py:602-613 (global mean of log nn when sharded)."""
     from .distributed import current
-    return float(np.exp(current().global_mean(np.log(np.asarray(nn_distances, dtype=np.float64))) + 3.0))
+    from .util import log_nn
+    return float(np.exp(current().global_mean(log_nn(nn_distances)) + 3.0))
 
 
 def compute_cov_func(cov_func_curry, ls, ls_time=None):

@@ -147,6 +147,9 @@ def validate_nn_distances(nn_distances, optional=False):
             return None
         raise ValueError("nn_distances are required but None is given.")
     nn = np.asarray(nn_distances, dtype=np.float64)
+    # the common case in two passes: smallest > 0 and largest finite (a NaN anywhere makes either comparison false)
+    if nn.ndim == 1 and nn.size and nn.min() > 0 and nn.max() < np.inf:
+        return nn
     bad = np.isnan(nn) | np.isinf(nn) | (nn <= 0)
     n_bad = int(bad.sum())
     if n_bad == nn.size:
