@@ -1119,6 +1119,13 @@ extern "C" int mln_kmeans_sklearn(mln_ctx* ctx, const double* x, int64_t n, int3
   return rc;
 }
 
+// A few Lloyd sweeps from given centres (device, m x d): the coarse clustering of the pruned 1-NN search (rowmin_f16.hip), where
+// any partition is valid and k-means++'s m dependent draws would cost more than the sweeps.
+int kmeans_lloyd_from(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int32_t max_iter, const double* init, double* centers) {
+  int32_t it = 0;
+  return kmeans_level(ctx, x, n, d, m, 0, max_iter, 0.0, init, centers, &it, nullptr);
+}
+
 // Reference: parameters.compute_landmarks -> sklearn.cluster.k_means(x, n_landmarks, n_init=1, random_state) (parameters.py:243-291).
 // Round 4, coarse to fine: with many cells per centre, Lloyd's ~200 sweeps over ALL cells mostly move centres that a
 // fraction of the cells already places well.  Above 64 cells per centre (and 2e5 cells) the seeding and a first Lloyd run

@@ -16,6 +16,7 @@
 // {hi, lo}) in registers for the whole sweep; candidate tiles (128 rows x 64 k x {hi, lo} halves = 32 KB) go through LDS
 // once per workgroup, double buffered, row pitch 272 B (conflict-free 16-byte reads).  v_mfma_f32_32x32x16_f16: both
 // operands are "k-contiguous rows" read with the same lane -> k map, so the k order inside the instruction is irrelevant.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,7 +28,7 @@ hipError_t mln_dfree_synced(void* p);   // alloc.hip: release after the caller s
 #include "rowmin_f16.h"
 // rowmin_w64.hip: the folded sweep, one wave per SIMD (round 6)
 int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16* Y, int64_t m, int64_t self_offset, int exclude_self,
-                      float* m1, float* m2, int* arg, const int* row_idx);
+                      float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order);
 #include "mln_options.h"
 
 namespace {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
 __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict__ Xs, int64_t cnt, const int* __restrict__ row_idx,
                                                      const _Float16* __restrict__ Ys, int64_t m, const float* __restrict__ fthr,
                                                      int* __restrict__ n_pairs, int cap, int* __restrict__ pair_row,
-                                                     int* __restrict__ pair_col) {
+                                                     int* __restrict__ pair_col, const uint32_t* __restrict__ stage_mask, int mask_words) {
   extern __shared__ unsigned char lds[];
   __shared__ int stop_s[2];     // (two slots by stage parity: the slot a stage reads is not written again before its barrier)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -339,7 +340,8 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
   h8 ahi[4], alo[4];
   {
     const int64_t ar0 = (row0w + lr < cnt) ? row0w + lr : cnt - 1;
-    const _Float16* src = Xs + (int64_t)row_idx[ar0] * ROWH + 8 * lg;
+    const int rid = row_idx[ar0];                                   // (< 0: a padding slot -- its threshold is -inf)
+    const _Float16* src = Xs + (int64_t)(rid < 0 ? 0 : rid) * ROWH + 8 * lg;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       ahi[ks] = *reinterpret_cast<const h8*>(src + 16 * ks);
@@ -368,18 +370,43 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
       *reinterpret_cast<v4i*>(lds + buf * (RT * PITCH) + r * PITCH + seg * 16) = st[q];
     }
   };
-  g_load(0);
-  l_store(0);
+  // stage_mask (the pruned search): bit b of this workgroup's row selects the candidates [256 b, 256 b + 256) -- two stages here
+  // (copied to LDS first: a global load per stage would sit on the critical path)
+  uint32_t* mrow = stage_mask ? reinterpret_cast<uint32_t*>(lds + 2 * RT * PITCH) : nullptr;
+  if (mrow) {
+    for (int w = tid; w < mask_words; w += 512) mrow[w] = stage_mask[(int64_t)blockIdx.x * mask_words + w];
+    __syncthreads();
+  }
+  auto next_stage = [&](int64_t s) -> int64_t {          // first selected stage >= s as a column; m when none
+    if (!mrow) return s * RT < m ? s * RT : m;
+    while (s * RT < m) {
+      const int64_t b = s >> 1;
+      const uint32_t w = __builtin_amdgcn_readfirstlane(mrow[b >> 5]);
+      if ((w >> (b & 31)) & 1u) return s * RT;
+      s = (w >> (b & 31)) == 0u ? ((b >> 5) + 1) * 64 : s + 1;       // nothing left in this word: on to the next one
+    }
+    return m;
+  };
+  // gridDim.y column segments (whole 256-candidate blocks): a workgroup walks its candidate stages one after the other whatever
+  // the number of its rows -- a list group whose rows must see every candidate is split over several workgroups
+  const int64_t nb256 = (m + 255) / 256;
+  const int64_t seg_lo = 256 * ((int64_t)blockIdx.y * nb256 / gridDim.y);
+  const int64_t m_full = m;
+  m = 256 * ((int64_t)(blockIdx.y + 1) * nb256 / gridDim.y);
+  if (m > m_full) m = m_full;
+  int64_t col0 = next_stage(seg_lo / RT);
+  if (col0 < m) { g_load(col0); l_store(0); }
   __syncthreads();
-  int buf = 0;
-  for (int64_t col0 = 0; col0 < m; col0 += RT, buf ^= 1) {
+  int buf = 0, stage_no = 0;
+  for (; col0 < m; buf ^= 1) {
     // A list that has outgrown its buffer is abandoned by the caller (exact search instead): stop feeding it.  Without this a
     // tight cluster of 50 000 mutual near-ties appends 2.5e9 pairs -- seconds of atomics on one address, and a 32-bit counter
     // that wraps to negative slots (found by tools/robustness_sweep_large.py as a write fault).  The test is the same for
     // (Thread 0 reads the counter before the barrier that ends a stage; everybody acts on that one value after it.)
     if (stop_s[buf]) return;
-    const bool more = col0 + RT < m;
-    if (more) g_load(col0 + RT);
+    const int64_t following = next_stage(col0 / RT + 1);
+    const bool more = following < m;
+    if (more) g_load(following);
     const unsigned char* base = lds + buf * (RT * PITCH);
 #pragma unroll
     for (int sp = 0; sp < RT / 64; ++sp) {
@@ -390,7 +417,7 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
       const unsigned char* brow1 = brow0 + 32 * PITCH;
       h8 bhi0[4], bhi1[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {          // (the same order of products as k_rowmin_f16x3: the same values)
+      for (int ks = 0; ks < 4; ++ks) {          // (the same order of products as the sweep: the same values)
         bhi0[ks] = *reinterpret_cast<const h8*>(brow0 + 32 * ks);
         bhi1[ks] = *reinterpret_cast<const h8*>(brow1 + 32 * ks);
         const h8 blo0 = *reinterpret_cast<const h8*>(brow0 + 2 * KP + 32 * ks);
@@ -424,8 +451,13 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
       }
     }
     if (more) l_store(buf ^ 1);
-    if (tid == 0) stop_s[buf ^ 1] = __hip_atomic_load(n_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cap ? 1 : 0;
+    // (every eighth stage: the counter's L2 round trip sat in front of every barrier -- 8 us per stage where the products take 3)
+    if (tid == 0 && (++stage_no & 7) == 0) {
+      const int over = __hip_atomic_load(n_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cap ? 1 : 0;
+      stop_s[0] = over; stop_s[1] = over;
+    }
     __syncthreads();
+    col0 = following;
   }
 }
 
@@ -450,7 +482,7 @@ __global__ __launch_bounds__(256) void k_nn_list_eval(const double* __restrict__
 __global__ void k_nn_list_finish(const int* __restrict__ flagged, int cnt, const unsigned long long* __restrict__ best,
                                  const double* __restrict__ fdd, double* __restrict__ out) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= cnt) return;
+  if (r >= cnt || flagged[r] < 0) return;          // (negative: a padding slot of the list sweep)
   const double b = __longlong_as_double((long long)best[r]);
   out[flagged[r]] = sqrt(fmin(b, fdd[r]));
 }
@@ -544,6 +576,167 @@ __global__ void k_scatter_rows(const double* __restrict__ vals, const int* __res
   if (r < cnt) out[idx[r]] = vals[r];
 }
 
+
+// ---- pruned exact 1-NN (round 6): coarse clusters + the triangle inequality decide which candidate BLOCKS a row block sweeps ----
+// cells are sorted by the coarse cluster they were assigned to; for x in cluster a and y in cluster b,
+// |x - y| >= |c_a - c_b| - r_a - r_b (r: the largest distance of a member to its centre, exact in fp64).
+struct NnPrune {
+  const int* label_sorted;      // n: cluster of every sorted cell
+  const int64_t* offsets;       // Kc + 1: first sorted cell of every cluster
+  const double* centers;        // Kc x d
+  const double* radius;         // Kc
+  int Kc;
+};
+
+// exact distance of every cell to the centre it was assigned to; cluster radii (max) and sizes
+__global__ __launch_bounds__(256) void k_prune_assign_stats(const double* __restrict__ x, int64_t n, int d, const double* __restrict__ c,
+                                                            const int* __restrict__ label, unsigned long long* __restrict__ radius_bits,
+                                                            int* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int l = label[i];
+  double dd = 0.0;
+  for (int k = 0; k < d; ++k) { const double t = x[i * d + k] - c[(int64_t)l * d + k]; dd = fma(t, t, dd); }
+  // (rounded UP a little: the radius must not be smaller than the true distance)
+  const double r = sqrt(dd) * (1.0 + 1e-12);
+  atomicMax(&radius_bits[l], (unsigned long long)__double_as_longlong(r));
+  atomicAdd(&counts[l], 1);
+}
+
+__global__ void k_prune_offsets(const int* __restrict__ counts, int Kc, int64_t* __restrict__ offsets, int* __restrict__ cursor) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int64_t s = 0;
+    for (int k = 0; k < Kc; ++k) { offsets[k] = s; s += counts[k]; cursor[k] = 0; }
+    offsets[Kc] = s;
+  }
+}
+
+// sorted position of every cell (order inside a cluster: arrival order -- the distances do not depend on it), its row copied there
+__global__ __launch_bounds__(256) void k_prune_scatter(const double* __restrict__ x, int64_t n, int d, const int* __restrict__ label,
+                                                       const int64_t* __restrict__ offsets, int* __restrict__ cursor,
+                                                       int* __restrict__ perm, int* __restrict__ label_sorted, double* __restrict__ xsorted) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int l = label[i];
+  int pos = 0;
+  if (lane == 0) pos = atomicAdd(&cursor[l], 1);
+  pos = __shfl(pos, 0, 64);
+  const int64_t p = offsets[l] + pos;
+  if (lane == 0) { perm[p] = (int)i; label_sorted[p] = l; }
+  for (int k = lane; k < d; k += 64) xsorted[p * d + k] = x[i * d + k];
+}
+
+// evenly spaced sample rows
+__global__ void k_prune_sample(const double* __restrict__ x, int64_t stride, int64_t ns, int d, double* __restrict__ out) {
+  const int64_t r = blockIdx.x;
+  if (r >= ns) return;
+  for (int k = threadIdx.x; k < d; k += blockDim.x) out[r * d + k] = x[r * stride * d + k];
+}
+
+// bit B of row B: every row block sweeps its own 256 cells first (the upper bounds)
+__global__ void k_prune_mask_own(uint32_t* __restrict__ mask, int nblk, int words) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nblk) mask[(int64_t)b * words + (b >> 5)] = 1u << (b & 31);      // (the matrix was zeroed)
+}
+
+// per row block of 256 sorted cells: the largest upper bound of a member's nearest-neighbour distance, in ORIGINAL units:
+// the best approximate value s~ = |y|^2 - 2 x.y inside the block satisfies s <= s~ + E, so dist^2 <= |x|^2 + s~ + E
+__global__ __launch_bounds__(256) void k_prune_block_bound(const double* __restrict__ xx, const float* __restrict__ m1, int64_t n,
+                                                           const double* __restrict__ yy_max, const double* __restrict__ prep,
+                                                           double* __restrict__ bub) {
+  __shared__ double red[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (i < n) {
+    const double E = rowmin_value_bound(sqrt(xx[i]), sqrt(yy_max[0]));
+    const double s = (double)m1[i];
+    v = isfinite(s) ? fmax(xx[i] + s + E, 0.0) : INFINITY;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double sc = prep[64];
+    const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    bub[blockIdx.x] = sqrt(m) / sc * (1.0 + 1e-9);
+  }
+}
+
+__global__ void k_prune_sqnorms(const double* __restrict__ x, int64_t n, int d, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) s = fma(x[i * d + k], x[i * d + k], s);
+  out[i] = s;
+}
+
+// dmin[B][b] = the smallest distance of a cell of row block B to centre b, from G = X C^T (fp64 matrix cores):
+// |x - c|^2 = |x|^2 - 2 x.c + |c|^2.  For y in cluster b and x in block B: |x - y| >= |x - c_b| - |y - c_b| >= dmin[B][b] - r_b --
+// in many dimensions far sharper than |c_a - c_b| - r_a - r_b (the cells of a cluster sit on a shell AROUND its centre).
+__global__ __launch_bounds__(256) void k_prune_block_dmin(const double* __restrict__ G, int Kc, const double* __restrict__ xxo,
+                                                          const double* __restrict__ cc, int64_t n, double* __restrict__ dmin) {
+  const int B = blockIdx.x;
+  const int64_t r_lo = (int64_t)B * 256, r_hi = r_lo + 256 < n ? r_lo + 256 : n;
+  for (int b = threadIdx.x; b < Kc; b += 256) {
+    double best = INFINITY;
+    const double c2 = cc[b];
+    // (rounded DOWN per cell: the three-term form cancels with an error of ~50 eps (|x|^2 + |c|^2) including the product's own)
+    for (int64_t i = r_lo; i < r_hi; ++i) {
+      const double xi = xxo[i];
+      best = fmin(best, (xi - 2.0 * G[i * Kc + b] + c2) - 1e-13 * (xi + c2));
+    }
+    dmin[(int64_t)B * Kc + b] = sqrt(fmax(best, 0.0)) * (1.0 - 1e-12);
+  }
+}
+
+// the candidate blocks of row block B: every block that holds a cell of a cluster b with dmin[B][b] - r_b < bound(B).
+// One workgroup per row block, a thread per cluster b.
+__global__ __launch_bounds__(256) void k_prune_mask(NnPrune pr, const double* __restrict__ dmin, int64_t n, const double* __restrict__ bub,
+                                                    uint32_t* __restrict__ mask, int words, int* __restrict__ n_stages,
+                                                    int* __restrict__ block_stages) {
+  extern __shared__ uint32_t bits[];
+  const int B = blockIdx.x;
+  for (int w = threadIdx.x; w < words; w += 256) bits[w] = 0u;
+  __syncthreads();
+  const double bound = bub[B];
+  for (int b = threadIdx.x; b < pr.Kc; b += 256) {
+    const int64_t o0 = pr.offsets[b], o1 = pr.offsets[b + 1];
+    if (o1 <= o0) continue;
+    const bool cand = !isfinite(bound) || dmin[(int64_t)B * pr.Kc + b] - pr.radius[b] < bound;
+    if (cand)
+      for (int64_t s = o0 >> 8; s <= (o1 - 1) >> 8; ++s) atomicOr(&bits[s >> 5], 1u << (s & 31));
+  }
+  __syncthreads();
+  int cnt = 0;
+  for (int w = threadIdx.x; w < words; w += 256) { mask[(int64_t)B * words + w] = bits[w]; cnt += __popc(bits[w]); }
+  if (cnt) { atomicAdd(n_stages, cnt); atomicAdd(&block_stages[B], cnt); }
+}
+
+// the list sweep's workgroup g handles the open rows flagged[256 g .. 256 g + 256) (ascending): the union of their row blocks' masks
+__global__ __launch_bounds__(256) void k_prune_union_mask(const int* __restrict__ flagged, int cnt, const uint32_t* __restrict__ mask, int words,
+                                                          uint32_t* __restrict__ out) {
+  const int g = blockIdx.x;
+  const int lo = g * 256, hi = lo + 256 < cnt ? lo + 256 : cnt;
+  for (int w = threadIdx.x; w < words; w += 256) {
+    uint32_t u = 0u;
+    int last = -1;
+    for (int sidx = lo; sidx < hi; ++sidx) {
+      const int f = flagged[sidx];
+      if (f < 0) continue;                                           // padding slot
+      const int B = f >> 8;
+      if (B != last) { u |= mask[(int64_t)B * words + w]; last = B; }
+    }
+    out[(int64_t)g * words + w] = u;
+  }
+}
+
+__global__ void k_prune_unsort(const double* __restrict__ vals, const int* __restrict__ perm, int64_t n, double* __restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) out[perm[p]] = vals[p];
+}
+
 }  // namespace
 
 size_t rowmin_split_bytes(int64_t rows) { return sizeof(_Float16) * (size_t)rows * ROWH; }
@@ -593,7 +786,7 @@ int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys,
   if (m > 2147483647LL) { mln_set_error(ctx, "rowmin: too many candidates"); return MLN_ERR_UNSUPPORTED; }
   const _Float16* X = reinterpret_cast<const _Float16*>(xs);
   const _Float16* Y = reinterpret_cast<const _Float16*>(ys);
-  if (fold) return launch_rowmin_w64(ctx, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx);
+  if (fold) return launch_rowmin_w64(ctx, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx, nullptr, 0, nullptr);
   const size_t lds_bytes = (size_t)2 * RT * PITCH + 2 * RT * sizeof(float);
   static bool attr = false;
   if (!attr) {
@@ -633,8 +826,8 @@ int launch_max_norm(mln_ctx* ctx, const double* xx, int64_t n, double* out) {
 
 // Exact 1-NN distances through the fp16 pre-filter (see the head of this file).  x: n x d, y: m x d (device), d <= 64.
 // stats (optional, host): [0] rows re-searched exactly.
-int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
-                             int64_t self_offset, double* out, double* stats) {
+static int nn_search_core(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                          int64_t self_offset, double* out, double* stats, const NnPrune* prune) {
   const bool same = (x == y && n == m);
   void *xs = nullptr, *ys = nullptr;
   double *xx = nullptr, *yy = nullptr, *ymax = nullptr, *prep = nullptr;
@@ -680,8 +873,70 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
   //  is a few per cent of |x||y| -- and took 249 ms against the three-product sweep's 360: its two-instruction epilogue is
   //  as long as its MFMAs.)
   int cnt = 0;
-  rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr);
-  if (rc != MLN_OK) return cleanup(rc);
+  const uint32_t* pr_mask = nullptr;      // the pruned search's candidate-block masks (one row per 256-row block)
+  int pr_words = 0;
+  if (prune && fold && same) {
+    // pass 1: every row block against its own 256 cells -> an upper bound of each member's nearest-neighbour distance;
+    // pass 2: the candidate blocks the triangle inequality cannot exclude for that bound (k_prune_mask)
+    const int nblk = (int)((n + 255) / 256), words = (nblk + 31) / 32;
+    uint32_t* mask = nullptr;
+    double* bub = nullptr;
+    int *nst = nullptr, *wg_order = nullptr;
+    if (!alloc((void**)&mask, sizeof(uint32_t) * (size_t)nblk * words) || !alloc((void**)&bub, sizeof(double) * nblk) ||
+        !alloc((void**)&nst, sizeof(int))) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+    if (hipMemsetAsync(mask, 0, sizeof(uint32_t) * (size_t)nblk * words, ctx->stream) != hipSuccess ||
+        hipMemsetAsync(nst, 0, sizeof(int), ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+    hipLaunchKernelGGL(k_prune_mask_own, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, ctx->stream, mask, nblk, words);
+    rc = launch_rowmin_w64(ctx, reinterpret_cast<const _Float16*>(xs), n, reinterpret_cast<const _Float16*>(ys), m, self_offset, 1, m1,
+                           nullptr, arg, nullptr, mask, words, nullptr);
+    if (rc != MLN_OK) return cleanup(rc);
+    hipLaunchKernelGGL(k_prune_block_bound, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, xx, m1, n, ymax, prep, bub);
+    {
+      const int Kc = prune->Kc;
+      double *G = nullptr, *dmin = nullptr, *xxo = nullptr, *cc = nullptr;
+      if (!alloc((void**)&G, sizeof(double) * (size_t)n * Kc) || !alloc((void**)&dmin, sizeof(double) * (size_t)nblk * Kc) ||
+          !alloc((void**)&xxo, sizeof(double) * n) || !alloc((void**)&cc, sizeof(double) * Kc)) {
+        mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP);
+      }
+      hipLaunchKernelGGL(k_prune_sqnorms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, d, xxo);
+      hipLaunchKernelGGL(k_prune_sqnorms, dim3((unsigned)((Kc + 255) / 256)), dim3(256), 0, ctx->stream, prune->centers, (int64_t)Kc, d, cc);
+      GemmArgs g{};
+      g.A = x; g.lda = d; g.B = prune->centers; g.ldb = d; g.C = G; g.ldc = Kc;
+      g.M = n; g.N = Kc; g.K = d; g.alpha = 1.0; g.beta = 0.0; g.ta = 0; g.tb = 1;
+      rc = launch_dgemm(ctx, g);
+      if (rc != MLN_OK) return cleanup(rc);
+      hipLaunchKernelGGL(k_prune_block_dmin, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, G, Kc, xxo, cc, n, dmin);
+      int* bst = nullptr;
+      if (!alloc((void**)&bst, sizeof(int) * nblk) || !alloc((void**)&wg_order, sizeof(int) * nblk)) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+      if (hipMemsetAsync(bst, 0, sizeof(int) * nblk, ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+      hipLaunchKernelGGL(k_prune_mask, dim3((unsigned)nblk), dim3(256), sizeof(uint32_t) * (size_t)words, ctx->stream, *prune, dmin, n, bub,
+                         mask, words, nst, bst);
+      // heaviest row blocks first (a block whose bound is infinite sweeps everything: not in the last round)
+      std::vector<int> hb((size_t)nblk), ord((size_t)nblk);
+      if (hipMemcpyAsync(hb.data(), bst, sizeof(int) * nblk, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+      for (int i = 0; i < nblk; ++i) ord[(size_t)i] = i;
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return hb[(size_t)a] > hb[(size_t)b]; });
+      if (hipMemcpyAsync(wg_order, ord.data(), sizeof(int) * nblk, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+    }
+    rc = launch_rowmin_w64(ctx, reinterpret_cast<const _Float16*>(xs), n, reinterpret_cast<const _Float16*>(ys), m, self_offset, 1, m1,
+                           m2, arg, nullptr, mask, words, wg_order);
+    if (rc != MLN_OK) return cleanup(rc);
+    pr_mask = mask; pr_words = words;
+    if (std::getenv("MELLON_AMD_TRACE") || stats) {
+      int hst = 0;
+      if (hipMemcpyAsync(&hst, nst, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        if (stats) stats[2] = (double)hst / ((double)nblk * (double)nblk);
+        if (std::getenv("MELLON_AMD_TRACE"))
+          std::fprintf(stderr, "[trace] nn_distances: %d of %lld (row block, candidate block) pairs swept (%.1f %%)\n", hst,
+                       (long long)nblk * nblk, 100.0 * hst / ((double)nblk * nblk));
+      }
+    }
+  } else {
+    rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr);
+    if (rc != MLN_OK) return cleanup(rc);
+  }
   hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
                      ymax, fold ? rowmin_fold_candidates() : 0, self_offset, prep, out, nflag, flagged, fthr, fdd);
   if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -692,26 +947,84 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
   // The open rows: a second fp16 sweep that LISTS the candidates below each row's threshold, exact distances of the listed
   // pairs.  A list that outgrows its buffer (masses of exact duplicates) falls through to the exact search below.
   bool listed = false;
+  int* flagged_compact = nullptr;
   if (cnt > 0 && fold && list_ok) {
+    // Pruned search: a candidate that could beat an open row's winner lies in a block its row block's mask selects (everything
+    // else is provably no nearer than a cell that block has seen).  The open rows are put in ascending order -- neighbours in
+    // the sorted order share clusters -- and each list workgroup sweeps the union of its rows' masks.  A list workgroup walks
+    // its candidate blocks one after the other whatever the number of its rows, and 1 % open rows are 37 workgroups of 256
+    // on 256 CUs: with few open rows a workgroup takes 32 of them (the other slots are padding with a -inf threshold), so
+    // that the unions stay small and every CU has a workgroup.
+    const uint32_t* lmask = nullptr;
+    int cnt_list = cnt;
+    if (pr_mask && cnt <= 262144) {
+      // (the compact list of open rows stays available for the exact fall-back below)
+      if (!alloc((void**)&flagged_compact, sizeof(int) * (size_t)cnt)) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+      if (hipMemcpyAsync(flagged_compact, flagged, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+      std::vector<int> hf((size_t)cnt);
+      std::vector<float> ht((size_t)cnt);
+      std::vector<double> hd((size_t)cnt);
+      if (hipMemcpyAsync(hf.data(), flagged, sizeof(int) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(ht.data(), fthr, sizeof(float) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(hd.data(), fdd, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+      std::vector<int> order((size_t)cnt);
+      for (int i = 0; i < cnt; ++i) order[(size_t)i] = i;
+      std::sort(order.begin(), order.end(), [&](int a, int b) { return hf[(size_t)a] < hf[(size_t)b]; });
+      // real rows per list workgroup: 32 or more, such that at most ~240 workgroups exist (one round on 256 CUs)
+      const int G = ((int64_t)cnt * 8 <= n && cnt <= 32768) ? std::max(32, (cnt + 239) / 240) : 256;
+      const int ngrp = (cnt + G - 1) / G;
+      cnt_list = ngrp * 256;
+      std::vector<int> sf((size_t)cnt_list, -1);
+      std::vector<float> stv((size_t)cnt_list, -INFINITY);
+      std::vector<double> sd((size_t)cnt_list, INFINITY);
+      for (int i = 0; i < cnt; ++i) {
+        const size_t slot = (size_t)(i / G) * 256 + (size_t)(i % G), o = (size_t)order[(size_t)i];
+        sf[slot] = hf[o]; stv[slot] = ht[o]; sd[slot] = hd[o];
+      }
+      uint32_t* um = nullptr;
+      if (!alloc((void**)&um, sizeof(uint32_t) * (size_t)ngrp * pr_words)) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+      if (hipMemcpyAsync(flagged, sf.data(), sizeof(int) * (size_t)cnt_list, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(fthr, stv.data(), sizeof(float) * (size_t)cnt_list, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(fdd, sd.data(), sizeof(double) * (size_t)cnt_list, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);      // (the host vectors go out of scope)
+      hipLaunchKernelGGL(k_prune_union_mask, dim3((unsigned)ngrp), dim3(256), 0, ctx->stream, flagged, cnt_list, pr_mask, pr_words, um);
+      lmask = um;
+      if (std::getenv("MELLON_AMD_TRACE")) {
+        std::vector<uint32_t> hu((size_t)ngrp * pr_words);
+        if (hipMemcpyAsync(hu.data(), um, sizeof(uint32_t) * hu.size(), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+            hipStreamSynchronize(ctx->stream) == hipSuccess) {
+          long long bitsum = 0;
+          for (uint32_t w : hu) bitsum += __builtin_popcount(w);
+          std::fprintf(stderr, "[trace] nn_distances: %d open rows in %d list workgroups of %d; their masks select %.1f %% of the candidate blocks\n",
+                       cnt, ngrp, G, 100.0 * (double)bitsum / ((double)ngrp * (double)((n + 255) / 256)));
+        }
+      }
+    }
     const int cap = (int)std::min<int64_t>((int64_t)32 * cnt + 65536, (int64_t)1 << 28);
     int *npairs = nullptr, *prow = nullptr, *pcol = nullptr;
     unsigned long long* best = nullptr;
     if (!alloc((void**)&npairs, sizeof(int)) || !alloc((void**)&prow, sizeof(int) * (size_t)cap) ||
-        !alloc((void**)&pcol, sizeof(int) * (size_t)cap) || !alloc((void**)&best, sizeof(unsigned long long) * (size_t)cnt)) {
+        !alloc((void**)&pcol, sizeof(int) * (size_t)cap) || !alloc((void**)&best, sizeof(unsigned long long) * (size_t)cnt_list)) {
       mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP);
     }
     if (hipMemsetAsync(npairs, 0, sizeof(int), ctx->stream) != hipSuccess ||
-        hipMemsetAsync(best, 0x7f, sizeof(unsigned long long) * (size_t)cnt, ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
-    const size_t lds_bytes = (size_t)2 * RT * PITCH;
+        hipMemsetAsync(best, 0x7f, sizeof(unsigned long long) * (size_t)cnt_list, ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+    if (lmask && pr_words > 4096) lmask = nullptr;                 // (the mask row lives in LDS)
+    const size_t lds_bytes = (size_t)2 * RT * PITCH + (lmask ? (size_t)pr_words * sizeof(uint32_t) : 0);
     static bool attr_l = false;
     if (!attr_l) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_list), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_list), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)2 * RT * PITCH + 4096 * sizeof(uint32_t))) != hipSuccess)
         return cleanup(MLN_ERR_HIP);
       attr_l = true;
     }
-    hipLaunchKernelGGL(k_rowmin_list, dim3((unsigned)((cnt + 255) / 256)), dim3(512), lds_bytes, ctx->stream,
-                       reinterpret_cast<const _Float16*>(xs), (int64_t)cnt, flagged, reinterpret_cast<const _Float16*>(ys), m, fthr,
-                       npairs, cap, prow, pcol);
+    // column segments: enough workgroups for every CU, and no workgroup with more than an eighth of the candidates
+    const int n_groups = (cnt_list + 255) / 256;
+    const int n_seg = (m >= 65536) ? std::max(8, std::min(64, 512 / std::max(1, n_groups))) : 1;
+    hipLaunchKernelGGL(k_rowmin_list, dim3((unsigned)n_groups, (unsigned)n_seg), dim3(512), lds_bytes, ctx->stream,
+                       reinterpret_cast<const _Float16*>(xs), (int64_t)cnt_list, flagged, reinterpret_cast<const _Float16*>(ys), m, fthr,
+                       npairs, cap, prow, pcol, lmask, pr_words);
     int np = 0;
     if (hipMemcpyAsync(&np, npairs, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn list", __FILE__, __LINE__));
@@ -721,7 +1034,7 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
       if (np > 0)
         hipLaunchKernelGGL(k_nn_list_eval, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, x, y, d, flagged, prow, pcol, np,
                            self_offset, best);
-      hipLaunchKernelGGL(k_nn_list_finish, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, flagged, cnt, best, fdd, out);
+      hipLaunchKernelGGL(k_nn_list_finish, dim3((unsigned)((cnt_list + 255) / 256)), dim3(256), 0, ctx->stream, flagged, cnt_list, best, fdd, out);
       listed = true;
     }
   }
@@ -731,11 +1044,85 @@ int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const dou
     int64_t* excl = nullptr;
     if (!alloc((void**)&xg, sizeof(double) * (size_t)cnt * d) || !alloc((void**)&og, sizeof(double) * cnt) ||
         !alloc((void**)&excl, sizeof(int64_t) * cnt)) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
-    hipLaunchKernelGGL(k_gather_rows_excl, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, x, d, flagged, cnt, self_offset, xg, excl);
+    const int* open_rows = flagged_compact ? flagged_compact : flagged;
+    hipLaunchKernelGGL(k_gather_rows_excl, dim3((unsigned)cnt), dim3(64), 0, ctx->stream, x, d, open_rows, cnt, self_offset, xg, excl);
     rc = launch_nn_distances_exact(ctx, xg, cnt, y, m, d, 0, excl, og);
     if (rc != MLN_OK) return cleanup(rc);
-    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, og, flagged, cnt, out);
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, og, open_rows, cnt, out);
   }
   if (hipGetLastError() != hipSuccess) return cleanup(MLN_ERR_HIP);
   return cleanup(MLN_OK);
+}
+
+int kmeans_lloyd_from(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int32_t max_iter, const double* init, double* centers);   // kmeans.hip
+
+// Exact 1-NN among the cells of ONE set (x against itself, the pair (i, i) excluded) with cluster pruning: a coarse k-means of a
+// sample (Kc centres, a few sweeps: any partition is valid, a good one prunes more), the cells sorted by cluster, and the
+// search of nn_search_core restricted per row block to the candidate blocks a triangle-inequality bound cannot exclude.  The
+// result is the exact distance for every row, as without pruning: an excluded candidate is provably no nearer than a cell the
+// row block has already seen; rows the certification leaves open are resolved against ALL candidates as before.
+static int nn_distances_pruned(mln_ctx* ctx, const double* x, int64_t n, int d, double* out, double* stats) {
+  int Kc = (int)std::min<int64_t>(1024, std::max<int64_t>(64, n / 2048));
+  const int64_t ns = std::min<int64_t>(n, (int64_t)64 * Kc), stride = n / ns;
+  std::vector<void*> owned;
+  auto alloc = [&](void** p, size_t bytes) -> bool {
+    if (mln_dmalloc(p, bytes > 0 ? bytes : 8) != hipSuccess) return false;
+    owned.push_back(*p);
+    return true;
+  };
+  auto cleanup = [&](int rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : owned) (void)mln_dfree_synced(p);
+    return rc;
+  };
+  double *sample = nullptr, *cent = nullptr, *prep = nullptr, *radius = nullptr, *xsorted = nullptr, *osorted = nullptr;
+  void *xs1 = nullptr, *cs = nullptr;
+  float *ccf = nullptr, *m1f = nullptr;
+  int *label = nullptr, *counts = nullptr, *cursor = nullptr, *perm = nullptr, *lsorted = nullptr;
+  int64_t* offsets = nullptr;
+  bool ok = alloc((void**)&sample, sizeof(double) * (size_t)ns * d) && alloc((void**)&cent, sizeof(double) * (size_t)Kc * d) &&
+            alloc((void**)&prep, sizeof(double) * ROWMIN_PREP_DOUBLES) && alloc((void**)&radius, sizeof(double) * Kc) &&
+            alloc((void**)&xsorted, sizeof(double) * (size_t)n * d) && alloc((void**)&osorted, sizeof(double) * n) &&
+            alloc(&xs1, rowmin_split_bytes(n)) && alloc(&cs, rowmin_split_bytes(Kc)) && alloc((void**)&ccf, sizeof(float) * Kc) &&
+            alloc((void**)&m1f, sizeof(float) * n) && alloc((void**)&label, sizeof(int) * n) && alloc((void**)&counts, sizeof(int) * Kc) &&
+            alloc((void**)&cursor, sizeof(int) * Kc) && alloc((void**)&perm, sizeof(int) * n) && alloc((void**)&lsorted, sizeof(int) * n) &&
+            alloc((void**)&offsets, sizeof(int64_t) * (Kc + 1));
+  if (!ok) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+  hipLaunchKernelGGL(k_prune_sample, dim3((unsigned)ns), dim3(64), 0, ctx->stream, x, stride, ns, d, sample);
+  // seeds: every 64th cell of the sample; four Lloyd sweeps (any partition is valid -- a better one only prunes more)
+  double* seeds = nullptr;
+  if (!alloc((void**)&seeds, sizeof(double) * (size_t)Kc * d)) { mln_set_error(ctx, "nn_distances: out of device memory"); return cleanup(MLN_ERR_HIP); }
+  hipLaunchKernelGGL(k_prune_sample, dim3((unsigned)Kc), dim3(64), 0, ctx->stream, sample, ns / Kc, (int64_t)Kc, d, seeds);
+  int rc = kmeans_lloyd_from(ctx, sample, ns, d, Kc, 4, seeds, cent);
+  if (rc != MLN_OK) return cleanup(rc);
+  // every cell to its (approximately) nearest centre: the folded sweep without the runner-up tracks the exact column
+  rc = rowmin_prepare(ctx, x, n, nullptr, 0, d, prep);
+  if (rc == MLN_OK) rc = launch_split_f16(ctx, x, n, d, xs1, nullptr, nullptr, 1, prep);
+  if (rc == MLN_OK) rc = launch_split_f16(ctx, cent, Kc, d, cs, nullptr, ccf, 2, prep);
+  if (rc == MLN_OK) rc = launch_rowmin_f16x3(ctx, xs1, n, cs, Kc, ccf, 0, 0, m1f, nullptr, label, 1, nullptr);
+  if (rc != MLN_OK) return cleanup(rc);
+  if (hipMemsetAsync(radius, 0, sizeof(double) * Kc, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(counts, 0, sizeof(int) * Kc, ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
+  hipLaunchKernelGGL(k_prune_assign_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, d, cent, label,
+                     reinterpret_cast<unsigned long long*>(radius), counts);
+  hipLaunchKernelGGL(k_prune_offsets, dim3(1), dim3(64), 0, ctx->stream, counts, Kc, offsets, cursor);
+  hipLaunchKernelGGL(k_prune_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, x, n, d, label, offsets, cursor, perm, lsorted,
+                     xsorted);
+  if (hipGetLastError() != hipSuccess) return cleanup(MLN_ERR_HIP);
+  NnPrune pr{lsorted, offsets, cent, radius, Kc};
+  rc = nn_search_core(ctx, xsorted, n, xsorted, n, d, 0, osorted, stats, &pr);
+  if (rc != MLN_OK) return cleanup(rc);
+  hipLaunchKernelGGL(k_prune_unsort, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, osorted, perm, n, out);
+  if (hipGetLastError() != hipSuccess) return cleanup(MLN_ERR_HIP);
+  return cleanup(MLN_OK);
+}
+
+int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,
+                             int64_t self_offset, double* out, double* stats) {
+  // one set against itself, folded operands, enough cells for the clustering to pay: the pruned search
+  // (MELLON_AMD_NN_PRUNE=0, experiment: every row block sweeps every candidate block)
+  const bool prune_ok = !(mln_experiment("MELLON_AMD_NN_PRUNE") && std::atoi(mln_experiment("MELLON_AMD_NN_PRUNE")) == 0);
+  if (prune_ok && x == y && n == m && self_offset == 0 && d <= KP - 3 && n >= (int64_t)1 << 18 && n <= (int64_t)1 << 25)
+    return nn_distances_pruned(ctx, x, n, d, out, stats);
+  return nn_search_core(ctx, x, n, y, m, d, self_offset, out, stats, nullptr);
 }

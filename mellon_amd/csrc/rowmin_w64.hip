@@ -58,11 +58,16 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
                                                     const _Float16* __restrict__ Ys, int64_t m,
                                                     int64_t self_offset, int exclude_self,
                                                     float* __restrict__ out_m1, float* __restrict__ out_m2,
-                                                    int* __restrict__ out_arg, const int* __restrict__ row_idx) {
+                                                    int* __restrict__ out_arg, const int* __restrict__ row_idx,
+                                                    const uint32_t* __restrict__ stage_mask, int mask_words,
+                                                    const int* __restrict__ wg_order) {
   extern __shared__ unsigned char lds[];                      // 2 x (RT x PITCH) candidate rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lg = lane >> 5;
-  const int64_t row0w = (int64_t)blockIdx.x * 256 + wave * 64;
+  // wg_order (with a stage mask): the row block this workgroup takes -- the blocks with the most candidate stages first, so
+  // that a block that must sweep everything does not start in the last round
+  const int64_t blk = wg_order ? (int64_t)wg_order[blockIdx.x] : (int64_t)blockIdx.x;
+  const int64_t row0w = blk * 256 + wave * 64;
   const int64_t d0 = row0w + self_offset;            // the excluded candidates of this wave's rows are [d0, d0 + 64)
   h8 ahi[2][4], alo[2][4];
 #pragma unroll
@@ -146,16 +151,39 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
     m1[rh][r] = vmin_raw(m1[rh][r], sv);
   };
 
-  g_load(0, 0);
+  // Which stages (blocks of RT candidates) this workgroup multiplies: all of them, or -- stage_mask -- the set bits of this
+  // workgroup's row of a bit matrix (the pruned 1-NN search: candidate blocks that a triangle-inequality bound cannot
+  // exclude, rowmin_f16.hip nn_distances_pruned).  Wave-uniform scalar work.
+  // (the workgroup's mask row is copied to LDS first: a global load per stage on the critical path cost a quarter of the sweep)
+  uint32_t* mrow = stage_mask ? reinterpret_cast<uint32_t*>(lds + 2 * RT * PITCH) : nullptr;
+  if (mrow) {
+    for (int w = tid; w < mask_words; w += 256) mrow[w] = stage_mask[blk * mask_words + w];
+    __syncthreads();
+  }
+  auto next_stage = [&](int64_t from_stage) -> int64_t {      // first selected stage >= from_stage, as a column; m when none
+    if (!mrow) return from_stage * RT;
+    int w = (int)(from_stage >> 5);
+    if (w >= mask_words) return m;
+    uint32_t bits = __builtin_amdgcn_readfirstlane(mrow[w]) & (0xffffffffu << (from_stage & 31));
+    while (bits == 0 && ++w < mask_words) bits = __builtin_amdgcn_readfirstlane(mrow[w]);
+    if (bits == 0) return m;
+    const int64_t c = ((int64_t)w * 32 + __builtin_ctz(bits)) * RT;
+    return c < m ? c : m;
+  };
+  int64_t col0 = next_stage(0);
+  if (col0 < m) {
+    g_load(col0, 0);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) l_store1(0, 0, q);
-  g_load(0, 1);
+    for (int q = 0; q < 8; ++q) l_store1(0, 0, q);
+    g_load(col0, 1);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) l_store1(0, 1, q);
+    for (int q = 0; q < 8; ++q) l_store1(0, 1, q);
+  }
   __syncthreads();
   int buf = 0;
-  for (int64_t col0 = 0; col0 < m; col0 += RT, buf ^= 1) {
-    const int64_t ncol0 = col0 + RT < m ? col0 + RT : col0;   // (no branch around the requests; past the end: a re-read nobody multiplies)
+  for (; col0 < m; buf ^= 1) {
+    const int64_t following = next_stage(col0 / RT + 1);
+    const int64_t ncol0 = following < m ? following : col0;   // (no branch around the requests; past the end: a re-read nobody multiplies)
     g_load(ncol0, 0);
     // The loop-invariant A operands and the staging registers belong in AGPRs (MFMA sources, global loads and LDS stores take
     // them directly); the 256 architectural VGPRs are for what the vector epilogue touches (accumulators, minima, columns).
@@ -222,6 +250,7 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
         for (int r = 0; r < 16; ++r) a1[rh][r] = (m1[rh][r] < m1_in[rh][r]) ? c0 : a1[rh][r];
     }
     __syncthreads();
+    col0 = following;
   }
   // merge the 32 column-lanes of each row (lanes with the same lg hold the same rows)
 #pragma unroll
@@ -249,18 +278,22 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
 
 }  // namespace
 
+// stage_mask (optional, device): a bit matrix, one row of mask_words 32-bit words per 256-row workgroup; bit s of a row selects
+// the candidate block [256 s, 256 s + 256)
 int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16* Y, int64_t m, int64_t self_offset, int exclude_self,
-                      float* m1, float* m2, int* arg, const int* row_idx) {
-  const size_t lds_bytes = (size_t)2 * RT * PITCH;
+                      float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order) {
+  if (stage_mask && mask_words > 4096) { mln_set_error(ctx, "rowmin: stage mask too wide for LDS"); return MLN_ERR_UNSUPPORTED; }
+  const size_t lds_max = (size_t)2 * RT * PITCH + 4096 * sizeof(uint32_t);
+  const size_t lds_bytes = (size_t)2 * RT * PITCH + (stage_mask ? (size_t)mask_words * sizeof(uint32_t) : 0);
   static bool attr = false;
   if (!attr) {
-    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr = true;
   }
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (m2) hipLaunchKernelGGL((k_rowmin_w64<true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx);
-  else hipLaunchKernelGGL((k_rowmin_w64<false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, (float*)nullptr, arg, row_idx);
+  if (m2) hipLaunchKernelGGL((k_rowmin_w64<true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx, stage_mask, mask_words, wg_order);
+  else hipLaunchKernelGGL((k_rowmin_w64<false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, (float*)nullptr, arg, row_idx, stage_mask, mask_words, wg_order);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

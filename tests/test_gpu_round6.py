@@ -141,3 +141,27 @@ def test_release_cached_memory_returns_the_pinned_pool(ctx):
     mellon.DensityEstimator(n_landmarks=100).fit_predict(est_x)     # a fit pins its m-vector mirrors and returns them to the pool
     _lib.release_cached_memory()
     mellon.DensityEstimator(n_landmarks=100).fit_predict(est_x)     # and the pool fills again from the driver
+
+
+@pytest.mark.parametrize("d", [10, 50])
+def test_pruned_nearest_neighbour_search_is_exact(ctx, d, monkeypatch):
+    """The cluster-pruned 1-NN search (2^18 cells and more: coarse clusters, cells sorted by cluster, candidate blocks the
+    triangle inequality cannot exclude) returns the exact distances: against a k-d tree (d = 10) and against the unpruned
+    device search (both d), with exact duplicates, a tight cluster far from the origin and an outlier among the cells."""
+    rng = np.random.default_rng(31)
+    n = 300_000
+    x = mo.gaussian_mixture(n, d, seed=12)
+    x[1000:1300] = x[5000:5300]                                    # exact duplicates
+    x[20000:21000] = 40.0 + 1e-3 * rng.normal(size=(1000, d))      # a tight cluster far away
+    x[77] = -500.0                                                 # an outlier: its neighbour is far
+    x = np.ascontiguousarray(x)
+    pruned = ctx.nn_distances(x)
+    monkeypatch.setenv("MELLON_AMD_NN_PRUNE", "0")
+    plain = ctx.nn_distances(x)
+    monkeypatch.delenv("MELLON_AMD_NN_PRUNE")
+    assert np.all(pruned[1000:1300] == 0.0) and np.all(pruned[5000:5300] == 0.0)
+    assert np.abs(pruned - plain).max() <= 1e-12 * np.abs(plain).max()
+    if d == 10:
+        from scipy.spatial import cKDTree
+        want = cKDTree(x).query(x, k=2, workers=-1)[0][:, 1]
+        assert np.abs(pruned - want).max() <= 1e-9 * want.max()

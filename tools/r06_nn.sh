@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06_nn; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_round6.py -m gpu -q -x -k pruned > $O/tests_pruned.log 2>&1 < /dev/null; tail -3 $O/tests_pruned.log
+timeout 900 python -m pytest tests -m gpu -q -x -k "nn or kmeans or rowmin or half_precision or c3_subsample or landmarks or labels" > $O/tests_nn.log 2>&1 < /dev/null; tail -3 $O/tests_nn.log
+bash tools/r06_nn_trace.sh
