@@ -776,9 +776,9 @@ int launch_split_f16(mln_ctx* ctx, const double* x, int64_t n, int d, void* spli
   return MLN_OK;
 }
 
-// A folded sweep (rowmin_w64.hip: 256-candidate stages) reports, with the runner-up tracked, the winner's column only per stage
-// and lane: it is one of arg + 32 q, q < rowmin_fold_candidates().
-int rowmin_fold_candidates() { return 8; }
+// A folded sweep (rowmin_w64.hip) reports, with the runner-up tracked, the winner's column only per half stage (128
+// candidates) and lane: it is one of arg + 32 q, q < rowmin_fold_candidates().
+int rowmin_fold_candidates() { return 4; }
 
 int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys, int64_t m, const float* yyf,
                         int64_t self_offset, int exclude_self, float* m1, float* m2, int* arg, int fold, const int* row_idx) {

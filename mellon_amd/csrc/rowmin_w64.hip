@@ -51,7 +51,7 @@ __device__ __forceinline__ float vmin_raw(float a, float b) {
 #define MLN_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // TOP2: the runner-up per row is tracked (1-NN certification) and the winner's column only per stage and lane (out_arg = the
-// stage's first candidate of that lane; the winner is one of out_arg + 32 q, q < ROWMIN_W64_CANDIDATES = 8); else (labels) the
+// half-stage's first candidate of that lane; the winner is one of out_arg + {0, 32, 64, 96}); else (labels) the
 // exact column.
 template <bool TOP2>
 __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__ Xs, int64_t n,
@@ -226,6 +226,19 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
       if (WRH >= 0 && i >= 12 && i < 20) l_store1(nbuf, WRH < 0 ? 0 : WRH, i - 12);                                \
       MLN_FENCE();                                                                                                 \
     }
+    // TOP2: the winner's column is recorded per HALF stage (128 candidates) and lane: after the epilogue of sub-tile 3 (in the
+    // step of sub-tile 4) and at the end of the stage -- the winner is one of arg + {0, 32, 64, 96}, four exact evaluations per
+    // row in k_nn_certify / k_km_resolve.  Measured at C3 (1-NN sweep + certification | k-means sweeps + resolve, ms): per whole
+    // stage (eight candidates) 41 + 14 | 202 + 90; per half stage, between the steps as here 50 + 8 | 227 + 52; per half stage with
+    // the updates placed inside the steps' slots 55 + 8 | 244 + 52 (five vector instructions per MFMA: past the issue knee).
+#define MLN_HALF_STAGE_ARG(REC)                                                                                    \
+    if (TOP2) {                                                                                                    \
+      _Pragma("unroll") for (int rh = 0; rh < 2; ++rh)                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                             \
+        a1[rh][r] = (m1[rh][r] < m1_in[rh][r]) ? (REC) : a1[rh][r];                                                \
+        m1_in[rh][r] = m1[rh][r];                                                                                  \
+      }                                                                                                            \
+    }
 #define MLN_STAGE(MASKED)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) read_b1(b0, base, 0, i);                                         \
     MLN_FENCE();                                                                                                   \
@@ -236,19 +249,16 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
     g_load(ncol0, 1);                                                                                              \
     MLN_FENCE();                                                                                                   \
     MLN_STEP(accA, b0, accB, 3, b1, 5, -1, MASKED)                                                                 \
+    MLN_HALF_STAGE_ARG(c0)                                                                                         \
     MLN_STEP(accB, b1, accA, 4, b0, 6, -1, MASKED)                                                                 \
     MLN_STEP(accA, b0, accB, 5, b1, 7, -1, MASKED)                                                                 \
     MLN_STEP(accB, b1, accA, 6, b0, -1, 1, MASKED)                                                                 \
     _Pragma("unroll") for (int e = 0; e < 32; ++e) epi1(accB[e >> 4], e >> 4, e & 15, 7, c0, MASKED);
     if (plain) { MLN_STAGE(false) } else { mask_prepare(col0); MLN_STAGE(true) }
+    MLN_HALF_STAGE_ARG(c0 + 128)
 #undef MLN_STAGE
 #undef MLN_STEP
-    if (TOP2) {
-#pragma unroll
-      for (int rh = 0; rh < 2; ++rh)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a1[rh][r] = (m1[rh][r] < m1_in[rh][r]) ? c0 : a1[rh][r];
-    }
+#undef MLN_HALF_STAGE_ARG
     __syncthreads();
     col0 = following;
   }

@@ -1,0 +1,35 @@
+#!/bin/bash
+# kernel-level breakdown of mln_kmeans at the C3 shape (1e6 x 50 -> 5000 centres)
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r06_km_trace; mkdir -p $O
+cat > $O/probe.py <<'PY'
+import sys, time
+sys.path.insert(0, ".")
+import bench
+from mellon_amd import _lib
+ctx = _lib.default_context()
+x = bench.gaussian_mixture(1_000_000, 50, 3); xd = ctx.to_device(x)
+for rep in range(2):
+    t0 = time.perf_counter(); c, it, inertia = ctx.kmeans(xd, 5000, seed=42, return_info=True); print("kmeans", round(time.perf_counter() - t0, 3), "s", it, "sweeps", inertia, flush=True)
+PY
+timeout 600 rocprofv3 --kernel-trace -d $O/db -o km -- python $O/probe.py > $O/log.txt 2>&1
+DB=$(find $O/db -name "*.db" | head -1)
+python - $DB > $O/km_kernels.txt <<'PY'
+import sqlite3, sys, re
+from collections import defaultdict
+con = sqlite3.connect(sys.argv[1])
+rows = con.execute("select name, start, end from kernels order by start").fetchall()
+# second call: the second half of the launches by time gap -- find the largest gap between launches
+gaps = [(rows[i + 1][1] - rows[i][2], i) for i in range(len(rows) - 1)]
+cut = max(gaps)[1] + 1
+rows = rows[cut:]
+t0, t1 = rows[0][1], rows[-1][2]
+tot = defaultdict(lambda: [0, 0.0]); idle = 0.0; prev = rows[0][1]
+for n, s, e in rows:
+    n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n); n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)[:70]
+    tot[n][0] += 1; tot[n][1] += (e - s) / 1e6; idle += max(s - prev, 0) / 1e6; prev = e
+print(f"span {(t1 - t0) / 1e6:.1f} ms, kernels busy {sum(v[1] for v in tot.values()):.1f} ms, idle between launches {idle:.1f} ms, {len(rows)} launches")
+for n, (c, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:22]:
+    print(f"{n:72s} {c:6d} {ms:9.3f} ms")
+PY
+rm -rf $O/db; cat $O/km_kernels.txt; grep kmeans $O/log.txt
