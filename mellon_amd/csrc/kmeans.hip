@@ -11,6 +11,7 @@
 //             structure), update = FIXED-POINT integer atomics into m x d sums (round 4c: any summation order gives
 //             the same bits -- the centres are bit-reproducible), stop when the summed squared centre shift
 //             <= tol * mean feature variance (sklearn's rule) or after max_iter sweeps.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -455,7 +456,10 @@ __global__ void k_finish(double* __restrict__ c, const double* __restrict__ sums
   if (delta) delta[j] = sqrt(s);
   sq[j] = s;
 }
-__global__ __launch_bounds__(256) void k_km_sum_fixed(const double* __restrict__ v, int64_t m, double* __restrict__ out) {
+// kstate (sweeps queued ahead of the host, see kmeans_level): [0] converged, [1] sweeps counted.  A counted sweep whose total
+// movement is <= tol is the last: the kernels of the sweeps queued behind it find nothing to do.
+__global__ __launch_bounds__(256) void k_km_sum_fixed(const double* __restrict__ v, int64_t m, double* __restrict__ out,
+                                                      double tol = 0.0, int* __restrict__ kstate = nullptr) {
   __shared__ double part[256];
   double s = 0.0;
   for (int64_t j = threadIdx.x; j < m; j += 256) s += v[j];
@@ -465,7 +469,13 @@ __global__ __launch_bounds__(256) void k_km_sum_fixed(const double* __restrict__
     if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = part[0];
+  if (threadIdx.x == 0) {
+    out[0] = part[0];
+    if (kstate && !kstate[0]) {
+      kstate[1] += 1;
+      if (part[0] <= tol) kstate[0] = 1;
+    }
+  }
 }
 
 // ---- Lloyd's iterations with distance bounds (Hamerly 2010: the same assignments, most of them without a search) --------
@@ -499,16 +509,21 @@ __global__ __launch_bounds__(256) void k_km_delta_stats(const double* __restrict
 
 // Eight lanes per cell (each reads every eighth coordinate: a wave touches 8 consecutive rows of x, coalesced); the exact
 // distance to the own centre is taken for EVERY cell (n d reads: a tenth of a search sweep), so ub is always tight.
-// A workgroup walks KB_ROWS cells and appends its flagged ones with ONE atomic (one per wave was 125 000 atomics on the
-// same address per sweep: 1.2 ms of a 1.4 ms kernel).
+// A workgroup walks KB_ROWS cells and writes its flagged ones, in row order, to ITS segment of flagged_tmp and their number to
+// wg_count; k_km_flag_scan / k_km_flag_compact close the gaps: the list of open rows is in row order (the same from run to
+// run -- the pruned sweep's row blocks are cut from it), with no atomics.
 constexpr int KB_ROWS = 512, KB_IT = KB_ROWS / 32;
 __global__ __launch_bounds__(256) void k_km_bounds(const double* __restrict__ x, int64_t n, int d, const double* __restrict__ c,
                                                    const int* __restrict__ label, double* __restrict__ ub, double* __restrict__ lb,
                                                    const double* __restrict__ delta, const double* __restrict__ dstat,
-                                                   int* __restrict__ n_flag, int* __restrict__ flagged) {
+                                                   const int* __restrict__ kstate, int* __restrict__ wg_count,
+                                                   int* __restrict__ flagged_tmp) {
   __shared__ unsigned long long masks[KB_IT * 4];     // per (iteration, wave): ballot of the flagged groups' first lanes
   __shared__ int offs[KB_IT * 4];
-  __shared__ int base_s;
+  if (kstate[0]) {                                    // converged: no row is open
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = 0;
+    return;
+  }
   const int sub = threadIdx.x & 7, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const double d1 = dstat[0], d2 = dstat[1];
   const int amax = (int)dstat[2];
@@ -537,19 +552,141 @@ __global__ __launch_bounds__(256) void k_km_bounds(const double* __restrict__ x,
   if (threadIdx.x == 0) {
     int run = 0;
     for (int e = 0; e < KB_IT * 4; ++e) { offs[e] = run; run += __popcll(masks[e]); }
-    base_s = run > 0 ? atomicAdd(n_flag, run) : 0;
+    wg_count[blockIdx.x] = run;
   }
   __syncthreads();
   if (threadIdx.x < KB_IT * 4) {
     const int e = threadIdx.x, it = e >> 2, w = e & 3;
     unsigned long long mk = masks[e];
-    int slot = base_s + offs[e];
+    int slot = blockIdx.x * KB_ROWS + offs[e];
     while (mk) {
       const int ln = __ffsll((long long)mk) - 1;
       mk &= mk - 1;
-      flagged[slot++] = (int)(row0 + it * 32 + w * 8 + (ln >> 3));
+      flagged_tmp[slot++] = (int)(row0 + it * 32 + w * 8 + (ln >> 3));
     }
   }
+}
+
+// exclusive prefix sums of the workgroups' counts (one workgroup; nwg <= 2^16 at 2^25 cells), total -> n_flag
+__global__ __launch_bounds__(1024) void k_km_flag_scan(const int* __restrict__ wg_count, int nwg, int* __restrict__ wg_off,
+                                                       int* __restrict__ n_flag) {
+  __shared__ int part[1024];
+  const int per = (nwg + 1023) / 1024, lo = threadIdx.x * per, hi = (lo + per < nwg) ? lo + per : nwg;
+  int s = 0;
+  for (int e = lo; e < hi; ++e) s += wg_count[e];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 1; w < 1024; w <<= 1) {
+    const int v = ((int)threadIdx.x >= w) ? part[threadIdx.x - w] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+  for (int e = lo; e < hi; ++e) { wg_off[e] = run; run += wg_count[e]; }
+  if (threadIdx.x == 1023) n_flag[0] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_km_flag_compact(const int* __restrict__ flagged_tmp, const int* __restrict__ wg_count,
+                                                         const int* __restrict__ wg_off, int* __restrict__ flagged) {
+  const int cnt = wg_count[blockIdx.x], off = wg_off[blockIdx.x];
+  for (int k = threadIdx.x; k < cnt; k += 256) flagged[off + k] = flagged_tmp[blockIdx.x * KB_ROWS + k];
+}
+
+// ---- pruned sweeps (round 6): which 256-centre stages of the sweep can hold a closer centre ------------------------------------
+// The centres are swept in a fixed geometric order (cperm: recursive bisection of the first centres along the coordinate of
+// largest spread, cut at multiples of 256 -- a stage of the sweep is a compact group of centres) and the cells are stored in
+// the order of their first label's position, so a 256-row block of the open-row list has few distinct labels, all close.
+// Per sweep: leaf l (32 centres) has centroid g_l and radius rho_l; cdist[a][s] = min over the eight leaves of stage s of
+// |c_a - g_l| - rho_l  <=  |c_a - c_j| for every j in s.
+// A row x with label a and u = |x - c_a| needs stage s only if cdist[a][s] < 2 u (Elkan 2003, lemma 1: |c_a - c_j| >= 2 u
+// implies |x - c_j| >= u); a block sweeps the union over its rows, and the centres of a skipped stage are at least
+// cdist[a][s] - u away from x (the lower bound k_km_resolve keeps for them).
+__global__ void k_km_gather_centres(const double* __restrict__ c, const int* __restrict__ cperm, int64_t m, int d,
+                                    double* __restrict__ cp) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * d) return;
+  const int64_t p = t / d;
+  cp[t] = c[(int64_t)cperm[p] * d + (t - p * d)];
+}
+// one workgroup per stage of the permuted centres cp; a stage is eight LEAVES of 32 centres (the bisection goes down to them):
+// centroid (sums in a fixed order) and radius of every leaf
+__global__ __launch_bounds__(256) void k_km_leaf_geom(const double* __restrict__ cp, int64_t m, int d, double* __restrict__ g,
+                                                      double* __restrict__ rho) {
+  __shared__ double gs[8][64];
+  const int64_t p0 = (int64_t)blockIdx.x * 256;
+  for (int e = threadIdx.x; e < 8 * d; e += 256) {
+    const int leaf = e / d, k = e - leaf * d;
+    const int64_t q0 = p0 + 32 * leaf;
+    const int cnt = (int)((m - q0 < 32) ? (m - q0 > 0 ? m - q0 : 0) : 32);
+    double s = 0.0;
+    for (int p = 0; p < cnt; ++p) s += cp[(q0 + p) * d + k];
+    const double mean = cnt > 0 ? s / cnt : 0.0;
+    gs[leaf][k] = mean;
+    g[((int64_t)blockIdx.x * 8 + leaf) * d + k] = mean;
+  }
+  __syncthreads();
+  const int leaf = threadIdx.x >> 5;
+  const int64_t p = p0 + threadIdx.x;
+  double dd = 0.0;
+  if (p < m)
+    for (int k = 0; k < d; ++k) { const double t = cp[p * d + k] - gs[leaf][k]; dd = fma(t, t, dd); }
+  for (int off = 1; off < 32; off <<= 1) dd = fmax(dd, __shfl_xor(dd, off, 64));
+  if ((threadIdx.x & 31) == 0) rho[(int64_t)blockIdx.x * 8 + leaf] = (p < m) ? sqrt(dd) : -1.0;     // (-1: an empty leaf)
+}
+// cdist[a][s] = min over the leaves l of stage s of |c_a - g_l| - rho_l, rounded down
+__global__ void k_km_cdist(const double* __restrict__ c, int64_t m, int d, const double* __restrict__ g,
+                           const double* __restrict__ rho, int S, double* __restrict__ cdist) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * S) return;
+  const int64_t a = t / S;
+  const int s = (int)(t - a * S);
+  double best = INFINITY;
+  for (int l = 8 * s; l < 8 * s + 8; ++l) {
+    if (rho[l] < 0.0) continue;
+    double dd = 0.0;
+    for (int k = 0; k < d; ++k) { const double u = c[a * d + k] - g[(int64_t)l * d + k]; dd = fma(u, u, dd); }
+    const double dist = sqrt(dd);
+    best = fmin(best, (dist - rho[l]) - 1e-12 * (dist + rho[l]));
+  }
+  cdist[t] = best;
+}
+// one workgroup per 256 rows of the open-row list: the union of the stages its rows need
+__global__ __launch_bounds__(256) void k_km_block_mask(const int* __restrict__ flagged, const int* __restrict__ n_flag,
+                                                       const int* __restrict__ label, const double* __restrict__ ub,
+                                                       const double* __restrict__ cdist, int S, int words,
+                                                       uint32_t* __restrict__ mask) {
+  __shared__ uint32_t acc[8];
+  const int F = n_flag[0];
+  if ((int64_t)blockIdx.x * 256 >= F) return;
+  if (threadIdx.x < 8) acc[threadIdx.x] = 0u;
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < F) {
+    const int i = flagged[r];
+    const double* cd = cdist + (int64_t)label[i] * S;
+    const double lim = 2.0 * ub[i] * (1.0 + 1e-12);
+    for (int w = 0; w < words; ++w) {
+      uint32_t bits = 0u;
+      for (int b = 0; b < 32 && 32 * w + b < S; ++b) bits |= (cd[32 * w + b] <= lim) ? (1u << b) : 0u;
+      if (bits) atomicOr(&acc[w], bits);
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < words) mask[(int64_t)blockIdx.x * words + threadIdx.x] = acc[threadIdx.x];
+}
+__global__ void k_km_gather_rows(const double* __restrict__ x, const int* __restrict__ perm, int64_t n, int d, double* __restrict__ xs) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * d) return;
+  const int64_t r = t / d;
+  xs[t] = x[(int64_t)perm[r] * d + (t - r * d)];
+}
+__global__ void k_km_gather_state(const int* __restrict__ perm, int64_t n, const int* __restrict__ label, const double* __restrict__ ub,
+                                  const double* __restrict__ lb, int* __restrict__ label_s, double* __restrict__ ub_s,
+                                  double* __restrict__ lb_s) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int i = perm[r];
+  label_s[r] = label[i]; ub_s[r] = ub[i]; lb_s[r] = lb[i];
 }
 
 struct XorShift {
@@ -559,6 +696,37 @@ struct XorShift {
   double uniform() { return (double)(next() >> 11) / 9007199254740992.0; }
 };
 }  // namespace
+
+// The order in which the pruned sweeps walk the centres: recursive bisection along the coordinate of largest variance, cut at
+// multiples of 256 (a stage of the sweep) and, inside a stage, of 32 (a leaf); ids ascending inside a leaf.
+static void centre_sweep_order(const double* c, int m, int d, int* order) {
+  for (int j = 0; j < m; ++j) order[j] = j;
+  struct Seg { int lo, hi; };
+  std::vector<Seg> todo{{0, m}};
+  while (!todo.empty()) {
+    const Seg sg = todo.back();
+    todo.pop_back();
+    const int len = sg.hi - sg.lo;
+    if (len <= 32) { std::sort(order + sg.lo, order + sg.hi); continue; }
+    const int unit = len > 256 ? 256 : 32;
+    int best = 0;
+    double best_var = -1.0;
+    for (int k = 0; k < d; ++k) {
+      double mean = 0.0, var = 0.0;
+      for (int p = sg.lo; p < sg.hi; ++p) mean += c[(size_t)order[p] * d + k];
+      mean /= len;
+      for (int p = sg.lo; p < sg.hi; ++p) { const double t = c[(size_t)order[p] * d + k] - mean; var += t * t; }
+      if (var > best_var) { best_var = var; best = k; }
+    }
+    const int left = (((len + unit - 1) / unit) / 2) * unit;
+    std::nth_element(order + sg.lo, order + sg.lo + left, order + sg.hi, [&](int a, int b) {
+      const double va = c[(size_t)a * d + best], vb = c[(size_t)b * d + best];
+      return va < vb || (va == vb && a < b);
+    });
+    todo.push_back({sg.lo, sg.lo + left});
+    todo.push_back({sg.lo + left, sg.hi});
+  }
+}
 
 // One level: k-means++ seeding (or the centres in `init`, device, m x d) followed by Lloyd's iterations on the n cells at x.
 static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int64_t m, int64_t seed,
@@ -700,38 +868,124 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(mln_dmalloc((void**)&nflag, sizeof(int)));
     chk(mln_dmalloc((void**)&flagged, sizeof(int) * (size_t)n));
   }
+  // Pruned sweeps (see k_km_gather_centres): 1024 centres and more, at most 128 stages.  MELLON_AMD_KM_PRUNE=0 disables.
+  const int S = (int)((m + 255) / 256), mask_words = (S + 31) / 32;
+  const bool km_prune = km_bounds && m >= 1024 && S <= 128 && n >= 65536 && n <= 2147483647LL &&
+                        !(mln_experiment("MELLON_AMD_KM_PRUNE") && std::atoi(mln_experiment("MELLON_AMD_KM_PRUNE")) == 0);
+  int *kstate = nullptr, *wg_count = nullptr, *wg_off = nullptr, *flagged_tmp = nullptr, *cperm = nullptr, *perm = nullptr, *label_s = nullptr;
+  double *dcp = nullptr, *sg = nullptr, *srho = nullptr, *cdist = nullptr, *dxs = nullptr, *ub_s = nullptr, *lb_s = nullptr;
+  uint32_t* smask = nullptr;
+  const int nwg = (int)((n + KB_ROWS - 1) / KB_ROWS);
   if (km_bounds && rc == MLN_OK) {
-    int64_t F = n;            // rows to search this sweep
-    for (; it < max_iter && rc == MLN_OK; ++it) {
-      rc = launch_split_f16(ctx, dc, m, d, csplit, yy, ccf, 2, prep);
-      if (rc == MLN_OK) rc = launch_max_norm(ctx, yy, m, ymax);
-      if (rc != MLN_OK) break;
-      const bool all = F >= n;
-      if (F > 0) {
-        rc = launch_rowmin_f16x3(ctx, xsplit, all ? n : F, csplit, m, ccf, 0, 0, m1f, m2f, argc, 1, all ? nullptr : flagged);
-        if (rc == MLN_OK) rc = launch_km_resolve(ctx, dx, all ? n : F, all ? nullptr : flagged, dc, m, d, xxs, ymax, prep, m2f, argc,
-                                                 label, ub, lb, it == 0 ? nullptr : sums, it == 0 ? nullptr : counts, colscale);
-        if (rc != MLN_OK) break;
-      }
-      if (it == 0) {
-        chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
-        chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
-        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts, colscale);
-      }
+    chk(mln_dmalloc((void**)&kstate, sizeof(int) * 2));
+    chk(mln_dmalloc((void**)&wg_count, sizeof(int) * (size_t)nwg));
+    chk(mln_dmalloc((void**)&wg_off, sizeof(int) * (size_t)nwg));
+    chk(mln_dmalloc((void**)&flagged_tmp, sizeof(int) * (size_t)nwg * KB_ROWS));
+    if (rc == MLN_OK) chk(hipMemsetAsync(kstate, 0, sizeof(int) * 2, st));
+  }
+  if (km_prune && rc == MLN_OK) {
+    chk(mln_dmalloc((void**)&cperm, sizeof(int) * (size_t)m));
+    chk(mln_dmalloc((void**)&perm, sizeof(int) * (size_t)n));
+    chk(mln_dmalloc((void**)&label_s, sizeof(int) * (size_t)n));
+    chk(mln_dmalloc((void**)&ub_s, sizeof(double) * (size_t)n));
+    chk(mln_dmalloc((void**)&lb_s, sizeof(double) * (size_t)n));
+    chk(mln_dmalloc((void**)&dcp, sizeof(double) * (size_t)m * d));
+    chk(mln_dmalloc((void**)&sg, sizeof(double) * (size_t)S * 8 * d));
+    chk(mln_dmalloc((void**)&srho, sizeof(double) * (size_t)S * 8));
+    chk(mln_dmalloc((void**)&cdist, sizeof(double) * (size_t)m * S));
+    chk(mln_dmalloc((void**)&dxs, sizeof(double) * (size_t)n * d));
+    chk(mln_dmalloc((void**)&smask, sizeof(uint32_t) * (size_t)((n + 255) / 256) * mask_words));
+  }
+  if (km_bounds && rc == MLN_OK && max_iter > 0) {
+    const double* xl = dx;        // the cells in the order the sweeps walk them (sorted by first label when pruning)
+    bool pruning = false;
+    // the part of a sweep after the assignment: new centres, their movement, the bounds, the list of open rows
+    auto tail = [&]() {
       chk(hipMemsetAsync(shift, 0, sizeof(double), st));
-      chk(hipMemsetAsync(nflag, 0, sizeof(int), st));
       hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, sq, delta, colscale);
-      hipLaunchKernelGGL(k_km_sum_fixed, dim3(1), dim3(256), 0, st, sq, m, shift);
+      hipLaunchKernelGGL(k_km_sum_fixed, dim3(1), dim3(256), 0, st, sq, m, shift, scaled_tol, kstate);
       hipLaunchKernelGGL(k_km_delta_stats, dim3(1), dim3(256), 0, st, delta, m, dstat);
-      hipLaunchKernelGGL(k_km_bounds, dim3((unsigned)((n + KB_ROWS - 1) / KB_ROWS)), dim3(256), 0, st, dx, n, d, dc, label, ub, lb, delta, dstat,
-                         nflag, flagged);
-      double hs = 0.0;
-      int hf = 0;
-      chk(hipMemcpyAsync(&hs, shift, sizeof(double), hipMemcpyDeviceToHost, st));
-      chk(hipMemcpyAsync(&hf, nflag, sizeof(int), hipMemcpyDeviceToHost, st));
+      hipLaunchKernelGGL(k_km_bounds, dim3((unsigned)nwg), dim3(256), 0, st, xl, n, d, dc, label, ub, lb, delta, dstat, kstate, wg_count,
+                         flagged_tmp);
+      hipLaunchKernelGGL(k_km_flag_scan, dim3(1), dim3(1024), 0, st, wg_count, nwg, wg_off, nflag);
+      hipLaunchKernelGGL(k_km_flag_compact, dim3((unsigned)nwg), dim3(256), 0, st, flagged_tmp, wg_count, wg_off, flagged);
+    };
+    // ---- sweep 0: every cell against every centre
+    rc = launch_split_f16(ctx, dc, m, d, csplit, yy, ccf, 2, prep);
+    if (rc == MLN_OK) rc = launch_max_norm(ctx, yy, m, ymax);
+    if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nullptr, csplit, m, m1f, m2f, argc, nullptr, nullptr, 0);
+    if (rc == MLN_OK) rc = launch_km_resolve(ctx, dx, n, nullptr, dc, m, d, xxs, ymax, prep, m2f, argc, label, ub, lb, nullptr, nullptr, colscale);
+    if (km_prune && rc == MLN_OK) {
+      // the order of the centres (host: m x d numbers) and of the cells (a stable counting sort of n labels: the same order
+      // from run to run), once per call
+      std::vector<double> hc((size_t)m * d);
+      std::vector<int> hl((size_t)n), order((size_t)m), cpos((size_t)m), hperm((size_t)n);
+      chk(hipMemcpyAsync(hc.data(), dc, sizeof(double) * (size_t)m * d, hipMemcpyDeviceToHost, st));
+      chk(hipMemcpyAsync(hl.data(), label, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
       chk(hipStreamSynchronize(st));
-      F = hf;
-      if (hs <= scaled_tol) { ++it; break; }
+      if (rc == MLN_OK) {
+        centre_sweep_order(hc.data(), (int)m, d, order.data());
+        for (int p = 0; p < (int)m; ++p) cpos[(size_t)order[p]] = p;
+        std::vector<int64_t> start((size_t)m + 1, 0);
+        for (int64_t i = 0; i < n; ++i) start[(size_t)cpos[(size_t)hl[(size_t)i]] + 1]++;
+        for (int64_t p = 0; p < m; ++p) start[(size_t)p + 1] += start[(size_t)p];
+        for (int64_t i = 0; i < n; ++i) hperm[(size_t)start[(size_t)cpos[(size_t)hl[(size_t)i]]]++] = (int)i;
+        chk(hipMemcpyAsync(cperm, order.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(perm, hperm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_km_gather_rows, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, st, dx, perm, n, d, dxs);
+        hipLaunchKernelGGL(k_km_gather_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, n, label, ub, lb, label_s, ub_s, lb_s);
+        chk(hipStreamSynchronize(st));                      // (the host vectors above are the copies' sources)
+        if (rc == MLN_OK) rc = launch_split_f16(ctx, dxs, n, d, xsplit, xxs, nullptr, 1, prep);      // the same rows, in the new order
+        std::swap(label, label_s); std::swap(ub, ub_s); std::swap(lb, lb_s);
+        xl = dxs;
+        pruning = true;
+      }
+    }
+    if (rc == MLN_OK) {
+      chk(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)m * d, st));
+      chk(hipMemsetAsync(counts, 0, sizeof(double) * (size_t)m, st));
+      hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, xl, n, d, label, sums, counts, colscale);
+      tail();
+    }
+    // ---- the sweeps over the open rows, queued eight at a time: their number (nflag) and the stopping test (kstate) stay
+    // on the device -- a sweep behind the converged one finds no open row and moves nothing
+    while (rc == MLN_OK) {
+      int hk[2] = {0, 0};
+      chk(hipMemcpyAsync(hk, kstate, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
+      chk(hipStreamSynchronize(st));
+      it = hk[1];
+      if (std::getenv("MELLON_AMD_KM_DEBUG")) {     // TEMPORARY
+        int hf = 0;
+        (void)hipMemcpy(&hf, nflag, sizeof(int), hipMemcpyDeviceToHost);
+        double frac = 1.0;
+        if (pruning && hf > 0) {
+          const int nb = (hf + 255) / 256;
+          std::vector<uint32_t> hm((size_t)nb * mask_words);
+          (void)hipMemcpy(hm.data(), smask, sizeof(uint32_t) * hm.size(), hipMemcpyDeviceToHost);
+          long bits = 0;
+          for (uint32_t w : hm) bits += __builtin_popcount(w);
+          frac = (double)bits / ((double)nb * S);
+        }
+        std::fprintf(stderr, "km sweep %d: open rows %d (%.3f), stages swept %.3f, done %d\n", it, hf, (double)hf / n, frac, hk[0]);
+      }
+      if (rc != MLN_OK || hk[0] || it >= max_iter) break;
+      const int batch = (max_iter - it < 8) ? max_iter - it : 8;
+      for (int b = 0; b < batch && rc == MLN_OK; ++b) {
+        if (pruning) {
+          hipLaunchKernelGGL(k_km_gather_centres, dim3((unsigned)((m * d + 255) / 256)), dim3(256), 0, st, dc, cperm, m, d, dcp);
+          hipLaunchKernelGGL(k_km_leaf_geom, dim3((unsigned)S), dim3(256), 0, st, dcp, m, d, sg, srho);
+          hipLaunchKernelGGL(k_km_cdist, dim3((unsigned)((m * S + 255) / 256)), dim3(256), 0, st, dc, m, d, sg, srho, S, cdist);
+          hipLaunchKernelGGL(k_km_block_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flagged, nflag, label, ub, cdist, S,
+                             mask_words, smask);
+        }
+        rc = launch_split_f16(ctx, pruning ? dcp : dc, m, d, csplit, yy, ccf, 2, prep);
+        if (rc == MLN_OK) rc = launch_max_norm(ctx, yy, m, ymax);
+        if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nflag, csplit, m, m1f, m2f, argc, flagged, pruning ? smask : nullptr,
+                                                    pruning ? mask_words : 0);
+        if (rc == MLN_OK) rc = launch_km_resolve(ctx, xl, n, flagged, dc, m, d, xxs, ymax, prep, m2f, argc, label, ub, lb, sums, counts,
+                                                 colscale, nflag, pruning ? cperm : nullptr, cdist, S, pruning ? smask : nullptr, mask_words);
+        if (rc == MLN_OK) tail();
+      }
     }
   } else
   for (; it < max_iter && rc == MLN_OK; ++it) {
@@ -749,7 +1003,7 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(hipMemsetAsync(shift, 0, sizeof(double), st));
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n + 3) / 4)), dim3(64, 4), 0, st, dx, n, d, label, sums, counts, colscale);
     hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, sq, (double*)nullptr, colscale);
-    hipLaunchKernelGGL(k_km_sum_fixed, dim3(1), dim3(256), 0, st, sq, m, shift);
+    hipLaunchKernelGGL(k_km_sum_fixed, dim3(1), dim3(256), 0, st, sq, m, shift, 0.0, (int*)nullptr);
     double hs = 0.0;
     chk(hipMemcpyAsync(&hs, shift, sizeof(double), hipMemcpyDeviceToHost, st));
     chk(hipStreamSynchronize(st));
@@ -776,7 +1030,8 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   if (n_iter_out) *n_iter_out = it;
   (void)hipStreamSynchronize(st);
   void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f, prep, xxs, ub, lb, delta, dstat, yy, ymax,
-                  m2f, argc, nflag, flagged, colmax, colscale, sq};
+                  m2f, argc, nflag, flagged, colmax, colscale, sq, kstate, wg_count, wg_off, flagged_tmp, cperm, perm, label_s, ub_s, lb_s,
+                  dcp, sg, srho, cdist, dxs, smask};
   for (void* p : ptrs) if (p) (void)mln_dfree_synced(p);      // everything ran on st, synchronised above
   if (own_x) (void)mln_dfree_synced(dx);
   return rc;

@@ -23,7 +23,15 @@ int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double
 // k-means with bounds: label, upper and lower bound of the searched rows from a (TOP2, fold) sweep's m2 / arg (see the kernel)
 int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,
                       const double* xxs, const double* yy_max, const double* prep, const float* m2, const int* arg,
-                      int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale);
+                      int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale,
+                      const int* cnt_dev = nullptr, const int* cperm = nullptr, const double* cdist = nullptr, int nstage = 0,
+                      const uint32_t* stage_mask = nullptr, int mask_words = 0);
+// cnt_dev (optional, device): the row count when the host does not know it (cnt bounds the grid); cperm: candidate position ->
+// centre id when the sweep saw permuted centres; cdist / stage_mask: the pruned sweep's tables, see the kernel
+// the folded TOP2 sweep over the rows row_idx[0 .. *n_dev) (n_dev null: n_max rows), each 256-row block restricted to the
+// candidate blocks its row of stage_mask selects (null: all)
+int launch_rowmin_masked(mln_ctx* ctx, const void* xs, int64_t n_max, const int* n_dev, const void* ys, int64_t m, float* m1,
+                         float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words);
 int launch_max_norm(mln_ctx* ctx, const double* xx, int64_t n, double* out);   // out[0] = max xx (one workgroup)
 // exact nearest-neighbour distances via the pre-filter + fp64 certification (+ exact re-search of uncertified rows)
 int nn_distances_prefiltered(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d,

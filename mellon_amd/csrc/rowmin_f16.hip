@@ -28,7 +28,8 @@ hipError_t mln_dfree_synced(void* p);   // alloc.hip: release after the caller s
 #include "rowmin_f16.h"
 // rowmin_w64.hip: the folded sweep, one wave per SIMD (round 6)
 int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16* Y, int64_t m, int64_t self_offset, int exclude_self,
-                      float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order);
+                      float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order,
+                      const int* n_dev = nullptr);
 #include "mln_options.h"
 
 namespace {
@@ -520,18 +521,27 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
                                                     const int* __restrict__ arg, int* __restrict__ label,
                                                     double* __restrict__ ub, double* __restrict__ lb,
                                                     double* __restrict__ sums, double* __restrict__ counts,
-                                                    const double* __restrict__ colscale, int ncand) {
+                                                    const double* __restrict__ colscale, int ncand,
+                                                    const int* __restrict__ cnt_dev, const int* __restrict__ cperm,
+                                                    const double* __restrict__ cdist, int nstage,
+                                                    const uint32_t* __restrict__ stage_mask, int mask_words) {
+  // cnt_dev: the row count lives on the device (cnt sized the grid).
+  // Pruned sweeps (kmeans.hip): the sweep saw the centres in a permuted order -- candidate POSITION j is centre cperm[j] -- and
+  // only the stages (256 positions) in the row block's stage_mask.  cdist[a * nstage + s] <= |c_a - c_j| for every centre j of
+  // stage s, so the centres of a skipped stage are at least cdist[old label][s] - |x - c_old| away.
   // eight lanes per row, every eighth coordinate each (coalesced over the 8 rows of a wave's load)
   const int sub = threadIdx.x & 7;
   const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (cnt_dev) cnt = *cnt_dev;
   if (r >= cnt) return;                       // (whole groups of eight leave together: the shuffles below stay inside a group)
   const int64_t i = idx ? (int64_t)idx[r] : r;
   const double* xr = x + i * d;
   double best = INFINITY, second = INFINITY;
   int bj = arg[r];
   for (int q = 0; q < ncand; ++q) {
-    const int64_t j = (int64_t)arg[r] + 32 * q;
-    if (j >= m) continue;
+    const int64_t jp = (int64_t)arg[r] + 32 * q;
+    if (jp >= m) continue;
+    const int64_t j = cperm ? (int64_t)cperm[jp] : jp;
     const double* cr = c + j * d;
     double dd = 0.0;
     for (int k = sub; k < d; k += 8) { const double t = xr[k] - cr[k]; dd = fma(t, t, dd); }
@@ -546,8 +556,17 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
   const double rest = fmax((xxs[i] + (double)m2[r] - E) / (sc * sc), 0.0);
   const int old = label[i];
   if (sub == 0) {
+    double l = sqrt(fmin(second, rest));
+    if (stage_mask) {
+      const uint32_t* mk = stage_mask + (r >> 8) * mask_words;
+      const double* cd = cdist + (int64_t)old * nstage;
+      double skipped = INFINITY;
+      for (int s = 0; s < nstage; ++s)
+        if (!((mk[s >> 5] >> (s & 31)) & 1u)) skipped = fmin(skipped, cd[s]);
+      l = fmin(l, fmax(skipped - ub[i], 0.0));                 // (ub[i]: still the distance to the OLD centre)
+    }
     ub[i] = sqrt(best);
-    lb[i] = sqrt(fmin(second, rest));
+    lb[i] = l;
     label[i] = bj;
   }
   if (sums && old != bj) {
@@ -801,6 +820,14 @@ int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys,
   return MLN_OK;
 }
 
+// the folded sweep restricted per 256-row workgroup to the candidate blocks its row of `stage_mask` selects (kmeans.hip)
+int launch_rowmin_masked(mln_ctx* ctx, const void* xs, int64_t n_max, const int* n_dev, const void* ys, int64_t m, float* m1, float* m2,
+                         int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words) {
+  if (n_max <= 0 || m <= 0) return MLN_OK;
+  return launch_rowmin_w64(ctx, reinterpret_cast<const _Float16*>(xs), n_max, reinterpret_cast<const _Float16*>(ys), m, 0, 0, m1, m2, arg,
+                           row_idx, stage_mask, mask_words, nullptr, n_dev);
+}
+
 int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg) {
   if (n <= 0) return MLN_OK;
   hipLaunchKernelGGL(k_resolve_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, yy, arg, rowmin_fold_candidates());
@@ -810,10 +837,12 @@ int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double
 
 int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,
                       const double* xxs, const double* yy_max, const double* prep, const float* m2, const int* arg,
-                      int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale) {
+                      int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale,
+                      const int* cnt_dev, const int* cperm, const double* cdist, int nstage, const uint32_t* stage_mask, int mask_words) {
   if (cnt <= 0) return MLN_OK;
   hipLaunchKernelGGL(k_km_resolve, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, ctx->stream, x, cnt, idx, c, m, d, xxs,
-                     yy_max, prep, m2, arg, label, ub, lb, sums, counts, colscale, rowmin_fold_candidates());
+                     yy_max, prep, m2, arg, label, ub, lb, sums, counts, colscale, rowmin_fold_candidates(), cnt_dev, cperm, cdist,
+                     nstage, stage_mask, mask_words);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

@@ -60,8 +60,13 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
                                                     float* __restrict__ out_m1, float* __restrict__ out_m2,
                                                     int* __restrict__ out_arg, const int* __restrict__ row_idx,
                                                     const uint32_t* __restrict__ stage_mask, int mask_words,
-                                                    const int* __restrict__ wg_order) {
+                                                    const int* __restrict__ wg_order, const int* __restrict__ n_dev) {
   extern __shared__ unsigned char lds[];                      // 2 x (RT x PITCH) candidate rows
+  // n_dev (k-means sweeps queued ahead of the host): the number of query rows lives on the device, n only sized the grid
+  if (n_dev) {
+    n = *n_dev;
+    if ((int64_t)blockIdx.x * 256 >= n) return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lg = lane >> 5;
   // wg_order (with a stage mask): the row block this workgroup takes -- the blocks with the most candidate stages first, so
@@ -291,7 +296,8 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
 // stage_mask (optional, device): a bit matrix, one row of mask_words 32-bit words per 256-row workgroup; bit s of a row selects
 // the candidate block [256 s, 256 s + 256)
 int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16* Y, int64_t m, int64_t self_offset, int exclude_self,
-                      float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order) {
+                      float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order,
+                      const int* n_dev) {
   if (stage_mask && mask_words > 4096) { mln_set_error(ctx, "rowmin: stage mask too wide for LDS"); return MLN_ERR_UNSUPPORTED; }
   const size_t lds_max = (size_t)2 * RT * PITCH + 4096 * sizeof(uint32_t);
   const size_t lds_bytes = (size_t)2 * RT * PITCH + (stage_mask ? (size_t)mask_words * sizeof(uint32_t) : 0);
@@ -302,8 +308,8 @@ int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16
     attr = true;
   }
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (m2) hipLaunchKernelGGL((k_rowmin_w64<true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx, stage_mask, mask_words, wg_order);
-  else hipLaunchKernelGGL((k_rowmin_w64<false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, (float*)nullptr, arg, row_idx, stage_mask, mask_words, wg_order);
+  if (m2) hipLaunchKernelGGL((k_rowmin_w64<true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx, stage_mask, mask_words, wg_order, n_dev);
+  else hipLaunchKernelGGL((k_rowmin_w64<false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, (float*)nullptr, arg, row_idx, stage_mask, mask_words, wg_order, n_dev);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

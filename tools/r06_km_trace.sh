@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel-level breakdown of mln_kmeans at the C3 shape (1e6 x 50 -> 5000 centres)
+# kernel-level breakdown of mln_kmeans at the C3 shape (1e6 x KM_D (default 20) -> 5000 centres)
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r06_km_trace; mkdir -p $O
 cat > $O/probe.py <<'PY'
@@ -8,7 +8,9 @@ sys.path.insert(0, ".")
 import bench
 from mellon_amd import _lib
 ctx = _lib.default_context()
-x = bench.gaussian_mixture(1_000_000, 50, 3); xd = ctx.to_device(x)
+import os
+D = int(os.environ.get("KM_D", "20"))
+x = bench.gaussian_mixture(1_000_000, D, 3); xd = ctx.to_device(x)
 for rep in range(2):
     t0 = time.perf_counter(); c, it, inertia = ctx.kmeans(xd, 5000, seed=42, return_info=True); print("kmeans", round(time.perf_counter() - t0, 3), "s", it, "sweeps", inertia, flush=True)
 PY
