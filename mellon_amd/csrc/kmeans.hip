@@ -592,15 +592,18 @@ __global__ __launch_bounds__(256) void k_km_flag_compact(const int* __restrict__
   for (int k = threadIdx.x; k < cnt; k += 256) flagged[off + k] = flagged_tmp[blockIdx.x * KB_ROWS + k];
 }
 
-// ---- pruned sweeps (round 6): which 256-centre stages of the sweep can hold a closer centre ------------------------------------
-// The centres are swept in a fixed geometric order (cperm: recursive bisection of the first centres along the coordinate of
-// largest spread, cut at multiples of 256 -- a stage of the sweep is a compact group of centres) and the cells are stored in
-// the order of their first label's position, so a 256-row block of the open-row list has few distinct labels, all close.
-// Per sweep: leaf l (32 centres) has centroid g_l and radius rho_l; cdist[a][s] = min over the eight leaves of stage s of
-// |c_a - g_l| - rho_l  <=  |c_a - c_j| for every j in s.
-// A row x with label a and u = |x - c_a| needs stage s only if cdist[a][s] < 2 u (Elkan 2003, lemma 1: |c_a - c_j| >= 2 u
-// implies |x - c_j| >= u); a block sweeps the union over its rows, and the centres of a skipped stage are at least
-// cdist[a][s] - u away from x (the lower bound k_km_resolve keeps for them).
+// ---- group bounds (round 6): which 256-centre stages of the sweep can hold a closer centre ---------------------------------------
+// (Ding et al. 2015, "Yinyang k-means", with the sweep's stages as the groups.)  The centres are swept in a fixed geometric
+// order (cperm: recursive bisection of the first centres along the coordinate of largest spread, cut at multiples of 256 -- a
+// stage of the sweep is a compact group of centres) and the cells are stored in the order of their first label's position, so
+// a 256-row block of the open-row list has few distinct labels, all close.  Per cell i and stage s,
+//     lbg[i][s] - cum[s]  <=  |x_i - c_j|   for every centre j of stage s other than the cell's label,
+// cum[s] the sum over the sweeps so far of the largest movement of a centre of the stage: a bound written once stays valid
+// without being touched (no n x S update per sweep).  A cell is open when its distance to its own centre exceeds one of
+// its bounds, and needs exactly the stages of those bounds; a row block sweeps the union.  Two sweeps over the open rows:
+// the winner sweep (label, second smallest value) and the stage-minimum sweep (rowmin_w64.hip, SMIN), from which
+// k_km_resolve renews the bounds of the swept stages.  On 1e6 cells / 5000 centres the Hamerly bound above leaves ~30 % of
+// the cells open, each against all 20 stages.
 __global__ void k_km_gather_centres(const double* __restrict__ c, const int* __restrict__ cperm, int64_t m, int d,
                                     double* __restrict__ cp) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,71 +611,92 @@ __global__ void k_km_gather_centres(const double* __restrict__ c, const int* __r
   const int64_t p = t / d;
   cp[t] = c[(int64_t)cperm[p] * d + (t - p * d)];
 }
-// one workgroup per stage of the permuted centres cp; a stage is eight LEAVES of 32 centres (the bisection goes down to them):
-// centroid (sums in a fixed order) and radius of every leaf
-__global__ __launch_bounds__(256) void k_km_leaf_geom(const double* __restrict__ cp, int64_t m, int d, double* __restrict__ g,
-                                                      double* __restrict__ rho) {
-  __shared__ double gs[8][64];
-  const int64_t p0 = (int64_t)blockIdx.x * 256;
-  for (int e = threadIdx.x; e < 8 * d; e += 256) {
-    const int leaf = e / d, k = e - leaf * d;
-    const int64_t q0 = p0 + 32 * leaf;
-    const int cnt = (int)((m - q0 < 32) ? (m - q0 > 0 ? m - q0 : 0) : 32);
-    double s = 0.0;
-    for (int p = 0; p < cnt; ++p) s += cp[(q0 + p) * d + k];
-    const double mean = cnt > 0 ? s / cnt : 0.0;
-    gs[leaf][k] = mean;
-    g[((int64_t)blockIdx.x * 8 + leaf) * d + k] = mean;
-  }
+// one workgroup per stage: cum[s] += the largest movement among the stage's centres
+__global__ __launch_bounds__(256) void k_km_stage_delta(const double* __restrict__ delta, const int* __restrict__ cperm, int64_t m,
+                                                        double* __restrict__ cum) {
+  __shared__ double red[256];
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  red[threadIdx.x] = (p < m) ? delta[cperm[p]] : 0.0;
   __syncthreads();
-  const int leaf = threadIdx.x >> 5;
-  const int64_t p = p0 + threadIdx.x;
-  double dd = 0.0;
-  if (p < m)
-    for (int k = 0; k < d; ++k) { const double t = cp[p * d + k] - gs[leaf][k]; dd = fma(t, t, dd); }
-  for (int off = 1; off < 32; off <<= 1) dd = fmax(dd, __shfl_xor(dd, off, 64));
-  if ((threadIdx.x & 31) == 0) rho[(int64_t)blockIdx.x * 8 + leaf] = (p < m) ? sqrt(dd) : -1.0;     // (-1: an empty leaf)
-}
-// cdist[a][s] = min over the leaves l of stage s of |c_a - g_l| - rho_l, rounded down
-__global__ void k_km_cdist(const double* __restrict__ c, int64_t m, int d, const double* __restrict__ g,
-                           const double* __restrict__ rho, int S, double* __restrict__ cdist) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= m * S) return;
-  const int64_t a = t / S;
-  const int s = (int)(t - a * S);
-  double best = INFINITY;
-  for (int l = 8 * s; l < 8 * s + 8; ++l) {
-    if (rho[l] < 0.0) continue;
-    double dd = 0.0;
-    for (int k = 0; k < d; ++k) { const double u = c[a * d + k] - g[(int64_t)l * d + k]; dd = fma(u, u, dd); }
-    const double dist = sqrt(dd);
-    best = fmin(best, (dist - rho[l]) - 1e-12 * (dist + rho[l]));
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + w]);
+    __syncthreads();
   }
-  cdist[t] = best;
+  if (threadIdx.x == 0) cum[blockIdx.x] += red[0];
 }
-// one workgroup per 256 rows of the open-row list: the union of the stages its rows need
-__global__ __launch_bounds__(256) void k_km_block_mask(const int* __restrict__ flagged, const int* __restrict__ n_flag,
-                                                       const int* __restrict__ label, const double* __restrict__ ub,
-                                                       const double* __restrict__ cdist, int S, int words,
-                                                       uint32_t* __restrict__ mask) {
-  __shared__ uint32_t acc[8];
-  const int F = n_flag[0];
-  if ((int64_t)blockIdx.x * 256 >= F) return;
-  if (threadIdx.x < 8) acc[threadIdx.x] = 0u;
-  __syncthreads();
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r < F) {
-    const int i = flagged[r];
-    const double* cd = cdist + (int64_t)label[i] * S;
-    const double lim = 2.0 * ub[i] * (1.0 + 1e-12);
-    for (int w = 0; w < words; ++w) {
+// k_km_bounds with group bounds: the exact distance to the own centre against every stage's bound; rowmask[i] = the stages
+// the cell needs (written for open cells).  S <= 32.
+__global__ __launch_bounds__(256) void k_km_bounds_g(const double* __restrict__ x, int64_t n, int d, const double* __restrict__ c,
+                                                     const int* __restrict__ label, double* __restrict__ ub,
+                                                     const float* __restrict__ lbg, const double* __restrict__ cum, int S,
+                                                     const int* __restrict__ cpos, const int* __restrict__ kstate,
+                                                     int* __restrict__ wg_count, int* __restrict__ flagged_tmp,
+                                                     uint32_t* __restrict__ rowmask) {
+  __shared__ unsigned long long masks[KB_IT * 4];
+  __shared__ int offs[KB_IT * 4];
+  if (kstate[0]) {
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = 0;
+    return;
+  }
+  const int sub = threadIdx.x & 7, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row0 = (int64_t)blockIdx.x * KB_ROWS;
+  for (int it = 0; it < KB_IT; ++it) {
+    const int64_t i = row0 + it * 32 + (threadIdx.x >> 3);
+    bool flag = false;
+    if (i < n) {
+      const int a = label[i];
+      const double* xr = x + i * d;
+      const double* cr = c + (int64_t)a * d;
+      double dd = 0.0;
+      for (int k = sub; k < d; k += 8) { const double t = xr[k] - cr[k]; dd = fma(t, t, dd); }
+      dd += __shfl_xor(dd, 1, 64);
+      dd += __shfl_xor(dd, 2, 64);
+      dd += __shfl_xor(dd, 4, 64);
+      const double u = sqrt(dd);
       uint32_t bits = 0u;
-      for (int b = 0; b < 32 && 32 * w + b < S; ++b) bits |= (cd[32 * w + b] <= lim) ? (1u << b) : 0u;
-      if (bits) atomicOr(&acc[w], bits);
+      for (int s = sub; s < S; s += 8) bits |= ((double)lbg[i * S + s] - cum[s] < u) ? (1u << s) : 0u;
+      bits |= __shfl_xor(bits, 1, 64);
+      bits |= __shfl_xor(bits, 2, 64);
+      bits |= __shfl_xor(bits, 4, 64);
+      // (an open cell's own stage is always swept: the new label is the sweep's winner, and the present label competes)
+      if (sub == 0) { ub[i] = u; if (bits) rowmask[i] = bits | (1u << (cpos[a] >> 8)); }
+      flag = (sub == 0) && bits != 0u;
+    }
+    const unsigned long long mask = __ballot(flag);
+    if (lane == 0) masks[it * 4 + wave] = mask;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int e = 0; e < KB_IT * 4; ++e) { offs[e] = run; run += __popcll(masks[e]); }
+    wg_count[blockIdx.x] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x < KB_IT * 4) {
+    const int e = threadIdx.x, it = e >> 2, w = e & 3;
+    unsigned long long mk = masks[e];
+    int slot = blockIdx.x * KB_ROWS + offs[e];
+    while (mk) {
+      const int ln = __ffsll((long long)mk) - 1;
+      mk &= mk - 1;
+      flagged_tmp[slot++] = (int)(row0 + it * 32 + w * 8 + (ln >> 3));
     }
   }
+}
+// one workgroup per 256 rows of the open-row list: the union of the stages its rows need
+__global__ __launch_bounds__(256) void k_km_block_mask_g(const int* __restrict__ flagged, const int* __restrict__ n_flag,
+                                                         const uint32_t* __restrict__ rowmask, uint32_t* __restrict__ mask) {
+  __shared__ uint32_t acc;
+  const int F = n_flag[0];
+  if ((int64_t)blockIdx.x * 256 >= F) return;
+  if (threadIdx.x == 0) acc = 0u;
   __syncthreads();
-  if ((int)threadIdx.x < words) mask[(int64_t)blockIdx.x * words + threadIdx.x] = acc[threadIdx.x];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  uint32_t bits = (r < F) ? rowmask[flagged[r]] : 0u;
+  for (int off = 1; off < 64; off <<= 1) bits |= __shfl_xor(bits, off, 64);
+  if ((threadIdx.x & 63) == 0) atomicOr(&acc, bits);
+  __syncthreads();
+  if (threadIdx.x == 0) mask[blockIdx.x] = acc;
 }
 __global__ void k_km_gather_rows(const double* __restrict__ x, const int* __restrict__ perm, int64_t n, int d, double* __restrict__ xs) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -868,13 +892,15 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     chk(mln_dmalloc((void**)&nflag, sizeof(int)));
     chk(mln_dmalloc((void**)&flagged, sizeof(int) * (size_t)n));
   }
-  // Pruned sweeps (see k_km_gather_centres): 1024 centres and more, at most 128 stages.  MELLON_AMD_KM_PRUNE=0 disables.
-  const int S = (int)((m + 255) / 256), mask_words = (S + 31) / 32;
-  const bool km_prune = km_bounds && m >= 1024 && S <= 128 && n >= 65536 && n <= 2147483647LL &&
+  // Group bounds (see k_km_gather_centres): 1024 to 8192 centres (at most 32 stages).  MELLON_AMD_KM_PRUNE=0 disables.
+  const int S = (int)((m + 255) / 256);
+  const bool km_prune = km_bounds && m >= 1024 && S <= 32 && n >= 65536 && n <= 2147483647LL &&
                         !(mln_experiment("MELLON_AMD_KM_PRUNE") && std::atoi(mln_experiment("MELLON_AMD_KM_PRUNE")) == 0);
-  int *kstate = nullptr, *wg_count = nullptr, *wg_off = nullptr, *flagged_tmp = nullptr, *cperm = nullptr, *perm = nullptr, *label_s = nullptr;
-  double *dcp = nullptr, *sg = nullptr, *srho = nullptr, *cdist = nullptr, *dxs = nullptr, *ub_s = nullptr, *lb_s = nullptr;
-  uint32_t* smask = nullptr;
+  int *kstate = nullptr, *wg_count = nullptr, *wg_off = nullptr, *flagged_tmp = nullptr, *cperm = nullptr, *cposd = nullptr, *perm = nullptr,
+      *label_s = nullptr;
+  double *dcp = nullptr, *cum = nullptr, *dxs = nullptr, *ub_s = nullptr, *lb_s = nullptr;
+  float *lbg = nullptr, *smin = nullptr;
+  uint32_t *smask = nullptr, *rowmask = nullptr;
   const int nwg = (int)((n + KB_ROWS - 1) / KB_ROWS);
   if (km_bounds && rc == MLN_OK) {
     chk(mln_dmalloc((void**)&kstate, sizeof(int) * 2));
@@ -885,60 +911,87 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   }
   if (km_prune && rc == MLN_OK) {
     chk(mln_dmalloc((void**)&cperm, sizeof(int) * (size_t)m));
+    chk(mln_dmalloc((void**)&cposd, sizeof(int) * (size_t)m));
     chk(mln_dmalloc((void**)&perm, sizeof(int) * (size_t)n));
     chk(mln_dmalloc((void**)&label_s, sizeof(int) * (size_t)n));
     chk(mln_dmalloc((void**)&ub_s, sizeof(double) * (size_t)n));
     chk(mln_dmalloc((void**)&lb_s, sizeof(double) * (size_t)n));
     chk(mln_dmalloc((void**)&dcp, sizeof(double) * (size_t)m * d));
-    chk(mln_dmalloc((void**)&sg, sizeof(double) * (size_t)S * 8 * d));
-    chk(mln_dmalloc((void**)&srho, sizeof(double) * (size_t)S * 8));
-    chk(mln_dmalloc((void**)&cdist, sizeof(double) * (size_t)m * S));
+    chk(mln_dmalloc((void**)&cum, sizeof(double) * (size_t)S));
     chk(mln_dmalloc((void**)&dxs, sizeof(double) * (size_t)n * d));
-    chk(mln_dmalloc((void**)&smask, sizeof(uint32_t) * (size_t)((n + 255) / 256) * mask_words));
+    chk(mln_dmalloc((void**)&lbg, sizeof(float) * (size_t)n * S));
+    chk(mln_dmalloc((void**)&smin, sizeof(float) * (size_t)n * S));
+    chk(mln_dmalloc((void**)&smask, sizeof(uint32_t) * (size_t)((n + 255) / 256)));
+    chk(mln_dmalloc((void**)&rowmask, sizeof(uint32_t) * (size_t)n));
+    if (rc == MLN_OK) chk(hipMemsetAsync(cum, 0, sizeof(double) * (size_t)S, st));
   }
   if (km_bounds && rc == MLN_OK && max_iter > 0) {
-    const double* xl = dx;        // the cells in the order the sweeps walk them (sorted by first label when pruning)
-    bool pruning = false;
+    const double* xl = dx;        // the cells in the order the sweeps walk them (sorted by first label with group bounds)
+    bool groups = false;
+    KmGroups grp{lbg, cum, smin, n, cposd, S};
     // the part of a sweep after the assignment: new centres, their movement, the bounds, the list of open rows
     auto tail = [&]() {
       chk(hipMemsetAsync(shift, 0, sizeof(double), st));
       hipLaunchKernelGGL(k_finish, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, dc, sums, counts, m, d, sq, delta, colscale);
       hipLaunchKernelGGL(k_km_sum_fixed, dim3(1), dim3(256), 0, st, sq, m, shift, scaled_tol, kstate);
-      hipLaunchKernelGGL(k_km_delta_stats, dim3(1), dim3(256), 0, st, delta, m, dstat);
-      hipLaunchKernelGGL(k_km_bounds, dim3((unsigned)nwg), dim3(256), 0, st, xl, n, d, dc, label, ub, lb, delta, dstat, kstate, wg_count,
-                         flagged_tmp);
+      if (groups) {
+        hipLaunchKernelGGL(k_km_stage_delta, dim3((unsigned)S), dim3(256), 0, st, delta, cperm, m, cum);
+        hipLaunchKernelGGL(k_km_bounds_g, dim3((unsigned)nwg), dim3(256), 0, st, xl, n, d, dc, label, ub, lbg, cum, S, cposd, kstate, wg_count,
+                           flagged_tmp, rowmask);
+      } else {
+        hipLaunchKernelGGL(k_km_delta_stats, dim3(1), dim3(256), 0, st, delta, m, dstat);
+        hipLaunchKernelGGL(k_km_bounds, dim3((unsigned)nwg), dim3(256), 0, st, xl, n, d, dc, label, ub, lb, delta, dstat, kstate, wg_count,
+                           flagged_tmp);
+      }
       hipLaunchKernelGGL(k_km_flag_scan, dim3(1), dim3(1024), 0, st, wg_count, nwg, wg_off, nflag);
       hipLaunchKernelGGL(k_km_flag_compact, dim3((unsigned)nwg), dim3(256), 0, st, flagged_tmp, wg_count, wg_off, flagged);
     };
-    // ---- sweep 0: every cell against every centre
-    rc = launch_split_f16(ctx, dc, m, d, csplit, yy, ccf, 2, prep);
-    if (rc == MLN_OK) rc = launch_max_norm(ctx, yy, m, ymax);
-    if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nullptr, csplit, m, m1f, m2f, argc, nullptr, nullptr, 0);
-    if (rc == MLN_OK) rc = launch_km_resolve(ctx, dx, n, nullptr, dc, m, d, xxs, ymax, prep, m2f, argc, label, ub, lb, nullptr, nullptr, colscale);
-    if (km_prune && rc == MLN_OK) {
-      // the order of the centres (host: m x d numbers) and of the cells (a stable counting sort of n labels: the same order
-      // from run to run), once per call
+    // ---- sweep 0: every cell against every centre (with group bounds: the centres already in their sweep order)
+    if (km_prune) {
       std::vector<double> hc((size_t)m * d);
-      std::vector<int> hl((size_t)n), order((size_t)m), cpos((size_t)m), hperm((size_t)n);
+      std::vector<int> order((size_t)m), cpos((size_t)m);
       chk(hipMemcpyAsync(hc.data(), dc, sizeof(double) * (size_t)m * d, hipMemcpyDeviceToHost, st));
-      chk(hipMemcpyAsync(hl.data(), label, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
       chk(hipStreamSynchronize(st));
       if (rc == MLN_OK) {
         centre_sweep_order(hc.data(), (int)m, d, order.data());
         for (int p = 0; p < (int)m; ++p) cpos[(size_t)order[p]] = p;
-        std::vector<int64_t> start((size_t)m + 1, 0);
-        for (int64_t i = 0; i < n; ++i) start[(size_t)cpos[(size_t)hl[(size_t)i]] + 1]++;
-        for (int64_t p = 0; p < m; ++p) start[(size_t)p + 1] += start[(size_t)p];
-        for (int64_t i = 0; i < n; ++i) hperm[(size_t)start[(size_t)cpos[(size_t)hl[(size_t)i]]]++] = (int)i;
         chk(hipMemcpyAsync(cperm, order.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(cposd, cpos.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice, st));
+        chk(hipStreamSynchronize(st));
+        groups = rc == MLN_OK;
+      }
+    }
+    auto centres_split = [&]() {
+      if (groups) hipLaunchKernelGGL(k_km_gather_centres, dim3((unsigned)((m * d + 255) / 256)), dim3(256), 0, st, dc, cperm, m, d, dcp);
+      int r = launch_split_f16(ctx, groups ? dcp : dc, m, d, csplit, yy, ccf, 2, prep);
+      if (r == MLN_OK) r = launch_max_norm(ctx, yy, m, ymax);
+      return r;
+    };
+    if (rc == MLN_OK) rc = centres_split();
+    if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nullptr, csplit, m, m1f, m2f, argc, nullptr, nullptr, 0);
+    if (rc == MLN_OK) rc = launch_km_resolve(ctx, dx, n, nullptr, dc, m, d, xxs, ymax, prep, m2f, argc, label, ub, lb, nullptr, nullptr, colscale,
+                                             nullptr, groups ? cperm : nullptr);
+    if (groups && rc == MLN_OK) {
+      // the order of the cells (a stable counting sort of the n first labels by sweep position: the same order from run to
+      // run), once per call; then the stage minima of every cell and the first group bounds
+      std::vector<int> hl((size_t)n), hpos((size_t)m), hperm((size_t)n);
+      chk(hipMemcpyAsync(hl.data(), label, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st));
+      chk(hipMemcpyAsync(hpos.data(), cposd, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, st));
+      chk(hipStreamSynchronize(st));
+      if (rc == MLN_OK) {
+        std::vector<int64_t> start((size_t)m + 1, 0);
+        for (int64_t i = 0; i < n; ++i) start[(size_t)hpos[(size_t)hl[(size_t)i]] + 1]++;
+        for (int64_t p = 0; p < m; ++p) start[(size_t)p + 1] += start[(size_t)p];
+        for (int64_t i = 0; i < n; ++i) hperm[(size_t)start[(size_t)hpos[(size_t)hl[(size_t)i]]]++] = (int)i;
         chk(hipMemcpyAsync(perm, hperm.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_km_gather_rows, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, st, dx, perm, n, d, dxs);
         hipLaunchKernelGGL(k_km_gather_state, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, perm, n, label, ub, lb, label_s, ub_s, lb_s);
-        chk(hipStreamSynchronize(st));                      // (the host vectors above are the copies' sources)
+        chk(hipStreamSynchronize(st));                      // (the host vector above is the copy's source)
         if (rc == MLN_OK) rc = launch_split_f16(ctx, dxs, n, d, xsplit, xxs, nullptr, 1, prep);      // the same rows, in the new order
         std::swap(label, label_s); std::swap(ub, ub_s); std::swap(lb, lb_s);
         xl = dxs;
-        pruning = true;
+        if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nullptr, csplit, m, nullptr, nullptr, nullptr, nullptr, nullptr, 0, smin, n);
+        if (rc == MLN_OK) rc = launch_km_init_groups(ctx, n, label, lb, xxs, ymax, prep, &grp);
       }
     }
     if (rc == MLN_OK) {
@@ -954,36 +1007,17 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
       chk(hipMemcpyAsync(hk, kstate, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
       chk(hipStreamSynchronize(st));
       it = hk[1];
-      if (std::getenv("MELLON_AMD_KM_DEBUG")) {     // TEMPORARY
-        int hf = 0;
-        (void)hipMemcpy(&hf, nflag, sizeof(int), hipMemcpyDeviceToHost);
-        double frac = 1.0;
-        if (pruning && hf > 0) {
-          const int nb = (hf + 255) / 256;
-          std::vector<uint32_t> hm((size_t)nb * mask_words);
-          (void)hipMemcpy(hm.data(), smask, sizeof(uint32_t) * hm.size(), hipMemcpyDeviceToHost);
-          long bits = 0;
-          for (uint32_t w : hm) bits += __builtin_popcount(w);
-          frac = (double)bits / ((double)nb * S);
-        }
-        std::fprintf(stderr, "km sweep %d: open rows %d (%.3f), stages swept %.3f, done %d\n", it, hf, (double)hf / n, frac, hk[0]);
-      }
       if (rc != MLN_OK || hk[0] || it >= max_iter) break;
       const int batch = (max_iter - it < 8) ? max_iter - it : 8;
       for (int b = 0; b < batch && rc == MLN_OK; ++b) {
-        if (pruning) {
-          hipLaunchKernelGGL(k_km_gather_centres, dim3((unsigned)((m * d + 255) / 256)), dim3(256), 0, st, dc, cperm, m, d, dcp);
-          hipLaunchKernelGGL(k_km_leaf_geom, dim3((unsigned)S), dim3(256), 0, st, dcp, m, d, sg, srho);
-          hipLaunchKernelGGL(k_km_cdist, dim3((unsigned)((m * S + 255) / 256)), dim3(256), 0, st, dc, m, d, sg, srho, S, cdist);
-          hipLaunchKernelGGL(k_km_block_mask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flagged, nflag, label, ub, cdist, S,
-                             mask_words, smask);
-        }
-        rc = launch_split_f16(ctx, pruning ? dcp : dc, m, d, csplit, yy, ccf, 2, prep);
-        if (rc == MLN_OK) rc = launch_max_norm(ctx, yy, m, ymax);
-        if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nflag, csplit, m, m1f, m2f, argc, flagged, pruning ? smask : nullptr,
-                                                    pruning ? mask_words : 0);
+        rc = centres_split();
+        if (groups)
+          hipLaunchKernelGGL(k_km_block_mask_g, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flagged, nflag, rowmask, smask);
+        if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nflag, csplit, m, m1f, m2f, argc, flagged, groups ? smask : nullptr,
+                                                    groups ? 1 : 0);
+        if (rc == MLN_OK && groups) rc = launch_rowmin_masked(ctx, xsplit, n, nflag, csplit, m, nullptr, nullptr, nullptr, flagged, smask, 1, smin, n);
         if (rc == MLN_OK) rc = launch_km_resolve(ctx, xl, n, flagged, dc, m, d, xxs, ymax, prep, m2f, argc, label, ub, lb, sums, counts,
-                                                 colscale, nflag, pruning ? cperm : nullptr, cdist, S, pruning ? smask : nullptr, mask_words);
+                                                 colscale, nflag, groups ? cperm : nullptr, groups ? &grp : nullptr, groups ? smask : nullptr, 1);
         if (rc == MLN_OK) tail();
       }
     }
@@ -1030,8 +1064,8 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   if (n_iter_out) *n_iter_out = it;
   (void)hipStreamSynchronize(st);
   void* ptrs[] = {dc, xx, cc, mind, bsum, sums, counts, shift, label, pick, xsplit, csplit, ccf, m1f, prep, xxs, ub, lb, delta, dstat, yy, ymax,
-                  m2f, argc, nflag, flagged, colmax, colscale, sq, kstate, wg_count, wg_off, flagged_tmp, cperm, perm, label_s, ub_s, lb_s,
-                  dcp, sg, srho, cdist, dxs, smask};
+                  m2f, argc, nflag, flagged, colmax, colscale, sq, kstate, wg_count, wg_off, flagged_tmp, cperm, cposd, perm, label_s, ub_s,
+                  lb_s, dcp, cum, dxs, lbg, smin, smask, rowmask};
   for (void* p : ptrs) if (p) (void)mln_dfree_synced(p);      // everything ran on st, synchronised above
   if (own_x) (void)mln_dfree_synced(dx);
   return rc;

@@ -29,7 +29,7 @@ hipError_t mln_dfree_synced(void* p);   // alloc.hip: release after the caller s
 // rowmin_w64.hip: the folded sweep, one wave per SIMD (round 6)
 int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16* Y, int64_t m, int64_t self_offset, int exclude_self,
                       float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order,
-                      const int* n_dev = nullptr);
+                      const int* n_dev = nullptr, float* smin = nullptr, int64_t smin_stride = 0);
 #include "mln_options.h"
 
 namespace {
@@ -523,12 +523,14 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
                                                     double* __restrict__ sums, double* __restrict__ counts,
                                                     const double* __restrict__ colscale, int ncand,
                                                     const int* __restrict__ cnt_dev, const int* __restrict__ cperm,
-                                                    const double* __restrict__ cdist, int nstage,
-                                                    const uint32_t* __restrict__ stage_mask, int mask_words) {
+                                                    KmGroups grp, const uint32_t* __restrict__ stage_mask, int mask_words) {
   // cnt_dev: the row count lives on the device (cnt sized the grid).
-  // Pruned sweeps (kmeans.hip): the sweep saw the centres in a permuted order -- candidate POSITION j is centre cperm[j] -- and
-  // only the stages (256 positions) in the row block's stage_mask.  cdist[a * nstage + s] <= |c_a - c_j| for every centre j of
-  // stage s, so the centres of a skipped stage are at least cdist[old label][s] - |x - c_old| away.
+  // Group bounds (kmeans.hip): the sweep saw the centres in a permuted order -- candidate POSITION j is centre cperm[j] -- and
+  // only the stages (256 positions) in the row block's stage_mask; a second sweep left the smallest value of every swept
+  // stage in grp.smin.  Every swept stage's bound grp.lbg[i][s] is renewed:
+  //   the winner's stage        the bound for "every candidate but the winner" (second / m2~, as without groups)
+  //   any other swept stage     the larger of that and the stage's own minimum
+  //   and never below what was known (the old bound; if the label changes, the old centre joins its stage's others).
   // eight lanes per row, every eighth coordinate each (coalesced over the 8 rows of a wave's load)
   const int sub = threadIdx.x & 7;
   const int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
   const int64_t i = idx ? (int64_t)idx[r] : r;
   const double* xr = x + i * d;
   double best = INFINITY, second = INFINITY;
-  int bj = arg[r];
+  int bj = arg[r], bjp = arg[r];
   for (int q = 0; q < ncand; ++q) {
     const int64_t jp = (int64_t)arg[r] + 32 * q;
     if (jp >= m) continue;
@@ -548,23 +550,28 @@ __global__ __launch_bounds__(256) void k_km_resolve(const double* __restrict__ x
     dd += __shfl_xor(dd, 1, 64);
     dd += __shfl_xor(dd, 2, 64);
     dd += __shfl_xor(dd, 4, 64);
-    if (dd < best) { second = best; best = dd; bj = (int)j; }
+    if (dd < best) { second = best; best = dd; bj = (int)j; bjp = (int)jp; }
     else if (dd < second) second = dd;
   }
   const double sc = prep[64];
   const double E = rowmin_value_bound(sqrt(xxs[i]), sqrt(yy_max[0]));
   const double rest = fmax((xxs[i] + (double)m2[r] - E) / (sc * sc), 0.0);
   const int old = label[i];
-  if (sub == 0) {
-    double l = sqrt(fmin(second, rest));
-    if (stage_mask) {
-      const uint32_t* mk = stage_mask + (r >> 8) * mask_words;
-      const double* cd = cdist + (int64_t)old * nstage;
-      double skipped = INFINITY;
-      for (int s = 0; s < nstage; ++s)
-        if (!((mk[s >> 5] >> (s & 31)) & 1u)) skipped = fmin(skipped, cd[s]);
-      l = fmin(l, fmax(skipped - ub[i], 0.0));                 // (ub[i]: still the distance to the OLD centre)
+  const double l = sqrt(fmin(second, rest));
+  if (grp.lbg) {
+    const double ub_old = ub[i];                               // (still the distance to the OLD centre)
+    const uint32_t* mk = stage_mask ? stage_mask + (r >> 8) * mask_words : nullptr;
+    const int sb = bjp >> 8, sa = grp.cpos[old] >> 8;
+    for (int s = sub; s < grp.nstage; s += 8) {                // the eight lanes of the row share the stages
+      if (mk && !((mk[s >> 5] >> (s & 31)) & 1u)) continue;
+      double val = l;
+      if (s != sb) val = fmax(l, sqrt(fmax((xxs[i] + (double)grp.smin[s * grp.smin_stride + r] - E) / (sc * sc), 0.0)));
+      double eff = (double)grp.lbg[i * grp.nstage + s] - grp.cum[s];
+      if (old != bj && s == sa) eff = fmin(eff, ub_old);
+      grp.lbg[i * grp.nstage + s] = __double2float_rd(fmax(eff, val) + grp.cum[s]);
     }
+  }
+  if (sub == 0) {
     ub[i] = sqrt(best);
     lb[i] = l;
     label[i] = bj;
@@ -822,10 +829,10 @@ int launch_rowmin_f16x3(mln_ctx* ctx, const void* xs, int64_t n, const void* ys,
 
 // the folded sweep restricted per 256-row workgroup to the candidate blocks its row of `stage_mask` selects (kmeans.hip)
 int launch_rowmin_masked(mln_ctx* ctx, const void* xs, int64_t n_max, const int* n_dev, const void* ys, int64_t m, float* m1, float* m2,
-                         int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words) {
+                         int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, float* smin, int64_t smin_stride) {
   if (n_max <= 0 || m <= 0) return MLN_OK;
   return launch_rowmin_w64(ctx, reinterpret_cast<const _Float16*>(xs), n_max, reinterpret_cast<const _Float16*>(ys), m, 0, 0, m1, m2, arg,
-                           row_idx, stage_mask, mask_words, nullptr, n_dev);
+                           row_idx, stage_mask, mask_words, nullptr, n_dev, smin, smin_stride);
 }
 
 int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double* y, int64_t m, int d, const double* yy, int* arg) {
@@ -838,11 +845,36 @@ int launch_resolve_labels(mln_ctx* ctx, const double* x, int64_t n, const double
 int launch_km_resolve(mln_ctx* ctx, const double* x, int64_t cnt, const int* idx, const double* c, int64_t m, int d,
                       const double* xxs, const double* yy_max, const double* prep, const float* m2, const int* arg,
                       int* label, double* ub, double* lb, double* sums, double* counts, const double* colscale,
-                      const int* cnt_dev, const int* cperm, const double* cdist, int nstage, const uint32_t* stage_mask, int mask_words) {
+                      const int* cnt_dev, const int* cperm, const KmGroups* grp, const uint32_t* stage_mask, int mask_words) {
   if (cnt <= 0) return MLN_OK;
+  KmGroups g{};
+  if (grp) g = *grp;
   hipLaunchKernelGGL(k_km_resolve, dim3((unsigned)((cnt + 31) / 32)), dim3(256), 0, ctx->stream, x, cnt, idx, c, m, d, xxs,
-                     yy_max, prep, m2, arg, label, ub, lb, sums, counts, colscale, rowmin_fold_candidates(), cnt_dev, cperm, cdist,
-                     nstage, stage_mask, mask_words);
+                     yy_max, prep, m2, arg, label, ub, lb, sums, counts, colscale, rowmin_fold_candidates(), cnt_dev, cperm, g,
+                     stage_mask, mask_words);
+  MLN_HIP(ctx, hipGetLastError());
+  return MLN_OK;
+}
+
+// the first group bounds, after the full sweeps: lbg[i][s] = the bound for every centre but the label (lb) in the label's stage,
+// the larger of that and the stage's minimum elsewhere (grp.cum is zero)
+__global__ void k_km_init_groups(int64_t n, const int* __restrict__ label, const double* __restrict__ lb,
+                                 const double* __restrict__ xxs, const double* __restrict__ yy_max, const double* __restrict__ prep,
+                                 KmGroups grp) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * grp.nstage) return;
+  const int64_t i = t / grp.nstage;
+  const int s = (int)(t - i * grp.nstage);
+  const double sc = prep[64];
+  const double E = rowmin_value_bound(sqrt(xxs[i]), sqrt(yy_max[0]));
+  double val = lb[i];
+  if (s != (grp.cpos[label[i]] >> 8)) val = fmax(val, sqrt(fmax((xxs[i] + (double)grp.smin[s * grp.smin_stride + i] - E) / (sc * sc), 0.0)));
+  grp.lbg[t] = __double2float_rd(val);
+}
+int launch_km_init_groups(mln_ctx* ctx, int64_t n, const int* label, const double* lb, const double* xxs, const double* yy_max,
+                          const double* prep, const KmGroups* grp) {
+  hipLaunchKernelGGL(k_km_init_groups, dim3((unsigned)((n * grp->nstage + 255) / 256)), dim3(256), 0, ctx->stream, n, label, lb, xxs,
+                     yy_max, prep, *grp);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

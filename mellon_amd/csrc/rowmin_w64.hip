@@ -50,17 +50,33 @@ __device__ __forceinline__ float vmin_raw(float a, float b) {
 
 #define MLN_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// one step of the SMIN reduction: the lane keeps HALF of its 2 HALF values (which half: its bit HALF of lr) and takes the
+// minimum with the partner's copies of the same elements
+template <int HALF>
+__device__ __forceinline__ void smin_exchange(float (&v)[32], int lr) {
+  const bool up = (lr & HALF) != 0;
+#pragma unroll
+  for (int e = 0; e < HALF; ++e) {
+    const float keep = up ? v[e + HALF] : v[e], send = up ? v[e] : v[e + HALF];
+    v[e] = vmin_raw(keep, __shfl_xor(send, HALF, 64));
+  }
+}
+
 // TOP2: the runner-up per row is tracked (1-NN certification) and the winner's column only per stage and lane (out_arg = the
 // half-stage's first candidate of that lane; the winner is one of out_arg + {0, 32, 64, 96}); else (labels) the
 // exact column.
-template <bool TOP2>
+// SMIN (k-means with group bounds, kmeans.hip): no winner at all -- per row and STAGE the smallest value of the stage's 256
+// candidates, smin[stage * smin_stride + row] (the running minimum is reduced over the wave's 32 column lanes and reset at
+// the end of every stage).
+template <bool TOP2, bool SMIN = false>
 __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__ Xs, int64_t n,
                                                     const _Float16* __restrict__ Ys, int64_t m,
                                                     int64_t self_offset, int exclude_self,
                                                     float* __restrict__ out_m1, float* __restrict__ out_m2,
                                                     int* __restrict__ out_arg, const int* __restrict__ row_idx,
                                                     const uint32_t* __restrict__ stage_mask, int mask_words,
-                                                    const int* __restrict__ wg_order, const int* __restrict__ n_dev) {
+                                                    const int* __restrict__ wg_order, const int* __restrict__ n_dev,
+                                                    float* __restrict__ smin, int64_t smin_stride) {
   extern __shared__ unsigned char lds[];                      // 2 x (RT x PITCH) candidate rows
   // n_dev (k-means sweeps queued ahead of the host): the number of query rows lives on the device, n only sized the grid
   if (n_dev) {
@@ -150,7 +166,7 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
     if (masked) sv = (32 * sub < mrem && dlt[rh] + 32 * sub != (r & 3) + 8 * (r >> 2)) ? sv : INFINITY;
     if (TOP2) {
       m2[rh][r] = __builtin_amdgcn_fmed3f(m1[rh][r], m2[rh][r], sv);
-    } else {
+    } else if (!SMIN) {
       a1[rh][r] = (sv < m1[rh][r]) ? c0 + 32 * sub : a1[rh][r];
     }
     m1[rh][r] = vmin_raw(m1[rh][r], sv);
@@ -264,9 +280,20 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
 #undef MLN_STAGE
 #undef MLN_STEP
 #undef MLN_HALF_STAGE_ARG
+    if (SMIN) {
+      // 32 values per lane (one per row of its half) x 32 column lanes -> lane lr keeps the minimum of element lr: five exchange
+      // steps in which a lane hands over the half of its values the partner keeps (31 shuffles instead of 160)
+      float v[32];
+#pragma unroll
+      for (int e = 0; e < 32; ++e) { v[e] = m1[e >> 4][e & 15]; m1[e >> 4][e & 15] = INFINITY; }
+      smin_exchange<16>(v, lr); smin_exchange<8>(v, lr); smin_exchange<4>(v, lr); smin_exchange<2>(v, lr); smin_exchange<1>(v, lr);
+      const int64_t row = row0w + (lr >> 4) * 32 + (lr & 3) + 8 * ((lr & 15) >> 2) + 4 * lg;
+      if (row < n) smin[(col0 / RT) * smin_stride + row] = v[0];
+    }
     __syncthreads();
     col0 = following;
   }
+  if (SMIN) return;
   // merge the 32 column-lanes of each row (lanes with the same lg hold the same rows)
 #pragma unroll
   for (int rh = 0; rh < 2; ++rh)
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
 // the candidate block [256 s, 256 s + 256)
 int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16* Y, int64_t m, int64_t self_offset, int exclude_self,
                       float* m1, float* m2, int* arg, const int* row_idx, const uint32_t* stage_mask, int mask_words, const int* wg_order,
-                      const int* n_dev) {
+                      const int* n_dev, float* smin, int64_t smin_stride) {
   if (stage_mask && mask_words > 4096) { mln_set_error(ctx, "rowmin: stage mask too wide for LDS"); return MLN_ERR_UNSUPPORTED; }
   const size_t lds_max = (size_t)2 * RT * PITCH + 4096 * sizeof(uint32_t);
   const size_t lds_bytes = (size_t)2 * RT * PITCH + (stage_mask ? (size_t)mask_words * sizeof(uint32_t) : 0);
@@ -305,11 +332,19 @@ int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16
   if (!attr) {
     MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr = true;
   }
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (m2) hipLaunchKernelGGL((k_rowmin_w64<true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx, stage_mask, mask_words, wg_order, n_dev);
-  else hipLaunchKernelGGL((k_rowmin_w64<false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, (float*)nullptr, arg, row_idx, stage_mask, mask_words, wg_order, n_dev);
+  if (smin)
+    hipLaunchKernelGGL((k_rowmin_w64<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, (float*)nullptr,
+                       (float*)nullptr, (int*)nullptr, row_idx, stage_mask, mask_words, wg_order, n_dev, smin, smin_stride);
+  else if (m2)
+    hipLaunchKernelGGL((k_rowmin_w64<true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx,
+                       stage_mask, mask_words, wg_order, n_dev, (float*)nullptr, (int64_t)0);
+  else
+    hipLaunchKernelGGL((k_rowmin_w64<false>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, (float*)nullptr, arg,
+                       row_idx, stage_mask, mask_words, wg_order, n_dev, (float*)nullptr, (int64_t)0);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }

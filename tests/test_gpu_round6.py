@@ -165,3 +165,33 @@ def test_pruned_nearest_neighbour_search_is_exact(ctx, d, monkeypatch):
         from scipy.spatial import cKDTree
         want = cKDTree(x).query(x, k=2, workers=-1)[0][:, 1]
         assert np.abs(pruned - want).max() <= 1e-9 * want.max()
+
+
+@pytest.mark.parametrize("case", ["mixture", "tree"])
+def test_kmeans_group_bounds(ctx, case, monkeypatch):
+    """Lloyd's sweeps with per-stage (group) lower bounds -- 1024 centres and more: the centres swept in a geometric order, the
+    cells stored by first label, every open cell against the stages its bounds cannot exclude -- are Lloyd's sweeps: against
+    the Hamerly-bound sweeps of the same call (MELLON_AMD_KM_PRUNE=0) the clustering quality is the same (the trajectories
+    part where a cell sits within the fp16 pre-filter's error of two centres), the returned centres are a fixed point of
+    an EXACT Lloyd step to the stopping tolerance (every cell is with its nearest centre), and the result is the same from
+    run to run."""
+    n, d, m = 200_000, 12, 1500
+    x = mo.gaussian_mixture(n, d, seed=5) if case == "mixture" else _tree(n, d, 9)
+    monkeypatch.setenv("MELLON_AMD_KM_LEVELS", "1")
+    cg, itg, ing = ctx.kmeans(x, m, seed=11, return_info=True)
+    cg2, itg2, ing2 = ctx.kmeans(x, m, seed=11, return_info=True)
+    assert itg == itg2 and ing == ing2 and np.array_equal(cg, cg2)
+    monkeypatch.setenv("MELLON_AMD_KM_PRUNE", "0")
+    cp, itp, inp = ctx.kmeans(x, m, seed=11, return_info=True)
+    monkeypatch.delenv("MELLON_AMD_KM_PRUNE")
+    assert abs(ing / inp - 1) < 2e-3, (ing, inp)
+    assert 0.5 * itp <= itg <= 1.6 * itp, (itg, itp)
+    lab = np.concatenate([np.argmin(mo.distance(x[i:i + 20_000], cg), axis=1) for i in range(0, n, 20_000)])
+    cnt = np.bincount(lab, minlength=m)
+    sums = np.zeros((m, d))
+    np.add.at(sums, lab, x)
+    means = np.where(cnt[:, None] > 0, sums / np.maximum(cnt, 1)[:, None], cg)
+    assert np.sum((means - cg) ** 2) <= 4 * 1e-4 * x.var(axis=0).mean()
+    if itg < 300:                                  # converged: inertia of the exact assignment == the reported one
+        dmin = np.concatenate([mo.distance(x[i:i + 20_000], cg).min(axis=1) for i in range(0, n, 20_000)])
+        assert abs(np.sum(dmin ** 2) / ing - 1) < 1e-9
