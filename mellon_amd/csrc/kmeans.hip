@@ -1014,8 +1014,7 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
         if (groups)
           hipLaunchKernelGGL(k_km_block_mask_g, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flagged, nflag, rowmask, smask);
         if (rc == MLN_OK) rc = launch_rowmin_masked(ctx, xsplit, n, nflag, csplit, m, m1f, m2f, argc, flagged, groups ? smask : nullptr,
-                                                    groups ? 1 : 0);
-        if (rc == MLN_OK && groups) rc = launch_rowmin_masked(ctx, xsplit, n, nflag, csplit, m, nullptr, nullptr, nullptr, flagged, smask, 1, smin, n);
+                                                    groups ? 1 : 0, groups ? smin : nullptr, n);       // (winner and stage minima in one sweep)
         if (rc == MLN_OK) rc = launch_km_resolve(ctx, xl, n, flagged, dc, m, d, xxs, ymax, prep, m2f, argc, label, ub, lb, sums, counts,
                                                  colscale, nflag, groups ? cperm : nullptr, groups ? &grp : nullptr, groups ? smask : nullptr, 1);
         if (rc == MLN_OK) tail();

@@ -65,9 +65,9 @@ __device__ __forceinline__ void smin_exchange(float (&v)[32], int lr) {
 // TOP2: the runner-up per row is tracked (1-NN certification) and the winner's column only per stage and lane (out_arg = the
 // half-stage's first candidate of that lane; the winner is one of out_arg + {0, 32, 64, 96}); else (labels) the
 // exact column.
-// SMIN (k-means with group bounds, kmeans.hip): no winner at all -- per row and STAGE the smallest value of the stage's 256
-// candidates, smin[stage * smin_stride + row] (the running minimum is reduced over the wave's 32 column lanes and reset at
-// the end of every stage).
+// SMIN (k-means with group bounds, kmeans.hip): per row and STAGE the smallest value of the stage's 256 candidates,
+// smin[stage * smin_stride + row] (a stage-local minimum, reduced over the wave's 32 column lanes and reset at the end of
+// every stage) -- on its own (no winner at all) or together with TOP2.
 template <bool TOP2, bool SMIN = false>
 __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__ Xs, int64_t n,
                                                     const _Float16* __restrict__ Ys, int64_t m,
@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
   for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { m1[rh][r] = INFINITY; m2[rh][r] = INFINITY; a1[rh][r] = 0; }
+  float ms[2][16];                     // TOP2 && SMIN: the minima of the stage in flight (SMIN alone: m1 is that)
+#pragma unroll
+  for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ms[rh][r] = INFINITY;
 
   // staging: a stage is 256 rows x 256 B = two halves of 2048 16-byte pieces, 8 per thread and half (the second half is
   // requested when the first has gone to LDS: 32 staging registers instead of 64)
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
       a1[rh][r] = (sv < m1[rh][r]) ? c0 + 32 * sub : a1[rh][r];
     }
     m1[rh][r] = vmin_raw(m1[rh][r], sv);
+    if (TOP2 && SMIN) ms[rh][r] = vmin_raw(ms[rh][r], sv);
   };
 
   // Which stages (blocks of RT candidates) this workgroup multiplies: all of them, or -- stage_mask -- the set bits of this
@@ -285,7 +291,10 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
       // steps in which a lane hands over the half of its values the partner keeps (31 shuffles instead of 160)
       float v[32];
 #pragma unroll
-      for (int e = 0; e < 32; ++e) { v[e] = m1[e >> 4][e & 15]; m1[e >> 4][e & 15] = INFINITY; }
+      for (int e = 0; e < 32; ++e) {
+        if (TOP2) { v[e] = ms[e >> 4][e & 15]; ms[e >> 4][e & 15] = INFINITY; }
+        else { v[e] = m1[e >> 4][e & 15]; m1[e >> 4][e & 15] = INFINITY; }
+      }
       smin_exchange<16>(v, lr); smin_exchange<8>(v, lr); smin_exchange<4>(v, lr); smin_exchange<2>(v, lr); smin_exchange<1>(v, lr);
       const int64_t row = row0w + (lr >> 4) * 32 + (lr & 3) + 8 * ((lr & 15) >> 2) + 4 * lg;
       if (row < n) smin[(col0 / RT) * smin_stride + row] = v[0];
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256) void k_rowmin_w64(const _Float16* __restrict__
     __syncthreads();
     col0 = following;
   }
-  if (SMIN) return;
+  if (SMIN && !TOP2) return;
   // merge the 32 column-lanes of each row (lanes with the same lg hold the same rows)
 #pragma unroll
   for (int rh = 0; rh < 2; ++rh)
@@ -333,10 +342,14 @@ int launch_rowmin_w64(mln_ctx* ctx, const _Float16* X, int64_t n, const _Float16
     MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    MLN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowmin_w64<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr = true;
   }
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (smin)
+  if (smin && m2)
+    hipLaunchKernelGGL((k_rowmin_w64<true, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, m1, m2, arg, row_idx,
+                       stage_mask, mask_words, wg_order, n_dev, smin, smin_stride);
+  else if (smin)
     hipLaunchKernelGGL((k_rowmin_w64<false, true>), grid, block, lds_bytes, ctx->stream, X, n, Y, m, self_offset, exclude_self, (float*)nullptr,
                        (float*)nullptr, (int*)nullptr, row_idx, stage_mask, mask_words, wg_order, n_dev, smin, smin_stride);
   else if (m2)
