@@ -78,6 +78,9 @@ __global__ void k_seed_pick(const double* __restrict__ mind, int64_t n, int64_t 
 // The same update from the half-precision copy of the cells (rowmin_f16.hip split rows, hi halves: one 128-byte line per
 // cell instead of 400 bytes): D^2 only weights the k-means++ draw, three significant digits are plenty, and the 5000
 // sequential updates of a 1e6-cell seeding are pure memory traffic.  scale: the copy holds scale * x.
+// SB cells per workgroup (and per entry of bsum): 256 -- two passes of 128 cells -- since round 6: the seeding of the first
+// level walks 1.7e5 cells, 163 workgroups of 1024 cells left three quarters of the CUs idle (12 us per centre, now see DESIGN.md)
+template <int SB>
 __global__ __launch_bounds__(1024) void k_seed_update_h(const _Float16* __restrict__ xh, int64_t n, int d, float inv_scale,
                                                        const double* __restrict__ c, const double* __restrict__ prep,
                                                        double* __restrict__ mind, double* __restrict__ bsum, int first) {
@@ -92,11 +95,11 @@ __global__ __launch_bounds__(1024) void k_seed_update_h(const _Float16* __restri
   // Eight lanes per cell, one 16-byte piece of its 128-byte line each: a wave reads 8 consecutive lines = 1 KB in one
   // instruction.  (One lane per cell -- 64 lanes, 64 different lines per load instruction -- ran at 2.1 TB/s: 61 us per
   // update at 1e6 cells, 0.3 s of a 5000-centre seeding.)
-  const int64_t base = (int64_t)blockIdx.x * SBLK;
+  const int64_t base = (int64_t)blockIdx.x * SB;
   const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;      // piece of the line, cell within the pass of 128
   const int dk = (d + 7) / 8;
   double acc = 0.0;
-  for (int q = 0; q < SBLK / 128; ++q) {
+  for (int q = 0; q < SB / 128; ++q) {
     const int64_t i = base + q * 128 + grp;
     float s = 0.f;
     if (i < n && sub < dk) {
@@ -127,6 +130,8 @@ __global__ __launch_bounds__(1024) void k_seed_update_h(const _Float16* __restri
   if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
 }
 
+// (Round 6 measured the draw fused into the update -- made by the last workgroup to finish, one launch per centre: the
+// device-scope fence every workgroup then needs took the update from 12 to 54 us.  Two launches it stays.)
 // One k-means++ draw on the device (no host round trip per centre): total of the block sums, the block and then the cell
 // where the running sum of D^2 passes u * total, and the cell's coordinates copied into the next centre's slot.  u: this
 // step's uniform draw (the whole sequence is uploaded once).  Both levels are a 256-wide inclusive scan (wave shuffles + four
@@ -155,6 +160,7 @@ __device__ __forceinline__ void seed_scan_find(double v, double target, int t, d
   __syncthreads();
 }
 
+template <int SB>
 __global__ __launch_bounds__(256) void k_seed_select(const double* __restrict__ bsum, int64_t nblk, const double* __restrict__ mind,
                                                      int64_t n, double u, const double* __restrict__ x, int d,
                                                      double* __restrict__ c_next) {
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void k_seed_select(const double* __restrict__ 
   __shared__ double rem;
   __shared__ int64_t chosen;
   const int t = threadIdx.x;
-  // level 1: which block of SBLK cells.  Thread t sums its run of block sums; the scan finds the run, its owner the block.
+  // level 1: which block of SB cells.  Thread t sums its run of block sums; the scan finds the run, its owner the block.
   const int64_t per = (nblk + 255) / 256;
   const int64_t b0 = t * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
   double ps = 0.0;
@@ -198,8 +204,8 @@ __global__ __launch_bounds__(256) void k_seed_select(const double* __restrict__ 
     }
     __syncthreads();
     // level 2: which cell of the block, the same way (4 cells per thread)
-    const int64_t lo = blk * SBLK, hi = (lo + SBLK < n) ? lo + SBLK : n;
-    constexpr int CPT = SBLK / 256;
+    const int64_t lo = blk * SB, hi = (lo + SB < n) ? lo + SB : n;
+    constexpr int CPT = SB / 256;
     double v[CPT], ls = 0.0;
 #pragma unroll
     for (int e = 0; e < CPT; ++e) { const int64_t i = lo + t * CPT + e; v[e] = (i < hi) ? mind[i] : 0.0; ls += v[e]; }
@@ -713,6 +719,30 @@ __global__ void k_km_gather_state(const int* __restrict__ perm, int64_t n, const
   label_s[r] = label[i]; ub_s[r] = ub[i]; lb_s[r] = lb[i];
 }
 
+// variance of column blockIdx.x over the rows 0, stride, 2 stride, ... (ns of them): two passes, sums in a fixed order
+__global__ __launch_bounds__(1024) void k_km_col_var(const double* __restrict__ x, int64_t ns, int64_t stride, int d, double* __restrict__ var) {
+  __shared__ double part[1024];
+  const int k = blockIdx.x;
+  auto block_sum = [&](double v) {
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+    }
+    const double r = part[0];
+    __syncthreads();
+    return r;
+  };
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < ns; i += 1024) s += x[i * stride * d + k];
+  const double mean = block_sum(s) / (double)ns;
+  double m2 = 0.0;
+  for (int64_t i = threadIdx.x; i < ns; i += 1024) { const double t = x[i * stride * d + k] - mean; m2 = fma(t, t, m2); }
+  const double tot = block_sum(m2);
+  if (threadIdx.x == 0) var[k] = tot / (double)ns;
+}
+
 struct XorShift {
   unsigned long long s;
   explicit XorShift(unsigned long long seed) : s(seed * 0x9E3779B97F4A7C15ULL + 0xD1B54A32D192ED03ULL) { next(); next(); }
@@ -771,12 +801,12 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
     own_x = true;
     MLN_HIP(ctx, hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n * d, hipMemcpyHostToDevice, st));
   }
-  const int64_t nblk = (n + SBLK - 1) / SBLK;
+  const int64_t nblk = (n + SBLK - 1) / SBLK, nblk_h = (n + 255) / 256;     // (block sums of the fp64 / the half-precision seeding)
   MLN_HIP(ctx, mln_dmalloc((void**)&dc, sizeof(double) * (size_t)m * d));
   MLN_HIP(ctx, mln_dmalloc((void**)&xx, sizeof(double) * (size_t)n));
   MLN_HIP(ctx, mln_dmalloc((void**)&cc, sizeof(double) * (size_t)m));
   MLN_HIP(ctx, mln_dmalloc((void**)&mind, sizeof(double) * (size_t)n));
-  MLN_HIP(ctx, mln_dmalloc((void**)&bsum, sizeof(double) * (size_t)nblk));
+  MLN_HIP(ctx, mln_dmalloc((void**)&bsum, sizeof(double) * (size_t)nblk_h));
   MLN_HIP(ctx, mln_dmalloc((void**)&sums, sizeof(double) * (size_t)m * d));
   MLN_HIP(ctx, mln_dmalloc((void**)&counts, sizeof(double) * (size_t)m));
   MLN_HIP(ctx, mln_dmalloc((void**)&shift, sizeof(double)));
@@ -785,7 +815,7 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   double *colscale = nullptr, *sq = nullptr;
   MLN_HIP(ctx, mln_dmalloc((void**)&colmax, sizeof(unsigned long long) * (size_t)(d + 1)));
   MLN_HIP(ctx, mln_dmalloc((void**)&colscale, sizeof(double) * 2 * (size_t)d));
-  MLN_HIP(ctx, mln_dmalloc((void**)&sq, sizeof(double) * (size_t)m));
+  MLN_HIP(ctx, mln_dmalloc((void**)&sq, sizeof(double) * (size_t)(m > d ? m : d)));     // (also the d column variances)
   MLN_HIP(ctx, mln_dmalloc((void**)&label, sizeof(int) * (size_t)n));
   MLN_HIP(ctx, mln_dmalloc((void**)&pick, sizeof(int64_t)));
   int rc = MLN_OK;
@@ -824,12 +854,14 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   if (rc == MLN_OK && seeded) chk(hipMemcpyAsync(dc, dx + cur * d, sizeof(double) * d, hipMemcpyDeviceToDevice, st));
   if (rc == MLN_OK && !seeded) chk(hipMemcpyAsync(dc, init, sizeof(double) * (size_t)m * d, hipMemcpyDeviceToDevice, st));
   for (int64_t j = 0; seeded && j + 1 < m && rc == MLN_OK; ++j) {
-    if (seed_h)
-      hipLaunchKernelGGL(k_seed_update_h, dim3((unsigned)nblk), dim3(1024), 0, st, reinterpret_cast<const _Float16*>(xsplit), n, d,
+    if (seed_h) {
+      hipLaunchKernelGGL((k_seed_update_h<256>), dim3((unsigned)nblk_h), dim3(1024), 0, st, reinterpret_cast<const _Float16*>(xsplit), n, d,
                          -0.5f, dc + j * d, prep, mind, bsum, j == 0 ? 1 : 0);
-    else
+      hipLaunchKernelGGL((k_seed_select<256>), dim3(1), dim3(256), 0, st, bsum, nblk_h, mind, n, rng.uniform(), dx, d, dc + (j + 1) * d);
+    } else {
       hipLaunchKernelGGL(k_seed_update, dim3((unsigned)nblk), dim3(256), 0, st, dx, n, d, dc + j * d, mind, bsum, j == 0 ? 1 : 0);
-    hipLaunchKernelGGL(k_seed_select, dim3(1), dim3(256), 0, st, bsum, nblk, mind, n, rng.uniform(), dx, d, dc + (j + 1) * d);
+      hipLaunchKernelGGL((k_seed_select<SBLK>), dim3(1), dim3(256), 0, st, bsum, nblk, mind, n, rng.uniform(), dx, d, dc + (j + 1) * d);
+    }
     if ((j & 1023) == 1023) chk(hipStreamSynchronize(st));     // (bounds the launch queue)
   }
   chk(hipGetLastError());
@@ -838,21 +870,14 @@ static int kmeans_level(mln_ctx* ctx, const double* x, int64_t n, int32_t d, int
   // tolerance scaled like sklearn: tol * mean over features of the feature variance
   double scaled_tol = 0.0;
   if (rc == MLN_OK) {
-    std::vector<double> hx;
-    const int64_t ns = (n < 200000) ? n : 200000;   // variance estimate from an evenly spaced subset
-    hx.resize((size_t)ns * d);
-    const int64_t stride = n / ns;
-    chk(hipMemcpy2DAsync(hx.data(), sizeof(double) * d, dx, sizeof(double) * d * stride, sizeof(double) * d, (size_t)ns,
-                         hipMemcpyDeviceToHost, st));
+    const int64_t ns = (n < 200000) ? n : 200000;   // variance estimate from an evenly spaced subset (on the device: the
+    const int64_t stride = n / ns;                   // 32 MB copy to the host and its loops were 8-14 ms per level)
+    std::vector<double> hv((size_t)d);
+    hipLaunchKernelGGL(k_km_col_var, dim3((unsigned)d), dim3(1024), 0, st, dx, ns, stride, d, sq);     // (sq: max(m, d) doubles)
+    chk(hipMemcpyAsync(hv.data(), sq, sizeof(double) * (size_t)d, hipMemcpyDeviceToHost, st));
     chk(hipStreamSynchronize(st));
     double var_sum = 0.0;
-    for (int k = 0; k < d; ++k) {
-      double mean = 0.0, m2 = 0.0;
-      for (int64_t i = 0; i < ns; ++i) mean += hx[(size_t)i * d + k];
-      mean /= (double)ns;
-      for (int64_t i = 0; i < ns; ++i) { double t = hx[(size_t)i * d + k] - mean; m2 += t * t; }
-      var_sum += m2 / (double)ns;
-    }
+    for (int k = 0; k < d; ++k) var_sum += hv[(size_t)k];
     scaled_tol = tol * var_sum / d;
   }
   int it = 0;
