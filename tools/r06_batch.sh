@@ -21,6 +21,9 @@ if [ -n "$DB" ]; then
   python tools/gap_report.py $DB > $O/r06_step_gaps.txt 2> $O/trace/gap.err
 fi
 rm -rf $O/trace/db
+bash tools/r06_nn_trace.sh > $O/r06_nn_trace.txt 2>&1 < /dev/null
+KM_D=20 bash tools/r06_km_trace.sh > $O/r06_km_trace.txt 2>&1 < /dev/null
+bash tools/r06_km.sh > $O/r06_kmeans_ab.txt 2>&1 < /dev/null
 timeout 1500 python tools/robustness_sweep_large.py > $O/r06_robustness_sweep_large.txt 2> $O/robust.err < /dev/null
 for c in c3_1gpu c2 c4 c5; do python - $O/r06_bench_$c.json <<'PY'
 import json, sys
