@@ -21,10 +21,9 @@ import sqlite3, sys, re
 from collections import defaultdict
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
-# second call: the second half of the launches by time gap -- find the largest gap between launches
-gaps = [(rows[i + 1][1] - rows[i][2], i) for i in range(len(rows) - 1)]
-cut = max(gaps)[1] + 1
-rows = rows[cut:]
+# the second call: every level of a call starts with k_km_colmax
+idx = [i for i, r in enumerate(rows) if "k_km_colmax" in r[0]]
+rows = rows[idx[len(idx) // 2]:]
 t0, t1 = rows[0][1], rows[-1][2]
 tot = defaultdict(lambda: [0, 0.0]); idle = 0.0; prev = rows[0][1]
 for n, s, e in rows:
