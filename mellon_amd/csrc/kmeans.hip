@@ -130,8 +130,10 @@ __global__ __launch_bounds__(1024) void k_seed_update_h(const _Float16* __restri
   if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
 }
 
-// (Round 6 measured the draw fused into the update -- made by the last workgroup to finish, one launch per centre: the
-// device-scope fence every workgroup then needs took the update from 12 to 54 us.  Two launches it stays.)
+// (Round 6 measured the draw fused into the update, twice: made by the LAST workgroup of the update to finish -- the
+// device-scope fence every workgroup then needs took the update from 12 to 54 us; repeated by EVERY workgroup of the next
+// update from ping-pong copies of the sums -- same cells drawn, 18.2 us per centre against 9.4 + 4.3: the draw's barriers
+// and dependent loads in front of 651 workgroups cost more than a launch.  Two launches it stays.)
 // One k-means++ draw on the device (no host round trip per centre): total of the block sums, the block and then the cell
 // where the running sum of D^2 passes u * total, and the cell's coordinates copied into the next centre's slot.  u: this
 // step's uniform draw (the whole sequence is uploaded once).  Both levels are a 256-wide inclusive scan (wave shuffles + four
