@@ -328,6 +328,12 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
 // is appended to a list of (row slot, candidate) pairs; k_nn_list_eval then takes the exact minimum over each row's pairs.
 // The fp64 search over ALL candidates that used to resolve these rows (5 % of them at C3: 112 ms of a 0.5 s search) becomes
 // a second fp16 sweep over 5 % of the rows plus a few exact distances per row.  FOLD operands only (d <= 61).
+// Round 6: a workgroup holds LIST_ROWS = 64 row slots (the open rows of a pruned search come ~40 to a group: with 256-row
+// tiles 85 % of the products were padding -- 28 ms of a 100 ms search); its eight waves are two row halves x four quarters
+// of a stage's 128 candidates.  The candidate blocks of a group are dealt to the gridDim.y workgroups of its row by ORDINAL
+// among the blocks its mask selects (every y-th one): contiguous column segments left most of them idle, a group's
+// candidates being a few contiguous runs of the cluster-sorted order.
+constexpr int LIST_ROWS = 64;
 __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict__ Xs, int64_t cnt, const int* __restrict__ row_idx,
                                                      const _Float16* __restrict__ Ys, int64_t m, const float* __restrict__ fthr,
                                                      int* __restrict__ n_pairs, int cap, int* __restrict__ pair_row,
@@ -337,7 +343,8 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { stop_s[0] = 0; stop_s[1] = 0; }
   const int lr = lane & 31, lg = lane >> 5;
-  const int64_t row0w = (int64_t)blockIdx.x * 256 + wave * 32;
+  const int quarter = wave >> 1;                                    // which 32 of a stage's 128 candidates
+  const int64_t row0w = (int64_t)blockIdx.x * LIST_ROWS + (wave & 1) * 32;
   h8 ahi[4], alo[4];
   {
     const int64_t ar0 = (row0w + lr < cnt) ? row0w + lr : cnt - 1;
@@ -378,75 +385,75 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
     for (int w = tid; w < mask_words; w += 512) mrow[w] = stage_mask[(int64_t)blockIdx.x * mask_words + w];
     __syncthreads();
   }
-  auto next_stage = [&](int64_t s) -> int64_t {          // first selected stage >= s as a column; m when none
-    if (!mrow) return s * RT < m ? s * RT : m;
-    while (s * RT < m) {
-      const int64_t b = s >> 1;
-      const uint32_t w = __builtin_amdgcn_readfirstlane(mrow[b >> 5]);
-      if ((w >> (b & 31)) & 1u) return s * RT;
-      s = (w >> (b & 31)) == 0u ? ((b >> 5) + 1) * 64 : s + 1;       // nothing left in this word: on to the next one
-    }
-    return m;
-  };
-  // gridDim.y column segments (whole 256-candidate blocks): a workgroup walks its candidate stages one after the other whatever
-  // the number of its rows -- a list group whose rows must see every candidate is split over several workgroups
+  // this workgroup's candidate blocks: the selected ones whose ordinal is blockIdx.y modulo gridDim.y (wave-uniform scalar work)
   const int64_t nb256 = (m + 255) / 256;
-  const int64_t seg_lo = 256 * ((int64_t)blockIdx.y * nb256 / gridDim.y);
-  const int64_t m_full = m;
-  m = 256 * ((int64_t)(blockIdx.y + 1) * nb256 / gridDim.y);
-  if (m > m_full) m = m_full;
-  int64_t col0 = next_stage(seg_lo / RT);
+  const int ny = (int)gridDim.y, yy = (int)blockIdx.y;
+  int64_t scan_blk = 0;         // the next block to look at
+  int skip = yy;                // selected blocks to pass over before this workgroup's next one
+  auto next_block = [&]() -> int64_t {                       // this workgroup's next block; nb256 when none is left
+    if (!mrow) {
+      const int64_t b = scan_blk + skip;
+      scan_blk = b + 1; skip = ny - 1;
+      return b < nb256 ? b : nb256;
+    }
+    while (scan_blk < nb256) {
+      const uint32_t w = __builtin_amdgcn_readfirstlane(mrow[scan_blk >> 5]) >> (scan_blk & 31);
+      const int have = __builtin_popcount(w);
+      if (have <= skip) { skip -= have; scan_blk = ((scan_blk >> 5) + 1) * 32; continue; }      // (a whole word passed over)
+      uint32_t rest = w;
+      for (int k = 0; k < skip; ++k) rest &= rest - 1;       // drop the `skip` lowest set bits
+      const int64_t b = scan_blk + __builtin_ctz(rest);
+      scan_blk = b + 1; skip = ny - 1;
+      return b;
+    }
+    return nb256;
+  };
+  // the stages: both halves of a block (the second only if it holds candidates), then the next block
+  int64_t blk = next_block();
+  int64_t col0 = blk < nb256 ? blk * 256 : m;
+  auto stage_after = [&](int64_t c) -> int64_t {             // the stage that follows column c; m when none
+    if ((c & 255) == 0 && c + RT < m) return c + RT;
+    blk = next_block();
+    return blk < nb256 ? blk * 256 : m;
+  };
   if (col0 < m) { g_load(col0); l_store(0); }
   __syncthreads();
   int buf = 0, stage_no = 0;
   for (; col0 < m; buf ^= 1) {
     // A list that has outgrown its buffer is abandoned by the caller (exact search instead): stop feeding it.  Without this a
     // tight cluster of 50 000 mutual near-ties appends 2.5e9 pairs -- seconds of atomics on one address, and a 32-bit counter
-    // that wraps to negative slots (found by tools/robustness_sweep_large.py as a write fault).  The test is the same for
+    // that wraps to negative slots (found by tools/robustness_sweep_large.py as a write fault).
     // (Thread 0 reads the counter before the barrier that ends a stage; everybody acts on that one value after it.)
     if (stop_s[buf]) return;
-    const int64_t following = next_stage(col0 / RT + 1);
+    const int64_t following = stage_after(col0);
     const bool more = following < m;
     if (more) g_load(following);
-    const unsigned char* base = lds + buf * (RT * PITCH);
+    const unsigned char* brow = lds + buf * (RT * PITCH) + (quarter * 32 + lr) * PITCH + 16 * lg;
+    f16v acc;
 #pragma unroll
-    for (int sp = 0; sp < RT / 64; ++sp) {
-      f16v acc[2];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    h8 bhi[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-      const unsigned char* brow0 = base + (sp * 64 + lr) * PITCH + 16 * lg;
-      const unsigned char* brow1 = brow0 + 32 * PITCH;
-      h8 bhi0[4], bhi1[4];
+    for (int ks = 0; ks < 4; ++ks) {          // (the same order of products as the sweep: the same values)
+      bhi[ks] = *reinterpret_cast<const h8*>(brow + 32 * ks);
+      const h8 blo = *reinterpret_cast<const h8*>(brow + 2 * KP + 32 * ks);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi[ks], acc, 0, 0, 0);
+    }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {          // (the same order of products as the sweep: the same values)
-        bhi0[ks] = *reinterpret_cast<const h8*>(brow0 + 32 * ks);
-        bhi1[ks] = *reinterpret_cast<const h8*>(brow1 + 32 * ks);
-        const h8 blo0 = *reinterpret_cast<const h8*>(brow0 + 2 * KP + 32 * ks);
-        const h8 blo1 = *reinterpret_cast<const h8*>(brow1 + 2 * KP + 32 * ks);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo1, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi0[ks], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi1[ks], acc[1], 0, 0, 0);
-      }
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi[ks], acc, 0, 0, 0);
+    {
+      const int64_t col = col0 + quarter * 32 + lr;
+      // one comparison per element; the append is the rare path
+      bool any = false;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi0[ks], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi1[ks], acc[1], 0, 0, 0);
-      }
+      for (int r = 0; r < 16; ++r) any = any || (acc[r] < thr[r]);
+      if (any && col < m) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int64_t col = col0 + (2 * sp + h) * 32 + lr;
-        // one comparison per element; the append is the rare path
-        bool any = false;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) any = any || (acc[h][r] < thr[r]);
-        if (any && col < m) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (acc[h][r] < thr[r]) {
-              const int slot = atomicAdd(n_pairs, 1);
-              if (slot >= 0 && slot < cap) { pair_row[slot] = (int)(row0w + (r & 3) + 8 * (r >> 2) + 4 * lg); pair_col[slot] = (int)col; }
-            }
+        for (int r = 0; r < 16; ++r) {
+          if (acc[r] < thr[r]) {
+            const int slot = atomicAdd(n_pairs, 1);
+            if (slot >= 0 && slot < cap) { pair_row[slot] = (int)(row0w + (r & 3) + 8 * (r >> 2) + 4 * lg); pair_col[slot] = (int)col; }
           }
         }
       }
@@ -740,11 +747,11 @@ __global__ __launch_bounds__(256) void k_prune_mask(NnPrune pr, const double* __
   if (cnt) { atomicAdd(n_stages, cnt); atomicAdd(&block_stages[B], cnt); }
 }
 
-// the list sweep's workgroup g handles the open rows flagged[256 g .. 256 g + 256) (ascending): the union of their row blocks' masks
+// the list sweep's workgroup g handles the open rows flagged[64 g .. 64 g + 64) (ascending): the union of their row blocks' masks
 __global__ __launch_bounds__(256) void k_prune_union_mask(const int* __restrict__ flagged, int cnt, const uint32_t* __restrict__ mask, int words,
                                                           uint32_t* __restrict__ out) {
   const int g = blockIdx.x;
-  const int lo = g * 256, hi = lo + 256 < cnt ? lo + 256 : cnt;
+  const int lo = g * LIST_ROWS, hi = lo + LIST_ROWS < cnt ? lo + LIST_ROWS : cnt;
   for (int w = threadIdx.x; w < words; w += 256) {
     uint32_t u = 0u;
     int last = -1;
@@ -1012,10 +1019,8 @@ static int nn_search_core(mln_ctx* ctx, const double* x, int64_t n, const double
   if (cnt > 0 && fold && list_ok) {
     // Pruned search: a candidate that could beat an open row's winner lies in a block its row block's mask selects (everything
     // else is provably no nearer than a cell that block has seen).  The open rows are put in ascending order -- neighbours in
-    // the sorted order share clusters -- and each list workgroup sweeps the union of its rows' masks.  A list workgroup walks
-    // its candidate blocks one after the other whatever the number of its rows, and 1 % open rows are 37 workgroups of 256
-    // on 256 CUs: with few open rows a workgroup takes 32 of them (the other slots are padding with a -inf threshold), so
-    // that the unions stay small and every CU has a workgroup.
+    // the sorted order share clusters -- in groups of 32 to 64 (the other slots of a group's 64 are padding with a -inf
+    // threshold), and each list workgroup sweeps its share of the union of its rows' masks.
     const uint32_t* lmask = nullptr;
     int cnt_list = cnt;
     if (pr_mask && cnt <= 262144) {
@@ -1032,15 +1037,15 @@ static int nn_search_core(mln_ctx* ctx, const double* x, int64_t n, const double
       std::vector<int> order((size_t)cnt);
       for (int i = 0; i < cnt; ++i) order[(size_t)i] = i;
       std::sort(order.begin(), order.end(), [&](int a, int b) { return hf[(size_t)a] < hf[(size_t)b]; });
-      // real rows per list workgroup: 32 or more, such that at most ~240 workgroups exist (one round on 256 CUs)
-      const int G = ((int64_t)cnt * 8 <= n && cnt <= 32768) ? std::max(32, (cnt + 239) / 240) : 256;
+      // real rows per list group: 32 to 64 (a group's tile is LIST_ROWS slots; ~240 groups x 8 column shares when the rows are few)
+      const int G = std::min(LIST_ROWS, std::max(32, (cnt + 239) / 240));
       const int ngrp = (cnt + G - 1) / G;
-      cnt_list = ngrp * 256;
+      cnt_list = ngrp * LIST_ROWS;
       std::vector<int> sf((size_t)cnt_list, -1);
       std::vector<float> stv((size_t)cnt_list, -INFINITY);
       std::vector<double> sd((size_t)cnt_list, INFINITY);
       for (int i = 0; i < cnt; ++i) {
-        const size_t slot = (size_t)(i / G) * 256 + (size_t)(i % G), o = (size_t)order[(size_t)i];
+        const size_t slot = (size_t)(i / G) * LIST_ROWS + (size_t)(i % G), o = (size_t)order[(size_t)i];
         sf[slot] = hf[o]; stv[slot] = ht[o]; sd[slot] = hd[o];
       }
       uint32_t* um = nullptr;
@@ -1080,9 +1085,9 @@ static int nn_search_core(mln_ctx* ctx, const double* x, int64_t n, const double
         return cleanup(MLN_ERR_HIP);
       attr_l = true;
     }
-    // column segments: enough workgroups for every CU, and no workgroup with more than an eighth of the candidates
-    const int n_groups = (cnt_list + 255) / 256;
-    const int n_seg = (m >= 65536) ? std::max(8, std::min(64, 512 / std::max(1, n_groups))) : 1;
+    // column shares: enough workgroups for every CU, and no workgroup with more than an eighth of the candidates
+    const int n_groups = (cnt_list + LIST_ROWS - 1) / LIST_ROWS;
+    const int n_seg = (m >= 65536) ? std::max(8, std::min(64, 4096 / std::max(1, n_groups))) : 1;
     hipLaunchKernelGGL(k_rowmin_list, dim3((unsigned)n_groups, (unsigned)n_seg), dim3(512), lds_bytes, ctx->stream,
                        reinterpret_cast<const _Float16*>(xs), (int64_t)cnt_list, flagged, reinterpret_cast<const _Float16*>(ys), m, fthr,
                        npairs, cap, prow, pcol, lmask, pr_words);
