@@ -110,15 +110,20 @@ __global__ __launch_bounds__(256) void k_max_centred_norm(const double* __restri
   }
 }
 
+// one workgroup: out = max xx; several (out zeroed by the launcher): an integer maximum of the bit patterns (non-negative doubles)
 __global__ void k_max_norm(const double* __restrict__ xx, int64_t n, double* __restrict__ out) {
   __shared__ double red[4];
   double m = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) m = fmax(m, xx[i]);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmax(m, xx[i]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  if (threadIdx.x == 0) {
+    const double v = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (gridDim.x == 1) out[0] = v;
+    else atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(v));
+  }
 }
 
 // min of two floats as ONE v_min_f32.  fminf() is llvm.minnum, and in IEEE mode the compiler has to quiet a possible
@@ -276,8 +281,11 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
                                                     const double* __restrict__ prep,
                                                     double* __restrict__ out, int* __restrict__ n_flag, int* __restrict__ flagged,
                                                     float* __restrict__ fthr, double* __restrict__ fdd) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  // eight lanes per row, every eighth coordinate each (a wave's load covers 8 consecutive rows: one thread per row walked its
+  // 400-byte row alone -- 7.6 ms for 1e6 rows where the data are 2 GB), partial sums added in a fixed order
+  const int sub = threadIdx.x & 7;
+  const int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (i >= n) return;                                  // (whole groups of eight leave together)
   // everything the sweep saw is (x - centre) * scale: xx, yy, m2 and the bound E live in those units; the winner's value
   // s is formed from the same centred and scaled coordinates in fp64
   const double sc = prep[64];
@@ -287,7 +295,10 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
     const int64_t j = (int64_t)arg[i] + 32 * q;
     if (j >= m || j == i + self_offset) continue;
     double dot = 0.0;
-    for (int k = 0; k < d; ++k) dot = fma((x[i * d + k] - prep[k]) * sc, (y[j * d + k] - prep[k]) * sc, dot);
+    for (int k = sub; k < d; k += 8) dot = fma((x[i * d + k] - prep[k]) * sc, (y[j * d + k] - prep[k]) * sc, dot);
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
     const double sv = yy[j] - 2.0 * dot;
     if (sv < s) { s = sv; js = j; }
   }
@@ -300,6 +311,9 @@ __global__ __launch_bounds__(256) void k_nn_certify(const double* __restrict__ x
   const bool certified = ((double)m2[i] - E) > s;
   // reported: the winner's distance from its coordinates (sum (x_k - y_k)^2), not from the cancelling |x|^2 - 2 x.y + |y|^2:
   // exact 0 for a duplicated cell, relative error ~eps otherwise (see nn_direct_distance in cov_kernels.hip)
+  // (one lane, the coordinates in order: the sum k_nn_list_eval and the exact search report -- a row's value does not depend
+  //  on which of them resolved it; both rows were just read by the eight lanes)
+  if (sub != 0) return;
   double dd = INFINITY;
   if (js >= 0) {
     dd = 0.0;
@@ -887,7 +901,9 @@ int launch_km_init_groups(mln_ctx* ctx, int64_t n, const int* label, const doubl
 }
 
 int launch_max_norm(mln_ctx* ctx, const double* xx, int64_t n, double* out) {
-  hipLaunchKernelGGL(k_max_norm, dim3(1), dim3(256), 0, ctx->stream, xx, n, out);
+  const unsigned grid = n > 65536 ? 512u : 1u;                 // (one workgroup over 1e6 values: 1.6 ms of the 1-NN search)
+  if (grid > 1) MLN_HIP(ctx, hipMemsetAsync(out, 0, sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_max_norm, dim3(grid), dim3(256), 0, ctx->stream, xx, n, out);
   MLN_HIP(ctx, hipGetLastError());
   return MLN_OK;
 }
@@ -928,7 +944,7 @@ static int nn_search_core(mln_ctx* ctx, const double* x, int64_t n, const double
   if (share) ys = xs;
   if (same) yy = xx;
   if (rc != MLN_OK) return cleanup(rc);
-  hipLaunchKernelGGL(k_max_norm, dim3(1), dim3(256), 0, ctx->stream, yy, m, ymax);
+  if (launch_max_norm(ctx, yy, m, ymax) != MLN_OK) return cleanup(MLN_ERR_HIP);
   if (hipMemsetAsync(nflag, 0, sizeof(int), ctx->stream) != hipSuccess) return cleanup(MLN_ERR_HIP);
   float* fthr = nullptr;
   double* fdd = nullptr;
@@ -1005,7 +1021,7 @@ static int nn_search_core(mln_ctx* ctx, const double* x, int64_t n, const double
     rc = launch_rowmin_f16x3(ctx, xs, n, ys, m, yyf, self_offset, 1, m1, m2, arg, fold, nullptr);
     if (rc != MLN_OK) return cleanup(rc);
   }
-  hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
+  hipLaunchKernelGGL(k_nn_certify, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, ctx->stream, x, n, y, m, d, xx, yy, m2, arg,
                      ymax, fold ? rowmin_fold_candidates() : 0, self_offset, prep, out, nflag, flagged, fthr, fdd);
   if (hipMemcpyAsync(&cnt, nflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess) return cleanup(mln_hip_fail(ctx, hipGetLastError(), "nn certify", __FILE__, __LINE__));
