@@ -195,3 +195,37 @@ def test_kmeans_group_bounds(ctx, case, monkeypatch):
     if itg < 300:                                  # converged: inertia of the exact assignment == the reported one
         dmin = np.concatenate([mo.distance(x[i:i + 20_000], cg).min(axis=1) for i in range(0, n, 20_000)])
         assert abs(np.sum(dmin ** 2) / ing - 1) < 1e-9
+
+
+@pytest.mark.parametrize("n,d,m", [(66_000, 61, 1024), (70_000, 3, 2049), (131_072, 8, 8192)])
+def test_kmeans_group_bounds_edges(ctx, n, d, m, monkeypatch):
+    """The group-bound sweeps at the edges of where they apply: the widest rows the folded product takes (d = 61), a ragged last
+    stage (m = 2049: one centre in the ninth stage), the most stages (m = 8192: 32), n just above the threshold, duplicated
+    cells and a far cluster -- each against the Hamerly-bound sweeps of the same call and against an exact Lloyd step."""
+    rng = np.random.default_rng(n + d)
+    x = mo.gaussian_mixture(n, d, seed=d + 1)
+    x[1000:1400] = x[5000:5400]                                    # exact duplicates
+    x[20_000:21_000] = 25.0 + 1e-2 * rng.normal(size=(1000, d))    # a tight cluster far away
+    x = np.ascontiguousarray(x)
+    monkeypatch.setenv("MELLON_AMD_KM_LEVELS", "1")
+    cg, itg, ing = ctx.kmeans(x, m, seed=3, max_iter=60, return_info=True)
+    monkeypatch.setenv("MELLON_AMD_KM_PRUNE", "0")
+    cp, itp, inp = ctx.kmeans(x, m, seed=3, max_iter=60, return_info=True)
+    monkeypatch.delenv("MELLON_AMD_KM_PRUNE")
+    assert np.all(np.isfinite(cg)) and abs(ing / inp - 1) < 5e-3, (ing, inp)
+    # the reported inertia is that of the exact assignment to the returned centres
+    dmin = np.concatenate([mo.distance(x[i:i + 8192], cg).min(axis=1) for i in range(0, n, 8192)])
+    assert abs(np.sum(dmin ** 2 - 1e-12) / ing - 1) < 1e-8
+    # and one exact Lloyd step moves the centres no further than the last sweep did (the sweeps assign every cell to its
+    # nearest centre: after 60 of them the movement per sweep is small and shrinking)
+    lab = np.concatenate([np.argmin(mo.distance(x[i:i + 8192], cg), axis=1) for i in range(0, n, 8192)])
+    cnt = np.bincount(lab, minlength=m)
+    sums = np.zeros((m, d))
+    np.add.at(sums, lab, x)
+    means = np.where(cnt[:, None] > 0, sums / np.maximum(cnt, 1)[:, None], cg)
+    lab_p = np.concatenate([np.argmin(mo.distance(x[i:i + 8192], cp), axis=1) for i in range(0, n, 8192)])
+    cnt_p = np.bincount(lab_p, minlength=m)
+    sums_p = np.zeros((m, d))
+    np.add.at(sums_p, lab_p, x)
+    means_p = np.where(cnt_p[:, None] > 0, sums_p / np.maximum(cnt_p, 1)[:, None], cp)
+    assert np.sum((means - cg) ** 2) <= 3.0 * np.sum((means_p - cp) ** 2) + 1e-12 * x.var(axis=0).sum()
