@@ -411,7 +411,11 @@ __global__ __launch_bounds__(512) void k_rowmin_list(const _Float16* __restrict_
       return b < nb256 ? b : nb256;
     }
     while (scan_blk < nb256) {
-      const uint32_t w = __builtin_amdgcn_readfirstlane(mrow[scan_blk >> 5]) >> (scan_blk & 31);
+      // (the word as UNSIGNED before the shift: readfirstlane returns an int, whose arithmetic shift filled the top with copies
+      //  of bit 31 -- phantom selected blocks that put the workgroups' ordinals out of step, ~10 rows in 1e6 lost their nearest
+      //  neighbour to the runner-up)
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)mrow[scan_blk >> 5]);
+      const uint32_t w = word >> (uint32_t)(scan_blk & 31);
       const int have = __builtin_popcount(w);
       if (have <= skip) { skip -= have; scan_blk = ((scan_blk >> 5) + 1) * 32; continue; }      // (a whole word passed over)
       uint32_t rest = w;
