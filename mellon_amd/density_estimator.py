@@ -136,6 +136,8 @@ class DensityEstimator(BaseEstimator):
         elif self.x is not None and self.x is not x:
             raise ValueError("self.x has been set already, but is not equal to the argument x.")
         self.set_x(x)
+        from .util import log_nn_new_fit
+        log_nn_new_fit()                     # (the host prologue's cached logarithms belong to ONE fit)
         try:
             return self._prepare_pipeline()
         finally:

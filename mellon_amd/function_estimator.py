@@ -41,6 +41,8 @@ class FunctionEstimator(BaseEstimator):
     def prepare_inference(self, x):
         """reference function_estimator.py:295-316."""
         self.set_x(x)
+        from .util import log_nn_new_fit
+        log_nn_new_fit()
         try:
             self._prepare_attribute("n_landmarks")
             self._prepare_attribute("gp_type")

@@ -38,12 +38,14 @@ def log_nn(nn_distances):
     """log of the nearest-neighbour distances, once per array: ls (parameters.py:613), mle / mu (util.py:348, parameters.py:599)
     and the likelihood constants (inference.py:83-85) all start from it -- three passes of np.log over n cells otherwise, the
     first of them on the critical path of a fit (nothing can be sent to the device before ls is known).  Cached on the array's
-    identity, size and three of its values.  (Splitting the pass over threads was measured: 18 ms against np.log's 2.2 ms
+    identity, size and three of its values -- WITHIN one fit: every prepare_inference() starts a new scope (log_nn_new_fit), so
+    that a second fit of the same array pays for its logarithms like the first (a benchmark loop over one array would
+    otherwise time steps that skip them).  (Splitting the pass over threads was measured: 18 ms against np.log's 2.2 ms
     at 1e6 cells in an 8-core container -- first-touch page faults of the output contend.)"""
     r = np.asarray(nn_distances, dtype=np.float64)
     if r.ndim != 1 or r.size < 100_000:
         return np.log(r)
-    key = (id(nn_distances), r.ctypes.data, r.size, float(r[0]), float(r[-1]), float(r[r.size // 2]))
+    key = (log_nn._scope, id(nn_distances), r.ctypes.data, r.size, float(r[0]), float(r[-1]), float(r[r.size // 2]))
     hit = log_nn._cache
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -54,6 +56,13 @@ def log_nn(nn_distances):
 
 
 log_nn._cache = None
+log_nn._scope = 0
+
+
+def log_nn_new_fit():
+    """A new fit begins: the logarithms cached for the previous one are not reused."""
+    log_nn._scope += 1
+    log_nn._cache = None
 
 
 def mle(nn_distances, d):
